@@ -1,0 +1,105 @@
+"""Synthetic EMG-envelope matrices for benchmarks and parity tests.
+
+The reference ships one 6 x 8 toy recording (``sample_data/abridged_data.csv``)
+and its tutorial factorises a 200 x 8 matrix; BASELINE.json's throughput
+configs are a scaled-up synthetic workload on the same call boundary
+(``find_synergies`` -> NMF).  This module is the single definition of that
+workload so that the host baseline, the oracle and the HIP
+engine all see identical bytes.
+
+Every operation below is either a counter-based NumPy bit generator or an
+element-wise IEEE operation / sequential cumulative sum -- no BLAS, no
+SIMD-width-dependent reductions -- so ``emg_matrix(seed)`` is bit-identical on
+the build container and on the GPU box.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+SEED_BASE = 20260000
+
+
+def emg_matrix(seed: int, T: int = 10_000, m: int = 16, k_true: int = 5, dtype=np.float32,
+               noise: float = 0.05, window: int = 201) -> np.ndarray:
+    """One non-negative EMG-envelope-like matrix, sklearn orientation (T x m).
+
+    ``k_true`` non-negative synergies ``S`` (k_true x m), activations ``A``
+    (T x k_true) = moving average (``window`` samples, about 0.1 s at 2 kHz) of
+    rectified white noise, ``X = A S + noise * |N(0,1)|``, each column scaled
+    to a maximum of 1 (as the tutorial does before ``find_synergies``).
+
+    The returned array is **F-contiguous** (channel-major ``m x T`` in memory),
+    which is what ``DataFrame.to_numpy()`` hands to sklearn in the reference
+    and what BASELINE.json calls a "16 x 10 000 EMG matrix".
+    """
+    rng = np.random.default_rng(SEED_BASE + int(seed))
+    S = rng.random((k_true, m)) ** 2
+    a = np.abs(rng.standard_normal((T + window - 1, k_true)))
+    c = np.cumsum(a, axis=0)
+    c = np.vstack([np.zeros((1, k_true)), c])
+    A = (c[window:] - c[:-window]) / window  # (T, k_true)
+    X = noise * np.abs(rng.standard_normal((T, m)))
+    for j in range(k_true):  # explicit rank-1 accumulation: no BLAS involved
+        X += A[:, j, None] * S[None, j, :]
+    X /= X.max(axis=0, keepdims=True)
+    return np.asfortranarray(X.astype(dtype))
+
+
+def random_init(X: np.ndarray, k: int, seed: int):
+    """``init='random'`` of sklearn (``_nmf.py:303-314``) with ``RandomState(seed)``.
+
+    H is drawn before W; both are ``sqrt(X.mean() / k) * |N(0, 1)|`` cast to
+    ``X.dtype``.  Returns C-contiguous ``(W0 (T x k), H0 (k x m))``.
+    """
+    T, m = X.shape
+    avg = np.sqrt(X.mean() / k)
+    rng = np.random.RandomState(seed)
+    H = avg * rng.standard_normal(size=(k, m)).astype(X.dtype, copy=False)
+    W = avg * rng.standard_normal(size=(T, k)).astype(X.dtype, copy=False)
+    np.abs(H, out=H)
+    np.abs(W, out=W)
+    return np.ascontiguousarray(W), np.ascontiguousarray(H)
+
+
+def emg_batch(seeds, T: int = 10_000, m: int = 16, k_true: int = 5, dtype=np.float32) -> np.ndarray:
+    """Stack of ``emg_matrix`` results as a ``[B, m, T]`` C-contiguous array
+    (each slice channel-major, the engine's native ``x_layout=1``)."""
+    out = np.empty((len(seeds), m, T), dtype=dtype)
+    for i, s in enumerate(seeds):
+        out[i] = emg_matrix(s, T, m, k_true, dtype).T
+    return out
+
+
+def emg_batch_torch(B: int, T: int = 10_000, m: int = 16, k_true: int = 5, *, k: int = 5,
+                    device="cuda", seed: int = 0, chunk: int = 256):
+    """Device-side generator of the throughput workload (same recipe as
+    ``emg_matrix`` but drawn from torch's generator, so it is not bit-identical
+    to the NumPy one -- parity runs use ``emg_batch``).
+
+    Returns ``(X [B, m, T], W0 [B, T, k], H0 [B, k, m])`` float32 tensors on
+    ``device``; W0/H0 follow sklearn's ``init='random'`` scaling.
+    """
+    import torch
+
+    g = torch.Generator(device=device)
+    g.manual_seed(SEED_BASE + seed)
+    X = torch.empty((B, m, T), dtype=torch.float32, device=device)
+    W0 = torch.empty((B, T, k), dtype=torch.float32, device=device)
+    H0 = torch.empty((B, k, m), dtype=torch.float32, device=device)
+    window = 201
+    for lo in range(0, B, chunk):
+        n = min(chunk, B - lo)
+        S = torch.rand((n, k_true, m), generator=g, device=device) ** 2
+        a = torch.randn((n, k_true, T + window - 1), generator=g, device=device).abs_()
+        c = torch.cumsum(a.double(), dim=2)
+        c = torch.cat([torch.zeros((n, k_true, 1), dtype=c.dtype, device=device), c], dim=2)
+        A = ((c[:, :, window:] - c[:, :, :-window]) / window).float()  # n, k_true, T
+        x = 0.05 * torch.randn((n, m, T), generator=g, device=device).abs_()
+        x += torch.einsum("nkm,nkt->nmt", S, A)
+        x /= x.amax(dim=2, keepdim=True)
+        X[lo:lo + n] = x
+        avg = torch.sqrt(x.mean(dim=(1, 2)) / k).view(n, 1, 1)
+        H0[lo:lo + n] = avg * torch.randn((n, k, m), generator=g, device=device).abs_()
+        W0[lo:lo + n] = avg * torch.randn((n, T, k), generator=g, device=device).abs_()
+    return X, W0, H0

@@ -1,0 +1,269 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under ``tests/golden/``.
+
+Runs ONLY in the build container: it imports the real reference
+(``/root/reference/src/muscle_synergies``, with a stub for the missing
+``seaborn``) and the image's scikit-learn 1.7.2 -- the third-party dependency
+where the reference's NMF arithmetic lives -- and records inputs and outputs as
+small data files.  No reference source travels; the fixtures are numbers.
+
+    python tests/golden/make_golden.py
+
+Fixture sets:
+  G1  plumbing: abridged Vicon CSV -> EMG block -> ``find_synergies``
+  G2  the mu loop at fixed iteration counts, fp32 and fp64, custom init
+  G3  the tol > 0 stop rule (n_iter_, error trace)
+  G4  NNDSVD / random initialisation vectors (host-side init parity)
+  G5  ``transform`` (update_H=False) and regularised fits
+"""
+
+import json
+import os
+import sys
+import types
+import warnings
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+os.environ.setdefault("MPLBACKEND", "Agg")
+sys.modules["seaborn"] = types.ModuleType("seaborn")  # analysis.py:23 imports it, uses it only at :133
+sys.path.insert(0, "/root/reference/src")
+
+import muscle_synergies as ms  # noqa: E402  (the reference)
+import sklearn  # noqa: E402
+from sklearn.decomposition import NMF  # noqa: E402
+from sklearn.decomposition._nmf import _beta_divergence, _initialize_nmf  # noqa: E402
+
+from muscle_synergies_amd.synth import emg_matrix, random_init  # noqa: E402
+
+warnings.simplefilter("ignore")
+
+
+def tolist(a):
+    return np.asarray(a).tolist()
+
+
+# --------------------------------------------------------------------------- G1
+def g1():
+    emg = ms.load_vicon_file("/root/reference/sample_data/abridged_data.csv").emg.df
+    V = emg.abs()
+    out = {
+        "sklearn_version": sklearn.__version__,
+        "columns": list(V.columns),
+        "raw_emg": tolist(emg.to_numpy()),
+        "V": tolist(V.to_numpy()),
+    }
+    # deterministic single-rank call through the reference's own entry point
+    kw = dict(solver="mu", max_iter=200, init="nndsvda", random_state=0)
+    res = ms.find_synergies(V, n_components=4, **kw)
+    W0, H0 = _initialize_nmf(V.to_numpy(), 4, init="nndsvda", random_state=0)
+    m = NMF(4, solver="mu", init="custom", max_iter=200, tol=1e-6)
+    W = m.fit_transform(V.to_numpy(), W=W0.copy(), H=H0.copy())
+    assert np.array_equal(m.components_, res.model.components_)
+    out["single_k4"] = {
+        "kwargs": kw,
+        "tol": 1e-6,
+        "W0": tolist(W0),
+        "H0": tolist(H0),
+        "n_iter": int(res.model.n_iter_),
+        "reconstruction_err": float(res.model.reconstruction_err_),
+        "components": tolist(res.model.components_),
+        "transformed": tolist(W),
+        "vaf_columns": list(res.vaf_values.columns),
+        "vaf_values": tolist(res.vaf_values.to_numpy()[0]),
+    }
+    # default (init=None, random_state=None) call as in SURVEY: record stats only
+    res_d = ms.find_synergies(V, n_components=4, solver="mu", max_iter=200)
+    out["single_k4_default_init"] = {
+        "n_iter": int(res_d.model.n_iter_),
+        "reconstruction_err": float(res_d.model.reconstruction_err_),
+        "vaf_values": tolist(res_d.vaf_values.to_numpy()[0]),
+    }
+    # range call
+    res_r = ms.find_synergies(V, 2, 4, **kw)
+    out["range_2_4"] = {
+        "kwargs": kw,
+        "keys": [int(k) for k in res_r.components.keys()],
+        "vaf_index": tolist(res_r.vaf_values.index),
+        "vaf_values": tolist(res_r.vaf_values.to_numpy()),
+        "components": {str(k): tolist(v.to_numpy()) for k, v in res_r.components.items()},
+        "n_iter": {str(k): int(v.n_iter_) for k, v in res_r.model.items()},
+        "reconstruction_err": {str(k): float(v.reconstruction_err_) for k, v in res_r.model.items()},
+    }
+    # default solver must still route to sklearn's 'cd'
+    res_cd = ms.find_synergies(V, n_components=4, init="nndsvda", random_state=0)
+    out["default_solver"] = {
+        "solver": res_cd.model.solver,
+        "n_iter": int(res_cd.model.n_iter_),
+        "reconstruction_err": float(res_cd.model.reconstruction_err_),
+        "vaf_values": tolist(res_cd.vaf_values.to_numpy()[0]),
+    }
+    # error cases
+    errs = {}
+    for name, args in {"k0": (0, None), "k9": (9, None), "3_2": (3, 2), "3_9": (3, 9)}.items():
+        try:
+            ms.find_synergies(V, args[0], args[1], solver="mu")
+        except ValueError as e:
+            errs[name] = str(e)
+    try:
+        ms.find_synergies(V.iloc[0:0], 2, solver="mu")
+    except ValueError as e:
+        errs["empty"] = str(e)
+    try:
+        ms.find_synergies(emg, 2, solver="mu")
+    except ValueError as e:
+        errs["negative"] = str(e)
+    out["errors"] = errs
+    with open(os.path.join(HERE, "g1_abridged.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("G1", out["single_k4"]["n_iter"], out["single_k4"]["reconstruction_err"], errs)
+
+
+# --------------------------------------------------------------------------- G2
+def run_sk(X, W0, H0, n_iter, tol=0.0, **kw):
+    m = NMF(W0.shape[1], solver="mu", init="custom", tol=tol, max_iter=n_iter, **kw)
+    W = m.fit_transform(X, W=W0.copy(), H=H0.copy())
+    return W, m.components_.copy(), m
+
+
+def g2_small():
+    """T=512, m=16, k=5: full W/H stored at a few iteration counts."""
+    arrays = {}
+    meta = {"sklearn_version": sklearn.__version__, "T": 512, "m": 16, "k": 5, "seed": 7, "iters": [1, 2, 10, 100]}
+    for dt in (np.float32, np.float64):
+        tag = np.dtype(dt).name
+        X = emg_matrix(7, T=512, dtype=dt)
+        W0, H0 = _initialize_nmf(X, 5, init="nndsvda", random_state=0)
+        arrays[f"X_{tag}"] = np.ascontiguousarray(X)
+        arrays[f"W0_{tag}"] = W0
+        arrays[f"H0_{tag}"] = H0
+        for n in meta["iters"]:
+            W, H, m = run_sk(X, W0, H0, n)
+            arrays[f"W_{tag}_{n}"] = W
+            arrays[f"H_{tag}_{n}"] = H
+            arrays[f"err_{tag}_{n}"] = np.array(m.reconstruction_err_)
+    np.savez_compressed(os.path.join(HERE, "g2_loop_T512.npz"), **arrays)
+    with open(os.path.join(HERE, "g2_loop_T512.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    print("G2 small done")
+
+
+def g2_full():
+    """Config #2 shape (10 000 x 16, k=5): X/W0/H0 by recipe, outputs as checksums."""
+    out = {"sklearn_version": sklearn.__version__, "T": 10000, "m": 16, "k": 5,
+           "rows": [0, 1234, 4999, 9999], "cases": []}
+    for dt in (np.float32, np.float64):
+        for seed, init in ((0, "random"), (1, "random"), (0, "nndsvda")):
+            X = emg_matrix(seed, dtype=dt)
+            if init == "random":
+                W0, H0 = random_init(X, 5, seed)
+                Wc, Hc = _initialize_nmf(X, 5, init="random", random_state=seed)
+                assert np.array_equal(W0, Wc) and np.array_equal(H0, Hc)
+            else:
+                W0, H0 = _initialize_nmf(X, 5, init="nndsvda", random_state=0)
+            case = {"dtype": np.dtype(dt).name, "seed": seed, "init": init,
+                    "X_sum": float(X.astype(np.float64).sum()),
+                    "X_fro": float(np.sqrt((X.astype(np.float64) ** 2).sum())),
+                    "W0_sum": float(W0.astype(np.float64).sum()), "H0_sum": float(H0.astype(np.float64).sum()),
+                    "H0": tolist(H0) if init == "nndsvda" else None,
+                    "W0_rows": tolist(W0[out["rows"]]) if init == "nndsvda" else None,
+                    "iters": {}}
+            for n in (1, 2, 10, 100, 500):
+                W, H, m = run_sk(X, W0, H0, n)
+                WH = (W.astype(np.float64) @ H.astype(np.float64))
+                Xd = X.astype(np.float64)
+                sse_col = ((Xd - WH) ** 2).sum(axis=0)
+                case["iters"][str(n)] = {
+                    "reconstruction_err": float(m.reconstruction_err_),
+                    "H": tolist(H),
+                    "W_rows": tolist(W[out["rows"]]),
+                    "WH_rows": tolist(WH[out["rows"]]),
+                    "WH_fro": float(np.sqrt((WH ** 2).sum())),
+                    "WH_colsum": tolist(WH.sum(axis=0)),
+                    "vaf_all": float(1 - sse_col.sum() / (Xd ** 2).sum()),
+                    "vaf_col": tolist(1 - sse_col / (Xd ** 2).sum(axis=0)),
+                }
+            out["cases"].append(case)
+            print("G2 full", case["dtype"], seed, init, case["iters"]["500"]["reconstruction_err"])
+    with open(os.path.join(HERE, "g2_loop_T10000.json"), "w") as f:
+        json.dump(out, f)
+
+
+# --------------------------------------------------------------------------- G3
+def g3():
+    """Stop rule: tol > 0, record n_iter_ and the error trace sklearn saw."""
+    out = {"cases": []}
+    for dt in (np.float32, np.float64):
+        for T, seed, tol, max_iter in ((512, 7, 1e-4, 2000), (512, 7, 1e-3, 2000), (2000, 3, 1e-4, 30)):
+            X = emg_matrix(seed, T=T, dtype=dt)
+            W0, H0 = _initialize_nmf(X, 5, init="nndsvda", random_state=0)
+            W, H, m = run_sk(X, W0, H0, max_iter, tol=tol)
+            # error trace: replay with sklearn's own _beta_divergence every 10 iterations
+            trace = [float(_beta_divergence(X, W0, H0, 2, square_root=True))]
+            for n in range(10, int(m.n_iter_) + 1, 10):
+                Wn, Hn, _ = run_sk(X, W0, H0, n)
+                trace.append(float(_beta_divergence(X, Wn, Hn, 2, square_root=True)))
+            out["cases"].append({"dtype": np.dtype(dt).name, "T": T, "seed": seed, "tol": tol,
+                                 "max_iter": max_iter, "n_iter": int(m.n_iter_),
+                                 "reconstruction_err": float(m.reconstruction_err_),
+                                 "err_trace": trace, "H": tolist(H)})
+            print("G3", np.dtype(dt).name, T, tol, m.n_iter_)
+    with open(os.path.join(HERE, "g3_stop_rule.json"), "w") as f:
+        json.dump(out, f)
+
+
+# --------------------------------------------------------------------------- G4
+def g4():
+    """Initialisation vectors: sklearn's _initialize_nmf on small matrices."""
+    arrays = {}
+    meta = []
+    for dt in (np.float32, np.float64):
+        tag = np.dtype(dt).name
+        for T, m_, k, seed in ((512, 16, 5, 7), (64, 8, 3, 11), (6, 8, 4, 5)):
+            X = emg_matrix(seed, T=T, m=m_, k_true=min(5, m_), dtype=dt)
+            arrays[f"X_{tag}_{T}_{m_}"] = np.ascontiguousarray(X)
+            for init in ("random", "nndsvd", "nndsvda", "nndsvdar"):
+                W0, H0 = _initialize_nmf(X, k, init=init, random_state=3)
+                arrays[f"W0_{tag}_{T}_{m_}_{k}_{init}"] = W0
+                arrays[f"H0_{tag}_{T}_{m_}_{k}_{init}"] = H0
+                meta.append({"dtype": tag, "T": T, "m": m_, "k": k, "init": init, "random_state": 3})
+    np.savez_compressed(os.path.join(HERE, "g4_init.npz"), **arrays)
+    with open(os.path.join(HERE, "g4_init.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    print("G4 done")
+
+
+# --------------------------------------------------------------------------- G5
+def g5():
+    """transform (update_H=False) and regularised fits, T=512."""
+    arrays = {}
+    for dt in (np.float32, np.float64):
+        tag = np.dtype(dt).name
+        X = emg_matrix(7, T=512, dtype=dt)
+        W0, H0 = _initialize_nmf(X, 5, init="nndsvda", random_state=0)
+        W, H, m = run_sk(X, W0, H0, 50)
+        X2 = emg_matrix(8, T=300, dtype=dt)
+        m.tol = 0.0
+        m.max_iter = 40
+        arrays[f"H_fit_{tag}"] = H
+        arrays[f"X2_{tag}"] = np.ascontiguousarray(X2)
+        arrays[f"W_transform_{tag}"] = m.transform(X2)
+        Wr, Hr, mr = run_sk(X, W0, H0, 60, alpha_W=0.002, alpha_H=0.001, l1_ratio=0.3)
+        arrays[f"W_reg_{tag}"] = Wr
+        arrays[f"H_reg_{tag}"] = Hr
+        arrays[f"err_reg_{tag}"] = np.array(mr.reconstruction_err_)
+    np.savez_compressed(os.path.join(HERE, "g5_transform_reg.npz"), **arrays)
+    print("G5 done")
+
+
+if __name__ == "__main__":
+    g1()
+    g2_small()
+    g2_full()
+    g3()
+    g4()
+    g5()
