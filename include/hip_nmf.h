@@ -1,0 +1,127 @@
+/*
+ * hip_nmf.h -- C ABI of libhip_nmf.so, the MI355X (gfx950) NMF multiplicative-update engine.
+ *
+ * Drop-in boundary for the one hot path of elvis-sik/muscle_synergies:
+ *
+ *     model = NMF(n_components=n_components, **sklearn_kwargs)      (src/muscle_synergies/analysis.py:862)
+ *     transformed_signal = model.fit_transform(matrix)              (src/muscle_synergies/analysis.py:863)
+ *
+ * with solver='mu', beta_loss='frobenius'.  The arithmetic replaced is scikit-learn's
+ * _fit_multiplicative_update (sklearn/decomposition/_nmf.py:731-893), _multiplicative_update_w (:526-631),
+ * _multiplicative_update_h (:634-728) and _beta_divergence (:85-134).  Notation is sklearn's:
+ * X (T x m) ~= W (T x k) * H (k x m), one muscle per column of X; W is updated first, then H.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes, no exceptions, no torch/STL types.
+ *  - Every array pointer is a DEVICE pointer valid on the handle's device (the Python host passes
+ *    torch.Tensor.data_ptr(); torch is only the allocator / H2D copier).
+ *  - The caller owns every buffer; the library keeps no caller pointer after a call returns.
+ *    Scratch memory lives inside the handle (grow-only, freed by hipnmf_destroy).
+ *  - A handle is bound to one device + one HIP stream and is not re-entrant; distinct handles
+ *    may be driven concurrently from different host threads.
+ *  - Calls return after the stream has been synchronised (results are ready on return).
+ *  - Return value: 0 = ok, <0 = error class below; text via hipnmf_last_error() (thread-local).
+ *  - There is NO CPU fallback: without a usable GPU every compute entry point returns HIPNMF_ERR_NO_DEVICE.
+ */
+#ifndef HIP_NMF_H
+#define HIP_NMF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HIPNMF_VERSION 100 /* 0.1.0 */
+
+#define HIPNMF_OK 0
+#define HIPNMF_ERR_BAD_ARG (-1)
+#define HIPNMF_ERR_HIP (-2)
+#define HIPNMF_ERR_UNSUPPORTED (-3) /* shape outside the compiled kernel set (m <= 32, k <= 8) */
+#define HIPNMF_ERR_NO_DEVICE (-4)
+
+/* memory layout of one X matrix */
+#define HIPNMF_X_ROW_MAJOR 0     /* X[t*ldx + j]  (T x m, C order; ldx >= m)                          */
+#define HIPNMF_X_CHANNEL_MAJOR 1 /* X[j*ldx + t]  (m x T; = DataFrame.to_numpy() F order; ldx >= T)   */
+
+/* memory layout of one W matrix (ldw / batch stride are implied: contiguous) */
+#define HIPNMF_W_ROW_MAJOR 0       /* W[t*k + c]  (T x k, C order: what sklearn returns)               */
+#define HIPNMF_W_COMPONENT_MAJOR 1 /* W[c*T + t]  (k x T: the engine's native streaming layout)        */
+
+typedef struct hipnmf_handle hipnmf_handle;
+
+/* Problem description shared by every compute entry point (POD, passed by pointer). */
+typedef struct hipnmf_problem {
+  int32_t struct_size;    /* = sizeof(hipnmf_problem), ABI guard                                       */
+  int32_t batch;          /* B  >= 1 independent factorisations                                        */
+  int64_t n_samples;      /* T  rows of X (time samples)                                               */
+  int32_t n_features;     /* m  columns of X (muscles), 1..32                                          */
+  int32_t n_components;   /* k  rank, 1..8                                                             */
+  int32_t x_layout;       /* HIPNMF_X_*                                                                */
+  int32_t update_h;       /* 1: fit (W and H updated, _nmf.py:854); 0: transform (H fixed, :1736-1763) */
+  int32_t w_layout;       /* HIPNMF_W_*                                                                */
+  int32_t reserved0;      /* must be 0                                                                 */
+  int64_t ldx;            /* leading dimension of one X matrix, in elements                            */
+  int64_t x_batch_stride; /* elements between consecutive X matrices                                   */
+  int32_t max_iter;       /* >= 1 (NMF max_iter, _nmf.py:831)                                          */
+  int32_t check_every;    /* convergence test period; sklearn hard-codes 10 (_nmf.py:872)              */
+  double tol;             /* 0 disables the test (_nmf.py:872); else stop when                         */
+                          /* (prev_err - err) / err_at_init < tol (_nmf.py:883)                        */
+  double l1_reg_W, l1_reg_H, l2_reg_W, l2_reg_H; /* already scaled as _compute_regularization (:1254)  */
+} hipnmf_problem;
+
+/* ---- library / device ---------------------------------------------------------------------------- */
+int hipnmf_version(void);
+const char* hipnmf_last_error(void);
+int hipnmf_device_count(void);                            /* <0 on error (no ROCm device / driver)     */
+int hipnmf_create(int device, hipnmf_handle** out);       /* own stream + workspace on `device`        */
+int hipnmf_destroy(hipnmf_handle* h);
+int hipnmf_set_stream(hipnmf_handle* h, void* hip_stream);/* NULL restores the handle's own stream     */
+size_t hipnmf_workspace_bytes(const hipnmf_problem* p, int elem_size /* 4 or 8 */);
+/* Device time (HIP events on the handle's stream) of the solver kernels of the last compute call. */
+int hipnmf_last_kernel_ms(hipnmf_handle* h, float* ms);
+/* Tuning knobs (0 = library default): threads per workgroup (256/512/1024), max row slices per matrix. */
+int hipnmf_set_tuning(hipnmf_handle* h, int threads, int max_slices, int variant);
+
+/* ---- batched fit: replaces NMF(solver='mu').fit_transform / .transform for B matrices ------------- */
+/*
+ * X        [B] matrices, layout per p->x_layout / ldx / x_batch_stride             (in)
+ * W        [B] matrices per p->w_layout, W0 on entry (init='custom', _nmf.py:1198-1208), result on return
+ * H        [B][k][m] row-major, H0 on entry, components_ on return (unchanged when update_h == 0)
+ * err_out  [B]    reconstruction_err_ = ||X - W H||_F after the loop (_nmf.py:1628-1630), or NULL
+ * n_iter_out [B]  n_iter_ (_nmf.py:893), or NULL
+ * sse_col_out [B][m]  per-column sum((X - W H)^2)  -> VAF numerators (analysis.py:660-662), or NULL
+ * xsq_col_out [B][m]  per-column sum(X^2)          -> VAF denominators (analysis.py:654-656), or NULL
+ */
+int hipnmf_fit_batched_f32(hipnmf_handle* h, const hipnmf_problem* p, const float* X, float* W, float* H,
+                           float* err_out, int32_t* n_iter_out, float* sse_col_out, float* xsq_col_out);
+int hipnmf_fit_batched_f64(hipnmf_handle* h, const hipnmf_problem* p, const double* X, double* W, double* H,
+                           double* err_out, int32_t* n_iter_out, double* sse_col_out, double* xsq_col_out);
+
+/* ---- time-sharded building blocks (one rank holds rows [t0, t1) of every X and W; H replicated) --- */
+/*
+ * One iteration of the sharded solver is
+ *     hipnmf_shard_pass   : W_s <- W_s * (X_s H^T) / (W_s H H^T);  sums <- [W_s^T X_s | W_s^T W_s]
+ *     all-reduce(sums)    : by the caller (RCCL over xGMI via torch.distributed; k*m + k*k floats)
+ *     hipnmf_shard_hupdate: H <- H * (W^T X) / ((W^T W) H)
+ * and hipnmf_shard_residual returns the shard's per-column SSE (and sum X^2) for the stop rule / VAF.
+ * sums: [B][k*m + k*k] device buffer; sse_col/xsq_col: [B][m].  max_iter/tol in *p are ignored here.
+ * The shard entry points require p->w_layout == HIPNMF_W_COMPONENT_MAJOR and channel-major X with
+ * ldx % 4 == 0 (no per-call layout conversion on the per-iteration path).
+ */
+int hipnmf_shard_pass_f32(hipnmf_handle* h, const hipnmf_problem* p, const float* X, float* W, const float* H,
+                          float* sums);
+int hipnmf_shard_hupdate_f32(hipnmf_handle* h, const hipnmf_problem* p, float* H, const float* sums);
+int hipnmf_shard_residual_f32(hipnmf_handle* h, const hipnmf_problem* p, const float* X, const float* W,
+                              const float* H, float* sse_col, float* xsq_col);
+int hipnmf_shard_pass_f64(hipnmf_handle* h, const hipnmf_problem* p, const double* X, double* W, const double* H,
+                          double* sums);
+int hipnmf_shard_hupdate_f64(hipnmf_handle* h, const hipnmf_problem* p, double* H, const double* sums);
+int hipnmf_shard_residual_f64(hipnmf_handle* h, const hipnmf_problem* p, const double* X, const double* W,
+                              const double* H, double* sse_col, double* xsq_col);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HIP_NMF_H */

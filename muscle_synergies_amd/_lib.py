@@ -1,0 +1,199 @@
+"""ctypes binding of ``libhip_nmf.so`` (the C ABI declared in ``include/hip_nmf.h``).
+
+The library is loaded lazily and exactly once.  There is no fallback: if the shared object is missing
+or no GPU is visible, compute calls raise :class:`HipNmfError` -- nothing here ever routes to a CPU
+implementation.
+
+``torch`` is imported *before* the library on purpose: PyTorch-ROCm ships its own ``libamdhip64.so.7``;
+loading it first makes the dynamic linker resolve our ``DT_NEEDED libamdhip64.so.7`` to the copy that is
+already mapped, so torch's device pointers and streams and our kernels live in one HIP runtime.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, "lib", "libhip_nmf.so")
+
+HIPNMF_OK = 0
+HIPNMF_ERR_BAD_ARG = -1
+HIPNMF_ERR_HIP = -2
+HIPNMF_ERR_UNSUPPORTED = -3
+HIPNMF_ERR_NO_DEVICE = -4
+
+X_ROW_MAJOR = 0
+X_CHANNEL_MAJOR = 1
+W_ROW_MAJOR = 0
+W_COMPONENT_MAJOR = 1
+
+#: every symbol ``include/hip_nmf.h`` declares (checked by tests/test_abi.py)
+EXPORTS = (
+    "hipnmf_version", "hipnmf_last_error", "hipnmf_device_count", "hipnmf_create", "hipnmf_destroy",
+    "hipnmf_set_stream", "hipnmf_workspace_bytes", "hipnmf_last_kernel_ms", "hipnmf_set_tuning",
+    "hipnmf_fit_batched_f32", "hipnmf_fit_batched_f64",
+    "hipnmf_shard_pass_f32", "hipnmf_shard_hupdate_f32", "hipnmf_shard_residual_f32",
+    "hipnmf_shard_pass_f64", "hipnmf_shard_hupdate_f64", "hipnmf_shard_residual_f64",
+)
+
+
+class HipNmfError(RuntimeError):
+    """Error reported by libhip_nmf (carries the C error code in ``.code``)."""
+
+    def __init__(self, code: int, message: str):
+        super().__init__(f"libhip_nmf error {code}: {message}")
+        self.code = code
+
+
+class Problem(ctypes.Structure):
+    """Mirror of ``struct hipnmf_problem`` (include/hip_nmf.h)."""
+
+    _fields_ = [
+        ("struct_size", ctypes.c_int32),
+        ("batch", ctypes.c_int32),
+        ("n_samples", ctypes.c_int64),
+        ("n_features", ctypes.c_int32),
+        ("n_components", ctypes.c_int32),
+        ("x_layout", ctypes.c_int32),
+        ("update_h", ctypes.c_int32),
+        ("w_layout", ctypes.c_int32),
+        ("reserved0", ctypes.c_int32),
+        ("ldx", ctypes.c_int64),
+        ("x_batch_stride", ctypes.c_int64),
+        ("max_iter", ctypes.c_int32),
+        ("check_every", ctypes.c_int32),
+        ("tol", ctypes.c_double),
+        ("l1_reg_W", ctypes.c_double),
+        ("l1_reg_H", ctypes.c_double),
+        ("l2_reg_W", ctypes.c_double),
+        ("l2_reg_H", ctypes.c_double),
+    ]
+
+
+_lock = threading.Lock()
+_lib = None
+
+
+def _declare(lib):
+    vp, ip = ctypes.c_void_p, ctypes.c_int
+    pp = ctypes.POINTER(Problem)
+    lib.hipnmf_version.restype = ip
+    lib.hipnmf_version.argtypes = []
+    lib.hipnmf_last_error.restype = ctypes.c_char_p
+    lib.hipnmf_last_error.argtypes = []
+    lib.hipnmf_device_count.restype = ip
+    lib.hipnmf_device_count.argtypes = []
+    lib.hipnmf_create.restype = ip
+    lib.hipnmf_create.argtypes = [ip, ctypes.POINTER(vp)]
+    lib.hipnmf_destroy.restype = ip
+    lib.hipnmf_destroy.argtypes = [vp]
+    lib.hipnmf_set_stream.restype = ip
+    lib.hipnmf_set_stream.argtypes = [vp, vp]
+    lib.hipnmf_workspace_bytes.restype = ctypes.c_size_t
+    lib.hipnmf_workspace_bytes.argtypes = [pp, ip]
+    lib.hipnmf_last_kernel_ms.restype = ip
+    lib.hipnmf_last_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
+    lib.hipnmf_set_tuning.restype = ip
+    lib.hipnmf_set_tuning.argtypes = [vp, ip, ip, ip]
+    for sfx in ("f32", "f64"):
+        f = getattr(lib, f"hipnmf_fit_batched_{sfx}")
+        f.restype = ip
+        f.argtypes = [vp, pp, vp, vp, vp, vp, vp, vp, vp]
+        f = getattr(lib, f"hipnmf_shard_pass_{sfx}")
+        f.restype = ip
+        f.argtypes = [vp, pp, vp, vp, vp, vp]
+        f = getattr(lib, f"hipnmf_shard_hupdate_{sfx}")
+        f.restype = ip
+        f.argtypes = [vp, pp, vp, vp]
+        f = getattr(lib, f"hipnmf_shard_residual_{sfx}")
+        f.restype = ip
+        f.argtypes = [vp, pp, vp, vp, vp, vp, vp]
+
+
+def load():
+    """Return the loaded ``ctypes.CDLL`` (loading it on first use)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        path = os.environ.get("HIPNMF_LIBRARY", LIB_PATH)
+        if not os.path.exists(path):
+            raise HipNmfError(
+                HIPNMF_ERR_NO_DEVICE,
+                f"{path} not found: build the HIP extension first (python -m muscle_synergies_amd.build). "
+                "There is no CPU fallback for solver='mu'.",
+            )
+        import torch  # noqa: F401  -- must precede the CDLL (shared HIP runtime, see module docstring)
+
+        lib = ctypes.CDLL(path)
+        _declare(lib)
+        _lib = lib
+    return _lib
+
+
+def check(code: int):
+    if code != HIPNMF_OK:
+        msg = load().hipnmf_last_error()
+        raise HipNmfError(code, msg.decode("utf-8", "replace") if msg else "unknown error")
+
+
+class Handle:
+    """RAII wrapper of ``hipnmf_handle`` (one per device and host thread)."""
+
+    def __init__(self, device: int = 0):
+        lib = load()
+        self._h = ctypes.c_void_p()
+        check(lib.hipnmf_create(int(device), ctypes.byref(self._h)))
+        self.device = int(device)
+
+    @property
+    def ptr(self):
+        return self._h
+
+    def set_tuning(self, threads: int = 0, max_slices: int = 0, variant: int = 0):
+        check(load().hipnmf_set_tuning(self._h, int(threads), int(max_slices), int(variant)))
+
+    def set_stream(self, stream_ptr):
+        check(load().hipnmf_set_stream(self._h, ctypes.c_void_p(stream_ptr) if stream_ptr else None))
+
+    def last_kernel_ms(self) -> float:
+        ms = ctypes.c_float()
+        check(load().hipnmf_last_kernel_ms(self._h, ctypes.byref(ms)))
+        return float(ms.value)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            load().hipnmf_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_handles: dict = {}
+_handles_lock = threading.Lock()
+
+
+def get_handle(device: int = 0) -> Handle:
+    """Per-(thread, device) cached handle."""
+    key = (threading.get_ident(), int(device))
+    with _handles_lock:
+        h = _handles.get(key)
+        if h is None:
+            h = Handle(device)
+            _handles[key] = h
+        return h
+
+
+def device_count() -> int:
+    n = load().hipnmf_device_count()
+    if n < 0:
+        check(n)
+    return n

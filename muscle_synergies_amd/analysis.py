@@ -1,0 +1,122 @@
+"""Synergy extraction with the call surface of the reference's ``muscle_synergies.analysis``.
+
+Mirrors, for the NMF hot path only, ``find_synergies`` (``src/muscle_synergies/analysis.py:713-914``),
+``vaf`` (``:597-667``) and ``SynergyRunResult`` (``:670-710``): same signatures, same validation
+messages, same return structure.  The one difference is what happens at the seam
+``NMF(...).fit_transform(X)`` (``:862-863``): when the keyword arguments select sklearn's
+multiplicative-update solver with the Frobenius loss (``solver='mu'``), the factorisation runs on an
+MI355X through :class:`~muscle_synergies_amd.hip_nmf.HipNMF`; any other solver / loss keeps going to
+``sklearn.decomposition.NMF`` exactly as in the reference (whose default is ``solver='cd'``).
+
+Plotting, filtering and the Vicon loader of the reference are out of scope and not reproduced here.
+"""
+
+from __future__ import annotations
+
+from collections import OrderedDict
+from dataclasses import dataclass
+from typing import Any, Mapping, Optional, Union
+
+import numpy as np
+import pandas
+
+from .hip_nmf import HipNMF
+
+
+@dataclass
+class SynergyRunResult:
+    """Result of one or several factorisations (``analysis.py:670-710``).
+
+    ``vaf_values``: one row per number of components (index = that number when a range was requested);
+    ``components``: DataFrame (k x muscles) or ``{k: DataFrame}``; ``model``: the fitted estimator
+    (:class:`HipNMF` or ``sklearn.decomposition.NMF``) or ``{k: estimator}``.
+    """
+
+    vaf_values: pandas.DataFrame
+    components: Union[pandas.DataFrame, Mapping[int, pandas.DataFrame]]
+    model: Union[Any, Mapping[int, Any]]
+
+
+def vaf(original_df: pandas.DataFrame, transformed_signal=None, components=None,
+        reconstructed_signal=None) -> pandas.DataFrame:
+    """Uncentered variance accounted for, ``1 - ||x - x_r||^2 / ||x||^2`` (``analysis.py:597-667``).
+
+    Returns a one-row DataFrame whose first column ``"All signals"`` is the VAF over every entry and
+    whose remaining columns (labelled like ``original_df``) are the per-muscle VAFs.
+    """
+    if reconstructed_signal is None:
+        reconstructed_signal = np.asarray(transformed_signal) @ np.asarray(components)
+    x = original_df.to_numpy()
+    sq_err = (x - np.asarray(reconstructed_signal)) ** 2
+    sq_x = x ** 2
+    overall = 1 - np.sum(sq_err, axis=(0, 1)) / np.sum(sq_x, axis=(0, 1))
+    per_column = 1 - np.sum(sq_err, axis=0) / np.sum(sq_x, axis=0)
+    labels = ["All signals"] + original_df.columns.tolist()
+    values = [overall] + list(per_column.reshape(-1))
+    return pandas.DataFrame({label: [value] for label, value in zip(labels, values)})
+
+
+def _make_model(n_components: int, **nmf_kwargs):
+    """The seam: HIP engine for the mu/Frobenius path, sklearn for everything else."""
+    if HipNMF.supports(**nmf_kwargs):
+        return HipNMF(n_components=n_components, **nmf_kwargs)
+    from sklearn.decomposition import NMF  # the reference's own behaviour (default solver 'cd')
+
+    nmf_kwargs.pop("device", None)
+    return NMF(n_components=n_components, **nmf_kwargs)
+
+
+def _check_component_range(df: pandas.DataFrame, n_components: int, max_components: Optional[int]):
+    """``validate_num_components`` (``analysis.py:829-846``)."""
+    if df.empty:
+        raise ValueError("empty EMG DataFrame")
+    n_muscles = len(df.columns)
+    message = "invalid number of components"
+    if not 1 <= n_components <= n_muscles:
+        raise ValueError(message)
+    if max_components is not None and not n_components <= max_components <= n_muscles:
+        raise ValueError(message)
+
+
+def _single_run(df: pandas.DataFrame, n_components: int, **nmf_kwargs) -> SynergyRunResult:
+    """One factorisation + its VAF row (``analysis.py:866-882``)."""
+    model = _make_model(n_components, **nmf_kwargs)
+    transformed = model.fit_transform(df)
+    vaf_row = vaf(df, transformed_signal=transformed, components=model.components_)
+    comps = pandas.DataFrame(model.components_, columns=df.columns)
+    return SynergyRunResult(vaf_row, comps, model)
+
+
+def find_synergies(processed_emg_df: pandas.DataFrame, n_components: int, max_components: Optional[int] = None, *,
+                   max_iter: int = 100_000, tol: float = 1e-6, **sklearn_kwargs) -> SynergyRunResult:
+    """Find spatial synergy components in a processed (non-negative) EMG DataFrame.
+
+    Same contract as the reference (``analysis.py:713-914``): ``processed_emg_df`` is
+    ``(num_measurements, num_muscles)``; with ``max_components=None`` one factorisation with exactly
+    ``n_components`` synergies is returned, otherwise one per rank in
+    ``n_components..max_components`` with dict-valued ``components`` / ``model`` and a VAF table indexed
+    by rank.  ``max_iter``, ``tol`` and ``**sklearn_kwargs`` are forwarded to the estimator.
+
+    Pass ``solver='mu'`` to run on the GPU (``device='cuda:1'`` etc. selects one); without it the call
+    behaves exactly like the reference and uses sklearn's coordinate-descent solver on the CPU.
+
+    Raises:
+        ValueError: ``"empty EMG DataFrame"``, ``"invalid number of components"`` (need
+            ``num_muscles >= max_components >= n_components >= 1``), or sklearn's own message for
+            negative input.
+    """
+    _check_component_range(processed_emg_df, n_components, max_components)
+    if max_components is None:
+        return _single_run(processed_emg_df, n_components, max_iter=max_iter, tol=tol, **sklearn_kwargs)
+
+    runs = OrderedDict()
+    for rank in range(n_components, max_components + 1):
+        runs[rank] = _single_run(processed_emg_df, rank, max_iter=max_iter, tol=tol, **sklearn_kwargs)
+
+    table = pandas.concat([run.vaf_values for run in runs.values()])
+    table.set_index(np.array(tuple(runs.keys())), inplace=True)
+    return SynergyRunResult(
+        table,
+        {rank: run.components for rank, run in runs.items()},
+        {rank: run.model for rank, run in runs.items()},
+    )

@@ -1,0 +1,93 @@
+"""Build libhip_nmf.so (hand-written HIP for gfx950) in-tree.
+
+    python -m muscle_synergies_amd.build [--force] [--jobs N]
+
+One `hipcc -c` per translation unit (run in parallel), then one link step.  The shared library lands in
+``muscle_synergies_amd/lib/libhip_nmf.so`` so that it travels with a repo snapshot to the GPU box.
+hipcc cross-compiles gfx950 code objects without a GPU.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG, "csrc")
+OBJ = os.path.join(CSRC, "_build")
+LIBDIR = os.path.join(PKG, "lib")
+LIB = os.path.join(LIBDIR, "libhip_nmf.so")
+INCLUDE = os.path.join(os.path.dirname(PKG), "include")
+
+ARCH = "gfx950"
+CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
+            "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
+
+
+def _hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: the ROCm toolchain is required to build libhip_nmf.so")
+    return exe
+
+
+def sources():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def headers():
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
+    hs.append(os.path.join(INCLUDE, "hip_nmf.h"))
+    return hs
+
+
+def _stale(target: str, deps) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _compile(src: str, extra) -> str:
+    obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
+    cmd = [_hipcc(), *CXXFLAGS, *extra, "-I", CSRC, "-c", src, "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
+    return obj
+
+
+def build(force: bool = False, jobs: int | None = None, extra_flags=(), verbose: bool = False) -> str:
+    os.makedirs(OBJ, exist_ok=True)
+    os.makedirs(LIBDIR, exist_ok=True)
+    hdrs = headers()
+    srcs = sources()
+    todo = [s for s in srcs
+            if force or _stale(os.path.join(OBJ, os.path.basename(s)[:-4] + ".o"), [s, *hdrs])]
+    jobs = jobs or min(8, os.cpu_count() or 1)
+    if todo:
+        if verbose:
+            print(f"[build] compiling {len(todo)} translation unit(s) for {ARCH} with {jobs} job(s)", flush=True)
+        with ThreadPoolExecutor(max_workers=jobs) as ex:
+            list(ex.map(lambda s: _compile(s, list(extra_flags)), todo))
+    objs = [os.path.join(OBJ, os.path.basename(s)[:-4] + ".o") for s in srcs]
+    if todo or _stale(LIB, objs):
+        cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", LIB]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+        if verbose:
+            print(f"[build] linked {LIB}", flush=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--force", action="store_true")
+    ap.add_argument("--jobs", type=int, default=None)
+    ap.add_argument("--flag", action="append", default=[])
+    a = ap.parse_args()
+    print(build(force=a.force, jobs=a.jobs, extra_flags=a.flag, verbose=True))

@@ -1,0 +1,560 @@
+// hipnmf_api.hip -- C ABI of libhip_nmf.so (see include/hip_nmf.h for the contract).
+//
+// Host-side driver of the CDNA4 kernels in nmf_kernels.hpp: argument validation, layout canonicalisation
+// (once per fit), path selection (one persistent workgroup per matrix vs. row-sliced launches), the
+// stop-rule bookkeeping of sklearn's _fit_multiplicative_update (_nmf.py:826-884) and HIP-event timing.
+// There is deliberately no CPU implementation here: without a GPU every compute call fails.
+#include "../../include/hip_nmf.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "nmf_inst.hpp"
+
+using namespace hipnmf;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t e_ = (expr);                                                                        \
+    if (e_ != hipSuccess)                                                                          \
+      return fail(HIPNMF_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, \
+                  __LINE__);                                                                       \
+  } while (0)
+
+inline long long round_up(long long v, long long q) { return (v + q - 1) / q * q; }
+
+template <typename real>
+const KernelSet<real>* select_kernels(int m, int k);
+
+template <>
+const KernelSet<float>* select_kernels<float>(int m, int k) {
+  if (m <= 4) return kernels_f32_g1c4(k);
+  if (m <= 8) return kernels_f32_g2c4(k);
+  if (m <= 16) return kernels_f32_g4c4(k);
+  if (m <= 32) return kernels_f32_g4c8(k);
+  return nullptr;
+}
+template <>
+const KernelSet<double>* select_kernels<double>(int m, int k) {
+  if (m <= 4) return kernels_f64_g1c4(k);
+  if (m <= 8) return kernels_f64_g2c4(k);
+  if (m <= 16) return kernels_f64_g4c4(k);
+  if (m <= 32) return kernels_f64_g4c8(k);
+  return nullptr;
+}
+
+}  // namespace
+
+struct hipnmf_handle {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  void* ws = nullptr;
+  size_t ws_bytes = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  float last_ms = 0.f;
+  int threads = 0;     // 0 = default
+  int max_slices = 0;  // 0 = default
+  int variant = 0;     // 0 auto, 1 force persistent, 2 force sliced
+  int num_cu = 256;
+};
+
+namespace {
+
+int ensure_ws(hipnmf_handle* h, size_t bytes) {
+  if (bytes <= h->ws_bytes) return HIPNMF_OK;
+  if (h->ws) {
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipFree(h->ws));
+    h->ws = nullptr;
+    h->ws_bytes = 0;
+  }
+  HIP_TRY(hipMalloc(&h->ws, bytes));
+  h->ws_bytes = bytes;
+  return HIPNMF_OK;
+}
+
+int validate(const hipnmf_problem* p, bool shard) {
+  if (!p) return fail(HIPNMF_ERR_BAD_ARG, "problem is NULL");
+  if (p->struct_size != (int32_t)sizeof(hipnmf_problem))
+    return fail(HIPNMF_ERR_BAD_ARG, "hipnmf_problem.struct_size = %d, library expects %d", p->struct_size,
+                (int)sizeof(hipnmf_problem));
+  if (p->batch < 1) return fail(HIPNMF_ERR_BAD_ARG, "batch must be >= 1 (got %d)", p->batch);
+  if (p->n_samples < 1 || p->n_samples > 2000000000LL)
+    return fail(HIPNMF_ERR_BAD_ARG, "n_samples must be in [1, 2e9] (got %lld)", (long long)p->n_samples);
+  if (p->n_features < 1) return fail(HIPNMF_ERR_BAD_ARG, "n_features must be >= 1 (got %d)", p->n_features);
+  if (p->n_components < 1) return fail(HIPNMF_ERR_BAD_ARG, "n_components must be >= 1 (got %d)", p->n_components);
+  if (p->n_features > 32 || p->n_components > 8)
+    return fail(HIPNMF_ERR_UNSUPPORTED, "shape outside the compiled kernel set: n_features=%d (max 32), n_components=%d (max 8)",
+                p->n_features, p->n_components);
+  if (p->x_layout != HIPNMF_X_ROW_MAJOR && p->x_layout != HIPNMF_X_CHANNEL_MAJOR)
+    return fail(HIPNMF_ERR_BAD_ARG, "bad x_layout %d", p->x_layout);
+  if (p->w_layout != HIPNMF_W_ROW_MAJOR && p->w_layout != HIPNMF_W_COMPONENT_MAJOR)
+    return fail(HIPNMF_ERR_BAD_ARG, "bad w_layout %d", p->w_layout);
+  if (p->reserved0 != 0) return fail(HIPNMF_ERR_BAD_ARG, "reserved0 must be 0");
+  const long long min_ld = (p->x_layout == HIPNMF_X_ROW_MAJOR) ? p->n_features : p->n_samples;
+  if (p->ldx < min_ld) return fail(HIPNMF_ERR_BAD_ARG, "ldx=%lld smaller than %lld", (long long)p->ldx, min_ld);
+  if (p->batch > 1 && p->x_batch_stride < 1) return fail(HIPNMF_ERR_BAD_ARG, "x_batch_stride must be >= 1");
+  if (!shard) {
+    if (p->max_iter < 1) return fail(HIPNMF_ERR_BAD_ARG, "max_iter must be >= 1 (got %d)", p->max_iter);
+    if (p->check_every < 1) return fail(HIPNMF_ERR_BAD_ARG, "check_every must be >= 1 (got %d)", p->check_every);
+    if (!(p->tol >= 0)) return fail(HIPNMF_ERR_BAD_ARG, "tol must be >= 0");
+  }
+  if (!(p->l1_reg_W >= 0) || !(p->l1_reg_H >= 0) || !(p->l2_reg_W >= 0) || !(p->l2_reg_H >= 0))
+    return fail(HIPNMF_ERR_BAD_ARG, "regularisation terms must be >= 0");
+  return HIPNMF_OK;
+}
+
+template <typename real>
+void launch(typename KernelSet<real>::Fn fn, dim3 grid, dim3 block, size_t smem, hipStream_t st,
+            const SolveArgs<real>& a) {
+  hipLaunchKernelGGL(fn, grid, block, smem, st, a);
+}
+
+// geometry of the row-sliced path
+struct SliceGeom {
+  int threads, S, rows_per_slice;
+};
+
+SliceGeom slice_geometry(const hipnmf_handle* h, long long T, int B) {
+  SliceGeom g;
+  g.threads = 256;
+  const long long quantum = g.threads;  // 64 rows per wave-step x waves
+  const long long t_pad = round_up(T, 64);
+  const long long target_wgs = 8LL * h->num_cu;
+  long long rps = round_up(std::max<long long>(2 * quantum, (t_pad * B + target_wgs - 1) / target_wgs), quantum);
+  long long S = (t_pad + rps - 1) / rps;
+  const long long cap = h->max_slices > 0 ? h->max_slices : 4096;
+  if (S > cap) {
+    rps = round_up((t_pad + cap - 1) / cap, quantum);
+    S = (t_pad + rps - 1) / rps;
+  }
+  g.S = (int)S;
+  g.rows_per_slice = (int)rps;
+  return g;
+}
+
+template <typename real>
+int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, real* W, real* H, real* err_out,
+                     int32_t* n_iter_out, real* sse_col_out, real* xsq_col_out) {
+  if (!h) return fail(HIPNMF_ERR_BAD_ARG, "handle is NULL");
+  int rc = validate(p, false);
+  if (rc) return rc;
+  if (!X || !W || !H) return fail(HIPNMF_ERR_BAD_ARG, "X, W and H must be non-NULL device pointers");
+  HIP_TRY(hipSetDevice(h->device));
+  const int B = p->batch, m = p->n_features, k = p->n_components;
+  const long long T = p->n_samples;
+  const KernelSet<real>* ks = select_kernels<real>(m, k);
+  if (!ks) return fail(HIPNMF_ERR_UNSUPPORTED, "no kernel for n_features=%d n_components=%d", m, k);
+  hipStream_t st = h->stream;
+
+  // ---- path selection ---------------------------------------------------------------------------
+  // persistent: one workgroup per matrix, ~1.2 ns per row-iteration per workgroup, num_cu in flight;
+  // sliced: ~3 launches (~7 us) per iteration, rows spread over the whole chip.
+  SliceGeom sg = slice_geometry(h, T, B);
+  bool persistent;
+  if (h->variant == 1)
+    persistent = true;
+  else if (h->variant == 2)
+    persistent = false;
+  else {
+    const double waves = (double)((B + h->num_cu - 1) / h->num_cu);
+    const double t_pers = waves * (double)T * 1.2e-9;
+    const double t_sliced = 7e-6 + (double)B * (double)T * 0.025e-9;
+    persistent = t_pers <= t_sliced;
+  }
+  if (!persistent && sg.S == 1 && h->variant != 2) persistent = true;
+
+  // ---- workspace carve-up -----------------------------------------------------------------------
+  const bool x_inplace = p->x_layout == HIPNMF_X_CHANNEL_MAJOR && (p->ldx % ks->G) == 0 && (T % ks->G) == 0 &&
+                         (reinterpret_cast<uintptr_t>(X) % 16) == 0 &&
+                         ((p->x_batch_stride * (long long)sizeof(real)) % 16) == 0;
+  const bool w_inplace = p->w_layout == HIPNMF_W_COMPONENT_MAJOR;
+  const long long ldx_c = x_inplace ? p->ldx : round_up(T, 64);
+  const long long ldw_c = w_inplace ? T : round_up(T, 64);
+  size_t off = 0;
+  auto carve = [&](size_t bytes) {
+    size_t o = off;
+    off += (bytes + 255) / 256 * 256;
+    return o;
+  };
+  const size_t o_x = x_inplace ? 0 : carve(sizeof(real) * (size_t)B * m * ldx_c);
+  const size_t o_w = w_inplace ? 0 : carve(sizeof(real) * (size_t)B * k * ldw_c);
+  size_t o_part = 0, o_sums = 0, o_col = 0, o_state = 0;
+  if (!persistent) {
+    o_part = carve(sizeof(real) * (size_t)B * sg.S * ks->NACC);
+    o_sums = carve(sizeof(real) * (size_t)B * (k * m + k * k));
+    o_col = carve(sizeof(real) * (size_t)B * sg.S * 2 * ks->MP);
+    o_state = carve(sizeof(real) * (size_t)B * 4);
+  }
+  rc = ensure_ws(h, std::max<size_t>(off, 256));
+  if (rc) return rc;
+  char* ws = static_cast<char*>(h->ws);
+
+  SolveArgs<real> a;
+  std::memset(&a, 0, sizeof(a));
+  if (x_inplace) {
+    a.X = X;
+    a.x_bstride = p->x_batch_stride;
+    a.ldx = p->ldx;
+  } else {
+    real* xc = reinterpret_cast<real*>(ws + o_x);
+    dim3 blk(32, 8);
+    dim3 grd((unsigned)((ldx_c + 31) / 32), (unsigned)((m + 31) / 32), (unsigned)B);
+    hipLaunchKernelGGL(x_to_channel_major_kernel<real>, grd, blk, 0, st, X, (long long)p->x_batch_stride,
+                       (long long)p->ldx, (int)p->x_layout, xc, (long long)m * ldx_c, ldx_c, (int)T, m);
+    a.X = xc;
+    a.x_bstride = (long long)m * ldx_c;
+    a.ldx = ldx_c;
+  }
+  if (w_inplace) {
+    a.W = W;
+    a.w_bstride = (long long)k * T;
+    a.ldw = T;
+  } else {
+    real* wc = reinterpret_cast<real*>(ws + o_w);
+    const long long n = (long long)k * ldw_c;
+    dim3 grd((unsigned)std::min<long long>((n + 255) / 256, 1024), (unsigned)B);
+    hipLaunchKernelGGL(w_convert_kernel<real>, grd, dim3(256), 0, st, W, wc, ldw_c, (int)T, k, 0);
+    a.W = wc;
+    a.w_bstride = (long long)k * ldw_c;
+    a.ldw = ldw_c;
+  }
+  a.H = H;
+  a.err_out = err_out;
+  a.n_iter_out = n_iter_out;
+  a.sse_col_out = sse_col_out;
+  a.xsq_col_out = xsq_col_out;
+  a.T = (int)T;
+  a.m = m;
+  a.max_iter = p->max_iter;
+  a.check_every = p->check_every;
+  a.update_h = p->update_h ? 1 : 0;
+  a.tol = (real)p->tol;
+  a.l1w = (real)p->l1_reg_W;
+  a.l2w = (real)p->l2_reg_W;
+  a.l1h = (real)p->l1_reg_H;
+  a.l2h = (real)p->l2_reg_H;
+  a.S = 1;
+  a.rows_per_slice = (int)round_up(T, 64);
+
+  HIP_TRY(hipEventRecord(h->ev0, st));
+  if (persistent) {
+    int threads = h->threads > 0 ? h->threads : 512;
+    threads = std::min(threads, (int)HIPNMF_MAXNT);
+    // a wave covers 64 rows per step: do not launch waves that would never get a row
+    const long long t_pad = round_up(T, 64);
+    while (threads > 256 && t_pad <= threads / 2) threads /= 2;
+    const int nw = threads / 64;
+    launch<real>(ks->fit_persistent, dim3(B), dim3(threads), ks->smem_bytes(nw), st, a);
+  } else {
+    a.S = sg.S;
+    a.rows_per_slice = sg.rows_per_slice;
+    a.part = reinterpret_cast<real*>(ws + o_part);
+    a.sums = reinterpret_cast<real*>(ws + o_sums);
+    a.colpart = reinterpret_cast<real*>(ws + o_col);
+    const bool stop_rule = p->tol > 0;
+    a.state = stop_rule ? reinterpret_cast<real*>(ws + o_state) : nullptr;
+    const int nt = sg.threads, nw = nt / 64;
+    const size_t smem = ks->smem_bytes(nw), smem1 = ks->smem_bytes(1);
+    const dim3 grid2(sg.S, B);
+    std::vector<real> host_state;
+    if (stop_rule) {
+      HIP_TRY(hipMemsetAsync(a.state, 0, sizeof(real) * (size_t)B * 4, st));
+      a.it = 0;
+      launch<real>(ks->slice_resid, grid2, dim3(nt), smem, st, a);
+      launch<real>(ks->resid_finalize, dim3(B), dim3(64), 0, st, a);
+      host_state.resize((size_t)B * 4);
+    }
+    for (int it = 1; it <= p->max_iter; ++it) {
+      a.it = it;
+      launch<real>(ks->slice_pass, grid2, dim3(nt), smem, st, a);
+      if (a.update_h) {
+        launch<real>(ks->reduce_slices, dim3(B), dim3(128), 0, st, a);
+        launch<real>(ks->hupdate, dim3(B), dim3(256), smem1, st, a);
+      }
+      if (stop_rule && (it % p->check_every) == 0) {
+        launch<real>(ks->slice_resid, grid2, dim3(nt), smem, st, a);
+        launch<real>(ks->resid_finalize, dim3(B), dim3(64), 0, st, a);
+        HIP_TRY(hipMemcpyAsync(host_state.data(), a.state, sizeof(real) * (size_t)B * 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        bool all_done = true;
+        for (int b = 0; b < B; ++b) all_done = all_done && host_state[(size_t)b * 4 + 3] != (real)0;
+        if (all_done) break;
+      }
+    }
+    a.it = -1;
+    launch<real>(ks->slice_resid, grid2, dim3(nt), smem, st, a);
+    launch<real>(ks->resid_finalize, dim3(B), dim3(64), 0, st, a);
+  }
+  HIP_TRY(hipEventRecord(h->ev1, st));
+  if (!w_inplace) {
+    real* wc = reinterpret_cast<real*>(ws + o_w);
+    const long long n = (long long)k * ldw_c;
+    dim3 grd((unsigned)std::min<long long>((n + 255) / 256, 1024), (unsigned)B);
+    hipLaunchKernelGGL(w_convert_kernel<real>, grd, dim3(256), 0, st, W, wc, ldw_c, (int)T, k, 1);
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(st));
+  HIP_TRY(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
+  return HIPNMF_OK;
+}
+
+// ---- shard building blocks ------------------------------------------------------------------------
+template <typename real>
+int shard_common(hipnmf_handle* h, const hipnmf_problem* p, const KernelSet<real>** ks_out, SolveArgs<real>* a,
+                 const real* X, const real* W, const real* H, SliceGeom* sg, bool need_part, bool need_col) {
+  if (!h) return fail(HIPNMF_ERR_BAD_ARG, "handle is NULL");
+  int rc = validate(p, true);
+  if (rc) return rc;
+  HIP_TRY(hipSetDevice(h->device));
+  const int B = p->batch, m = p->n_features, k = p->n_components;
+  const long long T = p->n_samples;
+  const KernelSet<real>* ks = select_kernels<real>(m, k);
+  if (!ks) return fail(HIPNMF_ERR_UNSUPPORTED, "no kernel for n_features=%d n_components=%d", m, k);
+  if (p->w_layout != HIPNMF_W_COMPONENT_MAJOR)
+    return fail(HIPNMF_ERR_UNSUPPORTED, "shard entry points need w_layout = HIPNMF_W_COMPONENT_MAJOR");
+  if (X) {
+    if (p->x_layout != HIPNMF_X_CHANNEL_MAJOR || (p->ldx % 4) != 0 || (T % ks->G) != 0 ||
+        (reinterpret_cast<uintptr_t>(X) % 16) != 0 || ((p->x_batch_stride * (long long)sizeof(real)) % 16) != 0)
+      return fail(HIPNMF_ERR_UNSUPPORTED,
+                  "shard entry points need channel-major X, 16-byte aligned, ldx %% 4 == 0 and n_samples %% %d == 0",
+                  ks->G);
+  }
+  *sg = slice_geometry(h, T, B);
+  size_t off = 0;
+  auto carve = [&](size_t bytes) {
+    size_t o = off;
+    off += (bytes + 255) / 256 * 256;
+    return o;
+  };
+  const size_t o_part = need_part ? carve(sizeof(real) * (size_t)B * sg->S * ks->NACC) : 0;
+  const size_t o_col = need_col ? carve(sizeof(real) * (size_t)B * sg->S * 2 * ks->MP) : 0;
+  rc = ensure_ws(h, std::max<size_t>(off, 256));
+  if (rc) return rc;
+  char* ws = static_cast<char*>(h->ws);
+  std::memset(a, 0, sizeof(*a));
+  a->X = X;
+  a->x_bstride = p->x_batch_stride;
+  a->ldx = p->ldx;
+  a->W = const_cast<real*>(W);
+  a->w_bstride = (long long)k * T;
+  a->ldw = T;
+  a->H = const_cast<real*>(H);
+  a->T = (int)T;
+  a->m = m;
+  a->update_h = p->update_h ? 1 : 0;
+  a->l1w = (real)p->l1_reg_W;
+  a->l2w = (real)p->l2_reg_W;
+  a->l1h = (real)p->l1_reg_H;
+  a->l2h = (real)p->l2_reg_H;
+  a->S = sg->S;
+  a->rows_per_slice = sg->rows_per_slice;
+  a->max_iter = 1;
+  a->check_every = 1;
+  if (need_part) a->part = reinterpret_cast<real*>(ws + o_part);
+  if (need_col) a->colpart = reinterpret_cast<real*>(ws + o_col);
+  *ks_out = ks;
+  return HIPNMF_OK;
+}
+
+template <typename real>
+int shard_pass_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, real* W, const real* H, real* sums) {
+  if (!X || !W || !H) return fail(HIPNMF_ERR_BAD_ARG, "X, W and H must be non-NULL device pointers");
+  if (p && p->update_h && !sums) return fail(HIPNMF_ERR_BAD_ARG, "sums must be non-NULL when update_h != 0");
+  const KernelSet<real>* ks = nullptr;
+  SolveArgs<real> a;
+  SliceGeom sg;
+  int rc = shard_common<real>(h, p, &ks, &a, X, W, H, &sg, true, false);
+  if (rc) return rc;
+  a.sums = sums;
+  hipStream_t st = h->stream;
+  HIP_TRY(hipEventRecord(h->ev0, st));
+  launch<real>(ks->slice_pass, dim3(sg.S, p->batch), dim3(sg.threads), ks->smem_bytes(sg.threads / 64), st, a);
+  if (a.update_h) launch<real>(ks->reduce_slices, dim3(p->batch), dim3(128), 0, st, a);
+  HIP_TRY(hipEventRecord(h->ev1, st));
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(st));
+  HIP_TRY(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
+  return HIPNMF_OK;
+}
+
+template <typename real>
+int shard_hupdate_impl(hipnmf_handle* h, const hipnmf_problem* p, real* H, const real* sums) {
+  if (!H || !sums) return fail(HIPNMF_ERR_BAD_ARG, "H and sums must be non-NULL device pointers");
+  const KernelSet<real>* ks = nullptr;
+  SolveArgs<real> a;
+  SliceGeom sg;
+  int rc = shard_common<real>(h, p, &ks, &a, nullptr, nullptr, H, &sg, false, false);
+  if (rc) return rc;
+  a.sums = const_cast<real*>(sums);
+  hipStream_t st = h->stream;
+  HIP_TRY(hipEventRecord(h->ev0, st));
+  launch<real>(ks->hupdate, dim3(p->batch), dim3(256), ks->smem_bytes(1), st, a);
+  HIP_TRY(hipEventRecord(h->ev1, st));
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(st));
+  HIP_TRY(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
+  return HIPNMF_OK;
+}
+
+template <typename real>
+int shard_residual_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, const real* W, const real* H,
+                        real* sse_col, real* xsq_col) {
+  if (!X || !W || !H || !sse_col) return fail(HIPNMF_ERR_BAD_ARG, "X, W, H and sse_col must be non-NULL");
+  const KernelSet<real>* ks = nullptr;
+  SolveArgs<real> a;
+  SliceGeom sg;
+  int rc = shard_common<real>(h, p, &ks, &a, X, W, H, &sg, false, true);
+  if (rc) return rc;
+  a.sse_col_out = sse_col;
+  a.xsq_col_out = xsq_col;
+  a.it = -1;
+  hipStream_t st = h->stream;
+  HIP_TRY(hipEventRecord(h->ev0, st));
+  launch<real>(ks->slice_resid, dim3(sg.S, p->batch), dim3(sg.threads), ks->smem_bytes(sg.threads / 64), st, a);
+  launch<real>(ks->resid_finalize, dim3(p->batch), dim3(64), 0, st, a);
+  HIP_TRY(hipEventRecord(h->ev1, st));
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(st));
+  HIP_TRY(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
+  return HIPNMF_OK;
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+int hipnmf_version(void) { return HIPNMF_VERSION; }
+
+const char* hipnmf_last_error(void) { return g_last_error.c_str(); }
+
+int hipnmf_device_count(void) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) return fail(HIPNMF_ERR_NO_DEVICE, "hipGetDeviceCount failed: %s", hipGetErrorString(e));
+  return n;
+}
+
+int hipnmf_create(int device, hipnmf_handle** out) {
+  if (!out) return fail(HIPNMF_ERR_BAD_ARG, "out is NULL");
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n < 1)
+    return fail(HIPNMF_ERR_NO_DEVICE, "no ROCm device available (%s); libhip_nmf has no CPU fallback",
+                e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+  if (device < 0 || device >= n) return fail(HIPNMF_ERR_BAD_ARG, "device %d out of range [0, %d)", device, n);
+  HIP_TRY(hipSetDevice(device));
+  hipnmf_handle* h = new hipnmf_handle();
+  h->device = device;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+    h->num_cu = prop.multiProcessorCount;
+  if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
+    delete h;
+    return fail(HIPNMF_ERR_HIP, "stream/event creation failed");
+  }
+  h->stream = h->own_stream;
+  *out = h;
+  return HIPNMF_OK;
+}
+
+int hipnmf_destroy(hipnmf_handle* h) {
+  if (!h) return HIPNMF_OK;
+  (void)hipSetDevice(h->device);
+  if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
+  if (h->ws) (void)hipFree(h->ws);
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+  delete h;
+  return HIPNMF_OK;
+}
+
+int hipnmf_set_stream(hipnmf_handle* h, void* hip_stream) {
+  if (!h) return fail(HIPNMF_ERR_BAD_ARG, "handle is NULL");
+  h->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : h->own_stream;
+  return HIPNMF_OK;
+}
+
+size_t hipnmf_workspace_bytes(const hipnmf_problem* p, int elem_size) {
+  if (!p || (elem_size != 4 && elem_size != 8)) return 0;
+  const long long ld = round_up(p->n_samples, 64);
+  size_t bytes = (size_t)elem_size * (size_t)p->batch * (size_t)(p->n_features + p->n_components) * (size_t)ld;
+  bytes += (size_t)elem_size * (size_t)p->batch * 4096 * 2;  // slice partials upper bound
+  return bytes;
+}
+
+int hipnmf_last_kernel_ms(hipnmf_handle* h, float* ms) {
+  if (!h || !ms) return fail(HIPNMF_ERR_BAD_ARG, "NULL argument");
+  *ms = h->last_ms;
+  return HIPNMF_OK;
+}
+
+int hipnmf_set_tuning(hipnmf_handle* h, int threads, int max_slices, int variant) {
+  if (!h) return fail(HIPNMF_ERR_BAD_ARG, "handle is NULL");
+  if (threads != 0 && threads != 256 && threads != 512 && threads != 1024)
+    return fail(HIPNMF_ERR_BAD_ARG, "threads must be 0, 256, 512 or 1024");
+  if (max_slices < 0 || variant < 0 || variant > 2) return fail(HIPNMF_ERR_BAD_ARG, "bad tuning value");
+  h->threads = threads;
+  h->max_slices = max_slices;
+  h->variant = variant;
+  return HIPNMF_OK;
+}
+
+int hipnmf_fit_batched_f32(hipnmf_handle* h, const hipnmf_problem* p, const float* X, float* W, float* H,
+                           float* err_out, int32_t* n_iter_out, float* sse_col_out, float* xsq_col_out) {
+  return fit_batched_impl<float>(h, p, X, W, H, err_out, n_iter_out, sse_col_out, xsq_col_out);
+}
+int hipnmf_fit_batched_f64(hipnmf_handle* h, const hipnmf_problem* p, const double* X, double* W, double* H,
+                           double* err_out, int32_t* n_iter_out, double* sse_col_out, double* xsq_col_out) {
+  return fit_batched_impl<double>(h, p, X, W, H, err_out, n_iter_out, sse_col_out, xsq_col_out);
+}
+
+int hipnmf_shard_pass_f32(hipnmf_handle* h, const hipnmf_problem* p, const float* X, float* W, const float* H,
+                          float* sums) {
+  return shard_pass_impl<float>(h, p, X, W, H, sums);
+}
+int hipnmf_shard_hupdate_f32(hipnmf_handle* h, const hipnmf_problem* p, float* H, const float* sums) {
+  return shard_hupdate_impl<float>(h, p, H, sums);
+}
+int hipnmf_shard_residual_f32(hipnmf_handle* h, const hipnmf_problem* p, const float* X, const float* W,
+                              const float* H, float* sse_col, float* xsq_col) {
+  return shard_residual_impl<float>(h, p, X, W, H, sse_col, xsq_col);
+}
+int hipnmf_shard_pass_f64(hipnmf_handle* h, const hipnmf_problem* p, const double* X, double* W, const double* H,
+                          double* sums) {
+  return shard_pass_impl<double>(h, p, X, W, H, sums);
+}
+int hipnmf_shard_hupdate_f64(hipnmf_handle* h, const hipnmf_problem* p, double* H, const double* sums) {
+  return shard_hupdate_impl<double>(h, p, H, sums);
+}
+int hipnmf_shard_residual_f64(hipnmf_handle* h, const hipnmf_problem* p, const double* X, const double* W,
+                              const double* H, double* sse_col, double* xsq_col) {
+  return shard_residual_impl<double>(h, p, X, W, H, sse_col, xsq_col);
+}
+
+}  // extern "C"

@@ -1,0 +1,55 @@
+// nmf_inst.hpp -- kernel tables: one translation unit per (real, G, CH), eight ranks (K = 1..8) each,
+// so that `make -j` compiles them in parallel.
+#pragma once
+#include "nmf_kernels.hpp"
+
+namespace hipnmf {
+
+template <typename real>
+struct KernelSet {
+  using Fn = void (*)(SolveArgs<real>);
+  Fn fit_persistent, slice_pass, reduce_slices, hupdate, slice_resid, resid_finalize;
+  int G, CH, K, MP, NACC;
+  size_t (*smem_bytes)(int nw);
+};
+
+template <typename real, int G, int CH, int K>
+KernelSet<real> make_kernel_set() {
+  KernelSet<real> ks;
+  ks.fit_persistent = fit_persistent_kernel<real, G, CH, K>;
+  ks.slice_pass = slice_pass_kernel<real, G, CH, K>;
+  ks.reduce_slices = reduce_slices_kernel<real, G, CH, K>;
+  ks.hupdate = hupdate_kernel<real, G, CH, K>;
+  ks.slice_resid = slice_resid_kernel<real, G, CH, K>;
+  ks.resid_finalize = resid_finalize_kernel<real, G, CH, K>;
+  ks.G = G;
+  ks.CH = CH;
+  ks.K = K;
+  ks.MP = G * CH;
+  ks.NACC = Cfg<real, G, CH, K>::NACC;
+  ks.smem_bytes = &Smem<real, G, CH, K>::bytes;
+  return ks;
+}
+
+#define HIPNMF_DECLARE_TABLE(REAL, TAG) const KernelSet<REAL>* kernels_##TAG(int K);
+
+HIPNMF_DECLARE_TABLE(float, f32_g1c4)
+HIPNMF_DECLARE_TABLE(float, f32_g2c4)
+HIPNMF_DECLARE_TABLE(float, f32_g4c4)
+HIPNMF_DECLARE_TABLE(float, f32_g4c8)
+HIPNMF_DECLARE_TABLE(double, f64_g1c4)
+HIPNMF_DECLARE_TABLE(double, f64_g2c4)
+HIPNMF_DECLARE_TABLE(double, f64_g4c4)
+HIPNMF_DECLARE_TABLE(double, f64_g4c8)
+
+#define HIPNMF_DEFINE_TABLE(REAL, TAG, G, CH)                                                          \
+  const KernelSet<REAL>* kernels_##TAG(int K) {                                                        \
+    static const KernelSet<REAL> tbl[8] = {                                                            \
+        make_kernel_set<REAL, G, CH, 1>(), make_kernel_set<REAL, G, CH, 2>(),                          \
+        make_kernel_set<REAL, G, CH, 3>(), make_kernel_set<REAL, G, CH, 4>(),                          \
+        make_kernel_set<REAL, G, CH, 5>(), make_kernel_set<REAL, G, CH, 6>(),                          \
+        make_kernel_set<REAL, G, CH, 7>(), make_kernel_set<REAL, G, CH, 8>()};                         \
+    return (K >= 1 && K <= 8) ? &tbl[K - 1] : nullptr;                                                 \
+  }
+
+}  // namespace hipnmf

@@ -1,0 +1,820 @@
+// nmf_kernels.hpp -- CDNA4 (gfx950) kernels of the NMF multiplicative-update solver.
+//
+// Arithmetic replaced: sklearn/decomposition/_nmf.py (1.7.2) _multiplicative_update_w (:526-631),
+// _multiplicative_update_h (:634-728), _beta_divergence (:85-134), loop + stop rule (:731-893), reached from
+// the reference at src/muscle_synergies/analysis.py:862-863.  sklearn notation: X (T x m) ~ W (T x k) H (k x m).
+//
+// Mapping (wave64, no LDS in the streaming loop):
+//   * a wave owns 64 consecutive rows (time samples) per step; lane l owns row  wbase + l  of W;
+//   * G consecutive lanes form a group that shares G rows of X: lane g of the group holds CH channels
+//     (columns g*CH .. g*CH+CH-1) of all G rows, loaded as CH vector loads of G elements from the
+//     channel-major X (coalesced, 16 B per lane for fp32 G=4);
+//   * X H^T : each lane forms partial dot products over its CH channels for the G rows, then a
+//     reduce-scatter over the G lanes (DPP quad permutes, no LDS) leaves lane g with row g's numerator;
+//   * W (H H^T), the division and the W update are row-per-lane;
+//   * W^T X : the updated row is broadcast inside the group (DPP) and each lane accumulates K x CH sums
+//     for its own channels; W^T W is accumulated row-per-lane (upper triangle);
+//   * the T-long reductions finish with a butterfly over the wave and a fixed-order sum over waves/slices,
+//     so results are bitwise reproducible for a given launch geometry.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+
+namespace hipnmf {
+
+constexpr int WAVE = 64;
+#ifndef HIPNMF_MAXNT
+#define HIPNMF_MAXNT 512
+#endif
+
+// EPSILON = np.finfo(np.float32).eps for fp32 *and* fp64 (_nmf.py:39)
+template <typename real>
+__device__ __forceinline__ real eps_val() {
+  return (real)1.1920928955078125e-07;
+}
+
+__device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float sqrt_(float a) { return __builtin_sqrtf(a); }
+__device__ __forceinline__ double sqrt_(double a) { return __builtin_sqrt(a); }
+
+// ------------------------------------------------------------------------------------------------
+// compile-time loop
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (N > 0) {
+    static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// cross-lane primitives
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  int i = __builtin_bit_cast(int, v);
+  i = __builtin_amdgcn_update_dpp(i, i, CTRL, 0xf, 0xf, true);
+  return __builtin_bit_cast(float, i);
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+  long long ll = __builtin_bit_cast(long long, v);
+  int lo = (int)(ll & 0xffffffffLL), hi = (int)(ll >> 32);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, true);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, true);
+  ll = ((long long)hi << 32) | (unsigned int)lo;
+  return __builtin_bit_cast(double, ll);
+}
+
+// value of lane (l ^ H); H in {1, 2} stays inside a quad -> DPP quad_perm, else ds_bpermute
+template <int H, typename real>
+__device__ __forceinline__ real xor_lane(real v) {
+  if constexpr (H == 1)
+    return dpp_mov<0xB1>(v);  // quad_perm [1,0,3,2]
+  else if constexpr (H == 2)
+    return dpp_mov<0x4E>(v);  // quad_perm [2,3,0,1]
+  else
+    return __shfl_xor(v, H, WAVE);
+}
+
+// value held by lane R of this lane's G-lane group
+template <int G, int R, typename real>
+__device__ __forceinline__ real group_bcast(real v) {
+  if constexpr (G == 1)
+    return v;
+  else if constexpr (G == 2)
+    return dpp_mov<(R == 0 ? 0xA0 : 0xF5)>(v);  // quad_perm [0,0,2,2] / [1,1,3,3]
+  else if constexpr (G == 4)
+    return dpp_mov<R * 0x55>(v);  // quad_perm [R,R,R,R]
+  else
+    return __shfl(v, R, G);
+}
+
+template <typename real>
+__device__ __forceinline__ real uniform(real v) {  // wave-uniform value -> SGPR
+  if constexpr (sizeof(real) == 4) {
+    return __builtin_bit_cast(real, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+  } else {
+    long long ll = __builtin_bit_cast(long long, v);
+    int lo = __builtin_amdgcn_readfirstlane((int)(ll & 0xffffffffLL));
+    int hi = __builtin_amdgcn_readfirstlane((int)(ll >> 32));
+    ll = ((long long)hi << 32) | (unsigned int)lo;
+    return __builtin_bit_cast(real, ll);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// vector load of N consecutive elements (N * sizeof(real) aligned)
+template <typename real, int N>
+struct alignas(sizeof(real) * N <= 16 ? sizeof(real) * N : 16) VecN {
+  real v[N];
+};
+template <typename real, int N>
+__device__ __forceinline__ void load_vec(const real* __restrict__ p, real (&out)[N]) {
+  const VecN<real, N> t = *reinterpret_cast<const VecN<real, N>*>(p);
+#pragma unroll
+  for (int i = 0; i < N; ++i) out[i] = t.v[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+template <typename real, int G, int CH, int K>
+struct Cfg {
+  static constexpr int MP = G * CH;            // padded channel count handled by a lane group
+  static constexpr int NB = K * (K + 1) / 2;   // upper triangle of W^T W
+  static constexpr int NACC = K * MP + NB;     // floats per wave partial
+};
+
+// kernel arguments (canonical layouts: X channel-major with ldx % G == 0, W component-major)
+template <typename real>
+struct SolveArgs {
+  const real* X;
+  long long x_bstride, ldx;
+  real* W;
+  long long w_bstride, ldw;
+  real* H;            // [B][k][m]
+  real* part;         // [B][S][NACC]    per-slice partial sums (multi-slice path / shard path)
+  real* sums;         // [B][k*m + k*k]  summed W^T X | W^T W (shard path), or nullptr
+  real* colpart;      // [B][S][2*MP]    per-slice sse / xsq partials (multi-slice path)
+  real* err_out;      // [B] or nullptr
+  int* n_iter_out;    // [B] or nullptr
+  real* sse_col_out;  // [B][m] or nullptr
+  real* xsq_col_out;  // [B][m] or nullptr
+  real* state;        // [B][4] err0, prev, err, done   (multi-slice path stop rule)
+  int T, m, max_iter, check_every, update_h, S, rows_per_slice, it;
+  real tol, l1w, l2w, l1h, l2h;
+};
+
+template <typename real, int G, int CH, int K>
+struct RowTile {
+  real x[CH][G];
+  real w[K];
+};
+
+// rows [row_grp, row_grp+G) of the group; lane_row = row owned by this lane
+template <typename real, int G, int CH, int K>
+__device__ __forceinline__ void load_tile(RowTile<real, G, CH, K>& t, const real* __restrict__ Xb, long long ldx,
+                                          const real* __restrict__ Wb, long long ldw, int T, int m, int row_grp,
+                                          int g, int lane_row) {
+  if (row_grp < T) {
+#pragma unroll
+    for (int cc = 0; cc < CH; ++cc) {
+      const int j = g * CH + cc;
+      if (j < m) {
+        load_vec<real, G>(Xb + (long long)j * ldx + row_grp, t.x[cc]);
+      } else {
+#pragma unroll
+        for (int r = 0; r < G; ++r) t.x[cc][r] = (real)0;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int cc = 0; cc < CH; ++cc)
+#pragma unroll
+      for (int r = 0; r < G; ++r) t.x[cc][r] = (real)0;
+  }
+  if (lane_row < T) {
+#pragma unroll
+    for (int c = 0; c < K; ++c) t.w[c] = Wb[(long long)c * ldw + lane_row];
+  } else {
+#pragma unroll
+    for (int c = 0; c < K; ++c) t.w[c] = (real)0;
+  }
+}
+
+// reduce-scatter of pn[G][K] over the G lanes of a group: afterwards pn[0][*] of lane g = sum over the
+// group's lanes of (their) pn[g][*].
+template <int HSZ, typename real, int G, int K>
+__device__ __forceinline__ void reduce_scatter(real (&pn)[G][K], int g) {
+  if constexpr (HSZ >= 1) {
+    const bool up = (g & HSZ) != 0;
+#pragma unroll
+    for (int i = 0; i < HSZ; ++i)
+#pragma unroll
+      for (int c = 0; c < K; ++c) {
+        const real lo = pn[i][c], hi = pn[i + HSZ][c];
+        const real send = up ? lo : hi;
+        const real keep = up ? hi : lo;
+        pn[i][c] = keep + xor_lane<HSZ>(send);
+      }
+    reduce_scatter<HSZ / 2, real, G, K>(pn, g);
+  }
+}
+
+// One step: W-update of the lane's row and accumulation of W^T X (lane's channels) and W^T W (own row).
+template <typename real, int G, int CH, int K>
+__device__ __forceinline__ void update_tile(RowTile<real, G, CH, K>& t, const real (&h)[K][CH], const real (&hht)[K][K],
+                                            real (&accA)[K][CH], real (&accB)[Cfg<real, G, CH, K>::NB], int g,
+                                            real l1w, real l2w, bool update_h) {
+  // numerator X H^T (_nmf.py:543): partial over this lane's channels, for each of the G rows
+  real pn[G][K];
+#pragma unroll
+  for (int r = 0; r < G; ++r)
+#pragma unroll
+    for (int c = 0; c < K; ++c) {
+      real s = t.x[0][r] * h[c][0];
+#pragma unroll
+      for (int cc = 1; cc < CH; ++cc) s = fma_(t.x[cc][r], h[c][cc], s);
+      pn[r][c] = s;
+    }
+  reduce_scatter<G / 2, real, G, K>(pn, g);
+
+  // denominator W (H H^T) (_nmf.py:553-554), regularisation (:616-619), zero guard (:620), update (:622-629)
+  real wn[K];
+#pragma unroll
+  for (int c = 0; c < K; ++c) {
+    real d = t.w[0] * hht[0][c];
+#pragma unroll
+    for (int c2 = 1; c2 < K; ++c2) d = fma_(t.w[c2], hht[c2][c], d);
+    if (l1w > (real)0) d = d + l1w;
+    if (l2w > (real)0) d = d + l2w * t.w[c];
+    d = (d == (real)0) ? eps_val<real>() : d;
+    wn[c] = t.w[c] * (pn[0][c] / d);
+  }
+#pragma unroll
+  for (int c = 0; c < K; ++c) t.w[c] = wn[c];
+
+  if (update_h) {
+    // W^T X (_nmf.py:639): rows of the group broadcast lane by lane
+    static_for<G>([&](auto R) {
+      constexpr int r = decltype(R)::value;
+#pragma unroll
+      for (int c = 0; c < K; ++c) {
+        const real wr = group_bcast<G, r>(wn[c]);
+#pragma unroll
+        for (int cc = 0; cc < CH; ++cc) accA[c][cc] = fma_(wr, t.x[cc][r], accA[c][cc]);
+      }
+    });
+    // W^T W (first factor of multi_dot, _nmf.py:640), upper triangle, own row
+    int idx = 0;
+#pragma unroll
+    for (int c = 0; c < K; ++c)
+#pragma unroll
+      for (int c2 = c; c2 < K; ++c2) {
+        accB[idx] = fma_(wn[c], wn[c2], accB[idx]);
+        ++idx;
+      }
+  }
+}
+
+// residual of the group's rows restricted to this lane's channels: sse += (x - w.h)^2, xsq += x^2
+template <typename real, int G, int CH, int K>
+__device__ __forceinline__ void resid_tile(const RowTile<real, G, CH, K>& t, const real (&h)[K][CH], real (&sse)[CH],
+                                           real (&xsq)[CH]) {
+  static_for<G>([&](auto R) {
+    constexpr int r = decltype(R)::value;
+    real wr[K];
+#pragma unroll
+    for (int c = 0; c < K; ++c) wr[c] = group_bcast<G, r>(t.w[c]);
+#pragma unroll
+    for (int cc = 0; cc < CH; ++cc) {
+      real rec = wr[0] * h[0][cc];
+#pragma unroll
+      for (int c = 1; c < K; ++c) rec = fma_(wr[c], h[c][cc], rec);
+      const real d = t.x[cc][r] - rec;
+      sse[cc] = fma_(d, d, sse[cc]);
+      xsq[cc] = fma_(t.x[cc][r], t.x[cc][r], xsq[cc]);
+    }
+  });
+}
+
+// ------------------------------------------------------------------------------------------------
+// LDS carve-up shared by all solver kernels
+template <typename real, int G, int CH, int K>
+struct Smem {
+  using C = Cfg<real, G, CH, K>;
+  real* H;     // [K][MP]
+  real* HHt;   // [K][K]
+  real* A;     // [K][MP]
+  real* B;     // [K][K]
+  real* part;  // [NW][NACC]  (also used as [NW][2*MP] by the residual)
+  real* scal;  // [8]
+  __device__ __forceinline__ Smem(unsigned char* raw, int nw) {
+    H = reinterpret_cast<real*>(raw);
+    HHt = H + K * C::MP;
+    A = HHt + K * K;
+    B = A + K * C::MP;
+    part = B + K * K;
+    scal = part + nw * C::NACC;
+  }
+  static size_t bytes(int nw) { return sizeof(real) * (size_t)(2 * K * C::MP + 2 * K * K + nw * C::NACC + 8); }
+};
+
+template <typename real, int G, int CH, int K>
+__device__ __forceinline__ void load_h_to_lds(Smem<real, G, CH, K>& s, const real* __restrict__ Hb, int m) {
+  constexpr int MP = G * CH;
+  for (int i = threadIdx.x; i < K * MP; i += blockDim.x) {
+    const int c = i / MP, j = i % MP;
+    s.H[i] = (j < m) ? Hb[c * m + j] : (real)0;
+  }
+}
+
+// H H^T from LDS H (_nmf.py:553); call between barriers
+template <typename real, int G, int CH, int K>
+__device__ __forceinline__ void compute_hht(Smem<real, G, CH, K>& s) {
+  constexpr int MP = G * CH;
+  for (int i = threadIdx.x; i < K * K; i += blockDim.x) {
+    const int c = i / K, c2 = i % K;
+    real acc = (real)0;
+#pragma unroll
+    for (int j = 0; j < MP; ++j) acc = fma_(s.H[c * MP + j], s.H[c2 * MP + j], acc);
+    s.HHt[i] = acc;
+  }
+}
+
+template <typename real, int G, int CH, int K>
+__device__ __forceinline__ void load_h_regs(const Smem<real, G, CH, K>& s, int g, real (&h)[K][CH], real (&hht)[K][K]) {
+  constexpr int MP = G * CH;
+#pragma unroll
+  for (int c = 0; c < K; ++c)
+#pragma unroll
+    for (int cc = 0; cc < CH; ++cc) h[c][cc] = s.H[c * MP + g * CH + cc];
+#pragma unroll
+  for (int c = 0; c < K; ++c)
+#pragma unroll
+    for (int c2 = 0; c2 < K; ++c2) hht[c][c2] = uniform(s.HHt[c * K + c2]);
+}
+
+// streaming pass over rows [row_begin, row_end) (row_begin % 64 == 0): W update + accumulation
+template <typename real, int G, int CH, int K>
+__device__ __forceinline__ void rows_update_pass(const real* __restrict__ Xb, long long ldx, real* __restrict__ Wb,
+                                                 long long ldw, int T, int m, int row_begin, int row_end,
+                                                 const real (&h)[K][CH], const real (&hht)[K][K],
+                                                 real (&accA)[K][CH], real (&accB)[Cfg<real, G, CH, K>::NB], real l1w,
+                                                 real l2w, bool update_h) {
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int wave = threadIdx.x / WAVE;
+  const int nw = blockDim.x / WAVE;
+  const int g = lane % G;
+  const int stride = nw * WAVE;
+  int wbase = row_begin + wave * WAVE;  // wave-uniform
+  if (wbase >= row_end) return;
+  RowTile<real, G, CH, K> ta, tb;
+  load_tile<real, G, CH, K>(ta, Xb, ldx, Wb, ldw, T, m, wbase + (lane - g), g, wbase + lane);
+  while (true) {
+    {
+      const int nb = wbase + stride;
+      if (nb < row_end) load_tile<real, G, CH, K>(tb, Xb, ldx, Wb, ldw, T, m, nb + (lane - g), g, nb + lane);
+      update_tile<real, G, CH, K>(ta, h, hht, accA, accB, g, l1w, l2w, update_h);
+      if (wbase + lane < T) {
+#pragma unroll
+        for (int c = 0; c < K; ++c) Wb[(long long)c * ldw + wbase + lane] = ta.w[c];
+      }
+      wbase = nb;
+      if (wbase >= row_end) break;
+    }
+    {
+      const int nb = wbase + stride;
+      if (nb < row_end) load_tile<real, G, CH, K>(ta, Xb, ldx, Wb, ldw, T, m, nb + (lane - g), g, nb + lane);
+      update_tile<real, G, CH, K>(tb, h, hht, accA, accB, g, l1w, l2w, update_h);
+      if (wbase + lane < T) {
+#pragma unroll
+        for (int c = 0; c < K; ++c) Wb[(long long)c * ldw + wbase + lane] = tb.w[c];
+      }
+      wbase = nb;
+      if (wbase >= row_end) break;
+    }
+  }
+}
+
+template <typename real, int G, int CH, int K>
+__device__ __forceinline__ void rows_resid_pass(const real* __restrict__ Xb, long long ldx, const real* __restrict__ Wb,
+                                                long long ldw, int T, int m, int row_begin, int row_end,
+                                                const real (&h)[K][CH], real (&sse)[CH], real (&xsq)[CH]) {
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int wave = threadIdx.x / WAVE;
+  const int nw = blockDim.x / WAVE;
+  const int g = lane % G;
+  const int stride = nw * WAVE;
+  for (int wbase = row_begin + wave * WAVE; wbase < row_end; wbase += stride) {
+    RowTile<real, G, CH, K> t;
+    load_tile<real, G, CH, K>(t, Xb, ldx, Wb, ldw, T, m, wbase + (lane - g), g, wbase + lane);
+    resid_tile<real, G, CH, K>(t, h, sse, xsq);
+  }
+}
+
+// wave butterfly of the accumulators, then one record per wave in LDS
+template <typename real, int G, int CH, int K>
+__device__ __forceinline__ void wave_reduce_acc(real* __restrict__ rec /* [NACC] of this wave */, real (&accA)[K][CH],
+                                                real (&accB)[Cfg<real, G, CH, K>::NB]) {
+  using C = Cfg<real, G, CH, K>;
+  const int lane = threadIdx.x & (WAVE - 1);
+#pragma unroll
+  for (int off = G; off < WAVE; off <<= 1)
+#pragma unroll
+    for (int c = 0; c < K; ++c)
+#pragma unroll
+      for (int cc = 0; cc < CH; ++cc) accA[c][cc] += __shfl_xor(accA[c][cc], off, WAVE);
+#pragma unroll
+  for (int off = 1; off < WAVE; off <<= 1)
+#pragma unroll
+    for (int i = 0; i < C::NB; ++i) accB[i] += __shfl_xor(accB[i], off, WAVE);
+  if (lane < G) {
+#pragma unroll
+    for (int c = 0; c < K; ++c)
+#pragma unroll
+      for (int cc = 0; cc < CH; ++cc) rec[c * C::MP + lane * CH + cc] = accA[c][cc];
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < C::NB; ++i) rec[K * C::MP + i] = accB[i];
+  }
+}
+
+// H update from LDS A (= W^T X, [K][MP]) and B (= W^T W, full [K][K]) (_nmf.py:638-640, 701-728).
+// Barriers inside; every thread of the block must call it.  Leaves new H and H H^T in LDS.
+template <typename real, int G, int CH, int K>
+__device__ __forceinline__ void h_update_lds(Smem<real, G, CH, K>& s, int m, real l1h, real l2h) {
+  constexpr int MP = G * CH;
+  real newh = (real)0;
+  const int i = threadIdx.x;
+  const bool active = i < K * MP;
+  if (active) {
+    const int c = i / MP, j = i % MP;
+    if (j < m) {
+      real d = s.B[c * K + 0] * s.H[0 * MP + j];
+#pragma unroll
+      for (int c2 = 1; c2 < K; ++c2) d = fma_(s.B[c * K + c2], s.H[c2 * MP + j], d);
+      const real hold = s.H[i];
+      if (l1h > (real)0) d = d + l1h;
+      if (l2h > (real)0) d = d + l2h * hold;
+      d = (d == (real)0) ? eps_val<real>() : d;
+      newh = hold * (s.A[i] / d);
+    }
+  }
+  __syncthreads();
+  if (active) s.H[i] = newh;
+  __syncthreads();
+  compute_hht(s);
+  __syncthreads();
+}
+
+// sum of wave records -> LDS A / B (fixed order over waves)
+template <typename real, int G, int CH, int K>
+__device__ __forceinline__ void combine_wave_records(Smem<real, G, CH, K>& s, int nw) {
+  using C = Cfg<real, G, CH, K>;
+  for (int i = threadIdx.x; i < C::NACC; i += blockDim.x) {
+    real acc = s.part[i];
+    for (int w = 1; w < nw; ++w) acc += s.part[w * C::NACC + i];
+    if (i < K * C::MP) {
+      s.A[i] = acc;
+    } else {
+      // unpack the upper triangle index
+      int idx = i - K * C::MP, c = 0;
+      while (idx >= K - c) {
+        idx -= K - c;
+        ++c;
+      }
+      const int c2 = c + idx;
+      s.B[c * K + c2] = acc;
+      s.B[c2 * K + c] = acc;
+    }
+  }
+}
+
+// block-wide residual over rows [row_begin,row_end): returns per-column sse/xsq in LDS part[0 .. 2*MP)
+// (sums over the block's waves, fixed order).  Barriers inside.
+template <typename real, int G, int CH, int K>
+__device__ __forceinline__ void block_residual(Smem<real, G, CH, K>& s, const real* __restrict__ Xb, long long ldx,
+                                               const real* __restrict__ Wb, long long ldw, int T, int m, int row_begin,
+                                               int row_end, const real (&h)[K][CH]) {
+  constexpr int MP = G * CH;
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int wave = threadIdx.x / WAVE;
+  const int nw = blockDim.x / WAVE;
+  real sse[CH], xsq[CH];
+#pragma unroll
+  for (int cc = 0; cc < CH; ++cc) sse[cc] = xsq[cc] = (real)0;
+  rows_resid_pass<real, G, CH, K>(Xb, ldx, Wb, ldw, T, m, row_begin, row_end, h, sse, xsq);
+#pragma unroll
+  for (int off = G; off < WAVE; off <<= 1)
+#pragma unroll
+    for (int cc = 0; cc < CH; ++cc) {
+      sse[cc] += __shfl_xor(sse[cc], off, WAVE);
+      xsq[cc] += __shfl_xor(xsq[cc], off, WAVE);
+    }
+  __syncthreads();  // part may still be read by a previous phase
+  real* rec = s.part + wave * (2 * MP);
+  if (lane < G) {
+#pragma unroll
+    for (int cc = 0; cc < CH; ++cc) {
+      rec[lane * CH + cc] = sse[cc];
+      rec[MP + lane * CH + cc] = xsq[cc];
+    }
+  }
+  __syncthreads();
+  // thread i reads part[i + w*2*MP] and rewrites part[i]: no other thread touches part[i]
+  if (threadIdx.x < 2 * MP) {
+    real acc = s.part[threadIdx.x];
+    for (int w = 1; w < nw; ++w) acc += s.part[w * 2 * MP + threadIdx.x];
+    s.part[threadIdx.x] = acc;
+  }
+  __syncthreads();
+}
+
+// =================================================================================================
+// Kernel 1: one workgroup per matrix, all iterations inside the kernel (batch mode, S == 1).
+// =================================================================================================
+template <typename real, int G, int CH, int K>
+__global__ void __launch_bounds__(HIPNMF_MAXNT) fit_persistent_kernel(SolveArgs<real> a) {
+  using C = Cfg<real, G, CH, K>;
+  constexpr int MP = C::MP;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int nw = blockDim.x / WAVE;
+  Smem<real, G, CH, K> s(smem_raw, nw);
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int wave = threadIdx.x / WAVE;
+  const int g = lane % G;
+  const real* __restrict__ Xb = a.X + (long long)b * a.x_bstride;
+  real* __restrict__ Wb = a.W + (long long)b * a.w_bstride;
+  real* __restrict__ Hb = a.H + (long long)b * K * a.m;
+  const int T = a.T, m = a.m;
+  const int row_end = ((T + WAVE - 1) / WAVE) * WAVE;
+
+  load_h_to_lds(s, Hb, m);
+  __syncthreads();
+  compute_hht(s);
+  __syncthreads();
+  real h[K][CH], hht[K][K];
+  load_h_regs(s, g, h, hht);
+
+  auto residual = [&]() -> real {
+    block_residual<real, G, CH, K>(s, Xb, a.ldx, Wb, a.ldw, T, m, 0, row_end, h);
+    real tot = (real)0;
+    for (int j = 0; j < MP; ++j) tot += s.part[j];
+    return sqrt_(tot);
+  };
+
+  real err0 = (real)0, prev = (real)0;
+  if (a.tol > (real)0) {
+    err0 = residual();
+    prev = err0;
+  }
+  int n_iter = 0;
+  for (int it = 1; it <= a.max_iter; ++it) {
+    n_iter = it;
+    real accA[K][CH], accB[C::NB];
+#pragma unroll
+    for (int c = 0; c < K; ++c)
+#pragma unroll
+      for (int cc = 0; cc < CH; ++cc) accA[c][cc] = (real)0;
+#pragma unroll
+    for (int i = 0; i < C::NB; ++i) accB[i] = (real)0;
+    rows_update_pass<real, G, CH, K>(Xb, a.ldx, Wb, a.ldw, T, m, 0, row_end, h, hht, accA, accB, a.l1w, a.l2w,
+                                     a.update_h != 0);
+    if (a.update_h) {
+      __syncthreads();  // previous readers of part are done
+      wave_reduce_acc<real, G, CH, K>(s.part + wave * C::NACC, accA, accB);
+      __syncthreads();
+      combine_wave_records(s, nw);
+      __syncthreads();
+      h_update_lds(s, m, a.l1h, a.l2h);
+      load_h_regs(s, g, h, hht);
+    }
+    if (a.tol > (real)0 && (it % a.check_every) == 0) {
+      const real err = residual();
+      if ((prev - err) / err0 < a.tol) break;
+      prev = err;
+    }
+  }
+  // reconstruction_err_ (_nmf.py:1628-1630) + per-column SSE / sum X^2 for VAF (analysis.py:654-662)
+  block_residual<real, G, CH, K>(s, Xb, a.ldx, Wb, a.ldw, T, m, 0, row_end, h);
+  if (threadIdx.x == 0) {
+    real tot = (real)0;
+    for (int j = 0; j < MP; ++j) tot += s.part[j];
+    if (a.err_out) a.err_out[b] = sqrt_(tot);
+    if (a.n_iter_out) a.n_iter_out[b] = n_iter;
+  }
+  if (threadIdx.x < m) {
+    if (a.sse_col_out) a.sse_col_out[(long long)b * m + threadIdx.x] = s.part[threadIdx.x];
+    if (a.xsq_col_out) a.xsq_col_out[(long long)b * m + threadIdx.x] = s.part[MP + threadIdx.x];
+  }
+  if (a.update_h) {
+    for (int i = threadIdx.x; i < K * MP; i += blockDim.x) {
+      const int c = i / MP, j = i % MP;
+      if (j < m) Hb[c * m + j] = s.H[i];
+    }
+  }
+}
+
+// =================================================================================================
+// Kernels 2..5: multi-slice path (few matrices / very long T; also the time-sharded building blocks).
+//   grid = (S, B); slice s owns rows [s*rows_per_slice, (s+1)*rows_per_slice)
+// =================================================================================================
+template <typename real, int G, int CH, int K>
+__global__ void __launch_bounds__(HIPNMF_MAXNT) slice_pass_kernel(SolveArgs<real> a) {
+  using C = Cfg<real, G, CH, K>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int nw = blockDim.x / WAVE;
+  Smem<real, G, CH, K> s(smem_raw, nw);
+  const int b = blockIdx.y, sl = blockIdx.x;
+  if (a.state && a.state[(long long)b * 4 + 3] != (real)0) return;  // matrix already converged
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int wave = threadIdx.x / WAVE;
+  const int g = lane % G;
+  const real* __restrict__ Xb = a.X + (long long)b * a.x_bstride;
+  real* __restrict__ Wb = a.W + (long long)b * a.w_bstride;
+  const real* __restrict__ Hb = a.H + (long long)b * K * a.m;
+  const int row_begin = sl * a.rows_per_slice;
+  int row_end = row_begin + a.rows_per_slice;
+  const int t_pad = ((a.T + WAVE - 1) / WAVE) * WAVE;
+  if (row_end > t_pad) row_end = t_pad;
+
+  load_h_to_lds(s, Hb, a.m);
+  __syncthreads();
+  compute_hht(s);
+  __syncthreads();
+  real h[K][CH], hht[K][K];
+  load_h_regs(s, g, h, hht);
+  real accA[K][CH], accB[C::NB];
+#pragma unroll
+  for (int c = 0; c < K; ++c)
+#pragma unroll
+    for (int cc = 0; cc < CH; ++cc) accA[c][cc] = (real)0;
+#pragma unroll
+  for (int i = 0; i < C::NB; ++i) accB[i] = (real)0;
+  rows_update_pass<real, G, CH, K>(Xb, a.ldx, Wb, a.ldw, a.T, a.m, row_begin, row_end, h, hht, accA, accB, a.l1w,
+                                   a.l2w, a.update_h != 0);
+  if (!a.update_h) return;
+  wave_reduce_acc<real, G, CH, K>(s.part + wave * C::NACC, accA, accB);
+  __syncthreads();
+  real* __restrict__ out = a.part + ((long long)b * a.S + sl) * C::NACC;
+  for (int i = threadIdx.x; i < C::NACC; i += blockDim.x) {
+    real acc = s.part[i];
+    for (int w = 1; w < nw; ++w) acc += s.part[w * C::NACC + i];
+    out[i] = acc;
+  }
+}
+
+// sums[b] = [ W^T X (k x m) | W^T W (k x k, full) ] = fixed-order sum of the slice records
+template <typename real, int G, int CH, int K>
+__global__ void reduce_slices_kernel(SolveArgs<real> a) {
+  using C = Cfg<real, G, CH, K>;
+  const int b = blockIdx.x, m = a.m;
+  const real* __restrict__ in = a.part + (long long)b * a.S * C::NACC;
+  real* __restrict__ out = a.sums + (long long)b * (K * m + K * K);
+  for (int i = threadIdx.x; i < K * m + K * K; i += blockDim.x) {
+    int src;
+    if (i < K * m) {
+      src = (i / m) * C::MP + (i % m);
+    } else {
+      int c = (i - K * m) / K, c2 = (i - K * m) % K;
+      if (c > c2) {
+        const int t = c;
+        c = c2;
+        c2 = t;
+      }
+      src = K * C::MP + c * K - c * (c - 1) / 2 + (c2 - c);
+    }
+    real acc = in[src];
+    for (int sl = 1; sl < a.S; ++sl) acc += in[(long long)sl * C::NACC + src];
+    out[i] = acc;
+  }
+}
+
+// H update of matrix b from sums[b] (k*m + k*k); one block per matrix
+template <typename real, int G, int CH, int K>
+__global__ void hupdate_kernel(SolveArgs<real> a) {
+  constexpr int MP = G * CH;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  Smem<real, G, CH, K> s(smem_raw, 1);
+  const int b = blockIdx.x, m = a.m;
+  if (a.state && a.state[(long long)b * 4 + 3] != (real)0) return;
+  real* __restrict__ Hb = a.H + (long long)b * K * m;
+  const real* __restrict__ in = a.sums + (long long)b * (K * m + K * K);
+  load_h_to_lds(s, Hb, m);
+  for (int i = threadIdx.x; i < K * MP; i += blockDim.x) {
+    const int c = i / MP, j = i % MP;
+    s.A[i] = (j < m) ? in[c * m + j] : (real)0;
+  }
+  for (int i = threadIdx.x; i < K * K; i += blockDim.x) s.B[i] = in[K * m + i];
+  __syncthreads();
+  h_update_lds(s, m, a.l1h, a.l2h);
+  for (int i = threadIdx.x; i < K * MP; i += blockDim.x) {
+    const int c = i / MP, j = i % MP;
+    if (j < m) Hb[c * m + j] = s.H[i];
+  }
+}
+
+// per-slice residual partials: colpart[b][s][0..MP) = sse, [MP..2MP) = xsq
+template <typename real, int G, int CH, int K>
+__global__ void __launch_bounds__(HIPNMF_MAXNT) slice_resid_kernel(SolveArgs<real> a) {
+  constexpr int MP = G * CH;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int nw = blockDim.x / WAVE;
+  Smem<real, G, CH, K> s(smem_raw, nw);
+  const int b = blockIdx.y, sl = blockIdx.x;
+  if (a.state && a.state[(long long)b * 4 + 3] != (real)0 && a.it >= 0) return;
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int g = lane % G;
+  const real* __restrict__ Xb = a.X + (long long)b * a.x_bstride;
+  const real* __restrict__ Wb = a.W + (long long)b * a.w_bstride;
+  const real* __restrict__ Hb = a.H + (long long)b * K * a.m;
+  const int row_begin = sl * a.rows_per_slice;
+  int row_end = row_begin + a.rows_per_slice;
+  const int t_pad = ((a.T + WAVE - 1) / WAVE) * WAVE;
+  if (row_end > t_pad) row_end = t_pad;
+  load_h_to_lds(s, Hb, a.m);
+  __syncthreads();
+  real h[K][CH];
+#pragma unroll
+  for (int c = 0; c < K; ++c)
+#pragma unroll
+    for (int cc = 0; cc < CH; ++cc) h[c][cc] = s.H[c * MP + g * CH + cc];
+  block_residual<real, G, CH, K>(s, Xb, a.ldx, Wb, a.ldw, a.T, a.m, row_begin, row_end, h);
+  real* __restrict__ out = a.colpart + ((long long)b * a.S + sl) * (2 * MP);
+  if (threadIdx.x < 2 * MP) out[threadIdx.x] = s.part[threadIdx.x];
+}
+
+// combine slice residuals; a.it < 0: final (write outputs), a.it == 0: error at init, a.it > 0: stop test
+template <typename real, int G, int CH, int K>
+__global__ void resid_finalize_kernel(SolveArgs<real> a) {
+  constexpr int MP = G * CH;
+  __shared__ real col[2 * MP];
+  const int b = blockIdx.x, m = a.m;
+  real* st = a.state ? a.state + (long long)b * 4 : nullptr;
+  if (st && st[3] != (real)0 && a.it >= 0) return;
+  const real* __restrict__ in = a.colpart + (long long)b * a.S * (2 * MP);
+  if (threadIdx.x < 2 * MP) {
+    real acc = in[threadIdx.x];
+    for (int sl = 1; sl < a.S; ++sl) acc += in[(long long)sl * 2 * MP + threadIdx.x];
+    col[threadIdx.x] = acc;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    real tot = (real)0;
+    for (int j = 0; j < MP; ++j) tot += col[j];
+    const real err = sqrt_(tot);
+    if (a.it < 0) {
+      if (a.err_out) a.err_out[b] = err;
+      if (a.n_iter_out && (!st || st[3] == (real)0)) a.n_iter_out[b] = a.max_iter;
+    } else if (a.it == 0) {
+      st[0] = err;
+      st[1] = err;
+      st[2] = err;
+      st[3] = (real)0;
+    } else {
+      st[2] = err;
+      if ((st[1] - err) / st[0] < a.tol) {
+        st[3] = (real)1;
+        if (a.n_iter_out) a.n_iter_out[b] = a.it;
+      }
+      st[1] = err;
+    }
+  }
+  if (a.it < 0 && threadIdx.x < m) {
+    if (a.sse_col_out) a.sse_col_out[(long long)b * m + threadIdx.x] = col[threadIdx.x];
+    if (a.xsq_col_out) a.xsq_col_out[(long long)b * m + threadIdx.x] = col[MP + threadIdx.x];
+  }
+}
+
+// =================================================================================================
+// layout conversion (once per fit, not per iteration)
+// =================================================================================================
+// X row-major [T][ldx_in] -> channel-major [m][ldx_out] (zero padded to ldx_out)
+template <typename real>
+__global__ void x_to_channel_major_kernel(const real* __restrict__ in, long long in_bstride, long long ld_in,
+                                          int in_layout, real* __restrict__ out, long long out_bstride,
+                                          long long ld_out, int T, int m) {
+  __shared__ real tile[32][33];
+  const int b = blockIdx.z;
+  const real* __restrict__ ib = in + (long long)b * in_bstride;
+  real* __restrict__ ob = out + (long long)b * out_bstride;
+  const int t0 = blockIdx.x * 32, j0 = blockIdx.y * 32;
+  if (in_layout == 1) {  // already channel-major: strided copy with padding
+    for (int jj = threadIdx.y; jj < 32; jj += blockDim.y) {
+      const int j = j0 + jj, t = t0 + threadIdx.x;
+      if (j < m && t < ld_out) ob[(long long)j * ld_out + t] = (t < T) ? ib[(long long)j * ld_in + t] : (real)0;
+    }
+    return;
+  }
+  for (int tt = threadIdx.y; tt < 32; tt += blockDim.y) {
+    const int t = t0 + tt, j = j0 + threadIdx.x;
+    tile[tt][threadIdx.x] = (t < T && j < m) ? ib[(long long)t * ld_in + j] : (real)0;
+  }
+  __syncthreads();
+  for (int jj = threadIdx.y; jj < 32; jj += blockDim.y) {
+    const int j = j0 + jj, t = t0 + threadIdx.x;
+    if (j < m && t < ld_out) ob[(long long)j * ld_out + t] = tile[threadIdx.x][jj];
+  }
+}
+
+// W row-major [T][k] <-> component-major [k][ldw]; dir 0: rm -> cm (zero pad), 1: cm -> rm
+template <typename real>
+__global__ void w_convert_kernel(real* __restrict__ rm, real* __restrict__ cm, long long ldw, int T, int k, int dir) {
+  const int b = blockIdx.y;
+  real* __restrict__ r = rm + (long long)b * T * k;
+  real* __restrict__ c = cm + (long long)b * k * ldw;
+  const long long n = (long long)k * ldw;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const int comp = (int)(i / ldw);
+    const long long t = i % ldw;
+    if (dir == 0)
+      c[i] = (t < T) ? r[t * k + comp] : (real)0;
+    else if (t < T)
+      r[t * k + comp] = c[i];
+  }
+}
+
+}  // namespace hipnmf

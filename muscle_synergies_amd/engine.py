@@ -1,0 +1,224 @@
+"""Batched host API of the HIP NMF engine.
+
+``fit_batched`` factorises ``B`` independent non-negative matrices ``X[b] (T x m) ~ W[b] (T x k) H[b] (k x m)``
+with the Lee-Seung multiplicative updates exactly as ``sklearn.decomposition.NMF(solver='mu',
+beta_loss='frobenius', init='custom')`` does for one matrix (``sklearn/decomposition/_nmf.py:731-893``),
+the arithmetic the reference reaches from ``src/muscle_synergies/analysis.py:862-863``.
+
+PyTorch-ROCm is used only as allocator / host-device copier: tensors' ``data_ptr()`` are handed to the
+C ABI of ``libhip_nmf.so``.  No computation of the solver happens in torch or NumPy.
+"""
+
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+
+from . import _lib
+
+
+@dataclass
+class BatchedResult:
+    """Outputs of :func:`fit_batched` (tensors on the compute device unless NumPy went in)."""
+
+    W: "object"  # [B, T, k]   transformed signal (``fit_transform`` output)
+    H: "object"  # [B, k, m]   ``components_``
+    n_iter: "object"  # [B] int32   ``n_iter_``
+    reconstruction_err: "object"  # [B]  ``reconstruction_err_`` = ||X - W H||_F
+    vaf: "object"  # [B, 1 + m]  "All signals" then one per column (analysis.py:661-667)
+    sse_col: "object"  # [B, m]  per-column sum((X - W H)^2)
+    xsq_col: "object"  # [B, m]  per-column sum(X^2)
+    kernel_ms: float  # device time of the solver kernels (HIP events)
+
+
+def _torch():
+    import torch
+
+    return torch
+
+
+def resolve_device(device=None):
+    """``torch.device`` of the GPU to use; fails loudly when there is none."""
+    torch = _torch()
+    if not torch.cuda.is_available():
+        raise _lib.HipNmfError(
+            _lib.HIPNMF_ERR_NO_DEVICE,
+            "no ROCm GPU visible to PyTorch; the HIP NMF engine has no CPU fallback",
+        )
+    if device is None:
+        return torch.device("cuda", torch.cuda.current_device())
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise ValueError(f"device must be a GPU (got {dev})")
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    return dev
+
+
+def _as_device_tensor(a, dev, dtype=None):
+    """NumPy / torch input -> tensor on ``dev`` with strides preserved (dense inputs)."""
+    torch = _torch()
+    if isinstance(a, torch.Tensor):
+        t = a
+    else:
+        arr = np.asarray(a)
+        if any(s < 0 for s in arr.strides):
+            arr = np.ascontiguousarray(arr)
+        t = torch.from_numpy(arr)
+    if dtype is not None and t.dtype != dtype:
+        t = t.to(dtype)
+    if t.device != dev:
+        t = t.to(dev)
+    return t
+
+
+def _x_layout(Xt):
+    """(x_layout, ldx, batch_stride, tensor) for a [B, T, m] tensor; copies only when unavoidable."""
+    B, T, m = Xt.shape
+    sb, st, sm = Xt.stride()
+    if B == 1:
+        sb = T * m if sb == 0 else sb
+    if sm == 1 and st >= m and (B == 1 or sb >= 1):
+        return _lib.X_ROW_MAJOR, st, sb, Xt
+    if st == 1 and sm >= T and (B == 1 or sb >= 1):
+        return _lib.X_CHANNEL_MAJOR, sm, sb, Xt
+    Xc = Xt.contiguous()
+    return _lib.X_ROW_MAJOR, m, T * m, Xc
+
+
+def make_problem(B, T, m, k, *, x_layout, ldx, x_batch_stride, w_layout=_lib.W_ROW_MAJOR, update_H=True,
+                 max_iter=200, tol=1e-4, check_every=10, l1_reg_W=0.0, l1_reg_H=0.0, l2_reg_W=0.0,
+                 l2_reg_H=0.0) -> _lib.Problem:
+    p = _lib.Problem()
+    p.struct_size = ctypes.sizeof(_lib.Problem)
+    p.batch, p.n_samples, p.n_features, p.n_components = int(B), int(T), int(m), int(k)
+    p.x_layout, p.update_h, p.w_layout, p.reserved0 = int(x_layout), int(bool(update_H)), int(w_layout), 0
+    p.ldx, p.x_batch_stride = int(ldx), int(x_batch_stride)
+    p.max_iter, p.check_every, p.tol = int(max_iter), int(check_every), float(tol)
+    p.l1_reg_W, p.l1_reg_H = float(l1_reg_W), float(l1_reg_H)
+    p.l2_reg_W, p.l2_reg_H = float(l2_reg_W), float(l2_reg_H)
+    return p
+
+
+def fit_batched(X, W0, H0, *, max_iter: int = 200, tol: float = 1e-4, check_every: int = 10,
+                update_H: bool = True, l1_reg_W: float = 0.0, l1_reg_H: float = 0.0, l2_reg_W: float = 0.0,
+                l2_reg_H: float = 0.0, device=None, handle: Optional[_lib.Handle] = None,
+                return_numpy: Optional[bool] = None, overwrite_init: bool = False) -> BatchedResult:
+    """Factorise a batch of matrices on one GPU.
+
+    Args:
+        X: ``[B, T, m]`` (or ``[T, m]``) non-negative float32/float64, NumPy or torch, any dense layout
+           (C order = row-major; a transposed view of a ``[B, m, T]`` array = channel-major, the
+           engine's native streaming layout and what ``DataFrame.to_numpy()`` produces).
+        W0: ``[B, T, k]`` initial activations; H0: ``[B, k, m]`` initial synergies (``init='custom'``).
+        max_iter, tol: as ``sklearn.decomposition.NMF``; ``tol=0`` runs exactly ``max_iter`` updates.
+        update_H: ``False`` keeps H fixed (``NMF.transform``).
+        overwrite_init: let the solver update contiguous device tensors ``W0``/``H0`` in place (no copy).
+    """
+    torch = _torch()
+    dev = resolve_device(device)
+    was_numpy = not isinstance(X, torch.Tensor)
+    if return_numpy is None:
+        return_numpy = was_numpy
+    Xt = _as_device_tensor(X, dev)
+    if Xt.dim() == 2:
+        Xt = Xt.unsqueeze(0)
+    if Xt.dim() != 3:
+        raise ValueError(f"X must be [B, T, m] or [T, m], got shape {tuple(Xt.shape)}")
+    if Xt.dtype not in (torch.float32, torch.float64):
+        raise TypeError(f"X must be float32 or float64, got {Xt.dtype}")
+    B, T, m = Xt.shape
+    if B == 0 or T == 0 or m == 0:
+        raise ValueError("empty input")
+    Wt = _as_device_tensor(W0, dev, Xt.dtype)
+    Ht = _as_device_tensor(H0, dev, Xt.dtype)
+    if Wt.dim() == 2:
+        Wt = Wt.unsqueeze(0)
+    if Ht.dim() == 2:
+        Ht = Ht.unsqueeze(0)
+    k = Ht.shape[1]
+    if tuple(Wt.shape) != (B, T, k) or tuple(Ht.shape) != (B, k, m):
+        raise ValueError(f"W0 must be [{B}, {T}, k] and H0 [{B}, k, {m}]; got {tuple(Wt.shape)} and {tuple(Ht.shape)}")
+    # W and H are in/out in the C ABI: work on private contiguous copies unless told otherwise
+    def private(t, src):
+        if isinstance(src, torch.Tensor) and not overwrite_init:
+            return t.clone(memory_format=torch.contiguous_format)
+        return t.contiguous()
+
+    Wt = private(Wt, W0)
+    Ht = private(Ht, H0)
+    x_layout, ldx, xbs, Xt = _x_layout(Xt)
+
+    p = make_problem(B, T, m, k, x_layout=x_layout, ldx=ldx, x_batch_stride=xbs, update_H=update_H,
+                     max_iter=max_iter, tol=tol, check_every=check_every, l1_reg_W=l1_reg_W, l1_reg_H=l1_reg_H,
+                     l2_reg_W=l2_reg_W, l2_reg_H=l2_reg_H)
+    err = torch.empty((B,), dtype=Xt.dtype, device=dev)
+    n_iter = torch.empty((B,), dtype=torch.int32, device=dev)
+    sse = torch.empty((B, m), dtype=Xt.dtype, device=dev)
+    xsq = torch.empty((B, m), dtype=Xt.dtype, device=dev)
+    h = handle if handle is not None else _lib.get_handle(dev.index)
+    lib = _lib.load()
+    fn = lib.hipnmf_fit_batched_f32 if Xt.dtype == torch.float32 else lib.hipnmf_fit_batched_f64
+    torch.cuda.synchronize(dev)  # inputs were produced on torch's stream; the handle has its own
+    _lib.check(fn(h.ptr, ctypes.byref(p), Xt.data_ptr(), Wt.data_ptr(), Ht.data_ptr(), err.data_ptr(),
+                  n_iter.data_ptr(), sse.data_ptr(), xsq.data_ptr()))
+    vaf = torch.cat([(1 - sse.sum(dim=1) / xsq.sum(dim=1)).unsqueeze(1), 1 - sse / xsq], dim=1)
+    res = BatchedResult(Wt, Ht, n_iter, err, vaf, sse, xsq, h.last_kernel_ms())
+    if return_numpy:
+        res = BatchedResult(*(t.cpu().numpy() for t in (Wt, Ht, n_iter, err, vaf, sse, xsq)), res.kernel_ms)
+    return res
+
+
+def fit_batched_multi_gpu(X, W0, H0, *, devices=None, **kw) -> BatchedResult:
+    """Scatter a host-resident batch over the GPUs of this process (contiguous slices, one host thread and
+    one handle per device, no collectives: every factorisation is independent).  Inputs are NumPy arrays;
+    outputs are NumPy arrays in batch order.  The multi-process flavour (one rank per GPU under
+    ``torch.distributed.run``) lives in ``bench.py``."""
+    import threading
+
+    torch = _torch()
+    n_dev = torch.cuda.device_count()
+    if n_dev < 1:
+        raise _lib.HipNmfError(_lib.HIPNMF_ERR_NO_DEVICE, "no ROCm GPU visible; no CPU fallback")
+    devices = list(range(n_dev)) if devices is None else list(devices)
+    X = np.asarray(X)
+    B = X.shape[0]
+    bounds = partition(B, len(devices))
+    results: list = [None] * len(devices)
+    errors: list = []
+
+    def work(i):
+        lo, hi = bounds[i]
+        if hi <= lo:
+            return
+        try:
+            results[i] = fit_batched(X[lo:hi], W0[lo:hi], H0[lo:hi], device=f"cuda:{devices[i]}",
+                                     return_numpy=True, **kw)
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(devices))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        raise errors[0]
+    parts = [r for r in results if r is not None]
+    cat = lambda name: np.concatenate([getattr(r, name) for r in parts], axis=0)  # noqa: E731
+    return BatchedResult(cat("W"), cat("H"), cat("n_iter"), cat("reconstruction_err"), cat("vaf"),
+                         cat("sse_col"), cat("xsq_col"), max(r.kernel_ms for r in parts))
+
+
+def partition(n_items: int, n_parts: int):
+    """Contiguous, balanced ``[lo, hi)`` ranges (first ``n_items % n_parts`` parts get one extra)."""
+    base, extra = divmod(int(n_items), int(n_parts))
+    out, lo = [], 0
+    for i in range(n_parts):
+        hi = lo + base + (1 if i < extra else 0)
+        out.append((lo, hi))
+        lo = hi
+    return out

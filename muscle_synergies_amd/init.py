@@ -1,0 +1,135 @@
+"""Host-side initialisation of W and H (not part of the hot loop).
+
+``find_synergies`` never passes ``init`` unless the user does, so the reference's default path is
+sklearn's ``_initialize_nmf`` with ``init=None`` -> NNDSVDa (``sklearn/decomposition/_nmf.py:221-373``)
+on top of a randomized SVD (``sklearn/utils/extmath.py:287-372, 531-605, 895-953``).  This module
+implements those published algorithms with NumPy/SciPy so that the product does not depend on
+sklearn's private API; drawing from the same ``RandomState`` in the same order makes the result match
+sklearn's for a given ``random_state`` (checked in ``tests/test_init.py`` against fixtures captured
+from sklearn 1.7.2).
+"""
+
+from __future__ import annotations
+
+import numbers
+
+import numpy as np
+from scipy import linalg
+
+
+def check_random_state(seed):
+    """None -> the global RandomState, int -> a fresh one, RandomState -> itself."""
+    if seed is None or seed is np.random:
+        return np.random.mtrand._rand
+    if isinstance(seed, numbers.Integral):
+        return np.random.RandomState(seed)
+    if isinstance(seed, np.random.RandomState):
+        return seed
+    raise ValueError(f"{seed!r} cannot be used to seed a numpy.random.RandomState instance")
+
+
+def _norm(x):
+    """Dot-product based Euclidean norm (``_nmf.py:42-50``)."""
+    x = np.ravel(x)
+    return np.sqrt(np.dot(x, x))
+
+
+def _svd_flip_u(u, v):
+    """Sign convention on the columns of u (``extmath.py:895-953``, u_based_decision=True)."""
+    idx = np.argmax(np.abs(u.T), axis=1)
+    signs = np.sign(u.T[np.arange(u.shape[1]), idx])
+    u *= signs[np.newaxis, :]
+    v *= signs[:, np.newaxis]
+    return u, v
+
+
+def _svd_flip_v(u, v):
+    idx = np.argmax(np.abs(v), axis=1)
+    signs = np.sign(v[np.arange(v.shape[0]), idx])
+    u *= signs[np.newaxis, :]
+    v *= signs[:, np.newaxis]
+    return u, v
+
+
+def randomized_svd(M, n_components, random_state, n_oversamples=10):
+    """Halko et al. randomized SVD as configured by ``_initialize_nmf`` (all defaults)."""
+    rng = check_random_state(random_state)
+    n_random = n_components + n_oversamples
+    n_samples, n_features = M.shape
+    n_iter = 7 if n_components < 0.1 * min(M.shape) else 4
+    transpose = n_samples < n_features
+    A = M.T if transpose else M
+    Q = rng.normal(size=(A.shape[1], n_random)).astype(A.dtype, copy=False)
+    for _ in range(n_iter):  # LU-normalised power iterations (n_iter > 2)
+        Q, _ = linalg.lu(A @ Q, permute_l=True, check_finite=False)
+        Q, _ = linalg.lu(A.T @ Q, permute_l=True, check_finite=False)
+    Q, _ = linalg.qr(A @ Q, mode="economic", check_finite=False)
+    B = Q.T @ A
+    Uhat, s, Vt = linalg.svd(B, full_matrices=False, lapack_driver="gesdd")
+    U = Q @ Uhat
+    if not transpose:
+        U, Vt = _svd_flip_u(U, Vt)
+        return U[:, :n_components], s[:n_components], Vt[:n_components, :]
+    U, Vt = _svd_flip_v(U, Vt)
+    return Vt[:n_components, :].T, s[:n_components], U[:, :n_components].T
+
+
+def initialize_nmf(X, n_components, init=None, eps=1e-6, random_state=None):
+    """W0 (T x k), H0 (k x m) in ``X.dtype``; same options and error messages as sklearn."""
+    X = np.asarray(X)
+    if (X < 0).any():
+        raise ValueError("Negative values in data passed to NMF initialization.")
+    n_samples, n_features = X.shape
+    if init is not None and init != "random" and n_components > min(n_samples, n_features):
+        raise ValueError(
+            "init = '{}' can only be used when n_components <= min(n_samples, n_features)".format(init)
+        )
+    if init is None:
+        init = "nndsvda" if n_components <= min(n_samples, n_features) else "random"
+
+    if init == "random":
+        avg = np.sqrt(X.mean() / n_components)
+        rng = check_random_state(random_state)
+        H = avg * rng.standard_normal(size=(n_components, n_features)).astype(X.dtype, copy=False)
+        W = avg * rng.standard_normal(size=(n_samples, n_components)).astype(X.dtype, copy=False)
+        np.abs(H, out=H)
+        np.abs(W, out=W)
+        return W, H
+
+    if init not in ("nndsvd", "nndsvda", "nndsvdar"):
+        raise ValueError(
+            "Invalid init parameter: got %r instead of one of %r"
+            % (init, (None, "random", "nndsvd", "nndsvda", "nndsvdar"))
+        )
+
+    U, S, V = randomized_svd(X, n_components, random_state)
+    W = np.zeros_like(U)
+    H = np.zeros_like(V)
+    W[:, 0] = np.sqrt(S[0]) * np.abs(U[:, 0])
+    H[0, :] = np.sqrt(S[0]) * np.abs(V[0, :])
+    for j in range(1, n_components):  # Boutsidis & Gallopoulos split of the +/- parts
+        x, y = U[:, j], V[j, :]
+        x_p, y_p = np.maximum(x, 0), np.maximum(y, 0)
+        x_n, y_n = np.abs(np.minimum(x, 0)), np.abs(np.minimum(y, 0))
+        x_p_nrm, y_p_nrm = _norm(x_p), _norm(y_p)
+        x_n_nrm, y_n_nrm = _norm(x_n), _norm(y_n)
+        m_p, m_n = x_p_nrm * y_p_nrm, x_n_nrm * y_n_nrm
+        if m_p > m_n:
+            u, v, sigma = x_p / x_p_nrm, y_p / y_p_nrm, m_p
+        else:
+            u, v, sigma = x_n / x_n_nrm, y_n / y_n_nrm, m_n
+        lbd = np.sqrt(S[j] * sigma)
+        W[:, j] = lbd * u
+        H[j, :] = lbd * v
+    W[W < eps] = 0
+    H[H < eps] = 0
+    if init == "nndsvda":
+        avg = X.mean()
+        W[W == 0] = avg
+        H[H == 0] = avg
+    elif init == "nndsvdar":
+        rng = check_random_state(random_state)
+        avg = X.mean()
+        W[W == 0] = abs(avg * rng.standard_normal(size=len(W[W == 0])) / 100)
+        H[H == 0] = abs(avg * rng.standard_normal(size=len(H[H == 0])) / 100)
+    return W, H

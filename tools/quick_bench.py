@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Quick throughput probe of the batched fit (development aid, not the contract bench)."""
+import argparse, sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import muscle_synergies_amd as ms
+from muscle_synergies_amd import _lib
+from muscle_synergies_amd.synth import emg_batch_torch
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=1024)
+ap.add_argument("--T", type=int, default=10000)
+ap.add_argument("--iters", type=int, default=100)
+ap.add_argument("--threads", type=int, nargs="*", default=[256, 512])
+ap.add_argument("--variant", type=int, default=0)
+ap.add_argument("--reps", type=int, default=2)
+a = ap.parse_args()
+X, W0, H0 = emg_batch_torch(a.batch, T=a.T, device="cuda:0")
+Xv = X.transpose(1, 2)  # [B, T, m] view of channel-major storage
+h = _lib.get_handle(0)
+for nt in a.threads:
+    h.set_tuning(nt, 0, a.variant)
+    for rep in range(a.reps):
+        t0 = time.perf_counter()
+        r = ms.fit_batched(Xv, W0, H0, max_iter=a.iters, tol=0.0)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        its = a.batch * a.iters / (r.kernel_ms * 1e-3)
+        gbs = its * 4 * a.T * 26 / 1e9
+        print(f"threads={nt} rep={rep} wall={dt*1e3:.1f} ms kernel={r.kernel_ms:.1f} ms  {its/1e6:.3f} M matrix-it/s  {gbs:.0f} GB/s algorithmic  err0={float(r.reconstruction_err[0]):.4f}", flush=True)
