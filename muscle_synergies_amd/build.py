@@ -23,8 +23,10 @@ LIB = os.path.join(LIBDIR, "libhip_nmf.so")
 INCLUDE = os.path.join(os.path.dirname(PKG), "include")
 
 ARCH = "gfx950"
-CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
-            "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
+# -fno-slp-vectorize: hipcc otherwise packs the fp32 FMAs into v_pk_fma_f32 plus v_mov shuffles, which costs
+# ~40 VGPRs and measured 14 % slower on MI355X (profiles/README.md, round 1).
+CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-slp-vectorize", "-Wall",
+            "-Wno-unused-function", "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
 
 
 def _hipcc() -> str:
@@ -51,8 +53,8 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def _compile(src: str, extra) -> str:
-    obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
+def _compile(src: str, extra, objdir: str = OBJ) -> str:
+    obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
     cmd = [_hipcc(), *CXXFLAGS, *extra, "-I", CSRC, "-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
@@ -60,34 +62,40 @@ def _compile(src: str, extra) -> str:
     return obj
 
 
-def build(force: bool = False, jobs: int | None = None, extra_flags=(), verbose: bool = False) -> str:
-    os.makedirs(OBJ, exist_ok=True)
+def build(force: bool = False, jobs: int | None = None, extra_flags=(), verbose: bool = False,
+          variant: str | None = None) -> str:
+    """Build the library.  ``variant`` (development aid) builds ``libhip_nmf_<variant>.so`` with
+    ``extra_flags`` in its own object directory; select it at run time with ``HIPNMF_LIBRARY``."""
+    objdir = OBJ if not variant else os.path.join(CSRC, "_build_" + variant)
+    lib = LIB if not variant else os.path.join(LIBDIR, f"libhip_nmf_{variant}.so")
+    os.makedirs(objdir, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
     hdrs = headers()
     srcs = sources()
     todo = [s for s in srcs
-            if force or _stale(os.path.join(OBJ, os.path.basename(s)[:-4] + ".o"), [s, *hdrs])]
+            if force or _stale(os.path.join(objdir, os.path.basename(s)[:-4] + ".o"), [s, *hdrs])]
     jobs = jobs or min(8, os.cpu_count() or 1)
     if todo:
         if verbose:
             print(f"[build] compiling {len(todo)} translation unit(s) for {ARCH} with {jobs} job(s)", flush=True)
         with ThreadPoolExecutor(max_workers=jobs) as ex:
-            list(ex.map(lambda s: _compile(s, list(extra_flags)), todo))
-    objs = [os.path.join(OBJ, os.path.basename(s)[:-4] + ".o") for s in srcs]
-    if todo or _stale(LIB, objs):
-        cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", LIB]
+            list(ex.map(lambda s: _compile(s, list(extra_flags), objdir), todo))
+    objs = [os.path.join(objdir, os.path.basename(s)[:-4] + ".o") for s in srcs]
+    if todo or _stale(lib, objs):
+        cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", lib]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
         if verbose:
-            print(f"[build] linked {LIB}", flush=True)
-    return LIB
+            print(f"[build] linked {lib}", flush=True)
+    return lib
 
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--force", action="store_true")
     ap.add_argument("--jobs", type=int, default=None)
-    ap.add_argument("--flag", action="append", default=[])
+    ap.add_argument("--flag", action="append", default=[], help="extra hipcc flag (repeatable), e.g. --flag=-DHIPNMF_PF=3")
+    ap.add_argument("--variant", default=None, help="build lib/libhip_nmf_<variant>.so instead of the default library")
     a = ap.parse_args()
-    print(build(force=a.force, jobs=a.jobs, extra_flags=a.flag, verbose=True))
+    print(build(force=a.force, jobs=a.jobs, extra_flags=a.flag, verbose=True, variant=a.variant))

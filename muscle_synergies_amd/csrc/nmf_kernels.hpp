@@ -27,6 +27,11 @@ constexpr int WAVE = 64;
 #ifndef HIPNMF_MAXNT
 #define HIPNMF_MAXNT 512
 #endif
+#ifndef HIPNMF_WAVES_PER_EU
+#define HIPNMF_OCC
+#else
+#define HIPNMF_OCC __attribute__((amdgpu_waves_per_eu(HIPNMF_WAVES_PER_EU)))
+#endif
 
 // EPSILON = np.finfo(np.float32).eps for fp32 *and* fp64 (_nmf.py:39)
 template <typename real>
@@ -105,16 +110,49 @@ __device__ __forceinline__ real uniform(real v) {  // wave-uniform value -> SGPR
 }
 
 // ------------------------------------------------------------------------------------------------
-// vector load of N consecutive elements (N * sizeof(real) aligned)
+// Buffer-resource (SRD) memory access: 32-bit per-lane offsets, base in SGPRs, and hardware range
+// checking -- a lane whose offset is >= num_records reads 0 / drops its store, so ragged tails and
+// padded channels need no branches around the loads (branches serialise them: one vmcnt(0) per load).
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+constexpr unsigned OOB = 0x80000000u;  // > any valid offset: matrices are limited to < 2 GiB each
+
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+
 template <typename real, int N>
-struct alignas(sizeof(real) * N <= 16 ? sizeof(real) * N : 16) VecN {
-  real v[N];
-};
-template <typename real, int N>
-__device__ __forceinline__ void load_vec(const real* __restrict__ p, real (&out)[N]) {
-  const VecN<real, N> t = *reinterpret_cast<const VecN<real, N>*>(p);
-#pragma unroll
-  for (int i = 0; i < N; ++i) out[i] = t.v[i];
+__device__ __forceinline__ void buf_load(rsrc_t r, unsigned voff, unsigned soff, real (&out)[N]) {
+  constexpr int BYTES = (int)sizeof(real) * N;
+  static_assert(BYTES == 4 || BYTES == 8 || BYTES == 16 || BYTES == 32, "unsupported vector width");
+  if constexpr (BYTES == 4) {
+    const unsigned v = __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0);
+    __builtin_memcpy(&out, &v, 4);
+  } else if constexpr (BYTES == 8) {
+    const auto v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    __builtin_memcpy(&out, &v, 8);
+  } else if constexpr (BYTES == 16) {
+    const auto v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    __builtin_memcpy(&out, &v, 16);
+  } else {
+    const auto v0 = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    const auto v1 = __builtin_amdgcn_raw_buffer_load_b128(r, voff + 16u, soff, 0);
+    __builtin_memcpy(&out, &v0, 16);
+    __builtin_memcpy(reinterpret_cast<char*>(&out) + 16, &v1, 16);
+  }
+}
+
+template <typename real>
+__device__ __forceinline__ void buf_store(rsrc_t r, unsigned voff, unsigned soff, real v) {
+  if constexpr (sizeof(real) == 4) {
+    unsigned u;
+    __builtin_memcpy(&u, &v, 4);
+    __builtin_amdgcn_raw_buffer_store_b32(u, r, voff, soff, 0);
+  } else {
+    using u32x2 = unsigned int __attribute__((ext_vector_type(2)));
+    u32x2 u;
+    __builtin_memcpy(&u, &v, 8);
+    __builtin_amdgcn_raw_buffer_store_b64(u, r, voff, soff, 0);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -151,35 +189,57 @@ struct RowTile {
   real w[K];
 };
 
-// rows [row_grp, row_grp+G) of the group; lane_row = row owned by this lane
+// Per-lane addressing state of one matrix (loop invariant): X is channel-major, W component-major.
+//   X element (row t, channel j)  at byte  (j*ldx + t) * sizeof(real)
+//   W element (row t, component c) at byte (c*ldw + t) * sizeof(real)
+// The wave-uniform row base goes into the SGPR offset, the lane part into the VGPR offset.
 template <typename real, int G, int CH, int K>
-__device__ __forceinline__ void load_tile(RowTile<real, G, CH, K>& t, const real* __restrict__ Xb, long long ldx,
-                                          const real* __restrict__ Wb, long long ldw, int T, int m, int row_grp,
-                                          int g, int lane_row) {
-  if (row_grp < T) {
+struct MatAddr {
+  rsrc_t xr, wr;
+  unsigned xoff[CH];  // (channel*ldx + lane's group row) * sizeof(real), or OOB for padded channels
+  unsigned woff;      // lane * sizeof(real)
+  unsigned ldw_b;     // ldw * sizeof(real)
+  int T, lane, g;
+  __device__ __forceinline__ MatAddr(const real* Xb, long long ldx, const real* Wb, long long ldw, int T_, int m) {
+    lane = threadIdx.x & (WAVE - 1);
+    g = lane % G;
+    T = T_;
+    xr = make_rsrc(Xb, (unsigned)((long long)m * ldx * (long long)sizeof(real)));
+    wr = make_rsrc(Wb, (unsigned)((long long)K * ldw * (long long)sizeof(real)));
 #pragma unroll
     for (int cc = 0; cc < CH; ++cc) {
       const int j = g * CH + cc;
-      if (j < m) {
-        load_vec<real, G>(Xb + (long long)j * ldx + row_grp, t.x[cc]);
-      } else {
-#pragma unroll
-        for (int r = 0; r < G; ++r) t.x[cc][r] = (real)0;
-      }
+      xoff[cc] = (j < m) ? (unsigned)(((long long)j * ldx + (lane - g)) * (long long)sizeof(real)) : OOB;
     }
-  } else {
-#pragma unroll
-    for (int cc = 0; cc < CH; ++cc)
-#pragma unroll
-      for (int r = 0; r < G; ++r) t.x[cc][r] = (real)0;
+    woff = (unsigned)(lane * (int)sizeof(real));
+    ldw_b = (unsigned)(ldw * (long long)sizeof(real));
   }
-  if (lane_row < T) {
+};
+
+// tile of the wave-step starting at row wbase (wave-uniform); rows >= T read as zero
+template <typename real, int G, int CH, int K>
+__device__ __forceinline__ void load_tile(RowTile<real, G, CH, K>& t, const MatAddr<real, G, CH, K>& ma, int wbase,
+                                          bool in_range) {
+  const unsigned sbase = (unsigned)wbase * (unsigned)sizeof(real);
+  const bool grp_ok = in_range && (wbase + (ma.lane - ma.g) < ma.T);
+  const bool row_ok = in_range && (wbase + ma.lane < ma.T);
 #pragma unroll
-    for (int c = 0; c < K; ++c) t.w[c] = Wb[(long long)c * ldw + lane_row];
-  } else {
+  for (int cc = 0; cc < CH; ++cc) buf_load<real, G>(ma.xr, grp_ok ? ma.xoff[cc] : OOB, sbase, t.x[cc]);
+  const unsigned wv = row_ok ? ma.woff : OOB;
 #pragma unroll
-    for (int c = 0; c < K; ++c) t.w[c] = (real)0;
+  for (int c = 0; c < K; ++c) {
+    real tmp[1];
+    buf_load<real, 1>(ma.wr, wv, sbase + (unsigned)c * ma.ldw_b, tmp);
+    t.w[c] = tmp[0];
   }
+}
+
+template <typename real, int G, int CH, int K>
+__device__ __forceinline__ void store_w(const RowTile<real, G, CH, K>& t, const MatAddr<real, G, CH, K>& ma, int wbase) {
+  const unsigned sbase = (unsigned)wbase * (unsigned)sizeof(real);
+  const unsigned wv = (wbase + ma.lane < ma.T) ? ma.woff : OOB;
+#pragma unroll
+  for (int c = 0; c < K; ++c) buf_store<real>(ma.wr, wv, sbase + (unsigned)c * ma.ldw_b, t.w[c]);
 }
 
 // reduce-scatter of pn[G][K] over the G lanes of a group: afterwards pn[0][*] of lane g = sum over the
@@ -335,61 +395,59 @@ __device__ __forceinline__ void load_h_regs(const Smem<real, G, CH, K>& s, int g
     for (int c2 = 0; c2 < K; ++c2) hht[c][c2] = uniform(s.HHt[c * K + c2]);
 }
 
-// streaming pass over rows [row_begin, row_end) (row_begin % 64 == 0): W update + accumulation
+// streaming pass over rows [row_begin, row_end) (row_begin % 64 == 0): W update + accumulation.
+// Software pipeline: PF tiles per wave are in flight (loads issued PF-1 steps ahead of their use).
+#ifndef HIPNMF_PF
+#define HIPNMF_PF 2
+#endif
 template <typename real, int G, int CH, int K>
-__device__ __forceinline__ void rows_update_pass(const real* __restrict__ Xb, long long ldx, real* __restrict__ Wb,
-                                                 long long ldw, int T, int m, int row_begin, int row_end,
+__device__ __forceinline__ void rows_update_pass(const MatAddr<real, G, CH, K>& ma, int row_begin, int row_end,
                                                  const real (&h)[K][CH], const real (&hht)[K][K],
                                                  real (&accA)[K][CH], real (&accB)[Cfg<real, G, CH, K>::NB], real l1w,
                                                  real l2w, bool update_h) {
-  const int lane = threadIdx.x & (WAVE - 1);
+  constexpr int PF = HIPNMF_PF;
   const int wave = threadIdx.x / WAVE;
-  const int nw = blockDim.x / WAVE;
-  const int g = lane % G;
-  const int stride = nw * WAVE;
+  const int stride = (blockDim.x / WAVE) * WAVE;
   int wbase = row_begin + wave * WAVE;  // wave-uniform
   if (wbase >= row_end) return;
-  RowTile<real, G, CH, K> ta, tb;
-  load_tile<real, G, CH, K>(ta, Xb, ldx, Wb, ldw, T, m, wbase + (lane - g), g, wbase + lane);
-  while (true) {
-    {
-      const int nb = wbase + stride;
-      if (nb < row_end) load_tile<real, G, CH, K>(tb, Xb, ldx, Wb, ldw, T, m, nb + (lane - g), g, nb + lane);
-      update_tile<real, G, CH, K>(ta, h, hht, accA, accB, g, l1w, l2w, update_h);
-      if (wbase + lane < T) {
+  RowTile<real, G, CH, K> tiles[PF];
 #pragma unroll
-        for (int c = 0; c < K; ++c) Wb[(long long)c * ldw + wbase + lane] = ta.w[c];
-      }
-      wbase = nb;
-      if (wbase >= row_end) break;
-    }
-    {
-      const int nb = wbase + stride;
-      if (nb < row_end) load_tile<real, G, CH, K>(ta, Xb, ldx, Wb, ldw, T, m, nb + (lane - g), g, nb + lane);
-      update_tile<real, G, CH, K>(tb, h, hht, accA, accB, g, l1w, l2w, update_h);
-      if (wbase + lane < T) {
+  for (int p = 0; p < PF; ++p) load_tile<real, G, CH, K>(tiles[p], ma, wbase + p * stride, wbase + p * stride < row_end);
+  bool more = true;
+  while (more) {
 #pragma unroll
-        for (int c = 0; c < K; ++c) Wb[(long long)c * ldw + wbase + lane] = tb.w[c];
+    for (int p = 0; p < PF; ++p) {
+      if (more) {
+        update_tile<real, G, CH, K>(tiles[p], h, hht, accA, accB, ma.g, l1w, l2w, update_h);
+        store_w<real, G, CH, K>(tiles[p], ma, wbase);
+        const int nb = wbase + PF * stride;
+        load_tile<real, G, CH, K>(tiles[p], ma, nb, nb < row_end);
+        wbase += stride;
+        more = wbase < row_end;
+        __builtin_amdgcn_sched_barrier(0);  // keep the tiles' arithmetic from being interleaved (VGPR pressure)
       }
-      wbase = nb;
-      if (wbase >= row_end) break;
     }
   }
 }
 
 template <typename real, int G, int CH, int K>
-__device__ __forceinline__ void rows_resid_pass(const real* __restrict__ Xb, long long ldx, const real* __restrict__ Wb,
-                                                long long ldw, int T, int m, int row_begin, int row_end,
+__device__ __forceinline__ void rows_resid_pass(const MatAddr<real, G, CH, K>& ma, int row_begin, int row_end,
                                                 const real (&h)[K][CH], real (&sse)[CH], real (&xsq)[CH]) {
-  const int lane = threadIdx.x & (WAVE - 1);
   const int wave = threadIdx.x / WAVE;
-  const int nw = blockDim.x / WAVE;
-  const int g = lane % G;
-  const int stride = nw * WAVE;
-  for (int wbase = row_begin + wave * WAVE; wbase < row_end; wbase += stride) {
-    RowTile<real, G, CH, K> t;
-    load_tile<real, G, CH, K>(t, Xb, ldx, Wb, ldw, T, m, wbase + (lane - g), g, wbase + lane);
-    resid_tile<real, G, CH, K>(t, h, sse, xsq);
+  const int stride = (blockDim.x / WAVE) * WAVE;
+  int wbase = row_begin + wave * WAVE;
+  if (wbase >= row_end) return;
+  RowTile<real, G, CH, K> ta, tb;
+  load_tile<real, G, CH, K>(ta, ma, wbase, true);
+  while (true) {
+    load_tile<real, G, CH, K>(tb, ma, wbase + stride, wbase + stride < row_end);
+    resid_tile<real, G, CH, K>(ta, h, sse, xsq);
+    wbase += stride;
+    if (wbase >= row_end) break;
+    load_tile<real, G, CH, K>(ta, ma, wbase + stride, wbase + stride < row_end);
+    resid_tile<real, G, CH, K>(tb, h, sse, xsq);
+    wbase += stride;
+    if (wbase >= row_end) break;
   }
 }
 
@@ -475,8 +533,7 @@ __device__ __forceinline__ void combine_wave_records(Smem<real, G, CH, K>& s, in
 // block-wide residual over rows [row_begin,row_end): returns per-column sse/xsq in LDS part[0 .. 2*MP)
 // (sums over the block's waves, fixed order).  Barriers inside.
 template <typename real, int G, int CH, int K>
-__device__ __forceinline__ void block_residual(Smem<real, G, CH, K>& s, const real* __restrict__ Xb, long long ldx,
-                                               const real* __restrict__ Wb, long long ldw, int T, int m, int row_begin,
+__device__ __forceinline__ void block_residual(Smem<real, G, CH, K>& s, const MatAddr<real, G, CH, K>& ma, int row_begin,
                                                int row_end, const real (&h)[K][CH]) {
   constexpr int MP = G * CH;
   const int lane = threadIdx.x & (WAVE - 1);
@@ -485,7 +542,7 @@ __device__ __forceinline__ void block_residual(Smem<real, G, CH, K>& s, const re
   real sse[CH], xsq[CH];
 #pragma unroll
   for (int cc = 0; cc < CH; ++cc) sse[cc] = xsq[cc] = (real)0;
-  rows_resid_pass<real, G, CH, K>(Xb, ldx, Wb, ldw, T, m, row_begin, row_end, h, sse, xsq);
+  rows_resid_pass<real, G, CH, K>(ma, row_begin, row_end, h, sse, xsq);
 #pragma unroll
   for (int off = G; off < WAVE; off <<= 1)
 #pragma unroll
@@ -516,7 +573,7 @@ __device__ __forceinline__ void block_residual(Smem<real, G, CH, K>& s, const re
 // Kernel 1: one workgroup per matrix, all iterations inside the kernel (batch mode, S == 1).
 // =================================================================================================
 template <typename real, int G, int CH, int K>
-__global__ void __launch_bounds__(HIPNMF_MAXNT) fit_persistent_kernel(SolveArgs<real> a) {
+__global__ void __launch_bounds__(HIPNMF_MAXNT) HIPNMF_OCC fit_persistent_kernel(SolveArgs<real> a) {
   using C = Cfg<real, G, CH, K>;
   constexpr int MP = C::MP;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -531,6 +588,7 @@ __global__ void __launch_bounds__(HIPNMF_MAXNT) fit_persistent_kernel(SolveArgs<
   real* __restrict__ Hb = a.H + (long long)b * K * a.m;
   const int T = a.T, m = a.m;
   const int row_end = ((T + WAVE - 1) / WAVE) * WAVE;
+  const MatAddr<real, G, CH, K> ma(Xb, a.ldx, Wb, a.ldw, T, m);
 
   load_h_to_lds(s, Hb, m);
   __syncthreads();
@@ -540,7 +598,7 @@ __global__ void __launch_bounds__(HIPNMF_MAXNT) fit_persistent_kernel(SolveArgs<
   load_h_regs(s, g, h, hht);
 
   auto residual = [&]() -> real {
-    block_residual<real, G, CH, K>(s, Xb, a.ldx, Wb, a.ldw, T, m, 0, row_end, h);
+    block_residual<real, G, CH, K>(s, ma, 0, row_end, h);
     real tot = (real)0;
     for (int j = 0; j < MP; ++j) tot += s.part[j];
     return sqrt_(tot);
@@ -561,8 +619,7 @@ __global__ void __launch_bounds__(HIPNMF_MAXNT) fit_persistent_kernel(SolveArgs<
       for (int cc = 0; cc < CH; ++cc) accA[c][cc] = (real)0;
 #pragma unroll
     for (int i = 0; i < C::NB; ++i) accB[i] = (real)0;
-    rows_update_pass<real, G, CH, K>(Xb, a.ldx, Wb, a.ldw, T, m, 0, row_end, h, hht, accA, accB, a.l1w, a.l2w,
-                                     a.update_h != 0);
+    rows_update_pass<real, G, CH, K>(ma, 0, row_end, h, hht, accA, accB, a.l1w, a.l2w, a.update_h != 0);
     if (a.update_h) {
       __syncthreads();  // previous readers of part are done
       wave_reduce_acc<real, G, CH, K>(s.part + wave * C::NACC, accA, accB);
@@ -579,7 +636,7 @@ __global__ void __launch_bounds__(HIPNMF_MAXNT) fit_persistent_kernel(SolveArgs<
     }
   }
   // reconstruction_err_ (_nmf.py:1628-1630) + per-column SSE / sum X^2 for VAF (analysis.py:654-662)
-  block_residual<real, G, CH, K>(s, Xb, a.ldx, Wb, a.ldw, T, m, 0, row_end, h);
+  block_residual<real, G, CH, K>(s, ma, 0, row_end, h);
   if (threadIdx.x == 0) {
     real tot = (real)0;
     for (int j = 0; j < MP; ++j) tot += s.part[j];
@@ -603,7 +660,7 @@ __global__ void __launch_bounds__(HIPNMF_MAXNT) fit_persistent_kernel(SolveArgs<
 //   grid = (S, B); slice s owns rows [s*rows_per_slice, (s+1)*rows_per_slice)
 // =================================================================================================
 template <typename real, int G, int CH, int K>
-__global__ void __launch_bounds__(HIPNMF_MAXNT) slice_pass_kernel(SolveArgs<real> a) {
+__global__ void __launch_bounds__(HIPNMF_MAXNT) HIPNMF_OCC slice_pass_kernel(SolveArgs<real> a) {
   using C = Cfg<real, G, CH, K>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int nw = blockDim.x / WAVE;
@@ -634,8 +691,8 @@ __global__ void __launch_bounds__(HIPNMF_MAXNT) slice_pass_kernel(SolveArgs<real
     for (int cc = 0; cc < CH; ++cc) accA[c][cc] = (real)0;
 #pragma unroll
   for (int i = 0; i < C::NB; ++i) accB[i] = (real)0;
-  rows_update_pass<real, G, CH, K>(Xb, a.ldx, Wb, a.ldw, a.T, a.m, row_begin, row_end, h, hht, accA, accB, a.l1w,
-                                   a.l2w, a.update_h != 0);
+  const MatAddr<real, G, CH, K> ma(Xb, a.ldx, Wb, a.ldw, a.T, a.m);
+  rows_update_pass<real, G, CH, K>(ma, row_begin, row_end, h, hht, accA, accB, a.l1w, a.l2w, a.update_h != 0);
   if (!a.update_h) return;
   wave_reduce_acc<real, G, CH, K>(s.part + wave * C::NACC, accA, accB);
   __syncthreads();
@@ -722,7 +779,8 @@ __global__ void __launch_bounds__(HIPNMF_MAXNT) slice_resid_kernel(SolveArgs<rea
   for (int c = 0; c < K; ++c)
 #pragma unroll
     for (int cc = 0; cc < CH; ++cc) h[c][cc] = s.H[c * MP + g * CH + cc];
-  block_residual<real, G, CH, K>(s, Xb, a.ldx, Wb, a.ldw, a.T, a.m, row_begin, row_end, h);
+  const MatAddr<real, G, CH, K> ma(Xb, a.ldx, Wb, a.ldw, a.T, a.m);
+  block_residual<real, G, CH, K>(s, ma, row_begin, row_end, h);
   real* __restrict__ out = a.colpart + ((long long)b * a.S + sl) * (2 * MP);
   if (threadIdx.x < 2 * MP) out[threadIdx.x] = s.part[threadIdx.x];
 }
