@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -77,6 +78,9 @@ struct hipnmf_handle {
   int max_slices = 0;  // 0 = default
   int variant = 0;     // 0 auto, 1 force persistent, 2 force sliced
   int num_cu = 256;
+  int lds_per_block = 65536;  // hipDeviceProp_t::maxSharedMemoryPerMultiProcessor (160 KiB on MI355X)
+  int lds_budget = 0;         // override (bytes), 0 = all of it
+  int use_lds_w = 1;
 };
 
 namespace {
@@ -266,7 +270,21 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
     const long long t_pad = round_up(T, 64);
     while (threads > 256 && t_pad <= threads / 2) threads /= 2;
     const int nw = threads / 64;
-    launch<real>(ks->fit_persistent, dim3(B), dim3(threads), ks->smem_bytes(nw), st, a);
+    // W cache in LDS: as many whole workgroup-steps (threads rows each) as fit beside the reduction scratch
+    const size_t base = (ks->smem_bytes(nw) + 15) / 16 * 16;
+    const size_t lds_cap = h->lds_budget > 0 ? (size_t)h->lds_budget : (size_t)h->lds_per_block;
+    long long lds_rows = 0;
+    if (lds_cap > base + 1024 && h->use_lds_w) {
+      lds_rows = (long long)((lds_cap - base) / (sizeof(real) * (size_t)k)) / threads * threads;
+      lds_rows = std::min<long long>(lds_rows, round_up(T, threads));
+      if (lds_rows > t_pad) lds_rows = t_pad / threads * threads;
+    }
+    a.lds_rows = (int)lds_rows;
+    const size_t smem = base + sizeof(real) * (size_t)k * (size_t)lds_rows;
+    if (smem > 48 * 1024)
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ks->fit_persistent),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    launch<real>(ks->fit_persistent, dim3(B), dim3(threads), smem, st, a);
   } else {
     a.S = sg.S;
     a.rows_per_slice = sg.rows_per_slice;
@@ -470,8 +488,12 @@ int hipnmf_create(int device, hipnmf_handle** out) {
   hipnmf_handle* h = new hipnmf_handle();
   h->device = device;
   hipDeviceProp_t prop;
-  if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) {
     h->num_cu = prop.multiProcessorCount;
+    if (prop.maxSharedMemoryPerMultiProcessor >= 65536) h->lds_per_block = (int)prop.maxSharedMemoryPerMultiProcessor;
+  }
+  if (const char* e = getenv("HIPNMF_LDS_W")) h->use_lds_w = atoi(e) != 0;
+  if (const char* e = getenv("HIPNMF_LDS_BUDGET")) h->lds_budget = atoi(e);
   if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
     delete h;

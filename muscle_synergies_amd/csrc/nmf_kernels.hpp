@@ -180,6 +180,7 @@ struct SolveArgs {
   real* xsq_col_out;  // [B][m] or nullptr
   real* state;        // [B][4] err0, prev, err, done   (multi-slice path stop rule)
   int T, m, max_iter, check_every, update_h, S, rows_per_slice, it;
+  int lds_rows;       // persistent kernel: rows [0, lds_rows) of W live in LDS for the whole fit
   real tol, l1w, l2w, l1h, l2h;
 };
 
@@ -200,7 +201,12 @@ struct MatAddr {
   unsigned woff;      // lane * sizeof(real)
   unsigned ldw_b;     // ldw * sizeof(real)
   int T, lane, g;
-  __device__ __forceinline__ MatAddr(const real* Xb, long long ldx, const real* Wb, long long ldw, int T_, int m) {
+  real* lds_w;        // [K][lds_rows] component-major W cache in LDS (persistent kernel), or nullptr
+  int lds_rows;
+  __device__ __forceinline__ MatAddr(const real* Xb, long long ldx, const real* Wb, long long ldw, int T_, int m,
+                                     real* lds_w_ = nullptr, int lds_rows_ = 0) {
+    lds_w = lds_w_;
+    lds_rows = lds_rows_;
     lane = threadIdx.x & (WAVE - 1);
     g = lane % G;
     T = T_;
@@ -216,30 +222,44 @@ struct MatAddr {
   }
 };
 
-// tile of the wave-step starting at row wbase (wave-uniform); rows >= T read as zero
-template <typename real, int G, int CH, int K>
+// tile of the wave-step starting at row wbase (wave-uniform); rows >= T read as zero.
+// WLDS: this step's rows of W are resident in LDS (each row is only ever touched by its owner lane,
+// so no barrier is needed around these accesses).
+template <typename real, int G, int CH, int K, bool WLDS>
 __device__ __forceinline__ void load_tile(RowTile<real, G, CH, K>& t, const MatAddr<real, G, CH, K>& ma, int wbase,
                                           bool in_range) {
   const unsigned sbase = (unsigned)wbase * (unsigned)sizeof(real);
   const bool grp_ok = in_range && (wbase + (ma.lane - ma.g) < ma.T);
-  const bool row_ok = in_range && (wbase + ma.lane < ma.T);
 #pragma unroll
   for (int cc = 0; cc < CH; ++cc) buf_load<real, G>(ma.xr, grp_ok ? ma.xoff[cc] : OOB, sbase, t.x[cc]);
-  const unsigned wv = row_ok ? ma.woff : OOB;
+  if constexpr (WLDS) {
+    const real* p = ma.lds_w + (in_range ? wbase : 0) + ma.lane;
 #pragma unroll
-  for (int c = 0; c < K; ++c) {
-    real tmp[1];
-    buf_load<real, 1>(ma.wr, wv, sbase + (unsigned)c * ma.ldw_b, tmp);
-    t.w[c] = tmp[0];
+    for (int c = 0; c < K; ++c) t.w[c] = p[c * ma.lds_rows];
+  } else {
+    const bool row_ok = in_range && (wbase + ma.lane < ma.T);
+    const unsigned wv = row_ok ? ma.woff : OOB;
+#pragma unroll
+    for (int c = 0; c < K; ++c) {
+      real tmp[1];
+      buf_load<real, 1>(ma.wr, wv, sbase + (unsigned)c * ma.ldw_b, tmp);
+      t.w[c] = tmp[0];
+    }
   }
 }
 
-template <typename real, int G, int CH, int K>
+template <typename real, int G, int CH, int K, bool WLDS>
 __device__ __forceinline__ void store_w(const RowTile<real, G, CH, K>& t, const MatAddr<real, G, CH, K>& ma, int wbase) {
-  const unsigned sbase = (unsigned)wbase * (unsigned)sizeof(real);
-  const unsigned wv = (wbase + ma.lane < ma.T) ? ma.woff : OOB;
+  if constexpr (WLDS) {
+    real* p = ma.lds_w + wbase + ma.lane;
 #pragma unroll
-  for (int c = 0; c < K; ++c) buf_store<real>(ma.wr, wv, sbase + (unsigned)c * ma.ldw_b, t.w[c]);
+    for (int c = 0; c < K; ++c) p[c * ma.lds_rows] = t.w[c];
+  } else {
+    const unsigned sbase = (unsigned)wbase * (unsigned)sizeof(real);
+    const unsigned wv = (wbase + ma.lane < ma.T) ? ma.woff : OOB;
+#pragma unroll
+    for (int c = 0; c < K; ++c) buf_store<real>(ma.wr, wv, sbase + (unsigned)c * ma.ldw_b, t.w[c]);
+  }
 }
 
 // reduce-scatter of pn[G][K] over the G lanes of a group: afterwards pn[0][*] of lane g = sum over the
@@ -357,7 +377,7 @@ struct Smem {
     part = B + K * K;
     scal = part + nw * C::NACC;
   }
-  static size_t bytes(int nw) { return sizeof(real) * (size_t)(2 * K * C::MP + 2 * K * K + nw * C::NACC + 8); }
+  __host__ __device__ static size_t bytes(int nw) { return sizeof(real) * (size_t)(2 * K * C::MP + 2 * K * K + nw * C::NACC + 8); }
 };
 
 template <typename real, int G, int CH, int K>
@@ -400,7 +420,7 @@ __device__ __forceinline__ void load_h_regs(const Smem<real, G, CH, K>& s, int g
 #ifndef HIPNMF_PF
 #define HIPNMF_PF 2
 #endif
-template <typename real, int G, int CH, int K>
+template <typename real, int G, int CH, int K, bool WLDS = false>
 __device__ __forceinline__ void rows_update_pass(const MatAddr<real, G, CH, K>& ma, int row_begin, int row_end,
                                                  const real (&h)[K][CH], const real (&hht)[K][K],
                                                  real (&accA)[K][CH], real (&accB)[Cfg<real, G, CH, K>::NB], real l1w,
@@ -412,16 +432,17 @@ __device__ __forceinline__ void rows_update_pass(const MatAddr<real, G, CH, K>& 
   if (wbase >= row_end) return;
   RowTile<real, G, CH, K> tiles[PF];
 #pragma unroll
-  for (int p = 0; p < PF; ++p) load_tile<real, G, CH, K>(tiles[p], ma, wbase + p * stride, wbase + p * stride < row_end);
+  for (int p = 0; p < PF; ++p)
+    load_tile<real, G, CH, K, WLDS>(tiles[p], ma, wbase + p * stride, wbase + p * stride < row_end);
   bool more = true;
   while (more) {
 #pragma unroll
     for (int p = 0; p < PF; ++p) {
       if (more) {
         update_tile<real, G, CH, K>(tiles[p], h, hht, accA, accB, ma.g, l1w, l2w, update_h);
-        store_w<real, G, CH, K>(tiles[p], ma, wbase);
+        store_w<real, G, CH, K, WLDS>(tiles[p], ma, wbase);
         const int nb = wbase + PF * stride;
-        load_tile<real, G, CH, K>(tiles[p], ma, nb, nb < row_end);
+        load_tile<real, G, CH, K, WLDS>(tiles[p], ma, nb, nb < row_end);
         wbase += stride;
         more = wbase < row_end;
         __builtin_amdgcn_sched_barrier(0);  // keep the tiles' arithmetic from being interleaved (VGPR pressure)
@@ -430,7 +451,7 @@ __device__ __forceinline__ void rows_update_pass(const MatAddr<real, G, CH, K>& 
   }
 }
 
-template <typename real, int G, int CH, int K>
+template <typename real, int G, int CH, int K, bool WLDS = false>
 __device__ __forceinline__ void rows_resid_pass(const MatAddr<real, G, CH, K>& ma, int row_begin, int row_end,
                                                 const real (&h)[K][CH], real (&sse)[CH], real (&xsq)[CH]) {
   const int wave = threadIdx.x / WAVE;
@@ -438,13 +459,13 @@ __device__ __forceinline__ void rows_resid_pass(const MatAddr<real, G, CH, K>& m
   int wbase = row_begin + wave * WAVE;
   if (wbase >= row_end) return;
   RowTile<real, G, CH, K> ta, tb;
-  load_tile<real, G, CH, K>(ta, ma, wbase, true);
+  load_tile<real, G, CH, K, WLDS>(ta, ma, wbase, true);
   while (true) {
-    load_tile<real, G, CH, K>(tb, ma, wbase + stride, wbase + stride < row_end);
+    load_tile<real, G, CH, K, WLDS>(tb, ma, wbase + stride, wbase + stride < row_end);
     resid_tile<real, G, CH, K>(ta, h, sse, xsq);
     wbase += stride;
     if (wbase >= row_end) break;
-    load_tile<real, G, CH, K>(ta, ma, wbase + stride, wbase + stride < row_end);
+    load_tile<real, G, CH, K, WLDS>(ta, ma, wbase + stride, wbase + stride < row_end);
     resid_tile<real, G, CH, K>(tb, h, sse, xsq);
     wbase += stride;
     if (wbase >= row_end) break;
@@ -542,7 +563,13 @@ __device__ __forceinline__ void block_residual(Smem<real, G, CH, K>& s, const Ma
   real sse[CH], xsq[CH];
 #pragma unroll
   for (int cc = 0; cc < CH; ++cc) sse[cc] = xsq[cc] = (real)0;
-  rows_resid_pass<real, G, CH, K>(ma, row_begin, row_end, h, sse, xsq);
+  if (ma.lds_rows > 0) {
+    const int split = row_end < ma.lds_rows ? row_end : ma.lds_rows;
+    rows_resid_pass<real, G, CH, K, true>(ma, row_begin, split, h, sse, xsq);
+    rows_resid_pass<real, G, CH, K, false>(ma, split, row_end, h, sse, xsq);
+  } else {
+    rows_resid_pass<real, G, CH, K, false>(ma, row_begin, row_end, h, sse, xsq);
+  }
 #pragma unroll
   for (int off = G; off < WAVE; off <<= 1)
 #pragma unroll
@@ -588,7 +615,15 @@ __global__ void __launch_bounds__(HIPNMF_MAXNT) HIPNMF_OCC fit_persistent_kernel
   real* __restrict__ Hb = a.H + (long long)b * K * a.m;
   const int T = a.T, m = a.m;
   const int row_end = ((T + WAVE - 1) / WAVE) * WAVE;
-  const MatAddr<real, G, CH, K> ma(Xb, a.ldx, Wb, a.ldw, T, m);
+  // W cache: rows [0, lds_rows) stay in LDS for the whole fit (lds_rows is a multiple of blockDim.x)
+  real* lds_w = reinterpret_cast<real*>(smem_raw + ((Smem<real, G, CH, K>::bytes(nw) + 15) / 16) * 16);
+  const int lds_rows = a.lds_rows;
+  const MatAddr<real, G, CH, K> ma(Xb, a.ldx, Wb, a.ldw, T, m, lds_w, lds_rows);
+  for (int t0 = 0; t0 < lds_rows; t0 += blockDim.x) {  // row t0 + tid is owned by this thread in every pass
+    const int t = t0 + threadIdx.x;
+#pragma unroll
+    for (int c = 0; c < K; ++c) lds_w[c * lds_rows + t] = (t < T) ? Wb[(long long)c * a.ldw + t] : (real)0;
+  }
 
   load_h_to_lds(s, Hb, m);
   __syncthreads();
@@ -619,7 +654,9 @@ __global__ void __launch_bounds__(HIPNMF_MAXNT) HIPNMF_OCC fit_persistent_kernel
       for (int cc = 0; cc < CH; ++cc) accA[c][cc] = (real)0;
 #pragma unroll
     for (int i = 0; i < C::NB; ++i) accB[i] = (real)0;
-    rows_update_pass<real, G, CH, K>(ma, 0, row_end, h, hht, accA, accB, a.l1w, a.l2w, a.update_h != 0);
+    if (lds_rows > 0)
+      rows_update_pass<real, G, CH, K, true>(ma, 0, lds_rows, h, hht, accA, accB, a.l1w, a.l2w, a.update_h != 0);
+    rows_update_pass<real, G, CH, K, false>(ma, lds_rows, row_end, h, hht, accA, accB, a.l1w, a.l2w, a.update_h != 0);
     if (a.update_h) {
       __syncthreads();  // previous readers of part are done
       wave_reduce_acc<real, G, CH, K>(s.part + wave * C::NACC, accA, accB);
@@ -651,6 +688,13 @@ __global__ void __launch_bounds__(HIPNMF_MAXNT) HIPNMF_OCC fit_persistent_kernel
     for (int i = threadIdx.x; i < K * MP; i += blockDim.x) {
       const int c = i / MP, j = i % MP;
       if (j < m) Hb[c * m + j] = s.H[i];
+    }
+  }
+  for (int t0 = 0; t0 < lds_rows; t0 += blockDim.x) {  // write the cached rows of W back
+    const int t = t0 + threadIdx.x;
+    if (t < T) {
+#pragma unroll
+      for (int c = 0; c < K; ++c) Wb[(long long)c * a.ldw + t] = lds_w[c * lds_rows + t];
     }
   }
 }
