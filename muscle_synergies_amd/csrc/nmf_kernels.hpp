@@ -426,7 +426,9 @@ __device__ __forceinline__ void rows_update_pass(const MatAddr<real, G, CH, K>& 
                                                  real (&accA)[K][CH], real (&accB)[Cfg<real, G, CH, K>::NB], real l1w,
                                                  real l2w, bool update_h) {
   constexpr int PF = HIPNMF_PF;
-  const int wave = threadIdx.x / WAVE;
+  // readfirstlane makes the wave id (hence every row base / SGPR offset) provably wave-uniform; without it
+  // hipcc wraps each buffer access in a waterfall loop
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
   const int stride = (blockDim.x / WAVE) * WAVE;
   int wbase = row_begin + wave * WAVE;  // wave-uniform
   if (wbase >= row_end) return;
@@ -454,7 +456,9 @@ __device__ __forceinline__ void rows_update_pass(const MatAddr<real, G, CH, K>& 
 template <typename real, int G, int CH, int K, bool WLDS = false>
 __device__ __forceinline__ void rows_resid_pass(const MatAddr<real, G, CH, K>& ma, int row_begin, int row_end,
                                                 const real (&h)[K][CH], real (&sse)[CH], real (&xsq)[CH]) {
-  const int wave = threadIdx.x / WAVE;
+  // readfirstlane makes the wave id (hence every row base / SGPR offset) provably wave-uniform; without it
+  // hipcc wraps each buffer access in a waterfall loop
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
   const int stride = (blockDim.x / WAVE) * WAVE;
   int wbase = row_begin + wave * WAVE;
   if (wbase >= row_end) return;
