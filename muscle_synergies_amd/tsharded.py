@@ -1,0 +1,162 @@
+"""Time-sharded factorisation of one (or a few) very long recording(s) across GPUs.
+
+BASELINE.json config #5: a single concatenated ``V`` (16 x 2e8) does not shard by matrix, it shards by
+time: rank ``r`` holds rows ``[t0_r, t1_r)`` of ``X`` (sklearn orientation, ``T x m``) and of ``W``;
+``H`` (``k x m``) is replicated.  One multiplicative-update iteration (``sklearn/decomposition/_nmf.py:831-862``)
+then has exactly one exchange step:
+
+    local   W_r <- W_r * (X_r H^T) / (W_r H H^T)                     (row-local, no communication)
+    local   sums_r = [ W_r^T X_r (k x m) | W_r^T W_r (k x k) ]       (the T-long reductions, per shard)
+    global  sums   = all_reduce(sum, sums_r)                         (k*m + k*k floats: RCCL over xGMI)
+    local   H <- H * (W^T X) / ((W^T W) H)                           (replicated, identical on all ranks)
+
+and, when the stop rule is live (``tol > 0``, every 10th iteration, ``_nmf.py:872-884``), one more
+all-reduce of the ``m`` per-column squared errors.  The payload is 105 floats for m=16, k=5: the step is
+latency-bound, so a single packed all-reduce per iteration is used and ring/tree choice is irrelevant.
+
+The per-shard compute is delegated to a *shard-ops* object.  The product implementation is
+:class:`HipShardOps` (the ``hipnmf_shard_*`` entry points of ``libhip_nmf.so``); the world_size-2
+``gloo`` test injects an oracle-backed ops object to check this orchestration without a GPU.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import math
+from dataclasses import dataclass
+from typing import Callable, Optional
+
+from . import _lib
+from .engine import make_problem, partition, resolve_device
+
+
+@dataclass
+class ShardedResult:
+    W_local: "object"  # this rank's rows of W, [B, T_local, k]
+    H: "object"  # replicated components, [B, k, m]
+    n_iter: int
+    reconstruction_err: "object"  # [B] global ||X - W H||_F
+    vaf: "object"  # [B, 1 + m]
+
+
+def shard_bounds(n_samples: int, world_size: int, align: int = 4):
+    """Contiguous row ranges, one per rank, each a multiple of ``align`` rows except the last."""
+    blocks = partition((n_samples + align - 1) // align, world_size)
+    return [(min(lo * align, n_samples), min(hi * align, n_samples)) for lo, hi in blocks]
+
+
+class HipShardOps:
+    """Shard-local compute on one GPU through the C ABI (native layouts: X ``[B, m, T_local]``
+    channel-major, W ``[B, k, T_local]`` component-major)."""
+
+    def __init__(self, X_local, W_local, H, *, l1_reg_W=0.0, l1_reg_H=0.0, l2_reg_W=0.0, l2_reg_H=0.0,
+                 update_H=True, device=None):
+        import torch
+
+        self.torch = torch
+        self.dev = resolve_device(device)
+        X = torch.as_tensor(X_local).to(self.dev)
+        if X.dim() == 2:
+            X, W_local, H = X.unsqueeze(0), torch.as_tensor(W_local).unsqueeze(0), torch.as_tensor(H).unsqueeze(0)
+        self.B, self.T, self.m = X.shape
+        self.dtype = X.dtype
+        # native layouts; the shard is zero-padded to a multiple of 4 rows (zero rows of X with zero rows of
+        # W stay zero under the update and contribute nothing to any sum)
+        self.ld = (self.T + 3) // 4 * 4
+        self.Xc = torch.zeros((self.B, self.m, self.ld), dtype=self.dtype, device=self.dev)
+        self.Xc[:, :, : self.T] = X.transpose(1, 2)
+        W = torch.as_tensor(W_local).to(self.dev, self.dtype)
+        self.k = W.shape[2]
+        self.Wc = torch.zeros((self.B, self.k, self.ld), dtype=self.dtype, device=self.dev)
+        self.Wc[:, :, : self.T] = W.transpose(1, 2)
+        self.H = torch.as_tensor(H).to(self.dev, self.dtype).contiguous().clone()
+        self.sums = torch.empty((self.B, self.k * self.m + self.k * self.k), dtype=self.dtype, device=self.dev)
+        self.sse = torch.empty((self.B, self.m), dtype=self.dtype, device=self.dev)
+        self.xsq = torch.empty((self.B, self.m), dtype=self.dtype, device=self.dev)
+        self.handle = _lib.get_handle(self.dev.index)
+        self.p = make_problem(self.B, self.ld, self.m, self.k, x_layout=_lib.X_CHANNEL_MAJOR, ldx=self.ld,
+                              x_batch_stride=self.m * self.ld, w_layout=_lib.W_COMPONENT_MAJOR, update_H=update_H,
+                              max_iter=1, tol=0.0, l1_reg_W=l1_reg_W, l1_reg_H=l1_reg_H, l2_reg_W=l2_reg_W,
+                              l2_reg_H=l2_reg_H)
+        sfx = "f32" if self.dtype == torch.float32 else "f64"
+        lib = _lib.load()
+        self._pass = getattr(lib, f"hipnmf_shard_pass_{sfx}")
+        self._hupd = getattr(lib, f"hipnmf_shard_hupdate_{sfx}")
+        self._res = getattr(lib, f"hipnmf_shard_residual_{sfx}")
+        torch.cuda.synchronize(self.dev)
+
+    def shard_pass(self):
+        _lib.check(self._pass(self.handle.ptr, ctypes.byref(self.p), self.Xc.data_ptr(), self.Wc.data_ptr(),
+                              self.H.data_ptr(), self.sums.data_ptr()))
+        return self.sums
+
+    def h_update(self, sums):
+        _lib.check(self._hupd(self.handle.ptr, ctypes.byref(self.p), self.H.data_ptr(), sums.data_ptr()))
+
+    def residual(self):
+        _lib.check(self._res(self.handle.ptr, ctypes.byref(self.p), self.Xc.data_ptr(), self.Wc.data_ptr(),
+                             self.H.data_ptr(), self.sse.data_ptr(), self.xsq.data_ptr()))
+        return self.sse, self.xsq
+
+    def result_W(self):
+        return self.Wc[:, :, : self.T].transpose(1, 2).contiguous()  # [B, T_local, k]
+
+    def result_H(self):
+        return self.H
+
+
+def fit_tsharded(ops, *, max_iter: int = 200, tol: float = 1e-4, check_every: int = 10, update_H: bool = True,
+                 group=None, all_reduce: Optional[Callable] = None) -> ShardedResult:
+    """Run the sharded solver on this rank.  ``ops`` provides ``shard_pass() -> sums``,
+    ``h_update(sums)``, ``residual() -> (sse_col, xsq_col)``, ``result_W()``, ``result_H()``; every rank
+    must call this function (collective).  ``all_reduce(tensor)`` defaults to a SUM all-reduce over
+    ``group`` with ``torch.distributed`` (backend ``nccl`` = RCCL on ROCm; ``gloo`` in the CPU test)."""
+    import torch
+
+    if all_reduce is None:
+        import torch.distributed as dist
+
+        if dist.is_available() and dist.is_initialized():
+            def all_reduce(t):
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+                return t
+        else:
+            def all_reduce(t):  # single rank
+                return t
+
+    def global_error():
+        sse, xsq = ops.residual()
+        packed = torch.cat([sse, xsq], dim=1).clone()
+        packed = all_reduce(packed)
+        m = sse.shape[1]
+        return packed[:, :m], packed[:, m:]
+
+    err_init = prev = None
+    if tol > 0:
+        sse, _ = global_error()
+        err_init = torch.sqrt(sse.sum(dim=1))
+        prev = err_init.clone()
+    n_iter = 0
+    for n_iter in range(1, max_iter + 1):
+        sums = ops.shard_pass()
+        if update_H:
+            sums = all_reduce(sums)
+            ops.h_update(sums)
+        if tol > 0 and n_iter % check_every == 0:
+            sse, _ = global_error()
+            err = torch.sqrt(sse.sum(dim=1))
+            # every matrix of the (small) batch must have converged; with B == 1 this is sklearn's rule
+            if bool((((prev - err) / err_init) < tol).all()):
+                break
+            prev = err
+    sse, xsq = global_error()
+    err = torch.sqrt(sse.sum(dim=1))
+    vaf = torch.cat([(1 - sse.sum(dim=1) / xsq.sum(dim=1)).unsqueeze(1), 1 - sse / xsq], dim=1)
+    return ShardedResult(ops.result_W(), ops.result_H(), n_iter, err, vaf)
+
+
+def fit_tsharded_hip(X_local, W_local, H, *, max_iter=200, tol=1e-4, check_every=10, update_H=True, group=None,
+                     device=None, **reg) -> ShardedResult:
+    """Convenience wrapper: build :class:`HipShardOps` for this rank's rows and run :func:`fit_tsharded`."""
+    ops = HipShardOps(X_local, W_local, H, update_H=update_H, device=device, **reg)
+    return fit_tsharded(ops, max_iter=max_iter, tol=tol, check_every=check_every, update_H=update_H, group=group)
