@@ -1,0 +1,74 @@
+"""The C-ABI library: builds for gfx950, loads, and exports every symbol ``include/hip_nmf.h`` declares.
+No compute call is made here (there is no GPU in the build container)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+HEADER = os.path.join(ROOT, "include", "hip_nmf.h")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from muscle_synergies_amd import _lib
+    from muscle_synergies_amd.build import build
+
+    build()  # no-op when up to date
+    return _lib.load()
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(hipnmf_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree():
+    from muscle_synergies_amd import _lib
+
+    assert declared_symbols() == sorted(_lib.EXPORTS)
+
+
+def test_every_declared_symbol_is_exported(lib):
+    for name in declared_symbols():
+        assert hasattr(lib, name), name
+
+
+def test_version_and_struct_layout(lib):
+    from muscle_synergies_amd import _lib
+
+    assert lib.hipnmf_version() == 100
+    # struct hipnmf_problem: 4+4+8+4*6+8+8+4+4+8*5 bytes with natural alignment
+    assert ctypes.sizeof(_lib.Problem) == 104
+    text = open(HEADER).read()
+    fields = re.findall(r"^\s+(?:int32_t|int64_t|double)\s+([a-zA-Z0-9_, ]+);", text, flags=re.M)
+    names = [n.strip() for group in fields for n in group.split(",")]
+    assert names == [f[0] for f in _lib.Problem._fields_]
+
+
+def test_no_device_is_a_loud_error(lib):
+    import torch
+
+    from muscle_synergies_amd import _lib
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    h = ctypes.c_void_p()
+    rc = lib.hipnmf_create(0, ctypes.byref(h))
+    assert rc == _lib.HIPNMF_ERR_NO_DEVICE
+    assert b"no CPU fallback" in lib.hipnmf_last_error() or b"device" in lib.hipnmf_last_error()
+    with pytest.raises(_lib.HipNmfError):
+        _lib.Handle(0)
+
+
+def test_workspace_query_is_pure(lib):
+    from muscle_synergies_amd.engine import make_problem
+    from muscle_synergies_amd import _lib
+
+    p = make_problem(4096, 10000, 16, 5, x_layout=_lib.X_ROW_MAJOR, ldx=16, x_batch_stride=160000)
+    n = lib.hipnmf_workspace_bytes(ctypes.byref(p), 4)
+    assert n >= 4 * 4096 * 21 * 10000
+    assert lib.hipnmf_workspace_bytes(ctypes.byref(p), 3) == 0

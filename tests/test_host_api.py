@@ -1,0 +1,152 @@
+"""Host logic that needs no GPU: validation, routing at the seam, VAF, result structure, layouts."""
+import warnings
+
+import numpy as np
+import pandas as pd
+import pytest
+
+import muscle_synergies_amd as ms
+from muscle_synergies_amd import _lib, engine
+from oracle import nmf_mu_oracle as orc
+
+
+@pytest.fixture()
+def V(g1):
+    return pd.DataFrame(np.array(g1["V"]), columns=g1["columns"])
+
+
+def test_public_names_mirror_the_reference_surface():
+    for name in ("find_synergies", "vaf", "SynergyRunResult", "HipNMF", "fit_batched"):
+        assert hasattr(ms, name)
+
+
+def test_error_cases_match_the_reference(V, g1):
+    """Messages recorded from the reference (analysis.py:829-846 and sklearn validation)."""
+    e = g1["errors"]
+    for name, args in {"k0": (0, None), "k9": (9, None), "3_2": (3, 2), "3_9": (3, 9)}.items():
+        with pytest.raises(ValueError, match=e[name]):
+            ms.find_synergies(V, args[0], args[1], solver="mu")
+    with pytest.raises(ValueError, match=e["empty"]):
+        ms.find_synergies(V.iloc[0:0], 2, solver="mu")
+    raw = pd.DataFrame(np.array(g1["raw_emg"]), columns=g1["columns"])
+    with pytest.raises(ValueError) as ei:
+        ms.find_synergies(raw, 2, solver="mu")
+    assert str(ei.value) == e["negative"] == "Negative values in data passed to NMF initialization."
+
+
+def test_default_solver_still_routes_to_sklearn(V, g1):
+    """find_synergies never sets `solver`; without solver='mu' the call must behave like the reference."""
+    pytest.importorskip("sklearn")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        res = ms.find_synergies(V, 4, init="nndsvda", random_state=0)
+    d = g1["default_solver"]
+    assert type(res.model).__module__.startswith("sklearn")
+    assert res.model.solver == d["solver"] == "cd"
+    assert res.model.n_iter_ == d["n_iter"]
+    np.testing.assert_allclose(res.model.reconstruction_err_, d["reconstruction_err"], rtol=1e-6)
+    np.testing.assert_allclose(res.vaf_values.to_numpy()[0], d["vaf_values"], rtol=1e-6)
+
+
+def test_mu_without_gpu_fails_loudly(V):
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(_lib.HipNmfError, match="no CPU fallback"):
+        ms.find_synergies(V, 2, solver="mu")
+    with pytest.raises(_lib.HipNmfError):
+        ms.fit_batched(np.ones((1, 8, 4), np.float32), np.ones((1, 8, 2), np.float32), np.ones((1, 2, 4), np.float32))
+
+
+def test_vaf_matches_reference_numbers(V, g1):
+    c = g1["single_k4"]
+    out = ms.vaf(V, transformed_signal=np.array(c["transformed"]), components=np.array(c["components"]))
+    assert list(out.columns) == c["vaf_columns"] == ["All signals"] + g1["columns"]
+    assert out.shape == (1, 9)
+    np.testing.assert_allclose(out.to_numpy()[0], c["vaf_values"], rtol=1e-12)
+    va, vc = orc.vaf(V.to_numpy(), np.array(c["transformed"]), np.array(c["components"]))
+    np.testing.assert_allclose(out.to_numpy()[0], np.r_[va, vc], rtol=1e-12)
+    rec = np.array(c["transformed"]) @ np.array(c["components"])
+    out2 = ms.vaf(V, reconstructed_signal=rec)
+    np.testing.assert_allclose(out2.to_numpy(), out.to_numpy())
+
+
+def test_range_result_structure_with_sklearn_backend(V):
+    """The merge logic (analysis.py:884-894) is backend independent: exercise it on the CPU route."""
+    pytest.importorskip("sklearn")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        res = ms.find_synergies(V, 2, 4, max_iter=50, init="nndsvda", random_state=0)
+    assert list(res.components.keys()) == [2, 3, 4] == list(res.model.keys())
+    assert list(res.vaf_values.index) == [2, 3, 4]
+    assert list(res.vaf_values.columns) == ["All signals"] + list(V.columns)
+    for k in (2, 3, 4):
+        assert res.components[k].shape == (k, 8)
+        assert list(res.components[k].columns) == list(V.columns)
+
+
+def test_hipnmf_parameter_validation():
+    X = np.abs(np.random.default_rng(0).standard_normal((20, 4)))
+    with pytest.raises(ValueError, match="solver='mu' only"):
+        ms.HipNMF(2, solver="cd").fit_transform(X)
+    with pytest.raises(NotImplementedError):
+        ms.HipNMF(2, beta_loss="kullback-leibler").fit_transform(X)
+    with pytest.raises(ValueError, match="max_iter"):
+        ms.HipNMF(2, max_iter=0).fit_transform(X)
+    with pytest.raises(ValueError, match="init"):
+        ms.HipNMF(2, init="bogus").fit_transform(X)
+    with pytest.raises(ValueError, match="Negative values in data passed to NMF initialization."):
+        ms.HipNMF(2).fit_transform(-X)
+    with pytest.raises(ValueError, match="wrong first dimension passed to NMF \\(input H\\)"):
+        ms.HipNMF(2, init="custom").fit_transform(X, W=np.ones((20, 2)), H=np.ones((3, 4)))
+    with pytest.raises(ValueError, match="full of zeros"):
+        ms.HipNMF(2, init="custom").fit_transform(X, W=np.zeros((20, 2)), H=np.ones((2, 4)))
+    with pytest.raises(TypeError, match="same dtype as X"):
+        ms.HipNMF(2, init="custom").fit_transform(X, W=np.ones((20, 2), np.float32), H=np.ones((2, 4), np.float32))
+    est = ms.HipNMF(3, tol=0.5)
+    assert est.get_params()["n_components"] == 3 and est.set_params(tol=0.1).tol == 0.1
+    assert ms.HipNMF.supports(solver="mu") and not ms.HipNMF.supports() and not ms.HipNMF.supports(solver="mu", beta_loss=1)
+    with pytest.raises(RuntimeError, match="not fitted"):
+        est.transform(X)
+
+
+def test_regularisation_scaling_follows_sklearn():
+    est = ms.HipNMF(2, alpha_W=0.002, alpha_H=0.001, l1_ratio=0.3)
+    assert est._regularization(512, 16) == pytest.approx(orc.compute_regularization(512, 16, 0.002, 0.001, 0.3))
+    est = ms.HipNMF(2, alpha_W=0.01)
+    assert est._regularization(100, 8) == pytest.approx(orc.compute_regularization(100, 8, 0.01, "same", 0.0))
+
+
+def test_partition_is_contiguous_and_balanced():
+    for n, p in ((4096, 8), (10, 3), (2, 4), (0, 2)):
+        parts = engine.partition(n, p)
+        assert len(parts) == p and parts[0][0] == 0 and parts[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
+        sizes = [hi - lo for lo, hi in parts]
+        assert max(sizes) - min(sizes) <= 1
+
+
+def test_layout_detection_on_host_tensors():
+    import torch
+
+    B, T, m = 3, 40, 8
+    c = torch.zeros((B, T, m))
+    assert engine._x_layout(c)[:3] == (_lib.X_ROW_MAJOR, m, T * m)
+    f = torch.zeros((B, m, T)).transpose(1, 2)  # DataFrame-style channel-major storage
+    assert engine._x_layout(f)[:3] == (_lib.X_CHANNEL_MAJOR, T, T * m)
+    sl = torch.zeros((B, T, 2 * m))[:, :, :m]  # row-major with a padded leading dimension
+    assert engine._x_layout(sl)[:3] == (_lib.X_ROW_MAJOR, 2 * m, T * 2 * m)
+    weird = torch.zeros((B, T, 2 * m))[:, :, ::2]
+    lay, ld, bs, t = engine._x_layout(weird)
+    assert (lay, ld, bs) == (_lib.X_ROW_MAJOR, m, T * m) and t.is_contiguous()
+    df_like = torch.from_numpy(np.asfortranarray(np.zeros((T, m)))).unsqueeze(0)
+    assert engine._x_layout(df_like)[:2] == (_lib.X_CHANNEL_MAJOR, T)
+
+
+def test_problem_struct_roundtrip():
+    p = engine.make_problem(7, 1000, 16, 5, x_layout=1, ldx=1000, x_batch_stride=16000, max_iter=33, tol=1e-3,
+                            l1_reg_W=0.5, l2_reg_H=0.25, update_H=False)
+    assert (p.batch, p.n_samples, p.n_features, p.n_components) == (7, 1000, 16, 5)
+    assert (p.x_layout, p.update_h, p.w_layout, p.max_iter, p.check_every) == (1, 0, 0, 33, 10)
+    assert (p.tol, p.l1_reg_W, p.l2_reg_H) == (1e-3, 0.5, 0.25)
