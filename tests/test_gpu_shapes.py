@@ -1,0 +1,181 @@
+"""GPU parity over shapes, layouts, dtypes and solver paths (persistent vs row-sliced), plus the
+transform / regularisation branches and the time-shard building blocks."""
+import numpy as np
+import pytest
+
+from oracle import nmf_mu_oracle as orc
+from muscle_synergies_amd.synth import emg_matrix, random_init
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _rel(X, W, H, ref):
+    xn = np.linalg.norm(X.astype(np.float64))
+    wh = W.astype(np.float64) @ H.astype(np.float64)
+    wr = ref["W"].astype(np.float64) @ ref["H"].astype(np.float64)
+    return np.linalg.norm(wh - wr) / xn
+
+
+def _case(T, m, k, dtype, seed=0):
+    X = emg_matrix(seed, T=T, m=m, k_true=min(5, m), dtype=dtype)
+    W0, H0 = random_init(X, k, seed)
+    return X, W0, H0
+
+
+@pytest.mark.parametrize("m,k", [(1, 1), (3, 2), (4, 4), (6, 3), (8, 8), (12, 5), (16, 1), (16, 5), (16, 8),
+                                 (20, 4), (32, 6)])
+@pytest.mark.parametrize("T", [7, 64, 1001])
+def test_shape_sweep_fp32(m, k, T):
+    import muscle_synergies_amd as ms
+
+    X, W0, H0 = _case(T, m, k, np.float32, seed=m * 100 + k)
+    for layout in ("F", "C"):
+        Xl = np.asfortranarray(X) if layout == "F" else np.ascontiguousarray(X)
+        res = ms.fit_batched(Xl, W0, H0, max_iter=20, tol=0.0)
+        ref = orc.nmf_mu_fit(X, W0, H0, max_iter=20, tol=0.0)
+        assert _rel(X, res.W[0], res.H[0], ref) <= TOL, (layout, m, k, T)
+        assert abs(float(res.reconstruction_err[0]) - float(ref["reconstruction_err"])) / np.linalg.norm(X) <= TOL
+        np.testing.assert_allclose(res.W[0], ref["W"], rtol=2e-4, atol=1e-6)
+        np.testing.assert_allclose(res.H[0], ref["H"], rtol=2e-4, atol=1e-6)
+        assert (res.W[0] >= 0).all() and (res.H[0] >= 0).all()
+
+
+@pytest.mark.parametrize("m,k,T", [(5, 2, 33), (8, 3, 200), (16, 5, 777), (24, 7, 130)])
+def test_shape_sweep_fp64(m, k, T):
+    import muscle_synergies_amd as ms
+
+    X, W0, H0 = _case(T, m, k, np.float64, seed=7)
+    res = ms.fit_batched(X, W0, H0, max_iter=40, tol=0.0)
+    ref = orc.nmf_mu_fit(X, W0, H0, max_iter=40, tol=0.0)
+    np.testing.assert_allclose(res.W[0], ref["W"], rtol=1e-10, atol=1e-14)
+    np.testing.assert_allclose(res.H[0], ref["H"], rtol=1e-10, atol=1e-14)
+    np.testing.assert_allclose(res.reconstruction_err[0], ref["reconstruction_err"], rtol=1e-10)
+
+
+def test_padded_row_major_leading_dimension():
+    import torch
+
+    import muscle_synergies_amd as ms
+
+    X, W0, H0 = _case(500, 6, 3, np.float32, seed=3)
+    big = torch.zeros((1, 500, 16), dtype=torch.float32, device="cuda")
+    big[0, :, :6] = torch.from_numpy(np.ascontiguousarray(X)).cuda()
+    view = big[:, :, :6]  # row-major with ldx = 16
+    res = ms.fit_batched(view, torch.from_numpy(W0).cuda()[None], torch.from_numpy(H0).cuda()[None], max_iter=30, tol=0.0)
+    ref = orc.nmf_mu_fit(X, W0, H0, max_iter=30, tol=0.0)
+    assert _rel(X, res.W[0].cpu().numpy(), res.H[0].cpu().numpy(), ref) <= TOL
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("tol", [0.0, 1e-3])
+def test_sliced_path_equals_persistent_path(dtype, tol):
+    """variant 2 = row-sliced launches (few matrices / long T), variant 1 = one workgroup per matrix."""
+    import muscle_synergies_amd as ms
+    from muscle_synergies_amd import _lib
+
+    X, W0, H0 = _case(5000, 16, 5, dtype, seed=5)
+    h = _lib.get_handle(0)
+    out = {}
+    try:
+        for variant in (1, 2):
+            h.set_tuning(0, 0, variant)
+            out[variant] = ms.fit_batched(np.stack([X, X[::-1]]), np.stack([W0, W0[::-1]]), np.stack([H0, H0]),
+                                          max_iter=200 if tol else 60, tol=tol)
+    finally:
+        h.set_tuning(0, 0, 0)
+    ref = orc.nmf_mu_fit(X, W0, H0, max_iter=200 if tol else 60, tol=tol)
+    for variant in (1, 2):
+        r = out[variant]
+        assert int(r.n_iter[0]) == ref["n_iter"], variant
+        assert _rel(X, r.W[0], r.H[0], ref) <= TOL
+        assert abs(float(r.reconstruction_err[0]) - float(ref["reconstruction_err"])) / np.linalg.norm(X) <= TOL
+        va, vc = orc.vaf(X.astype(np.float64), ref["W"].astype(np.float64), ref["H"].astype(np.float64))
+        assert abs(r.vaf[0, 0] - va) <= TOL
+    np.testing.assert_allclose(out[1].H[0], out[2].H[0], rtol=5e-4 if dtype == np.float32 else 1e-10)
+
+
+@pytest.mark.parametrize("dt", ["float32", "float64"])
+def test_transform_and_regularisation_vs_sklearn_fixtures(g5, g2_small, dt):
+    import muscle_synergies_amd as ms
+
+    X2 = np.asfortranarray(g5[f"X2_{dt}"])
+    H = g5[f"H_fit_{dt}"]
+    k = H.shape[0]
+    W0 = np.full((X2.shape[0], k), np.sqrt(X2.mean() / k), dtype=X2.dtype)
+    res = ms.fit_batched(X2, W0, H, max_iter=40, tol=0.0, update_H=False)
+    rt = 5e-4 if dt == "float32" else 1e-9
+    np.testing.assert_allclose(res.W[0], g5[f"W_transform_{dt}"], rtol=rt, atol=rt * 1e-2)
+    np.testing.assert_array_equal(res.H[0], H)  # H untouched
+    # estimator-level transform
+    est = ms.HipNMF(k, init="custom", max_iter=40, tol=0.0)
+    est.components_, est.n_components_, est.n_features_in_ = H, k, H.shape[1]
+    np.testing.assert_allclose(est.transform(X2), g5[f"W_transform_{dt}"], rtol=rt, atol=rt * 1e-2)
+    # L1 / L2 regularised fit (alpha_W=0.002, alpha_H=0.001, l1_ratio=0.3)
+    X = np.asfortranarray(g2_small[f"X_{dt}"])
+    est = ms.HipNMF(5, init="custom", max_iter=60, tol=0.0, alpha_W=0.002, alpha_H=0.001, l1_ratio=0.3)
+    W = est.fit_transform(X, W=g2_small[f"W0_{dt}"], H=g2_small[f"H0_{dt}"])
+    xn = np.linalg.norm(X.astype(np.float64))
+    wh = W.astype(np.float64) @ est.components_.astype(np.float64)
+    wh_ref = g5[f"W_reg_{dt}"].astype(np.float64) @ g5[f"H_reg_{dt}"].astype(np.float64)
+    assert np.linalg.norm(wh - wh_ref) / xn <= TOL
+    assert abs(float(est.reconstruction_err_) - float(g5[f"err_reg_{dt}"])) / xn <= TOL
+
+
+def test_estimator_default_init_and_inverse_transform():
+    import muscle_synergies_amd as ms
+
+    X = emg_matrix(2, T=400, m=8, k_true=3, dtype=np.float64)
+    est = ms.HipNMF(3, random_state=0, max_iter=100, tol=0.0)
+    W = est.fit_transform(X)
+    from muscle_synergies_amd.init import initialize_nmf
+
+    W0, H0 = initialize_nmf(X, 3, init=None, random_state=0)
+    ref = orc.nmf_mu_fit(X, W0, H0, max_iter=100, tol=0.0)
+    np.testing.assert_allclose(W, ref["W"], rtol=1e-9, atol=1e-13)
+    np.testing.assert_allclose(est.components_, ref["H"], rtol=1e-9, atol=1e-13)
+    assert est.n_iter_ == 100 and est.n_components_ == 3 and est.n_features_in_ == 8
+    np.testing.assert_allclose(est.inverse_transform(W), W @ est.components_)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_shard_building_blocks_single_rank(dtype):
+    """fit_tsharded driven by the hipnmf_shard_* entry points (one rank, no process group)."""
+    from muscle_synergies_amd.tsharded import HipShardOps, fit_tsharded
+
+    T = 3001  # padded to 3004 inside HipShardOps
+    X, W0, H0 = _case(T, 16, 5, dtype, seed=9)
+    ops = HipShardOps(np.ascontiguousarray(X), W0, H0)
+    res = fit_tsharded(ops, max_iter=30, tol=0.0)
+    ref = orc.nmf_mu_fit(X, W0, H0, max_iter=30, tol=0.0)
+    W = res.W_local.cpu().numpy()[0]
+    H = res.H.cpu().numpy()[0]
+    assert W.shape == (T, 5)
+    assert _rel(X, W, H, ref) <= TOL
+    assert abs(float(res.reconstruction_err[0]) - float(ref["reconstruction_err"])) / np.linalg.norm(X) <= TOL
+    ops = HipShardOps(np.ascontiguousarray(X), W0, H0)
+    res2 = fit_tsharded(ops, max_iter=300, tol=1e-3)
+    ref2 = orc.nmf_mu_fit(X, W0, H0, max_iter=300, tol=1e-3)
+    assert res2.n_iter == ref2["n_iter"]
+
+
+def test_two_shards_on_one_gpu_sum_to_the_unsharded_result():
+    """Emulates two ranks on one device: the all-reduce is replaced by an explicit sum of both shards."""
+    import torch
+
+    from muscle_synergies_amd.tsharded import HipShardOps, shard_bounds
+
+    T = 4000
+    X, W0, H0 = _case(T, 16, 5, np.float64, seed=13)
+    (a0, a1), (b0, b1) = shard_bounds(T, 2)
+    A = HipShardOps(np.ascontiguousarray(X[a0:a1]), W0[a0:a1], H0)
+    B = HipShardOps(np.ascontiguousarray(X[b0:b1]), W0[b0:b1], H0)
+    for _ in range(20):
+        s = A.shard_pass().clone() + B.shard_pass()
+        A.h_update(s)
+        B.h_update(s)
+    ref = orc.nmf_mu_fit(X, W0, H0, max_iter=20, tol=0.0)
+    W = torch.cat([A.result_W(), B.result_W()], dim=1).cpu().numpy()[0]
+    np.testing.assert_allclose(W, ref["W"], rtol=1e-9, atol=1e-13)
+    np.testing.assert_allclose(A.result_H().cpu().numpy()[0], ref["H"], rtol=1e-9, atol=1e-13)
+    np.testing.assert_array_equal(A.result_H().cpu().numpy(), B.result_H().cpu().numpy())
