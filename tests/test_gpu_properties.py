@@ -71,7 +71,8 @@ def test_batch_members_are_independent(workload):
     c = ms.fit_batched(X[:1].expand(5, -1, -1), W0[:1].expand(5, -1, -1), H0[:1].expand(5, -1, -1), max_iter=30, tol=0.0)
     for i in range(1, 5):
         assert torch.equal(c.W[0], c.W[i]) and torch.equal(c.H[0], c.H[i])
-    assert torch.equal(c.W[0], a.W[0])
+    # a 5-matrix call may take the row-sliced path (different, but fixed, summation order)
+    assert torch.allclose(c.W[0], a.W[0], rtol=1e-3, atol=1e-6)
 
 
 def test_stop_rule_in_a_batch_is_per_matrix(workload):
