@@ -41,6 +41,21 @@ __device__ __forceinline__ real eps_val() {
 
 __device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+// Quotient of the W update.  fp32: v_rcp_f32 + one Newton step on the quotient (<= 1 ulp; 4 VALU ops instead
+// of the ~10 of the IEEE expansion, 5 quotients per row); tiny denominators, whose reciprocal would overflow,
+// take the exact path.  fp64 always divides exactly.
+__device__ __forceinline__ float div_(float n, float d) {
+#ifdef HIPNMF_EXACT_DIV
+  return n / d;
+#else
+  if (__builtin_expect(d < 1e-37f, 0)) return n / d;
+  const float r = __builtin_amdgcn_rcpf(d);
+  const float q = n * r;
+  const float e = __builtin_fmaf(-d, q, n);
+  return __builtin_fmaf(e, r, q);
+#endif
+}
+__device__ __forceinline__ double div_(double n, double d) { return n / d; }
 __device__ __forceinline__ float sqrt_(float a) { return __builtin_sqrtf(a); }
 __device__ __forceinline__ double sqrt_(double a) { return __builtin_sqrt(a); }
 
@@ -161,6 +176,8 @@ struct Cfg {
   static constexpr int MP = G * CH;            // padded channel count handled by a lane group
   static constexpr int NB = K * (K + 1) / 2;   // upper triangle of W^T W
   static constexpr int NACC = K * MP + NB;     // floats per wave partial
+  // LDS record per wave: the update pass stores NACC sums, the residual pass 2*MP (sse | xsq)
+  static constexpr int NREC = NACC > 2 * MP ? NACC : 2 * MP;
 };
 
 // kernel arguments (canonical layouts: X channel-major with ldx % G == 0, W component-major)
@@ -309,7 +326,7 @@ __device__ __forceinline__ void update_tile(RowTile<real, G, CH, K>& t, const re
     if (l1w > (real)0) d = d + l1w;
     if (l2w > (real)0) d = d + l2w * t.w[c];
     d = (d == (real)0) ? eps_val<real>() : d;
-    wn[c] = t.w[c] * (pn[0][c] / d);
+    wn[c] = t.w[c] * div_(pn[0][c], d);
   }
 #pragma unroll
   for (int c = 0; c < K; ++c) t.w[c] = wn[c];
@@ -375,9 +392,9 @@ struct Smem {
     A = HHt + K * K;
     B = A + K * C::MP;
     part = B + K * K;
-    scal = part + nw * C::NACC;
+    scal = part + nw * C::NREC;
   }
-  __host__ __device__ static size_t bytes(int nw) { return sizeof(real) * (size_t)(2 * K * C::MP + 2 * K * K + nw * C::NACC + 8); }
+  __host__ __device__ static size_t bytes(int nw) { return sizeof(real) * (size_t)(2 * K * C::MP + 2 * K * K + nw * C::NREC + 8); }
 };
 
 template <typename real, int G, int CH, int K>
@@ -482,16 +499,35 @@ __device__ __forceinline__ void wave_reduce_acc(real* __restrict__ rec /* [NACC]
                                                 real (&accB)[Cfg<real, G, CH, K>::NB]) {
   using C = Cfg<real, G, CH, K>;
   const int lane = threadIdx.x & (WAVE - 1);
+  // inside a 16-lane row: DPP rotations (VALU only); across the four rows: two ds_bpermute stages
 #pragma unroll
-  for (int off = G; off < WAVE; off <<= 1)
+  for (int c = 0; c < K; ++c)
 #pragma unroll
-    for (int c = 0; c < K; ++c)
+    for (int cc = 0; cc < CH; ++cc) {
+      real v = accA[c][cc];
+      if constexpr (G == 1) {
+        v += xor_lane<1>(v);
+        v += xor_lane<2>(v);
+      } else if constexpr (G == 2) {
+        v += xor_lane<2>(v);
+      }
+      if constexpr (G <= 4) v += dpp_mov<0x124>(v);  // row_ror:4
+      if constexpr (G <= 8) v += dpp_mov<0x128>(v);  // row_ror:8
+      v += __shfl_xor(v, 16, WAVE);
+      v += __shfl_xor(v, 32, WAVE);
+      accA[c][cc] = v;
+    }
 #pragma unroll
-      for (int cc = 0; cc < CH; ++cc) accA[c][cc] += __shfl_xor(accA[c][cc], off, WAVE);
-#pragma unroll
-  for (int off = 1; off < WAVE; off <<= 1)
-#pragma unroll
-    for (int i = 0; i < C::NB; ++i) accB[i] += __shfl_xor(accB[i], off, WAVE);
+  for (int i = 0; i < C::NB; ++i) {
+    real v = accB[i];
+    v += xor_lane<1>(v);
+    v += xor_lane<2>(v);
+    v += dpp_mov<0x124>(v);
+    v += dpp_mov<0x128>(v);
+    v += __shfl_xor(v, 16, WAVE);
+    v += __shfl_xor(v, 32, WAVE);
+    accB[i] = v;
+  }
   if (lane < G) {
 #pragma unroll
     for (int c = 0; c < K; ++c)
