@@ -44,18 +44,35 @@ __device__ __forceinline__ double fma_(double a, double b, double c) { return __
 // Quotient of the W update.  fp32: v_rcp_f32 + one Newton step on the quotient (<= 1 ulp; 4 VALU ops instead
 // of the ~10 of the IEEE expansion, 5 quotients per row); tiny denominators, whose reciprocal would overflow,
 // take the exact path.  fp64 always divides exactly.
-__device__ __forceinline__ float div_(float n, float d) {
-#ifdef HIPNMF_EXACT_DIV
-  return n / d;
-#else
-  if (__builtin_expect(d < 1e-37f, 0)) return n / d;
+__device__ __forceinline__ float fast_div(float n, float d) {
   const float r = __builtin_amdgcn_rcpf(d);
   const float q = n * r;
   const float e = __builtin_fmaf(-d, q, n);
   return __builtin_fmaf(e, r, q);
+}
+template <int K>
+__device__ __forceinline__ void quotients(const float (&n)[K], const float (&d)[K], float (&q)[K]) {
+#ifdef HIPNMF_EXACT_DIV
+#pragma unroll
+  for (int c = 0; c < K; ++c) q[c] = n[c] / d[c];
+#else
+  bool tiny = false;
+#pragma unroll
+  for (int c = 0; c < K; ++c) tiny = tiny || (d[c] < 1e-37f);
+  if (__builtin_expect(__any(tiny), 0)) {  // one wave-uniform, practically never taken branch per tile
+#pragma unroll
+    for (int c = 0; c < K; ++c) q[c] = n[c] / d[c];
+  } else {
+#pragma unroll
+    for (int c = 0; c < K; ++c) q[c] = fast_div(n[c], d[c]);
+  }
 #endif
 }
-__device__ __forceinline__ double div_(double n, double d) { return n / d; }
+template <int K>
+__device__ __forceinline__ void quotients(const double (&n)[K], const double (&d)[K], double (&q)[K]) {
+#pragma unroll
+  for (int c = 0; c < K; ++c) q[c] = n[c] / d[c];
+}
 __device__ __forceinline__ float sqrt_(float a) { return __builtin_sqrtf(a); }
 __device__ __forceinline__ double sqrt_(double a) { return __builtin_sqrt(a); }
 
@@ -317,7 +334,7 @@ __device__ __forceinline__ void update_tile(RowTile<real, G, CH, K>& t, const re
   reduce_scatter<G / 2, real, G, K>(pn, g);
 
   // denominator W (H H^T) (_nmf.py:553-554), regularisation (:616-619), zero guard (:620), update (:622-629)
-  real wn[K];
+  real wn[K], den[K], num[K], quo[K];
 #pragma unroll
   for (int c = 0; c < K; ++c) {
     real d = t.w[0] * hht[0][c];
@@ -325,9 +342,12 @@ __device__ __forceinline__ void update_tile(RowTile<real, G, CH, K>& t, const re
     for (int c2 = 1; c2 < K; ++c2) d = fma_(t.w[c2], hht[c2][c], d);
     if (l1w > (real)0) d = d + l1w;
     if (l2w > (real)0) d = d + l2w * t.w[c];
-    d = (d == (real)0) ? eps_val<real>() : d;
-    wn[c] = t.w[c] * div_(pn[0][c], d);
+    den[c] = (d == (real)0) ? eps_val<real>() : d;
+    num[c] = pn[0][c];
   }
+  quotients<K>(num, den, quo);
+#pragma unroll
+  for (int c = 0; c < K; ++c) wn[c] = t.w[c] * quo[c];
 #pragma unroll
   for (int c = 0; c < K; ++c) t.w[c] = wn[c];
 
@@ -449,23 +469,30 @@ __device__ __forceinline__ void rows_update_pass(const MatAddr<real, G, CH, K>& 
   const int stride = (blockDim.x / WAVE) * WAVE;
   int wbase = row_begin + wave * WAVE;  // wave-uniform
   if (wbase >= row_end) return;
+  const int nsteps = (row_end - wbase + stride - 1) / stride;  // wave-uniform trip count
+  const int nfull = nsteps / PF, rem = nsteps - nfull * PF;
   RowTile<real, G, CH, K> tiles[PF];
 #pragma unroll
-  for (int p = 0; p < PF; ++p)
-    load_tile<real, G, CH, K, WLDS>(tiles[p], ma, wbase + p * stride, wbase + p * stride < row_end);
-  bool more = true;
-  while (more) {
+  for (int p = 0; p < PF; ++p) load_tile<real, G, CH, K, WLDS>(tiles[p], ma, wbase + p * stride, p < nsteps);
+  // Main loop: PF tiles per trip, no exit in the middle (a single back edge keeps hipcc's s_waitcnt vmcnt
+  // counting exact, so the tiles loaded PF-1 steps ahead really stay in flight).
+  for (int grp = 0; grp < nfull; ++grp) {
 #pragma unroll
     for (int p = 0; p < PF; ++p) {
-      if (more) {
-        update_tile<real, G, CH, K>(tiles[p], h, hht, accA, accB, ma.g, l1w, l2w, update_h);
-        store_w<real, G, CH, K, WLDS>(tiles[p], ma, wbase);
-        const int nb = wbase + PF * stride;
-        load_tile<real, G, CH, K, WLDS>(tiles[p], ma, nb, nb < row_end);
-        wbase += stride;
-        more = wbase < row_end;
-        __builtin_amdgcn_sched_barrier(0);  // keep the tiles' arithmetic from being interleaved (VGPR pressure)
-      }
+      update_tile<real, G, CH, K>(tiles[p], h, hht, accA, accB, ma.g, l1w, l2w, update_h);
+      store_w<real, G, CH, K, WLDS>(tiles[p], ma, wbase);
+      const int nb = wbase + PF * stride;
+      load_tile<real, G, CH, K, WLDS>(tiles[p], ma, nb, nb < row_end);
+      wbase += stride;
+      __builtin_amdgcn_sched_barrier(0);  // keep the tiles' arithmetic from being interleaved (VGPR pressure)
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < PF - 1; ++p) {
+    if (p < rem) {  // wave-uniform
+      update_tile<real, G, CH, K>(tiles[p], h, hht, accA, accB, ma.g, l1w, l2w, update_h);
+      store_w<real, G, CH, K, WLDS>(tiles[p], ma, wbase);
+      wbase += stride;
     }
   }
 }
