@@ -455,14 +455,17 @@ __device__ __forceinline__ void load_h_regs(const Smem<real, G, CH, K>& s, int g
 // streaming pass over rows [row_begin, row_end) (row_begin % 64 == 0): W update + accumulation.
 // Software pipeline: PF tiles per wave are in flight (loads issued PF-1 steps ahead of their use).
 #ifndef HIPNMF_PF
-#define HIPNMF_PF 2
+#define HIPNMF_PF 2      // tiles in flight per wave when W streams from global memory (21 VGPRs per tile)
+#endif
+#ifndef HIPNMF_PF_LDS
+#define HIPNMF_PF_LDS 2  // same for the rows whose W lives in LDS (16 VGPRs per tile)
 #endif
 template <typename real, int G, int CH, int K, bool WLDS = false>
 __device__ __forceinline__ void rows_update_pass(const MatAddr<real, G, CH, K>& ma, int row_begin, int row_end,
                                                  const real (&h)[K][CH], const real (&hht)[K][K],
                                                  real (&accA)[K][CH], real (&accB)[Cfg<real, G, CH, K>::NB], real l1w,
                                                  real l2w, bool update_h) {
-  constexpr int PF = HIPNMF_PF;
+  constexpr int PF = WLDS ? HIPNMF_PF_LDS : HIPNMF_PF;
   // readfirstlane makes the wave id (hence every row base / SGPR offset) provably wave-uniform; without it
   // hipcc wraps each buffer access in a waterfall loop
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
