@@ -460,12 +460,33 @@ __device__ __forceinline__ void load_h_regs(const Smem<real, G, CH, K>& s, int g
 #ifndef HIPNMF_PF_LDS
 #define HIPNMF_PF_LDS 2  // same for the rows whose W lives in LDS (16 VGPRs per tile)
 #endif
-template <typename real, int G, int CH, int K, bool WLDS = false>
+template <bool WLDS>
+struct PipeDepth {
+  static constexpr int value = WLDS ? HIPNMF_PF_LDS : HIPNMF_PF;
+};
+
+// issue the loads of this wave's first PF tiles of rows [row_begin, row_end)
+template <typename real, int G, int CH, int K, bool WLDS>
+__device__ __forceinline__ void prefetch_head(RowTile<real, G, CH, K> (&tiles)[PipeDepth<WLDS>::value],
+                                              const MatAddr<real, G, CH, K>& ma, int row_begin, int row_end) {
+  constexpr int PF = PipeDepth<WLDS>::value;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
+  const int stride = (blockDim.x / WAVE) * WAVE;
+  const int wbase = row_begin + wave * WAVE;
+#pragma unroll
+  for (int p = 0; p < PF; ++p)
+    load_tile<real, G, CH, K, WLDS>(tiles[p], ma, wbase + p * stride, wbase + p * stride < row_end);
+}
+
+// PRELOADED: `tiles` already holds (or has in flight) the first PF tiles -- the persistent kernel issues them
+// before the reduction / H-update phase of the previous iteration so the pipeline never starts cold.
+template <typename real, int G, int CH, int K, bool WLDS = false, bool PRELOADED = false>
 __device__ __forceinline__ void rows_update_pass(const MatAddr<real, G, CH, K>& ma, int row_begin, int row_end,
                                                  const real (&h)[K][CH], const real (&hht)[K][K],
                                                  real (&accA)[K][CH], real (&accB)[Cfg<real, G, CH, K>::NB], real l1w,
-                                                 real l2w, bool update_h) {
-  constexpr int PF = WLDS ? HIPNMF_PF_LDS : HIPNMF_PF;
+                                                 real l2w, bool update_h,
+                                                 RowTile<real, G, CH, K> (&tiles)[PipeDepth<WLDS>::value]) {
+  constexpr int PF = PipeDepth<WLDS>::value;
   // readfirstlane makes the wave id (hence every row base / SGPR offset) provably wave-uniform; without it
   // hipcc wraps each buffer access in a waterfall loop
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
@@ -474,9 +495,7 @@ __device__ __forceinline__ void rows_update_pass(const MatAddr<real, G, CH, K>& 
   if (wbase >= row_end) return;
   const int nsteps = (row_end - wbase + stride - 1) / stride;  // wave-uniform trip count
   const int nfull = nsteps / PF, rem = nsteps - nfull * PF;
-  RowTile<real, G, CH, K> tiles[PF];
-#pragma unroll
-  for (int p = 0; p < PF; ++p) load_tile<real, G, CH, K, WLDS>(tiles[p], ma, wbase + p * stride, p < nsteps);
+  if constexpr (!PRELOADED) prefetch_head<real, G, CH, K, WLDS>(tiles, ma, row_begin, row_end);
   // Main loop: PF tiles per trip, no exit in the middle (a single back edge keeps hipcc's s_waitcnt vmcnt
   // counting exact, so the tiles loaded PF-1 steps ahead really stay in flight).
   for (int grp = 0; grp < nfull; ++grp) {
@@ -487,7 +506,9 @@ __device__ __forceinline__ void rows_update_pass(const MatAddr<real, G, CH, K>& 
       const int nb = wbase + PF * stride;
       load_tile<real, G, CH, K, WLDS>(tiles[p], ma, nb, nb < row_end);
       wbase += stride;
+#ifndef HIPNMF_NO_TILE_BARRIER
       __builtin_amdgcn_sched_barrier(0);  // keep the tiles' arithmetic from being interleaved (VGPR pressure)
+#endif
     }
   }
 #pragma unroll
@@ -715,6 +736,8 @@ __global__ void __launch_bounds__(HIPNMF_MAXNT) HIPNMF_OCC fit_persistent_kernel
     prev = err0;
   }
   int n_iter = 0;
+  RowTile<real, G, CH, K> tiles_lds[PipeDepth<true>::value];
+  if (lds_rows > 0) prefetch_head<real, G, CH, K, true>(tiles_lds, ma, 0, lds_rows);
   for (int it = 1; it <= a.max_iter; ++it) {
     n_iter = it;
     real accA[K][CH], accB[C::NB];
@@ -725,8 +748,15 @@ __global__ void __launch_bounds__(HIPNMF_MAXNT) HIPNMF_OCC fit_persistent_kernel
 #pragma unroll
     for (int i = 0; i < C::NB; ++i) accB[i] = (real)0;
     if (lds_rows > 0)
-      rows_update_pass<real, G, CH, K, true>(ma, 0, lds_rows, h, hht, accA, accB, a.l1w, a.l2w, a.update_h != 0);
-    rows_update_pass<real, G, CH, K, false>(ma, lds_rows, row_end, h, hht, accA, accB, a.l1w, a.l2w, a.update_h != 0);
+      rows_update_pass<real, G, CH, K, true, true>(ma, 0, lds_rows, h, hht, accA, accB, a.l1w, a.l2w,
+                                                   a.update_h != 0, tiles_lds);
+    {
+      RowTile<real, G, CH, K> tiles_glb[PipeDepth<false>::value];
+      rows_update_pass<real, G, CH, K, false, false>(ma, lds_rows, row_end, h, hht, accA, accB, a.l1w, a.l2w,
+                                                     a.update_h != 0, tiles_glb);
+    }
+    // X does not depend on H: start streaming the next iteration's first tiles now, under the reduction
+    if (lds_rows > 0 && it < a.max_iter) prefetch_head<real, G, CH, K, true>(tiles_lds, ma, 0, lds_rows);
     if (a.update_h) {
       __syncthreads();  // previous readers of part are done
       wave_reduce_acc<real, G, CH, K>(s.part + wave * C::NACC, accA, accB);
@@ -806,7 +836,9 @@ __global__ void __launch_bounds__(HIPNMF_MAXNT) HIPNMF_OCC slice_pass_kernel(Sol
 #pragma unroll
   for (int i = 0; i < C::NB; ++i) accB[i] = (real)0;
   const MatAddr<real, G, CH, K> ma(Xb, a.ldx, Wb, a.ldw, a.T, a.m);
-  rows_update_pass<real, G, CH, K>(ma, row_begin, row_end, h, hht, accA, accB, a.l1w, a.l2w, a.update_h != 0);
+  RowTile<real, G, CH, K> tiles_glb[PipeDepth<false>::value];
+  rows_update_pass<real, G, CH, K, false, false>(ma, row_begin, row_end, h, hht, accA, accB, a.l1w, a.l2w,
+                                                 a.update_h != 0, tiles_glb);
   if (!a.update_h) return;
   wave_reduce_acc<real, G, CH, K>(s.part + wave * C::NACC, accA, accB);
   __syncthreads();
