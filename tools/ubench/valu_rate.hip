@@ -7,8 +7,8 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 
 template <int MODE>
 __global__ void k(float* out, int iters, float a, float b) {
-  float x[8]; f2 y[8];
-  for (int i = 0; i < 8; ++i) { x[i] = threadIdx.x * 0.001f + i; y[i] = f2{x[i], x[i] + 1.f}; }
+  float x[8]; f2 y[8]; float z[8], w[8];
+  for (int i = 0; i < 8; ++i) { x[i] = threadIdx.x * 0.001f + i; y[i] = f2{x[i], x[i] + 1.f}; z[i] = x[i] * 0.37f + a; w[i] = x[i] * 0.11f + b; }
   f2 av{a, a * 1.0001f};
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -21,10 +21,13 @@ __global__ void k(float* out, int iters, float a, float b) {
         if (MODE == 3) { int v = __builtin_bit_cast(int, x[i]); v = __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, true); x[i] = __builtin_bit_cast(float, v) + a; }  // dpp mov + add
         if (MODE == 4) x[i] = (x[i] > a) ? x[i] * b : a;                           // cmp+cndmask+mul
         if (MODE == 5) x[i] = x[i] / (a + x[i]);                                  // IEEE div
+        if (MODE == 6) x[i] = __builtin_fmaf(z[i], w[(i + u) & 7], x[i]);          // v_fmac with 3 VGPR operands
+        if (MODE == 7) x[i] = (threadIdx.x & 2) ? z[i] : x[(i + 1) & 7];           // v_cndmask (mask in SGPR pair)
+        if (MODE == 8) x[i] = __builtin_fmaf(z[i], a, x[i]);                       // v_fmac VGPR x SGPR + VGPR
       }
     }
   }
-  float s = 0; for (int i = 0; i < 8; ++i) s += x[i] + y[i].x + y[i].y;
+  float s = 0; for (int i = 0; i < 8; ++i) s += x[i] + y[i].x + y[i].y + z[i] + w[i];
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
@@ -49,6 +52,6 @@ template <int MODE> int run(const char* name, int opsPerInner) {
   return 0;
 }
 int main() {
-  run<0>("v_fma_f32", 1); run<1>("v_pk_fma_f32", 1); run<2>("rcp+add", 2); run<3>("dppmov+add", 2); run<4>("cmp+cnd+mul", 3); run<5>("ieee_div", 10);
+  run<0>("v_fma_f32", 1); run<1>("v_pk_fma_f32", 1); run<2>("rcp+add", 2); run<3>("dppmov+add", 2); run<4>("cmp+cnd+mul", 3); run<5>("ieee_div", 10); run<6>("fmac_3vgpr", 1); run<7>("cndmask", 1); run<8>("fmac_vsv", 1);
   return 0;
 }
