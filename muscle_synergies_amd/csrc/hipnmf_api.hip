@@ -265,7 +265,7 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
   HIP_TRY(hipEventRecord(h->ev0, st));
   if (persistent) {
     int threads = h->threads > 0 ? h->threads : 512;
-    threads = std::min(threads, (int)HIPNMF_MAXNT);
+    threads = std::min(threads, ks->max_threads);
     // a wave covers 64 rows per step: do not launch waves that would never get a row
     const long long t_pad = round_up(T, 64);
     while (threads > 256 && t_pad <= threads / 2) threads /= 2;

@@ -9,7 +9,7 @@ template <typename real>
 struct KernelSet {
   using Fn = void (*)(SolveArgs<real>);
   Fn fit_persistent, slice_pass, reduce_slices, hupdate, slice_resid, resid_finalize;
-  int G, CH, K, MP, NACC;
+  int G, CH, K, MP, NACC, max_threads;
   size_t (*smem_bytes)(int nw);
 };
 
@@ -27,6 +27,7 @@ KernelSet<real> make_kernel_set() {
   ks.K = K;
   ks.MP = G * CH;
   ks.NACC = Cfg<real, G, CH, K>::NACC;
+  ks.max_threads = max_threads<real, G, CH, K>();
   ks.smem_bytes = &Smem<real, G, CH, K>::bytes;
   return ks;
 }

@@ -188,6 +188,16 @@ __device__ __forceinline__ void buf_store(rsrc_t r, unsigned voff, unsigned soff
 }
 
 // ------------------------------------------------------------------------------------------------
+// Largest workgroup a kernel instance is compiled for.  512 threads = 2 waves/SIMD caps the allocation at 256
+// VGPRs; instances whose live state cannot fit (fp64, m > 16 or large k) are compiled for 256 threads
+// (1 wave/SIMD, up to 512 VGPRs) instead of spilling to scratch.
+template <typename real, int G, int CH, int K>
+constexpr int max_threads() {
+  constexpr int words = (int)(sizeof(real) / 4);
+  constexpr int est = words * (2 * K * CH + K * (K + 1) / 2 + 3 * G * CH + G * K + 40);
+  return est > 210 ? 256 : (HIPNMF_MAXNT);
+}
+
 template <typename real, int G, int CH, int K>
 struct Cfg {
   static constexpr int MP = G * CH;            // padded channel count handled by a lane group
@@ -691,7 +701,7 @@ __device__ __forceinline__ void block_residual(Smem<real, G, CH, K>& s, const Ma
 // Kernel 1: one workgroup per matrix, all iterations inside the kernel (batch mode, S == 1).
 // =================================================================================================
 template <typename real, int G, int CH, int K>
-__global__ void __launch_bounds__(HIPNMF_MAXNT) HIPNMF_OCC fit_persistent_kernel(SolveArgs<real> a) {
+__global__ void __launch_bounds__((max_threads<real, G, CH, K>())) HIPNMF_OCC fit_persistent_kernel(SolveArgs<real> a) {
   using C = Cfg<real, G, CH, K>;
   constexpr int MP = C::MP;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -804,7 +814,7 @@ __global__ void __launch_bounds__(HIPNMF_MAXNT) HIPNMF_OCC fit_persistent_kernel
 //   grid = (S, B); slice s owns rows [s*rows_per_slice, (s+1)*rows_per_slice)
 // =================================================================================================
 template <typename real, int G, int CH, int K>
-__global__ void __launch_bounds__(HIPNMF_MAXNT) HIPNMF_OCC slice_pass_kernel(SolveArgs<real> a) {
+__global__ void __launch_bounds__((max_threads<real, G, CH, K>())) HIPNMF_OCC slice_pass_kernel(SolveArgs<real> a) {
   using C = Cfg<real, G, CH, K>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int nw = blockDim.x / WAVE;
@@ -902,7 +912,7 @@ __global__ void hupdate_kernel(SolveArgs<real> a) {
 
 // per-slice residual partials: colpart[b][s][0..MP) = sse, [MP..2MP) = xsq
 template <typename real, int G, int CH, int K>
-__global__ void __launch_bounds__(HIPNMF_MAXNT) slice_resid_kernel(SolveArgs<real> a) {
+__global__ void __launch_bounds__((max_threads<real, G, CH, K>())) slice_resid_kernel(SolveArgs<real> a) {
   constexpr int MP = G * CH;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int nw = blockDim.x / WAVE;

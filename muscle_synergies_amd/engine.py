@@ -222,3 +222,67 @@ def partition(n_items: int, n_parts: int):
         out.append((lo, hi))
         lo = hi
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# Device-side initialisation and the per-trial rank sweep (BASELINE.json config #4)
+def random_init_batched(X, k: int, *, seed: int = 0):
+    """sklearn's ``init='random'`` scaling (``_nmf.py:303-314``: ``sqrt(X.mean()/k) * |N(0,1)|``) for every
+    matrix of a device batch ``X [B, T, m]``, drawn from torch's generator on the device (same law as
+    sklearn, not the same stream).  Returns ``(W0 [B, T, k], H0 [B, k, m])``."""
+    torch = _torch()
+    B, T, m = X.shape
+    g = torch.Generator(device=X.device)
+    g.manual_seed(int(seed))
+    avg = torch.sqrt(X.mean(dim=(1, 2)) / k).view(B, 1, 1)
+    H0 = avg * torch.randn((B, k, m), generator=g, device=X.device, dtype=X.dtype).abs_()
+    W0 = avg * torch.randn((B, T, k), generator=g, device=X.device, dtype=X.dtype).abs_()
+    return W0, H0
+
+
+@dataclass
+class RankSweepResult:
+    """Per-trial rank sweep: ``vaf_all[b, i]`` is the "All signals" VAF of trial ``b`` at rank ``ranks[i]``;
+    ``selected[b]`` the first rank whose VAF reaches ``vaf_threshold`` (``-1`` if none does) -- the
+    thresholding the reference leaves to the user (``analysis.py:753-756``, Rabbi et al. 2020 protocol)."""
+
+    ranks: list
+    vaf_all: "object"  # [B, n_ranks]
+    vaf: dict  # rank -> [B, 1 + m]
+    n_iter: dict  # rank -> [B]
+    reconstruction_err: dict  # rank -> [B]
+    components: dict  # rank -> [B, k, m]
+    selected: "object"  # [B] int64
+    kernel_ms: float
+
+
+def rank_sweep_batched(X, k_min: int, k_max: int, *, vaf_threshold: float = 0.90, max_iter: int = 500,
+                       tol: float = 1e-4, seed: int = 0, device=None, keep_W: bool = False) -> RankSweepResult:
+    """``find_synergies(df, k_min, k_max)`` for a whole batch of trials: one batched fit per rank
+    (``init='random'``), VAF per trial and rank, and the smallest rank with VAF >= ``vaf_threshold``."""
+    torch = _torch()
+    dev = resolve_device(device)
+    Xt = _as_device_tensor(X, dev)
+    if Xt.dim() == 2:
+        Xt = Xt.unsqueeze(0)
+    B, T, m = Xt.shape
+    if not 1 <= k_min <= k_max <= m:
+        raise ValueError("invalid number of components")
+    ranks = list(range(k_min, k_max + 1))
+    vaf, n_iter, err, comps, Ws = {}, {}, {}, {}, {}
+    total_ms = 0.0
+    for k in ranks:
+        W0, H0 = random_init_batched(Xt, k, seed=seed + k)
+        r = fit_batched(Xt, W0, H0, max_iter=max_iter, tol=tol, device=dev, return_numpy=False, overwrite_init=True)
+        vaf[k], n_iter[k], err[k], comps[k] = r.vaf, r.n_iter, r.reconstruction_err, r.H
+        if keep_W:
+            Ws[k] = r.W
+        total_ms += r.kernel_ms
+    vaf_all = torch.stack([vaf[k][:, 0] for k in ranks], dim=1)
+    ok = vaf_all >= vaf_threshold
+    first = torch.where(ok.any(dim=1), ok.float().argmax(dim=1), torch.full((B,), -1, device=dev, dtype=torch.long))
+    selected = torch.where(first >= 0, first + k_min, first)
+    res = RankSweepResult(ranks, vaf_all, vaf, n_iter, err, comps, selected, total_ms)
+    if keep_W:
+        res.W = Ws
+    return res

@@ -179,3 +179,30 @@ def test_two_shards_on_one_gpu_sum_to_the_unsharded_result():
     np.testing.assert_allclose(W, ref["W"], rtol=1e-9, atol=1e-13)
     np.testing.assert_allclose(A.result_H().cpu().numpy()[0], ref["H"], rtol=1e-9, atol=1e-13)
     np.testing.assert_array_equal(A.result_H().cpu().numpy(), B.result_H().cpu().numpy())
+
+
+def test_rank_sweep_matches_per_rank_fits():
+    """Config #4 in miniature: k = 2..6 on a batch of trials, VAF threshold selection."""
+    import torch
+
+    import muscle_synergies_amd as ms
+    from muscle_synergies_amd.synth import emg_batch
+
+    Xb = emg_batch(range(40, 52), T=1500, m=16, k_true=4)  # [B, m, T]
+    X = torch.from_numpy(Xb).cuda().transpose(1, 2)
+    res = ms.rank_sweep_batched(X, 2, 6, vaf_threshold=0.9, max_iter=150, tol=0.0, seed=3)
+    assert res.ranks == [2, 3, 4, 5, 6] and tuple(res.vaf_all.shape) == (12, 5)
+    v = res.vaf_all.cpu().numpy()
+    assert (np.diff(v, axis=1) > -5e-3).all()  # VAF grows with the rank (up to local-minimum noise)
+    sel = res.selected.cpu().numpy()
+    for b in range(12):
+        ok = np.nonzero(v[b] >= 0.9)[0]
+        assert sel[b] == (res.ranks[ok[0]] if len(ok) else -1)
+    # one (trial, rank) cell against the oracle from the same device-drawn initial factors
+    k = 4
+    W0, H0 = ms.random_init_batched(X, k, seed=3 + k)
+    ref = orc.nmf_mu_fit(np.ascontiguousarray(Xb[5].T), W0[5].cpu().numpy(), H0[5].cpu().numpy(), max_iter=150, tol=0.0)
+    va, _ = orc.vaf(Xb[5].T.astype(np.float64), ref["W"].astype(np.float64), ref["H"].astype(np.float64))
+    assert abs(v[5, res.ranks.index(k)] - va) <= TOL
+    with pytest.raises(ValueError, match="invalid number of components"):
+        ms.rank_sweep_batched(X, 3, 17)
