@@ -81,6 +81,7 @@ struct hipnmf_handle {
   int lds_per_block = 65536;  // hipDeviceProp_t::maxSharedMemoryPerMultiProcessor (160 KiB on MI355X)
   int lds_budget = 0;         // override (bytes), 0 = all of it
   int use_lds_w = 1;
+  int use_graph = 1;
 };
 
 namespace {
@@ -209,7 +210,7 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
     o_part = carve(sizeof(real) * (size_t)B * sg.S * ks->NACC);
     o_sums = carve(sizeof(real) * (size_t)B * (k * m + k * k));
     o_col = carve(sizeof(real) * (size_t)B * sg.S * 2 * ks->MP);
-    o_state = carve(sizeof(real) * (size_t)B * 4);
+    o_state = carve(sizeof(real) * (size_t)B * 8);
   }
   rc = ensure_ws(h, std::max<size_t>(off, 256));
   if (rc) return rc;
@@ -289,7 +290,7 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
     a.S = sg.S;
     a.rows_per_slice = sg.rows_per_slice;
     a.part = reinterpret_cast<real*>(ws + o_part);
-    a.sums = reinterpret_cast<real*>(ws + o_sums);
+    a.sums = nullptr;
     a.colpart = reinterpret_cast<real*>(ws + o_col);
     const bool stop_rule = p->tol > 0;
     a.state = stop_rule ? reinterpret_cast<real*>(ws + o_state) : nullptr;
@@ -298,27 +299,63 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
     const dim3 grid2(sg.S, B);
     std::vector<real> host_state;
     if (stop_rule) {
-      HIP_TRY(hipMemsetAsync(a.state, 0, sizeof(real) * (size_t)B * 4, st));
+      HIP_TRY(hipMemsetAsync(a.state, 0, sizeof(real) * (size_t)B * 8, st));
       a.it = 0;
       launch<real>(ks->slice_resid, grid2, dim3(nt), smem, st, a);
       launch<real>(ks->resid_finalize, dim3(B), dim3(64), 0, st, a);
-      host_state.resize((size_t)B * 4);
+      host_state.resize((size_t)B * 8);
     }
-    for (int it = 1; it <= p->max_iter; ++it) {
-      a.it = it;
-      launch<real>(ks->slice_pass, grid2, dim3(nt), smem, st, a);
-      if (a.update_h) {
-        launch<real>(ks->reduce_slices, dim3(B), dim3(128), 0, st, a);
-        launch<real>(ks->hupdate, dim3(B), dim3(256), smem1, st, a);
+    // `n` iterations, optionally followed by one stop-rule evaluation (sklearn: every check_every-th iteration)
+    auto enqueue = [&](int n, bool check) {
+      for (int i = 0; i < n; ++i) {
+        launch<real>(ks->slice_pass, grid2, dim3(nt), smem, st, a);
+        if (a.update_h) launch<real>(ks->hupdate, dim3(B), dim3(256), smem1, st, a);  // sums the slice records itself
       }
-      if (stop_rule && (it % p->check_every) == 0) {
+      if (check) {
+        a.it = 1;
         launch<real>(ks->slice_resid, grid2, dim3(nt), smem, st, a);
         launch<real>(ks->resid_finalize, dim3(B), dim3(64), 0, st, a);
-        HIP_TRY(hipMemcpyAsync(host_state.data(), a.state, sizeof(real) * (size_t)B * 4, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        bool all_done = true;
-        for (int b = 0; b < B; ++b) all_done = all_done && host_state[(size_t)b * 4 + 3] != (real)0;
-        if (all_done) break;
+      }
+    };
+    auto all_converged = [&](bool* done) -> int {
+      HIP_TRY(hipMemcpyAsync(host_state.data(), a.state, sizeof(real) * (size_t)B * 8, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      *done = true;
+      for (int b = 0; b < B; ++b) *done = *done && host_state[(size_t)b * 8 + 3] != (real)0;
+      return HIPNMF_OK;
+    };
+    // The launches of one chunk are captured once into a hipGraph and replayed: this path is launch-bound
+    // (2 small kernels per iteration), and a replay costs ~1.5 us per kernel instead of ~4 us of host work.
+    const int chunk = stop_rule ? p->check_every : std::min(p->max_iter, 64);
+    int it_done = 0;
+    bool converged = false;
+    if (h->use_graph && p->max_iter >= 2 * chunk) {
+      hipGraph_t graph = nullptr;
+      hipGraphExec_t exec = nullptr;
+      HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+      enqueue(chunk, stop_rule);
+      HIP_TRY(hipStreamEndCapture(st, &graph));
+      HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+      while (!converged && it_done + chunk <= p->max_iter) {
+        HIP_TRY(hipGraphLaunch(exec, st));
+        it_done += chunk;
+        if (stop_rule) {
+          rc = all_converged(&converged);
+          if (rc) return rc;
+        }
+      }
+      HIP_TRY(hipStreamSynchronize(st));
+      (void)hipGraphExecDestroy(exec);
+      (void)hipGraphDestroy(graph);
+    }
+    while (!converged && it_done < p->max_iter) {
+      const int n = std::min(chunk, p->max_iter - it_done);
+      const bool check = stop_rule && n == chunk;
+      enqueue(n, check);
+      it_done += n;
+      if (check) {
+        rc = all_converged(&converged);
+        if (rc) return rc;
       }
     }
     a.it = -1;
@@ -494,6 +531,7 @@ int hipnmf_create(int device, hipnmf_handle** out) {
   }
   if (const char* e = getenv("HIPNMF_LDS_W")) h->use_lds_w = atoi(e) != 0;
   if (const char* e = getenv("HIPNMF_LDS_BUDGET")) h->lds_budget = atoi(e);
+  if (const char* e = getenv("HIPNMF_GRAPH")) h->use_graph = atoi(e) != 0;
   if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
     delete h;

@@ -222,7 +222,7 @@ struct SolveArgs {
   int* n_iter_out;    // [B] or nullptr
   real* sse_col_out;  // [B][m] or nullptr
   real* xsq_col_out;  // [B][m] or nullptr
-  real* state;        // [B][4] err0, prev, err, done   (multi-slice path stop rule)
+  real* state;        // [B][8] err0, prev, err, done, checks-so-far   (multi-slice path stop rule)
   int T, m, max_iter, check_every, update_h, S, rows_per_slice, it;
   int lds_rows;       // persistent kernel: rows [0, lds_rows) of W live in LDS for the whole fit
   real tol, l1w, l2w, l1h, l2h;
@@ -820,7 +820,7 @@ __global__ void __launch_bounds__((max_threads<real, G, CH, K>())) HIPNMF_OCC sl
   const int nw = blockDim.x / WAVE;
   Smem<real, G, CH, K> s(smem_raw, nw);
   const int b = blockIdx.y, sl = blockIdx.x;
-  if (a.state && a.state[(long long)b * 4 + 3] != (real)0) return;  // matrix already converged
+  if (a.state && a.state[(long long)b * 8 + 3] != (real)0) return;  // matrix already converged
   const int lane = threadIdx.x & (WAVE - 1);
   const int wave = threadIdx.x / WAVE;
   const int g = lane % G;
@@ -886,22 +886,45 @@ __global__ void reduce_slices_kernel(SolveArgs<real> a) {
   }
 }
 
-// H update of matrix b from sums[b] (k*m + k*k); one block per matrix
+// H update of matrix b; one block per matrix.  a.sums != nullptr: from the already summed
+// [W^T X | W^T W] record (time-shard path, after the caller's all-reduce); otherwise straight from the S slice
+// records of slice_pass_kernel (fixed-order sum, saves the reduce launch on the single-GPU sliced path).
 template <typename real, int G, int CH, int K>
 __global__ void hupdate_kernel(SolveArgs<real> a) {
+  using C = Cfg<real, G, CH, K>;
   constexpr int MP = G * CH;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   Smem<real, G, CH, K> s(smem_raw, 1);
   const int b = blockIdx.x, m = a.m;
-  if (a.state && a.state[(long long)b * 4 + 3] != (real)0) return;
+  if (a.state && a.state[(long long)b * 8 + 3] != (real)0) return;
   real* __restrict__ Hb = a.H + (long long)b * K * m;
-  const real* __restrict__ in = a.sums + (long long)b * (K * m + K * K);
   load_h_to_lds(s, Hb, m);
-  for (int i = threadIdx.x; i < K * MP; i += blockDim.x) {
-    const int c = i / MP, j = i % MP;
-    s.A[i] = (j < m) ? in[c * m + j] : (real)0;
+  if (a.sums) {
+    const real* __restrict__ in = a.sums + (long long)b * (K * m + K * K);
+    for (int i = threadIdx.x; i < K * MP; i += blockDim.x) {
+      const int c = i / MP, j = i % MP;
+      s.A[i] = (j < m) ? in[c * m + j] : (real)0;
+    }
+    for (int i = threadIdx.x; i < K * K; i += blockDim.x) s.B[i] = in[K * m + i];
+  } else {
+    const real* __restrict__ in = a.part + (long long)b * a.S * C::NACC;
+    for (int i = threadIdx.x; i < C::NACC; i += blockDim.x) {
+      real acc = in[i];
+      for (int sl = 1; sl < a.S; ++sl) acc += in[(long long)sl * C::NACC + i];
+      if (i < K * MP) {
+        s.A[i] = acc;
+      } else {
+        int idx = i - K * MP, c = 0;
+        while (idx >= K - c) {
+          idx -= K - c;
+          ++c;
+        }
+        const int c2 = c + idx;
+        s.B[c * K + c2] = acc;
+        s.B[c2 * K + c] = acc;
+      }
+    }
   }
-  for (int i = threadIdx.x; i < K * K; i += blockDim.x) s.B[i] = in[K * m + i];
   __syncthreads();
   h_update_lds(s, m, a.l1h, a.l2h);
   for (int i = threadIdx.x; i < K * MP; i += blockDim.x) {
@@ -918,7 +941,7 @@ __global__ void __launch_bounds__((max_threads<real, G, CH, K>())) slice_resid_k
   const int nw = blockDim.x / WAVE;
   Smem<real, G, CH, K> s(smem_raw, nw);
   const int b = blockIdx.y, sl = blockIdx.x;
-  if (a.state && a.state[(long long)b * 4 + 3] != (real)0 && a.it >= 0) return;
+  if (a.state && a.state[(long long)b * 8 + 3] != (real)0 && a.it >= 0) return;
   const int lane = threadIdx.x & (WAVE - 1);
   const int g = lane % G;
   const real* __restrict__ Xb = a.X + (long long)b * a.x_bstride;
@@ -947,7 +970,7 @@ __global__ void resid_finalize_kernel(SolveArgs<real> a) {
   constexpr int MP = G * CH;
   __shared__ real col[2 * MP];
   const int b = blockIdx.x, m = a.m;
-  real* st = a.state ? a.state + (long long)b * 4 : nullptr;
+  real* st = a.state ? a.state + (long long)b * 8 : nullptr;
   if (st && st[3] != (real)0 && a.it >= 0) return;
   const real* __restrict__ in = a.colpart + (long long)b * a.S * (2 * MP);
   if (threadIdx.x < 2 * MP) {
@@ -968,11 +991,15 @@ __global__ void resid_finalize_kernel(SolveArgs<real> a) {
       st[1] = err;
       st[2] = err;
       st[3] = (real)0;
+      st[4] = (real)0;
     } else {
+      // the iteration number is kept on the device so that a replayed hipGraph needs no new arguments
+      const int it_now = ((int)st[4] + 1) * a.check_every;
+      st[4] = st[4] + (real)1;
       st[2] = err;
       if ((st[1] - err) / st[0] < a.tol) {
         st[3] = (real)1;
-        if (a.n_iter_out) a.n_iter_out[b] = a.it;
+        if (a.n_iter_out) a.n_iter_out[b] = it_now;
       }
       st[1] = err;
     }
