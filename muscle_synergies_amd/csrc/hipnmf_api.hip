@@ -49,9 +49,13 @@ const KernelSet<real>* select_kernels(int m, int k);
 
 template <>
 const KernelSet<float>* select_kernels<float>(int m, int k) {
+  static const bool g2c8 = [] {
+    const char* e = getenv("HIPNMF_G2C8");
+    return e && atoi(e) != 0;
+  }();
   if (m <= 4) return kernels_f32_g1c4(k);
   if (m <= 8) return kernels_f32_g2c4(k);
-  if (m <= 16) return kernels_f32_g4c4(k);
+  if (m <= 16) return g2c8 ? kernels_f32_g2c8(k) : kernels_f32_g4c4(k);
   if (m <= 32) return kernels_f32_g4c8(k);
   return nullptr;
 }
