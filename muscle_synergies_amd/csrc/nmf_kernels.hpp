@@ -363,7 +363,13 @@ __device__ __forceinline__ void update_tile(RowTile<real, G, CH, K>& t, const re
 
   if (update_h) {
     // W^T X (_nmf.py:639): rows of the group broadcast lane by lane
-    static_for<G>([&](auto R) {
+    static_for<(
+#ifdef HIPNMF_EXP_HALF_ACCA
+        G / 2
+#else
+        G
+#endif
+        )>([&](auto R) {
       constexpr int r = decltype(R)::value;
 #pragma unroll
       for (int c = 0; c < K; ++c) {
@@ -373,6 +379,7 @@ __device__ __forceinline__ void update_tile(RowTile<real, G, CH, K>& t, const re
       }
     });
     // W^T W (first factor of multi_dot, _nmf.py:640), upper triangle, own row
+#ifndef HIPNMF_EXP_NO_ACCB
     int idx = 0;
 #pragma unroll
     for (int c = 0; c < K; ++c)
@@ -381,6 +388,9 @@ __device__ __forceinline__ void update_tile(RowTile<real, G, CH, K>& t, const re
         accB[idx] = fma_(wn[c], wn[c2], accB[idx]);
         ++idx;
       }
+#else
+    accB[0] += wn[0];
+#endif
   }
 }
 
