@@ -81,6 +81,11 @@ int hipnmf_set_stream(hipnmf_handle* h, void* hip_stream);/* NULL restores the h
 size_t hipnmf_workspace_bytes(const hipnmf_problem* p, int elem_size /* 4 or 8 */);
 /* Device time (HIP events on the handle's stream) of the solver kernels of the last compute call. */
 int hipnmf_last_kernel_ms(hipnmf_handle* h, float* ms);
+/* 1: compute entry points return right after enqueueing their kernels on the handle's stream (no host
+ * synchronisation; hipnmf_last_kernel_ms is then unavailable).  Used with hipnmf_set_stream(torch's current
+ * stream) by the time-sharded solver so that kernels and RCCL collectives are ordered by the stream alone.
+ * Only the shard entry points honour it; hipnmf_fit_batched_* always returns with results ready. */
+int hipnmf_set_async(hipnmf_handle* h, int enable);
 /* Tuning knobs (0 = library default): threads per workgroup (256/512/1024), max row slices per matrix. */
 int hipnmf_set_tuning(hipnmf_handle* h, int threads, int max_slices, int variant);
 

@@ -32,7 +32,7 @@ W_COMPONENT_MAJOR = 1
 #: every symbol ``include/hip_nmf.h`` declares (checked by tests/test_abi.py)
 EXPORTS = (
     "hipnmf_version", "hipnmf_last_error", "hipnmf_device_count", "hipnmf_create", "hipnmf_destroy",
-    "hipnmf_set_stream", "hipnmf_workspace_bytes", "hipnmf_last_kernel_ms", "hipnmf_set_tuning",
+    "hipnmf_set_stream", "hipnmf_workspace_bytes", "hipnmf_last_kernel_ms", "hipnmf_set_async", "hipnmf_set_tuning",
     "hipnmf_fit_batched_f32", "hipnmf_fit_batched_f64",
     "hipnmf_shard_pass_f32", "hipnmf_shard_hupdate_f32", "hipnmf_shard_residual_f32",
     "hipnmf_shard_pass_f64", "hipnmf_shard_hupdate_f64", "hipnmf_shard_residual_f64",
@@ -95,6 +95,8 @@ def _declare(lib):
     lib.hipnmf_workspace_bytes.argtypes = [pp, ip]
     lib.hipnmf_last_kernel_ms.restype = ip
     lib.hipnmf_last_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
+    lib.hipnmf_set_async.restype = ip
+    lib.hipnmf_set_async.argtypes = [vp, ip]
     lib.hipnmf_set_tuning.restype = ip
     lib.hipnmf_set_tuning.argtypes = [vp, ip, ip, ip]
     for sfx in ("f32", "f64"):
@@ -159,6 +161,9 @@ class Handle:
 
     def set_stream(self, stream_ptr):
         check(load().hipnmf_set_stream(self._h, ctypes.c_void_p(stream_ptr) if stream_ptr else None))
+
+    def set_async(self, enable: bool):
+        check(load().hipnmf_set_async(self._h, int(bool(enable))))
 
     def last_kernel_ms(self) -> float:
         ms = ctypes.c_float()

@@ -86,6 +86,7 @@ struct hipnmf_handle {
   int lds_budget = 0;         // override (bytes), 0 = all of it
   int use_lds_w = 1;
   int use_graph = 1;
+  int async_mode = 0;
 };
 
 namespace {
@@ -448,13 +449,16 @@ int shard_pass_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
   if (rc) return rc;
   a.sums = sums;
   hipStream_t st = h->stream;
-  HIP_TRY(hipEventRecord(h->ev0, st));
+  const bool async = h->async_mode != 0;
+  if (!async) HIP_TRY(hipEventRecord(h->ev0, st));
   launch<real>(ks->slice_pass, dim3(sg.S, p->batch), dim3(sg.threads), ks->smem_bytes(sg.threads / 64), st, a);
   if (a.update_h) launch<real>(ks->reduce_slices, dim3(p->batch), dim3(128), 0, st, a);
-  HIP_TRY(hipEventRecord(h->ev1, st));
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipStreamSynchronize(st));
-  HIP_TRY(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
+  if (!async) {
+    HIP_TRY(hipEventRecord(h->ev1, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
+  }
   return HIPNMF_OK;
 }
 
@@ -468,12 +472,15 @@ int shard_hupdate_impl(hipnmf_handle* h, const hipnmf_problem* p, real* H, const
   if (rc) return rc;
   a.sums = const_cast<real*>(sums);
   hipStream_t st = h->stream;
-  HIP_TRY(hipEventRecord(h->ev0, st));
+  const bool async = h->async_mode != 0;
+  if (!async) HIP_TRY(hipEventRecord(h->ev0, st));
   launch<real>(ks->hupdate, dim3(p->batch), dim3(256), ks->smem_bytes(1), st, a);
-  HIP_TRY(hipEventRecord(h->ev1, st));
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipStreamSynchronize(st));
-  HIP_TRY(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
+  if (!async) {
+    HIP_TRY(hipEventRecord(h->ev1, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
+  }
   return HIPNMF_OK;
 }
 
@@ -490,13 +497,16 @@ int shard_residual_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X
   a.xsq_col_out = xsq_col;
   a.it = -1;
   hipStream_t st = h->stream;
-  HIP_TRY(hipEventRecord(h->ev0, st));
+  const bool async = h->async_mode != 0;
+  if (!async) HIP_TRY(hipEventRecord(h->ev0, st));
   launch<real>(ks->slice_resid, dim3(sg.S, p->batch), dim3(sg.threads), ks->smem_bytes(sg.threads / 64), st, a);
   launch<real>(ks->resid_finalize, dim3(p->batch), dim3(64), 0, st, a);
-  HIP_TRY(hipEventRecord(h->ev1, st));
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipStreamSynchronize(st));
-  HIP_TRY(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
+  if (!async) {
+    HIP_TRY(hipEventRecord(h->ev1, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
+  }
   return HIPNMF_OK;
 }
 
@@ -575,6 +585,12 @@ size_t hipnmf_workspace_bytes(const hipnmf_problem* p, int elem_size) {
 int hipnmf_last_kernel_ms(hipnmf_handle* h, float* ms) {
   if (!h || !ms) return fail(HIPNMF_ERR_BAD_ARG, "NULL argument");
   *ms = h->last_ms;
+  return HIPNMF_OK;
+}
+
+int hipnmf_set_async(hipnmf_handle* h, int enable) {
+  if (!h) return fail(HIPNMF_ERR_BAD_ARG, "handle is NULL");
+  h->async_mode = enable ? 1 : 0;
   return HIPNMF_OK;
 }
 

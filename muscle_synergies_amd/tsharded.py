@@ -73,7 +73,11 @@ class HipShardOps:
         self.sums = torch.empty((self.B, self.k * self.m + self.k * self.k), dtype=self.dtype, device=self.dev)
         self.sse = torch.empty((self.B, self.m), dtype=self.dtype, device=self.dev)
         self.xsq = torch.empty((self.B, self.m), dtype=self.dtype, device=self.dev)
-        self.handle = _lib.get_handle(self.dev.index)
+        # a private handle bound to torch's current stream, asynchronous: kernels, torch ops and the RCCL
+        # all-reduce are then ordered by that one stream, with no host synchronisation inside an iteration
+        self.handle = _lib.Handle(self.dev.index)
+        self.handle.set_stream(torch.cuda.current_stream(self.dev).cuda_stream)
+        self.handle.set_async(True)
         self.p = make_problem(self.B, self.ld, self.m, self.k, x_layout=_lib.X_CHANNEL_MAJOR, ldx=self.ld,
                               x_batch_stride=self.m * self.ld, w_layout=_lib.W_COMPONENT_MAJOR, update_H=update_H,
                               max_iter=1, tol=0.0, l1_reg_W=l1_reg_W, l1_reg_H=l1_reg_H, l2_reg_W=l2_reg_W,

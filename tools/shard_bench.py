@@ -25,3 +25,14 @@ for rep in range(2):
     dt = time.perf_counter() - t0
     gb = a.iters * 4 * a.T * 26 / 1e9
     print(f"T={a.T} iters={a.iters} wall={dt*1e3:.1f} ms -> {dt/a.iters*1e3:.3f} ms/iter, {gb/dt:.0f} GB/s algorithmic, err={float(res.reconstruction_err[0]):.3f}", flush=True)
+
+# pure pass / h-update timings on the stream (no Python loop overhead between events)
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+for name, fn, n in (("shard_pass", ops.shard_pass, 10), ("h_update", lambda: ops.h_update(ops.sums), 50), ("residual", ops.residual, 10)):
+    fn(); torch.cuda.synchronize()
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / n
+    print(f"{name}: {ms:.3f} ms per call" + (f" = {4*a.T*26/1e9/(ms*1e-3):.0f} GB/s algorithmic" if name == "shard_pass" else ""), flush=True)
