@@ -77,6 +77,7 @@ const char* hipnmf_last_error(void);
 int hipnmf_device_count(void);                            /* <0 on error (no ROCm device / driver)     */
 int hipnmf_create(int device, hipnmf_handle** out);       /* own stream + workspace on `device`        */
 int hipnmf_destroy(hipnmf_handle* h);
+#define HIPNMF_STREAM_NULL ((void*)1)                    /* the device's default (null) HIP stream    */
 int hipnmf_set_stream(hipnmf_handle* h, void* hip_stream);/* NULL restores the handle's own stream     */
 size_t hipnmf_workspace_bytes(const hipnmf_problem* p, int elem_size /* 4 or 8 */);
 /* Device time (HIP events on the handle's stream) of the solver kernels of the last compute call. */

@@ -160,7 +160,13 @@ class Handle:
         check(load().hipnmf_set_tuning(self._h, int(threads), int(max_slices), int(variant)))
 
     def set_stream(self, stream_ptr):
-        check(load().hipnmf_set_stream(self._h, ctypes.c_void_p(stream_ptr) if stream_ptr else None))
+        """``stream_ptr``: a ``hipStream_t`` as int; 0 = the device's default (null) stream; None = the
+        handle's own stream."""
+        if stream_ptr is None:
+            arg = None
+        else:
+            arg = ctypes.c_void_p(int(stream_ptr) if stream_ptr else 1)  # HIPNMF_STREAM_NULL
+        check(load().hipnmf_set_stream(self._h, arg))
 
     def set_async(self, enable: bool):
         check(load().hipnmf_set_async(self._h, int(bool(enable))))

@@ -570,7 +570,10 @@ int hipnmf_destroy(hipnmf_handle* h) {
 
 int hipnmf_set_stream(hipnmf_handle* h, void* hip_stream) {
   if (!h) return fail(HIPNMF_ERR_BAD_ARG, "handle is NULL");
-  h->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : h->own_stream;
+  if (hip_stream == HIPNMF_STREAM_NULL)
+    h->stream = nullptr;  // legacy default stream
+  else
+    h->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : h->own_stream;
   return HIPNMF_OK;
 }
 
