@@ -151,7 +151,7 @@ SliceGeom slice_geometry(const hipnmf_handle* h, long long T, int B) {
   g.threads = 256;
   const long long quantum = g.threads;  // 64 rows per wave-step x waves
   const long long t_pad = round_up(T, 64);
-  const long long target_wgs = 8LL * h->num_cu;
+  const long long target_wgs = 4LL * h->num_cu;
   long long rps = round_up(std::max<long long>(2 * quantum, (t_pad * B + target_wgs - 1) / target_wgs), quantum);
   long long S = (t_pad + rps - 1) / rps;
   const long long cap = h->max_slices > 0 ? h->max_slices : 4096;
@@ -307,19 +307,19 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
       HIP_TRY(hipMemsetAsync(a.state, 0, sizeof(real) * (size_t)B * 8, st));
       a.it = 0;
       launch<real>(ks->slice_resid, grid2, dim3(nt), smem, st, a);
-      launch<real>(ks->resid_finalize, dim3(B), dim3(64), 0, st, a);
+      launch<real>(ks->resid_finalize, dim3(B), dim3(1024), 0, st, a);
       host_state.resize((size_t)B * 8);
     }
     // `n` iterations, optionally followed by one stop-rule evaluation (sklearn: every check_every-th iteration)
     auto enqueue = [&](int n, bool check) {
       for (int i = 0; i < n; ++i) {
         launch<real>(ks->slice_pass, grid2, dim3(nt), smem, st, a);
-        if (a.update_h) launch<real>(ks->hupdate, dim3(B), dim3(256), smem1, st, a);  // sums the slice records itself
+        if (a.update_h) launch<real>(ks->hupdate, dim3(B), dim3(1024), smem1, st, a);  // sums the slice records itself
       }
       if (check) {
         a.it = 1;
         launch<real>(ks->slice_resid, grid2, dim3(nt), smem, st, a);
-        launch<real>(ks->resid_finalize, dim3(B), dim3(64), 0, st, a);
+        launch<real>(ks->resid_finalize, dim3(B), dim3(1024), 0, st, a);
       }
     };
     auto all_converged = [&](bool* done) -> int {
@@ -365,7 +365,7 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
     }
     a.it = -1;
     launch<real>(ks->slice_resid, grid2, dim3(nt), smem, st, a);
-    launch<real>(ks->resid_finalize, dim3(B), dim3(64), 0, st, a);
+    launch<real>(ks->resid_finalize, dim3(B), dim3(1024), 0, st, a);
   }
   HIP_TRY(hipEventRecord(h->ev1, st));
   if (!w_inplace) {
@@ -452,7 +452,7 @@ int shard_pass_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
   const bool async = h->async_mode != 0;
   if (!async) HIP_TRY(hipEventRecord(h->ev0, st));
   launch<real>(ks->slice_pass, dim3(sg.S, p->batch), dim3(sg.threads), ks->smem_bytes(sg.threads / 64), st, a);
-  if (a.update_h) launch<real>(ks->reduce_slices, dim3(p->batch), dim3(128), 0, st, a);
+  if (a.update_h) launch<real>(ks->reduce_slices, dim3(p->batch), dim3(1024), 0, st, a);
   HIP_TRY(hipGetLastError());
   if (!async) {
     HIP_TRY(hipEventRecord(h->ev1, st));
@@ -474,7 +474,7 @@ int shard_hupdate_impl(hipnmf_handle* h, const hipnmf_problem* p, real* H, const
   hipStream_t st = h->stream;
   const bool async = h->async_mode != 0;
   if (!async) HIP_TRY(hipEventRecord(h->ev0, st));
-  launch<real>(ks->hupdate, dim3(p->batch), dim3(256), ks->smem_bytes(1), st, a);
+  launch<real>(ks->hupdate, dim3(p->batch), dim3(1024), ks->smem_bytes(1), st, a);
   HIP_TRY(hipGetLastError());
   if (!async) {
     HIP_TRY(hipEventRecord(h->ev1, st));
@@ -500,7 +500,7 @@ int shard_residual_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X
   const bool async = h->async_mode != 0;
   if (!async) HIP_TRY(hipEventRecord(h->ev0, st));
   launch<real>(ks->slice_resid, dim3(sg.S, p->batch), dim3(sg.threads), ks->smem_bytes(sg.threads / 64), st, a);
-  launch<real>(ks->resid_finalize, dim3(p->batch), dim3(64), 0, st, a);
+  launch<real>(ks->resid_finalize, dim3(p->batch), dim3(1024), 0, st, a);
   HIP_TRY(hipGetLastError());
   if (!async) {
     HIP_TRY(hipEventRecord(h->ev1, st));

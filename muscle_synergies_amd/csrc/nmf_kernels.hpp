@@ -870,13 +870,38 @@ __global__ void __launch_bounds__((max_threads<real, G, CH, K>())) HIPNMF_OCC sl
   }
 }
 
+// Fixed-order parallel sum of S slice records of `nout` values each (record stride `stride`):
+// thread (q, o) adds slices q, q+nq, q+2nq, ... of output o; the nq partial sums are then added in order.
+// scratch: blockDim.x values of LDS.  Result for output o is returned to threads o < nout (others get 0).
+template <typename real>
+__device__ __forceinline__ real block_sum_slices(const real* __restrict__ in, long long stride, int S, int nout,
+                                                 real* scratch) {
+  const int nq = blockDim.x / nout > 0 ? blockDim.x / nout : 1;
+  const int o = threadIdx.x % nout, q = threadIdx.x / nout;
+  real acc = (real)0;
+  if (q < nq)
+    for (int sl = q; sl < S; sl += nq) acc += in[(long long)sl * stride + o];
+  __syncthreads();
+  if (q < nq) scratch[q * nout + o] = acc;
+  __syncthreads();
+  real tot = (real)0;
+  if (threadIdx.x < nout)
+    for (int i = 0; i < nq; ++i) tot += scratch[i * nout + threadIdx.x];
+  return tot;
+}
+
 // sums[b] = [ W^T X (k x m) | W^T W (k x k, full) ] = fixed-order sum of the slice records
 template <typename real, int G, int CH, int K>
 __global__ void reduce_slices_kernel(SolveArgs<real> a) {
   using C = Cfg<real, G, CH, K>;
+  __shared__ real scratch[1024];
+  __shared__ real tot[C::NACC];
   const int b = blockIdx.x, m = a.m;
   const real* __restrict__ in = a.part + (long long)b * a.S * C::NACC;
   real* __restrict__ out = a.sums + (long long)b * (K * m + K * K);
+  const real t = block_sum_slices<real>(in, C::NACC, a.S, C::NACC, scratch);
+  if (threadIdx.x < C::NACC) tot[threadIdx.x] = t;
+  __syncthreads();
   for (int i = threadIdx.x; i < K * m + K * K; i += blockDim.x) {
     int src;
     if (i < K * m) {
@@ -884,15 +909,13 @@ __global__ void reduce_slices_kernel(SolveArgs<real> a) {
     } else {
       int c = (i - K * m) / K, c2 = (i - K * m) % K;
       if (c > c2) {
-        const int t = c;
+        const int tmp = c;
         c = c2;
-        c2 = t;
+        c2 = tmp;
       }
       src = K * C::MP + c * K - c * (c - 1) / 2 + (c2 - c);
     }
-    real acc = in[src];
-    for (int sl = 1; sl < a.S; ++sl) acc += in[(long long)sl * C::NACC + src];
-    out[i] = acc;
+    out[i] = tot[src];
   }
 }
 
@@ -918,10 +941,12 @@ __global__ void hupdate_kernel(SolveArgs<real> a) {
     for (int i = threadIdx.x; i < K * K; i += blockDim.x) s.B[i] = in[K * m + i];
   } else {
     const real* __restrict__ in = a.part + (long long)b * a.S * C::NACC;
-    for (int i = threadIdx.x; i < C::NACC; i += blockDim.x) {
-      real acc = in[i];
-      for (int sl = 1; sl < a.S; ++sl) acc += in[(long long)sl * C::NACC + i];
-      if (i < K * MP) {
+    __shared__ real scratch[1024];
+    const real acc = block_sum_slices<real>(in, C::NACC, a.S, C::NACC, scratch);
+    {
+      const int i = threadIdx.x;
+      if (i >= C::NACC) {
+      } else if (i < K * MP) {
         s.A[i] = acc;
       } else {
         int idx = i - K * MP, c = 0;
@@ -983,11 +1008,9 @@ __global__ void resid_finalize_kernel(SolveArgs<real> a) {
   real* st = a.state ? a.state + (long long)b * 8 : nullptr;
   if (st && st[3] != (real)0 && a.it >= 0) return;
   const real* __restrict__ in = a.colpart + (long long)b * a.S * (2 * MP);
-  if (threadIdx.x < 2 * MP) {
-    real acc = in[threadIdx.x];
-    for (int sl = 1; sl < a.S; ++sl) acc += in[(long long)sl * 2 * MP + threadIdx.x];
-    col[threadIdx.x] = acc;
-  }
+  __shared__ real scratch[1024];
+  const real colsum = block_sum_slices<real>(in, 2 * MP, a.S, 2 * MP, scratch);
+  if (threadIdx.x < 2 * MP) col[threadIdx.x] = colsum;
   __syncthreads();
   if (threadIdx.x == 0) {
     real tot = (real)0;
