@@ -117,7 +117,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
-    distributed = world > 1
+    distributed = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ  # under torchrun always use the process group
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
