@@ -135,6 +135,21 @@ int validate(const hipnmf_problem* p, bool shard) {
   return HIPNMF_OK;
 }
 
+// One matrix is addressed through a 32-bit buffer resource with 0x80000000 as the out-of-range sentinel:
+// X (and W) of a single matrix must stay below 2 GiB.  Longer recordings are time-sharded (tsharded.py).
+template <typename real>
+int check_matrix_bytes(const hipnmf_problem* p) {
+  const long long ld = std::max<long long>(p->x_layout == HIPNMF_X_CHANNEL_MAJOR ? p->ldx : 0, p->n_samples + 64);
+  const long long xbytes = (long long)p->n_features * ld * (long long)sizeof(real);
+  const long long wbytes = (long long)p->n_components * (p->n_samples + 64) * (long long)sizeof(real);
+  if (xbytes >= (1LL << 31) || wbytes >= (1LL << 31))
+    return fail(HIPNMF_ERR_UNSUPPORTED,
+                "one matrix needs %lld bytes of X and %lld of W; the engine addresses < 2 GiB per matrix -- "
+                "shard the time axis (hipnmf_shard_* / muscle_synergies_amd.tsharded)",
+                xbytes, wbytes);
+  return HIPNMF_OK;
+}
+
 template <typename real>
 void launch(typename KernelSet<real>::Fn fn, dim3 grid, dim3 block, size_t smem, hipStream_t st,
             const SolveArgs<real>& a) {
@@ -176,6 +191,8 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
   const long long T = p->n_samples;
   const KernelSet<real>* ks = select_kernels<real>(m, k);
   if (!ks) return fail(HIPNMF_ERR_UNSUPPORTED, "no kernel for n_features=%d n_components=%d", m, k);
+  rc = check_matrix_bytes<real>(p);
+  if (rc) return rc;
   hipStream_t st = h->stream;
 
   // ---- path selection ---------------------------------------------------------------------------
@@ -394,6 +411,8 @@ int shard_common(hipnmf_handle* h, const hipnmf_problem* p, const KernelSet<real
   if (!ks) return fail(HIPNMF_ERR_UNSUPPORTED, "no kernel for n_features=%d n_components=%d", m, k);
   if (p->w_layout != HIPNMF_W_COMPONENT_MAJOR)
     return fail(HIPNMF_ERR_UNSUPPORTED, "shard entry points need w_layout = HIPNMF_W_COMPONENT_MAJOR");
+  rc = check_matrix_bytes<real>(p);
+  if (rc) return rc;
   if (X) {
     if (p->x_layout != HIPNMF_X_CHANNEL_MAJOR || (p->ldx % 4) != 0 || (T % ks->G) != 0 ||
         (reinterpret_cast<uintptr_t>(X) % 16) != 0 || ((p->x_batch_stride * (long long)sizeof(real)) % 16) != 0)

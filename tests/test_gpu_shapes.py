@@ -206,3 +206,49 @@ def test_rank_sweep_matches_per_rank_fits():
     assert abs(v[5, res.ranks.index(k)] - va) <= TOL
     with pytest.raises(ValueError, match="invalid number of components"):
         ms.rank_sweep_batched(X, 3, 17)
+
+
+def test_oversize_matrix_is_rejected_not_mangled():
+    """A single matrix >= 2 GiB cannot be addressed by one buffer resource: loud error, pointing at sharding."""
+    import ctypes
+
+    import torch
+
+    from muscle_synergies_amd import _lib
+    from muscle_synergies_amd.engine import make_problem
+
+    T = 40_000_000  # 16 x 4e7 x 4 B = 2.56 GB
+    p = make_problem(1, T, 16, 5, x_layout=_lib.X_CHANNEL_MAJOR, ldx=T, x_batch_stride=16 * T)
+    dummy = torch.zeros(16, device="cuda")
+    h = _lib.get_handle(0)
+    rc = _lib.load().hipnmf_fit_batched_f32(h.ptr, ctypes.byref(p), dummy.data_ptr(), dummy.data_ptr(), dummy.data_ptr(),
+                                            None, None, None, None)
+    assert rc == _lib.HIPNMF_ERR_UNSUPPORTED
+    assert b"shard the time axis" in _lib.load().hipnmf_last_error()
+
+
+def test_bad_arguments_are_reported():
+    import ctypes
+
+    import torch
+
+    from muscle_synergies_amd import _lib
+    from muscle_synergies_amd.engine import make_problem
+
+    lib, h = _lib.load(), _lib.get_handle(0)
+    d = torch.zeros(1024, device="cuda")
+    ok = dict(x_layout=_lib.X_ROW_MAJOR, ldx=8, x_batch_stride=80)
+    for kwargs, code in ((dict(ok, max_iter=0), _lib.HIPNMF_ERR_BAD_ARG), (dict(ok, tol=-1.0), _lib.HIPNMF_ERR_BAD_ARG),
+                         (dict(ok, ldx=4), _lib.HIPNMF_ERR_BAD_ARG)):
+        p = make_problem(1, 10, 8, 2, **kwargs)
+        assert lib.hipnmf_fit_batched_f32(h.ptr, ctypes.byref(p), d.data_ptr(), d.data_ptr(), d.data_ptr(), None, None,
+                                          None, None) == code
+    p = make_problem(1, 10, 40, 2, x_layout=_lib.X_ROW_MAJOR, ldx=40, x_batch_stride=400)
+    assert lib.hipnmf_fit_batched_f32(h.ptr, ctypes.byref(p), d.data_ptr(), d.data_ptr(), d.data_ptr(), None, None, None,
+                                      None) == _lib.HIPNMF_ERR_UNSUPPORTED
+    p = make_problem(1, 10, 8, 2, **ok)
+    p.struct_size = 8
+    assert lib.hipnmf_fit_batched_f32(h.ptr, ctypes.byref(p), d.data_ptr(), d.data_ptr(), d.data_ptr(), None, None, None,
+                                      None) == _lib.HIPNMF_ERR_BAD_ARG
+    assert lib.hipnmf_fit_batched_f32(h.ptr, ctypes.byref(make_problem(1, 10, 8, 2, **ok)), None, d.data_ptr(), d.data_ptr(),
+                                      None, None, None, None) == _lib.HIPNMF_ERR_BAD_ARG
