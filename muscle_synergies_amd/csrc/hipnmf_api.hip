@@ -53,6 +53,11 @@ const KernelSet<float>* select_kernels<float>(int m, int k) {
     const char* e = getenv("HIPNMF_G2C8");
     return e && atoi(e) != 0;
   }();
+  static const bool g1c16 = [] {
+    const char* e = getenv("HIPNMF_G1C16");
+    return e && atoi(e) != 0;
+  }();
+  if (g1c16 && m > 8 && m <= 16) return kernels_f32_g1c16(k);
   if (m <= 4) return kernels_f32_g1c4(k);
   if (m <= 8) return kernels_f32_g2c4(k);
   if (m <= 16) return g2c8 ? kernels_f32_g2c8(k) : kernels_f32_g4c4(k);

@@ -191,11 +191,19 @@ __device__ __forceinline__ void buf_store(rsrc_t r, unsigned voff, unsigned soff
 // Largest workgroup a kernel instance is compiled for.  512 threads = 2 waves/SIMD caps the allocation at 256
 // VGPRs; instances whose live state cannot fit (fp64, m > 16 or large k) are compiled for 256 threads
 // (1 wave/SIMD, up to 512 VGPRs) instead of spilling to scratch.
+// Row-per-lane instances (G == 1 with >= 16 channels per lane) read H from LDS (wave-uniform broadcast reads,
+// re-issued per tile) instead of holding K x CH values in VGPRs: no cross-lane work at all in the row loop.
+template <int G, int CH>
+constexpr bool h_in_lds() {
+  return G == 1 && CH >= 16;
+}
+
 template <typename real, int G, int CH, int K>
 constexpr int max_threads() {
   constexpr int words = (int)(sizeof(real) / 4);
-  constexpr int est = words * (2 * K * CH + K * (K + 1) / 2 + 3 * G * CH + G * K + 40);
-  return est > 210 ? 256 : (HIPNMF_MAXNT);
+  constexpr int est = words * ((h_in_lds<G, CH>() ? 1 : 2) * K * CH + K * (K + 1) / 2 + 3 * G * CH + G * K + 40 +
+                               (h_in_lds<G, CH>() ? 24 : 0));
+  return est > 215 ? 256 : (HIPNMF_MAXNT);
 }
 
 template <typename real, int G, int CH, int K>
@@ -247,10 +255,12 @@ struct MatAddr {
   int T, lane, g;
   real* lds_w;        // [K][lds_rows] component-major W cache in LDS (persistent kernel), or nullptr
   int lds_rows;
+  const real* h_lds;  // LDS copy of H ([K][MP]), read per tile by the h_in_lds instances
   __device__ __forceinline__ MatAddr(const real* Xb, long long ldx, const real* Wb, long long ldw, int T_, int m,
                                      real* lds_w_ = nullptr, int lds_rows_ = 0) {
     lds_w = lds_w_;
     lds_rows = lds_rows_;
+    h_lds = nullptr;
     lane = threadIdx.x & (WAVE - 1);
     g = lane % G;
     T = T_;
@@ -327,20 +337,34 @@ __device__ __forceinline__ void reduce_scatter(real (&pn)[G][K], int g) {
 
 // One step: W-update of the lane's row and accumulation of W^T X (lane's channels) and W^T W (own row).
 template <typename real, int G, int CH, int K>
-__device__ __forceinline__ void update_tile(RowTile<real, G, CH, K>& t, const real (&h)[K][CH], const real (&hht)[K][K],
-                                            real (&accA)[K][CH], real (&accB)[Cfg<real, G, CH, K>::NB], int g,
+__device__ __forceinline__ void update_tile(RowTile<real, G, CH, K>& t, const MatAddr<real, G, CH, K>& ma,
+                                            const real (&h)[K][CH], const real (&hht)[K][K],
+                                            real (&accA)[K][CH], real (&accB)[Cfg<real, G, CH, K>::NB],
                                             real l1w, real l2w, bool update_h) {
+  const int g = ma.g;
   // numerator X H^T (_nmf.py:543): partial over this lane's channels, for each of the G rows
   real pn[G][K];
-#pragma unroll
-  for (int r = 0; r < G; ++r)
+  if constexpr (h_in_lds<G, CH>()) {
+    const real* hp = ma.h_lds;
+    asm volatile("" : "+v"(hp));  // opaque per tile: keeps the K*CH broadcast reads inside the row loop
 #pragma unroll
     for (int c = 0; c < K; ++c) {
-      real s = t.x[0][r] * h[c][0];
+      real s = t.x[0][0] * hp[c * CH];
 #pragma unroll
-      for (int cc = 1; cc < CH; ++cc) s = fma_(t.x[cc][r], h[c][cc], s);
-      pn[r][c] = s;
+      for (int cc = 1; cc < CH; ++cc) s = fma_(t.x[cc][0], hp[c * CH + cc], s);
+      pn[0][c] = s;
     }
+  } else {
+#pragma unroll
+    for (int r = 0; r < G; ++r)
+#pragma unroll
+      for (int c = 0; c < K; ++c) {
+        real s = t.x[0][r] * h[c][0];
+#pragma unroll
+        for (int cc = 1; cc < CH; ++cc) s = fma_(t.x[cc][r], h[c][cc], s);
+        pn[r][c] = s;
+      }
+  }
   reduce_scatter<G / 2, real, G, K>(pn, g);
 
   // denominator W (H H^T) (_nmf.py:553-554), regularisation (:616-619), zero guard (:620), update (:622-629)
@@ -396,8 +420,22 @@ __device__ __forceinline__ void update_tile(RowTile<real, G, CH, K>& t, const re
 
 // residual of the group's rows restricted to this lane's channels: sse += (x - w.h)^2, xsq += x^2
 template <typename real, int G, int CH, int K>
-__device__ __forceinline__ void resid_tile(const RowTile<real, G, CH, K>& t, const real (&h)[K][CH], real (&sse)[CH],
-                                           real (&xsq)[CH]) {
+__device__ __forceinline__ void resid_tile(const RowTile<real, G, CH, K>& t, const MatAddr<real, G, CH, K>& ma,
+                                           const real (&h)[K][CH], real (&sse)[CH], real (&xsq)[CH]) {
+  if constexpr (h_in_lds<G, CH>()) {
+    const real* hp = ma.h_lds;
+    asm volatile("" : "+v"(hp));
+#pragma unroll
+    for (int cc = 0; cc < CH; ++cc) {
+      real rec = t.w[0] * hp[cc];
+#pragma unroll
+      for (int c = 1; c < K; ++c) rec = fma_(t.w[c], hp[c * CH + cc], rec);
+      const real d = t.x[cc][0] - rec;
+      sse[cc] = fma_(d, d, sse[cc]);
+      xsq[cc] = fma_(t.x[cc][0], t.x[cc][0], xsq[cc]);
+    }
+    return;
+  }
   static_for<G>([&](auto R) {
     constexpr int r = decltype(R)::value;
     real wr[K];
@@ -462,10 +500,12 @@ __device__ __forceinline__ void compute_hht(Smem<real, G, CH, K>& s) {
 template <typename real, int G, int CH, int K>
 __device__ __forceinline__ void load_h_regs(const Smem<real, G, CH, K>& s, int g, real (&h)[K][CH], real (&hht)[K][K]) {
   constexpr int MP = G * CH;
+  if constexpr (!h_in_lds<G, CH>()) {
 #pragma unroll
-  for (int c = 0; c < K; ++c)
+    for (int c = 0; c < K; ++c)
 #pragma unroll
-    for (int cc = 0; cc < CH; ++cc) h[c][cc] = s.H[c * MP + g * CH + cc];
+      for (int cc = 0; cc < CH; ++cc) h[c][cc] = s.H[c * MP + g * CH + cc];
+  }
 #pragma unroll
   for (int c = 0; c < K; ++c)
 #pragma unroll
@@ -521,7 +561,7 @@ __device__ __forceinline__ void rows_update_pass(const MatAddr<real, G, CH, K>& 
   for (int grp = 0; grp < nfull; ++grp) {
 #pragma unroll
     for (int p = 0; p < PF; ++p) {
-      update_tile<real, G, CH, K>(tiles[p], h, hht, accA, accB, ma.g, l1w, l2w, update_h);
+      update_tile<real, G, CH, K>(tiles[p], ma, h, hht, accA, accB, l1w, l2w, update_h);
       store_w<real, G, CH, K, WLDS>(tiles[p], ma, wbase);
       const int nb = wbase + PF * stride;
       load_tile<real, G, CH, K, WLDS>(tiles[p], ma, nb, nb < row_end);
@@ -534,7 +574,7 @@ __device__ __forceinline__ void rows_update_pass(const MatAddr<real, G, CH, K>& 
 #pragma unroll
   for (int p = 0; p < PF - 1; ++p) {
     if (p < rem) {  // wave-uniform
-      update_tile<real, G, CH, K>(tiles[p], h, hht, accA, accB, ma.g, l1w, l2w, update_h);
+      update_tile<real, G, CH, K>(tiles[p], ma, h, hht, accA, accB, l1w, l2w, update_h);
       store_w<real, G, CH, K, WLDS>(tiles[p], ma, wbase);
       wbase += stride;
     }
@@ -554,11 +594,11 @@ __device__ __forceinline__ void rows_resid_pass(const MatAddr<real, G, CH, K>& m
   load_tile<real, G, CH, K, WLDS>(ta, ma, wbase, true);
   while (true) {
     load_tile<real, G, CH, K, WLDS>(tb, ma, wbase + stride, wbase + stride < row_end);
-    resid_tile<real, G, CH, K>(ta, h, sse, xsq);
+    resid_tile<real, G, CH, K>(ta, ma, h, sse, xsq);
     wbase += stride;
     if (wbase >= row_end) break;
     load_tile<real, G, CH, K, WLDS>(ta, ma, wbase + stride, wbase + stride < row_end);
-    resid_tile<real, G, CH, K>(tb, h, sse, xsq);
+    resid_tile<real, G, CH, K>(tb, ma, h, sse, xsq);
     wbase += stride;
     if (wbase >= row_end) break;
   }
@@ -729,7 +769,8 @@ __global__ void __launch_bounds__((max_threads<real, G, CH, K>())) HIPNMF_OCC fi
   // W cache: rows [0, lds_rows) stay in LDS for the whole fit (lds_rows is a multiple of blockDim.x)
   real* lds_w = reinterpret_cast<real*>(smem_raw + ((Smem<real, G, CH, K>::bytes(nw) + 15) / 16) * 16);
   const int lds_rows = a.lds_rows;
-  const MatAddr<real, G, CH, K> ma(Xb, a.ldx, Wb, a.ldw, T, m, lds_w, lds_rows);
+  MatAddr<real, G, CH, K> ma(Xb, a.ldx, Wb, a.ldw, T, m, lds_w, lds_rows);
+  ma.h_lds = s.H;
   for (int t0 = 0; t0 < lds_rows; t0 += blockDim.x) {  // row t0 + tid is owned by this thread in every pass
     const int t = t0 + threadIdx.x;
 #pragma unroll
@@ -855,7 +896,8 @@ __global__ void __launch_bounds__((max_threads<real, G, CH, K>())) HIPNMF_OCC sl
     for (int cc = 0; cc < CH; ++cc) accA[c][cc] = (real)0;
 #pragma unroll
   for (int i = 0; i < C::NB; ++i) accB[i] = (real)0;
-  const MatAddr<real, G, CH, K> ma(Xb, a.ldx, Wb, a.ldw, a.T, a.m);
+  MatAddr<real, G, CH, K> ma(Xb, a.ldx, Wb, a.ldw, a.T, a.m);
+  ma.h_lds = s.H;
   RowTile<real, G, CH, K> tiles_glb[PipeDepth<false>::value];
   rows_update_pass<real, G, CH, K, false, false>(ma, row_begin, row_end, h, hht, accA, accB, a.l1w, a.l2w,
                                                  a.update_h != 0, tiles_glb);
@@ -993,7 +1035,8 @@ __global__ void __launch_bounds__((max_threads<real, G, CH, K>())) slice_resid_k
   for (int c = 0; c < K; ++c)
 #pragma unroll
     for (int cc = 0; cc < CH; ++cc) h[c][cc] = s.H[c * MP + g * CH + cc];
-  const MatAddr<real, G, CH, K> ma(Xb, a.ldx, Wb, a.ldw, a.T, a.m);
+  MatAddr<real, G, CH, K> ma(Xb, a.ldx, Wb, a.ldw, a.T, a.m);
+  ma.h_lds = s.H;
   block_residual<real, G, CH, K>(s, ma, row_begin, row_end, h);
   real* __restrict__ out = a.colpart + ((long long)b * a.S + sl) * (2 * MP);
   if (threadIdx.x < 2 * MP) out[threadIdx.x] = s.part[threadIdx.x];
