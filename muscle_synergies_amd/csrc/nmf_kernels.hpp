@@ -387,13 +387,7 @@ __device__ __forceinline__ void update_tile(RowTile<real, G, CH, K>& t, const Ma
 
   if (update_h) {
     // W^T X (_nmf.py:639): rows of the group broadcast lane by lane
-    static_for<(
-#ifdef HIPNMF_EXP_HALF_ACCA
-        G / 2
-#else
-        G
-#endif
-        )>([&](auto R) {
+    static_for<G>([&](auto R) {
       constexpr int r = decltype(R)::value;
 #pragma unroll
       for (int c = 0; c < K; ++c) {
@@ -403,7 +397,6 @@ __device__ __forceinline__ void update_tile(RowTile<real, G, CH, K>& t, const Ma
       }
     });
     // W^T W (first factor of multi_dot, _nmf.py:640), upper triangle, own row
-#ifndef HIPNMF_EXP_NO_ACCB
     int idx = 0;
 #pragma unroll
     for (int c = 0; c < K; ++c)
@@ -412,9 +405,6 @@ __device__ __forceinline__ void update_tile(RowTile<real, G, CH, K>& t, const Ma
         accB[idx] = fma_(wn[c], wn[c2], accB[idx]);
         ++idx;
       }
-#else
-    accB[0] += wn[0];
-#endif
   }
 }
 
