@@ -127,6 +127,34 @@ int hipnmf_shard_hupdate_f64(hipnmf_handle* h, const hipnmf_problem* p, double* 
 int hipnmf_shard_residual_f64(hipnmf_handle* h, const hipnmf_problem* p, const double* X, const double* W,
                               const double* H, double* sse_col, double* xsq_col);
 
+/* ---- EMG envelope preprocessing: the producer of X ------------------ */
+/*
+ * Batched GPU version of the tutorial pipeline that builds the matrix handed to find_synergies
+ * (docs/source/tutorials/Finding muscle synergies.ipynb; src/muscle_synergies/analysis.py):
+ *     zero_center (analysis.py:230-249)  ->  rms (analysis.py:435-507: sqrt(np.convolve(x^2, ones(W)/W, 'same')))
+ *     ->  time_normalize (analysis.py:551-594: linear interp1d onto linspace(0, 1, n_out))
+ *     ->  normalize (analysis.py:510-525: divide each channel by its max |value|)
+ * Every stage is optional.  raw: [B] matrices in the layout given by x_layout / ldx / x_batch_stride
+ * (same meaning as in hipnmf_problem); out: [B][n_channels][n_out ? n_out : n_samples], channel-major
+ * (= the engine's native X layout, so the result can be fed to hipnmf_fit_batched_* without a copy).
+ */
+typedef struct hipnmf_envelope_params {
+  int32_t struct_size;    /* = sizeof(hipnmf_envelope_params)                                          */
+  int32_t batch;          /* B >= 1 recordings                                                         */
+  int64_t n_samples;      /* T rows (time samples) of every recording                                  */
+  int32_t n_channels;     /* m columns (muscles)                                                       */
+  int32_t x_layout;       /* HIPNMF_X_*                                                                */
+  int64_t ldx;            /* leading dimension of one recording, in elements                           */
+  int64_t x_batch_stride; /* elements between consecutive recordings                                   */
+  int32_t window;         /* RMS window in samples, >= 1 (0 skips the RMS stage)                       */
+  int32_t zero_center;    /* 1: subtract the per-channel mean first                                    */
+  int32_t n_out;          /* 0: keep n_samples rows; > 0: time-normalise to n_out rows                 */
+  int32_t normalize;      /* 1: divide every channel by its max absolute value                         */
+} hipnmf_envelope_params;
+
+int hipnmf_emg_envelope_f32(hipnmf_handle* h, const hipnmf_envelope_params* p, const float* raw, float* out);
+int hipnmf_emg_envelope_f64(hipnmf_handle* h, const hipnmf_envelope_params* p, const double* raw, double* out);
+
 #ifdef __cplusplus
 }
 #endif

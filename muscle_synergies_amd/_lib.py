@@ -36,6 +36,7 @@ EXPORTS = (
     "hipnmf_fit_batched_f32", "hipnmf_fit_batched_f64",
     "hipnmf_shard_pass_f32", "hipnmf_shard_hupdate_f32", "hipnmf_shard_residual_f32",
     "hipnmf_shard_pass_f64", "hipnmf_shard_hupdate_f64", "hipnmf_shard_residual_f64",
+    "hipnmf_emg_envelope_f32", "hipnmf_emg_envelope_f64",
 )
 
 
@@ -112,6 +113,9 @@ def _declare(lib):
         f = getattr(lib, f"hipnmf_shard_residual_{sfx}")
         f.restype = ip
         f.argtypes = [vp, pp, vp, vp, vp, vp, vp]
+        f = getattr(lib, f"hipnmf_emg_envelope_{sfx}")
+        f.restype = ip
+        f.argtypes = [vp, vp, vp, vp]
 
 
 def load():

@@ -1,0 +1,166 @@
+// envelope_kernels.hpp -- batched EMG envelope preprocessing on gfx950.
+//
+// Reference semantics (src/muscle_synergies/analysis.py): zero_center :230-249, rms :435-507
+// (np.sqrt(np.convolve(x**2, ones(W)/W, "same"))), time_normalize :551-594 (scipy interp1d, linear, on
+// linspace(0,1,T) -> linspace(0,1,n_out)), normalize :510-525 (divide by max |.| per column).
+//
+// One workgroup per (channel, recording).  The sliding-window mean is taken from an fp64 prefix sum of the
+// squared (centred) samples, so every global access is coalesced and the window sum costs two loads per
+// output regardless of W; sums are accumulated in fp64 for both fp32 and fp64 I/O.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace hipnmf {
+
+struct EnvArgs {
+  const void* raw;     // canonical channel-major [B][m][ld]
+  long long bstride, ld;
+  double* prefix;      // workspace [B][m][T + 1]: prefix[i] = sum_{j < i} v_j^2
+  double* chan_stat;   // workspace [B][m][2]: mean, max |out|
+  void* out;           // [B][m][n_out]
+  int T, m, window, zero_center, n_out, normalize;
+};
+
+__device__ __forceinline__ double block_sum(double v, double* scratch /* [blockDim/64] */) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+  __syncthreads();
+  if (lane == 0) scratch[wave] = v;
+  __syncthreads();
+  double tot = 0.0;
+  for (int w = 0; w < nw; ++w) tot += scratch[w];  // fixed order
+  return tot;
+}
+
+__device__ __forceinline__ double block_max(double v, double* scratch) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+  __syncthreads();
+  if (lane == 0) scratch[wave] = v;
+  __syncthreads();
+  double tot = 0.0;
+  for (int w = 0; w < nw; ++w) tot = fmax(tot, scratch[w]);
+  return tot;
+}
+
+// Pass 1: per-channel mean (optional) and the prefix sums of the squared centred samples.
+template <typename real>
+__global__ void __launch_bounds__(256) emg_prefix_kernel(EnvArgs a) {
+  __shared__ double scratch[8];
+  __shared__ double wave_tot[4];
+  const int ch = blockIdx.x, b = blockIdx.y;
+  const real* __restrict__ x = static_cast<const real*>(a.raw) + (long long)b * a.bstride + (long long)ch * a.ld;
+  double* __restrict__ ps = a.prefix + ((long long)b * a.m + ch) * ((long long)a.T + 1);
+  double mean = 0.0;
+  if (a.zero_center) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < a.T; i += blockDim.x) s += (double)x[i];
+    mean = block_sum(s, scratch) / (double)a.T;
+  }
+  if (threadIdx.x == 0) {
+    a.chan_stat[((long long)b * a.m + ch) * 2] = mean;
+    ps[0] = 0.0;
+  }
+  // blocked inclusive scan: tiles of blockDim.x * 4 consecutive samples, running carry in `base`
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  double base = 0.0;
+  const int tile = blockDim.x * 4;
+  for (int t0 = 0; t0 < a.T; t0 += tile) {
+    const int i0 = t0 + threadIdx.x * 4;
+    double v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int i = i0 + e;
+      const double d = (i < a.T) ? (double)x[i] - mean : 0.0;
+      v[e] = d * d;
+    }
+    v[1] += v[0];
+    v[2] += v[1];
+    v[3] += v[2];
+    double incl = v[3];  // inclusive scan of the per-thread totals across the wave
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const double n = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += n;
+    }
+    __syncthreads();
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    double woff = 0.0;
+    for (int w = 0; w < wave; ++w) woff += wave_tot[w];
+    const double excl = base + woff + incl - v[3];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int i = i0 + e;
+      if (i < a.T) ps[i + 1] = excl + v[e];
+    }
+    double tile_tot = 0.0;
+    for (int w = 0; w < nw; ++w) tile_tot += wave_tot[w];
+    base += tile_tot;
+  }
+}
+
+// windowed RMS at sample i from the prefix sums: np.convolve(sq, ones(W)/W, "same")[i]
+//   = (1/W) * sum_{j = i - (W-1 - (W-1)/2)}^{i + (W-1)/2} sq[j]   (zeros outside [0, T))
+__device__ __forceinline__ double rms_at(const double* __restrict__ ps, int i, int T, int W) {
+  const int hi = (W - 1) / 2, lo = (W - 1) - hi;
+  int j0 = i - lo, j1 = i + hi + 1;  // [j0, j1)
+  if (j0 < 0) j0 = 0;
+  if (j1 > T) j1 = T;
+  const double s = ps[j1] - ps[j0];
+  return sqrt((s > 0.0 ? s : 0.0) / (double)W);
+}
+
+// Pass 2: RMS (or the plain centred signal when window == 0), optional linear time normalisation, optional
+// max normalisation.  Writes out[b][ch][0 .. n_out).
+template <typename real>
+__global__ void __launch_bounds__(256) emg_output_kernel(EnvArgs a) {
+  __shared__ double scratch[8];
+  const int ch = blockIdx.x, b = blockIdx.y;
+  const long long cidx = (long long)b * a.m + ch;
+  const real* __restrict__ x = static_cast<const real*>(a.raw) + (long long)b * a.bstride + (long long)ch * a.ld;
+  const double* __restrict__ ps = a.prefix + cidx * ((long long)a.T + 1);
+  const double mean = a.chan_stat[cidx * 2];
+  const int n_out = a.n_out > 0 ? a.n_out : a.T;
+  real* __restrict__ o = static_cast<real*>(a.out) + cidx * (long long)n_out;
+  auto value = [&](int i) -> double {
+    if (a.window > 0) return rms_at(ps, i, a.T, a.window);
+    return (double)x[i] - mean;
+  };
+  double vmax = 0.0;
+  for (int q = threadIdx.x; q < n_out; q += blockDim.x) {
+    double y;
+    if (a.n_out > 0 && a.n_out != a.T) {
+      // scipy interp1d(kind="linear") between linspace(0,1,T) knots, evaluated at q/(n_out-1)
+      // knots as np.linspace builds them: i * step with the end point pinned to 1.0
+      const double step_out = (n_out > 1) ? 1.0 / (double)(n_out - 1) : 0.0;
+      const double xn = (q == n_out - 1 && n_out > 1) ? 1.0 : (double)q * step_out;
+      if (a.T == 1) {
+        y = value(0);
+      } else {
+        const double step_in = 1.0 / (double)(a.T - 1);
+        auto knot = [&](int i) { return (i == a.T - 1) ? 1.0 : (double)i * step_in; };
+        int i0 = (int)floor(xn * (double)(a.T - 1));
+        if (i0 > a.T - 2) i0 = a.T - 2;
+        if (i0 < 0) i0 = 0;
+        while (i0 > 0 && knot(i0) >= xn) --i0;           // searchsorted(side="left") - 1, clipped to >= 0
+        while (i0 < a.T - 2 && knot(i0 + 1) < xn) ++i0;
+        const double x0 = knot(i0), x1 = knot(i0 + 1);
+        const double y0 = value(i0), y1 = value(i0 + 1);
+        y = (y1 - y0) / (x1 - x0) * (xn - x0) + y0;
+      }
+    } else {
+      y = value(q);
+    }
+    o[q] = (real)y;
+    vmax = fmax(vmax, fabs(y));
+  }
+  if (a.normalize) {
+    vmax = block_max(vmax, scratch);
+    for (int q = threadIdx.x; q < n_out; q += blockDim.x) o[q] = (real)((double)o[q] / vmax);
+  }
+}
+
+}  // namespace hipnmf

@@ -16,15 +16,14 @@
 #include <string>
 #include <vector>
 
+#include "hipnmf_internal.hpp"
 #include "nmf_inst.hpp"
 
 using namespace hipnmf;
 
-namespace {
-
 thread_local std::string g_last_error;
 
-int fail(int code, const char* fmt, ...) {
+int hipnmf_fail(int code, const char* fmt, ...) {
   char buf[512];
   va_list ap;
   va_start(ap, fmt);
@@ -34,15 +33,8 @@ int fail(int code, const char* fmt, ...) {
   return code;
 }
 
-#define HIP_TRY(expr)                                                                              \
-  do {                                                                                             \
-    hipError_t e_ = (expr);                                                                        \
-    if (e_ != hipSuccess)                                                                          \
-      return fail(HIPNMF_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, \
-                  __LINE__);                                                                       \
-  } while (0)
+namespace {
 
-inline long long round_up(long long v, long long q) { return (v + q - 1) / q * q; }
 
 template <typename real>
 const KernelSet<real>* select_kernels(int m, int k);
@@ -75,28 +67,8 @@ const KernelSet<double>* select_kernels<double>(int m, int k) {
 
 }  // namespace
 
-struct hipnmf_handle {
-  int device = 0;
-  hipStream_t own_stream = nullptr;
-  hipStream_t stream = nullptr;
-  void* ws = nullptr;
-  size_t ws_bytes = 0;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  float last_ms = 0.f;
-  int threads = 0;     // 0 = default
-  int max_slices = 0;  // 0 = default
-  int variant = 0;     // 0 auto, 1 force persistent, 2 force sliced
-  int num_cu = 256;
-  int lds_per_block = 65536;  // hipDeviceProp_t::maxSharedMemoryPerMultiProcessor (160 KiB on MI355X)
-  int lds_budget = 0;         // override (bytes), 0 = all of it
-  int use_lds_w = 1;
-  int use_graph = 1;
-  int async_mode = 0;
-};
 
-namespace {
-
-int ensure_ws(hipnmf_handle* h, size_t bytes) {
+int hipnmf_ensure_ws(hipnmf_handle* h, size_t bytes) {
   if (bytes <= h->ws_bytes) return HIPNMF_OK;
   if (h->ws) {
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -108,6 +80,8 @@ int ensure_ws(hipnmf_handle* h, size_t bytes) {
   h->ws_bytes = bytes;
   return HIPNMF_OK;
 }
+
+namespace {
 
 int validate(const hipnmf_problem* p, bool shard) {
   if (!p) return fail(HIPNMF_ERR_BAD_ARG, "problem is NULL");
@@ -239,7 +213,7 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
     o_col = carve(sizeof(real) * (size_t)B * sg.S * 2 * ks->MP);
     o_state = carve(sizeof(real) * (size_t)B * 8);
   }
-  rc = ensure_ws(h, std::max<size_t>(off, 256));
+  rc = hipnmf_ensure_ws(h, std::max<size_t>(off, 256));
   if (rc) return rc;
   char* ws = static_cast<char*>(h->ws);
 
@@ -434,7 +408,7 @@ int shard_common(hipnmf_handle* h, const hipnmf_problem* p, const KernelSet<real
   };
   const size_t o_part = need_part ? carve(sizeof(real) * (size_t)B * sg->S * ks->NACC) : 0;
   const size_t o_col = need_col ? carve(sizeof(real) * (size_t)B * sg->S * 2 * ks->MP) : 0;
-  rc = ensure_ws(h, std::max<size_t>(off, 256));
+  rc = hipnmf_ensure_ws(h, std::max<size_t>(off, 256));
   if (rc) return rc;
   char* ws = static_cast<char*>(h->ws);
   std::memset(a, 0, sizeof(*a));

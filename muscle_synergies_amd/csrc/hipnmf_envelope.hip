@@ -1,0 +1,94 @@
+// hipnmf_envelope.hip -- C ABI of the EMG envelope preprocessing (include/hip_nmf.h, row f-1 of SURVEY.md section 8).
+#include <algorithm>
+#include <cstdint>
+
+#include "envelope_kernels.hpp"
+#include "hipnmf_internal.hpp"
+#include "nmf_kernels.hpp"  // x_to_channel_major_kernel
+
+using namespace hipnmf;
+
+namespace {
+
+template <typename real>
+int envelope_impl(hipnmf_handle* h, const hipnmf_envelope_params* p, const real* raw, real* out) {
+  if (!h) return fail(HIPNMF_ERR_BAD_ARG, "handle is NULL");
+  if (!p) return fail(HIPNMF_ERR_BAD_ARG, "params is NULL");
+  if (p->struct_size != (int32_t)sizeof(hipnmf_envelope_params))
+    return fail(HIPNMF_ERR_BAD_ARG, "hipnmf_envelope_params.struct_size = %d, library expects %d", p->struct_size,
+                (int)sizeof(hipnmf_envelope_params));
+  if (!raw || !out) return fail(HIPNMF_ERR_BAD_ARG, "raw and out must be non-NULL device pointers");
+  if (p->batch < 1 || p->n_samples < 1 || p->n_samples > 2000000000LL || p->n_channels < 1 || p->n_channels > 65535)
+    return fail(HIPNMF_ERR_BAD_ARG, "bad shape: batch=%d n_samples=%lld n_channels=%d", p->batch,
+                (long long)p->n_samples, p->n_channels);
+  if (p->window < 0 || p->n_out < 0) return fail(HIPNMF_ERR_BAD_ARG, "window and n_out must be >= 0");
+  if (p->x_layout != HIPNMF_X_ROW_MAJOR && p->x_layout != HIPNMF_X_CHANNEL_MAJOR)
+    return fail(HIPNMF_ERR_BAD_ARG, "bad x_layout %d", p->x_layout);
+  const long long min_ld = (p->x_layout == HIPNMF_X_ROW_MAJOR) ? p->n_channels : p->n_samples;
+  if (p->ldx < min_ld) return fail(HIPNMF_ERR_BAD_ARG, "ldx=%lld smaller than %lld", (long long)p->ldx, min_ld);
+  HIP_TRY(hipSetDevice(h->device));
+  const int B = p->batch, m = p->n_channels;
+  const long long T = p->n_samples;
+  hipStream_t st = h->stream;
+
+  size_t off = 0;
+  auto carve = [&](size_t bytes) {
+    size_t o = off;
+    off += (bytes + 255) / 256 * 256;
+    return o;
+  };
+  const bool inplace = p->x_layout == HIPNMF_X_CHANNEL_MAJOR;
+  const size_t o_x = inplace ? 0 : carve(sizeof(real) * (size_t)B * m * T);
+  const size_t o_ps = carve(sizeof(double) * (size_t)B * m * (T + 1));
+  const size_t o_st = carve(sizeof(double) * (size_t)B * m * 2);
+  int rc = hipnmf_ensure_ws(h, off);
+  if (rc) return rc;
+  char* ws = static_cast<char*>(h->ws);
+
+  EnvArgs a;
+  if (inplace) {
+    a.raw = raw;
+    a.bstride = p->x_batch_stride;
+    a.ld = p->ldx;
+  } else {
+    real* xc = reinterpret_cast<real*>(ws + o_x);
+    dim3 blk(32, 8);
+    dim3 grd((unsigned)((T + 31) / 32), (unsigned)((m + 31) / 32), (unsigned)B);
+    hipLaunchKernelGGL(x_to_channel_major_kernel<real>, grd, blk, 0, st, raw, (long long)p->x_batch_stride,
+                       (long long)p->ldx, (int)p->x_layout, xc, (long long)m * T, T, (int)T, m);
+    a.raw = xc;
+    a.bstride = (long long)m * T;
+    a.ld = T;
+  }
+  a.prefix = reinterpret_cast<double*>(ws + o_ps);
+  a.chan_stat = reinterpret_cast<double*>(ws + o_st);
+  a.out = out;
+  a.T = (int)T;
+  a.m = m;
+  a.window = p->window;
+  a.zero_center = p->zero_center ? 1 : 0;
+  a.n_out = p->n_out;
+  a.normalize = p->normalize ? 1 : 0;
+  const bool async = h->async_mode != 0;
+  if (!async) HIP_TRY(hipEventRecord(h->ev0, st));
+  hipLaunchKernelGGL(emg_prefix_kernel<real>, dim3(m, B), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(emg_output_kernel<real>, dim3(m, B), dim3(256), 0, st, a);
+  HIP_TRY(hipGetLastError());
+  if (!async) {
+    HIP_TRY(hipEventRecord(h->ev1, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
+  }
+  return HIPNMF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+int hipnmf_emg_envelope_f32(hipnmf_handle* h, const hipnmf_envelope_params* p, const float* raw, float* out) {
+  return envelope_impl<float>(h, p, raw, out);
+}
+int hipnmf_emg_envelope_f64(hipnmf_handle* h, const hipnmf_envelope_params* p, const double* raw, double* out) {
+  return envelope_impl<double>(h, p, raw, out);
+}
+}

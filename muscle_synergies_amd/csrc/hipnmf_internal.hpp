@@ -1,0 +1,44 @@
+// hipnmf_internal.hpp -- shared by the translation units that implement the C ABI (not installed).
+#pragma once
+#include "../../include/hip_nmf.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+
+struct hipnmf_handle {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  void* ws = nullptr;
+  size_t ws_bytes = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  float last_ms = 0.f;
+  int threads = 0;     // 0 = default
+  int max_slices = 0;  // 0 = default
+  int variant = 0;     // 0 auto, 1 force persistent, 2 force sliced
+  int num_cu = 256;
+  int lds_per_block = 65536;  // hipDeviceProp_t::maxSharedMemoryPerMultiProcessor (160 KiB on MI355X)
+  int lds_budget = 0;         // override (bytes), 0 = all of it
+  int use_lds_w = 1;
+  int use_graph = 1;
+  int async_mode = 0;
+};
+
+// sets the thread-local error text returned by hipnmf_last_error() and returns `code`
+int hipnmf_fail(int code, const char* fmt, ...);
+// grow-only workspace of the handle
+int hipnmf_ensure_ws(hipnmf_handle* h, size_t bytes);
+
+#define fail hipnmf_fail
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t e_ = (expr);                                                                        \
+    if (e_ != hipSuccess)                                                                          \
+      return fail(HIPNMF_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, \
+                  __LINE__);                                                                       \
+  } while (0)
+
+inline long long round_up(long long v, long long q) { return (v + q - 1) / q * q; }
+
+// X layout canonicalisation kernel (nmf_kernels.hpp) reused by the envelope entry point

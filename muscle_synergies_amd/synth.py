@@ -62,6 +62,15 @@ def random_init(X: np.ndarray, k: int, seed: int):
     return np.ascontiguousarray(W), np.ascontiguousarray(H)
 
 
+def raw_emg(seed: int, T: int, m: int, fs: float = 2000.0) -> np.ndarray:
+    """Synthetic *raw* (signed) EMG, ``(T, m)`` float64: amplitude-modulated white noise with a small DC
+    offset per channel -- input of the envelope preprocessing (``preprocess.py``)."""
+    rng = np.random.default_rng(777 + int(seed))
+    t = np.arange(T) / fs
+    amp = 0.2 + np.abs(np.sin(2 * np.pi * (0.7 + 0.1 * np.arange(m))[None, :] * t[:, None]))
+    return amp * rng.standard_normal((T, m)) + 0.01 * rng.standard_normal((1, m))
+
+
 def emg_batch(seeds, T: int = 10_000, m: int = 16, k_true: int = 5, dtype=np.float32) -> np.ndarray:
     """Stack of ``emg_matrix`` results as a ``[B, m, T]`` C-contiguous array
     (each slice channel-major, the engine's native ``x_layout=1``)."""

@@ -15,6 +15,7 @@ Fixture sets:
   G3  the tol > 0 stop rule (n_iter_, error trace)
   G4  NNDSVD / random initialisation vectors (host-side init parity)
   G5  ``transform`` (update_H=False) and regularised fits
+  G6  EMG envelope preprocessing (zero_center, rms, time_normalize, normalize) -- row f-1
 """
 
 import json
@@ -38,7 +39,7 @@ import sklearn  # noqa: E402
 from sklearn.decomposition import NMF  # noqa: E402
 from sklearn.decomposition._nmf import _beta_divergence, _initialize_nmf  # noqa: E402
 
-from muscle_synergies_amd.synth import emg_matrix, random_init  # noqa: E402
+from muscle_synergies_amd.synth import emg_matrix, random_init, raw_emg  # noqa: E402
 
 warnings.simplefilter("ignore")
 
@@ -260,6 +261,37 @@ def g5():
     print("G5 done")
 
 
+# --------------------------------------------------------------------------- G6
+def g6():
+    """Envelope preprocessing: outputs of the reference's own DataFrame functions."""
+    import pandas as pd
+
+    arrays = {}
+    for seed, (name, (T, m, win, fs, reduce_to)) in enumerate({"small": (600, 4, 25, None, 50), "odd": (1001, 3, 0.0505, 200, 77),
+                                                              "tutorial": (20000, 8, 0.5, 2000, 200)}.items()):
+        raw = raw_emg(seed, T, m)
+        df = pd.DataFrame(raw, columns=[f"m{j}" for j in range(m)])
+        if T <= 2000:
+            arrays[f"{name}_raw"] = raw
+        zc = ms.zero_center(df)
+        r = ms.rms(zc, window_size=win, sampling_frequency=fs)
+        tn = ms.time_normalize(r, reduce_to=reduce_to)
+        nm = tn / tn.max()            # tutorial cell 23
+        nm2 = ms.normalize(tn)
+        arrays[f"{name}_params"] = np.array([T, m, round(win * fs) if fs else win, reduce_to, seed], dtype=np.int64)
+        arrays[f"{name}_raw_sum"] = np.array(raw.sum())
+        if T <= 2000:
+            arrays[f"{name}_zero_center"] = zc.to_numpy()
+            arrays[f"{name}_rms"] = r.to_numpy()
+        else:
+            arrays[f"{name}_rms_rows"] = r.to_numpy()[[0, 1, 499, 500, 501, 9999, 19998, 19999]]
+        arrays[f"{name}_time_normalize"] = tn.to_numpy()
+        arrays[f"{name}_normalize"] = nm2.to_numpy()
+        assert np.allclose(nm.to_numpy(), nm2.to_numpy())
+    np.savez_compressed(os.path.join(HERE, "g6_envelope.npz"), **arrays)
+    print("G6 done")
+
+
 if __name__ == "__main__":
     g1()
     g2_small()
@@ -267,3 +299,4 @@ if __name__ == "__main__":
     g3()
     g4()
     g5()
+    g6()

@@ -44,9 +44,17 @@ def test_version_and_struct_layout(lib):
     # struct hipnmf_problem: 4+4+8+4*6+8+8+4+4+8*5 bytes with natural alignment
     assert ctypes.sizeof(_lib.Problem) == 104
     text = open(HEADER).read()
-    fields = re.findall(r"^\s+(?:int32_t|int64_t|double)\s+([a-zA-Z0-9_, ]+);", text, flags=re.M)
-    names = [n.strip() for group in fields for n in group.split(",")]
-    assert names == [f[0] for f in _lib.Problem._fields_]
+    def struct_fields(name):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), text, flags=re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        groups = re.findall(r"^\s+(?:int32_t|int64_t|double)\s+([a-zA-Z0-9_, ]+);", body, flags=re.M)
+        return [n.strip() for g in groups for n in g.split(",")]
+
+    assert struct_fields("hipnmf_problem") == [f[0] for f in _lib.Problem._fields_]
+    from muscle_synergies_amd.preprocess import EnvelopeParams
+
+    assert struct_fields("hipnmf_envelope_params") == [f[0] for f in EnvelopeParams._fields_]
+    assert ctypes.sizeof(EnvelopeParams) == 56
 
 
 def test_no_device_is_a_loud_error(lib):

@@ -1,0 +1,101 @@
+"""EMG envelope preprocessing: oracle vs the reference's recorded outputs (CPU), and the
+HIP kernels vs oracle / fixtures (GPU)."""
+import numpy as np
+import pandas as pd
+import pytest
+
+from conftest import load_npz
+from oracle import emg_envelope_oracle as eo
+from muscle_synergies_amd.synth import raw_emg
+
+CASES = ("small", "odd", "tutorial")
+
+
+@pytest.fixture(scope="module")
+def g6():
+    return load_npz("g6_envelope.npz")
+
+
+def _raw(g6, name):
+    T, m, win, reduce_to, seed = (int(v) for v in g6[f"{name}_params"])
+    raw = g6[f"{name}_raw"] if f"{name}_raw" in g6.files else raw_emg(seed, T, m)
+    np.testing.assert_allclose(raw.sum(), g6[f"{name}_raw_sum"], rtol=1e-9)
+    return raw, win, reduce_to
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_matches_reference_outputs(g6, name):
+    raw, win, reduce_to = _raw(g6, name)
+    zc = eo.zero_center(raw)
+    r = eo.rms(zc, win)
+    tn = eo.time_normalize(r, reduce_to)
+    if f"{name}_rms" in g6.files:
+        np.testing.assert_allclose(zc, g6[f"{name}_zero_center"], rtol=1e-12, atol=1e-15)
+        np.testing.assert_allclose(r, g6[f"{name}_rms"], rtol=1e-11)
+    else:
+        np.testing.assert_allclose(r[[0, 1, 499, 500, 501, 9999, 19998, 19999]], g6[f"{name}_rms_rows"], rtol=1e-10)
+    np.testing.assert_allclose(tn, g6[f"{name}_time_normalize"], rtol=1e-10)
+    np.testing.assert_allclose(eo.normalize(tn), g6[f"{name}_normalize"], rtol=1e-10)
+    np.testing.assert_allclose(eo.envelope(raw, win, reduce_to), g6[f"{name}_normalize"], rtol=1e-10)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("layout", ["C", "F"])
+def test_gpu_chain_matches_reference_outputs(g6, name, layout):
+    from muscle_synergies_amd.preprocess import emg_envelope_batched
+
+    raw, win, reduce_to = _raw(g6, name)
+    x = np.ascontiguousarray(raw) if layout == "C" else np.asfortranarray(raw)
+    out = emg_envelope_batched(x, win, reduce_to=reduce_to)[0].cpu().numpy()
+    np.testing.assert_allclose(out, g6[f"{name}_normalize"], rtol=1e-9, atol=1e-12)
+    tn = emg_envelope_batched(x, win, reduce_to=reduce_to, normalize=False)[0].cpu().numpy()
+    np.testing.assert_allclose(tn, g6[f"{name}_time_normalize"], rtol=1e-9, atol=1e-12)
+    full = emg_envelope_batched(x, win, normalize=False)[0].cpu().numpy()
+    if f"{name}_rms" in g6.files:
+        np.testing.assert_allclose(full, g6[f"{name}_rms"], rtol=1e-9, atol=1e-12)
+    else:
+        np.testing.assert_allclose(full[[0, 1, 499, 500, 501, 9999, 19998, 19999]], g6[f"{name}_rms_rows"], rtol=1e-9)
+
+
+@pytest.mark.gpu
+def test_gpu_dataframe_mirrors_and_fp32(g6):
+    from muscle_synergies_amd import preprocess as pp
+
+    raw, win, reduce_to = _raw(g6, "small")
+    df = pd.DataFrame(raw, columns=list("abcd"))
+    zc = pp.zero_center(df)
+    assert list(zc.columns) == list(df.columns) and zc.index.equals(df.index)
+    np.testing.assert_allclose(zc.to_numpy(), g6["small_zero_center"], rtol=1e-12, atol=1e-15)
+    r = pp.rms(zc, win)
+    np.testing.assert_allclose(r.to_numpy(), g6["small_rms"], rtol=1e-10)
+    tn = pp.time_normalize(r, reduce_to)
+    np.testing.assert_allclose(tn.index.to_numpy(), np.linspace(0, 1, reduce_to))
+    np.testing.assert_allclose(tn.to_numpy(), g6["small_time_normalize"], rtol=1e-10)
+    np.testing.assert_allclose(pp.normalize(tn).to_numpy(), g6["small_normalize"], rtol=1e-10)
+    r2 = pp.rms(df, 0.0125, sampling_frequency=2000)  # 25 samples
+    np.testing.assert_allclose(r2.to_numpy(), eo.rms(raw, 25), rtol=1e-10)
+    with pytest.raises(NotImplementedError):
+        pp.time_normalize(r, 10, kind="cubic")
+    # fp32 I/O (fp64 accumulation inside)
+    out32 = pp.emg_envelope_batched(raw.astype(np.float32), win, reduce_to=reduce_to)[0].cpu().numpy()
+    assert out32.dtype == np.float32
+    np.testing.assert_allclose(out32, g6["small_normalize"], rtol=2e-5, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_gpu_batch_feeds_the_solver_without_a_copy():
+    import torch
+
+    import muscle_synergies_amd as ms
+    from muscle_synergies_amd.preprocess import emg_envelope_batched
+
+    B, T, m = 6, 4000, 8
+    raw = np.stack([raw_emg(100 + b, T, m) for b in range(B)])
+    env = emg_envelope_batched(raw, 200, reduce_to=400)  # [B, 400, m] view on channel-major storage
+    assert tuple(env.shape) == (B, 400, m) and env.stride()[1] == 1
+    for b in range(B):
+        np.testing.assert_allclose(env[b].cpu().numpy(), eo.envelope(raw[b], 200, 400), rtol=1e-9, atol=1e-12)
+    W0, H0 = ms.random_init_batched(env, 3, seed=0)
+    r = ms.fit_batched(env, W0, H0, max_iter=50, tol=0.0)
+    assert bool(torch.isfinite(r.reconstruction_err).all()) and float(r.vaf[:, 0].min()) > 0.5
