@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""Throughput probe of the EMG envelope preprocessing (row f-1): samples/s and algorithmic GB/s."""
+import argparse, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from muscle_synergies_amd import _lib
+from muscle_synergies_amd.preprocess import emg_envelope_batched
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=1024)
+ap.add_argument("--T", type=int, default=20000)
+ap.add_argument("--m", type=int, default=16)
+ap.add_argument("--window", type=int, default=200)
+ap.add_argument("--dtype", default="float32")
+a = ap.parse_args()
+dt = getattr(torch, a.dtype)
+raw = torch.randn((a.batch, a.m, a.T), device="cuda:0", dtype=dt).transpose(1, 2)
+h = _lib.get_handle(0)
+for reduce_to in (None, 200):
+    for rep in range(3):
+        out = emg_envelope_batched(raw, a.window, reduce_to=reduce_to)
+    ms = h.last_kernel_ms()
+    n_out = reduce_to or a.T
+    esz = raw.element_size()
+    alg = esz * a.batch * a.m * (a.T + n_out)
+    print(f"B={a.batch} T={a.T} m={a.m} W={a.window} {a.dtype} reduce_to={reduce_to}: {ms:.3f} ms, "
+          f"{a.batch*a.m*a.T/ms/1e6:.1f} G samples/s, {alg/ms/1e6:.0f} GB/s algorithmic (read raw once + write out)")
