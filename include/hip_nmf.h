@@ -105,6 +105,20 @@ int hipnmf_fit_batched_f32(hipnmf_handle* h, const hipnmf_problem* p, const floa
 int hipnmf_fit_batched_f64(hipnmf_handle* h, const hipnmf_problem* p, const double* X, double* W, double* H,
                            double* err_out, int32_t* n_iter_out, double* sse_col_out, double* xsq_col_out);
 
+/* ---- ragged batch: trials of unequal length --------------------------------- */
+/*
+ * Same solver, but matrix b has its own number of rows.  X and W are packed in the engine-native layouts:
+ * matrix b's X is channel-major [m][ld_b] starting at element x_off_b of X, its W component-major [k][ld_b]
+ * starting at element w_off_b of W (ld_b >= T_b, ld_b % 4 == 0, x_off_b % 4 == 0, padding rows zero).
+ * desc: HOST array [B][4] = {T_b, x_off_b, ld_b, w_off_b}.  p->n_samples = max_b T_b; p->x_layout must be
+ * HIPNMF_X_CHANNEL_MAJOR and p->w_layout HIPNMF_W_COMPONENT_MAJOR; ldx / x_batch_stride are ignored.
+ * H, err_out, n_iter_out, sse_col_out, xsq_col_out as in hipnmf_fit_batched_*.
+ */
+int hipnmf_fit_ragged_f32(hipnmf_handle* h, const hipnmf_problem* p, const int64_t* desc, const float* X, float* W,
+                          float* H, float* err_out, int32_t* n_iter_out, float* sse_col_out, float* xsq_col_out);
+int hipnmf_fit_ragged_f64(hipnmf_handle* h, const hipnmf_problem* p, const int64_t* desc, const double* X, double* W,
+                          double* H, double* err_out, int32_t* n_iter_out, double* sse_col_out, double* xsq_col_out);
+
 /* ---- time-sharded building blocks (one rank holds rows [t0, t1) of every X and W; H replicated) --- */
 /*
  * One iteration of the sharded solver is

@@ -10,8 +10,8 @@ Importing this package never loads the HIP library; the first compute call does,
 """
 
 from .analysis import SynergyRunResult, find_synergies, vaf
-from .engine import (BatchedResult, RankSweepResult, fit_batched, fit_batched_multi_gpu, random_init_batched,
-                     rank_sweep_batched)
+from .engine import (BatchedResult, RankSweepResult, fit_batched, fit_batched_multi_gpu, fit_ragged,
+                     random_init_batched, rank_sweep_batched)
 from .hip_nmf import HipNMF
 from ._lib import HipNmfError
 
@@ -24,6 +24,7 @@ __all__ = [
     "HipNMF",
     "fit_batched",
     "fit_batched_multi_gpu",
+    "fit_ragged",
     "BatchedResult",
     "rank_sweep_batched",
     "random_init_batched",

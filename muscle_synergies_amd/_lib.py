@@ -33,7 +33,7 @@ W_COMPONENT_MAJOR = 1
 EXPORTS = (
     "hipnmf_version", "hipnmf_last_error", "hipnmf_device_count", "hipnmf_create", "hipnmf_destroy",
     "hipnmf_set_stream", "hipnmf_workspace_bytes", "hipnmf_last_kernel_ms", "hipnmf_set_async", "hipnmf_set_tuning",
-    "hipnmf_fit_batched_f32", "hipnmf_fit_batched_f64",
+    "hipnmf_fit_batched_f32", "hipnmf_fit_batched_f64", "hipnmf_fit_ragged_f32", "hipnmf_fit_ragged_f64",
     "hipnmf_shard_pass_f32", "hipnmf_shard_hupdate_f32", "hipnmf_shard_residual_f32",
     "hipnmf_shard_pass_f64", "hipnmf_shard_hupdate_f64", "hipnmf_shard_residual_f64",
     "hipnmf_emg_envelope_f32", "hipnmf_emg_envelope_f64",
@@ -104,6 +104,9 @@ def _declare(lib):
         f = getattr(lib, f"hipnmf_fit_batched_{sfx}")
         f.restype = ip
         f.argtypes = [vp, pp, vp, vp, vp, vp, vp, vp, vp]
+        f = getattr(lib, f"hipnmf_fit_ragged_{sfx}")
+        f.restype = ip
+        f.argtypes = [vp, pp, vp, vp, vp, vp, vp, vp, vp, vp]
         f = getattr(lib, f"hipnmf_shard_pass_{sfx}")
         f.restype = ip
         f.argtypes = [vp, pp, vp, vp, vp, vp]

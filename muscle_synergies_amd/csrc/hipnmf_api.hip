@@ -160,7 +160,7 @@ SliceGeom slice_geometry(const hipnmf_handle* h, long long T, int B) {
 
 template <typename real>
 int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, real* W, real* H, real* err_out,
-                     int32_t* n_iter_out, real* sse_col_out, real* xsq_col_out) {
+                     int32_t* n_iter_out, real* sse_col_out, real* xsq_col_out, const int64_t* ragged = nullptr) {
   if (!h) return fail(HIPNMF_ERR_BAD_ARG, "handle is NULL");
   int rc = validate(p, false);
   if (rc) return rc;
@@ -190,11 +190,24 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
     persistent = t_pers <= t_sliced;
   }
   if (!persistent && sg.S == 1 && h->variant != 2) persistent = true;
+  if (ragged) {
+    persistent = true;  // one workgroup per matrix handles any mix of lengths
+    if (p->x_layout != HIPNMF_X_CHANNEL_MAJOR || p->w_layout != HIPNMF_W_COMPONENT_MAJOR)
+      return fail(HIPNMF_ERR_UNSUPPORTED, "ragged batches use the packed native layouts (channel-major X, component-major W)");
+    if ((reinterpret_cast<uintptr_t>(X) % 16) != 0) return fail(HIPNMF_ERR_BAD_ARG, "X must be 16-byte aligned");
+    for (int b = 0; b < B; ++b) {
+      const int64_t* d = ragged + 4 * (size_t)b;
+      if (d[0] < 1 || d[0] > p->n_samples || d[2] < d[0] || (d[2] % 4) != 0 || (d[1] % 4) != 0 || d[1] < 0 || d[3] < 0)
+        return fail(HIPNMF_ERR_BAD_ARG, "bad ragged descriptor for matrix %d (T=%lld, xoff=%lld, ld=%lld, woff=%lld)", b,
+                    (long long)d[0], (long long)d[1], (long long)d[2], (long long)d[3]);
+    }
+  }
 
   // ---- workspace carve-up -----------------------------------------------------------------------
-  const bool x_inplace = p->x_layout == HIPNMF_X_CHANNEL_MAJOR && (p->ldx % ks->G) == 0 && (T % ks->G) == 0 &&
-                         (reinterpret_cast<uintptr_t>(X) % 16) == 0 &&
-                         ((p->x_batch_stride * (long long)sizeof(real)) % 16) == 0;
+  const size_t o_desc_bytes = ragged ? sizeof(long long) * 4 * (size_t)B : 0;
+  const bool x_inplace = ragged || (p->x_layout == HIPNMF_X_CHANNEL_MAJOR && (p->ldx % ks->G) == 0 &&
+                                    (T % ks->G) == 0 && (reinterpret_cast<uintptr_t>(X) % 16) == 0 &&
+                                    ((p->x_batch_stride * (long long)sizeof(real)) % 16) == 0);
   const bool w_inplace = p->w_layout == HIPNMF_W_COMPONENT_MAJOR;
   const long long ldx_c = x_inplace ? p->ldx : round_up(T, 64);
   const long long ldw_c = w_inplace ? T : round_up(T, 64);
@@ -206,6 +219,7 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
   };
   const size_t o_x = x_inplace ? 0 : carve(sizeof(real) * (size_t)B * m * ldx_c);
   const size_t o_w = w_inplace ? 0 : carve(sizeof(real) * (size_t)B * k * ldw_c);
+  const size_t o_desc = ragged ? carve(o_desc_bytes) : 0;
   size_t o_part = 0, o_sums = 0, o_col = 0, o_state = 0;
   if (!persistent) {
     o_part = carve(sizeof(real) * (size_t)B * sg.S * ks->NACC);
@@ -245,6 +259,10 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
     a.W = wc;
     a.w_bstride = (long long)k * ldw_c;
     a.ldw = ldw_c;
+  }
+  if (ragged) {  // descriptors to the device (pageable host memory: the copy is complete on return)
+    HIP_TRY(hipMemcpyAsync(ws + o_desc, ragged, o_desc_bytes, hipMemcpyHostToDevice, st));
+    a.ragged = reinterpret_cast<const long long*>(ws + o_desc);
   }
   a.H = H;
   a.err_out = err_out;
@@ -613,6 +631,17 @@ int hipnmf_fit_batched_f32(hipnmf_handle* h, const hipnmf_problem* p, const floa
 int hipnmf_fit_batched_f64(hipnmf_handle* h, const hipnmf_problem* p, const double* X, double* W, double* H,
                            double* err_out, int32_t* n_iter_out, double* sse_col_out, double* xsq_col_out) {
   return fit_batched_impl<double>(h, p, X, W, H, err_out, n_iter_out, sse_col_out, xsq_col_out);
+}
+
+int hipnmf_fit_ragged_f32(hipnmf_handle* h, const hipnmf_problem* p, const int64_t* desc, const float* X, float* W,
+                          float* H, float* err_out, int32_t* n_iter_out, float* sse_col_out, float* xsq_col_out) {
+  if (!desc) return fail(HIPNMF_ERR_BAD_ARG, "desc is NULL");
+  return fit_batched_impl<float>(h, p, X, W, H, err_out, n_iter_out, sse_col_out, xsq_col_out, desc);
+}
+int hipnmf_fit_ragged_f64(hipnmf_handle* h, const hipnmf_problem* p, const int64_t* desc, const double* X, double* W,
+                          double* H, double* err_out, int32_t* n_iter_out, double* sse_col_out, double* xsq_col_out) {
+  if (!desc) return fail(HIPNMF_ERR_BAD_ARG, "desc is NULL");
+  return fit_batched_impl<double>(h, p, X, W, H, err_out, n_iter_out, sse_col_out, xsq_col_out, desc);
 }
 
 int hipnmf_shard_pass_f32(hipnmf_handle* h, const hipnmf_problem* p, const float* X, float* W, const float* H,

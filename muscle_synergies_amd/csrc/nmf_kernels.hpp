@@ -233,6 +233,7 @@ struct SolveArgs {
   real* state;        // [B][8] err0, prev, err, done, checks-so-far   (multi-slice path stop rule)
   int T, m, max_iter, check_every, update_h, S, rows_per_slice, it;
   int lds_rows;       // persistent kernel: rows [0, lds_rows) of W live in LDS for the whole fit
+  const long long* ragged;  // [B][4] = {T_b, X offset, leading dimension, W offset} (elements) or nullptr
   real tol, l1w, l2w, l1h, l2h;
 };
 
@@ -254,12 +255,14 @@ struct MatAddr {
   unsigned ldw_b;     // ldw * sizeof(real)
   int T, lane, g;
   real* lds_w;        // [K][lds_rows] component-major W cache in LDS (persistent kernel), or nullptr
-  int lds_rows;
+  int lds_rows;       // stride of the cache (rows)
+  int lds_used;       // rows of this matrix that live in the cache
   const real* h_lds;  // LDS copy of H ([K][MP]), read per tile by the h_in_lds instances
   __device__ __forceinline__ MatAddr(const real* Xb, long long ldx, const real* Wb, long long ldw, int T_, int m,
                                      real* lds_w_ = nullptr, int lds_rows_ = 0) {
     lds_w = lds_w_;
     lds_rows = lds_rows_;
+    lds_used = lds_rows_;
     h_lds = nullptr;
     lane = threadIdx.x & (WAVE - 1);
     g = lane % G;
@@ -704,8 +707,8 @@ __device__ __forceinline__ void block_residual(Smem<real, G, CH, K>& s, const Ma
   real sse[CH], xsq[CH];
 #pragma unroll
   for (int cc = 0; cc < CH; ++cc) sse[cc] = xsq[cc] = (real)0;
-  if (ma.lds_rows > 0) {
-    const int split = row_end < ma.lds_rows ? row_end : ma.lds_rows;
+  if (ma.lds_used > 0) {
+    const int split = row_end < ma.lds_used ? row_end : ma.lds_used;
     rows_resid_pass<real, G, CH, K, true>(ma, row_begin, split, h, sse, xsq);
     rows_resid_pass<real, G, CH, K, false>(ma, split, row_end, h, sse, xsq);
   } else {
@@ -754,17 +757,30 @@ __global__ void __launch_bounds__((max_threads<real, G, CH, K>())) HIPNMF_OCC fi
   const real* __restrict__ Xb = a.X + (long long)b * a.x_bstride;
   real* __restrict__ Wb = a.W + (long long)b * a.w_bstride;
   real* __restrict__ Hb = a.H + (long long)b * K * a.m;
-  const int T = a.T, m = a.m;
+  int T = a.T;
+  long long ldx = a.ldx, ldw = a.ldw;
+  if (a.ragged) {  // packed batch of matrices with different numbers of rows (trials of unequal length)
+    const long long* d = a.ragged + 4LL * b;
+    T = (int)d[0];
+    Xb = a.X + d[1];
+    ldx = ldw = d[2];
+    Wb = a.W + d[3];
+  }
+  const int m = a.m;
   const int row_end = ((T + WAVE - 1) / WAVE) * WAVE;
-  // W cache: rows [0, lds_rows) stay in LDS for the whole fit (lds_rows is a multiple of blockDim.x)
+  // W cache: rows [0, lds_rows) stay in LDS for the whole fit (a multiple of blockDim.x; lds_stride is the
+  // launch-wide capacity, lds_rows what this matrix uses of it)
   real* lds_w = reinterpret_cast<real*>(smem_raw + ((Smem<real, G, CH, K>::bytes(nw) + 15) / 16) * 16);
-  const int lds_rows = a.lds_rows;
-  MatAddr<real, G, CH, K> ma(Xb, a.ldx, Wb, a.ldw, T, m, lds_w, lds_rows);
+  const int lds_stride = a.lds_rows;
+  const int t_blk = (int)(((long long)T + blockDim.x - 1) / blockDim.x * blockDim.x);
+  const int lds_rows = lds_stride < t_blk ? lds_stride : t_blk;
+  MatAddr<real, G, CH, K> ma(Xb, ldx, Wb, ldw, T, m, lds_w, lds_stride);
   ma.h_lds = s.H;
+  ma.lds_used = lds_rows;
   for (int t0 = 0; t0 < lds_rows; t0 += blockDim.x) {  // row t0 + tid is owned by this thread in every pass
     const int t = t0 + threadIdx.x;
 #pragma unroll
-    for (int c = 0; c < K; ++c) lds_w[c * lds_rows + t] = (t < T) ? Wb[(long long)c * a.ldw + t] : (real)0;
+    for (int c = 0; c < K; ++c) lds_w[c * lds_stride + t] = (t < T) ? Wb[(long long)c * ldw + t] : (real)0;
   }
 
   load_h_to_lds(s, Hb, m);
@@ -845,7 +861,7 @@ __global__ void __launch_bounds__((max_threads<real, G, CH, K>())) HIPNMF_OCC fi
     const int t = t0 + threadIdx.x;
     if (t < T) {
 #pragma unroll
-      for (int c = 0; c < K; ++c) Wb[(long long)c * a.ldw + t] = lds_w[c * lds_rows + t];
+      for (int c = 0; c < K; ++c) Wb[(long long)c * ldw + t] = lds_w[c * lds_stride + t];
     }
   }
 }

@@ -286,3 +286,65 @@ def rank_sweep_batched(X, k_min: int, k_max: int, *, vaf_threshold: float = 0.90
     if keep_W:
         res.W = Ws
     return res
+
+
+# ------------------------------------------------------------------------------------------------
+# Ragged batches: trials of unequal length (gait cycles, segments of a recording)
+def fit_ragged(Xs, W0s, H0s, *, max_iter: int = 200, tol: float = 1e-4, check_every: int = 10,
+               update_H: bool = True, l1_reg_W: float = 0.0, l1_reg_H: float = 0.0, l2_reg_W: float = 0.0,
+               l2_reg_H: float = 0.0, device=None, handle: Optional[_lib.Handle] = None):
+    """Factorise ``B`` matrices with different numbers of rows in one launch.
+
+    ``Xs[b]`` is ``(T_b, m)``, ``W0s[b]`` ``(T_b, k)``, ``H0s[b]`` ``(k, m)`` (NumPy or torch; one dtype, one
+    ``m`` and one ``k`` for the whole batch).  The matrices are packed on the device in the engine-native
+    layouts (each padded to a multiple of 4 rows) and handed to ``hipnmf_fit_ragged_*``; one workgroup per
+    matrix runs the whole fit, whatever the mix of lengths.  Returns a :class:`BatchedResult` whose ``W`` is
+    a list of ``(T_b, k)`` tensors; the other fields are batched tensors as in :func:`fit_batched`.
+    """
+    torch = _torch()
+    dev = resolve_device(device)
+    B = len(Xs)
+    if B == 0 or len(W0s) != B or len(H0s) != B:
+        raise ValueError("Xs, W0s and H0s must be non-empty lists of equal length")
+    first = _as_device_tensor(Xs[0], dev)
+    dtype = first.dtype if first.dtype in (torch.float32, torch.float64) else torch.float64
+    m = first.shape[1]
+    k = _as_device_tensor(H0s[0], dev).shape[0]
+    Ts = [int(x.shape[0]) for x in Xs]
+    lds = [(t + 3) // 4 * 4 for t in Ts]
+    x_off, w_off, xo, wo = [], [], 0, 0
+    for ld in lds:
+        x_off.append(xo)
+        w_off.append(wo)
+        xo += m * ld
+        wo += (k * ld + 3) // 4 * 4
+    Xp = torch.zeros((xo,), dtype=dtype, device=dev)
+    Wp = torch.zeros((wo,), dtype=dtype, device=dev)
+    Hp = torch.empty((B, k, m), dtype=dtype, device=dev)
+    for b in range(B):
+        xb = _as_device_tensor(Xs[b], dev, dtype)
+        wb = _as_device_tensor(W0s[b], dev, dtype)
+        hb = _as_device_tensor(H0s[b], dev, dtype)
+        if tuple(xb.shape) != (Ts[b], m) or tuple(wb.shape) != (Ts[b], k) or tuple(hb.shape) != (k, m):
+            raise ValueError(f"matrix {b}: expected X ({Ts[b]}, {m}), W0 ({Ts[b]}, {k}), H0 ({k}, {m})")
+        Xp[x_off[b]: x_off[b] + m * lds[b]].view(m, lds[b])[:, : Ts[b]] = xb.t()
+        Wp[w_off[b]: w_off[b] + k * lds[b]].view(k, lds[b])[:, : Ts[b]] = wb.t()
+        Hp[b] = hb
+    desc = np.array([[Ts[b], x_off[b], lds[b], w_off[b]] for b in range(B)], dtype=np.int64)
+    Tmax = max(Ts)
+    p = make_problem(B, Tmax, m, k, x_layout=_lib.X_CHANNEL_MAJOR, ldx=Tmax, x_batch_stride=1,
+                     w_layout=_lib.W_COMPONENT_MAJOR, update_H=update_H, max_iter=max_iter, tol=tol,
+                     check_every=check_every, l1_reg_W=l1_reg_W, l1_reg_H=l1_reg_H, l2_reg_W=l2_reg_W, l2_reg_H=l2_reg_H)
+    err = torch.empty((B,), dtype=dtype, device=dev)
+    n_iter = torch.empty((B,), dtype=torch.int32, device=dev)
+    sse = torch.empty((B, m), dtype=dtype, device=dev)
+    xsq = torch.empty((B, m), dtype=dtype, device=dev)
+    h = handle if handle is not None else _lib.get_handle(dev.index)
+    lib = _lib.load()
+    fn = lib.hipnmf_fit_ragged_f32 if dtype == torch.float32 else lib.hipnmf_fit_ragged_f64
+    torch.cuda.synchronize(dev)
+    _lib.check(fn(h.ptr, ctypes.byref(p), desc.ctypes.data_as(ctypes.c_void_p), Xp.data_ptr(), Wp.data_ptr(),
+                  Hp.data_ptr(), err.data_ptr(), n_iter.data_ptr(), sse.data_ptr(), xsq.data_ptr()))
+    Ws = [Wp[w_off[b]: w_off[b] + k * lds[b]].view(k, lds[b])[:, : Ts[b]].t().contiguous() for b in range(B)]
+    vaf = torch.cat([(1 - sse.sum(dim=1) / xsq.sum(dim=1)).unsqueeze(1), 1 - sse / xsq], dim=1)
+    return BatchedResult(Ws, Hp, n_iter, err, vaf, sse, xsq, h.last_kernel_ms())

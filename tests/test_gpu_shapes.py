@@ -252,3 +252,28 @@ def test_bad_arguments_are_reported():
                                       None) == _lib.HIPNMF_ERR_BAD_ARG
     assert lib.hipnmf_fit_batched_f32(h.ptr, ctypes.byref(make_problem(1, 10, 8, 2, **ok)), None, d.data_ptr(), d.data_ptr(),
                                       None, None, None, None) == _lib.HIPNMF_ERR_BAD_ARG
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_ragged_batch_matches_per_matrix_oracle(dtype):
+    """Row f-3: trials of unequal length in one launch (lengths deliberately not multiples of 4 / 64 / 512)."""
+    import muscle_synergies_amd as ms
+
+    Ts = [7, 64, 333, 1001, 2500, 9999, 10000, 13001]
+    Xs = [emg_matrix(200 + i, T=t, m=16, dtype=dtype) for i, t in enumerate(Ts)]
+    inits = [random_init(x, 5, i) for i, x in enumerate(Xs)]
+    res = ms.fit_ragged(Xs, [w for w, _ in inits], [h for _, h in inits], max_iter=40, tol=0.0)
+    assert len(res.W) == len(Ts)
+    for b, t in enumerate(Ts):
+        ref = orc.nmf_mu_fit(Xs[b], inits[b][0], inits[b][1], max_iter=40, tol=0.0)
+        W, H = res.W[b].cpu().numpy(), res.H[b].cpu().numpy()
+        assert W.shape == (t, 5)
+        assert _rel(Xs[b], W, H, ref) <= TOL, t
+        assert abs(float(res.reconstruction_err[b]) - float(ref["reconstruction_err"])) / np.linalg.norm(Xs[b]) <= TOL
+        va, _ = orc.vaf(Xs[b].astype(np.float64), ref["W"].astype(np.float64), ref["H"].astype(np.float64))
+        assert abs(float(res.vaf[b, 0]) - va) <= TOL
+    # per-matrix stop rule with mixed lengths
+    res2 = ms.fit_ragged(Xs[2:5], [w for w, _ in inits[2:5]], [h for _, h in inits[2:5]], max_iter=500, tol=1e-3)
+    for i, b in enumerate(range(2, 5)):
+        ref = orc.nmf_mu_fit(Xs[b], inits[b][0], inits[b][1], max_iter=500, tol=1e-3)
+        assert int(res2.n_iter[i]) == ref["n_iter"]
