@@ -9,7 +9,7 @@ Importing this package never loads the HIP library; the first compute call does,
 ``libhip_nmf.so`` is missing or no GPU is visible (there is no CPU fallback for ``solver='mu'``).
 """
 
-from .analysis import SynergyRunResult, find_synergies, vaf
+from .analysis import SynergyRunResult, find_synergies, find_synergies_batched, vaf
 from .engine import (BatchedResult, RankSweepResult, fit_batched, fit_batched_multi_gpu, fit_ragged,
                      random_init_batched, rank_sweep_batched)
 from .hip_nmf import HipNMF
@@ -19,6 +19,7 @@ __version__ = "0.1.0"
 
 __all__ = [
     "find_synergies",
+    "find_synergies_batched",
     "vaf",
     "SynergyRunResult",
     "HipNMF",

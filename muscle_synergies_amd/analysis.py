@@ -120,3 +120,63 @@ def find_synergies(processed_emg_df: pandas.DataFrame, n_components: int, max_co
         {rank: run.components for rank, run in runs.items()},
         {rank: run.model for rank, run in runs.items()},
     )
+
+
+def find_synergies_batched(processed_emg_dfs, n_components: int, max_components: Optional[int] = None, *,
+                           max_iter: int = 100_000, tol: float = 1e-6, init=None, random_state=None,
+                           alpha_W: float = 0.0, alpha_H="same", l1_ratio: float = 0.0, device=None):
+    """``find_synergies(df, ..., solver='mu')`` for a list of trials in one GPU launch per rank.
+
+    ``processed_emg_dfs`` is a sequence of DataFrames with the same muscles (columns) and any numbers of rows
+    (e.g. the gait cycles cut by ``project/segment.py``).  Returns one :class:`SynergyRunResult` per trial,
+    each identical in structure -- and, trial by trial, in values -- to what ``find_synergies`` returns for
+    that DataFrame alone; the factorisations of a rank run together through ``fit_ragged``.
+    """
+    from .engine import fit_ragged
+    from .init import initialize_nmf
+
+    dfs = list(processed_emg_dfs)
+    if not dfs:
+        raise ValueError("empty EMG DataFrame")
+    columns = dfs[0].columns
+    for df in dfs:
+        _check_component_range(df, n_components, max_components)
+        if len(df.columns) != len(columns) or not (df.columns == columns).all():
+            raise ValueError("all trials must have the same muscle columns")
+    ranks = [n_components] if max_components is None else list(range(n_components, max_components + 1))
+    arrays = [HipNMF._validate_X(df) for df in dfs]
+    dtype = np.float32 if all(a.dtype == np.float32 for a in arrays) else np.float64
+    arrays = [np.asarray(a, dtype=dtype) for a in arrays]
+    per_trial = [OrderedDict() for _ in dfs]
+    for rank in ranks:
+        template = HipNMF(rank, init=init, tol=tol, max_iter=max_iter, random_state=random_state, alpha_W=alpha_W,
+                          alpha_H=alpha_H, l1_ratio=l1_ratio, device=device)
+        template._check_params()
+        inits = [initialize_nmf(a, rank, init=init, random_state=random_state) for a in arrays]
+        # regularisation scales with each trial's own shape (_nmf.py:1254-1265): only equal-length trials share it
+        regs = {template._regularization(a.shape[0], a.shape[1]) for a in arrays}
+        if len(regs) > 1:
+            raise NotImplementedError("alpha_W / alpha_H with trials of different lengths: fit them per trial")
+        l1w, l1h, l2w, l2h = regs.pop()
+        res = fit_ragged(arrays, [w for w, _ in inits], [h for _, h in inits], max_iter=max_iter, tol=tol,
+                         l1_reg_W=l1w, l1_reg_H=l1h, l2_reg_W=l2w, l2_reg_H=l2h, device=device)
+        H = res.H.cpu().numpy()
+        n_iter = res.n_iter.cpu().numpy()
+        err = res.reconstruction_err.cpu().numpy()
+        for b, df in enumerate(dfs):
+            model = HipNMF(rank, init=init, tol=tol, max_iter=max_iter, random_state=random_state, alpha_W=alpha_W,
+                           alpha_H=alpha_H, l1_ratio=l1_ratio, device=device)
+            model.components_, model.n_components_, model.n_features_in_ = H[b], rank, H.shape[2]
+            model.n_iter_, model.reconstruction_err_ = int(n_iter[b]), err[b]
+            W = res.W[b].cpu().numpy()
+            vaf_row = vaf(df, transformed_signal=W, components=H[b])
+            per_trial[b][rank] = SynergyRunResult(vaf_row, pandas.DataFrame(H[b], columns=df.columns), model)
+    if max_components is None:
+        return [runs[n_components] for runs in per_trial]
+    out = []
+    for runs in per_trial:
+        table = pandas.concat([run.vaf_values for run in runs.values()])
+        table.set_index(np.array(tuple(runs.keys())), inplace=True)
+        out.append(SynergyRunResult(table, {r: run.components for r, run in runs.items()},
+                                    {r: run.model for r, run in runs.items()}))
+    return out

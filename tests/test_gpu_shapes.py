@@ -277,3 +277,32 @@ def test_ragged_batch_matches_per_matrix_oracle(dtype):
     for i, b in enumerate(range(2, 5)):
         ref = orc.nmf_mu_fit(Xs[b], inits[b][0], inits[b][1], max_iter=500, tol=1e-3)
         assert int(res2.n_iter[i]) == ref["n_iter"]
+
+
+def test_find_synergies_batched_equals_per_trial_calls():
+    """A list of trials of unequal length through one launch per rank == find_synergies trial by trial."""
+    import warnings
+
+    import pandas as pd
+
+    import muscle_synergies_amd as ms
+
+    cols = [f"m{j}" for j in range(8)]
+    dfs = [pd.DataFrame(emg_matrix(300 + i, T=t, m=8, k_true=3, dtype=np.float64), columns=cols)
+           for i, t in enumerate((180, 200, 257))]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        batched = ms.find_synergies_batched(dfs, 2, 3, max_iter=300, tol=1e-5, random_state=0)
+        single = [ms.find_synergies(df, 2, 3, solver="mu", max_iter=300, tol=1e-5, random_state=0) for df in dfs]
+    assert len(batched) == 3
+    for b, s in zip(batched, single):
+        assert list(b.components.keys()) == [2, 3] and list(b.vaf_values.index) == [2, 3]
+        np.testing.assert_allclose(b.vaf_values.to_numpy(), s.vaf_values.to_numpy(), rtol=1e-9)
+        for k in (2, 3):
+            np.testing.assert_allclose(b.components[k].to_numpy(), s.components[k].to_numpy(), rtol=1e-8, atol=1e-12)
+            assert b.model[k].n_iter_ == s.model[k].n_iter_
+            assert list(b.components[k].columns) == cols
+    one = ms.find_synergies_batched(dfs, 2, max_iter=50, tol=0.0, random_state=0)
+    assert isinstance(one[0].components, pd.DataFrame) and one[1].model.n_iter_ == 50
+    with pytest.raises(ValueError, match="invalid number of components"):
+        ms.find_synergies_batched(dfs, 9)
