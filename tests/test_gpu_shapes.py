@@ -306,3 +306,24 @@ def test_find_synergies_batched_equals_per_trial_calls():
     assert isinstance(one[0].components, pd.DataFrame) and one[1].model.n_iter_ == 50
     with pytest.raises(ValueError, match="invalid number of components"):
         ms.find_synergies_batched(dfs, 9)
+
+
+def test_multi_gpu_scatter_on_the_visible_devices():
+    """Host-thread scatter (one handle per device, contiguous slices, no collective); with one visible GPU the
+    batch goes to it in one slice, and a device listed twice exercises the two-thread path."""
+    import torch
+
+    import muscle_synergies_amd as ms
+
+    B, T = 10, 800
+    Xs = np.stack([np.ascontiguousarray(emg_matrix(400 + b, T=T, dtype=np.float32)) for b in range(B)])
+    inits = [random_init(Xs[b], 5, b) for b in range(B)]
+    W0, H0 = np.stack([i[0] for i in inits]), np.stack([i[1] for i in inits])
+    ref = ms.fit_batched(Xs, W0, H0, max_iter=30, tol=0.0)
+    out = ms.fit_batched_multi_gpu(Xs, W0, H0, max_iter=30, tol=0.0)
+    np.testing.assert_array_equal(out.W, ref.W)
+    if torch.cuda.device_count() == 1:
+        two = ms.fit_batched_multi_gpu(Xs, W0, H0, devices=[0, 0], max_iter=30, tol=0.0)
+        assert two.W.shape == ref.W.shape
+        np.testing.assert_allclose(two.H, ref.H, rtol=2e-4, atol=1e-6)  # a 5-matrix slice may use another path
+        np.testing.assert_array_equal(two.n_iter, ref.n_iter)
