@@ -163,4 +163,136 @@ __global__ void __launch_bounds__(256) emg_output_kernel(EnvArgs a) {
   }
 }
 
+// =================================================================================================
+// Fused version (default): no prefix array in HBM.
+//   full-length output : tiles of ENV_TILE outputs; the squared centred samples of tile + halo go to LDS as
+//                        fp64, are scanned there, and every output is a difference of two LDS prefix values;
+//   resampled output   : only 2 * n_out window sums are needed -- one wave per output sums its two windows
+//                        directly (coalesced 256-B pieces, fp64 accumulation).
+// Traffic per sample (fp32, W << tile): read x once for the mean (if centred), once (1 + W/tile) for the
+// windows, write the output once (+ read/write it once more when normalising).
+// =================================================================================================
+constexpr int ENV_TILE = 2048;
+
+// exclusive block scan of n (<= capacity) fp64 values in LDS, in place: buf[i] <- sum_{j<i} buf[j]; buf[n] <- total
+__device__ __forceinline__ void lds_exclusive_scan(double* buf, int n, double* wave_tot /* [blockDim/64] */) {
+  const int nt = blockDim.x, per = (n + nt - 1) / nt;
+  const int b0 = threadIdx.x * per;
+  double run = 0.0;
+  for (int i = b0; i < b0 + per && i < n; ++i) run += buf[i];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = nt >> 6;
+  double incl = run;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const double v = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += v;
+  }
+  __syncthreads();
+  if (lane == 63) wave_tot[wave] = incl;
+  __syncthreads();
+  double base = incl - run;
+  for (int w = 0; w < wave; ++w) base += wave_tot[w];
+  double tot = 0.0;
+  for (int w = 0; w < nw; ++w) tot += wave_tot[w];
+  for (int i = b0; i < b0 + per && i < n; ++i) {
+    const double v = buf[i];
+    buf[i] = base;
+    base += v;
+  }
+  if (threadIdx.x == 0) buf[n] = tot;
+  __syncthreads();
+}
+
+template <typename real>
+__global__ void __launch_bounds__(256) emg_fused_kernel(EnvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char env_smem[];
+  double* buf = reinterpret_cast<double*>(env_smem);  // [ENV_TILE + window + 1]
+  __shared__ double scratch[8];
+  const int ch = blockIdx.x, b = blockIdx.y;
+  const long long cidx = (long long)b * a.m + ch;
+  const real* __restrict__ x = static_cast<const real*>(a.raw) + (long long)b * a.bstride + (long long)ch * a.ld;
+  const int T = a.T, W = a.window;
+  const int n_out = a.n_out > 0 ? a.n_out : T;
+  real* __restrict__ o = static_cast<real*>(a.out) + cidx * (long long)n_out;
+  double mean = 0.0;
+  if (a.zero_center) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < T; i += blockDim.x) s += (double)x[i];
+    mean = block_sum(s, scratch) / (double)T;
+  }
+  const int hi = W > 0 ? (W - 1) / 2 : 0, lo = W > 0 ? (W - 1) - hi : 0;
+  double vmax = 0.0;
+  if (a.n_out > 0 && a.n_out != T) {
+    // ---- resampled: one wave per output q, two direct window sums
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    auto value = [&](int i) -> double {  // wave-cooperative
+      if (W == 0) return (double)x[i] - mean;
+      int j0 = i - lo, j1 = i + hi + 1;
+      if (j0 < 0) j0 = 0;
+      if (j1 > T) j1 = T;
+      double s = 0.0;
+      for (int j = j0 + lane; j < j1; j += 64) {
+        const double d = (double)x[j] - mean;
+        s += d * d;
+      }
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+      return sqrt(s / (double)W);
+    };
+    const double step_out = (n_out > 1) ? 1.0 / (double)(n_out - 1) : 0.0;
+    for (int q = wave; q < n_out; q += nw) {
+      double y;
+      const double xn = (q == n_out - 1 && n_out > 1) ? 1.0 : (double)q * step_out;
+      if (T == 1) {
+        y = value(0);
+      } else {
+        const double step_in = 1.0 / (double)(T - 1);
+        auto knot = [&](int i) { return (i == T - 1) ? 1.0 : (double)i * step_in; };
+        int i0 = (int)floor(xn * (double)(T - 1));
+        if (i0 > T - 2) i0 = T - 2;
+        if (i0 < 0) i0 = 0;
+        while (i0 > 0 && knot(i0) >= xn) --i0;
+        while (i0 < T - 2 && knot(i0 + 1) < xn) ++i0;
+        const double x0 = knot(i0), x1 = knot(i0 + 1);
+        const double y0 = value(i0), y1 = value(i0 + 1);
+        y = (y1 - y0) / (x1 - x0) * (xn - x0) + y0;
+      }
+      if (lane == 0) o[q] = (real)y;
+      vmax = fmax(vmax, fabs(y));
+    }
+  } else {
+    // ---- full length: LDS prefix sums per tile
+    for (int t0 = 0; t0 < T; t0 += ENV_TILE) {
+      const int nout_t = (T - t0 < ENV_TILE) ? T - t0 : ENV_TILE;
+      if (W > 0) {
+        const int nbuf = nout_t + W - 1;  // buf[e] <-> sample t0 - lo + e
+        __syncthreads();
+        for (int e = threadIdx.x; e < nbuf; e += blockDim.x) {
+          const int j = t0 - lo + e;
+          const double d = (j >= 0 && j < T) ? (double)x[j] - mean : 0.0;
+          buf[e] = (j >= 0 && j < T) ? d * d : 0.0;
+        }
+        __syncthreads();
+        lds_exclusive_scan(buf, nbuf, scratch);
+        for (int i = threadIdx.x; i < nout_t; i += blockDim.x) {
+          const double s = buf[i + W] - buf[i];
+          const double y = sqrt((s > 0.0 ? s : 0.0) / (double)W);
+          o[t0 + i] = (real)y;
+          vmax = fmax(vmax, y);
+        }
+      } else {
+        for (int i = threadIdx.x; i < nout_t; i += blockDim.x) {
+          const double y = (double)x[t0 + i] - mean;
+          o[t0 + i] = (real)y;
+          vmax = fmax(vmax, fabs(y));
+        }
+      }
+    }
+  }
+  if (a.normalize) {
+    vmax = block_max(vmax, scratch);  // barriers inside also order the writes of `o` above
+    for (int q = threadIdx.x; q < n_out; q += blockDim.x) o[q] = (real)((double)o[q] / vmax);
+  }
+}
+
 }  // namespace hipnmf

@@ -1,6 +1,7 @@
 // hipnmf_envelope.hip -- C ABI of the EMG envelope preprocessing (include/hip_nmf.h, row f-1 of SURVEY.md section 8).
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 
 #include "envelope_kernels.hpp"
 #include "hipnmf_internal.hpp"
@@ -39,9 +40,16 @@ int envelope_impl(hipnmf_handle* h, const hipnmf_envelope_params* p, const real*
   };
   const bool inplace = p->x_layout == HIPNMF_X_CHANNEL_MAJOR;
   const size_t o_x = inplace ? 0 : carve(sizeof(real) * (size_t)B * m * T);
-  const size_t o_ps = carve(sizeof(double) * (size_t)B * m * (T + 1));
-  const size_t o_st = carve(sizeof(double) * (size_t)B * m * 2);
-  int rc = hipnmf_ensure_ws(h, off);
+  // fused kernel (LDS prefix sums) unless the window does not fit in LDS beside a tile, or HIPNMF_ENV_FUSED=0
+  static const bool fused_ok = [] {
+    const char* e = getenv("HIPNMF_ENV_FUSED");
+    return !(e && atoi(e) == 0);
+  }();
+  const size_t fused_lds = sizeof(double) * (size_t)(ENV_TILE + p->window + 8);
+  const bool fused = fused_ok && fused_lds <= 96 * 1024;
+  const size_t o_ps = fused ? 0 : carve(sizeof(double) * (size_t)B * m * (T + 1));
+  const size_t o_st = fused ? 0 : carve(sizeof(double) * (size_t)B * m * 2);
+  int rc = hipnmf_ensure_ws(h, std::max<size_t>(off, 256));
   if (rc) return rc;
   char* ws = static_cast<char*>(h->ws);
 
@@ -71,8 +79,15 @@ int envelope_impl(hipnmf_handle* h, const hipnmf_envelope_params* p, const real*
   a.normalize = p->normalize ? 1 : 0;
   const bool async = h->async_mode != 0;
   if (!async) HIP_TRY(hipEventRecord(h->ev0, st));
-  hipLaunchKernelGGL(emg_prefix_kernel<real>, dim3(m, B), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(emg_output_kernel<real>, dim3(m, B), dim3(256), 0, st, a);
+  if (fused) {
+    if (fused_lds > 48 * 1024)
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(emg_fused_kernel<real>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds));
+    hipLaunchKernelGGL(emg_fused_kernel<real>, dim3(m, B), dim3(256), fused_lds, st, a);
+  } else {
+    hipLaunchKernelGGL(emg_prefix_kernel<real>, dim3(m, B), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(emg_output_kernel<real>, dim3(m, B), dim3(256), 0, st, a);
+  }
   HIP_TRY(hipGetLastError());
   if (!async) {
     HIP_TRY(hipEventRecord(h->ev1, st));
