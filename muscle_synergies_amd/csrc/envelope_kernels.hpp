@@ -167,8 +167,8 @@ __global__ void __launch_bounds__(256) emg_output_kernel(EnvArgs a) {
 // Fused version (default): no prefix array in HBM.
 //   full-length output : tiles of ENV_TILE outputs; the squared centred samples of tile + halo go to LDS as
 //                        fp64, are scanned there, and every output is a difference of two LDS prefix values;
-//   resampled output   : only 2 * n_out window sums are needed -- one wave per output sums its two windows
-//                        directly (coalesced 256-B pieces, fp64 accumulation).
+//   resampled output   : the same tiles, but only the outputs whose left interpolation knot lies in the tile
+//                        are produced (the full-length RMS never leaves LDS).
 // Traffic per sample (fp32, W << tile): read x once for the mean (if centred), once (1 + W/tile) for the
 // windows, write the output once (+ read/write it once more when normalising).
 // =================================================================================================
@@ -222,70 +222,59 @@ __global__ void __launch_bounds__(256) emg_fused_kernel(EnvArgs a) {
   }
   const int hi = W > 0 ? (W - 1) / 2 : 0, lo = W > 0 ? (W - 1) - hi : 0;
   double vmax = 0.0;
-  if (a.n_out > 0 && a.n_out != T) {
-    // ---- resampled: one wave per output q, two direct window sums
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    auto value = [&](int i) -> double {  // wave-cooperative
-      if (W == 0) return (double)x[i] - mean;
-      int j0 = i - lo, j1 = i + hi + 1;
-      if (j0 < 0) j0 = 0;
-      if (j1 > T) j1 = T;
-      double s = 0.0;
-      for (int j = j0 + lane; j < j1; j += 64) {
-        const double d = (double)x[j] - mean;
-        s += d * d;
+  const bool resample = a.n_out > 0 && a.n_out != T;
+  const double step_out = (n_out > 1) ? 1.0 / (double)(n_out - 1) : 0.0;
+  const double step_in = (T > 1) ? 1.0 / (double)(T - 1) : 0.0;
+  auto knot = [&](int i) { return (i == T - 1) ? 1.0 : (double)i * step_in; };  // np.linspace(0, 1, T)[i]
+  for (int t0 = 0; t0 < T; t0 += ENV_TILE) {
+    const int nout_t = (T - t0 < ENV_TILE) ? T - t0 : ENV_TILE;
+    const int nval = nout_t + 1;  // one value past the tile: right neighbour for the interpolation
+    if (W > 0) {
+      const int nbuf = nval + W - 1;  // buf[e] <-> squared centred sample t0 - lo + e (0 outside [0, T))
+      __syncthreads();
+      for (int e = threadIdx.x; e < nbuf; e += blockDim.x) {
+        const int j = t0 - lo + e;
+        const double d = (j >= 0 && j < T) ? (double)x[j] - mean : 0.0;
+        buf[e] = d * d;
       }
-#pragma unroll
-      for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
-      return sqrt(s / (double)W);
-    };
-    const double step_out = (n_out > 1) ? 1.0 / (double)(n_out - 1) : 0.0;
-    for (int q = wave; q < n_out; q += nw) {
-      double y;
-      const double xn = (q == n_out - 1 && n_out > 1) ? 1.0 : (double)q * step_out;
-      if (T == 1) {
-        y = value(0);
-      } else {
-        const double step_in = 1.0 / (double)(T - 1);
-        auto knot = [&](int i) { return (i == T - 1) ? 1.0 : (double)i * step_in; };
-        int i0 = (int)floor(xn * (double)(T - 1));
-        if (i0 > T - 2) i0 = T - 2;
-        if (i0 < 0) i0 = 0;
-        while (i0 > 0 && knot(i0) >= xn) --i0;
-        while (i0 < T - 2 && knot(i0 + 1) < xn) ++i0;
-        const double x0 = knot(i0), x1 = knot(i0 + 1);
-        const double y0 = value(i0), y1 = value(i0 + 1);
-        y = (y1 - y0) / (x1 - x0) * (xn - x0) + y0;
-      }
-      if (lane == 0) o[q] = (real)y;
-      vmax = fmax(vmax, fabs(y));
+      __syncthreads();
+      lds_exclusive_scan(buf, nbuf, scratch);
     }
-  } else {
-    // ---- full length: LDS prefix sums per tile
-    for (int t0 = 0; t0 < T; t0 += ENV_TILE) {
-      const int nout_t = (T - t0 < ENV_TILE) ? T - t0 : ENV_TILE;
+    auto value = [&](int i) -> double {  // i in [t0, t0 + nout_t]
       if (W > 0) {
-        const int nbuf = nout_t + W - 1;  // buf[e] <-> sample t0 - lo + e
-        __syncthreads();
-        for (int e = threadIdx.x; e < nbuf; e += blockDim.x) {
-          const int j = t0 - lo + e;
-          const double d = (j >= 0 && j < T) ? (double)x[j] - mean : 0.0;
-          buf[e] = (j >= 0 && j < T) ? d * d : 0.0;
+        const double s = buf[i - t0 + W] - buf[i - t0];
+        return sqrt((s > 0.0 ? s : 0.0) / (double)W);
+      }
+      return (i < T) ? (double)x[i] - mean : 0.0;
+    };
+    if (!resample) {
+      for (int i = threadIdx.x; i < nout_t; i += blockDim.x) {
+        const double y = value(t0 + i);
+        o[t0 + i] = (real)y;
+        vmax = fmax(vmax, fabs(y));
+      }
+    } else {
+      // scipy interp1d(kind="linear") from linspace(0,1,T) onto linspace(0,1,n_out): output q is produced by
+      // the tile that holds its left knot i0
+      for (int q = threadIdx.x; q < n_out; q += blockDim.x) {
+        const double xn = (q == n_out - 1 && n_out > 1) ? 1.0 : (double)q * step_out;
+        double y;
+        if (T == 1) {
+          if (t0 != 0) continue;
+          y = value(0);
+        } else {
+          int i0 = (int)floor(xn * (double)(T - 1));
+          if (i0 > T - 2) i0 = T - 2;
+          if (i0 < 0) i0 = 0;
+          while (i0 > 0 && knot(i0) >= xn) --i0;  // searchsorted(side="left") - 1, clipped to >= 0
+          while (i0 < T - 2 && knot(i0 + 1) < xn) ++i0;
+          if (i0 < t0 || i0 >= t0 + nout_t) continue;
+          const double x0 = knot(i0), x1 = knot(i0 + 1);
+          const double y0 = value(i0), y1 = value(i0 + 1);
+          y = (y1 - y0) / (x1 - x0) * (xn - x0) + y0;
         }
-        __syncthreads();
-        lds_exclusive_scan(buf, nbuf, scratch);
-        for (int i = threadIdx.x; i < nout_t; i += blockDim.x) {
-          const double s = buf[i + W] - buf[i];
-          const double y = sqrt((s > 0.0 ? s : 0.0) / (double)W);
-          o[t0 + i] = (real)y;
-          vmax = fmax(vmax, y);
-        }
-      } else {
-        for (int i = threadIdx.x; i < nout_t; i += blockDim.x) {
-          const double y = (double)x[t0 + i] - mean;
-          o[t0 + i] = (real)y;
-          vmax = fmax(vmax, fabs(y));
-        }
+        o[q] = (real)y;
+        vmax = fmax(vmax, fabs(y));
       }
     }
   }

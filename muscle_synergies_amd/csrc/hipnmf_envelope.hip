@@ -45,7 +45,7 @@ int envelope_impl(hipnmf_handle* h, const hipnmf_envelope_params* p, const real*
     const char* e = getenv("HIPNMF_ENV_FUSED");
     return !(e && atoi(e) == 0);
   }();
-  const size_t fused_lds = sizeof(double) * (size_t)(ENV_TILE + p->window + 8);
+  const size_t fused_lds = sizeof(double) * (size_t)(ENV_TILE + p->window + 16);
   const bool fused = fused_ok && fused_lds <= 96 * 1024;
   const size_t o_ps = fused ? 0 : carve(sizeof(double) * (size_t)B * m * (T + 1));
   const size_t o_st = fused ? 0 : carve(sizeof(double) * (size_t)B * m * 2);
