@@ -169,6 +169,31 @@ typedef struct hipnmf_envelope_params {
 int hipnmf_emg_envelope_f32(hipnmf_handle* h, const hipnmf_envelope_params* p, const float* raw, float* out);
 int hipnmf_emg_envelope_f64(hipnmf_handle* h, const hipnmf_envelope_params* p, const double* raw, double* out);
 
+/* ---- on-device NNDSVD initialisation building blocks ---------------------- */
+/*
+ * sklearn's default init for find_synergies is NNDSVDa (_initialize_nmf, _nmf.py:221-373) on a randomized SVD.
+ * For T >> m the same leading singular triplets follow from the m x m Gram matrix; the two T-long passes
+ * run here, the m x m eigen-problem and the k x m algebra stay on the host (muscle_synergies_amd/init.py):
+ *   hipnmf_gram          : gram[b] = X_b^T X_b (m x m, fp64) and colsum[b] = column sums of X_b (fp64)
+ *   hipnmf_nndsvd_stats  : for u_j = X v_j / s_j  (j < k): sum of squares of the positive part, of the negative
+ *                          part, and the signed entry of largest magnitude (svd_flip's pivot): stats[b][k][4]
+ *   hipnmf_nndsvd_write  : W0[b][t][j] = coef[b][j][0] * max(+-u_j[t], 0) (sign = coef[b][j][1]), entries below
+ *                          `eps` set to 0, zeros then replaced by fill[b] (NNDSVDa; pass 0 for plain NNDSVD)
+ * X as in hipnmf_problem (only batch, n_samples, n_features, n_components, x_layout, ldx, x_batch_stride are
+ * read); V: [B][k][m] right singular vectors, inv_s: [B][k] = 1 / s_j; W0: [B][T][k] row-major.
+ * All array arguments are device pointers; gram, colsum, stats, coef, fill are fp64 for both variants.
+ */
+int hipnmf_gram_f32(hipnmf_handle* h, const hipnmf_problem* p, const float* X, double* gram, double* colsum);
+int hipnmf_gram_f64(hipnmf_handle* h, const hipnmf_problem* p, const double* X, double* gram, double* colsum);
+int hipnmf_nndsvd_stats_f32(hipnmf_handle* h, const hipnmf_problem* p, const float* X, const double* V,
+                            const double* inv_s, double* stats);
+int hipnmf_nndsvd_stats_f64(hipnmf_handle* h, const hipnmf_problem* p, const double* X, const double* V,
+                            const double* inv_s, double* stats);
+int hipnmf_nndsvd_write_f32(hipnmf_handle* h, const hipnmf_problem* p, const float* X, const double* V,
+                            const double* inv_s, const double* coef, const double* fill, double eps, float* W0);
+int hipnmf_nndsvd_write_f64(hipnmf_handle* h, const hipnmf_problem* p, const double* X, const double* V,
+                            const double* inv_s, const double* coef, const double* fill, double eps, double* W0);
+
 #ifdef __cplusplus
 }
 #endif

@@ -37,6 +37,8 @@ EXPORTS = (
     "hipnmf_shard_pass_f32", "hipnmf_shard_hupdate_f32", "hipnmf_shard_residual_f32",
     "hipnmf_shard_pass_f64", "hipnmf_shard_hupdate_f64", "hipnmf_shard_residual_f64",
     "hipnmf_emg_envelope_f32", "hipnmf_emg_envelope_f64",
+    "hipnmf_gram_f32", "hipnmf_gram_f64", "hipnmf_nndsvd_stats_f32", "hipnmf_nndsvd_stats_f64",
+    "hipnmf_nndsvd_write_f32", "hipnmf_nndsvd_write_f64",
 )
 
 
@@ -119,6 +121,15 @@ def _declare(lib):
         f = getattr(lib, f"hipnmf_emg_envelope_{sfx}")
         f.restype = ip
         f.argtypes = [vp, vp, vp, vp]
+        f = getattr(lib, f"hipnmf_gram_{sfx}")
+        f.restype = ip
+        f.argtypes = [vp, pp, vp, vp, vp]
+        f = getattr(lib, f"hipnmf_nndsvd_stats_{sfx}")
+        f.restype = ip
+        f.argtypes = [vp, pp, vp, vp, vp, vp]
+        f = getattr(lib, f"hipnmf_nndsvd_write_{sfx}")
+        f.restype = ip
+        f.argtypes = [vp, pp, vp, vp, vp, vp, vp, ctypes.c_double, vp]
 
 
 def load():

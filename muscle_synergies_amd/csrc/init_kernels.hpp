@@ -1,0 +1,175 @@
+// init_kernels.hpp -- T-long passes of the on-device NNDSVD initialisation.
+//
+// Reference semantics: sklearn _initialize_nmf (sklearn/decomposition/_nmf.py:221-373).  The leading singular
+// triplets of X (T x m, T >> m) are taken from the Gram matrix X^T X = V S^2 V^T; u_j = X v_j / s_j.
+// One workgroup per matrix; every accumulation is fp64 with a fixed summation order.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace hipnmf {
+
+struct InitArgs {
+  const void* X;  // canonical channel-major [B][m][ld]
+  long long bstride, ld;
+  int T, m, k;
+  double* gram;    // [B][m][m]
+  double* colsum;  // [B][m]
+  const double* V;      // [B][k][m]
+  const double* inv_s;  // [B][k]
+  double* stats;        // [B][k][4]: sum u+^2, sum u-^2, pivot value (signed, largest |u|), unused
+  const double* coef;   // [B][k][2]: scale, sign (+1: positive part of u, -1: negative part, 0: |u|)
+  const double* fill;   // [B]
+  double eps;
+  void* W0;  // [B][T][k]
+};
+
+constexpr int GRAM_TILE = 128;  // rows per LDS tile
+constexpr int GRAM_MAXM = 32;
+
+// gram[b][j][j2] = sum_t X[t][j] X[t][j2];  colsum[b][j] = sum_t X[t][j]
+template <typename real>
+__global__ void __launch_bounds__(256) gram_kernel(InitArgs a) {
+  __shared__ double xs[GRAM_MAXM][GRAM_TILE + 1];
+  const int b = blockIdx.x, m = a.m;
+  const real* __restrict__ Xb = static_cast<const real*>(a.X) + (long long)b * a.bstride;
+  const int npair = m * m;
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};  // up to 4 (j, j2) pairs per thread (m <= 32)
+  double csum = 0.0;
+  for (int t0 = 0; t0 < a.T; t0 += GRAM_TILE) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < m * GRAM_TILE; i += blockDim.x) {
+      const int j = i / GRAM_TILE, tt = i % GRAM_TILE, t = t0 + tt;
+      xs[j][tt] = (t < a.T) ? (double)Xb[(long long)j * a.ld + t] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int pidx = threadIdx.x + q * 256;
+      if (pidx < npair) {
+        const int j = pidx / m, j2 = pidx % m;
+        double s = acc[q];
+        for (int tt = 0; tt < GRAM_TILE; ++tt) s = fma(xs[j][tt], xs[j2][tt], s);
+        acc[q] = s;
+      }
+    }
+    if (threadIdx.x < m) {
+      double s = csum;
+      for (int tt = 0; tt < GRAM_TILE; ++tt) s += xs[threadIdx.x][tt];
+      csum = s;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int pidx = threadIdx.x + q * 256;
+    if (pidx < npair) a.gram[(long long)b * npair + pidx] = acc[q];
+  }
+  if (threadIdx.x < m) a.colsum[(long long)b * m + threadIdx.x] = csum;
+}
+
+// u_j[t] = (sum_c X[t][c] V[j][c]) * inv_s[j]
+template <typename real, int KMAX>
+__device__ __forceinline__ void project_row(const real* __restrict__ Xb, long long ld, int t, int m, int k,
+                                            const double (*Vs)[GRAM_MAXM], const double* is, double (&u)[KMAX]) {
+#pragma unroll
+  for (int j = 0; j < KMAX; ++j) u[j] = 0.0;
+  for (int c = 0; c < m; ++c) {
+    const double x = (double)Xb[(long long)c * ld + t];
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j)
+      if (j < k) u[j] = fma(x, Vs[j][c], u[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < KMAX; ++j) u[j] *= is[j < k ? j : 0];
+}
+
+template <typename real>
+__global__ void __launch_bounds__(256) nndsvd_stats_kernel(InitArgs a) {
+  constexpr int KMAX = 8;
+  __shared__ double Vs[KMAX][GRAM_MAXM];
+  __shared__ double is[KMAX];
+  __shared__ double red[4][KMAX][3];
+  const int b = blockIdx.x, m = a.m, k = a.k;
+  const real* __restrict__ Xb = static_cast<const real*>(a.X) + (long long)b * a.bstride;
+  for (int i = threadIdx.x; i < k * m; i += blockDim.x) Vs[i / m][i % m] = a.V[(long long)b * k * m + i];
+  if (threadIdx.x < k) is[threadIdx.x] = a.inv_s[(long long)b * k + threadIdx.x];
+  __syncthreads();
+  double sp[KMAX], sn[KMAX], piv[KMAX];
+#pragma unroll
+  for (int j = 0; j < KMAX; ++j) sp[j] = sn[j] = piv[j] = 0.0;
+  for (int t = threadIdx.x; t < a.T; t += blockDim.x) {
+    double u[KMAX];
+    project_row<real, KMAX>(Xb, a.ld, t, m, k, Vs, is, u);
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) {
+      const double up = u[j] > 0 ? u[j] : 0.0, un = u[j] < 0 ? -u[j] : 0.0;
+      sp[j] = fma(up, up, sp[j]);
+      sn[j] = fma(un, un, sn[j]);
+      if (fabs(u[j]) > fabs(piv[j])) piv[j] = u[j];  // first occurrence wins inside a thread (np.argmax)
+    }
+  }
+  // wave reduction (fixed order), then across the 4 waves
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int j = 0; j < KMAX; ++j) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      sp[j] += __shfl_xor(sp[j], off, 64);
+      sn[j] += __shfl_xor(sn[j], off, 64);
+      const double o = __shfl_xor(piv[j], off, 64);
+      if (fabs(o) > fabs(piv[j])) piv[j] = o;
+    }
+    if (lane == 0) {
+      red[wave][j][0] = sp[j];
+      red[wave][j][1] = sn[j];
+      red[wave][j][2] = piv[j];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < k) {
+    const int j = threadIdx.x;
+    double p = 0.0, n = 0.0, pv = 0.0;
+    for (int w = 0; w < 4; ++w) {
+      p += red[w][j][0];
+      n += red[w][j][1];
+      if (fabs(red[w][j][2]) > fabs(pv)) pv = red[w][j][2];
+    }
+    double* o = a.stats + ((long long)b * k + j) * 4;
+    o[0] = p;
+    o[1] = n;
+    o[2] = pv;
+    o[3] = 0.0;
+  }
+}
+
+template <typename real>
+__global__ void __launch_bounds__(256) nndsvd_write_kernel(InitArgs a) {
+  constexpr int KMAX = 8;
+  __shared__ double Vs[KMAX][GRAM_MAXM];
+  __shared__ double is[KMAX], cf[KMAX][2];
+  const int b = blockIdx.x, m = a.m, k = a.k;
+  const real* __restrict__ Xb = static_cast<const real*>(a.X) + (long long)b * a.bstride;
+  real* __restrict__ Wb = static_cast<real*>(a.W0) + (long long)b * a.T * k;
+  for (int i = threadIdx.x; i < k * m; i += blockDim.x) Vs[i / m][i % m] = a.V[(long long)b * k * m + i];
+  if (threadIdx.x < k) {
+    is[threadIdx.x] = a.inv_s[(long long)b * k + threadIdx.x];
+    cf[threadIdx.x][0] = a.coef[((long long)b * k + threadIdx.x) * 2];
+    cf[threadIdx.x][1] = a.coef[((long long)b * k + threadIdx.x) * 2 + 1];
+  }
+  __syncthreads();
+  const double fill = a.fill[b];
+  for (int t = threadIdx.x; t < a.T; t += blockDim.x) {
+    double u[KMAX];
+    project_row<real, KMAX>(Xb, a.ld, t, m, k, Vs, is, u);
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j)
+      if (j < k) {
+        const double part = cf[j][1] > 0 ? (u[j] > 0 ? u[j] : 0.0) : (cf[j][1] < 0 ? (u[j] < 0 ? -u[j] : 0.0) : fabs(u[j]));
+        real w = (real)(cf[j][0] * part);
+        if ((double)w < a.eps) w = (real)0;      // W[W < eps] = 0            (_nmf.py:355)
+        if (w == (real)0) w = (real)fill;        // nndsvda: zeros -> X.mean() (_nmf.py:360-362); fill = 0 for nndsvd
+        Wb[(long long)t * k + j] = w;
+      }
+  }
+}
+
+}  // namespace hipnmf

@@ -133,3 +133,93 @@ def initialize_nmf(X, n_components, init=None, eps=1e-6, random_state=None):
         W[W == 0] = abs(avg * rng.standard_normal(size=len(W[W == 0])) / 100)
         H[H == 0] = abs(avg * rng.standard_normal(size=len(H[H == 0])) / 100)
     return W, H
+
+
+# ------------------------------------------------------------------------------------------------
+# Batched NNDSVD / NNDSVDa on the device
+def nndsvd_init_batched(X, n_components: int, init: str = "nndsvda", eps: float = 1e-6, device=None):
+    """``_initialize_nmf(X_b, k, init='nndsvd'|'nndsvda')`` for every matrix of ``X [B, T, m]`` (``T >= m``).
+
+    The two T-long passes run on the GPU (``hipnmf_gram_*``, ``hipnmf_nndsvd_stats_*`` / ``_write_*``); the
+    ``m x m`` symmetric eigen-problem and the ``k x m`` algebra of Boutsidis & Gallopoulos run on the host in
+    fp64.  The singular triplets come from the exact Gram-matrix SVD instead of sklearn's randomized SVD;
+    for ``T >> m`` both agree to rounding (checked in ``tests/test_envelope.py``-style GPU tests against
+    sklearn).  Returns device tensors ``(W0 [B, T, k], H0 [B, k, m])`` in ``X``'s dtype.
+    """
+    import ctypes
+
+    import torch
+
+    from . import _lib
+    from .engine import _as_device_tensor, _x_layout, make_problem, resolve_device
+
+    if init not in ("nndsvd", "nndsvda"):
+        raise ValueError("nndsvd_init_batched implements init='nndsvd' and 'nndsvda'")
+    dev = resolve_device(device)
+    Xt = _as_device_tensor(X, dev)
+    if Xt.dim() == 2:
+        Xt = Xt.unsqueeze(0)
+    if Xt.dtype not in (torch.float32, torch.float64):
+        Xt = Xt.to(torch.float64)
+    B, T, m = Xt.shape
+    k = int(n_components)
+    if k > min(T, m):
+        raise ValueError("init = '{}' can only be used when n_components <= min(n_samples, n_features)".format(init))
+    if bool((Xt < 0).any()):
+        raise ValueError("Negative values in data passed to NMF initialization.")
+    layout, ldx, xbs, Xt = _x_layout(Xt)
+    p = make_problem(B, T, m, k, x_layout=layout, ldx=ldx, x_batch_stride=xbs)
+    sfx = "f32" if Xt.dtype == torch.float32 else "f64"
+    lib, h = _lib.load(), _lib.get_handle(dev.index)
+    f64 = dict(dtype=torch.float64, device=dev)
+    gram, colsum = torch.empty((B, m, m), **f64), torch.empty((B, m), **f64)
+    torch.cuda.synchronize(dev)
+    _lib.check(getattr(lib, f"hipnmf_gram_{sfx}")(h.ptr, ctypes.byref(p), Xt.data_ptr(), gram.data_ptr(),
+                                                  colsum.data_ptr()))
+    G = gram.cpu().numpy()
+    evals, Q = np.linalg.eigh(0.5 * (G + G.transpose(0, 2, 1)))  # ascending
+    order = np.argsort(-evals, axis=1)[:, :k]
+    S = np.sqrt(np.maximum(np.take_along_axis(evals, order, axis=1), 0.0))  # [B, k]
+    V = np.stack([Q[b][:, order[b]].T for b in range(B)])  # [B, k, m]
+    inv_s = np.where(S > 0, 1.0 / np.where(S > 0, S, 1.0), 0.0)
+    Vd, isd = torch.from_numpy(V).to(dev), torch.from_numpy(inv_s).to(dev)
+    stats = torch.empty((B, k, 4), **f64)
+    _lib.check(getattr(lib, f"hipnmf_nndsvd_stats_{sfx}")(h.ptr, ctypes.byref(p), Xt.data_ptr(), Vd.data_ptr(),
+                                                          isd.data_ptr(), stats.data_ptr()))
+    st = stats.cpu().numpy()
+    # svd_flip (extmath.py:895-953): the entry of largest magnitude of every left vector becomes positive
+    sign = np.where(st[:, :, 2] < 0, -1.0, 1.0)
+    V = V * sign[:, :, None]
+    sp = np.where(sign > 0, st[:, :, 0], st[:, :, 1])  # ||u_+||^2 after the flip
+    sn = np.where(sign > 0, st[:, :, 1], st[:, :, 0])
+    H0 = np.zeros((B, k, m))
+    coef = np.zeros((B, k, 2))
+    H0[:, 0, :] = np.sqrt(S[:, 0])[:, None] * np.abs(V[:, 0, :])  # leading triplet is non-negative (_nmf.py:323-326)
+    coef[:, 0, 0] = np.sqrt(S[:, 0])
+    for j in range(1, k):
+        y = V[:, j, :]
+        y_p, y_n = np.maximum(y, 0), np.abs(np.minimum(y, 0))
+        x_p_nrm, x_n_nrm = np.sqrt(sp[:, j]), np.sqrt(sn[:, j])
+        y_p_nrm, y_n_nrm = np.linalg.norm(y_p, axis=1), np.linalg.norm(y_n, axis=1)
+        m_p, m_n = x_p_nrm * y_p_nrm, x_n_nrm * y_n_nrm
+        pos = m_p > m_n
+        sigma = np.where(pos, m_p, m_n)
+        lbd = np.sqrt(S[:, j] * sigma)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            coef[:, j, 0] = lbd / np.where(pos, x_p_nrm, x_n_nrm)
+            H0[:, j, :] = lbd[:, None] * np.where(pos[:, None], y_p / y_p_nrm[:, None], y_n / y_n_nrm[:, None])
+        coef[:, j, 1] = np.where(pos, 1.0, -1.0)
+    avg = colsum.cpu().numpy().sum(axis=1) / (T * m)
+    np_dtype = np.float32 if Xt.dtype == torch.float32 else np.float64
+    H0 = H0.astype(np_dtype)
+    H0[H0 < eps] = 0
+    fill = avg if init == "nndsvda" else np.zeros(B)
+    if init == "nndsvda":
+        H0 = np.where(H0 == 0, avg[:, None, None].astype(np_dtype), H0)
+    W0 = torch.empty((B, T, k), dtype=Xt.dtype, device=dev)
+    Vd = torch.from_numpy(np.ascontiguousarray(V)).to(dev)
+    cd, fd = torch.from_numpy(coef).to(dev), torch.from_numpy(np.ascontiguousarray(fill, dtype=np.float64)).to(dev)
+    _lib.check(getattr(lib, f"hipnmf_nndsvd_write_{sfx}")(h.ptr, ctypes.byref(p), Xt.data_ptr(), Vd.data_ptr(),
+                                                          isd.data_ptr(), cd.data_ptr(), fd.data_ptr(),
+                                                          ctypes.c_double(eps), W0.data_ptr()))
+    return W0, torch.from_numpy(np.ascontiguousarray(H0)).to(dev)

@@ -1,0 +1,52 @@
+"""On-device NNDSVD / NNDSVDa (row f-2) against sklearn's _initialize_nmf and the host restatement."""
+import numpy as np
+import pytest
+
+from muscle_synergies_amd.synth import emg_matrix
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-7), (np.float32, 2e-3)])
+@pytest.mark.parametrize("init", ["nndsvd", "nndsvda"])
+def test_device_nndsvd_matches_host(dtype, tol, init):
+    from muscle_synergies_amd.init import initialize_nmf, nndsvd_init_batched
+
+    shapes = [(2000, 16, 5), (2000, 16, 1), (500, 8, 3), (77, 6, 6), (4000, 20, 4)]
+    for T, m, k in shapes:
+        Xs = np.stack([np.ascontiguousarray(emg_matrix(500 + b, T=T, m=m, k_true=min(5, m), dtype=dtype)) for b in range(3)])
+        W0, H0 = nndsvd_init_batched(Xs, k, init=init)
+        W0, H0 = W0.cpu().numpy(), H0.cpu().numpy()
+        assert W0.dtype == dtype and W0.shape == (3, T, k) and H0.shape == (3, k, m)
+        for b in range(3):
+            Wr, Hr = initialize_nmf(Xs[b], k, init=init, random_state=0)
+            scale = max(np.abs(Wr).max(), np.abs(Hr).max())
+            # entries that sit at the 1e-6 truncation threshold may fall on either side of it
+            close_w = np.isclose(W0[b], Wr, rtol=tol, atol=tol * scale)
+            close_h = np.isclose(H0[b], Hr, rtol=tol, atol=tol * scale)
+            assert close_w.mean() > 0.999, (T, m, k, b, (~close_w).sum())
+            assert close_h.all(), (T, m, k, b)
+            assert (W0[b] >= 0).all() and (H0[b] >= 0).all()
+
+
+def test_device_nndsvda_against_live_sklearn_and_as_a_starting_point():
+    sk = pytest.importorskip("sklearn.decomposition._nmf")
+    import muscle_synergies_amd as ms
+    from muscle_synergies_amd.init import nndsvd_init_batched
+    from oracle import nmf_mu_oracle as orc
+
+    Xs = np.stack([np.ascontiguousarray(emg_matrix(600 + b, T=3000, dtype=np.float64)) for b in range(4)])
+    W0, H0 = nndsvd_init_batched(Xs, 5, init="nndsvda")
+    for b in range(4):
+        Ws, Hs = sk._initialize_nmf(Xs[b], 5, init="nndsvda", random_state=0)
+        np.testing.assert_allclose(H0[b].cpu().numpy(), Hs, rtol=1e-6, atol=1e-9)
+        np.testing.assert_allclose(W0[b].cpu().numpy(), Ws, rtol=1e-6, atol=1e-9)
+    res = ms.fit_batched(Xs, W0, H0, max_iter=100, tol=0.0)
+    for b in range(4):
+        Ws, Hs = sk._initialize_nmf(Xs[b], 5, init="nndsvda", random_state=0)
+        ref = orc.nmf_mu_fit(Xs[b], Ws, Hs, max_iter=100, tol=0.0)
+        assert abs(float(res.reconstruction_err[b]) - float(ref["reconstruction_err"])) / np.linalg.norm(Xs[b]) <= 1e-6
+    with pytest.raises(ValueError, match="Negative values"):
+        nndsvd_init_batched(-Xs, 5)
+    with pytest.raises(ValueError, match="can only be used when"):
+        nndsvd_init_batched(Xs, 17)
