@@ -7,7 +7,10 @@ from muscle_synergies_amd.synth import emg_matrix
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-7), (np.float32, 2e-3)])
+# The device path takes the singular triplets from the exact Gram-matrix SVD; sklearn's randomized SVD
+# (k + 10 = 15 random vectors, 4 power iterations) is itself only accurate to ~1e-5 on the tightly clustered
+# trailing singular vectors of a 16-channel matrix (measured: 8.7e-6), and exact when k + 10 >= m.
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-4), (np.float32, 2e-3)])
 @pytest.mark.parametrize("init", ["nndsvd", "nndsvda"])
 def test_device_nndsvd_matches_host(dtype, tol, init):
     from muscle_synergies_amd.init import initialize_nmf, nndsvd_init_batched
@@ -21,6 +24,8 @@ def test_device_nndsvd_matches_host(dtype, tol, init):
         for b in range(3):
             Wr, Hr = initialize_nmf(Xs[b], k, init=init, random_state=0)
             scale = max(np.abs(Wr).max(), np.abs(Hr).max())
+            if dtype == np.float64 and k + 10 >= m:
+                tol = 1e-9  # randomized SVD spans the whole column space: both are exact
             # entries that sit at the 1e-6 truncation threshold may fall on either side of it
             close_w = np.isclose(W0[b], Wr, rtol=tol, atol=tol * scale)
             close_h = np.isclose(H0[b], Hr, rtol=tol, atol=tol * scale)
@@ -39,13 +44,15 @@ def test_device_nndsvda_against_live_sklearn_and_as_a_starting_point():
     W0, H0 = nndsvd_init_batched(Xs, 5, init="nndsvda")
     for b in range(4):
         Ws, Hs = sk._initialize_nmf(Xs[b], 5, init="nndsvda", random_state=0)
-        np.testing.assert_allclose(H0[b].cpu().numpy(), Hs, rtol=1e-6, atol=1e-9)
-        np.testing.assert_allclose(W0[b].cpu().numpy(), Ws, rtol=1e-6, atol=1e-9)
+        np.testing.assert_allclose(H0[b].cpu().numpy(), Hs, rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(W0[b].cpu().numpy(), Ws, rtol=1e-4, atol=1e-4)
     res = ms.fit_batched(Xs, W0, H0, max_iter=100, tol=0.0)
-    for b in range(4):
+    for b in range(4):  # the solver itself, from the device-made starting point, against the oracle
+        ref = orc.nmf_mu_fit(Xs[b], W0[b].cpu().numpy(), H0[b].cpu().numpy(), max_iter=100, tol=0.0)
+        assert abs(float(res.reconstruction_err[b]) - float(ref["reconstruction_err"])) / np.linalg.norm(Xs[b]) <= 1e-9
         Ws, Hs = sk._initialize_nmf(Xs[b], 5, init="nndsvda", random_state=0)
-        ref = orc.nmf_mu_fit(Xs[b], Ws, Hs, max_iter=100, tol=0.0)
-        assert abs(float(res.reconstruction_err[b]) - float(ref["reconstruction_err"])) / np.linalg.norm(Xs[b]) <= 1e-6
+        ref_sk = orc.nmf_mu_fit(Xs[b], Ws, Hs, max_iter=100, tol=0.0)  # and it lands where sklearn's start lands
+        assert abs(float(res.reconstruction_err[b]) - float(ref_sk["reconstruction_err"])) / np.linalg.norm(Xs[b]) <= 1e-4
     with pytest.raises(ValueError, match="Negative values"):
         nndsvd_init_batched(-Xs, 5)
     with pytest.raises(ValueError, match="can only be used when"):
