@@ -24,11 +24,11 @@ def test_device_nndsvd_matches_host(dtype, tol, init):
         for b in range(3):
             Wr, Hr = initialize_nmf(Xs[b], k, init=init, random_state=0)
             scale = max(np.abs(Wr).max(), np.abs(Hr).max())
-            if dtype == np.float64 and k + 10 >= m:
-                tol = 1e-9  # randomized SVD spans the whole column space: both are exact
+            # randomized SVD spans the whole column space when k + 10 >= m: both are exact
+            tl = 1e-9 if (dtype == np.float64 and k + 10 >= m) else tol
             # entries that sit at the 1e-6 truncation threshold may fall on either side of it
-            close_w = np.isclose(W0[b], Wr, rtol=tol, atol=tol * scale)
-            close_h = np.isclose(H0[b], Hr, rtol=tol, atol=tol * scale)
+            close_w = np.isclose(W0[b], Wr, rtol=tl, atol=tl * scale)
+            close_h = np.isclose(H0[b], Hr, rtol=tl, atol=tl * scale)
             assert close_w.mean() > 0.999, (T, m, k, b, (~close_w).sum())
             assert close_h.all(), (T, m, k, b)
             assert (W0[b] >= 0).all() and (H0[b] >= 0).all()
