@@ -74,8 +74,21 @@ def randomized_svd(M, n_components, random_state, n_oversamples=10):
     return Vt[:n_components, :].T, s[:n_components], U[:, :n_components].T
 
 
-def initialize_nmf(X, n_components, init=None, eps=1e-6, random_state=None):
-    """W0 (T x k), H0 (k x m) in ``X.dtype``; same options and error messages as sklearn."""
+def exact_svd(M, n_components):
+    """Leading singular triplets from LAPACK (gesdd) with sklearn's sign convention (``svd_flip``)."""
+    U, s, Vt = linalg.svd(M, full_matrices=False, lapack_driver="gesdd")
+    if M.shape[0] >= M.shape[1]:
+        U, Vt = _svd_flip_u(U, Vt)
+    else:
+        U, Vt = _svd_flip_v(U, Vt)
+    return U[:, :n_components], s[:n_components], Vt[:n_components, :]
+
+
+def initialize_nmf(X, n_components, init=None, eps=1e-6, random_state=None, svd_solver="randomized"):
+    """W0 (T x k), H0 (k x m) in ``X.dtype``; same options and error messages as sklearn.
+
+    ``svd_solver='randomized'`` is sklearn's behaviour; ``'exact'`` takes the triplets from a full LAPACK SVD
+    (what the on-device :func:`nndsvd_init_batched` reproduces through the Gram matrix)."""
     X = np.asarray(X)
     if (X < 0).any():
         raise ValueError("Negative values in data passed to NMF initialization.")
@@ -102,7 +115,10 @@ def initialize_nmf(X, n_components, init=None, eps=1e-6, random_state=None):
             % (init, (None, "random", "nndsvd", "nndsvda", "nndsvdar"))
         )
 
-    U, S, V = randomized_svd(X, n_components, random_state)
+    if svd_solver == "exact":
+        U, S, V = exact_svd(X, n_components)
+    else:
+        U, S, V = randomized_svd(X, n_components, random_state)
     W = np.zeros_like(U)
     H = np.zeros_like(V)
     W[:, 0] = np.sqrt(S[0]) * np.abs(U[:, 0])

@@ -61,3 +61,11 @@ def test_synthetic_workload_is_reproducible(g2_full):
         W0, H0 = random_init(X, 5, c["seed"])
         np.testing.assert_allclose(W0.astype(np.float64).sum(), c["W0_sum"], rtol=1e-7)
         np.testing.assert_allclose(H0.astype(np.float64).sum(), c["H0_sum"], rtol=1e-7)
+
+
+def test_exact_svd_solver_agrees_with_randomized_when_that_is_exact():
+    X = emg_matrix(9, T=300, m=8, k_true=4, dtype=np.float64)
+    a = initialize_nmf(X, 4, init="nndsvda", random_state=0)
+    b = initialize_nmf(X, 4, init="nndsvda", svd_solver="exact")
+    np.testing.assert_allclose(a[0], b[0], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(a[1], b[1], rtol=1e-9, atol=1e-12)
