@@ -22,15 +22,20 @@ def test_device_nndsvd_matches_host(dtype, tol, init):
         W0, H0 = W0.cpu().numpy(), H0.cpu().numpy()
         assert W0.dtype == dtype and W0.shape == (3, T, k) and H0.shape == (3, k, m)
         for b in range(3):
-            Wr, Hr = initialize_nmf(Xs[b], k, init=init, random_state=0)
-            scale = max(np.abs(Wr).max(), np.abs(Hr).max())
-            # randomized SVD spans the whole column space when k + 10 >= m: both are exact
-            tl = 1e-9 if (dtype == np.float64 and k + 10 >= m) else tol
+            # (1) against the host algorithm fed with an exact LAPACK SVD: same triplets, tight tolerance
+            We, He = initialize_nmf(Xs[b], k, init=init, svd_solver="exact")
+            scale = max(np.abs(We).max(), np.abs(He).max())
+            te = 1e-8 if dtype == np.float64 else tol
             # entries that sit at the 1e-6 truncation threshold may fall on either side of it
-            close_w = np.isclose(W0[b], Wr, rtol=tl, atol=tl * scale)
-            close_h = np.isclose(H0[b], Hr, rtol=tl, atol=tl * scale)
+            close_w = np.isclose(W0[b], We, rtol=te, atol=te * scale)
             assert close_w.mean() > 0.999, (T, m, k, b, (~close_w).sum())
-            assert close_h.all(), (T, m, k, b)
+            assert np.isclose(H0[b], He, rtol=te, atol=te * scale).all(), (T, m, k, b)
+            # (2) against sklearn's randomized SVD where that one is exact too (k + 10 >= m)
+            if k + 10 >= m:
+                Wr, Hr = initialize_nmf(Xs[b], k, init=init, random_state=0)
+                tl = 1e-9 if dtype == np.float64 else tol
+                assert np.isclose(W0[b], Wr, rtol=tl, atol=tl * scale).mean() > 0.999, (T, m, k, b)
+                assert np.isclose(H0[b], Hr, rtol=tl, atol=tl * scale).all(), (T, m, k, b)
             assert (W0[b] >= 0).all() and (H0[b] >= 0).all()
 
 
