@@ -130,7 +130,9 @@ def find_synergies_batched(processed_emg_dfs, n_components: int, max_components:
     ``processed_emg_dfs`` is a sequence of DataFrames with the same muscles (columns) and any numbers of rows
     (e.g. the gait cycles cut by ``project/segment.py``).  Returns one :class:`SynergyRunResult` per trial,
     each identical in structure -- and, trial by trial, in values -- to what ``find_synergies`` returns for
-    that DataFrame alone; the factorisations of a rank run together through ``fit_ragged``.
+    that DataFrame alone; the factorisations of a rank run together through ``fit_ragged``.  When all trials
+    have the same length and the init is of the NNDSVD family, the starting factors come from the batched
+    on-device NNDSVD (exact SVD; sklearn's randomized SVD differs from it by its own approximation error).
     """
     from .engine import fit_ragged
     from .init import initialize_nmf
@@ -152,7 +154,15 @@ def find_synergies_batched(processed_emg_dfs, n_components: int, max_components:
         template = HipNMF(rank, init=init, tol=tol, max_iter=max_iter, random_state=random_state, alpha_W=alpha_W,
                           alpha_H=alpha_H, l1_ratio=l1_ratio, device=device)
         template._check_params()
-        inits = [initialize_nmf(a, rank, init=init, random_state=random_state) for a in arrays]
+        equal_len = len({a.shape[0] for a in arrays}) == 1
+        if equal_len and init in (None, "nndsvd", "nndsvda") and rank <= min(arrays[0].shape) and rank <= 8:
+            # one batched on-device NNDSVD (exact Gram-matrix SVD) instead of one randomized SVD per trial
+            from .init import nndsvd_init_batched
+
+            W0d, H0d = nndsvd_init_batched(np.stack(arrays), rank, init=init or "nndsvda", device=device)
+            inits = [(W0d[b], H0d[b]) for b in range(len(arrays))]
+        else:
+            inits = [initialize_nmf(a, rank, init=init, random_state=random_state) for a in arrays]
         # regularisation scales with each trial's own shape (_nmf.py:1254-1265): only equal-length trials share it
         regs = {template._regularization(a.shape[0], a.shape[1]) for a in arrays}
         if len(regs) > 1:

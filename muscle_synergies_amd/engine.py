@@ -257,9 +257,11 @@ class RankSweepResult:
 
 
 def rank_sweep_batched(X, k_min: int, k_max: int, *, vaf_threshold: float = 0.90, max_iter: int = 500,
-                       tol: float = 1e-4, seed: int = 0, device=None, keep_W: bool = False) -> RankSweepResult:
-    """``find_synergies(df, k_min, k_max)`` for a whole batch of trials: one batched fit per rank
-    (``init='random'``), VAF per trial and rank, and the smallest rank with VAF >= ``vaf_threshold``."""
+                       tol: float = 1e-4, seed: int = 0, device=None, keep_W: bool = False,
+                       init: str = "random") -> RankSweepResult:
+    """``find_synergies(df, k_min, k_max)`` for a whole batch of trials: one batched fit per rank, VAF per
+    trial and rank, and the smallest rank with VAF >= ``vaf_threshold``.  ``init='random'`` draws the starting
+    factors on the device; ``'nndsvda'`` / ``'nndsvd'`` (sklearn's default family) use the on-device NNDSVD."""
     torch = _torch()
     dev = resolve_device(device)
     Xt = _as_device_tensor(X, dev)
@@ -272,7 +274,12 @@ def rank_sweep_batched(X, k_min: int, k_max: int, *, vaf_threshold: float = 0.90
     vaf, n_iter, err, comps, Ws = {}, {}, {}, {}, {}
     total_ms = 0.0
     for k in ranks:
-        W0, H0 = random_init_batched(Xt, k, seed=seed + k)
+        if init == "random":
+            W0, H0 = random_init_batched(Xt, k, seed=seed + k)
+        else:
+            from .init import nndsvd_init_batched
+
+            W0, H0 = nndsvd_init_batched(Xt, k, init=init, device=dev)
         r = fit_batched(Xt, W0, H0, max_iter=max_iter, tol=tol, device=dev, return_numpy=False, overwrite_init=True)
         vaf[k], n_iter[k], err[k], comps[k] = r.vaf, r.n_iter, r.reconstruction_err, r.H
         if keep_W:

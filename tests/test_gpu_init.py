@@ -63,3 +63,27 @@ def test_device_nndsvda_against_live_sklearn_and_as_a_starting_point():
         nndsvd_init_batched(-Xs, 5)
     with pytest.raises(ValueError, match="can only be used when"):
         nndsvd_init_batched(Xs, 17)
+
+
+def test_rank_sweep_and_batched_synergies_with_device_nndsvda():
+    import warnings
+
+    import pandas as pd
+    import torch
+
+    import muscle_synergies_amd as ms
+    from muscle_synergies_amd.synth import emg_batch
+
+    Xb = emg_batch(range(70, 76), T=1200, m=16, k_true=4)
+    X = torch.from_numpy(Xb).cuda().transpose(1, 2)
+    a = ms.rank_sweep_batched(X, 2, 5, max_iter=100, tol=0.0, init="nndsvda")
+    assert tuple(a.vaf_all.shape) == (6, 4) and bool(torch.isfinite(a.vaf_all).all())
+    assert float(a.vaf_all[:, -1].min()) > 0.9
+    cols = [f"m{j}" for j in range(16)]
+    dfs = [pd.DataFrame(Xb[b].T.astype(np.float64), columns=cols) for b in range(3)]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        got = ms.find_synergies_batched(dfs, 3, max_iter=200, tol=0.0)           # device NNDSVDa (equal lengths)
+        ref = [ms.find_synergies(df, 3, solver="mu", max_iter=200, tol=0.0, random_state=0) for df in dfs]
+    for g, r in zip(got, ref):  # same optimum up to sklearn's randomized-SVD error in the starting point
+        np.testing.assert_allclose(g.vaf_values.to_numpy(), r.vaf_values.to_numpy(), atol=1e-4)
