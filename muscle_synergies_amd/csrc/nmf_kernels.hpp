@@ -195,7 +195,11 @@ __device__ __forceinline__ void buf_store(rsrc_t r, unsigned voff, unsigned soff
 // re-issued per tile) instead of holding K x CH values in VGPRs: no cross-lane work at all in the row loop.
 template <int G, int CH>
 constexpr bool h_in_lds() {
+#ifdef HIPNMF_HLDS_CH8
+  return CH >= 8;
+#else
   return G == 1 && CH >= 16;
+#endif
 }
 
 template <typename real, int G, int CH, int K>
@@ -348,14 +352,21 @@ __device__ __forceinline__ void update_tile(RowTile<real, G, CH, K>& t, const Ma
   // numerator X H^T (_nmf.py:543): partial over this lane's channels, for each of the G rows
   real pn[G][K];
   if constexpr (h_in_lds<G, CH>()) {
-    const real* hp = ma.h_lds;
+    constexpr int MP = G * CH;
+    const real* hp = ma.h_lds + g * CH;
     asm volatile("" : "+v"(hp));  // opaque per tile: keeps the K*CH broadcast reads inside the row loop
 #pragma unroll
     for (int c = 0; c < K; ++c) {
-      real s = t.x[0][0] * hp[c * CH];
+      real hc[CH];
 #pragma unroll
-      for (int cc = 1; cc < CH; ++cc) s = fma_(t.x[cc][0], hp[c * CH + cc], s);
-      pn[0][c] = s;
+      for (int cc = 0; cc < CH; ++cc) hc[cc] = hp[c * MP + cc];
+#pragma unroll
+      for (int r = 0; r < G; ++r) {
+        real s = t.x[0][r] * hc[0];
+#pragma unroll
+        for (int cc = 1; cc < CH; ++cc) s = fma_(t.x[cc][r], hc[cc], s);
+        pn[r][c] = s;
+      }
     }
   } else {
 #pragma unroll
@@ -416,17 +427,29 @@ template <typename real, int G, int CH, int K>
 __device__ __forceinline__ void resid_tile(const RowTile<real, G, CH, K>& t, const MatAddr<real, G, CH, K>& ma,
                                            const real (&h)[K][CH], real (&sse)[CH], real (&xsq)[CH]) {
   if constexpr (h_in_lds<G, CH>()) {
-    const real* hp = ma.h_lds;
+    constexpr int MP = G * CH;
+    const real* hp = ma.h_lds + ma.g * CH;
     asm volatile("" : "+v"(hp));
+    real hl[K][CH];
 #pragma unroll
-    for (int cc = 0; cc < CH; ++cc) {
-      real rec = t.w[0] * hp[cc];
+    for (int c = 0; c < K; ++c)
 #pragma unroll
-      for (int c = 1; c < K; ++c) rec = fma_(t.w[c], hp[c * CH + cc], rec);
-      const real d = t.x[cc][0] - rec;
-      sse[cc] = fma_(d, d, sse[cc]);
-      xsq[cc] = fma_(t.x[cc][0], t.x[cc][0], xsq[cc]);
-    }
+      for (int cc = 0; cc < CH; ++cc) hl[c][cc] = hp[c * MP + cc];
+    static_for<G>([&](auto R) {
+      constexpr int r = decltype(R)::value;
+      real wr[K];
+#pragma unroll
+      for (int c = 0; c < K; ++c) wr[c] = group_bcast<G, r>(t.w[c]);
+#pragma unroll
+      for (int cc = 0; cc < CH; ++cc) {
+        real rec = wr[0] * hl[0][cc];
+#pragma unroll
+        for (int c = 1; c < K; ++c) rec = fma_(wr[c], hl[c][cc], rec);
+        const real d = t.x[cc][r] - rec;
+        sse[cc] = fma_(d, d, sse[cc]);
+        xsq[cc] = fma_(t.x[cc][r], t.x[cc][r], xsq[cc]);
+      }
+    });
     return;
   }
   static_for<G>([&](auto R) {
