@@ -695,6 +695,70 @@ __device__ __forceinline__ void h_update_lds(Smem<real, G, CH, K>& s, int m, rea
   __syncthreads();
 }
 
+// Persistent-kernel epilogue of an iteration, executed by wave 0 alone between two workgroup barriers:
+// sum the wave records (fixed order) -> W^T X, W^T W; H update (_nmf.py:638-640, 701-728); H H^T.
+// LDS accesses of one wave execute in order, so only compiler/LDS-counter fences are needed inside.
+template <typename real, int G, int CH, int K>
+__device__ __forceinline__ void wave0_combine_and_update_h(Smem<real, G, CH, K>& s, int nw, int m, real l1h, real l2h) {
+  using C = Cfg<real, G, CH, K>;
+  constexpr int MP = C::MP;
+  const int lane = threadIdx.x & (WAVE - 1);
+  for (int i = lane; i < C::NACC; i += WAVE) {
+    real acc = s.part[i];
+    for (int w = 1; w < nw; ++w) acc += s.part[w * C::NACC + i];
+    if (i < K * MP) {
+      s.A[i] = acc;
+    } else {
+      int idx = i - K * MP, c = 0;
+      while (idx >= K - c) {
+        idx -= K - c;
+        ++c;
+      }
+      const int c2 = c + idx;
+      s.B[c * K + c2] = acc;
+      s.B[c2 * K + c] = acc;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+  constexpr int NH = (K * MP + WAVE - 1) / WAVE;
+  real newh[NH];
+#pragma unroll
+  for (int q = 0; q < NH; ++q) {
+    const int i = lane + q * WAVE;
+    newh[q] = (real)0;
+    if (i < K * MP) {
+      const int c = i / MP, j = i % MP;
+      if (j < m) {
+        real d = s.B[c * K + 0] * s.H[0 * MP + j];
+#pragma unroll
+        for (int c2 = 1; c2 < K; ++c2) d = fma_(s.B[c * K + c2], s.H[c2 * MP + j], d);
+        const real hold = s.H[i];
+        if (l1h > (real)0) d = d + l1h;
+        if (l2h > (real)0) d = d + l2h * hold;
+        d = (d == (real)0) ? eps_val<real>() : d;
+        newh[q] = hold * (s.A[i] / d);
+      }
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+#pragma unroll
+  for (int q = 0; q < NH; ++q) {
+    const int i = lane + q * WAVE;
+    if (i < K * MP) s.H[i] = newh[q];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  if (lane < K * K) {
+    const int c = lane / K, c2 = lane % K;
+    real acc = (real)0;
+#pragma unroll
+    for (int j = 0; j < MP; ++j) acc = fma_(s.H[c * MP + j], s.H[c2 * MP + j], acc);
+    s.HHt[lane] = acc;
+  }
+}
+
 // sum of wave records -> LDS A / B (fixed order over waves)
 template <typename real, int G, int CH, int K>
 __device__ __forceinline__ void combine_wave_records(Smem<real, G, CH, K>& s, int nw) {
@@ -817,6 +881,7 @@ __global__ void __launch_bounds__((max_threads<real, G, CH, K>())) HIPNMF_OCC fi
     block_residual<real, G, CH, K>(s, ma, 0, row_end, h);
     real tot = (real)0;
     for (int j = 0; j < MP; ++j) tot += s.part[j];
+    __syncthreads();  // the next iteration writes its wave records into s.part without another barrier
     return sqrt_(tot);
   };
 
@@ -848,12 +913,12 @@ __global__ void __launch_bounds__((max_threads<real, G, CH, K>())) HIPNMF_OCC fi
     // X does not depend on H: start streaming the next iteration's first tiles now, under the reduction
     if (lds_rows > 0 && it < a.max_iter) prefetch_head<real, G, CH, K, true>(tiles_lds, ma, 0, lds_rows);
     if (a.update_h) {
-      __syncthreads();  // previous readers of part are done
+      // s.part was last read before the previous iteration's second barrier (or by a residual pass that ends
+      // with a barrier), so the records can be written right away: two workgroup barriers per iteration
       wave_reduce_acc<real, G, CH, K>(s.part + wave * C::NACC, accA, accB);
       __syncthreads();
-      combine_wave_records(s, nw);
+      if (wave == 0) wave0_combine_and_update_h(s, nw, m, a.l1h, a.l2h);
       __syncthreads();
-      h_update_lds(s, m, a.l1h, a.l2h);
       load_h_regs(s, g, h, hht);
     }
     if (a.tol > (real)0 && (it % a.check_every) == 0) {
