@@ -200,6 +200,108 @@ def vaf(X, W, H):
 
 
 # ---------------------------------------------------------------------------
+# Kullback-Leibler loss (beta_loss = 1) -- SURVEY.md section 8 row f-4.  Dense X only.
+# ---------------------------------------------------------------------------
+EPS64 = np.finfo(np.float64).eps
+
+
+def kl_divergence(X, W, H, square_root: bool = False):
+    """beta = 1 branch of ``_beta_divergence`` (_nmf.py:140-161, 185-189): generalised KL divergence
+    ``sum(X log(X / WH)) - sum(X) + sum(WH)`` with zeros of X skipped and WH clamped at EPSILON."""
+    WH_data = np.dot(W, H).ravel()
+    X_data = X.ravel()
+    indices = X_data > EPSILON
+    WH_data = WH_data[indices]
+    X_data = X_data[indices]
+    WH_data[WH_data < EPSILON] = EPSILON
+    sum_WH = np.dot(np.sum(W, axis=0), np.sum(H, axis=1))
+    div = X_data / WH_data
+    res = np.dot(X_data, np.log(div))
+    res += sum_WH - X_data.sum()
+    if square_root:
+        res = max(res, 0)
+        return np.sqrt(2 * res)
+    return res
+
+
+def kl_update_w(X, W, H, l1_reg_W=0.0, l2_reg_W=0.0):
+    """beta = 1 branch of ``_multiplicative_update_w`` (_nmf.py:556-591, 615-631):
+    ``W *= ((X / WH) H^T) / colsum(H)``."""
+    WH_safe_X = np.dot(W, H)
+    WH_safe_X[WH_safe_X < EPSILON] = EPSILON
+    np.divide(X, WH_safe_X, out=WH_safe_X)
+    numerator = WH_safe_X @ H.T
+    H_sum = np.sum(H, axis=1)
+    denominator = H_sum[np.newaxis, :]
+    if l1_reg_W > 0:
+        denominator = denominator + l1_reg_W
+    if l2_reg_W > 0:
+        denominator = denominator + l2_reg_W * W
+    denominator = np.array(np.broadcast_to(denominator, numerator.shape))
+    denominator[denominator == 0] = EPSILON
+    numerator /= denominator
+    W *= numerator
+    return W
+
+
+def kl_update_h(X, W, H, l1_reg_H=0.0, l2_reg_H=0.0):
+    """beta = 1 branch of ``_multiplicative_update_h`` (_nmf.py:642-684, 701-728):
+    ``H *= (W^T (X / WH)) / colsum(W)``."""
+    WH_safe_X = np.dot(W, H)
+    WH_safe_X[WH_safe_X < EPSILON] = EPSILON
+    np.divide(X, WH_safe_X, out=WH_safe_X)
+    numerator = W.T @ WH_safe_X
+    W_sum = np.sum(W, axis=0)
+    W_sum[W_sum == 0] = 1.0
+    denominator = W_sum[:, np.newaxis]
+    if l1_reg_H > 0:
+        denominator = denominator + l1_reg_H
+    if l2_reg_H > 0:
+        denominator = denominator + l2_reg_H * H
+    denominator = np.array(np.broadcast_to(denominator, numerator.shape))
+    denominator[denominator == 0] = EPSILON
+    numerator /= denominator
+    H *= numerator
+    return H
+
+
+def fit_multiplicative_update_kl(X, W, H, max_iter=200, tol=1e-4, l1_reg_W=0.0, l1_reg_H=0.0, l2_reg_W=0.0,
+                                 l2_reg_H=0.0, update_H=True, check_every=10, err_trace=None):
+    """``_fit_multiplicative_update`` with beta_loss = 1 (_nmf.py:731-893; gamma = 1).  After the H update,
+    entries of H below float64 eps are set to 0 (_nmf.py:866-868; the analogous W rule only applies to
+    beta_loss < 1)."""
+    error_at_init = kl_divergence(X, W, H, square_root=True)
+    previous_error = error_at_init
+    if err_trace is not None:
+        err_trace.append(float(error_at_init))
+    n_iter = 0
+    for n_iter in range(1, max_iter + 1):
+        W = kl_update_w(X, W, H, l1_reg_W, l2_reg_W)
+        if update_H:
+            H = kl_update_h(X, W, H, l1_reg_H, l2_reg_H)
+            H[H < EPS64] = 0.0
+        if tol > 0 and n_iter % check_every == 0:
+            error = kl_divergence(X, W, H, square_root=True)
+            if err_trace is not None:
+                err_trace.append(float(error))
+            if (previous_error - error) / error_at_init < tol:
+                break
+            previous_error = error
+    return W, H, n_iter
+
+
+def nmf_mu_fit_kl(X, W0, H0, max_iter=200, tol=1e-4, alpha_W=0.0, alpha_H="same", l1_ratio=0.0):
+    """``NMF(solver='mu', beta_loss='kullback-leibler', init='custom').fit_transform(X, W=W0, H=H0)``."""
+    X = np.asarray(X)
+    W = np.array(W0, dtype=X.dtype, order="C", copy=True)
+    H = np.array(H0, dtype=X.dtype, order="C", copy=True)
+    regs = compute_regularization(X.shape[0], X.shape[1], alpha_W, alpha_H, l1_ratio)
+    W, H, n_iter = fit_multiplicative_update_kl(X, W, H, max_iter, tol, regs[0], regs[1], regs[2], regs[3])
+    err = kl_divergence(X, W, H, square_root=True)
+    return {"W": W, "H": H, "n_iter": n_iter, "reconstruction_err": err}
+
+
+# ---------------------------------------------------------------------------
 # T-sharded restatement: the same iteration written as per-shard passes plus
 # one sum over shards.  Used by the world_size-2 gloo test to check the
 # multi-GPU orchestration (SURVEY.md section 8e) without a GPU.

@@ -16,6 +16,7 @@ Fixture sets:
   G4  NNDSVD / random initialisation vectors (host-side init parity)
   G5  ``transform`` (update_H=False) and regularised fits
   G6  EMG envelope preprocessing (zero_center, rms, time_normalize, normalize) -- row f-1
+  G7  Kullback-Leibler loss (beta_loss='kullback-leibler') -- row f-4
 """
 
 import json
@@ -292,6 +293,34 @@ def g6():
     print("G6 done")
 
 
+# --------------------------------------------------------------------------- G7
+def g7():
+    """Kullback-Leibler loss (solver='mu', beta_loss='kullback-leibler'): sklearn outputs, T=512."""
+    arrays = {}
+    for dt in (np.float32, np.float64):
+        tag = np.dtype(dt).name
+        X = emg_matrix(7, T=512, dtype=dt)
+        X[::37, 3] = 0  # exact zeros exercise the X > EPSILON mask of the divergence
+        W0, H0 = _initialize_nmf(X, 5, init="nndsvda", random_state=0)
+        arrays[f"X_{tag}"] = np.ascontiguousarray(X)
+        arrays[f"W0_{tag}"], arrays[f"H0_{tag}"] = W0, H0
+        for n in (1, 2, 10, 100):
+            m = NMF(5, solver="mu", beta_loss="kullback-leibler", init="custom", tol=0, max_iter=n)
+            W = m.fit_transform(X, W=W0.copy(), H=H0.copy())
+            arrays[f"W_{tag}_{n}"], arrays[f"H_{tag}_{n}"] = W, m.components_.copy()
+            arrays[f"err_{tag}_{n}"] = np.array(m.reconstruction_err_)
+        m = NMF(5, solver="mu", beta_loss="kullback-leibler", init="custom", tol=1e-4, max_iter=2000)
+        W = m.fit_transform(X, W=W0.copy(), H=H0.copy())
+        arrays[f"stop_n_iter_{tag}"] = np.array(m.n_iter_)
+        arrays[f"stop_err_{tag}"] = np.array(m.reconstruction_err_)
+        m = NMF(5, solver="mu", beta_loss="kullback-leibler", init="custom", tol=0, max_iter=40, alpha_W=0.002,
+                alpha_H=0.001, l1_ratio=0.3)
+        W = m.fit_transform(X, W=W0.copy(), H=H0.copy())
+        arrays[f"W_reg_{tag}"], arrays[f"H_reg_{tag}"] = W, m.components_.copy()
+    np.savez_compressed(os.path.join(HERE, "g7_kl.npz"), **arrays)
+    print("G7 done", arrays["stop_n_iter_float64"])
+
+
 if __name__ == "__main__":
     g1()
     g2_small()
@@ -300,3 +329,4 @@ if __name__ == "__main__":
     g4()
     g5()
     g6()
+    g7()

@@ -115,3 +115,22 @@ def test_sharded_restatement_equals_unsharded():
         orc.h_update_from_sums(sum(s[0] for s in sums), sum(s[1] for s in sums), H)
     np.testing.assert_allclose(W, ref["W"], rtol=1e-9)
     np.testing.assert_allclose(H, ref["H"], rtol=1e-9)
+
+
+@pytest.mark.parametrize("dt", ["float32", "float64"])
+def test_g7_kullback_leibler_oracle(dt):
+    from conftest import load_npz
+
+    g7 = load_npz("g7_kl.npz")
+    X = np.asfortranarray(g7[f"X_{dt}"])
+    for n in (1, 2, 10, 100):
+        r = orc.nmf_mu_fit_kl(X, g7[f"W0_{dt}"], g7[f"H0_{dt}"], max_iter=n, tol=0)
+        scale = 1 if n <= 10 else 50
+        np.testing.assert_allclose(r["W"], g7[f"W_{dt}_{n}"], rtol=RT[dt] * scale, atol=RT[dt] * scale * 1e-2)
+        np.testing.assert_allclose(r["H"], g7[f"H_{dt}_{n}"], rtol=RT[dt] * scale, atol=RT[dt] * scale * 1e-2)
+        np.testing.assert_allclose(r["reconstruction_err"], g7[f"err_{dt}_{n}"], rtol=RT[dt] * scale * 10)
+    r = orc.nmf_mu_fit_kl(X, g7[f"W0_{dt}"], g7[f"H0_{dt}"], max_iter=2000, tol=1e-4)
+    assert r["n_iter"] == int(g7[f"stop_n_iter_{dt}"])
+    r = orc.nmf_mu_fit_kl(X, g7[f"W0_{dt}"], g7[f"H0_{dt}"], max_iter=40, tol=0, alpha_W=0.002, alpha_H=0.001,
+                          l1_ratio=0.3)
+    np.testing.assert_allclose(r["H"], g7[f"H_reg_{dt}"], rtol=RT[dt] * 50, atol=RT[dt])
