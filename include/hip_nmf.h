@@ -49,6 +49,11 @@ extern "C" {
 #define HIPNMF_W_ROW_MAJOR 0       /* W[t*k + c]  (T x k, C order: what sklearn returns)               */
 #define HIPNMF_W_COMPONENT_MAJOR 1 /* W[c*T + t]  (k x T: the engine's native streaming layout)        */
 
+/* objective (sklearn's beta_loss, _nmf.py:1397-1401) */
+#define HIPNMF_LOSS_FROBENIUS 0 /* 'frobenius' (beta = 2): the reference's default, every entry point          */
+#define HIPNMF_LOSS_KL 1        /* 'kullback-leibler' (beta = 1): hipnmf_fit_batched_* / hipnmf_fit_ragged_*;  */
+                                /* err_out = sqrt(2 * KL(X || WH)) as reconstruction_err_ (_nmf.py:185-189)    */
+
 typedef struct hipnmf_handle hipnmf_handle;
 
 /* Problem description shared by every compute entry point (POD, passed by pointer). */
@@ -61,7 +66,7 @@ typedef struct hipnmf_problem {
   int32_t x_layout;       /* HIPNMF_X_*                                                                */
   int32_t update_h;       /* 1: fit (W and H updated, _nmf.py:854); 0: transform (H fixed, :1736-1763) */
   int32_t w_layout;       /* HIPNMF_W_*                                                                */
-  int32_t reserved0;      /* must be 0                                                                 */
+  int32_t loss;           /* HIPNMF_LOSS_*; the shard entry points accept FROBENIUS only               */
   int64_t ldx;            /* leading dimension of one X matrix, in elements                            */
   int64_t x_batch_stride; /* elements between consecutive X matrices                                   */
   int32_t max_iter;       /* >= 1 (NMF max_iter, _nmf.py:831)                                          */

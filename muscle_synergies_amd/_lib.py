@@ -24,6 +24,8 @@ HIPNMF_ERR_HIP = -2
 HIPNMF_ERR_UNSUPPORTED = -3
 HIPNMF_ERR_NO_DEVICE = -4
 
+LOSS_FROBENIUS = 0
+LOSS_KL = 1
 X_ROW_MAJOR = 0
 X_CHANNEL_MAJOR = 1
 W_ROW_MAJOR = 0
@@ -62,7 +64,7 @@ class Problem(ctypes.Structure):
         ("x_layout", ctypes.c_int32),
         ("update_h", ctypes.c_int32),
         ("w_layout", ctypes.c_int32),
-        ("reserved0", ctypes.c_int32),
+        ("loss", ctypes.c_int32),
         ("ldx", ctypes.c_int64),
         ("x_batch_stride", ctypes.c_int64),
         ("max_iter", ctypes.c_int32),

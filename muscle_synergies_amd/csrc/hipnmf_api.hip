@@ -100,7 +100,10 @@ int validate(const hipnmf_problem* p, bool shard) {
     return fail(HIPNMF_ERR_BAD_ARG, "bad x_layout %d", p->x_layout);
   if (p->w_layout != HIPNMF_W_ROW_MAJOR && p->w_layout != HIPNMF_W_COMPONENT_MAJOR)
     return fail(HIPNMF_ERR_BAD_ARG, "bad w_layout %d", p->w_layout);
-  if (p->reserved0 != 0) return fail(HIPNMF_ERR_BAD_ARG, "reserved0 must be 0");
+  if (p->loss != HIPNMF_LOSS_FROBENIUS && p->loss != HIPNMF_LOSS_KL)
+    return fail(HIPNMF_ERR_BAD_ARG, "bad loss %d", p->loss);
+  if (shard && p->loss != HIPNMF_LOSS_FROBENIUS)
+    return fail(HIPNMF_ERR_UNSUPPORTED, "the time-shard entry points implement the Frobenius loss only");
   const long long min_ld = (p->x_layout == HIPNMF_X_ROW_MAJOR) ? p->n_features : p->n_samples;
   if (p->ldx < min_ld) return fail(HIPNMF_ERR_BAD_ARG, "ldx=%lld smaller than %lld", (long long)p->ldx, min_ld);
   if (p->batch > 1 && p->x_batch_stride < 1) return fail(HIPNMF_ERR_BAD_ARG, "x_batch_stride must be >= 1");
@@ -190,6 +193,13 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
     persistent = t_pers <= t_sliced;
   }
   if (!persistent && sg.S == 1 && h->variant != 2) persistent = true;
+  const bool kl = p->loss == HIPNMF_LOSS_KL;
+  if (kl) {
+    // the KL iteration exists as the one-workgroup-per-matrix kernel only (every batch size, any T < 2 GiB)
+    persistent = true;
+    if (!ks->fit_persistent_kl)
+      return fail(HIPNMF_ERR_UNSUPPORTED, "no Kullback-Leibler kernel in the selected instance (G=%d, CH=%d)", ks->G, ks->CH);
+  }
   if (ragged) {
     persistent = true;  // one workgroup per matrix handles any mix of lengths
     if (p->x_layout != HIPNMF_X_CHANNEL_MAJOR || p->w_layout != HIPNMF_W_COMPONENT_MAJOR)
@@ -301,10 +311,11 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
     }
     a.lds_rows = (int)lds_rows;
     const size_t smem = base + sizeof(real) * (size_t)k * (size_t)lds_rows;
+    const auto kern = kl ? ks->fit_persistent_kl : ks->fit_persistent;
     if (smem > 48 * 1024)
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ks->fit_persistent),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    launch<real>(ks->fit_persistent, dim3(B), dim3(threads), smem, st, a);
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)smem));
+    launch<real>(kern, dim3(B), dim3(threads), smem, st, a);
   } else {
     a.S = sg.S;
     a.rows_per_slice = sg.rows_per_slice;

@@ -9,6 +9,7 @@ template <typename real>
 struct KernelSet {
   using Fn = void (*)(SolveArgs<real>);
   Fn fit_persistent, slice_pass, reduce_slices, hupdate, slice_resid, resid_finalize;
+  Fn fit_persistent_kl;  // Kullback-Leibler loss (persistent path only); nullptr where not built
   int G, CH, K, MP, NACC, max_threads;
   size_t (*smem_bytes)(int nw);
 };
@@ -17,6 +18,10 @@ template <typename real, int G, int CH, int K>
 KernelSet<real> make_kernel_set() {
   KernelSet<real> ks;
   ks.fit_persistent = fit_persistent_kernel<real, G, CH, K>;
+  if constexpr (h_in_lds<G, CH>())
+    ks.fit_persistent_kl = nullptr;
+  else
+    ks.fit_persistent_kl = fit_persistent_kernel<real, G, CH, K, 1>;
   ks.slice_pass = slice_pass_kernel<real, G, CH, K>;
   ks.reduce_slices = reduce_slices_kernel<real, G, CH, K>;
   ks.hupdate = hupdate_kernel<real, G, CH, K>;

@@ -216,7 +216,7 @@ struct Cfg {
   static constexpr int NB = K * (K + 1) / 2;   // upper triangle of W^T W
   static constexpr int NACC = K * MP + NB;     // floats per wave partial
   // LDS record per wave: the update pass stores NACC sums, the residual pass 2*MP (sse | xsq)
-  static constexpr int NREC = NACC > 2 * MP ? NACC : 2 * MP;
+  static constexpr int NREC = NACC > 2 * MP + 1 ? NACC : 2 * MP + 1;  // +1: KL divergence partial
 };
 
 // kernel arguments (canonical layouts: X channel-major with ldx % G == 0, W component-major)
@@ -422,10 +422,95 @@ __device__ __forceinline__ void update_tile(RowTile<real, G, CH, K>& t, const Ma
   }
 }
 
-// residual of the group's rows restricted to this lane's channels: sse += (x - w.h)^2, xsq += x^2
+// ------------------------------------------------------------------------------------------------
+// Kullback-Leibler loss (beta_loss = 1).  Same lane mapping as update_tile:
+//   W *= ((X / WH) H^T) / rowsum(H)          (_nmf.py:556-591, 615-631), WH clamped at EPSILON (:574-575)
+//   H *= (W^T (X / WH)) / colsum(W)          (_nmf.py:642-684, 701-728) -- WH recomputed with the new W
+// hsum[c] = sum_j H[c][j] arrives in hht[0][c]; accB[0..K) accumulates colsum(W) (the rest stays 0).
 template <typename real, int G, int CH, int K>
+__device__ __forceinline__ void update_tile_kl(RowTile<real, G, CH, K>& t, const MatAddr<real, G, CH, K>& ma,
+                                               const real (&h)[K][CH], const real (&hht)[K][K],
+                                               real (&accA)[K][CH], real (&accB)[Cfg<real, G, CH, K>::NB],
+                                               real l1w, real l2w, bool update_h) {
+  const int g = ma.g;
+  // q = X / max(WH, EPSILON) for the group's G rows restricted to this lane's channels
+  real q[CH][G];
+  static_for<G>([&](auto R) {
+    constexpr int r = decltype(R)::value;
+    real wr[K];
+#pragma unroll
+    for (int c = 0; c < K; ++c) wr[c] = group_bcast<G, r>(t.w[c]);
+#pragma unroll
+    for (int cc = 0; cc < CH; ++cc) {
+      real rec = wr[0] * h[0][cc];
+#pragma unroll
+      for (int c = 1; c < K; ++c) rec = fma_(wr[c], h[c][cc], rec);
+      rec = rec < eps_val<real>() ? eps_val<real>() : rec;
+      if constexpr (sizeof(real) == 4)
+        q[cc][r] = fast_div(t.x[cc][r], rec);
+      else
+        q[cc][r] = t.x[cc][r] / rec;
+    }
+  });
+  real pn[G][K];
+#pragma unroll
+  for (int r = 0; r < G; ++r)
+#pragma unroll
+    for (int c = 0; c < K; ++c) {
+      real s = q[0][r] * h[c][0];
+#pragma unroll
+      for (int cc = 1; cc < CH; ++cc) s = fma_(q[cc][r], h[c][cc], s);
+      pn[r][c] = s;
+    }
+  reduce_scatter<G / 2, real, G, K>(pn, g);
+  real wn[K], den[K], num[K], quo[K];
+#pragma unroll
+  for (int c = 0; c < K; ++c) {
+    real d = hht[0][c];
+    if (l1w > (real)0) d = d + l1w;
+    if (l2w > (real)0) d = d + l2w * t.w[c];
+    den[c] = (d == (real)0) ? eps_val<real>() : d;
+    num[c] = pn[0][c];
+  }
+  quotients<K>(num, den, quo);
+#pragma unroll
+  for (int c = 0; c < K; ++c) wn[c] = t.w[c] * quo[c];
+#pragma unroll
+  for (int c = 0; c < K; ++c) t.w[c] = wn[c];
+  if (update_h) {
+    static_for<G>([&](auto R) {
+      constexpr int r = decltype(R)::value;
+      real wr[K];
+#pragma unroll
+      for (int c = 0; c < K; ++c) wr[c] = group_bcast<G, r>(wn[c]);
+#pragma unroll
+      for (int cc = 0; cc < CH; ++cc) {
+        real rec = wr[0] * h[0][cc];
+#pragma unroll
+        for (int c = 1; c < K; ++c) rec = fma_(wr[c], h[c][cc], rec);
+        rec = rec < eps_val<real>() ? eps_val<real>() : rec;
+        real qq;
+        if constexpr (sizeof(real) == 4)
+          qq = fast_div(t.x[cc][r], rec);
+        else
+          qq = t.x[cc][r] / rec;
+#pragma unroll
+        for (int c = 0; c < K; ++c) accA[c][cc] = fma_(wr[c], qq, accA[c][cc]);
+      }
+    });
+#pragma unroll
+    for (int c = 0; c < K; ++c) accB[c] += wn[c];
+  }
+}
+
+// residual of the group's rows restricted to this lane's channels: sse += (x - w.h)^2, xsq += x^2
+// LOSS == 1 additionally accumulates the generalised KL divergence (_nmf.py:140-161, 185-189), element by
+// element as x log(x / wh) - x + wh (each term >= 0) with zeros of X skipped and wh clamped at EPSILON.
+__device__ __forceinline__ float log_(float a) { return ::logf(a); }
+__device__ __forceinline__ double log_(double a) { return ::log(a); }
+template <typename real, int G, int CH, int K, int LOSS = 0>
 __device__ __forceinline__ void resid_tile(const RowTile<real, G, CH, K>& t, const MatAddr<real, G, CH, K>& ma,
-                                           const real (&h)[K][CH], real (&sse)[CH], real (&xsq)[CH]) {
+                                           const real (&h)[K][CH], real (&sse)[CH], real (&xsq)[CH], real& kl) {
   if constexpr (h_in_lds<G, CH>()) {
     constexpr int MP = G * CH;
     const real* hp = ma.h_lds + ma.g * CH;
@@ -465,6 +550,15 @@ __device__ __forceinline__ void resid_tile(const RowTile<real, G, CH, K>& t, con
       const real d = t.x[cc][r] - rec;
       sse[cc] = fma_(d, d, sse[cc]);
       xsq[cc] = fma_(t.x[cc][r], t.x[cc][r], xsq[cc]);
+      if constexpr (LOSS == 1) {
+        const real x = t.x[cc][r];
+        real term = rec;
+        if (x > eps_val<real>()) {
+          const real whc = rec < eps_val<real>() ? eps_val<real>() : rec;
+          term = fma_(x, log_(x / whc), rec - x);
+        }
+        kl += term;
+      }
     }
   });
 }
@@ -556,7 +650,7 @@ __device__ __forceinline__ void prefetch_head(RowTile<real, G, CH, K> (&tiles)[P
 
 // PRELOADED: `tiles` already holds (or has in flight) the first PF tiles -- the persistent kernel issues them
 // before the reduction / H-update phase of the previous iteration so the pipeline never starts cold.
-template <typename real, int G, int CH, int K, bool WLDS = false, bool PRELOADED = false>
+template <typename real, int G, int CH, int K, bool WLDS = false, bool PRELOADED = false, int LOSS = 0>
 __device__ __forceinline__ void rows_update_pass(const MatAddr<real, G, CH, K>& ma, int row_begin, int row_end,
                                                  const real (&h)[K][CH], const real (&hht)[K][K],
                                                  real (&accA)[K][CH], real (&accB)[Cfg<real, G, CH, K>::NB], real l1w,
@@ -577,7 +671,10 @@ __device__ __forceinline__ void rows_update_pass(const MatAddr<real, G, CH, K>& 
   for (int grp = 0; grp < nfull; ++grp) {
 #pragma unroll
     for (int p = 0; p < PF; ++p) {
-      update_tile<real, G, CH, K>(tiles[p], ma, h, hht, accA, accB, l1w, l2w, update_h);
+      if constexpr (LOSS == 1)
+        update_tile_kl<real, G, CH, K>(tiles[p], ma, h, hht, accA, accB, l1w, l2w, update_h);
+      else
+        update_tile<real, G, CH, K>(tiles[p], ma, h, hht, accA, accB, l1w, l2w, update_h);
       store_w<real, G, CH, K, WLDS>(tiles[p], ma, wbase);
       const int nb = wbase + PF * stride;
       load_tile<real, G, CH, K, WLDS>(tiles[p], ma, nb, nb < row_end);
@@ -590,16 +687,19 @@ __device__ __forceinline__ void rows_update_pass(const MatAddr<real, G, CH, K>& 
 #pragma unroll
   for (int p = 0; p < PF - 1; ++p) {
     if (p < rem) {  // wave-uniform
-      update_tile<real, G, CH, K>(tiles[p], ma, h, hht, accA, accB, l1w, l2w, update_h);
+      if constexpr (LOSS == 1)
+        update_tile_kl<real, G, CH, K>(tiles[p], ma, h, hht, accA, accB, l1w, l2w, update_h);
+      else
+        update_tile<real, G, CH, K>(tiles[p], ma, h, hht, accA, accB, l1w, l2w, update_h);
       store_w<real, G, CH, K, WLDS>(tiles[p], ma, wbase);
       wbase += stride;
     }
   }
 }
 
-template <typename real, int G, int CH, int K, bool WLDS = false>
+template <typename real, int G, int CH, int K, bool WLDS = false, int LOSS = 0>
 __device__ __forceinline__ void rows_resid_pass(const MatAddr<real, G, CH, K>& ma, int row_begin, int row_end,
-                                                const real (&h)[K][CH], real (&sse)[CH], real (&xsq)[CH]) {
+                                                const real (&h)[K][CH], real (&sse)[CH], real (&xsq)[CH], real& kl) {
   // readfirstlane makes the wave id (hence every row base / SGPR offset) provably wave-uniform; without it
   // hipcc wraps each buffer access in a waterfall loop
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
@@ -610,11 +710,11 @@ __device__ __forceinline__ void rows_resid_pass(const MatAddr<real, G, CH, K>& m
   load_tile<real, G, CH, K, WLDS>(ta, ma, wbase, true);
   while (true) {
     load_tile<real, G, CH, K, WLDS>(tb, ma, wbase + stride, wbase + stride < row_end);
-    resid_tile<real, G, CH, K>(ta, ma, h, sse, xsq);
+    resid_tile<real, G, CH, K, LOSS>(ta, ma, h, sse, xsq, kl);
     wbase += stride;
     if (wbase >= row_end) break;
     load_tile<real, G, CH, K, WLDS>(ta, ma, wbase + stride, wbase + stride < row_end);
-    resid_tile<real, G, CH, K>(tb, ma, h, sse, xsq);
+    resid_tile<real, G, CH, K, LOSS>(tb, ma, h, sse, xsq, kl);
     wbase += stride;
     if (wbase >= row_end) break;
   }
@@ -693,6 +793,61 @@ __device__ __forceinline__ void h_update_lds(Smem<real, G, CH, K>& s, int m, rea
   __syncthreads();
   compute_hht(s);
   __syncthreads();
+}
+
+// KL: rowsum(H) (the W-update denominator, _nmf.py:577-581) into s.HHt[0..K); call between barriers
+template <typename real, int G, int CH, int K>
+__device__ __forceinline__ void compute_hsum(Smem<real, G, CH, K>& s) {
+  constexpr int MP = G * CH;
+  if (threadIdx.x < K) {
+    real acc = (real)0;
+#pragma unroll
+    for (int j = 0; j < MP; ++j) acc += s.H[threadIdx.x * MP + j];
+    s.HHt[threadIdx.x] = acc;
+  }
+}
+
+// KL epilogue (wave 0 alone): records hold W^T (X / WH) [K][MP] followed by colsum(W) [K].
+//   H *= A / colsum(W)   (_nmf.py:663-684, 701-728; colsum 0 -> 1, then regularisation, then 0 -> EPSILON),
+//   H[H < float64 eps] = 0 (_nmf.py:866-868), rowsum(H) for the next W update.
+template <typename real, int G, int CH, int K>
+__device__ __forceinline__ void wave0_combine_and_update_h_kl(Smem<real, G, CH, K>& s, int nw, int m, real l1h, real l2h) {
+  using C = Cfg<real, G, CH, K>;
+  constexpr int MP = C::MP;
+  const int lane = threadIdx.x & (WAVE - 1);
+  for (int i = lane; i < K * MP + K; i += WAVE) {
+    real acc = s.part[i];
+    for (int w = 1; w < nw; ++w) acc += s.part[w * C::NACC + i];
+    if (i < K * MP)
+      s.A[i] = acc;
+    else
+      s.B[i - K * MP] = acc;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+  for (int i = lane; i < K * MP; i += WAVE) {
+    const int c = i / MP, j = i % MP;
+    real newh = (real)0;
+    if (j < m) {
+      real d = s.B[c];
+      if (d == (real)0) d = (real)1;
+      const real hold = s.H[i];
+      if (l1h > (real)0) d = d + l1h;
+      if (l2h > (real)0) d = d + l2h * hold;
+      d = (d == (real)0) ? eps_val<real>() : d;
+      newh = hold * (s.A[i] / d);
+      if (newh < (real)2.220446049250313e-16) newh = (real)0;
+    }
+    s.H[i] = newh;  // element i is read and written by the same lane only
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  if (lane < K) {
+    real acc = (real)0;
+#pragma unroll
+    for (int j = 0; j < MP; ++j) acc += s.H[lane * MP + j];
+    s.HHt[lane] = acc;
+  }
 }
 
 // Persistent-kernel epilogue of an iteration, executed by wave 0 alone between two workgroup barriers:
@@ -783,23 +938,24 @@ __device__ __forceinline__ void combine_wave_records(Smem<real, G, CH, K>& s, in
 }
 
 // block-wide residual over rows [row_begin,row_end): returns per-column sse/xsq in LDS part[0 .. 2*MP)
-// (sums over the block's waves, fixed order).  Barriers inside.
-template <typename real, int G, int CH, int K>
+// (sums over the block's waves, fixed order) and, for LOSS == 1, the KL divergence in part[2*MP].  Barriers inside.
+template <typename real, int G, int CH, int K, int LOSS = 0>
 __device__ __forceinline__ void block_residual(Smem<real, G, CH, K>& s, const MatAddr<real, G, CH, K>& ma, int row_begin,
                                                int row_end, const real (&h)[K][CH]) {
   constexpr int MP = G * CH;
+  constexpr int NR = 2 * MP + (LOSS == 1 ? 1 : 0);
   const int lane = threadIdx.x & (WAVE - 1);
   const int wave = threadIdx.x / WAVE;
   const int nw = blockDim.x / WAVE;
-  real sse[CH], xsq[CH];
+  real sse[CH], xsq[CH], kl = (real)0;
 #pragma unroll
   for (int cc = 0; cc < CH; ++cc) sse[cc] = xsq[cc] = (real)0;
   if (ma.lds_used > 0) {
     const int split = row_end < ma.lds_used ? row_end : ma.lds_used;
-    rows_resid_pass<real, G, CH, K, true>(ma, row_begin, split, h, sse, xsq);
-    rows_resid_pass<real, G, CH, K, false>(ma, split, row_end, h, sse, xsq);
+    rows_resid_pass<real, G, CH, K, true, LOSS>(ma, row_begin, split, h, sse, xsq, kl);
+    rows_resid_pass<real, G, CH, K, false, LOSS>(ma, split, row_end, h, sse, xsq, kl);
   } else {
-    rows_resid_pass<real, G, CH, K, false>(ma, row_begin, row_end, h, sse, xsq);
+    rows_resid_pass<real, G, CH, K, false, LOSS>(ma, row_begin, row_end, h, sse, xsq, kl);
   }
 #pragma unroll
   for (int off = G; off < WAVE; off <<= 1)
@@ -808,8 +964,12 @@ __device__ __forceinline__ void block_residual(Smem<real, G, CH, K>& s, const Ma
       sse[cc] += __shfl_xor(sse[cc], off, WAVE);
       xsq[cc] += __shfl_xor(xsq[cc], off, WAVE);
     }
+  if constexpr (LOSS == 1) {
+#pragma unroll
+    for (int off = 1; off < WAVE; off <<= 1) kl += __shfl_xor(kl, off, WAVE);
+  }
   __syncthreads();  // part may still be read by a previous phase
-  real* rec = s.part + wave * (2 * MP);
+  real* rec = s.part + wave * NR;
   if (lane < G) {
 #pragma unroll
     for (int cc = 0; cc < CH; ++cc) {
@@ -817,11 +977,14 @@ __device__ __forceinline__ void block_residual(Smem<real, G, CH, K>& s, const Ma
       rec[MP + lane * CH + cc] = xsq[cc];
     }
   }
+  if constexpr (LOSS == 1) {
+    if (lane == 0) rec[2 * MP] = kl;
+  }
   __syncthreads();
-  // thread i reads part[i + w*2*MP] and rewrites part[i]: no other thread touches part[i]
-  if (threadIdx.x < 2 * MP) {
+  // thread i reads part[i + w*NR] and rewrites part[i]: no other thread touches part[i]
+  if (threadIdx.x < NR) {
     real acc = s.part[threadIdx.x];
-    for (int w = 1; w < nw; ++w) acc += s.part[w * 2 * MP + threadIdx.x];
+    for (int w = 1; w < nw; ++w) acc += s.part[w * NR + threadIdx.x];
     s.part[threadIdx.x] = acc;
   }
   __syncthreads();
@@ -830,7 +993,8 @@ __device__ __forceinline__ void block_residual(Smem<real, G, CH, K>& s, const Ma
 // =================================================================================================
 // Kernel 1: one workgroup per matrix, all iterations inside the kernel (batch mode, S == 1).
 // =================================================================================================
-template <typename real, int G, int CH, int K>
+// LOSS: 0 = Frobenius (beta_loss = 2), 1 = Kullback-Leibler (beta_loss = 1; update_tile_kl)
+template <typename real, int G, int CH, int K, int LOSS = 0>
 __global__ void __launch_bounds__((max_threads<real, G, CH, K>())) HIPNMF_OCC fit_persistent_kernel(SolveArgs<real> a) {
   using C = Cfg<real, G, CH, K>;
   constexpr int MP = C::MP;
@@ -872,17 +1036,30 @@ __global__ void __launch_bounds__((max_threads<real, G, CH, K>())) HIPNMF_OCC fi
 
   load_h_to_lds(s, Hb, m);
   __syncthreads();
-  compute_hht(s);
+  if constexpr (LOSS == 1)
+    compute_hsum(s);
+  else
+    compute_hht(s);
   __syncthreads();
   real h[K][CH], hht[K][K];
   load_h_regs(s, g, h, hht);
 
+  // reconstruction error from the block sums in s.part: ||X - WH||_F, or sqrt(2 KL(X || WH)) (_nmf.py:185-189)
+  auto error_from_part = [&]() -> real {
+    if constexpr (LOSS == 1) {
+      const real d = s.part[2 * MP];
+      return sqrt_((real)2 * (d > (real)0 ? d : (real)0));
+    } else {
+      real tot = (real)0;
+      for (int j = 0; j < MP; ++j) tot += s.part[j];
+      return sqrt_(tot);
+    }
+  };
   auto residual = [&]() -> real {
-    block_residual<real, G, CH, K>(s, ma, 0, row_end, h);
-    real tot = (real)0;
-    for (int j = 0; j < MP; ++j) tot += s.part[j];
+    block_residual<real, G, CH, K, LOSS>(s, ma, 0, row_end, h);
+    const real e = error_from_part();
     __syncthreads();  // the next iteration writes its wave records into s.part without another barrier
-    return sqrt_(tot);
+    return e;
   };
 
   real err0 = (real)0, prev = (real)0;
@@ -903,12 +1080,12 @@ __global__ void __launch_bounds__((max_threads<real, G, CH, K>())) HIPNMF_OCC fi
 #pragma unroll
     for (int i = 0; i < C::NB; ++i) accB[i] = (real)0;
     if (lds_rows > 0)
-      rows_update_pass<real, G, CH, K, true, true>(ma, 0, lds_rows, h, hht, accA, accB, a.l1w, a.l2w,
-                                                   a.update_h != 0, tiles_lds);
+      rows_update_pass<real, G, CH, K, true, true, LOSS>(ma, 0, lds_rows, h, hht, accA, accB, a.l1w, a.l2w,
+                                                         a.update_h != 0, tiles_lds);
     {
       RowTile<real, G, CH, K> tiles_glb[PipeDepth<false>::value];
-      rows_update_pass<real, G, CH, K, false, false>(ma, lds_rows, row_end, h, hht, accA, accB, a.l1w, a.l2w,
-                                                     a.update_h != 0, tiles_glb);
+      rows_update_pass<real, G, CH, K, false, false, LOSS>(ma, lds_rows, row_end, h, hht, accA, accB, a.l1w, a.l2w,
+                                                           a.update_h != 0, tiles_glb);
     }
     // X does not depend on H: start streaming the next iteration's first tiles now, under the reduction
     if (lds_rows > 0 && it < a.max_iter) prefetch_head<real, G, CH, K, true>(tiles_lds, ma, 0, lds_rows);
@@ -917,7 +1094,12 @@ __global__ void __launch_bounds__((max_threads<real, G, CH, K>())) HIPNMF_OCC fi
       // with a barrier), so the records can be written right away: two workgroup barriers per iteration
       wave_reduce_acc<real, G, CH, K>(s.part + wave * C::NACC, accA, accB);
       __syncthreads();
-      if (wave == 0) wave0_combine_and_update_h(s, nw, m, a.l1h, a.l2h);
+      if (wave == 0) {
+        if constexpr (LOSS == 1)
+          wave0_combine_and_update_h_kl(s, nw, m, a.l1h, a.l2h);
+        else
+          wave0_combine_and_update_h(s, nw, m, a.l1h, a.l2h);
+      }
       __syncthreads();
       load_h_regs(s, g, h, hht);
     }
@@ -928,11 +1110,9 @@ __global__ void __launch_bounds__((max_threads<real, G, CH, K>())) HIPNMF_OCC fi
     }
   }
   // reconstruction_err_ (_nmf.py:1628-1630) + per-column SSE / sum X^2 for VAF (analysis.py:654-662)
-  block_residual<real, G, CH, K>(s, ma, 0, row_end, h);
+  block_residual<real, G, CH, K, LOSS>(s, ma, 0, row_end, h);
   if (threadIdx.x == 0) {
-    real tot = (real)0;
-    for (int j = 0; j < MP; ++j) tot += s.part[j];
-    if (a.err_out) a.err_out[b] = sqrt_(tot);
+    if (a.err_out) a.err_out[b] = error_from_part();
     if (a.n_iter_out) a.n_iter_out[b] = n_iter;
   }
   if (threadIdx.x < m) {

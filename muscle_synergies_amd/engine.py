@@ -89,13 +89,23 @@ def _x_layout(Xt):
     return _lib.X_ROW_MAJOR, m, T * m, Xc
 
 
+def beta_loss_code(beta_loss) -> int:
+    """sklearn's ``beta_loss`` spelling (``_nmf.py:86-92``) -> ``HIPNMF_LOSS_*``; anything but Frobenius (2)
+    and Kullback-Leibler (1) is outside this engine."""
+    if beta_loss in ("frobenius", 2, 2.0):
+        return _lib.LOSS_FROBENIUS
+    if beta_loss in ("kullback-leibler", 1, 1.0):
+        return _lib.LOSS_KL
+    raise NotImplementedError(f"beta_loss={beta_loss!r}: the HIP engine implements 'frobenius' and 'kullback-leibler'")
+
+
 def make_problem(B, T, m, k, *, x_layout, ldx, x_batch_stride, w_layout=_lib.W_ROW_MAJOR, update_H=True,
                  max_iter=200, tol=1e-4, check_every=10, l1_reg_W=0.0, l1_reg_H=0.0, l2_reg_W=0.0,
-                 l2_reg_H=0.0) -> _lib.Problem:
+                 l2_reg_H=0.0, loss=_lib.LOSS_FROBENIUS) -> _lib.Problem:
     p = _lib.Problem()
     p.struct_size = ctypes.sizeof(_lib.Problem)
     p.batch, p.n_samples, p.n_features, p.n_components = int(B), int(T), int(m), int(k)
-    p.x_layout, p.update_h, p.w_layout, p.reserved0 = int(x_layout), int(bool(update_H)), int(w_layout), 0
+    p.x_layout, p.update_h, p.w_layout, p.loss = int(x_layout), int(bool(update_H)), int(w_layout), int(loss)
     p.ldx, p.x_batch_stride = int(ldx), int(x_batch_stride)
     p.max_iter, p.check_every, p.tol = int(max_iter), int(check_every), float(tol)
     p.l1_reg_W, p.l1_reg_H = float(l1_reg_W), float(l1_reg_H)
@@ -105,7 +115,7 @@ def make_problem(B, T, m, k, *, x_layout, ldx, x_batch_stride, w_layout=_lib.W_R
 
 def fit_batched(X, W0, H0, *, max_iter: int = 200, tol: float = 1e-4, check_every: int = 10,
                 update_H: bool = True, l1_reg_W: float = 0.0, l1_reg_H: float = 0.0, l2_reg_W: float = 0.0,
-                l2_reg_H: float = 0.0, device=None, handle: Optional[_lib.Handle] = None,
+                l2_reg_H: float = 0.0, beta_loss="frobenius", device=None, handle: Optional[_lib.Handle] = None,
                 return_numpy: Optional[bool] = None, overwrite_init: bool = False) -> BatchedResult:
     """Factorise a batch of matrices on one GPU.
 
@@ -116,6 +126,8 @@ def fit_batched(X, W0, H0, *, max_iter: int = 200, tol: float = 1e-4, check_ever
         W0: ``[B, T, k]`` initial activations; H0: ``[B, k, m]`` initial synergies (``init='custom'``).
         max_iter, tol: as ``sklearn.decomposition.NMF``; ``tol=0`` runs exactly ``max_iter`` updates.
         update_H: ``False`` keeps H fixed (``NMF.transform``).
+        beta_loss: ``'frobenius'`` (the reference's default) or ``'kullback-leibler'``
+           (``reconstruction_err`` is then ``sqrt(2 KL(X || WH))``; ``vaf`` stays the squared-error VAF).
         overwrite_init: let the solver update contiguous device tensors ``W0``/``H0`` in place (no copy).
     """
     torch = _torch()
@@ -154,7 +166,7 @@ def fit_batched(X, W0, H0, *, max_iter: int = 200, tol: float = 1e-4, check_ever
 
     p = make_problem(B, T, m, k, x_layout=x_layout, ldx=ldx, x_batch_stride=xbs, update_H=update_H,
                      max_iter=max_iter, tol=tol, check_every=check_every, l1_reg_W=l1_reg_W, l1_reg_H=l1_reg_H,
-                     l2_reg_W=l2_reg_W, l2_reg_H=l2_reg_H)
+                     l2_reg_W=l2_reg_W, l2_reg_H=l2_reg_H, loss=beta_loss_code(beta_loss))
     err = torch.empty((B,), dtype=Xt.dtype, device=dev)
     n_iter = torch.empty((B,), dtype=torch.int32, device=dev)
     sse = torch.empty((B, m), dtype=Xt.dtype, device=dev)

@@ -5,7 +5,8 @@ The reference constructs ``NMF(n_components=k, **sklearn_kwargs)`` and calls ``f
 (``src/muscle_synergies/analysis.py:862-863``), then reads ``components_`` (``:875, 879``) and hands the
 model object to the user (``:882``), who may look at ``n_iter_``, ``reconstruction_err_``,
 ``n_components_`` or call ``transform`` / ``inverse_transform`` (``analysis.py:763-767``).  This class
-duck-types exactly that, for ``solver='mu'`` with ``beta_loss='frobenius'`` on dense input; parameter
+duck-types exactly that, for ``solver='mu'`` with ``beta_loss`` ``'frobenius'`` (the reference's default)
+or ``'kullback-leibler'`` on dense input; parameter
 names, defaults, validation messages and warnings follow sklearn 1.7.2
 (``sklearn/decomposition/_nmf.py:1140-1265, 1538-1763``).
 """
@@ -54,11 +55,11 @@ def _check_init(A, shape, whom):
 
 
 class HipNMF:
-    """NMF by multiplicative updates (Frobenius loss) on an AMD MI355X.
+    """NMF by multiplicative updates (Frobenius or Kullback-Leibler loss) on an AMD MI355X.
 
-    Parameters mirror ``sklearn.decomposition.NMF``; only ``solver='mu'`` and
-    ``beta_loss in ('frobenius', 2)`` are implemented here -- ``find_synergies`` routes everything else
-    to sklearn, as the reference does.
+    Parameters mirror ``sklearn.decomposition.NMF``; only ``solver='mu'`` with
+    ``beta_loss in ('frobenius', 2, 'kullback-leibler', 1)`` is implemented here -- ``find_synergies``
+    routes everything else to sklearn, as the reference does.
     """
 
     def __init__(self, n_components=None, *, init=None, solver="mu", beta_loss="frobenius", tol=1e-4,
@@ -98,14 +99,15 @@ class HipNMF:
     @staticmethod
     def supports(solver="cd", beta_loss="frobenius", **_ignored) -> bool:
         """True when these NMF kwargs select the path this engine implements."""
-        return solver == "mu" and beta_loss in ("frobenius", 2, 2.0)
+        return solver == "mu" and beta_loss in ("frobenius", 2, 2.0, "kullback-leibler", 1, 1.0)
 
     def _check_params(self):
         if self.solver != "mu":
             raise ValueError(f"HipNMF implements solver='mu' only (got {self.solver!r})")
-        if self.beta_loss not in ("frobenius", 2, 2.0):
+        if self.beta_loss not in ("frobenius", 2, 2.0, "kullback-leibler", 1, 1.0):
             raise NotImplementedError(
-                f"HipNMF implements beta_loss='frobenius' only (got {self.beta_loss!r}); use sklearn for other losses"
+                f"HipNMF implements beta_loss 'frobenius' and 'kullback-leibler' (got {self.beta_loss!r}); "
+                "use sklearn for other losses"
             )
         if not (isinstance(self.max_iter, (int, np.integer)) and self.max_iter >= 1):
             raise ValueError(f"The 'max_iter' parameter of NMF must be an int in the range [1, inf). Got {self.max_iter!r} instead.")
@@ -174,7 +176,8 @@ class HipNMF:
             W0, H0 = initialize_nmf(X, k, init=self.init, random_state=self.random_state)
         l1w, l1h, l2w, l2h = self._regularization(T, m)
         res = engine.fit_batched(X, W0, H0, max_iter=self.max_iter, tol=self.tol, l1_reg_W=l1w, l1_reg_H=l1h,
-                                 l2_reg_W=l2w, l2_reg_H=l2h, device=self.device, return_numpy=True)
+                                 l2_reg_W=l2w, l2_reg_H=l2h, beta_loss=self.beta_loss, device=self.device,
+                                 return_numpy=True)
         n_iter = int(res.n_iter[0])
         if n_iter == self.max_iter and self.tol > 0:
             warnings.warn("Maximum number of iterations %d reached. Increase it to improve convergence." % self.max_iter,
@@ -210,7 +213,8 @@ class HipNMF:
         W0 = np.full((T, k), avg, dtype=X.dtype)
         l1w, l1h, l2w, l2h = self._regularization(T, m)
         res = engine.fit_batched(X, W0, H, max_iter=self.max_iter, tol=self.tol, update_H=False, l1_reg_W=l1w,
-                                 l1_reg_H=l1h, l2_reg_W=l2w, l2_reg_H=l2h, device=self.device, return_numpy=True)
+                                 l1_reg_H=l1h, l2_reg_W=l2w, l2_reg_H=l2h, beta_loss=self.beta_loss,
+                                 device=self.device, return_numpy=True)
         if int(res.n_iter[0]) == self.max_iter and self.tol > 0:
             warnings.warn("Maximum number of iterations %d reached. Increase it to improve convergence." % self.max_iter,
                           _convergence_warning_class())

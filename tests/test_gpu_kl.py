@@ -1,0 +1,146 @@
+"""GPU parity of the Kullback-Leibler loss (row f-4: ``NMF(solver='mu', beta_loss='kullback-leibler')``)
+against sklearn's recorded outputs (``tests/golden/g7_kl.npz``) and the oracle restatement.
+
+Tolerances: the reconstruction WH relative to ||X||_F (<= 1e-5, fp32 and fp64); the reported error
+``sqrt(2 KL)`` relative to its own size (sklearn evaluates ``sum(x log(x/wh)) - sum(x) + sum(wh)`` as three
+large fp32 sums that cancel, this engine sums the non-negative per-element terms -- both are compared with
+the fp64 value, and against each other at 2e-3 in fp32 / 1e-9 in fp64).
+"""
+import warnings
+
+import numpy as np
+import pytest
+
+from conftest import load_npz
+from oracle import nmf_mu_oracle as orc
+from muscle_synergies_amd.synth import emg_matrix, random_init
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+ERR_RT = {"float32": 2e-3, "float64": 1e-9}
+
+
+def _fit(X, W0, H0, **kw):
+    import muscle_synergies_amd as ms
+
+    return ms.fit_batched(X, W0, H0, beta_loss="kullback-leibler", **kw)
+
+
+def _rel_wh(X, W, H, Wr, Hr):
+    xn = np.linalg.norm(X.astype(np.float64))
+    return np.linalg.norm(W.astype(np.float64) @ H.astype(np.float64) - Wr.astype(np.float64) @ Hr.astype(np.float64)) / xn
+
+
+@pytest.mark.parametrize("dt", ["float32", "float64"])
+@pytest.mark.parametrize("n_iter", [1, 2, 10, 100])
+def test_kl_loop_vs_golden_and_oracle(dt, n_iter):
+    g7 = load_npz("g7_kl.npz")
+    X = np.asfortranarray(g7[f"X_{dt}"])
+    W0, H0 = g7[f"W0_{dt}"], g7[f"H0_{dt}"]
+    res = _fit(X, W0, H0, max_iter=n_iter, tol=0.0)
+    assert int(res.n_iter[0]) == n_iter
+    assert _rel_wh(X, res.W[0], res.H[0], g7[f"W_{dt}_{n_iter}"], g7[f"H_{dt}_{n_iter}"]) <= TOL
+    ref = orc.nmf_mu_fit_kl(X, W0, H0, max_iter=n_iter, tol=0)
+    assert _rel_wh(X, res.W[0], res.H[0], ref["W"], ref["H"]) <= TOL
+    np.testing.assert_allclose(float(res.reconstruction_err[0]), float(g7[f"err_{dt}_{n_iter}"]), rtol=ERR_RT[dt])
+    # the error the engine reports is the divergence of the factors it returns (checked in fp64)
+    e64 = orc.kl_divergence(X.astype(np.float64), res.W[0].astype(np.float64), res.H[0].astype(np.float64), True)
+    np.testing.assert_allclose(float(res.reconstruction_err[0]), e64, rtol=1e-4 if dt == "float32" else 1e-11)
+    if n_iter <= 10:
+        rt = 2e-5 if dt == "float32" else 1e-11
+        np.testing.assert_allclose(res.W[0], g7[f"W_{dt}_{n_iter}"], rtol=rt, atol=rt * 1e-2)
+        np.testing.assert_allclose(res.H[0], g7[f"H_{dt}_{n_iter}"], rtol=rt, atol=rt * 1e-2)
+    # the squared-error VAF columns are still produced for the KL fit
+    err2 = ((X.astype(np.float64) - res.W[0].astype(np.float64) @ res.H[0].astype(np.float64)) ** 2).sum(axis=0)
+    vaf_col = 1 - err2 / (X.astype(np.float64) ** 2).sum(axis=0)
+    np.testing.assert_allclose(res.vaf[0][1:], vaf_col, atol=1e-5)
+
+
+def test_kl_stop_rule_and_regularisation():
+    g7 = load_npz("g7_kl.npz")
+    X = np.asfortranarray(g7["X_float64"])
+    W0, H0 = g7["W0_float64"], g7["H0_float64"]
+    res = _fit(X, W0, H0, max_iter=2000, tol=1e-4)
+    assert int(res.n_iter[0]) == int(g7["stop_n_iter_float64"])
+    np.testing.assert_allclose(float(res.reconstruction_err[0]), float(g7["stop_err_float64"]), rtol=1e-9)
+    # fp32: the stop rule fires on the same check or a neighbouring one (the fp32 divergence is noisy)
+    X32 = np.asfortranarray(g7["X_float32"])
+    res32 = _fit(X32, g7["W0_float32"], g7["H0_float32"], max_iter=2000, tol=1e-4)
+    assert abs(int(res32.n_iter[0]) - int(g7["stop_n_iter_float32"])) <= 20 and int(res32.n_iter[0]) % 10 == 0
+    for dt in ("float32", "float64"):
+        Xd = np.asfortranarray(g7[f"X_{dt}"])
+        T, m = Xd.shape
+        l1w, l1h, l2w, l2h = orc.compute_regularization(T, m, 0.002, 0.001, 0.3)
+        r = _fit(Xd, g7[f"W0_{dt}"], g7[f"H0_{dt}"], max_iter=40, tol=0.0, l1_reg_W=l1w, l1_reg_H=l1h,
+                 l2_reg_W=l2w, l2_reg_H=l2h)
+        assert _rel_wh(Xd, r.W[0], r.H[0], g7[f"W_reg_{dt}"], g7[f"H_reg_{dt}"]) <= TOL
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("T,m,k", [(1, 1, 1), (63, 3, 2), (1001, 8, 3), (777, 16, 8), (3000, 16, 5), (9000, 16, 5),
+                                    (2000, 5, 1), (1500, 12, 7), (640, 20, 4), (500, 32, 6)])
+def test_kl_shapes_vs_oracle(dtype, T, m, k):
+    """Every lane mapping (m <= 4, 8, 16, 32), ragged tails, the LDS-resident / streamed split of W."""
+    X = emg_matrix(900 + T + m, T=T, m=m, k_true=min(5, m), dtype=dtype)
+    if T > 10:
+        X[::7, 0] = 0
+    W0, H0 = random_init(X, k, seed=3)
+    res = _fit(X, W0, H0, max_iter=30, tol=0.0)
+    ref = orc.nmf_mu_fit_kl(X, W0, H0, max_iter=30, tol=0)
+    assert _rel_wh(X, res.W[0], res.H[0], ref["W"], ref["H"]) <= TOL
+    e64 = orc.kl_divergence(X.astype(np.float64), res.W[0].astype(np.float64), res.H[0].astype(np.float64), True)
+    np.testing.assert_allclose(float(res.reconstruction_err[0]), e64, rtol=2e-4 if dtype == np.float32 else 1e-10,
+                               atol=1e-6)
+
+
+def test_kl_batch_transform_estimator_and_unsupported_paths():
+    sk = pytest.importorskip("sklearn.decomposition")
+    import muscle_synergies_amd as ms
+    from muscle_synergies_amd import _lib
+
+    # a batch: every matrix equals its single-matrix fit bit for bit (one workgroup per matrix, fixed-order sums)
+    Xs = np.stack([np.ascontiguousarray(emg_matrix(40 + b, T=2500, dtype=np.float32)) for b in range(6)])
+    inits = [random_init(Xs[b], 4, seed=b) for b in range(6)]
+    W0 = np.stack([w for w, _ in inits])
+    H0 = np.stack([h for _, h in inits])
+    rb = _fit(Xs, W0, H0, max_iter=50, tol=0.0)
+    for b in (0, 5):
+        r1 = _fit(Xs[b], W0[b], H0[b], max_iter=50, tol=0.0)
+        assert np.array_equal(r1.W[0], rb.W[b]) and np.array_equal(r1.H[0], rb.H[b])
+
+    # the estimator against live sklearn: fit (NNDSVDa start) and transform
+    X = np.asfortranarray(emg_matrix(77, T=1500, dtype=np.float64))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        mine = ms.HipNMF(5, solver="mu", beta_loss="kullback-leibler", init="nndsvda", max_iter=150, tol=1e-4,
+                         random_state=0)
+        Wm = mine.fit_transform(X)
+        ref = sk.NMF(5, solver="mu", beta_loss="kullback-leibler", init="nndsvda", max_iter=150, tol=1e-4, random_state=0)
+        Wr = ref.fit_transform(X)
+    assert mine.n_iter_ == ref.n_iter_
+    assert _rel_wh(X, Wm, mine.components_, Wr, ref.components_) <= TOL
+    np.testing.assert_allclose(mine.reconstruction_err_, ref.reconstruction_err_, rtol=1e-7)
+    Xn = np.asfortranarray(emg_matrix(78, T=700, dtype=np.float64))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        Tm, Tr = mine.transform(Xn), ref.transform(Xn)
+    assert _rel_wh(Xn, Tm, mine.components_, Tr, ref.components_) <= TOL
+    assert ms.HipNMF.supports(solver="mu", beta_loss="kullback-leibler")
+    assert not ms.HipNMF.supports(solver="mu", beta_loss="itakura-saito")
+
+    # the time-shard building blocks are Frobenius only and say so
+    import ctypes
+
+    import torch
+
+    from muscle_synergies_amd.engine import make_problem
+
+    p = make_problem(1, 128, 4, 2, x_layout=_lib.X_CHANNEL_MAJOR, ldx=128, x_batch_stride=512, loss=_lib.LOSS_KL)
+    h = _lib.get_handle(0)
+    buf = torch.zeros(4096, device="cuda")
+    rc = _lib.load().hipnmf_shard_pass_f32(h.ptr, ctypes.byref(p), buf.data_ptr(), buf.data_ptr(), buf.data_ptr(),
+                                           buf.data_ptr())
+    assert rc == _lib.HIPNMF_ERR_UNSUPPORTED
+    with pytest.raises(NotImplementedError):
+        ms.fit_batched(X, Wm, mine.components_, beta_loss="itakura-saito")

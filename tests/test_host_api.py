@@ -91,7 +91,7 @@ def test_hipnmf_parameter_validation():
     with pytest.raises(ValueError, match="solver='mu' only"):
         ms.HipNMF(2, solver="cd").fit_transform(X)
     with pytest.raises(NotImplementedError):
-        ms.HipNMF(2, beta_loss="kullback-leibler").fit_transform(X)
+        ms.HipNMF(2, beta_loss="itakura-saito").fit_transform(X)
     with pytest.raises(ValueError, match="max_iter"):
         ms.HipNMF(2, max_iter=0).fit_transform(X)
     with pytest.raises(ValueError, match="init"):
@@ -106,7 +106,7 @@ def test_hipnmf_parameter_validation():
         ms.HipNMF(2, init="custom").fit_transform(X, W=np.ones((20, 2), np.float32), H=np.ones((2, 4), np.float32))
     est = ms.HipNMF(3, tol=0.5)
     assert est.get_params()["n_components"] == 3 and est.set_params(tol=0.1).tol == 0.1
-    assert ms.HipNMF.supports(solver="mu") and not ms.HipNMF.supports() and not ms.HipNMF.supports(solver="mu", beta_loss=1)
+    assert ms.HipNMF.supports(solver="mu") and not ms.HipNMF.supports() and ms.HipNMF.supports(solver="mu", beta_loss=1) and not ms.HipNMF.supports(solver="mu", beta_loss=0.5)
     with pytest.raises(RuntimeError, match="not fitted"):
         est.transform(X)
 
