@@ -124,7 +124,8 @@ def find_synergies(processed_emg_df: pandas.DataFrame, n_components: int, max_co
 
 def find_synergies_batched(processed_emg_dfs, n_components: int, max_components: Optional[int] = None, *,
                            max_iter: int = 100_000, tol: float = 1e-6, init=None, random_state=None,
-                           alpha_W: float = 0.0, alpha_H="same", l1_ratio: float = 0.0, device=None):
+                           alpha_W: float = 0.0, alpha_H="same", l1_ratio: float = 0.0, beta_loss="frobenius",
+                           device=None):
     """``find_synergies(df, ..., solver='mu')`` for a list of trials in one GPU launch per rank.
 
     ``processed_emg_dfs`` is a sequence of DataFrames with the same muscles (columns) and any numbers of rows
@@ -152,7 +153,7 @@ def find_synergies_batched(processed_emg_dfs, n_components: int, max_components:
     per_trial = [OrderedDict() for _ in dfs]
     for rank in ranks:
         template = HipNMF(rank, init=init, tol=tol, max_iter=max_iter, random_state=random_state, alpha_W=alpha_W,
-                          alpha_H=alpha_H, l1_ratio=l1_ratio, device=device)
+                          alpha_H=alpha_H, l1_ratio=l1_ratio, beta_loss=beta_loss, device=device)
         template._check_params()
         equal_len = len({a.shape[0] for a in arrays}) == 1
         if equal_len and init in (None, "nndsvd", "nndsvda") and rank <= min(arrays[0].shape) and rank <= 8:
@@ -169,13 +170,13 @@ def find_synergies_batched(processed_emg_dfs, n_components: int, max_components:
             raise NotImplementedError("alpha_W / alpha_H with trials of different lengths: fit them per trial")
         l1w, l1h, l2w, l2h = regs.pop()
         res = fit_ragged(arrays, [w for w, _ in inits], [h for _, h in inits], max_iter=max_iter, tol=tol,
-                         l1_reg_W=l1w, l1_reg_H=l1h, l2_reg_W=l2w, l2_reg_H=l2h, device=device)
+                         l1_reg_W=l1w, l1_reg_H=l1h, l2_reg_W=l2w, l2_reg_H=l2h, beta_loss=beta_loss, device=device)
         H = res.H.cpu().numpy()
         n_iter = res.n_iter.cpu().numpy()
         err = res.reconstruction_err.cpu().numpy()
         for b, df in enumerate(dfs):
             model = HipNMF(rank, init=init, tol=tol, max_iter=max_iter, random_state=random_state, alpha_W=alpha_W,
-                           alpha_H=alpha_H, l1_ratio=l1_ratio, device=device)
+                           alpha_H=alpha_H, l1_ratio=l1_ratio, beta_loss=beta_loss, device=device)
             model.components_, model.n_components_, model.n_features_in_ = H[b], rank, H.shape[2]
             model.n_iter_, model.reconstruction_err_ = int(n_iter[b]), err[b]
             W = res.W[b].cpu().numpy()

@@ -270,7 +270,7 @@ class RankSweepResult:
 
 def rank_sweep_batched(X, k_min: int, k_max: int, *, vaf_threshold: float = 0.90, max_iter: int = 500,
                        tol: float = 1e-4, seed: int = 0, device=None, keep_W: bool = False,
-                       init: str = "random") -> RankSweepResult:
+                       init: str = "random", beta_loss="frobenius") -> RankSweepResult:
     """``find_synergies(df, k_min, k_max)`` for a whole batch of trials: one batched fit per rank, VAF per
     trial and rank, and the smallest rank with VAF >= ``vaf_threshold``.  ``init='random'`` draws the starting
     factors on the device; ``'nndsvda'`` / ``'nndsvd'`` (sklearn's default family) use the on-device NNDSVD."""
@@ -292,7 +292,8 @@ def rank_sweep_batched(X, k_min: int, k_max: int, *, vaf_threshold: float = 0.90
             from .init import nndsvd_init_batched
 
             W0, H0 = nndsvd_init_batched(Xt, k, init=init, device=dev)
-        r = fit_batched(Xt, W0, H0, max_iter=max_iter, tol=tol, device=dev, return_numpy=False, overwrite_init=True)
+        r = fit_batched(Xt, W0, H0, max_iter=max_iter, tol=tol, beta_loss=beta_loss, device=dev, return_numpy=False,
+                        overwrite_init=True)
         vaf[k], n_iter[k], err[k], comps[k] = r.vaf, r.n_iter, r.reconstruction_err, r.H
         if keep_W:
             Ws[k] = r.W
@@ -311,7 +312,7 @@ def rank_sweep_batched(X, k_min: int, k_max: int, *, vaf_threshold: float = 0.90
 # Ragged batches: trials of unequal length (gait cycles, segments of a recording)
 def fit_ragged(Xs, W0s, H0s, *, max_iter: int = 200, tol: float = 1e-4, check_every: int = 10,
                update_H: bool = True, l1_reg_W: float = 0.0, l1_reg_H: float = 0.0, l2_reg_W: float = 0.0,
-               l2_reg_H: float = 0.0, device=None, handle: Optional[_lib.Handle] = None):
+               l2_reg_H: float = 0.0, beta_loss="frobenius", device=None, handle: Optional[_lib.Handle] = None):
     """Factorise ``B`` matrices with different numbers of rows in one launch.
 
     ``Xs[b]`` is ``(T_b, m)``, ``W0s[b]`` ``(T_b, k)``, ``H0s[b]`` ``(k, m)`` (NumPy or torch; one dtype, one
@@ -353,7 +354,8 @@ def fit_ragged(Xs, W0s, H0s, *, max_iter: int = 200, tol: float = 1e-4, check_ev
     Tmax = max(Ts)
     p = make_problem(B, Tmax, m, k, x_layout=_lib.X_CHANNEL_MAJOR, ldx=Tmax, x_batch_stride=1,
                      w_layout=_lib.W_COMPONENT_MAJOR, update_H=update_H, max_iter=max_iter, tol=tol,
-                     check_every=check_every, l1_reg_W=l1_reg_W, l1_reg_H=l1_reg_H, l2_reg_W=l2_reg_W, l2_reg_H=l2_reg_H)
+                     check_every=check_every, l1_reg_W=l1_reg_W, l1_reg_H=l1_reg_H, l2_reg_W=l2_reg_W, l2_reg_H=l2_reg_H,
+                     loss=beta_loss_code(beta_loss))
     err = torch.empty((B,), dtype=dtype, device=dev)
     n_iter = torch.empty((B,), dtype=torch.int32, device=dev)
     sse = torch.empty((B, m), dtype=dtype, device=dev)

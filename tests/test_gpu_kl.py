@@ -144,3 +144,35 @@ def test_kl_batch_transform_estimator_and_unsupported_paths():
     assert rc == _lib.HIPNMF_ERR_UNSUPPORTED
     with pytest.raises(NotImplementedError):
         ms.fit_batched(X, Wm, mine.components_, beta_loss="itakura-saito")
+
+
+def test_kl_ragged_trials_and_rank_sweep():
+    """Trials of unequal length in one launch, and the batched rank sweep, under the KL loss."""
+    import pandas as pd
+    import torch
+
+    import muscle_synergies_amd as ms
+
+    lens = [700, 1234, 64, 2999]
+    Xs = [np.ascontiguousarray(emg_matrix(300 + i, T=t, m=8, k_true=3, dtype=np.float64)) for i, t in enumerate(lens)]
+    inits = [random_init(x, 3, seed=i) for i, x in enumerate(Xs)]
+    res = ms.fit_ragged(Xs, [w for w, _ in inits], [h for _, h in inits], max_iter=60, tol=0.0,
+                        beta_loss="kullback-leibler")
+    for b, x in enumerate(Xs):
+        ref = orc.nmf_mu_fit_kl(x, inits[b][0], inits[b][1], max_iter=60, tol=0)
+        assert _rel_wh(x, res.W[b].cpu().numpy(), res.H[b].cpu().numpy(), ref["W"], ref["H"]) <= 1e-9
+        np.testing.assert_allclose(float(res.reconstruction_err[b]), float(ref["reconstruction_err"]), rtol=1e-9)
+    cols = [f"m{j}" for j in range(8)]
+    dfs = [pd.DataFrame(x, columns=cols) for x in Xs[:2]]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        got = ms.find_synergies_batched(dfs, 2, 3, max_iter=100, tol=0.0, beta_loss="kullback-leibler", random_state=0)
+        one = [ms.find_synergies(df, 2, 3, solver="mu", beta_loss="kullback-leibler", max_iter=100, tol=0.0,
+                                 random_state=0) for df in dfs]
+    for g, r in zip(got, one):
+        np.testing.assert_allclose(g.vaf_values.to_numpy(), r.vaf_values.to_numpy(), atol=1e-9)
+        assert g.model[3].beta_loss == "kullback-leibler"
+    Xb = torch.from_numpy(np.stack([emg_matrix(400 + b, T=1500, dtype=np.float32) for b in range(5)])).cuda()
+    sw = ms.rank_sweep_batched(Xb, 2, 5, max_iter=100, tol=0.0, beta_loss="kullback-leibler")
+    assert tuple(sw.vaf_all.shape) == (5, 4) and bool(torch.isfinite(sw.vaf_all).all())
+    assert bool((sw.vaf_all[:, 1:] >= sw.vaf_all[:, :-1] - 1e-2).all())

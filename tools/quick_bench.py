@@ -14,6 +14,7 @@ ap.add_argument("--iters", type=int, default=100)
 ap.add_argument("--threads", type=int, nargs="*", default=[256, 512])
 ap.add_argument("--variant", type=int, default=0)
 ap.add_argument("--reps", type=int, default=2)
+ap.add_argument("--loss", default="frobenius")
 a = ap.parse_args()
 X, W0, H0 = emg_batch_torch(a.batch, T=a.T, device="cuda:0")
 Xv = X.transpose(1, 2)  # [B, T, m] view of channel-major storage
@@ -22,7 +23,7 @@ for nt in a.threads:
     h.set_tuning(nt, 0, a.variant)
     for rep in range(a.reps):
         t0 = time.perf_counter()
-        r = ms.fit_batched(Xv, W0, H0, max_iter=a.iters, tol=0.0)
+        r = ms.fit_batched(Xv, W0, H0, max_iter=a.iters, tol=0.0, beta_loss=a.loss)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         its = a.batch * a.iters / (r.kernel_ms * 1e-3)
