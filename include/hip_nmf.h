@@ -174,6 +174,42 @@ typedef struct hipnmf_envelope_params {
 int hipnmf_emg_envelope_f32(hipnmf_handle* h, const hipnmf_envelope_params* p, const float* raw, float* out);
 int hipnmf_emg_envelope_f64(hipnmf_handle* h, const hipnmf_envelope_params* p, const double* raw, double* out);
 
+
+/*
+ * Batched IIR filter stage of the reference: digital_filter (src/muscle_synergies/analysis.py:314-432 ->
+ * scipy.signal.sosfiltfilt when zero_lag, scipy.signal.sosfilt otherwise, along the time axis) and, with
+ * zero_center / rectify set, linear_envelope (analysis.py:252-311: zero_center -> abs -> low-pass).
+ * The section coefficients are designed on the host exactly as the reference does (scipy.signal.butter /
+ * cheby1 / cheby2(..., output="sos"), analysis.py:381-403) and handed over as `sos` = [n_sections][6] doubles
+ * in HOST memory ({b0, b1, b2, 1, a1, a2} per section); `zi` = [n_sections][2] doubles in HOST memory =
+ * scipy.signal.sosfilt_zi(sos) (zero_lag only; NULL lets the library compute the same steady state itself,
+ * possibly different in the last bit).  x as in hipnmf_envelope_params; y: [B][n_channels][n_samples],
+ * channel-major.  All arithmetic is fp64 in scipy's operation order without fused multiply-adds: the f64
+ * entry point reproduces scipy bit for bit on identical input, the f32 one reads float samples and rounds the
+ * fp64 result to float.  Errors: HIPNMF_ERR_BAD_ARG when n_samples <= padlen (scipy's ValueError) or
+ * sos[:, 3] != 1; HIPNMF_ERR_UNSUPPORTED for more than 8 sections.
+ */
+typedef struct hipnmf_sosfilt_params {
+  int32_t struct_size;    /* = sizeof(hipnmf_sosfilt_params)                                           */
+  int32_t batch;          /* B >= 1 recordings                                                         */
+  int64_t n_samples;      /* T rows (time samples) of every recording                                  */
+  int32_t n_channels;     /* m columns (muscles)                                                       */
+  int32_t x_layout;       /* HIPNMF_X_*                                                                */
+  int64_t ldx;            /* leading dimension of one recording, in elements                           */
+  int64_t x_batch_stride; /* elements between consecutive recordings                                   */
+  int32_t n_sections;     /* second-order sections, 1..8                                               */
+  int32_t zero_lag;       /* 1: sosfiltfilt (forward-backward, padtype='odd'); 0: sosfilt, zero state  */
+  int32_t padlen;         /* zero_lag: samples of extension at each end; -1 = scipy's default 3*ntaps  */
+  int32_t zero_center;    /* 1: subtract the per-channel mean before filtering (linear_envelope)       */
+  int32_t rectify;        /* 1: take |x| (after centring) before filtering (linear_envelope)           */
+  int32_t reserved0;      /* must be 0                                                                 */
+} hipnmf_sosfilt_params;
+
+int hipnmf_sosfilt_f32(hipnmf_handle* h, const hipnmf_sosfilt_params* p, const double* sos, const double* zi,
+                       const float* x, float* y);
+int hipnmf_sosfilt_f64(hipnmf_handle* h, const hipnmf_sosfilt_params* p, const double* sos, const double* zi,
+                       const double* x, double* y);
+
 /* ---- on-device NNDSVD initialisation building blocks ---------------------- */
 /*
  * sklearn's default init for find_synergies is NNDSVDa (_initialize_nmf, _nmf.py:221-373) on a randomized SVD.

@@ -38,7 +38,7 @@ EXPORTS = (
     "hipnmf_fit_batched_f32", "hipnmf_fit_batched_f64", "hipnmf_fit_ragged_f32", "hipnmf_fit_ragged_f64",
     "hipnmf_shard_pass_f32", "hipnmf_shard_hupdate_f32", "hipnmf_shard_residual_f32",
     "hipnmf_shard_pass_f64", "hipnmf_shard_hupdate_f64", "hipnmf_shard_residual_f64",
-    "hipnmf_emg_envelope_f32", "hipnmf_emg_envelope_f64",
+    "hipnmf_emg_envelope_f32", "hipnmf_emg_envelope_f64", "hipnmf_sosfilt_f32", "hipnmf_sosfilt_f64",
     "hipnmf_gram_f32", "hipnmf_gram_f64", "hipnmf_nndsvd_stats_f32", "hipnmf_nndsvd_stats_f64",
     "hipnmf_nndsvd_write_f32", "hipnmf_nndsvd_write_f64",
 )
@@ -123,6 +123,9 @@ def _declare(lib):
         f = getattr(lib, f"hipnmf_emg_envelope_{sfx}")
         f.restype = ip
         f.argtypes = [vp, vp, vp, vp]
+        f = getattr(lib, f"hipnmf_sosfilt_{sfx}")
+        f.restype = ip
+        f.argtypes = [vp, vp, vp, vp, vp, vp]
         f = getattr(lib, f"hipnmf_gram_{sfx}")
         f.restype = ip
         f.argtypes = [vp, pp, vp, vp, vp]

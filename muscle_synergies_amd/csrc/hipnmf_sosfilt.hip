@@ -1,0 +1,170 @@
+// hipnmf_sosfilt.hip -- C ABI of the batched IIR filter stage (include/hip_nmf.h, row f-1 of SURVEY.md section 8):
+// scipy.signal.sosfilt / sosfiltfilt as the reference's digital_filter / linear_envelope use them
+// (src/muscle_synergies/analysis.py:252-432).
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+
+#include "hipnmf_internal.hpp"
+#include "nmf_kernels.hpp"  // x_to_channel_major_kernel
+#include "sosfilt_kernels.hpp"
+
+using namespace hipnmf;
+
+namespace {
+
+// scipy.signal.sosfiltfilt's default padlen: 3 * (2 n_sections + 1 - min(#(b2 == 0), #(a2 == 0)))
+int default_padlen(const double* sos, int ns) {
+  int zb = 0, za = 0;
+  for (int s = 0; s < ns; ++s) {
+    zb += sos[6 * s + 2] == 0.0;
+    za += sos[6 * s + 5] == 0.0;
+  }
+  return 3 * (2 * ns + 1 - std::min(zb, za));
+}
+
+// scipy.signal.sosfilt_zi: steady-state step-response state of every section ((I - A^T) zi = B per section),
+// scaled by the DC gain of the sections before it.  (scipy solves the 2 x 2 system with LAPACK; this closed form
+// can differ from it in the last bit -- pass scipy's zi for bit parity.)
+void steady_state_zi(const double* sos, int ns, double (*zi)[2]) {
+  double scale = 1.0;
+  for (int s = 0; s < ns; ++s) {
+    const double b0 = sos[6 * s], b1 = sos[6 * s + 1], b2 = sos[6 * s + 2];
+    const double a1 = sos[6 * s + 4], a2 = sos[6 * s + 5];
+    const double B0 = b1 - a1 * b0, B1 = b2 - a2 * b0;
+    // [[1 + a1, -1], [a2, 1]] zi = [B0, B1]
+    const double det = (1.0 + a1) + a2;
+    zi[s][0] = scale * ((B0 + B1) / det);
+    zi[s][1] = scale * (((1.0 + a1) * B1 - a2 * B0) / det);
+    scale *= (b0 + b1 + b2) / (1.0 + a1 + a2);
+  }
+}
+
+template <typename real, int NS>
+void launch_ns(const SosArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL((sosfilt_kernel<real, NS>), dim3((a.N + 63) / 64), dim3(64), 0, st, a);
+}
+
+template <typename real>
+int sosfilt_impl(hipnmf_handle* h, const hipnmf_sosfilt_params* p, const double* sos, const double* zi, const real* x,
+                 real* y) {
+  if (!h) return fail(HIPNMF_ERR_BAD_ARG, "handle is NULL");
+  if (!p) return fail(HIPNMF_ERR_BAD_ARG, "params is NULL");
+  if (p->struct_size != (int32_t)sizeof(hipnmf_sosfilt_params))
+    return fail(HIPNMF_ERR_BAD_ARG, "hipnmf_sosfilt_params.struct_size = %d, library expects %d", p->struct_size,
+                (int)sizeof(hipnmf_sosfilt_params));
+  if (!sos || !x || !y) return fail(HIPNMF_ERR_BAD_ARG, "sos (host), x and y (device) must be non-NULL");
+  if (p->batch < 1 || p->n_samples < 1 || p->n_samples > 1000000000LL || p->n_channels < 1)
+    return fail(HIPNMF_ERR_BAD_ARG, "bad shape: batch=%d n_samples=%lld n_channels=%d", p->batch,
+                (long long)p->n_samples, p->n_channels);
+  if ((long long)p->batch * p->n_channels > 2000000000LL) return fail(HIPNMF_ERR_BAD_ARG, "too many series");
+  if (p->n_sections < 1) return fail(HIPNMF_ERR_BAD_ARG, "n_sections must be >= 1 (got %d)", p->n_sections);
+  if (p->n_sections > SOS_MAX_SECTIONS)
+    return fail(HIPNMF_ERR_UNSUPPORTED, "n_sections=%d outside the compiled kernel set (max %d)", p->n_sections,
+                SOS_MAX_SECTIONS);
+  for (int s = 0; s < p->n_sections; ++s) {
+    if (sos[6 * s + 3] != 1.0) return fail(HIPNMF_ERR_BAD_ARG, "sos[:, 3] should be all ones");
+    for (int q = 0; q < 6; ++q)
+      if (!std::isfinite(sos[6 * s + q])) return fail(HIPNMF_ERR_BAD_ARG, "sos contains NaN or infinity");
+  }
+  if (p->x_layout != HIPNMF_X_ROW_MAJOR && p->x_layout != HIPNMF_X_CHANNEL_MAJOR)
+    return fail(HIPNMF_ERR_BAD_ARG, "bad x_layout %d", p->x_layout);
+  const long long min_ld = (p->x_layout == HIPNMF_X_ROW_MAJOR) ? p->n_channels : p->n_samples;
+  if (p->ldx < min_ld) return fail(HIPNMF_ERR_BAD_ARG, "ldx=%lld smaller than %lld", (long long)p->ldx, min_ld);
+  const int zero_lag = p->zero_lag ? 1 : 0;
+  int edge = 0;
+  if (zero_lag) {
+    edge = p->padlen < 0 ? default_padlen(sos, p->n_sections) : p->padlen;
+    if (p->n_samples <= edge)
+      return fail(HIPNMF_ERR_BAD_ARG, "The length of the input vector x must be greater than padlen, which is %d.", edge);
+  }
+  HIP_TRY(hipSetDevice(h->device));
+  const int B = p->batch, m = p->n_channels;
+  const long long T = p->n_samples, L = T + 2LL * edge;
+  const long long N = (long long)B * m;
+  hipStream_t st = h->stream;
+
+  size_t off = 0;
+  auto carve = [&](size_t bytes) {
+    size_t o = off;
+    off += (bytes + 255) / 256 * 256;
+    return o;
+  };
+  const bool inplace = p->x_layout == HIPNMF_X_CHANNEL_MAJOR;
+  const size_t o_x = inplace ? 0 : carve(sizeof(real) * (size_t)N * T);
+  const size_t o_ws = zero_lag ? carve(sizeof(double) * (size_t)N * (size_t)L) : 0;
+  int rc = hipnmf_ensure_ws(h, std::max<size_t>(off, 256));
+  if (rc) return rc;
+  char* ws = static_cast<char*>(h->ws);
+
+  SosArgs a;
+  if (inplace) {
+    a.x = x;
+    a.bstride = p->x_batch_stride;
+    a.ld = p->ldx;
+  } else {
+    real* xc = reinterpret_cast<real*>(ws + o_x);
+    dim3 blk(32, 8);
+    dim3 grd((unsigned)((T + 31) / 32), (unsigned)((m + 31) / 32), (unsigned)B);
+    hipLaunchKernelGGL(x_to_channel_major_kernel<real>, grd, blk, 0, st, x, (long long)p->x_batch_stride,
+                       (long long)p->ldx, (int)p->x_layout, xc, (long long)m * T, T, (int)T, m);
+    a.x = xc;
+    a.bstride = (long long)m * T;
+    a.ld = T;
+  }
+  a.ws = reinterpret_cast<double*>(ws + o_ws);
+  a.y = y;
+  for (int s = 0; s < SOS_MAX_SECTIONS; ++s) {
+    for (int q = 0; q < 6; ++q) a.sos[s][q] = s < p->n_sections ? sos[6 * s + q] : 0.0;
+    a.zi[s][0] = a.zi[s][1] = 0.0;
+  }
+  if (zero_lag) {
+    if (zi) {
+      for (int s = 0; s < p->n_sections; ++s) {
+        a.zi[s][0] = zi[2 * s];
+        a.zi[s][1] = zi[2 * s + 1];
+      }
+    } else {
+      steady_state_zi(sos, p->n_sections, a.zi);
+    }
+  }
+  a.T = (int)T;
+  a.m = m;
+  a.N = (int)N;
+  a.edge = edge;
+  a.zero_lag = zero_lag;
+  a.zero_center = p->zero_center ? 1 : 0;
+  a.rectify = p->rectify ? 1 : 0;
+  const bool async = h->async_mode != 0;
+  if (!async) HIP_TRY(hipEventRecord(h->ev0, st));
+  switch (p->n_sections) {
+    case 1: launch_ns<real, 1>(a, st); break;
+    case 2: launch_ns<real, 2>(a, st); break;
+    case 3: launch_ns<real, 3>(a, st); break;
+    case 4: launch_ns<real, 4>(a, st); break;
+    case 5: launch_ns<real, 5>(a, st); break;
+    case 6: launch_ns<real, 6>(a, st); break;
+    case 7: launch_ns<real, 7>(a, st); break;
+    default: launch_ns<real, 8>(a, st); break;
+  }
+  HIP_TRY(hipGetLastError());
+  if (!async) {
+    HIP_TRY(hipEventRecord(h->ev1, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
+  }
+  return HIPNMF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+int hipnmf_sosfilt_f32(hipnmf_handle* h, const hipnmf_sosfilt_params* p, const double* sos, const double* zi,
+                       const float* x, float* y) {
+  return sosfilt_impl<float>(h, p, sos, zi, x, y);
+}
+int hipnmf_sosfilt_f64(hipnmf_handle* h, const hipnmf_sosfilt_params* p, const double* sos, const double* zi,
+                       const double* x, double* y) {
+  return sosfilt_impl<double>(h, p, sos, zi, x, y);
+}
+}

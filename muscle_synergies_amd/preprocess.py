@@ -2,12 +2,14 @@
 
 Mirrors, for the tutorial pipeline of the reference (``docs/source/tutorials/Finding muscle synergies.ipynb``),
 the DataFrame functions ``zero_center`` (``src/muscle_synergies/analysis.py:230-249``), ``rms`` (``:435-507``),
-``time_normalize`` (``:551-594``, linear interpolation only) and ``normalize`` (``:510-525``) -- same
-signatures and return types -- and adds a batched entry point that runs the whole chain for many
-recordings in one call and leaves the result on the device in the NMF engine's native layout.
+``time_normalize`` (``:551-594``, linear interpolation only), ``normalize`` (``:510-525``),
+``digital_filter`` (``:314-432``) and ``linear_envelope`` (``:252-311``) -- same signatures and return types
+-- and adds batched entry points that run a whole chain for many recordings in one call and leave the
+result on the device in the NMF engine's native layout.
 
-All arithmetic happens in ``libhip_nmf.so`` (``hipnmf_emg_envelope_*``); there is no CPU fallback.
-Filters (``digital_filter`` / ``linear_envelope``), ``subsample`` and plotting are not part of this module.
+All sample arithmetic happens in ``libhip_nmf.so`` (``hipnmf_emg_envelope_*``, ``hipnmf_sosfilt_*``); there is
+no CPU fallback.  Filter *design* (a handful of coefficients) stays on the host with ``scipy.signal``, exactly
+where the reference does it (``analysis.py:381-403``).  ``subsample`` and plotting are not part of this module.
 """
 
 from __future__ import annotations
@@ -37,6 +39,26 @@ class EnvelopeParams(ctypes.Structure):
         ("zero_center", ctypes.c_int32),
         ("n_out", ctypes.c_int32),
         ("normalize", ctypes.c_int32),
+    ]
+
+
+class SosfiltParams(ctypes.Structure):
+    """Mirror of ``struct hipnmf_sosfilt_params`` (include/hip_nmf.h)."""
+
+    _fields_ = [
+        ("struct_size", ctypes.c_int32),
+        ("batch", ctypes.c_int32),
+        ("n_samples", ctypes.c_int64),
+        ("n_channels", ctypes.c_int32),
+        ("x_layout", ctypes.c_int32),
+        ("ldx", ctypes.c_int64),
+        ("x_batch_stride", ctypes.c_int64),
+        ("n_sections", ctypes.c_int32),
+        ("zero_lag", ctypes.c_int32),
+        ("padlen", ctypes.c_int32),
+        ("zero_center", ctypes.c_int32),
+        ("rectify", ctypes.c_int32),
+        ("reserved0", ctypes.c_int32),
     ]
 
 
@@ -129,3 +151,108 @@ def time_normalize(signal_df: pandas.DataFrame, reduce_to: int, kind="linear",
         raise NotImplementedError("the GPU time_normalize implements kind='linear' only")
     vals = _frame_through_gpu(signal_df, window_size=0, zero_center=False, normalize=False, reduce_to=reduce_to)
     return pandas.DataFrame(vals, index=np.linspace(0, 1, reduce_to), columns=signal_df.columns)
+
+
+# ------------------------------------------------------------------------------------------------
+# IIR filters: digital_filter / linear_envelope
+def design_sos(filter_type: str, order: int, sampling_frequency, critical_freqs, band_type: str = "lowpass",
+               cheby_param: Optional[float] = None) -> np.ndarray:
+    """Section coefficients as the reference designs them (``filter_coeffs``, ``analysis.py:381-403``)."""
+    from scipy import signal
+
+    if filter_type not in {"butter", "cheby1", "cheby2"}:
+        raise ValueError("filter type not understood.")
+    if filter_type == "butter":
+        return signal.butter(order, critical_freqs, btype=band_type, output="sos", fs=sampling_frequency)
+    coeff_func = signal.cheby1 if filter_type == "cheby1" else signal.cheby2
+    return coeff_func(order, cheby_param, critical_freqs, btype=band_type, output="sos", fs=sampling_frequency)
+
+
+def sosfilt_batched(x, sos, *, zero_lag: bool = True, zero_center: bool = False, rectify: bool = False,
+                    padlen: Optional[int] = None, device=None):
+    """``scipy.signal.sosfiltfilt(sos, x, axis=time)`` (``zero_lag``) or ``sosfilt`` for a batch of recordings.
+
+    Args:
+        x: ``[B, T, m]`` (or ``[T, m]``) float32/float64, NumPy or torch, any dense layout.
+        sos: ``(n_sections, 6)`` second-order sections (``scipy.signal`` layout), at most 8 sections.
+        zero_center, rectify: the two steps ``linear_envelope`` applies before its low-pass filter.
+    Returns:
+        tensor ``[B, T, m]`` on the device (transposed view of channel-major storage), dtype of ``x``; the
+        arithmetic is fp64 either way.
+    """
+    torch = _torch()
+    dev = resolve_device(device)
+    sos = np.ascontiguousarray(np.asarray(sos, dtype=np.float64))
+    if sos.ndim != 2 or sos.shape[1] != 6:
+        raise ValueError("sos array must be shape (n_sections, 6)")
+    if not (sos[:, 3] == 1).all():
+        raise ValueError("sos[:, 3] should be all ones")
+    Xt = _as_device_tensor(x, dev)
+    if Xt.dim() == 2:
+        Xt = Xt.unsqueeze(0)
+    if Xt.dim() != 3:
+        raise ValueError(f"x must be [B, T, m] or [T, m], got shape {tuple(Xt.shape)}")
+    if Xt.dtype not in (torch.float32, torch.float64):
+        Xt = Xt.to(torch.float64)
+    B, T, m = Xt.shape
+    if B == 0 or T == 0 or m == 0:
+        raise ValueError("empty input")
+    zi = None
+    if zero_lag:
+        from scipy import signal
+
+        ntaps = 2 * sos.shape[0] + 1 - min(int((sos[:, 2] == 0).sum()), int((sos[:, 5] == 0).sum()))
+        edge = 3 * ntaps if padlen is None else int(padlen)
+        if T <= edge:  # scipy's own message (_validate_pad)
+            raise ValueError("The length of the input vector x must be greater than padlen, which is %d." % edge)
+        zi = np.ascontiguousarray(signal.sosfilt_zi(sos), dtype=np.float64)
+    layout, ldx, xbs, Xt = _x_layout(Xt)
+    p = SosfiltParams(ctypes.sizeof(SosfiltParams), B, T, m, layout, ldx, xbs, sos.shape[0], int(bool(zero_lag)),
+                      -1 if padlen is None else int(padlen), int(bool(zero_center)), int(bool(rectify)), 0)
+    out = torch.empty((B, m, T), dtype=Xt.dtype, device=dev)
+    h = _lib.get_handle(dev.index)
+    lib = _lib.load()
+    fn = lib.hipnmf_sosfilt_f32 if Xt.dtype == torch.float32 else lib.hipnmf_sosfilt_f64
+    torch.cuda.synchronize(dev)
+    _lib.check(fn(h.ptr, ctypes.byref(p), sos.ctypes.data_as(ctypes.c_void_p),
+                  zi.ctypes.data_as(ctypes.c_void_p) if zi is not None else None,
+                  ctypes.c_void_p(Xt.data_ptr()), ctypes.c_void_p(out.data_ptr())))
+    return out.transpose(1, 2)
+
+
+def _filter_frame(signal_df: pandas.DataFrame, sos, zero_lag: bool, inplace: bool, **pre) -> pandas.DataFrame:
+    # scipy filters in float64 whatever the input dtype and the reference returns that (analysis.py:414-416)
+    arr = signal_df.to_numpy().astype(np.float64, copy=False)
+    vals = sosfilt_batched(arr, sos, zero_lag=zero_lag, **pre)[0].cpu().numpy()
+    return _recreate(signal_df, inplace, vals)
+
+
+def digital_filter(signal_df: pandas.DataFrame, critical_freqs, sampling_frequency: int, order: int,
+                   filter_type: str = "butter", band_type: str = "lowpass", zero_lag: bool = True,
+                   cheby_param: Optional[float] = None, inplace: bool = False) -> pandas.DataFrame:
+    """Butterworth / Chebyshev I / II filter of any band type, forward-backward when ``zero_lag``
+    (``analysis.py:314-432``); every column is filtered on the GPU."""
+    sos = design_sos(filter_type, order, sampling_frequency, critical_freqs, band_type, cheby_param)
+    return _filter_frame(signal_df, sos, zero_lag, inplace)
+
+
+def linear_envelope(signal_df: pandas.DataFrame, critical_freqs, sampling_frequency: int, order: int,
+                    filter_type: str = "butter", zero_lag: bool = True, cheby_param: Optional[float] = None,
+                    zero_center_: bool = True, inplace: bool = False) -> pandas.DataFrame:
+    """Linear envelope of raw EMG: (optional) zero-centring, rectification, low-pass filter
+    (``analysis.py:252-311``) -- one fused GPU pass."""
+    sos = design_sos(filter_type, order, sampling_frequency, critical_freqs, "lowpass", cheby_param)
+    return _filter_frame(signal_df, sos, zero_lag, inplace, zero_center=zero_center_, rectify=True)
+
+
+def linear_envelope_batched(raw, critical_freqs, sampling_frequency, order: int = 4, *, filter_type: str = "butter",
+                            zero_lag: bool = True, cheby_param: Optional[float] = None, zero_center: bool = True,
+                            reduce_to: Optional[int] = None, normalize: bool = True, device=None):
+    """``linear_envelope -> time_normalize -> normalize`` for a batch of recordings ``[B, T, m]`` on one GPU
+    (the filter-based alternative to :func:`emg_envelope_batched`).  Returns ``[B, T_out, m]`` on the device,
+    channel-major underneath, ready for ``fit_batched``."""
+    sos = design_sos(filter_type, order, sampling_frequency, critical_freqs, "lowpass", cheby_param)
+    env = sosfilt_batched(raw, sos, zero_lag=zero_lag, zero_center=zero_center, rectify=True, device=device)
+    if reduce_to or normalize:
+        env = emg_envelope_batched(env, 0, zero_center=False, reduce_to=reduce_to, normalize=normalize, device=device)
+    return env

@@ -17,6 +17,7 @@ Fixture sets:
   G5  ``transform`` (update_H=False) and regularised fits
   G6  EMG envelope preprocessing (zero_center, rms, time_normalize, normalize) -- row f-1
   G7  Kullback-Leibler loss (beta_loss='kullback-leibler') -- row f-4
+  G8  IIR filters: ``digital_filter`` / ``linear_envelope`` (scipy sosfilt / sosfiltfilt) -- row f-1
 """
 
 import json
@@ -321,6 +322,73 @@ def g7():
     print("G7 done", arrays["stop_n_iter_float64"])
 
 
+# --------------------------------------------------------------------------- G8
+G8_CASES = {
+    # name: (T, m, fs, digital_filter kwargs)
+    "lp4": (600, 4, 2000, dict(critical_freqs=6, order=4, filter_type="butter", band_type="lowpass", zero_lag=True)),
+    "hp2_fwd": (500, 3, 2000, dict(critical_freqs=20, order=2, filter_type="butter", band_type="highpass", zero_lag=False)),
+    "bp3": (1001, 5, 2000, dict(critical_freqs=[20, 450], order=3, filter_type="butter", band_type="bandpass", zero_lag=True)),
+    "cheby1_lp5": (777, 2, 1000, dict(critical_freqs=10, order=5, filter_type="cheby1", band_type="lowpass", zero_lag=True,
+                                      cheby_param=1.0)),
+    "cheby2_bs2_fwd": (300, 2, 1000, dict(critical_freqs=[45, 55], order=2, filter_type="cheby2", band_type="bandstop",
+                                           zero_lag=False, cheby_param=30.0)),
+    "long_lp2": (20000, 8, 2000, dict(critical_freqs=4, order=2, filter_type="butter", band_type="lowpass", zero_lag=True)),
+    "short": (20, 2, 100, dict(critical_freqs=5, order=1, filter_type="butter", band_type="lowpass", zero_lag=True)),
+}
+
+
+def g8_design(kw, fs):
+    """The section coefficients exactly as the reference designs them (analysis.py:381-403) + scipy's zi."""
+    from scipy import signal
+
+    if kw["filter_type"] == "butter":
+        sos = signal.butter(kw["order"], kw["critical_freqs"], btype=kw["band_type"], output="sos", fs=fs)
+    else:
+        f = signal.cheby1 if kw["filter_type"] == "cheby1" else signal.cheby2
+        sos = f(kw["order"], kw["cheby_param"], kw["critical_freqs"], btype=kw["band_type"], output="sos", fs=fs)
+    return sos, signal.sosfilt_zi(sos)
+
+
+def g8():
+    """Outputs of the reference's own ``digital_filter`` and ``linear_envelope`` on synthetic raw EMG."""
+    import pandas as pd
+
+    arrays = {}
+    for seed, (name, (T, m, fs, kw)) in enumerate(G8_CASES.items()):
+        raw = raw_emg(100 + seed, T, m, fs=float(fs))
+        df = pd.DataFrame(raw, columns=[f"m{j}" for j in range(m)])
+        sos, zi = g8_design(kw, fs)
+        filt = ms.digital_filter(df, sampling_frequency=fs, **kw).to_numpy()
+        arrays[f"{name}_params"] = np.array([T, m, fs, int(kw["zero_lag"]), 100 + seed], dtype=np.int64)
+        arrays[f"{name}_sos"], arrays[f"{name}_zi"] = sos, zi
+        if T <= 2000:
+            arrays[f"{name}_raw"] = raw
+            arrays[f"{name}_filtered"] = filt
+        else:
+            rows = np.array([0, 1, 2, 17, 5000, 9999, 19997, 19998, 19999])
+            arrays[f"{name}_rows"] = rows
+            arrays[f"{name}_filtered_rows"] = filt[rows]
+            arrays[f"{name}_filtered_colsum"] = filt.sum(axis=0)
+        if kw["band_type"] == "lowpass":
+            le_kw = {k: v for k, v in kw.items() if k != "band_type"}
+            le = ms.linear_envelope(df, sampling_frequency=fs, **le_kw).to_numpy()
+            le_nc = ms.linear_envelope(df, sampling_frequency=fs, zero_center_=False, **le_kw).to_numpy()
+            if T <= 2000:
+                arrays[f"{name}_linear_envelope"] = le
+                arrays[f"{name}_linear_envelope_nocenter"] = le_nc
+            else:
+                arrays[f"{name}_linear_envelope_rows"] = le[rows]
+                arrays[f"{name}_linear_envelope_colsum"] = le.sum(axis=0)
+    # float32 input: scipy filters in float64 and the reference returns a float64 frame
+    raw32 = raw_emg(100, 600, 4).astype(np.float32)
+    kw = G8_CASES["lp4"][3]
+    out32 = ms.digital_filter(pd.DataFrame(raw32), sampling_frequency=2000, **kw).to_numpy()
+    assert out32.dtype == np.float64
+    arrays["lp4_filtered_from_f32"] = out32
+    np.savez_compressed(os.path.join(HERE, "g8_filters.npz"), **arrays)
+    print("G8 done")
+
+
 if __name__ == "__main__":
     g1()
     g2_small()
@@ -330,3 +398,4 @@ if __name__ == "__main__":
     g5()
     g6()
     g7()
+    g8()

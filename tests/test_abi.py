@@ -55,6 +55,10 @@ def test_version_and_struct_layout(lib):
 
     assert struct_fields("hipnmf_envelope_params") == [f[0] for f in EnvelopeParams._fields_]
     assert ctypes.sizeof(EnvelopeParams) == 56
+    from muscle_synergies_amd.preprocess import SosfiltParams
+
+    assert struct_fields("hipnmf_sosfilt_params") == [f[0] for f in SosfiltParams._fields_]
+    assert ctypes.sizeof(SosfiltParams) == 64
 
 
 def test_no_device_is_a_loud_error(lib):

@@ -1,0 +1,176 @@
+"""IIR filter stage (``digital_filter`` / ``linear_envelope`` = scipy sosfilt /
+sosfiltfilt): oracle vs the reference's recorded outputs (CPU) and the HIP kernel vs both (GPU)."""
+import numpy as np
+import pandas as pd
+import pytest
+
+from conftest import load_npz
+from oracle import sosfilt_oracle as so
+from muscle_synergies_amd.synth import raw_emg
+
+CASES = ("lp4", "hp2_fwd", "bp3", "cheby1_lp5", "cheby2_bs2_fwd", "long_lp2", "short")
+# the reference's digital_filter kwargs behind every fixture (tests/golden/make_golden.py::G8_CASES)
+KW = {
+    "lp4": dict(critical_freqs=6, order=4, filter_type="butter", band_type="lowpass", zero_lag=True),
+    "hp2_fwd": dict(critical_freqs=20, order=2, filter_type="butter", band_type="highpass", zero_lag=False),
+    "bp3": dict(critical_freqs=[20, 450], order=3, filter_type="butter", band_type="bandpass", zero_lag=True),
+    "cheby1_lp5": dict(critical_freqs=10, order=5, filter_type="cheby1", band_type="lowpass", zero_lag=True, cheby_param=1.0),
+    "cheby2_bs2_fwd": dict(critical_freqs=[45, 55], order=2, filter_type="cheby2", band_type="bandstop", zero_lag=False,
+                           cheby_param=30.0),
+    "long_lp2": dict(critical_freqs=4, order=2, filter_type="butter", band_type="lowpass", zero_lag=True),
+    "short": dict(critical_freqs=5, order=1, filter_type="butter", band_type="lowpass", zero_lag=True),
+}
+
+
+@pytest.fixture(scope="module")
+def g8():
+    return load_npz("g8_filters.npz")
+
+
+def _case(g8, name):
+    T, m, fs, zero_lag, seed = (int(v) for v in g8[f"{name}_params"])
+    raw = raw_emg(seed, T, m, fs=float(fs))
+    if f"{name}_raw" in g8.files:
+        assert np.array_equal(raw, g8[f"{name}_raw"])  # the generator is bit-reproducible across hosts
+    return raw, fs, bool(zero_lag), g8[f"{name}_sos"], g8[f"{name}_zi"]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_matches_reference_outputs(g8, name):
+    raw, fs, zero_lag, sos, zi = _case(g8, name)
+    assert np.allclose(so.sosfilt_zi(sos), zi, rtol=1e-13, atol=1e-300)
+    y = so.digital_filter(raw, sos, zero_lag)
+    if f"{name}_filtered" in g8.files:
+        assert np.array_equal(y, g8[f"{name}_filtered"])  # same operations in the same order: bit-exact
+    else:
+        assert np.array_equal(y[g8[f"{name}_rows"]], g8[f"{name}_filtered_rows"])
+        np.testing.assert_allclose(y.sum(axis=0), g8[f"{name}_filtered_colsum"], rtol=1e-12)
+    if KW[name]["band_type"] == "lowpass":
+        le = so.linear_envelope(raw, sos, zero_lag)
+        if f"{name}_linear_envelope" in g8.files:
+            np.testing.assert_allclose(le, g8[f"{name}_linear_envelope"], rtol=1e-12, atol=1e-15)
+            np.testing.assert_allclose(so.linear_envelope(raw, sos, zero_lag, zero_center=False),
+                                       g8[f"{name}_linear_envelope_nocenter"], rtol=0, atol=0)
+        else:
+            np.testing.assert_allclose(le[g8[f"{name}_rows"]], g8[f"{name}_linear_envelope_rows"], rtol=1e-12, atol=1e-15)
+
+
+def test_oracle_against_live_scipy_and_host_design(g8):
+    signal = pytest.importorskip("scipy.signal")
+    from muscle_synergies_amd.preprocess import design_sos
+
+    for name in CASES:
+        raw, fs, zero_lag, sos, zi = _case(g8, name)
+        kw = KW[name]
+        mine = design_sos(kw["filter_type"], kw["order"], fs, kw["critical_freqs"], kw["band_type"], kw.get("cheby_param"))
+        np.testing.assert_allclose(mine, sos, rtol=1e-12, atol=1e-300)  # design may differ in the last bits across hosts
+        ref = signal.sosfiltfilt(sos, raw, axis=0) if zero_lag else signal.sosfilt(sos, raw, axis=0)
+        assert np.array_equal(so.digital_filter(raw, sos, zero_lag), ref)
+        assert so.default_padlen(sos) == 3 * (2 * len(sos) + 1 - min((sos[:, 2] == 0).sum(), (sos[:, 5] == 0).sum()))
+    with pytest.raises(ValueError, match="must be greater than padlen"):
+        so.sosfiltfilt(g8["lp4_sos"], np.ones((15, 2)))
+    with pytest.raises(ValueError, match="filter type not understood"):
+        design_sos("bessel", 2, 100, 5)
+
+
+# ------------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES)
+def test_gpu_filter_is_bit_exact_in_fp64(g8, name):
+    from muscle_synergies_amd.preprocess import sosfilt_batched
+
+    raw, fs, zero_lag, sos, zi = _case(g8, name)
+    ref = so.digital_filter(raw, sos, zero_lag)
+    for arr in (np.ascontiguousarray(raw), np.asfortranarray(raw)):  # row-major and channel-major inputs
+        got = sosfilt_batched(arr, sos, zero_lag=zero_lag)[0].cpu().numpy()
+        assert got.shape == raw.shape and got.dtype == np.float64
+        assert np.array_equal(got, ref), np.abs(got - ref).max()
+    if f"{name}_filtered" in g8.files:
+        assert np.array_equal(got, g8[f"{name}_filtered"])
+    else:
+        assert np.array_equal(got[g8[f"{name}_rows"]], g8[f"{name}_filtered_rows"])
+    if KW[name]["band_type"] == "lowpass":
+        le = sosfilt_batched(raw, sos, zero_lag=zero_lag, zero_center=True, rectify=True)[0].cpu().numpy()
+        np.testing.assert_allclose(le, so.linear_envelope(raw, sos, zero_lag), rtol=1e-10, atol=1e-13)  # mean: other order
+        le_nc = sosfilt_batched(raw, sos, zero_lag=zero_lag, rectify=True)[0].cpu().numpy()
+        assert np.array_equal(le_nc, so.linear_envelope(raw, sos, zero_lag, zero_center=False))
+
+
+@pytest.mark.gpu
+def test_gpu_filter_batches_fp32_and_errors(g8):
+    import torch
+
+    from muscle_synergies_amd import _lib
+    from muscle_synergies_amd.preprocess import sosfilt_batched
+
+    sos = g8["lp4_sos"]
+    # 70 recordings x 3 channels = 210 series: several waves, the last one partly filled; T not a tile multiple
+    raw = np.stack([raw_emg(300 + b, 1333, 3) for b in range(70)])
+    got = sosfilt_batched(raw, sos, zero_lag=True, rectify=True).cpu().numpy()
+    for b in (0, 21, 69):
+        assert np.array_equal(got[b], so.linear_envelope(raw[b], sos, True, zero_center=False))
+    # more sections than the usual one or two (order-8 band-pass = 8 sections), forward only
+    from scipy import signal
+
+    sos8 = signal.butter(8, [20, 400], btype="bandpass", output="sos", fs=2000)
+    assert sos8.shape == (8, 6)
+    got8 = sosfilt_batched(raw[:2], sos8, zero_lag=False).cpu().numpy()
+    assert np.array_equal(got8[1], so.sosfilt(sos8, raw[1])[0])
+    got8 = sosfilt_batched(raw[:2], sos8, zero_lag=True).cpu().numpy()
+    assert np.array_equal(got8[0], so.sosfiltfilt(sos8, raw[0]))
+    # float32 samples: filtered in fp64 from the float values, rounded to float at the end
+    raw32 = raw_emg(100, 600, 4).astype(np.float32)
+    got32 = sosfilt_batched(raw32, sos, zero_lag=True)[0].cpu().numpy()
+    assert got32.dtype == np.float32
+    np.testing.assert_array_equal(got32, g8["lp4_filtered_from_f32"].astype(np.float32))
+    # a device tensor that is a transposed view (channel-major) is used in place
+    xt = torch.from_numpy(np.ascontiguousarray(raw[:4].transpose(0, 2, 1))).cuda().transpose(1, 2)
+    assert np.array_equal(sosfilt_batched(xt, sos).cpu().numpy(), np.stack([so.sosfiltfilt(sos, raw[b]) for b in range(4)]))
+    # explicit padlen, including none at all
+    assert np.array_equal(sosfilt_batched(raw[0], sos, padlen=0)[0].cpu().numpy(), so.sosfiltfilt(sos, raw[0], padlen=0))
+    assert np.array_equal(sosfilt_batched(raw[0], sos, padlen=100)[0].cpu().numpy(), so.sosfiltfilt(sos, raw[0], padlen=100))
+    # scipy's errors
+    with pytest.raises(ValueError, match="must be greater than padlen, which is 15"):
+        sosfilt_batched(np.ones((15, 2)), sos)
+    with pytest.raises(ValueError, match="sos\\[:, 3\\] should be all ones"):
+        sosfilt_batched(raw[0], sos * 2.0)
+    with pytest.raises(_lib.HipNmfError, match="outside the compiled kernel set"):
+        sosfilt_batched(raw[0], np.tile(sos, (5, 1)))
+
+
+@pytest.mark.gpu
+def test_gpu_dataframe_functions_match_the_reference_outputs(g8):
+    import muscle_synergies_amd.preprocess as pp
+
+    for name in ("lp4", "cheby1_lp5", "bp3", "hp2_fwd"):
+        raw, fs, zero_lag, sos, zi = _case(g8, name)
+        df = pd.DataFrame(raw, columns=[f"m{j}" for j in range(raw.shape[1])], index=np.arange(len(raw)) / fs)
+        out = pp.digital_filter(df, sampling_frequency=fs, **KW[name])
+        assert list(out.columns) == list(df.columns) and out.index.equals(df.index) and out is not df
+        np.testing.assert_allclose(out.to_numpy(), g8[f"{name}_filtered"], rtol=1e-12, atol=1e-300)
+        if KW[name]["band_type"] == "lowpass":
+            kw = {k: v for k, v in KW[name].items() if k != "band_type"}
+            le = pp.linear_envelope(df, sampling_frequency=fs, **kw)
+            np.testing.assert_allclose(le.to_numpy(), g8[f"{name}_linear_envelope"], rtol=1e-10, atol=1e-13)
+            le_nc = pp.linear_envelope(df, sampling_frequency=fs, zero_center_=False, **kw)
+            np.testing.assert_allclose(le_nc.to_numpy(), g8[f"{name}_linear_envelope_nocenter"], rtol=1e-12, atol=1e-300)
+    df2 = df.copy()
+    same = pp.digital_filter(df2, sampling_frequency=fs, inplace=True, **KW["hp2_fwd"])
+    assert same is df2 and np.allclose(df2.to_numpy(), g8["hp2_fwd_filtered"], rtol=1e-12)
+    with pytest.raises(ValueError, match="filter type not understood"):
+        pp.digital_filter(df, 5, 100, 2, filter_type="bessel")
+    # the whole filter-based chain on a batch, feeding the solver without a copy
+    import muscle_synergies_amd as ms
+    from oracle import emg_envelope_oracle as eo
+
+    raw = np.stack([raw_emg(500 + b, 4000, 6) for b in range(5)])
+    env = pp.linear_envelope_batched(raw, 6, 2000, 4, reduce_to=300)
+    assert tuple(env.shape) == (5, 300, 6) and env.stride(1) == 1
+    sos = pp.design_sos("butter", 4, 2000, 6)
+    for b in (0, 4):
+        ref = eo.normalize(eo.time_normalize(so.linear_envelope(raw[b], sos), 300))
+        np.testing.assert_allclose(env[b].cpu().numpy(), ref, rtol=1e-9, atol=1e-12)
+    X = env.clamp_min(0)  # a low-pass filter can undershoot slightly below zero
+    W0, H0 = ms.random_init_batched(X, 3, seed=0)
+    res = ms.fit_batched(X, W0, H0, max_iter=50, tol=0.0)
+    assert float(res.vaf[:, 0].min()) > 0.8
