@@ -41,8 +41,8 @@ void steady_state_zi(const double* sos, int ns, double (*zi)[2]) {
 }
 
 template <typename real, int NS>
-void launch_ns(const SosArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL((sosfilt_kernel<real, NS>), dim3((a.N + 63) / 64), dim3(64), 0, st, a);
+void launch_ns(const SosArgs& a, const double* stat, hipStream_t st) {
+  hipLaunchKernelGGL((sosfilt_kernel<real, NS>), dim3((a.N + 63) / 64), dim3(64), 0, st, a, stat);
 }
 
 template <typename real>
@@ -93,6 +93,7 @@ int sosfilt_impl(hipnmf_handle* h, const hipnmf_sosfilt_params* p, const double*
   const bool inplace = p->x_layout == HIPNMF_X_CHANNEL_MAJOR;
   const size_t o_x = inplace ? 0 : carve(sizeof(real) * (size_t)N * T);
   const size_t o_ws = zero_lag ? carve(sizeof(double) * (size_t)N * (size_t)L) : 0;
+  const size_t o_stat = carve(sizeof(double) * (size_t)N * 3);
   int rc = hipnmf_ensure_ws(h, std::max<size_t>(off, 256));
   if (rc) return rc;
   char* ws = static_cast<char*>(h->ws);
@@ -137,15 +138,17 @@ int sosfilt_impl(hipnmf_handle* h, const hipnmf_sosfilt_params* p, const double*
   a.rectify = p->rectify ? 1 : 0;
   const bool async = h->async_mode != 0;
   if (!async) HIP_TRY(hipEventRecord(h->ev0, st));
+  double* stat = reinterpret_cast<double*>(ws + o_stat);
+  hipLaunchKernelGGL(sos_stats_kernel<real>, dim3((unsigned)N), dim3(256), 0, st, a, stat);
   switch (p->n_sections) {
-    case 1: launch_ns<real, 1>(a, st); break;
-    case 2: launch_ns<real, 2>(a, st); break;
-    case 3: launch_ns<real, 3>(a, st); break;
-    case 4: launch_ns<real, 4>(a, st); break;
-    case 5: launch_ns<real, 5>(a, st); break;
-    case 6: launch_ns<real, 6>(a, st); break;
-    case 7: launch_ns<real, 7>(a, st); break;
-    default: launch_ns<real, 8>(a, st); break;
+    case 1: launch_ns<real, 1>(a, stat, st); break;
+    case 2: launch_ns<real, 2>(a, stat, st); break;
+    case 3: launch_ns<real, 3>(a, stat, st); break;
+    case 4: launch_ns<real, 4>(a, stat, st); break;
+    case 5: launch_ns<real, 5>(a, stat, st); break;
+    case 6: launch_ns<real, 6>(a, stat, st); break;
+    case 7: launch_ns<real, 7>(a, stat, st); break;
+    default: launch_ns<real, 8>(a, stat, st); break;
   }
   HIP_TRY(hipGetLastError());
   if (!async) {

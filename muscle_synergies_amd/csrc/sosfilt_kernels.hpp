@@ -46,8 +46,67 @@ __device__ __forceinline__ double sos_step(double xc, double (&z)[NS][2], const 
   return xc;
 }
 
+// pre-processing of one raw sample in the precision of the samples (numpy / pandas compute the centring, the
+// rectification and scipy's odd extension in the array's own dtype before sosfilt promotes to float64)
+template <typename real>
+__device__ __forceinline__ real sos_pre(real x, real mean, int rectify) {
+  real v = x - mean;
+  return rectify ? (real)fabs((double)v) : v;
+}
+
+// per-series statistics: stat[s] = {mean (0 unless zero_center), first, last pre-processed sample}
+template <typename real>
+__global__ void __launch_bounds__(256) sos_stats_kernel(SosArgs a, double* __restrict__ stat) {
+  __shared__ double scratch[4];
+  const int s = blockIdx.x;
+  const real* __restrict__ xr =
+      static_cast<const real*>(a.x) + (long long)(s / a.m) * a.bstride + (long long)(s % a.m) * a.ld;
+  double mean = 0.0;
+  if (a.zero_center) {
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < a.T; i += 256) acc += (double)xr[i];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    mean = (scratch[0] + scratch[1] + scratch[2] + scratch[3]) / (double)a.T;
+  }
+  if (threadIdx.x == 0) {
+    const real mr = (real)mean;
+    stat[3LL * s + 0] = (double)mr;
+    stat[3LL * s + 1] = (double)sos_pre<real>(xr[0], mr, a.rectify);
+    stat[3LL * s + 2] = (double)sos_pre<real>(xr[a.T - 1], mr, a.rectify);
+  }
+}
+
+// filter `nval` consecutive samples of this lane's series in place in LDS, eight at a time (eight LDS reads in
+// flight, then the dependent recursion, then eight writes); DIR = +1 forward in time, -1 backward
+template <int NS, int DIR>
+__device__ __forceinline__ double sos_run_tile(double* __restrict__ row, int nval, double (&z)[NS][2],
+                                               const double (&c)[NS][5], double ylast) {
+  if (nval == SOS_TT) {
+    for (int q = 0; q < SOS_TT; q += 8) {
+      double v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = row[DIR > 0 ? q + e : SOS_TT - 1 - q - e];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = sos_step<NS>(v[e], z, c);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) row[DIR > 0 ? q + e : SOS_TT - 1 - q - e] = v[e];
+      ylast = v[7];
+    }
+  } else {
+    for (int n = 0; n < nval; ++n) {
+      const int idx = DIR > 0 ? n : nval - 1 - n;
+      ylast = sos_step<NS>(row[idx], z, c);
+      row[idx] = ylast;
+    }
+  }
+  return ylast;
+}
+
 template <typename real, int NS>
-__global__ void __launch_bounds__(64) sosfilt_kernel(SosArgs a) {
+__global__ void __launch_bounds__(64) sosfilt_kernel(SosArgs a, const double* __restrict__ stat_g) {
   __shared__ double tile[SOS_TT * SOS_LD];
   __shared__ double stat[64][3];  // per series of this wave: mean, first and last pre-processed sample
   const int lane = threadIdx.x;
@@ -55,33 +114,11 @@ __global__ void __launch_bounds__(64) sosfilt_kernel(SosArgs a) {
   const int T = a.T, edge = a.edge, L = T + 2 * edge, N = a.N;
   const int nrows = (N - s0 < 64) ? N - s0 : 64;  // series handled by this wave
   const real* __restrict__ xbase = static_cast<const real*>(a.x);
-  auto series = [&](int r) -> const real* {  // wave-uniform
-    const int s = s0 + r;
-    return xbase + (long long)(s / a.m) * a.bstride + (long long)(s % a.m) * a.ld;
-  };
-
-  // ---- per-series mean (zero_center) and end samples ------------------------------------------------------
-  for (int r = 0; r < nrows; ++r) {
-    const real* __restrict__ xr = series(r);
-    double mean = 0.0;
-    if (a.zero_center) {
-      double s = 0.0;
-      for (int i = lane; i < T; i += 64) s += (double)xr[i];
-#pragma unroll
-      for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
-      mean = s / (double)T;
-    }
-    if (lane == 0) {
-      double v0 = (double)xr[0] - mean, v1 = (double)xr[T - 1] - mean;
-      if (a.rectify) {
-        v0 = fabs(v0);
-        v1 = fabs(v1);
-      }
-      stat[r][0] = mean;
-      stat[r][1] = v0;
-      stat[r][2] = v1;
-    }
-  }
+  // series s0 + r starts at xbase + off_r; the offsets advance by ld inside a recording and jump at its end
+  const long long off0 = (long long)(s0 / a.m) * a.bstride + (long long)(s0 % a.m) * a.ld;
+  const int ch0 = s0 % a.m;
+  const long long jump = a.bstride - (long long)a.m * a.ld;
+  for (int i = lane; i < 64 * 3; i += 64) (&stat[0][0])[i] = (i < nrows * 3) ? stat_g[3LL * s0 + i] : 0.0;
   __syncthreads();
 
   double c[NS][5];
@@ -103,30 +140,35 @@ __global__ void __launch_bounds__(64) sosfilt_kernel(SosArgs a) {
     if (j < 0) j = -j;
     if (j >= T) j = 2 * (T - 1) - j;
     const bool ok = i < L;
+    long long off = off0;
+    int ch = ch0;
 #pragma unroll
     for (int r = 0; r < 64; ++r) {
       pf[r] = (real)0;
-      if (r < nrows && ok) pf[r] = series(r)[j];
+      if (r < nrows && ok) pf[r] = xbase[off + j];
+      off += a.ld;
+      if (++ch == a.m) {
+        ch = 0;
+        off += jump;
+      }
     }
   };
-  auto commit_fwd = [&](int k) {  // registers -> LDS as pre-processed fp64 (zero-centre, rectify, odd extension)
+  auto commit_fwd = [&](int k) {  // registers -> LDS: zero-centre, rectify, odd extension, then fp64
     const int i = k * SOS_TT + lane;
     const int j = i - edge;
 #pragma unroll
     for (int r = 0; r < 64; ++r) {
-      double v = (double)pf[r] - stat[r][0];
-      if (a.rectify) v = fabs(v);
+      real v = sos_pre<real>(pf[r], (real)stat[r][0], a.rectify);
       if (j < 0)
-        v = 2.0 * stat[r][1] - v;
+        v = (real)2 * (real)stat[r][1] - v;
       else if (j >= T)
-        v = 2.0 * stat[r][2] - v;
-      tile[r * SOS_LD + lane] = v;
+        v = (real)2 * (real)stat[r][2] - v;
+      tile[r * SOS_LD + lane] = (double)v;
     }
   };
 
   double z[NS][2];
   double ylast = 0.0;
-  bool primed = false;
   issue_fwd(0);
   for (int k = 0; k < ntiles; ++k) {
     const int t0 = k * SOS_TT;
@@ -135,40 +177,29 @@ __global__ void __launch_bounds__(64) sosfilt_kernel(SosArgs a) {
     __syncthreads();
     if (k + 1 < ntiles) issue_fwd(k + 1);
     const int nval = (L - t0 < SOS_TT) ? L - t0 : SOS_TT;
-    if (!primed) {  // initial state: zi * ext[0] (sosfiltfilt) or zeros (sosfilt)
+    if (k == 0) {  // initial state: zi * ext[0] (sosfiltfilt) or zeros (sosfilt)
       const double x0 = tile[lane * SOS_LD];
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
         z[s][0] = a.zero_lag ? a.zi[s][0] * x0 : 0.0;
         z[s][1] = a.zero_lag ? a.zi[s][1] * x0 : 0.0;
       }
-      primed = true;
     }
-    if (nval == SOS_TT) {
-#pragma unroll 8
-      for (int n = 0; n < SOS_TT; ++n) {
-        ylast = sos_step<NS>(tile[lane * SOS_LD + n], z, c);
-        tile[lane * SOS_LD + n] = ylast;
-      }
-    } else {
-      for (int n = 0; n < nval; ++n) {
-        ylast = sos_step<NS>(tile[lane * SOS_LD + n], z, c);
-        tile[lane * SOS_LD + n] = ylast;
-      }
-    }
+    ylast = sos_run_tile<NS, +1>(tile + lane * SOS_LD, nval, z, c, ylast);
     __syncthreads();
     const int i = t0 + lane;
     if (a.zero_lag) {
       if (i < L) {
+        double* __restrict__ wp = a.ws + (long long)s0 * L + i;
 #pragma unroll 8
         for (int r = 0; r < 64; ++r)
-          if (r < nrows) a.ws[(long long)(s0 + r) * L + i] = tile[r * SOS_LD + lane];
+          if (r < nrows) wp[(long long)r * L] = tile[r * SOS_LD + lane];
       }
     } else if (i < T) {
-      real* __restrict__ yb = static_cast<real*>(a.y);
+      real* __restrict__ yp = static_cast<real*>(a.y) + (long long)s0 * T + i;
 #pragma unroll 8
       for (int r = 0; r < 64; ++r)
-        if (r < nrows) yb[(long long)(s0 + r) * T + i] = (real)tile[r * SOS_LD + lane];
+        if (r < nrows) yp[(long long)r * T] = (real)tile[r * SOS_LD + lane];
     }
   }
   if (!a.zero_lag) return;
@@ -183,10 +214,11 @@ __global__ void __launch_bounds__(64) sosfilt_kernel(SosArgs a) {
   double pb[64];
   auto issue_bwd = [&](int k) {
     const int i = k * SOS_TT + lane;
+    const double* __restrict__ wp = a.ws + (long long)s0 * L + i;
 #pragma unroll
     for (int r = 0; r < 64; ++r) {
       pb[r] = 0.0;
-      if (r < nrows && i < L) pb[r] = a.ws[(long long)(s0 + r) * L + i];
+      if (r < nrows && i < L) pb[r] = wp[(long long)r * L];
     }
   };
   issue_bwd(ntiles - 1);
@@ -198,19 +230,17 @@ __global__ void __launch_bounds__(64) sosfilt_kernel(SosArgs a) {
     __syncthreads();
     if (k > 0) issue_bwd(k - 1);
     const int nval = (L - t0 < SOS_TT) ? L - t0 : SOS_TT;
-    if (nval == SOS_TT) {
-#pragma unroll 8
-      for (int n = SOS_TT - 1; n >= 0; --n) tile[lane * SOS_LD + n] = sos_step<NS>(tile[lane * SOS_LD + n], z, c);
-    } else {
-      for (int n = nval - 1; n >= 0; --n) tile[lane * SOS_LD + n] = sos_step<NS>(tile[lane * SOS_LD + n], z, c);
-    }
+    if (nval == SOS_TT)
+      sos_run_tile<NS, -1>(tile + lane * SOS_LD, SOS_TT, z, c, 0.0);
+    else
+      sos_run_tile<NS, -1>(tile + lane * SOS_LD, nval, z, c, 0.0);
     __syncthreads();
     const int j = t0 + lane - edge;
     if (j >= 0 && j < T) {
-      real* __restrict__ yb = static_cast<real*>(a.y);
+      real* __restrict__ yp = static_cast<real*>(a.y) + (long long)s0 * T + j;
 #pragma unroll 8
       for (int r = 0; r < 64; ++r)
-        if (r < nrows) yb[(long long)(s0 + r) * T + j] = (real)tile[r * SOS_LD + lane];
+        if (r < nrows) yp[(long long)r * T] = (real)tile[r * SOS_LD + lane];
     }
   }
 }
