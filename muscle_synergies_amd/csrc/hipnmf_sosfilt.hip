@@ -92,7 +92,8 @@ int sosfilt_impl(hipnmf_handle* h, const hipnmf_sosfilt_params* p, const double*
   };
   const bool inplace = p->x_layout == HIPNMF_X_CHANNEL_MAJOR;
   const size_t o_x = inplace ? 0 : carve(sizeof(real) * (size_t)N * T);
-  const size_t o_ws = zero_lag ? carve(sizeof(double) * (size_t)N * (size_t)L) : 0;
+  // forward output of the zero-lag filter: 64 rows per wave, so the last wave needs no row guards
+  const size_t o_ws = zero_lag ? carve(sizeof(double) * (size_t)round_up(N, 64) * (size_t)L) : 0;
   const size_t o_stat = carve(sizeof(double) * (size_t)N * 3);
   int rc = hipnmf_ensure_ws(h, std::max<size_t>(off, 256));
   if (rc) return rc;

@@ -139,18 +139,19 @@ __global__ void __launch_bounds__(64) sosfilt_kernel(SosArgs a, const double* __
     int j = i - edge;
     if (j < 0) j = -j;
     if (j >= T) j = 2 * (T - 1) - j;
-    const bool ok = i < L;
+    j = j < 0 ? 0 : j;  // lanes past the end of the extended signal: any valid address, value unused
+    // branch-free on purpose: a load inside a conditional makes hipcc wait for it at the join, which would
+    // serialise the 64 row loads; rows past the last series re-read the last valid row instead
     long long off = off0;
     int ch = ch0;
 #pragma unroll
     for (int r = 0; r < 64; ++r) {
-      pf[r] = (real)0;
-      if (r < nrows && ok) pf[r] = xbase[off + j];
-      off += a.ld;
-      if (++ch == a.m) {
-        ch = 0;
-        off += jump;
-      }
+      pf[r] = xbase[off + j];
+      const bool more = r + 1 < nrows;
+      long long step = a.ld;
+      if (ch + 1 == a.m) step += jump;
+      ch = more ? (ch + 1 == a.m ? 0 : ch + 1) : ch;
+      off += more ? step : 0;
     }
   };
   auto commit_fwd = [&](int k) {  // registers -> LDS: zero-centre, rectify, odd extension, then fp64
@@ -164,6 +165,16 @@ __global__ void __launch_bounds__(64) sosfilt_kernel(SosArgs a, const double* __
       else if (j >= T)
         v = (real)2 * (real)stat[r][2] - v;
       tile[r * SOS_LD + lane] = (double)v;
+    }
+  };
+
+  auto store_rows = [&](int j) {  // LDS rows -> y[series][j] (j valid for this lane)
+    real* __restrict__ yp = static_cast<real*>(a.y) + (long long)s0 * T + j;
+    if (nrows == 64) {
+#pragma unroll 8
+      for (int r = 0; r < 64; ++r) yp[(long long)r * T] = (real)tile[r * SOS_LD + lane];
+    } else {
+      for (int r = 0; r < nrows; ++r) yp[(long long)r * T] = (real)tile[r * SOS_LD + lane];
     }
   };
 
@@ -189,17 +200,13 @@ __global__ void __launch_bounds__(64) sosfilt_kernel(SosArgs a, const double* __
     __syncthreads();
     const int i = t0 + lane;
     if (a.zero_lag) {
-      if (i < L) {
+      if (i < L) {  // ws has room for 64 rows per wave: no row guard
         double* __restrict__ wp = a.ws + (long long)s0 * L + i;
 #pragma unroll 8
-        for (int r = 0; r < 64; ++r)
-          if (r < nrows) wp[(long long)r * L] = tile[r * SOS_LD + lane];
+        for (int r = 0; r < 64; ++r) wp[(long long)r * L] = tile[r * SOS_LD + lane];
       }
     } else if (i < T) {
-      real* __restrict__ yp = static_cast<real*>(a.y) + (long long)s0 * T + i;
-#pragma unroll 8
-      for (int r = 0; r < 64; ++r)
-        if (r < nrows) yp[(long long)r * T] = (real)tile[r * SOS_LD + lane];
+      store_rows(i);
     }
   }
   if (!a.zero_lag) return;
@@ -213,13 +220,11 @@ __global__ void __launch_bounds__(64) sosfilt_kernel(SosArgs a, const double* __
   }
   double pb[64];
   auto issue_bwd = [&](int k) {
-    const int i = k * SOS_TT + lane;
+    int i = k * SOS_TT + lane;
+    i = i < L ? i : L - 1;  // branch-free (see issue_fwd); ws holds 64 rows for every wave
     const double* __restrict__ wp = a.ws + (long long)s0 * L + i;
 #pragma unroll
-    for (int r = 0; r < 64; ++r) {
-      pb[r] = 0.0;
-      if (r < nrows && i < L) pb[r] = wp[(long long)r * L];
-    }
+    for (int r = 0; r < 64; ++r) pb[r] = wp[(long long)r * L];
   };
   issue_bwd(ntiles - 1);
   for (int k = ntiles - 1; k >= 0; --k) {
@@ -236,12 +241,7 @@ __global__ void __launch_bounds__(64) sosfilt_kernel(SosArgs a, const double* __
       sos_run_tile<NS, -1>(tile + lane * SOS_LD, nval, z, c, 0.0);
     __syncthreads();
     const int j = t0 + lane - edge;
-    if (j >= 0 && j < T) {
-      real* __restrict__ yp = static_cast<real*>(a.y) + (long long)s0 * T + j;
-#pragma unroll 8
-      for (int r = 0; r < 64; ++r)
-        if (r < nrows) yp[(long long)r * T] = (real)tile[r * SOS_LD + lane];
-    }
+    if (j >= 0 && j < T) store_rows(j);
   }
 }
 
