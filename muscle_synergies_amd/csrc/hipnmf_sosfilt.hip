@@ -41,8 +41,12 @@ void steady_state_zi(const double* sos, int ns, double (*zi)[2]) {
 }
 
 template <typename real, int NS>
-void launch_ns(const SosArgs& a, const double* stat, hipStream_t st) {
-  hipLaunchKernelGGL((sosfilt_kernel<real, NS>), dim3((a.N + 63) / 64), dim3(64), 0, st, a, stat);
+hipError_t launch_ns(const SosArgs& a, const double* stat, hipStream_t st) {
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(sosfilt_kernel<real, NS>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)SOS_SMEM_BYTES);
+  if (attr != hipSuccess) return attr;
+  hipLaunchKernelGGL((sosfilt_kernel<real, NS>), dim3((a.N + 63) / 64), dim3(64), SOS_SMEM_BYTES, st, a, stat);
+  return hipSuccess;
 }
 
 template <typename real>
@@ -142,14 +146,14 @@ int sosfilt_impl(hipnmf_handle* h, const hipnmf_sosfilt_params* p, const double*
   double* stat = reinterpret_cast<double*>(ws + o_stat);
   hipLaunchKernelGGL(sos_stats_kernel<real>, dim3((unsigned)N), dim3(256), 0, st, a, stat);
   switch (p->n_sections) {
-    case 1: launch_ns<real, 1>(a, stat, st); break;
-    case 2: launch_ns<real, 2>(a, stat, st); break;
-    case 3: launch_ns<real, 3>(a, stat, st); break;
-    case 4: launch_ns<real, 4>(a, stat, st); break;
-    case 5: launch_ns<real, 5>(a, stat, st); break;
-    case 6: launch_ns<real, 6>(a, stat, st); break;
-    case 7: launch_ns<real, 7>(a, stat, st); break;
-    default: launch_ns<real, 8>(a, stat, st); break;
+    case 1: HIP_TRY((launch_ns<real, 1>(a, stat, st))); break;
+    case 2: HIP_TRY((launch_ns<real, 2>(a, stat, st))); break;
+    case 3: HIP_TRY((launch_ns<real, 3>(a, stat, st))); break;
+    case 4: HIP_TRY((launch_ns<real, 4>(a, stat, st))); break;
+    case 5: HIP_TRY((launch_ns<real, 5>(a, stat, st))); break;
+    case 6: HIP_TRY((launch_ns<real, 6>(a, stat, st))); break;
+    case 7: HIP_TRY((launch_ns<real, 7>(a, stat, st))); break;
+    default: HIP_TRY((launch_ns<real, 8>(a, stat, st))); break;
   }
   HIP_TRY(hipGetLastError());
   if (!async) {

@@ -7,8 +7,8 @@
 // channel) series, 64 series per wave, one wave per workgroup.  HBM is still streamed coalesced: a tile of
 // 64 series x 64 samples is loaded row by row (64 lanes = 64 consecutive samples of one series), transposed
 // through LDS (row stride 65 doubles: conflict-free both ways), filtered lane-per-series out of LDS, and
-// stored row by row again.  The next tile's rows are in flight (registers) while the current tile is
-// filtered.  All arithmetic is fp64 with every product and sum rounded separately, in scipy's order
+// stored row by row again.  The next tile's rows are in flight (registers) and the previous tile's rows are
+// being stored (second LDS buffer) while the current tile is filtered.  All arithmetic is fp64 with every product and sum rounded separately, in scipy's order
 // (direct form II transposed), so the fp64 result is bit-identical to scipy's for identical input.
 //
 // Zero-lag needs the whole forward output before the backward pass starts: it goes to an fp64 workspace
@@ -105,10 +105,18 @@ __device__ __forceinline__ double sos_run_tile(double* __restrict__ row, int nva
   return ylast;
 }
 
+constexpr int SOS_TILE = SOS_TT * SOS_LD;                       // doubles per LDS tile
+constexpr size_t SOS_SMEM_BYTES = sizeof(double) * (2 * SOS_TILE + 64 * 3);
+
+// Per tile k (both passes): wait for the rows of tile k -> LDS buffer k%2; issue the row stores of tile k-1
+// (other buffer) and then the row loads of tile k+1; run the recursion on tile k.  Every global access thus
+// has a whole tile's recursion to complete before the wave waits on it, and the wait (vmcnt(0)) never covers
+// an operation that was issued just before it.
 template <typename real, int NS>
 __global__ void __launch_bounds__(64) sosfilt_kernel(SosArgs a, const double* __restrict__ stat_g) {
-  __shared__ double tile[SOS_TT * SOS_LD];
-  __shared__ double stat[64][3];  // per series of this wave: mean, first and last pre-processed sample
+  extern __shared__ __attribute__((aligned(16))) double sos_smem[];
+  double* tile = sos_smem;                                    // [2][SOS_TILE]
+  double (*stat)[3] = reinterpret_cast<double (*)[3]>(sos_smem + 2 * SOS_TILE);  // mean, first, last sample
   const int lane = threadIdx.x;
   const int s0 = blockIdx.x * 64;
   const int T = a.T, edge = a.edge, L = T + 2 * edge, N = a.N;
@@ -154,7 +162,7 @@ __global__ void __launch_bounds__(64) sosfilt_kernel(SosArgs a, const double* __
       off += more ? step : 0;
     }
   };
-  auto commit_fwd = [&](int k) {  // registers -> LDS: zero-centre, rectify, odd extension, then fp64
+  auto commit_fwd = [&](int k, double* __restrict__ buf) {  // registers -> LDS: centre, rectify, odd extension
     const int i = k * SOS_TT + lane;
     const int j = i - edge;
 #pragma unroll
@@ -164,17 +172,29 @@ __global__ void __launch_bounds__(64) sosfilt_kernel(SosArgs a, const double* __
         v = (real)2 * (real)stat[r][1] - v;
       else if (j >= T)
         v = (real)2 * (real)stat[r][2] - v;
-      tile[r * SOS_LD + lane] = (double)v;
+      buf[r * SOS_LD + lane] = (double)v;
     }
   };
-
-  auto store_rows = [&](int j) {  // LDS rows -> y[series][j] (j valid for this lane)
+  auto store_y = [&](const double* __restrict__ buf, int j) {  // LDS rows -> y[series][j] where j is in range
+    if (j < 0 || j >= T) return;
     real* __restrict__ yp = static_cast<real*>(a.y) + (long long)s0 * T + j;
     if (nrows == 64) {
 #pragma unroll 8
-      for (int r = 0; r < 64; ++r) yp[(long long)r * T] = (real)tile[r * SOS_LD + lane];
+      for (int r = 0; r < 64; ++r) yp[(long long)r * T] = (real)buf[r * SOS_LD + lane];
     } else {
-      for (int r = 0; r < nrows; ++r) yp[(long long)r * T] = (real)tile[r * SOS_LD + lane];
+      for (int r = 0; r < nrows; ++r) yp[(long long)r * T] = (real)buf[r * SOS_LD + lane];
+    }
+  };
+  auto store_fwd = [&](int k, const double* __restrict__ buf) {  // filtered tile k of the forward pass
+    const int i = k * SOS_TT + lane;
+    if (a.zero_lag) {
+      if (i < L) {  // ws has room for 64 rows per wave: no row guard
+        double* __restrict__ wp = a.ws + (long long)s0 * L + i;
+#pragma unroll 8
+        for (int r = 0; r < 64; ++r) wp[(long long)r * L] = buf[r * SOS_LD + lane];
+      }
+    } else {
+      store_y(buf, i);
     }
   };
 
@@ -182,33 +202,26 @@ __global__ void __launch_bounds__(64) sosfilt_kernel(SosArgs a, const double* __
   double ylast = 0.0;
   issue_fwd(0);
   for (int k = 0; k < ntiles; ++k) {
-    const int t0 = k * SOS_TT;
-    __syncthreads();  // previous tile's row stores have read the LDS tile
-    commit_fwd(k);
+    double* buf = tile + (k & 1) * SOS_TILE;
     __syncthreads();
+    commit_fwd(k, buf);
+    __syncthreads();
+    if (k > 0) store_fwd(k - 1, tile + ((k - 1) & 1) * SOS_TILE);
     if (k + 1 < ntiles) issue_fwd(k + 1);
+    const int t0 = k * SOS_TT;
     const int nval = (L - t0 < SOS_TT) ? L - t0 : SOS_TT;
     if (k == 0) {  // initial state: zi * ext[0] (sosfiltfilt) or zeros (sosfilt)
-      const double x0 = tile[lane * SOS_LD];
+      const double x0 = buf[lane * SOS_LD];
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
         z[s][0] = a.zero_lag ? a.zi[s][0] * x0 : 0.0;
         z[s][1] = a.zero_lag ? a.zi[s][1] * x0 : 0.0;
       }
     }
-    ylast = sos_run_tile<NS, +1>(tile + lane * SOS_LD, nval, z, c, ylast);
-    __syncthreads();
-    const int i = t0 + lane;
-    if (a.zero_lag) {
-      if (i < L) {  // ws has room for 64 rows per wave: no row guard
-        double* __restrict__ wp = a.ws + (long long)s0 * L + i;
-#pragma unroll 8
-        for (int r = 0; r < 64; ++r) wp[(long long)r * L] = tile[r * SOS_LD + lane];
-      }
-    } else if (i < T) {
-      store_rows(i);
-    }
+    ylast = sos_run_tile<NS, +1>(buf + lane * SOS_LD, nval, z, c, ylast);
   }
+  __syncthreads();
+  store_fwd(ntiles - 1, tile + ((ntiles - 1) & 1) * SOS_TILE);
   if (!a.zero_lag) return;
 
   // ---- backward pass: the forward output reversed, initial state zi * y[L-1]; keep the central T samples ------
@@ -228,21 +241,19 @@ __global__ void __launch_bounds__(64) sosfilt_kernel(SosArgs a, const double* __
   };
   issue_bwd(ntiles - 1);
   for (int k = ntiles - 1; k >= 0; --k) {
-    const int t0 = k * SOS_TT;
+    double* buf = tile + (k & 1) * SOS_TILE;
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 64; ++r) tile[r * SOS_LD + lane] = pb[r];
+    for (int r = 0; r < 64; ++r) buf[r * SOS_LD + lane] = pb[r];
     __syncthreads();
+    if (k + 1 < ntiles) store_y(tile + ((k + 1) & 1) * SOS_TILE, (k + 1) * SOS_TT + lane - edge);
     if (k > 0) issue_bwd(k - 1);
+    const int t0 = k * SOS_TT;
     const int nval = (L - t0 < SOS_TT) ? L - t0 : SOS_TT;
-    if (nval == SOS_TT)
-      sos_run_tile<NS, -1>(tile + lane * SOS_LD, SOS_TT, z, c, 0.0);
-    else
-      sos_run_tile<NS, -1>(tile + lane * SOS_LD, nval, z, c, 0.0);
-    __syncthreads();
-    const int j = t0 + lane - edge;
-    if (j >= 0 && j < T) store_rows(j);
+    sos_run_tile<NS, -1>(buf + lane * SOS_LD, nval, z, c, 0.0);
   }
+  __syncthreads();
+  store_y(tile, lane - edge);
 }
 
 }  // namespace hipnmf
