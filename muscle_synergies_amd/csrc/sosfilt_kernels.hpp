@@ -54,6 +54,17 @@ __device__ __forceinline__ real sos_pre(real x, real mean, int rectify) {
   return rectify ? (real)fabs((double)v) : v;
 }
 
+// value of lane `r` (wave-uniform r) for every lane: v_readlane into an SGPR, no LDS round trip
+__device__ __forceinline__ float lane_bcast(float v, int r) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), r));
+}
+__device__ __forceinline__ double lane_bcast(double v, int r) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, r);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), r);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
 // per-series statistics: stat[s] = {mean (0 unless zero_center), first, last pre-processed sample}
 template <typename real>
 __global__ void __launch_bounds__(256) sos_stats_kernel(SosArgs a, double* __restrict__ stat) {
@@ -106,7 +117,7 @@ __device__ __forceinline__ double sos_run_tile(double* __restrict__ row, int nva
 }
 
 constexpr int SOS_TILE = SOS_TT * SOS_LD;                       // doubles per LDS tile
-constexpr size_t SOS_SMEM_BYTES = sizeof(double) * (2 * SOS_TILE + 64 * 3);
+constexpr size_t SOS_SMEM_BYTES = sizeof(double) * (2 * SOS_TILE);
 
 // Per tile k (both passes): wait for the rows of tile k -> LDS buffer k%2; issue the row stores of tile k-1
 // (other buffer) and then the row loads of tile k+1; run the recursion on tile k.  Every global access thus
@@ -115,8 +126,7 @@ constexpr size_t SOS_SMEM_BYTES = sizeof(double) * (2 * SOS_TILE + 64 * 3);
 template <typename real, int NS>
 __global__ void __launch_bounds__(64) sosfilt_kernel(SosArgs a, const double* __restrict__ stat_g) {
   extern __shared__ __attribute__((aligned(16))) double sos_smem[];
-  double* tile = sos_smem;                                    // [2][SOS_TILE]
-  double (*stat)[3] = reinterpret_cast<double (*)[3]>(sos_smem + 2 * SOS_TILE);  // mean, first, last sample
+  double* tile = sos_smem;  // [2][SOS_TILE]
   const int lane = threadIdx.x;
   const int s0 = blockIdx.x * 64;
   const int T = a.T, edge = a.edge, L = T + 2 * edge, N = a.N;
@@ -126,8 +136,11 @@ __global__ void __launch_bounds__(64) sosfilt_kernel(SosArgs a, const double* __
   const long long off0 = (long long)(s0 / a.m) * a.bstride + (long long)(s0 % a.m) * a.ld;
   const int ch0 = s0 % a.m;
   const long long jump = a.bstride - (long long)a.m * a.ld;
-  for (int i = lane; i < 64 * 3; i += 64) (&stat[0][0])[i] = (i < nrows * 3) ? stat_g[3LL * s0 + i] : 0.0;
-  __syncthreads();
+  // lane r keeps the statistics of series s0 + r: mean, first and last pre-processed sample
+  const int sl = lane < nrows ? lane : nrows - 1;
+  const real mean_l = (real)stat_g[3LL * (s0 + sl) + 0];
+  const real first_l = (real)stat_g[3LL * (s0 + sl) + 1];
+  const real last_l = (real)stat_g[3LL * (s0 + sl) + 2];
 
   double c[NS][5];
 #pragma unroll
@@ -165,14 +178,20 @@ __global__ void __launch_bounds__(64) sosfilt_kernel(SosArgs a, const double* __
   auto commit_fwd = [&](int k, double* __restrict__ buf) {  // registers -> LDS: centre, rectify, odd extension
     const int i = k * SOS_TT + lane;
     const int j = i - edge;
+    const bool left = j < 0, ext = left || j >= T;
+    if (k * SOS_TT >= edge && k * SOS_TT + SOS_TT <= edge + T) {  // interior tile (wave-uniform): no extension
 #pragma unroll
-    for (int r = 0; r < 64; ++r) {
-      real v = sos_pre<real>(pf[r], (real)stat[r][0], a.rectify);
-      if (j < 0)
-        v = (real)2 * (real)stat[r][1] - v;
-      else if (j >= T)
-        v = (real)2 * (real)stat[r][2] - v;
-      buf[r * SOS_LD + lane] = (double)v;
+      for (int r = 0; r < 64; ++r)
+        buf[r * SOS_LD + lane] = (double)sos_pre<real>(pf[r], lane_bcast(mean_l, r), a.rectify);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 64; ++r) {
+        const real v = sos_pre<real>(pf[r], lane_bcast(mean_l, r), a.rectify);
+        const real e0 = lane_bcast(first_l, r), e1 = lane_bcast(last_l, r);
+        const real end = left ? e0 : e1;
+        const real refl = (real)2 * end - v;  // odd extension about the end sample
+        buf[r * SOS_LD + lane] = (double)(ext ? refl : v);
+      }
     }
   };
   auto store_y = [&](const double* __restrict__ buf, int j) {  // LDS rows -> y[series][j] where j is in range
