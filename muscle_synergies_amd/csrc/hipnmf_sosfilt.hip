@@ -42,10 +42,8 @@ void steady_state_zi(const double* sos, int ns, double (*zi)[2]) {
 
 template <typename real, int NS>
 hipError_t launch_ns(const SosArgs& a, const double* stat, hipStream_t st) {
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(sosfilt_kernel<real, NS>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)SOS_SMEM_BYTES);
-  if (attr != hipSuccess) return attr;
-  hipLaunchKernelGGL((sosfilt_kernel<real, NS>), dim3((a.N + 63) / 64), dim3(64), SOS_SMEM_BYTES, st, a, stat);
+  constexpr int S = SOS_SERIES;
+  hipLaunchKernelGGL((sosfilt_kernel<real, NS, S>), dim3((a.N + S - 1) / S), dim3(64), sos_smem_bytes<S>(), st, a, stat);
   return hipSuccess;
 }
 
@@ -96,8 +94,8 @@ int sosfilt_impl(hipnmf_handle* h, const hipnmf_sosfilt_params* p, const double*
   };
   const bool inplace = p->x_layout == HIPNMF_X_CHANNEL_MAJOR;
   const size_t o_x = inplace ? 0 : carve(sizeof(real) * (size_t)N * T);
-  // forward output of the zero-lag filter: 64 rows per wave, so the last wave needs no row guards
-  const size_t o_ws = zero_lag ? carve(sizeof(double) * (size_t)round_up(N, 64) * (size_t)L) : 0;
+  // forward output of the zero-lag filter: SOS_SERIES rows per wave, so the last wave needs no row guards
+  const size_t o_ws = zero_lag ? carve(sizeof(double) * (size_t)round_up(N, SOS_SERIES) * (size_t)L) : 0;
   const size_t o_stat = carve(sizeof(double) * (size_t)N * 3);
   int rc = hipnmf_ensure_ws(h, std::max<size_t>(off, 256));
   if (rc) return rc;

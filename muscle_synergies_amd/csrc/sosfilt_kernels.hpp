@@ -4,10 +4,12 @@
 // initial conditions, forward then backward).  SURVEY.md section 8, row f-1.
 //
 // An IIR recursion is sequential in time, so the parallel axis is the series: one lane per (recording,
-// channel) series, 64 series per wave, one wave per workgroup.  HBM is still streamed coalesced: a tile of
-// 64 series x 64 samples is loaded row by row (64 lanes = 64 consecutive samples of one series), transposed
+// channel) series, S series per wave, one wave per workgroup.  HBM is still streamed coalesced: a tile of
+// S series x 64 samples is loaded row by row (64 lanes = 64 consecutive samples of one series), transposed
 // through LDS (row stride 65 doubles: conflict-free both ways), filtered lane-per-series out of LDS, and
-// stored row by row again.  The next tile's rows are in flight (registers) and the previous tile's rows are
+// stored row by row again.  The recursion is bound by the latency of its dependent fp64 chain (about 40 cycles
+// per sample and section), not by lane count, so S = 16 (a quarter of the lanes active in the recursion, four
+// times the waves) is what fills the chip for batches up to ~10^5 series.  The next tile's rows are in flight (registers) and the previous tile's rows are
 // being stored (second LDS buffer) while the current tile is filtered.  All arithmetic is fp64 with every product and sum rounded separately, in scipy's order
 // (direct form II transposed), so the fp64 result is bit-identical to scipy's for identical input.
 //
@@ -90,21 +92,29 @@ __global__ void __launch_bounds__(256) sos_stats_kernel(SosArgs a, double* __res
   }
 }
 
-// filter `nval` consecutive samples of this lane's series in place in LDS, eight at a time (eight LDS reads in
-// flight, then the dependent recursion, then eight writes); DIR = +1 forward in time, -1 backward
+// filter `nval` consecutive samples of this lane's series in place in LDS, eight at a time; the next eight
+// are read before the current eight are filtered (LDS latency hidden behind the dependent recursion);
+// DIR = +1 forward in time, -1 backward
 template <int NS, int DIR>
 __device__ __forceinline__ double sos_run_tile(double* __restrict__ row, int nval, double (&z)[NS][2],
                                                const double (&c)[NS][5], double ylast) {
   if (nval == SOS_TT) {
+    double cur[8], nxt[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) cur[e] = row[DIR > 0 ? e : SOS_TT - 1 - e];
+#pragma unroll
     for (int q = 0; q < SOS_TT; q += 8) {
-      double v[8];
+      if (q + 8 < SOS_TT) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = row[DIR > 0 ? q + e : SOS_TT - 1 - q - e];
+        for (int e = 0; e < 8; ++e) nxt[e] = row[DIR > 0 ? q + 8 + e : SOS_TT - 1 - q - 8 - e];
+      }
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = sos_step<NS>(v[e], z, c);
+      for (int e = 0; e < 8; ++e) cur[e] = sos_step<NS>(cur[e], z, c);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) row[DIR > 0 ? q + e : SOS_TT - 1 - q - e] = v[e];
-      ylast = v[7];
+      for (int e = 0; e < 8; ++e) row[DIR > 0 ? q + e : SOS_TT - 1 - q - e] = cur[e];
+      ylast = cur[7];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) cur[e] = nxt[e];
     }
   } else {
     for (int n = 0; n < nval; ++n) {
@@ -116,31 +126,36 @@ __device__ __forceinline__ double sos_run_tile(double* __restrict__ row, int nva
   return ylast;
 }
 
-constexpr int SOS_TILE = SOS_TT * SOS_LD;                       // doubles per LDS tile
-constexpr size_t SOS_SMEM_BYTES = sizeof(double) * (2 * SOS_TILE);
+constexpr int SOS_SERIES = 16;  // series per wave (S)
+template <int S>
+constexpr size_t sos_smem_bytes() {
+  return sizeof(double) * 2 * S * SOS_LD;
+}
 
 // Per tile k (both passes): wait for the rows of tile k -> LDS buffer k%2; issue the row stores of tile k-1
 // (other buffer) and then the row loads of tile k+1; run the recursion on tile k.  Every global access thus
 // has a whole tile's recursion to complete before the wave waits on it, and the wait (vmcnt(0)) never covers
 // an operation that was issued just before it.
-template <typename real, int NS>
+template <typename real, int NS, int S>
 __global__ void __launch_bounds__(64) sosfilt_kernel(SosArgs a, const double* __restrict__ stat_g) {
+  constexpr int TILE = S * SOS_LD;  // doubles per LDS tile
   extern __shared__ __attribute__((aligned(16))) double sos_smem[];
-  double* tile = sos_smem;  // [2][SOS_TILE]
+  double* tile = sos_smem;  // [2][TILE]
   const int lane = threadIdx.x;
-  const int s0 = blockIdx.x * 64;
+  const int s0 = blockIdx.x * S;
   const int T = a.T, edge = a.edge, L = T + 2 * edge, N = a.N;
-  const int nrows = (N - s0 < 64) ? N - s0 : 64;  // series handled by this wave
+  const int nrows = (N - s0 < S) ? N - s0 : S;  // series handled by this wave
   const real* __restrict__ xbase = static_cast<const real*>(a.x);
   // series s0 + r starts at xbase + off_r; the offsets advance by ld inside a recording and jump at its end
   const long long off0 = (long long)(s0 / a.m) * a.bstride + (long long)(s0 % a.m) * a.ld;
   const int ch0 = s0 % a.m;
   const long long jump = a.bstride - (long long)a.m * a.ld;
-  // lane r keeps the statistics of series s0 + r: mean, first and last pre-processed sample
+  // lane r < S keeps the statistics of series s0 + r: mean, first and last pre-processed sample
   const int sl = lane < nrows ? lane : nrows - 1;
   const real mean_l = (real)stat_g[3LL * (s0 + sl) + 0];
   const real first_l = (real)stat_g[3LL * (s0 + sl) + 1];
   const real last_l = (real)stat_g[3LL * (s0 + sl) + 2];
+  const bool active = lane < S;  // lanes that own a series in the recursion
 
   double c[NS][5];
 #pragma unroll
@@ -152,9 +167,10 @@ __global__ void __launch_bounds__(64) sosfilt_kernel(SosArgs a, const double* __
     c[s][4] = a.sos[s][5];
   }
   const int ntiles = (L + SOS_TT - 1) / SOS_TT;
+  double* __restrict__ myrow = tile + (active ? lane : 0) * SOS_LD;
 
   // ---- forward pass over the (odd-)extended signal ------------------------------------------------------------
-  real pf[64];
+  real pf[S];
   auto issue_fwd = [&](int k) {  // rows of tile k -> registers (raw samples; reflection applied on the index)
     const int i = k * SOS_TT + lane;
     int j = i - edge;
@@ -162,11 +178,11 @@ __global__ void __launch_bounds__(64) sosfilt_kernel(SosArgs a, const double* __
     if (j >= T) j = 2 * (T - 1) - j;
     j = j < 0 ? 0 : j;  // lanes past the end of the extended signal: any valid address, value unused
     // branch-free on purpose: a load inside a conditional makes hipcc wait for it at the join, which would
-    // serialise the 64 row loads; rows past the last series re-read the last valid row instead
+    // serialise the row loads; rows past the last series re-read the last valid row instead
     long long off = off0;
     int ch = ch0;
 #pragma unroll
-    for (int r = 0; r < 64; ++r) {
+    for (int r = 0; r < S; ++r) {
       pf[r] = xbase[off + j];
       const bool more = r + 1 < nrows;
       long long step = a.ld;
@@ -181,11 +197,11 @@ __global__ void __launch_bounds__(64) sosfilt_kernel(SosArgs a, const double* __
     const bool left = j < 0, ext = left || j >= T;
     if (k * SOS_TT >= edge && k * SOS_TT + SOS_TT <= edge + T) {  // interior tile (wave-uniform): no extension
 #pragma unroll
-      for (int r = 0; r < 64; ++r)
+      for (int r = 0; r < S; ++r)
         buf[r * SOS_LD + lane] = (double)sos_pre<real>(pf[r], lane_bcast(mean_l, r), a.rectify);
     } else {
 #pragma unroll
-      for (int r = 0; r < 64; ++r) {
+      for (int r = 0; r < S; ++r) {
         const real v = sos_pre<real>(pf[r], lane_bcast(mean_l, r), a.rectify);
         const real e0 = lane_bcast(first_l, r), e1 = lane_bcast(last_l, r);
         const real end = left ? e0 : e1;
@@ -197,9 +213,12 @@ __global__ void __launch_bounds__(64) sosfilt_kernel(SosArgs a, const double* __
   auto store_y = [&](const double* __restrict__ buf, int j) {  // LDS rows -> y[series][j] where j is in range
     if (j < 0 || j >= T) return;
     real* __restrict__ yp = static_cast<real*>(a.y) + (long long)s0 * T + j;
-    if (nrows == 64) {
-#pragma unroll 8
-      for (int r = 0; r < 64; ++r) yp[(long long)r * T] = (real)buf[r * SOS_LD + lane];
+    if (nrows == S) {
+      double v[S];
+#pragma unroll
+      for (int r = 0; r < S; ++r) v[r] = buf[r * SOS_LD + lane];
+#pragma unroll
+      for (int r = 0; r < S; ++r) yp[(long long)r * T] = (real)v[r];
     } else {
       for (int r = 0; r < nrows; ++r) yp[(long long)r * T] = (real)buf[r * SOS_LD + lane];
     }
@@ -207,10 +226,13 @@ __global__ void __launch_bounds__(64) sosfilt_kernel(SosArgs a, const double* __
   auto store_fwd = [&](int k, const double* __restrict__ buf) {  // filtered tile k of the forward pass
     const int i = k * SOS_TT + lane;
     if (a.zero_lag) {
-      if (i < L) {  // ws has room for 64 rows per wave: no row guard
+      if (i < L) {  // ws has room for S rows per wave: no row guard
         double* __restrict__ wp = a.ws + (long long)s0 * L + i;
-#pragma unroll 8
-        for (int r = 0; r < 64; ++r) wp[(long long)r * L] = buf[r * SOS_LD + lane];
+        double v[S];
+#pragma unroll
+        for (int r = 0; r < S; ++r) v[r] = buf[r * SOS_LD + lane];
+#pragma unroll
+        for (int r = 0; r < S; ++r) wp[(long long)r * L] = v[r];
       }
     } else {
       store_y(buf, i);
@@ -221,26 +243,29 @@ __global__ void __launch_bounds__(64) sosfilt_kernel(SosArgs a, const double* __
   double ylast = 0.0;
   issue_fwd(0);
   for (int k = 0; k < ntiles; ++k) {
-    double* buf = tile + (k & 1) * SOS_TILE;
+    double* buf = tile + (k & 1) * TILE;
     __syncthreads();
     commit_fwd(k, buf);
     __syncthreads();
-    if (k > 0) store_fwd(k - 1, tile + ((k - 1) & 1) * SOS_TILE);
+    if (k > 0) store_fwd(k - 1, tile + ((k - 1) & 1) * TILE);
     if (k + 1 < ntiles) issue_fwd(k + 1);
     const int t0 = k * SOS_TT;
     const int nval = (L - t0 < SOS_TT) ? L - t0 : SOS_TT;
-    if (k == 0) {  // initial state: zi * ext[0] (sosfiltfilt) or zeros (sosfilt)
-      const double x0 = buf[lane * SOS_LD];
+    if (active) {
+      double* __restrict__ row = myrow + (k & 1) * TILE;
+      if (k == 0) {  // initial state: zi * ext[0] (sosfiltfilt) or zeros (sosfilt)
+        const double x0 = row[0];
 #pragma unroll
-      for (int s = 0; s < NS; ++s) {
-        z[s][0] = a.zero_lag ? a.zi[s][0] * x0 : 0.0;
-        z[s][1] = a.zero_lag ? a.zi[s][1] * x0 : 0.0;
+        for (int s = 0; s < NS; ++s) {
+          z[s][0] = a.zero_lag ? a.zi[s][0] * x0 : 0.0;
+          z[s][1] = a.zero_lag ? a.zi[s][1] * x0 : 0.0;
+        }
       }
+      ylast = sos_run_tile<NS, +1>(row, nval, z, c, ylast);
     }
-    ylast = sos_run_tile<NS, +1>(buf + lane * SOS_LD, nval, z, c, ylast);
   }
   __syncthreads();
-  store_fwd(ntiles - 1, tile + ((ntiles - 1) & 1) * SOS_TILE);
+  store_fwd(ntiles - 1, tile + ((ntiles - 1) & 1) * TILE);
   if (!a.zero_lag) return;
 
   // ---- backward pass: the forward output reversed, initial state zi * y[L-1]; keep the central T samples ------
@@ -250,26 +275,26 @@ __global__ void __launch_bounds__(64) sosfilt_kernel(SosArgs a, const double* __
     z[s][0] = a.zi[s][0] * ylast;
     z[s][1] = a.zi[s][1] * ylast;
   }
-  double pb[64];
+  double pb[S];
   auto issue_bwd = [&](int k) {
     int i = k * SOS_TT + lane;
-    i = i < L ? i : L - 1;  // branch-free (see issue_fwd); ws holds 64 rows for every wave
+    i = i < L ? i : L - 1;  // branch-free (see issue_fwd); ws holds S rows for every wave
     const double* __restrict__ wp = a.ws + (long long)s0 * L + i;
 #pragma unroll
-    for (int r = 0; r < 64; ++r) pb[r] = wp[(long long)r * L];
+    for (int r = 0; r < S; ++r) pb[r] = wp[(long long)r * L];
   };
   issue_bwd(ntiles - 1);
   for (int k = ntiles - 1; k >= 0; --k) {
-    double* buf = tile + (k & 1) * SOS_TILE;
+    double* buf = tile + (k & 1) * TILE;
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 64; ++r) buf[r * SOS_LD + lane] = pb[r];
+    for (int r = 0; r < S; ++r) buf[r * SOS_LD + lane] = pb[r];
     __syncthreads();
-    if (k + 1 < ntiles) store_y(tile + ((k + 1) & 1) * SOS_TILE, (k + 1) * SOS_TT + lane - edge);
+    if (k + 1 < ntiles) store_y(tile + ((k + 1) & 1) * TILE, (k + 1) * SOS_TT + lane - edge);
     if (k > 0) issue_bwd(k - 1);
     const int t0 = k * SOS_TT;
     const int nval = (L - t0 < SOS_TT) ? L - t0 : SOS_TT;
-    sos_run_tile<NS, -1>(buf + lane * SOS_LD, nval, z, c, 0.0);
+    if (active) sos_run_tile<NS, -1>(myrow + (k & 1) * TILE, nval, z, c, 0.0);
   }
   __syncthreads();
   store_y(tile, lane - edge);
