@@ -43,7 +43,9 @@ void steady_state_zi(const double* sos, int ns, double (*zi)[2]) {
 template <typename real, int NS>
 hipError_t launch_ns(const SosArgs& a, const double* stat, hipStream_t st) {
   constexpr int S = SOS_SERIES;
-  hipLaunchKernelGGL((sosfilt_kernel<real, NS, S>), dim3((a.N + S - 1) / S), dim3(64), sos_smem_bytes<S>(), st, a, stat);
+  // at most four of these one-wave workgroups per CU (160 KiB of LDS / 40 KiB)
+  constexpr size_t smem = sos_smem_bytes<S>() > 40960 ? sos_smem_bytes<S>() : 40960;
+  hipLaunchKernelGGL((sosfilt_kernel<real, NS, S>), dim3((a.N + S - 1) / S), dim3(64), smem, st, a, stat);
   return hipSuccess;
 }
 

@@ -8,8 +8,9 @@
 // S series x 64 samples is loaded row by row (64 lanes = 64 consecutive samples of one series), transposed
 // through LDS (row stride 65 doubles: conflict-free both ways), filtered lane-per-series out of LDS, and
 // stored row by row again.  The recursion is bound by the latency of its dependent fp64 chain (about 40 cycles
-// per sample and section), not by lane count, so S = 16 (a quarter of the lanes active in the recursion, four
-// times the waves) is what fills the chip for batches up to ~10^5 series.  The next tile's rows are in flight (registers) and the previous tile's rows are
+// per sample and section), not by lane count; measured on MI355X for 16 384 series (1024 x 16 x
+// 20 000 fp32, order 4, zero-lag): S = 64 (256 waves) 3.8 ms, S = 32 (512 waves) 3.15 ms, S = 16 (1024 waves)
+// 4.1 ms -- with four single-wave workgroups per CU the cost per section doubles, so S = 32 it is.  The next tile's rows are in flight (registers) and the previous tile's rows are
 // being stored (second LDS buffer) while the current tile is filtered.  All arithmetic is fp64 with every product and sum rounded separately, in scipy's order
 // (direct form II transposed), so the fp64 result is bit-identical to scipy's for identical input.
 //
@@ -126,7 +127,7 @@ __device__ __forceinline__ double sos_run_tile(double* __restrict__ row, int nva
   return ylast;
 }
 
-constexpr int SOS_SERIES = 16;  // series per wave (S)
+constexpr int SOS_SERIES = 32;  // series per wave (S)
 template <int S>
 constexpr size_t sos_smem_bytes() {
   return sizeof(double) * 2 * S * SOS_LD;
