@@ -2,8 +2,10 @@
 elvis-sik/muscle_synergies.
 
 Public names mirror the part of the reference's API that sits on the hot path
-(``src/muscle_synergies/__init__.py:5-23``): ``find_synergies``, ``vaf``, ``SynergyRunResult`` -- plus the
-estimator (``HipNMF``) and the batched / multi-GPU entry points the reference does not have.
+(``src/muscle_synergies/__init__.py:5-23``): ``find_synergies``, ``vaf``, ``SynergyRunResult`` and the
+preprocessing functions that build the matrix (``zero_center``, ``rms``, ``linear_envelope``,
+``digital_filter``, ``time_normalize``, ``normalize``) -- plus the estimator (``HipNMF``) and the batched /
+multi-GPU entry points the reference does not have.
 
 Importing this package never loads the HIP library; the first compute call does, and fails loudly if
 ``libhip_nmf.so`` is missing or no GPU is visible (there is no CPU fallback for ``solver='mu'``).
@@ -13,6 +15,8 @@ from .analysis import SynergyRunResult, find_synergies, find_synergies_batched, 
 from .engine import (BatchedResult, RankSweepResult, fit_batched, fit_batched_multi_gpu, fit_ragged,
                      random_init_batched, rank_sweep_batched)
 from .hip_nmf import HipNMF
+from .preprocess import (digital_filter, emg_envelope_batched, linear_envelope, linear_envelope_batched, normalize,
+                         rms, sosfilt_batched, time_normalize, zero_center)
 from ._lib import HipNmfError
 
 __version__ = "0.1.0"
@@ -31,4 +35,14 @@ __all__ = [
     "random_init_batched",
     "RankSweepResult",
     "HipNmfError",
+    # the preprocessing functions of the reference that build the matrix (src/muscle_synergies/__init__.py:11-18)
+    "zero_center",
+    "linear_envelope",
+    "digital_filter",
+    "rms",
+    "normalize",
+    "time_normalize",
+    "emg_envelope_batched",
+    "linear_envelope_batched",
+    "sosfilt_batched",
 ]
