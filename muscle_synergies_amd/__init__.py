@@ -17,6 +17,7 @@ from .engine import (BatchedResult, RankSweepResult, RestartResult, fit_batched,
 from .hip_nmf import HipNMF
 from .preprocess import (digital_filter, emg_envelope_batched, linear_envelope, linear_envelope_batched, normalize,
                          rms, sosfilt_batched, time_normalize, zero_center)
+from .segments import find_synergies_segments, segment_frames
 from ._lib import HipNmfError
 
 __version__ = "0.1.0"
@@ -24,6 +25,8 @@ __version__ = "0.1.0"
 __all__ = [
     "find_synergies",
     "find_synergies_batched",
+    "find_synergies_segments",
+    "segment_frames",
     "vaf",
     "SynergyRunResult",
     "HipNMF",

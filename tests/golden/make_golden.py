@@ -18,6 +18,7 @@ Fixture sets:
   G6  EMG envelope preprocessing (zero_center, rms, time_normalize, normalize) -- row f-1
   G7  Kullback-Leibler loss (beta_loss='kullback-leibler') -- row f-4
   G8  IIR filters: ``digital_filter`` / ``linear_envelope`` (scipy sosfilt / sosfiltfilt) -- row f-1
+  G9  ``DeviceData`` (frame, subframe) -> row indexing of the abridged recording (segment glue) -- row f-3
 """
 
 import json
@@ -389,6 +390,24 @@ def g8():
     print("G8 done")
 
 
+# --------------------------------------------------------------------------- G9
+def g9():
+    """The indexing protocol the segment glue relies on: DeviceData.to_index / __getitem__ on the real loader."""
+    emg = ms.load_vicon_file("/root/reference/sample_data/abridged_data.csv").emg
+    ft = emg._frame_tracker
+    out = {"n_rows": len(emg.df), "num_frames": ft.num_frames, "num_subframes": ft.num_subframes,
+           "sampling_frequency": emg.sampling_frequency, "columns": list(emg.df.columns), "cases": []}
+    for a, b in [((1, 0), (1, 2)), ((1, 1), (2, 1)), ((1, 0), (2, 2)), ((2, 0), (2, 2))]:
+        sl = slice(a, b)
+        rows = emg.to_index(sl)
+        out["cases"].append({"start": list(a), "stop": list(b), "row_start": rows.start, "row_stop": rows.stop,
+                             "values": tolist(emg[sl].to_numpy())})
+    out["emg"] = tolist(emg.df.to_numpy())
+    with open(os.path.join(HERE, "g9_segments.json"), "w") as f:
+        json.dump(out, f)
+    print("G9 done")
+
+
 if __name__ == "__main__":
     g1()
     g2_small()
@@ -399,3 +418,4 @@ if __name__ == "__main__":
     g6()
     g7()
     g8()
+    g9()
