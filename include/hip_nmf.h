@@ -92,7 +92,9 @@ int hipnmf_last_kernel_ms(hipnmf_handle* h, float* ms);
  * stream) by the time-sharded solver so that kernels and RCCL collectives are ordered by the stream alone.
  * Only the shard entry points honour it; hipnmf_fit_batched_* always returns with results ready. */
 int hipnmf_set_async(hipnmf_handle* h, int enable);
-/* Tuning knobs (0 = library default): threads per workgroup (256/512/1024), max row slices per matrix. */
+/* Tuning knobs (0 = library default): threads per workgroup (256/512/1024), max row slices per matrix, and the
+ * solver path: 0 chosen by the library, 1 one persistent workgroup per matrix, 2 row-sliced launches,
+ * 3 cooperative multi-workgroup kernel (few long matrices; HIPNMF_ERR_UNSUPPORTED when not applicable). */
 int hipnmf_set_tuning(hipnmf_handle* h, int threads, int max_slices, int variant);
 
 /* ---- batched fit: replaces NMF(solver='mu').fit_transform / .transform for B matrices ------------- */

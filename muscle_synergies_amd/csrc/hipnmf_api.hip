@@ -213,6 +213,36 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
     }
   }
 
+  // cooperative multi-workgroup fit: few matrices, each long enough to keep several workgroups busy, the slice
+  // of W of every workgroup resident in LDS.  S workgroups per matrix, S * B <= number of CUs (co-residency is
+  // what hipLaunchCooperativeKernel guarantees; it refuses the launch otherwise and the sliced path runs).
+  int coop_S = 0, coop_threads = 0;
+  long long coop_rps = 0;
+  size_t coop_smem = 0;
+  if (!ragged && !kl && ks->fit_coop && h->use_coop && (h->variant == 0 || h->variant == 3) && B <= h->num_cu / 2) {
+    int threads = std::min(h->threads > 0 ? h->threads : 512, ks->max_threads);
+    const long long t_pad = round_up(T, 64);
+    while (threads > 64 && t_pad < 2LL * threads) threads /= 2;  // at least two workgroup-steps of rows in total
+    long long S = std::min<long long>(h->num_cu / B, (t_pad + threads - 1) / threads);
+    if (h->max_slices > 0) S = std::min<long long>(S, h->max_slices);
+    if (S >= 2) {
+      const long long rps = round_up((T + S - 1) / S, threads);
+      S = (T + rps - 1) / rps;
+      const size_t base = (ks->smem_bytes(threads / 64) + 15) / 16 * 16;
+      const size_t smem = base + sizeof(real) * (size_t)k * (size_t)rps;
+      const size_t lds_cap = h->lds_budget > 0 ? (size_t)h->lds_budget : (size_t)h->lds_per_block;
+      if (S >= 2 && smem <= lds_cap) {
+        coop_S = (int)S;
+        coop_threads = threads;
+        coop_rps = rps;
+        coop_smem = smem;
+      }
+    }
+  }
+  if (h->variant == 3 && coop_S == 0)
+    return fail(HIPNMF_ERR_UNSUPPORTED, "cooperative path not applicable (batch=%d, n_samples=%lld)", B, T);
+  const bool coop = coop_S > 0;
+
   // ---- workspace carve-up -----------------------------------------------------------------------
   const size_t o_desc_bytes = ragged ? sizeof(long long) * 4 * (size_t)B : 0;
   const bool x_inplace = ragged || (p->x_layout == HIPNMF_X_CHANNEL_MAJOR && (p->ldx % ks->G) == 0 &&
@@ -231,7 +261,13 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
   const size_t o_w = w_inplace ? 0 : carve(sizeof(real) * (size_t)B * k * ldw_c);
   const size_t o_desc = ragged ? carve(o_desc_bytes) : 0;
   size_t o_part = 0, o_sums = 0, o_col = 0, o_state = 0;
-  if (!persistent) {
+  size_t o_cpart = 0, o_ccol = 0, o_sync = 0;
+  if (coop) {
+    o_cpart = carve(sizeof(real) * (size_t)B * 2 * coop_S * ks->NACC);
+    o_ccol = carve(sizeof(real) * (size_t)B * 2 * coop_S * 2 * ks->MP);
+    o_sync = carve(sizeof(unsigned) * ((size_t)B + 1));
+  }
+  if (!persistent || coop) {
     o_part = carve(sizeof(real) * (size_t)B * sg.S * ks->NACC);
     o_sums = carve(sizeof(real) * (size_t)B * (k * m + k * k));
     o_col = carve(sizeof(real) * (size_t)B * sg.S * 2 * ks->MP);
@@ -293,7 +329,35 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
   a.rows_per_slice = (int)round_up(T, 64);
 
   HIP_TRY(hipEventRecord(h->ev0, st));
-  if (persistent) {
+  bool coop_done = false;
+  if (coop) {
+    SolveArgs<real> c = a;
+    c.S = coop_S;
+    c.rows_per_slice = (int)coop_rps;
+    c.lds_rows = (int)coop_rps;
+    c.part = reinterpret_cast<real*>(ws + o_cpart);
+    c.colpart = reinterpret_cast<real*>(ws + o_ccol);
+    c.sync = reinterpret_cast<unsigned*>(ws + o_sync);
+    HIP_TRY(hipMemsetAsync(c.sync, 0, sizeof(unsigned) * ((size_t)B + 1), st));
+    const void* kern = reinterpret_cast<const void*>(ks->fit_coop);
+    if (coop_smem > 48 * 1024)
+      HIP_TRY(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)coop_smem));
+    void* args[] = {&c};
+    const hipError_t e = hipLaunchCooperativeKernel(kern, dim3(coop_S, B), dim3(coop_threads), args,
+                                                    (unsigned)coop_smem, st);
+    if (e == hipSuccess) {
+      coop_done = true;
+      h->last_path = 3;
+    } else {
+      (void)hipGetLastError();  // not launchable as a cooperative grid on this device: use the regular paths
+      if (h->variant == 3)
+        return fail(HIPNMF_ERR_HIP, "hipLaunchCooperativeKernel failed: %s", hipGetErrorString(e));
+    }
+  }
+  if (coop_done) {
+    // nothing else to enqueue
+  } else if (persistent) {
+    h->last_path = 1;
     int threads = h->threads > 0 ? h->threads : 512;
     threads = std::min(threads, ks->max_threads);
     // a wave covers 64 rows per step: do not launch waves that would never get a row
@@ -317,6 +381,7 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
                                   (int)smem));
     launch<real>(kern, dim3(B), dim3(threads), smem, st, a);
   } else {
+    h->last_path = 2;
     a.S = sg.S;
     a.rows_per_slice = sg.rows_per_slice;
     a.part = reinterpret_cast<real*>(ws + o_part);
@@ -402,6 +467,11 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(st));
   HIP_TRY(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
+  if (coop_done) {  // a barrier that gave up (workgroups not co-resident after all) leaves the abort flag set
+    unsigned aborted = 0;
+    HIP_TRY(hipMemcpy(&aborted, reinterpret_cast<unsigned*>(ws + o_sync) + B, sizeof(unsigned), hipMemcpyDeviceToHost));
+    if (aborted) return fail(HIPNMF_ERR_HIP, "cooperative fit: a grid barrier timed out (results are invalid)");
+  }
   return HIPNMF_OK;
 }
 
@@ -573,6 +643,7 @@ int hipnmf_create(int device, hipnmf_handle** out) {
   if (const char* e = getenv("HIPNMF_LDS_W")) h->use_lds_w = atoi(e) != 0;
   if (const char* e = getenv("HIPNMF_LDS_BUDGET")) h->lds_budget = atoi(e);
   if (const char* e = getenv("HIPNMF_GRAPH")) h->use_graph = atoi(e) != 0;
+  if (const char* e = getenv("HIPNMF_COOP")) h->use_coop = atoi(e) != 0;
   if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
     delete h;
@@ -628,7 +699,7 @@ int hipnmf_set_tuning(hipnmf_handle* h, int threads, int max_slices, int variant
   if (!h) return fail(HIPNMF_ERR_BAD_ARG, "handle is NULL");
   if (threads != 0 && threads != 256 && threads != 512 && threads != 1024)
     return fail(HIPNMF_ERR_BAD_ARG, "threads must be 0, 256, 512 or 1024");
-  if (max_slices < 0 || variant < 0 || variant > 2) return fail(HIPNMF_ERR_BAD_ARG, "bad tuning value");
+  if (max_slices < 0 || variant < 0 || variant > 3) return fail(HIPNMF_ERR_BAD_ARG, "bad tuning value");
   h->threads = threads;
   h->max_slices = max_slices;
   h->variant = variant;

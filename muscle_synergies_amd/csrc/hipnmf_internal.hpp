@@ -16,12 +16,14 @@ struct hipnmf_handle {
   float last_ms = 0.f;
   int threads = 0;     // 0 = default
   int max_slices = 0;  // 0 = default
-  int variant = 0;     // 0 auto, 1 force persistent, 2 force sliced
+  int variant = 0;     // 0 auto, 1 force persistent, 2 force sliced, 3 force cooperative
+  int last_path = 0;   // path the last fit took: 1 persistent, 2 sliced, 3 cooperative
   int num_cu = 256;
   int lds_per_block = 65536;  // hipDeviceProp_t::maxSharedMemoryPerMultiProcessor (160 KiB on MI355X)
   int lds_budget = 0;         // override (bytes), 0 = all of it
   int use_lds_w = 1;
   int use_graph = 1;
+  int use_coop = 1;
   int async_mode = 0;
 };
 

@@ -10,6 +10,7 @@ struct KernelSet {
   using Fn = void (*)(SolveArgs<real>);
   Fn fit_persistent, slice_pass, reduce_slices, hupdate, slice_resid, resid_finalize;
   Fn fit_persistent_kl;  // Kullback-Leibler loss (persistent path only); nullptr where not built
+  Fn fit_coop;           // cooperative multi-workgroup fit of few long matrices (Frobenius); nullptr where not built
   int G, CH, K, MP, NACC, max_threads;
   size_t (*smem_bytes)(int nw);
 };
@@ -22,6 +23,10 @@ KernelSet<real> make_kernel_set() {
     ks.fit_persistent_kl = nullptr;
   else
     ks.fit_persistent_kl = fit_persistent_kernel<real, G, CH, K, 1>;
+  if constexpr (h_in_lds<G, CH>())
+    ks.fit_coop = nullptr;
+  else
+    ks.fit_coop = fit_coop_kernel<real, G, CH, K>;
   ks.slice_pass = slice_pass_kernel<real, G, CH, K>;
   ks.reduce_slices = reduce_slices_kernel<real, G, CH, K>;
   ks.hupdate = hupdate_kernel<real, G, CH, K>;

@@ -238,6 +238,7 @@ struct SolveArgs {
   int T, m, max_iter, check_every, update_h, S, rows_per_slice, it;
   int lds_rows;       // persistent kernel: rows [0, lds_rows) of W live in LDS for the whole fit
   const long long* ragged;  // [B][4] = {T_b, X offset, leading dimension, W offset} (elements) or nullptr
+  unsigned* sync;     // cooperative kernel: [B] arrival counters (zeroed before the launch) followed by one abort flag
   real tol, l1w, l2w, l1h, l2h;
 };
 
@@ -1130,6 +1131,192 @@ __global__ void __launch_bounds__((max_threads<real, G, CH, K>())) HIPNMF_OCC fi
     if (t < T) {
 #pragma unroll
       for (int c = 0; c < K; ++c) Wb[(long long)c * ldw + t] = lds_w[c * lds_stride + t];
+    }
+  }
+}
+
+// =================================================================================================
+// Kernel 1b: cooperative multi-workgroup fit (few matrices, each too long for one workgroup to be fast:
+// BASELINE config #2, one 16 x 10 000 matrix).  grid = (S, B), launched with hipLaunchCooperativeKernel so
+// that all S x B workgroups are co-resident.  Slice s of matrix b owns rows [s*rows_per_slice, ...) for the
+// whole fit: its rows of W never leave LDS, its rows of X stay in L2.  Per iteration: W update + partial
+// sums of the slice -> one record in global memory -> barrier among the S workgroups of the matrix
+// (arrival counter in global memory) -> every workgroup adds the S records in the same fixed order and
+// updates its own copy of H.  One exchange of NACC numbers per workgroup and iteration, no kernel launch.
+// =================================================================================================
+#ifndef HIPNMF_COOP_SPIN_LIMIT
+#define HIPNMF_COOP_SPIN_LIMIT (1u << 22)  // ~1 s of polling before a barrier gives up and raises the abort flag
+#endif
+
+// barrier number `n` (1, 2, ...) among the `S` workgroups that share `counter`; false after an abort
+__device__ __forceinline__ bool coop_barrier(unsigned* counter, unsigned* abort_flag, unsigned S, unsigned n) {
+  __shared__ int ok_sh;
+  __syncthreads();  // every thread's global stores of this phase are complete (s_waitcnt vmcnt(0) + s_barrier)
+  if (threadIdx.x == 0) {
+    int ok = 1;
+    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned target = S * n;
+    unsigned spins = 0;
+    while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(1);
+      if ((++spins & 1023u) == 0) {
+        if (spins > HIPNMF_COOP_SPIN_LIMIT) __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+          ok = 0;
+          break;
+        }
+      }
+    }
+    ok_sh = ok;
+  }
+  __syncthreads();
+  return ok_sh != 0;
+}
+
+// value written by another workgroup before the barrier: read past this CU's L1
+template <typename real>
+__device__ __forceinline__ real coop_load(const real* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <typename real, int G, int CH, int K>
+__global__ void __launch_bounds__((max_threads<real, G, CH, K>())) HIPNMF_OCC fit_coop_kernel(SolveArgs<real> a) {
+  using C = Cfg<real, G, CH, K>;
+  constexpr int MP = C::MP;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int nw = blockDim.x / WAVE;
+  Smem<real, G, CH, K> s(smem_raw, nw);
+  const int b = blockIdx.y, sl = blockIdx.x, S = a.S;
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int wave = threadIdx.x / WAVE;
+  const int g = lane % G;
+  const int m = a.m;
+  const int row_begin = sl * a.rows_per_slice;  // multiple of blockDim.x
+  int T = a.T - row_begin;                      // rows of this slice (slice-local indexing from here on)
+  if (T > a.rows_per_slice) T = a.rows_per_slice;
+  const real* __restrict__ Xb = a.X + (long long)b * a.x_bstride + row_begin;
+  real* __restrict__ Wb = a.W + (long long)b * a.w_bstride + row_begin;
+  real* __restrict__ Hb = a.H + (long long)b * K * m;
+  unsigned* counter = a.sync + b;
+  unsigned* abort_flag = a.sync + gridDim.y;
+  unsigned nbar = 0;
+  const int row_end = ((T + WAVE - 1) / WAVE) * WAVE;
+  // all rows of the slice live in LDS for the whole fit
+  real* lds_w = reinterpret_cast<real*>(smem_raw + ((Smem<real, G, CH, K>::bytes(nw) + 15) / 16) * 16);
+  const int lds_rows = a.lds_rows;  // = rows_per_slice rounded up to a multiple of blockDim.x
+  MatAddr<real, G, CH, K> ma(Xb, a.ldx, Wb, a.ldw, T, m, lds_w, lds_rows);
+  ma.h_lds = s.H;
+  ma.lds_used = lds_rows;
+  for (int t0 = 0; t0 < lds_rows; t0 += blockDim.x) {
+    const int t = t0 + threadIdx.x;
+#pragma unroll
+    for (int c = 0; c < K; ++c) lds_w[c * lds_rows + t] = (t < T) ? Wb[(long long)c * a.ldw + t] : (real)0;
+  }
+  load_h_to_lds(s, Hb, m);
+  __syncthreads();
+  compute_hht(s);
+  __syncthreads();
+  real h[K][CH], hht[K][K];
+  load_h_regs(s, g, h, hht);
+
+  real* __restrict__ gpart = a.part + (long long)b * S * 2 * C::NACC;  // [2][S][NACC], alternating per exchange
+  real* __restrict__ gcol = a.colpart + (long long)b * S * 2 * (2 * MP);  // [2][S][2*MP]
+  unsigned nres = 0;
+  bool alive = true;
+  // ||X - WH||_F^2 per column over all slices -> s.part[0 .. 2*MP) in every workgroup (same order everywhere)
+  auto residual_all = [&]() {
+    block_residual<real, G, CH, K>(s, ma, 0, row_end, h);
+    real* mine = gcol + ((long long)(nres & 1) * S + sl) * (2 * MP);
+    if (threadIdx.x < 2 * MP) mine[threadIdx.x] = s.part[threadIdx.x];
+    alive = coop_barrier(counter, abort_flag, (unsigned)S, ++nbar) && alive;
+    if (threadIdx.x < 2 * MP) {
+      const real* all = gcol + (long long)(nres & 1) * S * (2 * MP) + threadIdx.x;
+      real acc = coop_load(all);
+      for (int q = 1; q < S; ++q) acc += coop_load(all + (long long)q * (2 * MP));
+      s.part[threadIdx.x] = acc;
+    }
+    ++nres;
+    __syncthreads();
+  };
+  auto total_err = [&]() -> real {
+    real tot = (real)0;
+    for (int j = 0; j < MP; ++j) tot += s.part[j];
+    return sqrt_(tot);
+  };
+
+  real err0 = (real)0, prev = (real)0;
+  if (a.tol > (real)0) {
+    residual_all();
+    err0 = total_err();
+    prev = err0;
+    __syncthreads();
+  }
+  int n_iter = 0;
+  RowTile<real, G, CH, K> tiles_lds[PipeDepth<true>::value];
+  prefetch_head<real, G, CH, K, true>(tiles_lds, ma, 0, lds_rows);
+  for (int it = 1; it <= a.max_iter && alive; ++it) {
+    n_iter = it;
+    real accA[K][CH], accB[C::NB];
+#pragma unroll
+    for (int c = 0; c < K; ++c)
+#pragma unroll
+      for (int cc = 0; cc < CH; ++cc) accA[c][cc] = (real)0;
+#pragma unroll
+    for (int i = 0; i < C::NB; ++i) accB[i] = (real)0;
+    rows_update_pass<real, G, CH, K, true, true>(ma, 0, lds_rows, h, hht, accA, accB, a.l1w, a.l2w, a.update_h != 0,
+                                                 tiles_lds);
+    if (it < a.max_iter) prefetch_head<real, G, CH, K, true>(tiles_lds, ma, 0, lds_rows);
+    if (a.update_h) {
+      wave_reduce_acc<real, G, CH, K>(s.part + wave * C::NACC, accA, accB);
+      __syncthreads();
+      real* mine = gpart + ((long long)(it & 1) * S + sl) * C::NACC;
+      for (int i = threadIdx.x; i < C::NACC; i += blockDim.x) {
+        real acc = s.part[i];
+        for (int w = 1; w < nw; ++w) acc += s.part[w * C::NACC + i];
+        mine[i] = acc;
+      }
+      alive = coop_barrier(counter, abort_flag, (unsigned)S, ++nbar) && alive;
+      for (int i = threadIdx.x; i < C::NACC; i += blockDim.x) {
+        const real* all = gpart + (long long)(it & 1) * S * C::NACC + i;
+        real acc = coop_load(all);
+        for (int q = 1; q < S; ++q) acc += coop_load(all + (long long)q * C::NACC);
+        s.part[i] = acc;  // one summed record
+      }
+      __syncthreads();
+      if (wave == 0) wave0_combine_and_update_h(s, 1, m, a.l1h, a.l2h);
+      __syncthreads();
+      load_h_regs(s, g, h, hht);
+    }
+    if (a.tol > (real)0 && (it % a.check_every) == 0) {
+      residual_all();
+      const real err = total_err();
+      __syncthreads();
+      if ((prev - err) / err0 < a.tol) break;
+      prev = err;
+    }
+  }
+  residual_all();
+  if (sl == 0) {
+    if (threadIdx.x == 0) {
+      if (a.err_out) a.err_out[b] = total_err();
+      if (a.n_iter_out) a.n_iter_out[b] = n_iter;
+    }
+    if (threadIdx.x < m) {
+      if (a.sse_col_out) a.sse_col_out[(long long)b * m + threadIdx.x] = s.part[threadIdx.x];
+      if (a.xsq_col_out) a.xsq_col_out[(long long)b * m + threadIdx.x] = s.part[MP + threadIdx.x];
+    }
+    if (a.update_h) {
+      for (int i = threadIdx.x; i < K * MP; i += blockDim.x) {
+        const int c = i / MP, j = i % MP;
+        if (j < m) Hb[c * m + j] = s.H[i];
+      }
+    }
+  }
+  for (int t0 = 0; t0 < lds_rows; t0 += blockDim.x) {  // this slice's rows of W back to global memory
+    const int t = t0 + threadIdx.x;
+    if (t < T) {
+#pragma unroll
+      for (int c = 0; c < K; ++c) Wb[(long long)c * a.ldw + t] = lds_w[c * lds_rows + t];
     }
   }
 }

@@ -356,3 +356,78 @@ def test_multi_restart_best_of_r_matches_single_fits():
     assert torch.equal(again.restart_err, res.restart_err)
     kl = ms.fit_restarts(Xs.astype(np.float32), 2, n_restarts=3, max_iter=30, tol=0.0, beta_loss="kullback-leibler")
     assert bool(torch.isfinite(kl.restart_err).all())
+
+
+@pytest.fixture
+def tuned_handle():
+    from muscle_synergies_amd import _lib
+
+    h = _lib.get_handle(0)
+    yield h
+    h.set_tuning(0, 0, 0)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("B,T,m,k", [(1, 10000, 16, 5), (1, 1001, 8, 3), (3, 5000, 12, 4), (2, 2500, 32, 6), (1, 130, 4, 2),
+                                     (5, 20000, 16, 8), (1, 70000, 16, 5)])
+def test_cooperative_path_matches_oracle_and_persistent(tuned_handle, dtype, B, T, m, k):
+    """Kernel 1b: S workgroups per matrix with a grid barrier per iteration (few long matrices)."""
+    import muscle_synergies_amd as ms
+    from oracle import nmf_mu_oracle as orc
+
+    Xs = np.stack([np.ascontiguousarray(emg_matrix(60 + b, T=T, m=m, k_true=min(5, m), dtype=dtype)) for b in range(B)])
+    inits = [random_init(Xs[b], k, seed=b) for b in range(B)]
+    W0, H0 = np.stack([w for w, _ in inits]), np.stack([h for _, h in inits])
+    tuned_handle.set_tuning(0, 0, 3)
+    got = ms.fit_batched(Xs, W0, H0, max_iter=40, tol=0.0)
+    tuned_handle.set_tuning(0, 0, 1)
+    per = ms.fit_batched(Xs, W0, H0, max_iter=40, tol=0.0)
+    tol = 1e-5 if dtype == np.float32 else 1e-10
+    for b in range(B):
+        xn = np.linalg.norm(Xs[b].astype(np.float64))
+        wh = got.W[b].astype(np.float64) @ got.H[b].astype(np.float64)
+        assert np.linalg.norm(wh - per.W[b].astype(np.float64) @ per.H[b].astype(np.float64)) / xn <= tol
+        if T <= 20000:
+            ref = orc.nmf_mu_fit(Xs[b], W0[b], H0[b], max_iter=40, tol=0.0)
+            assert np.linalg.norm(wh - ref["W"].astype(np.float64) @ ref["H"].astype(np.float64)) / xn <= tol
+            assert abs(float(got.reconstruction_err[b]) - float(ref["reconstruction_err"])) / xn <= tol
+        np.testing.assert_allclose(got.vaf[b], per.vaf[b], atol=1e-5 if dtype == np.float32 else 1e-10)
+        assert int(got.n_iter[b]) == 40
+    # run-to-run determinism: fixed summation order across workgroups
+    tuned_handle.set_tuning(0, 0, 3)
+    again = ms.fit_batched(Xs, W0, H0, max_iter=40, tol=0.0)
+    assert np.array_equal(again.W, got.W) and np.array_equal(again.H, got.H)
+
+
+def test_cooperative_path_stop_rule_transform_and_auto_selection(tuned_handle):
+    import muscle_synergies_amd as ms
+    from muscle_synergies_amd import _lib
+    from oracle import nmf_mu_oracle as orc
+
+    X = np.ascontiguousarray(emg_matrix(5, T=8000, m=16, dtype=np.float64))
+    W0, H0 = random_init(X, 5, seed=1)
+    tuned_handle.set_tuning(0, 0, 3)
+    got = ms.fit_batched(X, W0, H0, max_iter=600, tol=1e-4)
+    ref = orc.nmf_mu_fit(X, W0, H0, max_iter=600, tol=1e-4)
+    assert int(got.n_iter[0]) == ref["n_iter"] and ref["n_iter"] < 600
+    np.testing.assert_allclose(float(got.reconstruction_err[0]), float(ref["reconstruction_err"]), rtol=1e-9)
+    # transform: H fixed
+    tr = ms.fit_batched(X, np.full_like(W0, np.sqrt(X.mean() / 5)), got.H[0], max_iter=50, tol=0.0, update_H=False)
+    Wt = np.full_like(W0, np.sqrt(X.mean() / 5))
+    for _ in range(50):
+        Wt = orc.multiplicative_update_w(X, Wt, got.H[0].copy())
+    np.testing.assert_allclose(tr.W[0], Wt, rtol=1e-9, atol=1e-12)
+    assert np.array_equal(tr.H[0], got.H[0])
+    # regularised fit
+    reg = ms.fit_batched(X, W0, H0, max_iter=30, tol=0.0, l1_reg_W=0.02, l1_reg_H=0.5, l2_reg_W=0.01, l2_reg_H=0.3)
+    W, H, _ = orc.fit_multiplicative_update(X, W0.copy(), H0.copy(), 30, 0.0, 0.02, 0.5, 0.01, 0.3)
+    np.testing.assert_allclose(reg.W[0] @ reg.H[0], W @ H, rtol=1e-8, atol=1e-10)
+    # default selection: one long matrix goes cooperative, a large batch does not need it; where the path does
+    # not apply, forcing it is an error rather than a silent substitution
+    tuned_handle.set_tuning(0, 0, 0)
+    auto = ms.fit_batched(X, W0, H0, max_iter=600, tol=1e-4)
+    assert np.array_equal(auto.W, got.W) and int(auto.n_iter[0]) == ref["n_iter"]
+    tuned_handle.set_tuning(0, 0, 3)
+    Xb = np.stack([X[:640]] * 200)
+    with pytest.raises(_lib.HipNmfError, match="cooperative path not applicable"):
+        ms.fit_batched(Xb, np.stack([W0[:640]] * 200), np.stack([H0] * 200), max_iter=5, tol=0.0)
