@@ -229,7 +229,7 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
       const long long rps = round_up((T + S - 1) / S, threads);
       S = (T + rps - 1) / rps;
       const size_t base = (ks->smem_bytes(threads / 64) + 15) / 16 * 16;
-      const size_t smem = base + sizeof(real) * (size_t)k * (size_t)rps;
+      const size_t smem = base + sizeof(real) * ((size_t)k * (size_t)rps + (size_t)threads);
       const size_t lds_cap = h->lds_budget > 0 ? (size_t)h->lds_budget : (size_t)h->lds_per_block;
       if (S >= 2 && smem <= lds_cap) {
         coop_S = (int)S;

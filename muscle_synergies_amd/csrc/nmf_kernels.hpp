@@ -1170,13 +1170,25 @@ __device__ __forceinline__ bool coop_barrier(unsigned* counter, unsigned* abort_
     ok_sh = ok;
   }
   __syncthreads();
+  // every wave: acquire at agent scope (invalidates this CU's vector L1), so that the plain, pipelined loads
+  // of the other workgroups' records that follow cannot hit lines cached two exchanges ago
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   return ok_sh != 0;
 }
 
-// value written by another workgroup before the barrier: read past this CU's L1
 template <typename real>
-__device__ __forceinline__ real coop_load(const real* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+__device__ __forceinline__ real block_sum_slices(const real* __restrict__ in, long long stride, int S, int nout,
+                                                 real* scratch);
+// out[o] = sum over the S records of in[record][o], o < nout (fixed order; nout may exceed the workgroup size)
+template <typename real>
+__device__ __forceinline__ void coop_sum_records(const real* __restrict__ in, int S, int nout, real* scratch,
+                                                 real* __restrict__ out) {
+  for (int o0 = 0; o0 < nout; o0 += blockDim.x) {
+    const int n = (nout - o0 < (int)blockDim.x) ? nout - o0 : (int)blockDim.x;
+    const real t = block_sum_slices<real>(in + o0, nout, S, n, scratch);
+    if ((int)threadIdx.x < n) out[o0 + threadIdx.x] = t;
+    __syncthreads();
+  }
 }
 
 template <typename real, int G, int CH, int K>
@@ -1204,6 +1216,7 @@ __global__ void __launch_bounds__((max_threads<real, G, CH, K>())) HIPNMF_OCC fi
   // all rows of the slice live in LDS for the whole fit
   real* lds_w = reinterpret_cast<real*>(smem_raw + ((Smem<real, G, CH, K>::bytes(nw) + 15) / 16) * 16);
   const int lds_rows = a.lds_rows;  // = rows_per_slice rounded up to a multiple of blockDim.x
+  real* scratch = lds_w + (long long)K * lds_rows;  // [blockDim.x] for the cross-workgroup sums
   MatAddr<real, G, CH, K> ma(Xb, a.ldx, Wb, a.ldw, T, m, lds_w, lds_rows);
   ma.h_lds = s.H;
   ma.lds_used = lds_rows;
@@ -1229,14 +1242,8 @@ __global__ void __launch_bounds__((max_threads<real, G, CH, K>())) HIPNMF_OCC fi
     real* mine = gcol + ((long long)(nres & 1) * S + sl) * (2 * MP);
     if (threadIdx.x < 2 * MP) mine[threadIdx.x] = s.part[threadIdx.x];
     alive = coop_barrier(counter, abort_flag, (unsigned)S, ++nbar) && alive;
-    if (threadIdx.x < 2 * MP) {
-      const real* all = gcol + (long long)(nres & 1) * S * (2 * MP) + threadIdx.x;
-      real acc = coop_load(all);
-      for (int q = 1; q < S; ++q) acc += coop_load(all + (long long)q * (2 * MP));
-      s.part[threadIdx.x] = acc;
-    }
+    coop_sum_records<real>(gcol + (long long)(nres & 1) * S * (2 * MP), S, 2 * MP, scratch, s.part);
     ++nres;
-    __syncthreads();
   };
   auto total_err = [&]() -> real {
     real tot = (real)0;
@@ -1276,13 +1283,7 @@ __global__ void __launch_bounds__((max_threads<real, G, CH, K>())) HIPNMF_OCC fi
         mine[i] = acc;
       }
       alive = coop_barrier(counter, abort_flag, (unsigned)S, ++nbar) && alive;
-      for (int i = threadIdx.x; i < C::NACC; i += blockDim.x) {
-        const real* all = gpart + (long long)(it & 1) * S * C::NACC + i;
-        real acc = coop_load(all);
-        for (int q = 1; q < S; ++q) acc += coop_load(all + (long long)q * C::NACC);
-        s.part[i] = acc;  // one summed record
-      }
-      __syncthreads();
+      coop_sum_records<real>(gpart + (long long)(it & 1) * S * C::NACC, S, C::NACC, scratch, s.part);  // one record
       if (wave == 0) wave0_combine_and_update_h(s, 1, m, a.l1h, a.l2h);
       __syncthreads();
       load_h_regs(s, g, h, hht);
