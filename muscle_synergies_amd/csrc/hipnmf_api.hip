@@ -187,9 +187,12 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
   else if (h->variant == 2)
     persistent = false;
   else {
+    // per-iteration cost models fitted to tools/config2_bench.py on MI355X (k = 5, m = 16, fp32):
+    // persistent 2.7 ns per row of one matrix, num_cu matrices at a time; sliced 9.5 us of launches +
+    // 0.021 ns per row of the whole batch
     const double waves = (double)((B + h->num_cu - 1) / h->num_cu);
-    const double t_pers = waves * (double)T * 1.2e-9;
-    const double t_sliced = 7e-6 + (double)B * (double)T * 0.025e-9;
+    const double t_pers = waves * ((double)T * 2.7e-9 + 1e-6);
+    const double t_sliced = 9.5e-6 + (double)B * (double)T * 0.021e-9;
     persistent = t_pers <= t_sliced;
   }
   if (!persistent && sg.S == 1 && h->variant != 2) persistent = true;
@@ -219,7 +222,11 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
   int coop_S = 0, coop_threads = 0;
   long long coop_rps = 0;
   size_t coop_smem = 0;
-  if (!ragged && !kl && ks->fit_coop && h->use_coop && (h->variant == 0 || h->variant == 3) && B <= h->num_cu / 2) {
+  // Measured on MI355X (tools/config2_bench.py, profiles/README.md): the barrier among workgroups that sit on
+  // different XCDs costs ~8 us per iteration (device-scope release / acquire = L2 write-back / invalidate, which
+  // also evicts the slice of X from L2), so this path only ties the sliced one for a single 16 x 10 000 matrix
+  // (9.6 vs 9.7 us per iteration) and loses elsewhere: it is opt-in (variant 3 or HIPNMF_COOP=1), never automatic.
+  if (!ragged && !kl && ks->fit_coop && (h->variant == 3 || (h->variant == 0 && h->use_coop)) && B <= h->num_cu / 2) {
     int threads = std::min(h->threads > 0 ? h->threads : 512, ks->max_threads);
     const long long t_pad = round_up(T, 64);
     while (threads > 64 && t_pad < 2LL * threads) threads /= 2;  // at least two workgroup-steps of rows in total
