@@ -274,6 +274,8 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
     o_ccol = carve(sizeof(real) * (size_t)B * 2 * coop_S * 2 * ks->MP);
     o_sync = carve(sizeof(unsigned) * ((size_t)B + 1));
   }
+  size_t o_fsync = 0;
+  if (!persistent) o_fsync = carve(sizeof(unsigned) * (size_t)B);
   if (!persistent || coop) {
     o_part = carve(sizeof(real) * (size_t)B * sg.S * ks->NACC);
     o_sums = carve(sizeof(real) * (size_t)B * (k * m + k * k));
@@ -396,6 +398,10 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
     a.colpart = reinterpret_cast<real*>(ws + o_col);
     const bool stop_rule = p->tol > 0;
     a.state = stop_rule ? reinterpret_cast<real*>(ws + o_state) : nullptr;
+    // one launch per iteration: the last slice of a matrix to finish does the H update (HIPNMF_FUSE_H=0: two launches)
+    a.fuse_h = (h->use_fuse_h && a.update_h && sg.threads >= 256) ? 1 : 0;
+    a.sync = reinterpret_cast<unsigned*>(ws + o_fsync);
+    if (a.fuse_h) HIP_TRY(hipMemsetAsync(a.sync, 0, sizeof(unsigned) * (size_t)B, st));
     const int nt = sg.threads, nw = nt / 64;
     const size_t smem = ks->smem_bytes(nw), smem1 = ks->smem_bytes(1);
     const dim3 grid2(sg.S, B);
@@ -411,7 +417,7 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
     auto enqueue = [&](int n, bool check) {
       for (int i = 0; i < n; ++i) {
         launch<real>(ks->slice_pass, grid2, dim3(nt), smem, st, a);
-        if (a.update_h) launch<real>(ks->hupdate, dim3(B), dim3(1024), smem1, st, a);  // sums the slice records itself
+        if (a.update_h && !a.fuse_h) launch<real>(ks->hupdate, dim3(B), dim3(1024), smem1, st, a);  // sums the records
       }
       if (check) {
         a.it = 1;
@@ -651,6 +657,7 @@ int hipnmf_create(int device, hipnmf_handle** out) {
   if (const char* e = getenv("HIPNMF_LDS_BUDGET")) h->lds_budget = atoi(e);
   if (const char* e = getenv("HIPNMF_GRAPH")) h->use_graph = atoi(e) != 0;
   if (const char* e = getenv("HIPNMF_COOP")) h->use_coop = atoi(e) != 0;
+  if (const char* e = getenv("HIPNMF_FUSE_H")) h->use_fuse_h = atoi(e) != 0;
   if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
     delete h;

@@ -238,7 +238,9 @@ struct SolveArgs {
   int T, m, max_iter, check_every, update_h, S, rows_per_slice, it;
   int lds_rows;       // persistent kernel: rows [0, lds_rows) of W live in LDS for the whole fit
   const long long* ragged;  // [B][4] = {T_b, X offset, leading dimension, W offset} (elements) or nullptr
-  unsigned* sync;     // cooperative kernel: [B] arrival counters (zeroed before the launch) followed by one abort flag
+  unsigned* sync;     // cooperative kernel: [B] arrival counters (zeroed before the launch) followed by one abort flag;
+                      // sliced path with fuse_h: [B] arrival counters (the last slice to finish updates H)
+  int fuse_h;         // slice_pass_kernel: 1 = the last workgroup of a matrix sums the records and updates H itself
   real tol, l1w, l2w, l1h, l2h;
 };
 
@@ -1371,6 +1373,45 @@ __global__ void __launch_bounds__((max_threads<real, G, CH, K>())) HIPNMF_OCC sl
     real acc = s.part[i];
     for (int w = 1; w < nw; ++w) acc += s.part[w * C::NACC + i];
     out[i] = acc;
+  }
+  if (!a.fuse_h) return;
+  // Single-GPU sliced path: one launch per iteration.  The workgroup that arrives last at the matrix's counter
+  // owns the H update (the classic "last block" reduction: release fence, ticket, acquire fence); the records
+  // are still added in slice order, so the result does not depend on which workgroup that is.
+  __shared__ int is_last;
+  __shared__ real scratch[HIPNMF_MAXNT];
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned ticket = __hip_atomic_fetch_add(a.sync + b, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    is_last = ticket == (unsigned)a.S - 1u;
+    if (is_last) __hip_atomic_store(a.sync + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch
+  }
+  __syncthreads();
+  if (!is_last) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  coop_sum_records<real>(a.part + (long long)b * a.S * C::NACC, a.S, C::NACC, scratch, s.part);
+  for (int i = threadIdx.x; i < C::NACC; i += blockDim.x) {
+    const real acc = s.part[i];
+    if (i < K * C::MP) {
+      s.A[i] = acc;
+    } else {
+      int idx = i - K * C::MP, c = 0;
+      while (idx >= K - c) {
+        idx -= K - c;
+        ++c;
+      }
+      const int c2 = c + idx;
+      s.B[c * K + c2] = acc;
+      s.B[c2 * K + c] = acc;
+    }
+  }
+  __syncthreads();
+  h_update_lds(s, a.m, a.l1h, a.l2h);  // s.H still holds the H this launch started from
+  real* __restrict__ Hout = a.H + (long long)b * K * a.m;
+  for (int i = threadIdx.x; i < K * C::MP; i += blockDim.x) {
+    const int c = i / C::MP, j = i % C::MP;
+    if (j < a.m) Hout[c * a.m + j] = s.H[i];
   }
 }
 
