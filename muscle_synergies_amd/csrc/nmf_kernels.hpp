@@ -1156,10 +1156,14 @@ __device__ __forceinline__ bool coop_barrier(unsigned* counter, unsigned* abort_
   __syncthreads();  // every thread's global stores of this phase are complete (s_waitcnt vmcnt(0) + s_barrier)
   if (threadIdx.x == 0) {
     int ok = 1;
-    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    // No release / acquire fences: on a multi-XCD part they mean an L2 write-back / invalidate per barrier
+    // (measured ~8 us).  The records exchanged around the barrier are written and read with device-scope
+    // relaxed atomics (straight to / from the coherence point), the __syncthreads above has waited for those
+    // stores to be acknowledged, and the counter itself is only ever touched atomically.
+    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned target = S * n;
     unsigned spins = 0;
-    while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
       __builtin_amdgcn_s_sleep(1);
       if ((++spins & 1023u) == 0) {
         if (spins > HIPNMF_COOP_SPIN_LIMIT) __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1172,15 +1176,56 @@ __device__ __forceinline__ bool coop_barrier(unsigned* counter, unsigned* abort_
     ok_sh = ok;
   }
   __syncthreads();
-  // every wave: acquire at agent scope (invalidates this CU's vector L1), so that the plain, pipelined loads
-  // of the other workgroups' records that follow cannot hit lines cached two exchanges ago
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   return ok_sh != 0;
+}
+
+// record exchanged between workgroups: device-scope relaxed atomic store / load (no cache holds a stale copy)
+template <typename real>
+__device__ __forceinline__ void coop_store(real* p, real v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <typename real>
+__device__ __forceinline__ real coop_load(const real* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 template <typename real>
 __device__ __forceinline__ real block_sum_slices(const real* __restrict__ in, long long stride, int S, int nout,
                                                  real* scratch);
+// the same with device-scope atomic loads, four records in flight per thread (cooperative kernel)
+template <typename real>
+__device__ __forceinline__ void coop_sum_records_atomic(const real* __restrict__ in, int S, int nout, real* scratch,
+                                                        real* __restrict__ out) {
+  for (int o0 = 0; o0 < nout; o0 += blockDim.x) {
+    const int n = (nout - o0 < (int)blockDim.x) ? nout - o0 : (int)blockDim.x;
+    const int nq = (int)blockDim.x / n > 0 ? (int)blockDim.x / n : 1;
+    const int o = threadIdx.x % n, q = threadIdx.x / n;
+    real acc = (real)0;
+    if (q < nq) {
+      const real* p = in + o0 + o;
+      int sl = q;
+      for (; sl + 3 * nq < S; sl += 4 * nq) {
+        const real v0 = coop_load(p + (long long)sl * nout), v1 = coop_load(p + (long long)(sl + nq) * nout);
+        const real v2 = coop_load(p + (long long)(sl + 2 * nq) * nout), v3 = coop_load(p + (long long)(sl + 3 * nq) * nout);
+        acc += v0;
+        acc += v1;
+        acc += v2;
+        acc += v3;
+      }
+      for (; sl < S; sl += nq) acc += coop_load(p + (long long)sl * nout);
+    }
+    __syncthreads();
+    if (q < nq) scratch[q * n + o] = acc;
+    __syncthreads();
+    if ((int)threadIdx.x < n) {
+      real tot = (real)0;
+      for (int i = 0; i < nq; ++i) tot += scratch[i * n + threadIdx.x];
+      out[o0 + threadIdx.x] = tot;
+    }
+    __syncthreads();
+  }
+}
+
 // out[o] = sum over the S records of in[record][o], o < nout (fixed order; nout may exceed the workgroup size)
 template <typename real>
 __device__ __forceinline__ void coop_sum_records(const real* __restrict__ in, int S, int nout, real* scratch,
@@ -1242,9 +1287,9 @@ __global__ void __launch_bounds__((max_threads<real, G, CH, K>())) HIPNMF_OCC fi
   auto residual_all = [&]() {
     block_residual<real, G, CH, K>(s, ma, 0, row_end, h);
     real* mine = gcol + ((long long)(nres & 1) * S + sl) * (2 * MP);
-    if (threadIdx.x < 2 * MP) mine[threadIdx.x] = s.part[threadIdx.x];
+    if (threadIdx.x < 2 * MP) coop_store(mine + threadIdx.x, s.part[threadIdx.x]);
     alive = coop_barrier(counter, abort_flag, (unsigned)S, ++nbar) && alive;
-    coop_sum_records<real>(gcol + (long long)(nres & 1) * S * (2 * MP), S, 2 * MP, scratch, s.part);
+    coop_sum_records_atomic<real>(gcol + (long long)(nres & 1) * S * (2 * MP), S, 2 * MP, scratch, s.part);
     ++nres;
   };
   auto total_err = [&]() -> real {
@@ -1282,10 +1327,10 @@ __global__ void __launch_bounds__((max_threads<real, G, CH, K>())) HIPNMF_OCC fi
       for (int i = threadIdx.x; i < C::NACC; i += blockDim.x) {
         real acc = s.part[i];
         for (int w = 1; w < nw; ++w) acc += s.part[w * C::NACC + i];
-        mine[i] = acc;
+        coop_store(mine + i, acc);
       }
       alive = coop_barrier(counter, abort_flag, (unsigned)S, ++nbar) && alive;
-      coop_sum_records<real>(gpart + (long long)(it & 1) * S * C::NACC, S, C::NACC, scratch, s.part);  // one record
+      coop_sum_records_atomic<real>(gpart + (long long)(it & 1) * S * C::NACC, S, C::NACC, scratch, s.part);  // one record
       if (wave == 0) wave0_combine_and_update_h(s, 1, m, a.l1h, a.l2h);
       __syncthreads();
       load_h_regs(s, g, h, hht);
