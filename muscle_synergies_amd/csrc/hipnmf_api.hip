@@ -181,20 +181,19 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
   // persistent: one workgroup per matrix, ~1.2 ns per row-iteration per workgroup, num_cu in flight;
   // sliced: ~3 launches (~7 us) per iteration, rows spread over the whole chip.
   SliceGeom sg = slice_geometry(h, T, B);
+  // per-iteration cost models fitted to tools/config2_bench.py on MI355X (k = 5, m = 16, fp32):
+  // persistent 2.7 ns per row of one matrix, num_cu matrices at a time; sliced 9.5 us of launches +
+  // 0.021 ns per row of the whole batch; cooperative (further down) 5.5 us + 2.4 us per workgroup-step of rows
+  const double waves = (double)((B + h->num_cu - 1) / h->num_cu);
+  const double t_pers = waves * ((double)T * 2.7e-9 + 1e-6);
+  const double t_sliced = 9.5e-6 + (double)B * (double)T * 0.021e-9;
   bool persistent;
   if (h->variant == 1)
     persistent = true;
   else if (h->variant == 2)
     persistent = false;
-  else {
-    // per-iteration cost models fitted to tools/config2_bench.py on MI355X (k = 5, m = 16, fp32):
-    // persistent 2.7 ns per row of one matrix, num_cu matrices at a time; sliced 9.5 us of launches +
-    // 0.021 ns per row of the whole batch
-    const double waves = (double)((B + h->num_cu - 1) / h->num_cu);
-    const double t_pers = waves * ((double)T * 2.7e-9 + 1e-6);
-    const double t_sliced = 9.5e-6 + (double)B * (double)T * 0.021e-9;
+  else
     persistent = t_pers <= t_sliced;
-  }
   if (!persistent && sg.S == 1 && h->variant != 2) persistent = true;
   const bool kl = p->loss == HIPNMF_LOSS_KL;
   if (kl) {
@@ -222,10 +221,10 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
   int coop_S = 0, coop_threads = 0;
   long long coop_rps = 0;
   size_t coop_smem = 0;
-  // Measured on MI355X (tools/config2_bench.py, profiles/README.md): the barrier among workgroups that sit on
-  // different XCDs costs ~8 us per iteration (device-scope release / acquire = L2 write-back / invalidate, which
-  // also evicts the slice of X from L2), so this path only ties the sliced one for a single 16 x 10 000 matrix
-  // (9.6 vs 9.7 us per iteration) and loses elsewhere: it is opt-in (variant 3 or HIPNMF_COOP=1), never automatic.
+  // Measured on MI355X (tools/config2_bench.py, profiles/README.md): with release / acquire fences the barrier
+  // costs ~8 us (L2 write-back / invalidate on a multi-XCD part); with the fence-free exchange the kernel uses
+  // (device-scope relaxed atomics for the records and the counter) an iteration of one 16 x 10 000 matrix takes
+  // 7.1 us against 10.2 us for the sliced path and 27 us for one persistent workgroup.
   if (!ragged && !kl && ks->fit_coop && (h->variant == 3 || (h->variant == 0 && h->use_coop)) && B <= h->num_cu / 2) {
     int threads = std::min(h->threads > 0 ? h->threads : 512, ks->max_threads);
     const long long t_pad = round_up(T, 64);
@@ -238,7 +237,9 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
       const size_t base = (ks->smem_bytes(threads / 64) + 15) / 16 * 16;
       const size_t smem = base + sizeof(real) * ((size_t)k * (size_t)rps + (size_t)threads);
       const size_t lds_cap = h->lds_budget > 0 ? (size_t)h->lds_budget : (size_t)h->lds_per_block;
-      if (S >= 2 && smem <= lds_cap) {
+      const double t_coop = 5.5e-6 + 2.4e-6 * (double)(rps / threads) + 0.022e-6 * (double)S;
+      const bool wins = h->variant == 3 || t_coop < std::min(t_pers, t_sliced);
+      if (S >= 2 && smem <= lds_cap && wins) {
         coop_S = (int)S;
         coop_threads = threads;
         coop_rps = rps;

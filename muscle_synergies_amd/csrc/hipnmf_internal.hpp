@@ -25,7 +25,7 @@ struct hipnmf_handle {
   int use_graph = 1;
   int use_fuse_h = 0;  // HIPNMF_FUSE_H=1: sliced path, H update by the last slice of the pass (one launch per
                        // iteration; measured slower: every workgroup's release fence writes its XCD's L2 back)
-  int use_coop = 0;    // HIPNMF_COOP=1: let the library pick the cooperative kernel where it applies
+  int use_coop = 1;    // HIPNMF_COOP=0: never pick the cooperative kernel automatically
   int async_mode = 0;
 };
 

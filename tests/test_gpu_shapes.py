@@ -422,12 +422,16 @@ def test_cooperative_path_stop_rule_transform_and_auto_selection(tuned_handle):
     reg = ms.fit_batched(X, W0, H0, max_iter=30, tol=0.0, l1_reg_W=0.02, l1_reg_H=0.5, l2_reg_W=0.01, l2_reg_H=0.3)
     W, H, _ = orc.fit_multiplicative_update(X, W0.copy(), H0.copy(), 30, 0.0, 0.02, 0.5, 0.01, 0.3)
     np.testing.assert_allclose(reg.W[0] @ reg.H[0], W @ H, rtol=1e-8, atol=1e-10)
-    # the library's own choice (row-sliced launches for this shape) lands on the same answer; where the
-    # cooperative path does not apply, forcing it is an error rather than a silent substitution
+    # the library's own choice for one long matrix is this path (bitwise the same answer); the row-sliced
+    # launches land on it too; where the cooperative path does not apply, forcing it is an error rather than a
+    # silent substitution
     tuned_handle.set_tuning(0, 0, 0)
     auto = ms.fit_batched(X, W0, H0, max_iter=600, tol=1e-4)
-    np.testing.assert_allclose(auto.W, got.W, rtol=1e-7, atol=1e-10)
-    assert int(auto.n_iter[0]) == ref["n_iter"]
+    assert np.array_equal(auto.W, got.W) and int(auto.n_iter[0]) == ref["n_iter"]
+    tuned_handle.set_tuning(0, 0, 2)
+    sliced = ms.fit_batched(X, W0, H0, max_iter=600, tol=1e-4)
+    np.testing.assert_allclose(sliced.W, got.W, rtol=1e-7, atol=1e-10)
+    assert int(sliced.n_iter[0]) == ref["n_iter"]
     tuned_handle.set_tuning(0, 0, 3)
     Xb = np.stack([X[:640]] * 200)
     with pytest.raises(_lib.HipNmfError, match="cooperative path not applicable"):
