@@ -219,7 +219,7 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
   // of W of every workgroup resident in LDS.  S workgroups per matrix, S * B <= number of CUs (co-residency is
   // what hipLaunchCooperativeKernel guarantees; it refuses the launch otherwise and the sliced path runs).
   int coop_S = 0, coop_threads = 0;
-  long long coop_rps = 0;
+  long long coop_rps = 0, coop_lds_rows = 0;
   size_t coop_smem = 0;
   // Measured on MI355X (tools/config2_bench.py, profiles/README.md): with release / acquire fences the barrier
   // costs ~8 us (L2 write-back / invalidate on a multi-XCD part); with the fence-free exchange the kernel uses
@@ -234,15 +234,19 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
     if (S >= 2) {
       const long long rps = round_up((T + S - 1) / S, threads);
       S = (T + rps - 1) / rps;
-      const size_t base = (ks->smem_bytes(threads / 64) + 15) / 16 * 16;
-      const size_t smem = base + sizeof(real) * ((size_t)k * (size_t)rps + (size_t)threads);
+      const size_t base = (ks->smem_bytes(threads / 64) + 15) / 16 * 16 + sizeof(real) * (size_t)threads;
       const size_t lds_cap = h->lds_budget > 0 ? (size_t)h->lds_budget : (size_t)h->lds_per_block;
+      // as many whole workgroup-steps of the slice's W as fit in LDS; the rest streams from global memory
+      long long lds_rows = lds_cap > base ? (long long)((lds_cap - base) / (sizeof(real) * (size_t)k)) / threads * threads : 0;
+      lds_rows = std::min(lds_rows, rps);
+      const size_t smem = base + sizeof(real) * (size_t)k * (size_t)lds_rows;
       const double t_coop = 5.5e-6 + 2.4e-6 * (double)(rps / threads) + 0.022e-6 * (double)S;
       const bool wins = h->variant == 3 || t_coop < std::min(t_pers, t_sliced);
-      if (S >= 2 && smem <= lds_cap && wins) {
+      if (S >= 2 && lds_rows >= threads && wins) {
         coop_S = (int)S;
         coop_threads = threads;
         coop_rps = rps;
+        coop_lds_rows = lds_rows;
         coop_smem = smem;
       }
     }
@@ -344,7 +348,7 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
     SolveArgs<real> c = a;
     c.S = coop_S;
     c.rows_per_slice = (int)coop_rps;
-    c.lds_rows = (int)coop_rps;
+    c.lds_rows = (int)coop_lds_rows;
     c.part = reinterpret_cast<real*>(ws + o_cpart);
     c.colpart = reinterpret_cast<real*>(ws + o_ccol);
     c.sync = reinterpret_cast<unsigned*>(ws + o_sync);

@@ -1260,17 +1260,19 @@ __global__ void __launch_bounds__((max_threads<real, G, CH, K>())) HIPNMF_OCC fi
   unsigned* abort_flag = a.sync + gridDim.y;
   unsigned nbar = 0;
   const int row_end = ((T + WAVE - 1) / WAVE) * WAVE;
-  // all rows of the slice live in LDS for the whole fit
+  // rows [0, lds_rows) of the slice live in LDS for the whole fit (all of them when the slice fits), the rest
+  // of W streams from global memory as in the persistent kernel
   real* lds_w = reinterpret_cast<real*>(smem_raw + ((Smem<real, G, CH, K>::bytes(nw) + 15) / 16) * 16);
-  const int lds_rows = a.lds_rows;  // = rows_per_slice rounded up to a multiple of blockDim.x
-  real* scratch = lds_w + (long long)K * lds_rows;  // [blockDim.x] for the cross-workgroup sums
-  MatAddr<real, G, CH, K> ma(Xb, a.ldx, Wb, a.ldw, T, m, lds_w, lds_rows);
+  const int lds_rows = a.lds_rows < row_end ? a.lds_rows : ((row_end + (int)blockDim.x - 1) / (int)blockDim.x) * (int)blockDim.x;
+  real* scratch = lds_w + (long long)K * a.lds_rows;  // [blockDim.x] for the cross-workgroup sums
+  const int lds_stride = a.lds_rows;
+  MatAddr<real, G, CH, K> ma(Xb, a.ldx, Wb, a.ldw, T, m, lds_w, lds_stride);
   ma.h_lds = s.H;
   ma.lds_used = lds_rows;
   for (int t0 = 0; t0 < lds_rows; t0 += blockDim.x) {
     const int t = t0 + threadIdx.x;
 #pragma unroll
-    for (int c = 0; c < K; ++c) lds_w[c * lds_rows + t] = (t < T) ? Wb[(long long)c * a.ldw + t] : (real)0;
+    for (int c = 0; c < K; ++c) lds_w[c * lds_stride + t] = (t < T) ? Wb[(long long)c * a.ldw + t] : (real)0;
   }
   load_h_to_lds(s, Hb, m);
   __syncthreads();
@@ -1319,6 +1321,11 @@ __global__ void __launch_bounds__((max_threads<real, G, CH, K>())) HIPNMF_OCC fi
     for (int i = 0; i < C::NB; ++i) accB[i] = (real)0;
     rows_update_pass<real, G, CH, K, true, true>(ma, 0, lds_rows, h, hht, accA, accB, a.l1w, a.l2w, a.update_h != 0,
                                                  tiles_lds);
+    if (lds_rows < row_end) {
+      RowTile<real, G, CH, K> tiles_glb[PipeDepth<false>::value];
+      rows_update_pass<real, G, CH, K, false, false>(ma, lds_rows, row_end, h, hht, accA, accB, a.l1w, a.l2w,
+                                                     a.update_h != 0, tiles_glb);
+    }
     if (it < a.max_iter) prefetch_head<real, G, CH, K, true>(tiles_lds, ma, 0, lds_rows);
     if (a.update_h) {
       wave_reduce_acc<real, G, CH, K>(s.part + wave * C::NACC, accA, accB);
@@ -1364,7 +1371,7 @@ __global__ void __launch_bounds__((max_threads<real, G, CH, K>())) HIPNMF_OCC fi
     const int t = t0 + threadIdx.x;
     if (t < T) {
 #pragma unroll
-      for (int c = 0; c < K; ++c) Wb[(long long)c * a.ldw + t] = lds_w[c * lds_rows + t];
+      for (int c = 0; c < K; ++c) Wb[(long long)c * a.ldw + t] = lds_w[c * lds_stride + t];
     }
   }
 }

@@ -436,3 +436,26 @@ def test_cooperative_path_stop_rule_transform_and_auto_selection(tuned_handle):
     Xb = np.stack([X[:640]] * 200)
     with pytest.raises(_lib.HipNmfError, match="cooperative path not applicable"):
         ms.fit_batched(Xb, np.stack([W0[:640]] * 200), np.stack([H0] * 200), max_iter=5, tol=0.0)
+
+
+def test_cooperative_path_with_slices_larger_than_lds(tuned_handle):
+    """One very long matrix: the slice of a workgroup exceeds LDS, part of its W streams from global memory."""
+    import muscle_synergies_amd as ms
+
+    T = 3_000_000
+    X = np.ascontiguousarray(emg_matrix(9, T=T, m=8, k_true=3, dtype=np.float64))
+    W0, H0 = random_init(X, 5, seed=2)
+    tuned_handle.set_tuning(0, 0, 3)
+    got = ms.fit_batched(X, W0, H0, max_iter=12, tol=0.0)
+    tuned_handle.set_tuning(0, 0, 2)
+    ref = ms.fit_batched(X, W0, H0, max_iter=12, tol=0.0)
+    np.testing.assert_allclose(got.H[0], ref.H[0], rtol=1e-9)
+    np.testing.assert_allclose(got.W[0][::997], ref.W[0][::997], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(float(got.reconstruction_err[0]), float(ref.reconstruction_err[0]), rtol=1e-10)
+    # and a fully reduced check of the last rows (tail of the last slice) against the update rule itself
+    from oracle import nmf_mu_oracle as orc
+
+    tail = slice(T - 1000, T)
+    Wt = orc.multiplicative_update_w(X[tail], ref.W[0][tail].copy(), ref.H[0].copy())
+    one_more = ms.fit_batched(X, ref.W[0], ref.H[0], max_iter=1, tol=0.0, update_H=False)
+    np.testing.assert_allclose(one_more.W[0][tail], Wt, rtol=1e-9, atol=1e-12)
