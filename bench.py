@@ -222,7 +222,7 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
-                "kernel": "fit_persistent_kernel<float,4,4,5>",
+                "kernel": "fit_persistent_kernel<float,4,4,5,0>",
                 "kernel_ms_avg": avg_ms,
                 "algorithmic_bytes_per_unit": bytes_per_unit,
                 "units_per_launch": a.batch * a.iters,
