@@ -145,10 +145,10 @@ struct SliceGeom {
 
 SliceGeom slice_geometry(const hipnmf_handle* h, long long T, int B) {
   SliceGeom g;
-  g.threads = 256;
+  g.threads = (h->threads == 512 && h->slice_threads_ok512) ? 512 : 256;
   const long long quantum = g.threads;  // 64 rows per wave-step x waves
   const long long t_pad = round_up(T, 64);
-  const long long target_wgs = 4LL * h->num_cu;
+  const long long target_wgs = h->max_slices > 0 ? (long long)h->max_slices : 4LL * h->num_cu;
   long long rps = round_up(std::max<long long>(2 * quantum, (t_pad * B + target_wgs - 1) / target_wgs), quantum);
   long long S = (t_pad + rps - 1) / rps;
   const long long cap = h->max_slices > 0 ? h->max_slices : 4096;
@@ -663,6 +663,7 @@ int hipnmf_create(int device, hipnmf_handle** out) {
   if (const char* e = getenv("HIPNMF_GRAPH")) h->use_graph = atoi(e) != 0;
   if (const char* e = getenv("HIPNMF_COOP")) h->use_coop = atoi(e) != 0;
   if (const char* e = getenv("HIPNMF_FUSE_H")) h->use_fuse_h = atoi(e) != 0;
+  if (const char* e = getenv("HIPNMF_SLICE512")) h->slice_threads_ok512 = atoi(e) != 0;
   if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
     delete h;

@@ -25,6 +25,7 @@ struct hipnmf_handle {
   int use_graph = 1;
   int use_fuse_h = 0;  // HIPNMF_FUSE_H=1: sliced path, H update by the last slice of the pass (one launch per
                        // iteration; measured slower: every workgroup's release fence writes its XCD's L2 back)
+  int slice_threads_ok512 = 0;  // experiment: let hipnmf_set_tuning(threads=512) also apply to the sliced kernels
   int use_coop = 1;    // HIPNMF_COOP=0: never pick the cooperative kernel automatically
   int async_mode = 0;
 };
