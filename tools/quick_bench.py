@@ -15,8 +15,11 @@ ap.add_argument("--threads", type=int, nargs="*", default=[256, 512])
 ap.add_argument("--variant", type=int, default=0)
 ap.add_argument("--reps", type=int, default=2)
 ap.add_argument("--loss", default="frobenius")
+ap.add_argument("--dtype", default="float32")
 a = ap.parse_args()
 X, W0, H0 = emg_batch_torch(a.batch, T=a.T, device="cuda:0")
+if a.dtype == "float64":
+    X, W0, H0 = X.double(), W0.double(), H0.double()
 Xv = X.transpose(1, 2)  # [B, T, m] view of channel-major storage
 h = _lib.get_handle(0)
 for nt in a.threads:
@@ -27,5 +30,5 @@ for nt in a.threads:
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         its = a.batch * a.iters / (r.kernel_ms * 1e-3)
-        gbs = its * 4 * a.T * 26 / 1e9
+        gbs = its * X.element_size() * a.T * 26 / 1e9
         print(f"threads={nt} rep={rep} wall={dt*1e3:.1f} ms kernel={r.kernel_ms:.1f} ms  {its/1e6:.3f} M matrix-it/s  {gbs:.0f} GB/s algorithmic  err0={float(r.reconstruction_err[0]):.4f}", flush=True)
