@@ -1421,28 +1421,35 @@ __global__ void __launch_bounds__((max_threads<real, G, CH, K>())) HIPNMF_OCC sl
   wave_reduce_acc<real, G, CH, K>(s.part + wave * C::NACC, accA, accB);
   __syncthreads();
   real* __restrict__ out = a.part + ((long long)b * a.S + sl) * C::NACC;
+  if (!a.fuse_h) {
+    for (int i = threadIdx.x; i < C::NACC; i += blockDim.x) {
+      real acc = s.part[i];
+      for (int w = 1; w < nw; ++w) acc += s.part[w * C::NACC + i];
+      out[i] = acc;
+    }
+    return;
+  }
+  // Single-GPU sliced path: one launch per iteration.  The workgroup that arrives last at the matrix's counter
+  // owns the H update ("last block" reduction).  As in the cooperative kernel the exchange is fence-free: the
+  // records travel as device-scope relaxed atomics and the ticket is an atomic, so no workgroup has to write
+  // its XCD's L2 (full of freshly updated W) back just to publish 95 numbers.  The records are still added in
+  // slice order, so the result does not depend on which workgroup happens to be last.
   for (int i = threadIdx.x; i < C::NACC; i += blockDim.x) {
     real acc = s.part[i];
     for (int w = 1; w < nw; ++w) acc += s.part[w * C::NACC + i];
-    out[i] = acc;
+    coop_store(out + i, acc);
   }
-  if (!a.fuse_h) return;
-  // Single-GPU sliced path: one launch per iteration.  The workgroup that arrives last at the matrix's counter
-  // owns the H update (the classic "last block" reduction: release fence, ticket, acquire fence); the records
-  // are still added in slice order, so the result does not depend on which workgroup that is.
   __shared__ int is_last;
   __shared__ real scratch[HIPNMF_MAXNT];
-  __threadfence();
-  __syncthreads();
+  __syncthreads();  // the record's stores are acknowledged
   if (threadIdx.x == 0) {
-    const unsigned ticket = __hip_atomic_fetch_add(a.sync + b, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned ticket = __hip_atomic_fetch_add(a.sync + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     is_last = ticket == (unsigned)a.S - 1u;
     if (is_last) __hip_atomic_store(a.sync + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch
   }
   __syncthreads();
   if (!is_last) return;
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  coop_sum_records<real>(a.part + (long long)b * a.S * C::NACC, a.S, C::NACC, scratch, s.part);
+  coop_sum_records_atomic<real>(a.part + (long long)b * a.S * C::NACC, a.S, C::NACC, scratch, s.part);
   for (int i = threadIdx.x; i < C::NACC; i += blockDim.x) {
     const real acc = s.part[i];
     if (i < K * C::MP) {
