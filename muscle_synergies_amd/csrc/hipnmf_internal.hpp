@@ -24,7 +24,9 @@ struct hipnmf_handle {
   int use_lds_w = 1;
   int use_graph = 1;
   int use_fuse_h = 0;  // HIPNMF_FUSE_H=1: sliced path, H update by the last slice of the pass (one launch per
-                       // iteration; measured slower: every workgroup's release fence writes its XCD's L2 back)
+                       // iteration).  Measured: with release/acquire fences 12.6 us per iteration (every workgroup
+                       // writes its XCD's L2 back), fence-free 9.5 us vs 10.2 us for two launches on one 16 x 10 000
+                       // matrix but slower for many slices (60.7 vs 50.6 us at T = 1e6): off by default
   int slice_threads_ok512 = 0;  // experiment: let hipnmf_set_tuning(threads=512) also apply to the sliced kernels
   int use_coop = 1;    // HIPNMF_COOP=0: never pick the cooperative kernel automatically
   int async_mode = 0;
