@@ -16,6 +16,16 @@
 //     for its own channels; W^T W is accumulated row-per-lane (upper triangle);
 //   * the T-long reductions finish with a butterfly over the wave and a fixed-order sum over waves/slices,
 //     so results are bitwise reproducible for a given launch geometry.
+//
+// Kernels (all instantiated per (real, G, CH, K) in inst_*.hip through nmf_inst.hpp):
+//   fit_persistent_kernel<.., LOSS>  one workgroup per matrix, every iteration inside the kernel, most rows of W
+//                                    resident in LDS (the batch / headline path; LOSS = 1: Kullback-Leibler)
+//   fit_coop_kernel                  S co-resident workgroups per matrix with a fence-free exchange of the
+//                                    partial sums per iteration (few long matrices)
+//   slice_pass / reduce_slices / hupdate / slice_resid / resid_finalize
+//                                    one launch per phase over row slices (very long T; also the building blocks
+//                                    of the multi-GPU time-sharded solver, where an all-reduce sits between them)
+//   x_to_channel_major_kernel, w_convert_kernel   layout conversions, once per fit
 #pragma once
 #include <hip/hip_runtime.h>
 
