@@ -69,3 +69,21 @@ def test_segments_of_a_recording_in_one_launch():
                                      max_iter=100, tol=0.0)
     assert len(eq) == 3 and all(r.vaf_values.shape == (1, 9) for r in eq)
     assert all(float(r.vaf_values.iloc[0, 0]) > 0.85 for r in eq)
+
+
+@pytest.mark.gpu
+def test_tutorial_flow_example_runs_end_to_end():
+    import importlib.util
+    import os
+
+    from conftest import ROOT
+
+    spec = importlib.util.spec_from_file_location("tutorial_flow", os.path.join(ROOT, "examples", "tutorial_flow.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    raw, envelope, envelope_rms, processed, result, chosen = mod.main(T=6000, quiet=True)
+    assert envelope.shape == raw.shape == envelope_rms.shape and processed.shape == (1000, 8)
+    assert float(processed.to_numpy().max()) == 1.0 and float(processed.to_numpy().min()) >= 0.0
+    assert list(result.vaf_values.index) == [2, 3, 4, 5, 6] and 2 <= chosen <= 6
+    vaf_all = result.vaf_values["All signals"].to_numpy()
+    assert (np.diff(vaf_all) > -1e-3).all()  # more synergies never explain (noticeably) less
