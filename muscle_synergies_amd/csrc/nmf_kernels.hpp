@@ -1081,6 +1081,9 @@ __global__ void __launch_bounds__((max_threads<real, G, CH, K>())) HIPNMF_OCC fi
     prev = err0;
   }
   int n_iter = 0;
+#ifdef HIPNMF_TIMING
+  unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0};
+#endif
   RowTile<real, G, CH, K> tiles_lds[PipeDepth<true>::value];
   if (lds_rows > 0) prefetch_head<real, G, CH, K, true>(tiles_lds, ma, 0, lds_rows);
   for (int it = 1; it <= a.max_iter; ++it) {
@@ -1092,6 +1095,9 @@ __global__ void __launch_bounds__((max_threads<real, G, CH, K>())) HIPNMF_OCC fi
       for (int cc = 0; cc < CH; ++cc) accA[c][cc] = (real)0;
 #pragma unroll
     for (int i = 0; i < C::NB; ++i) accB[i] = (real)0;
+#ifdef HIPNMF_TIMING
+    const unsigned long long tm0 = __builtin_readcyclecounter();
+#endif
     if (lds_rows > 0)
       rows_update_pass<real, G, CH, K, true, true, LOSS>(ma, 0, lds_rows, h, hht, accA, accB, a.l1w, a.l2w,
                                                          a.update_h != 0, tiles_lds);
@@ -1105,16 +1111,35 @@ __global__ void __launch_bounds__((max_threads<real, G, CH, K>())) HIPNMF_OCC fi
     if (a.update_h) {
       // s.part was last read before the previous iteration's second barrier (or by a residual pass that ends
       // with a barrier), so the records can be written right away: two workgroup barriers per iteration
+#ifdef HIPNMF_TIMING
+      const unsigned long long tm1 = __builtin_readcyclecounter();
+#endif
       wave_reduce_acc<real, G, CH, K>(s.part + wave * C::NACC, accA, accB);
+#ifdef HIPNMF_TIMING
+      const unsigned long long tm2 = __builtin_readcyclecounter();
+#endif
       __syncthreads();
+#ifdef HIPNMF_TIMING
+      const unsigned long long tm3 = __builtin_readcyclecounter();
+#endif
       if (wave == 0) {
         if constexpr (LOSS == 1)
           wave0_combine_and_update_h_kl(s, nw, m, a.l1h, a.l2h);
         else
           wave0_combine_and_update_h(s, nw, m, a.l1h, a.l2h);
       }
+#ifdef HIPNMF_TIMING
+      const unsigned long long tm4 = __builtin_readcyclecounter();
+#endif
       __syncthreads();
+#ifdef HIPNMF_TIMING
+      const unsigned long long tm5 = __builtin_readcyclecounter();
+#endif
       load_h_regs(s, g, h, hht);
+#ifdef HIPNMF_TIMING
+      const unsigned long long tm6 = __builtin_readcyclecounter();
+      tacc[0] += tm1 - tm0; tacc[1] += tm2 - tm1; tacc[2] += tm3 - tm2; tacc[3] += tm4 - tm3; tacc[4] += tm5 - tm4; tacc[5] += tm6 - tm5;
+#endif
     }
     if (a.tol > (real)0 && (it % a.check_every) == 0) {
       const real err = residual();
@@ -1132,6 +1157,13 @@ __global__ void __launch_bounds__((max_threads<real, G, CH, K>())) HIPNMF_OCC fi
     if (a.sse_col_out) a.sse_col_out[(long long)b * m + threadIdx.x] = s.part[threadIdx.x];
     if (a.xsq_col_out) a.xsq_col_out[(long long)b * m + threadIdx.x] = s.part[MP + threadIdx.x];
   }
+#ifdef HIPNMF_TIMING
+  // development aid: average cycles per iteration of the phases, wave 0 -> sse_col_out[b][0..5], wave 1 -> xsq_col_out
+  if (lane == 0 && wave < 2 && m >= 6) {
+    real* dst = (wave == 0 ? a.sse_col_out : a.xsq_col_out) + (long long)b * m;
+    for (int q = 0; q < 6; ++q) dst[q] = (real)((double)tacc[q] / (double)n_iter);
+  }
+#endif
   if (a.update_h) {
     for (int i = threadIdx.x; i < K * MP; i += blockDim.x) {
       const int c = i / MP, j = i % MP;
