@@ -275,12 +275,36 @@ struct MatAddr {
   int lds_rows;       // stride of the cache (rows)
   int lds_used;       // rows of this matrix that live in the cache
   const real* h_lds;  // LDS copy of H ([K][MP]), read per tile by the h_in_lds instances
+  // Progress-balanced issue priority (persistent kernel).  The SIMD arbiter serves the older of its two waves
+  // first, so with equal tile counts the older wave finishes its pass ~30 % early and idles at the barrier
+  // while the younger one runs alone (measured: 44 k vs 60 k cycles).  Each wave publishes how many tiles it
+  // has done and yields (s_setprio 0) while it is ahead of the wave it shares its SIMD with, takes priority
+  // (s_setprio 2) while behind.  Only the timing changes: the tile -> wave assignment stays static, so the
+  // sums keep their fixed order.
+  int* bal_prog;      // LDS [nw] tiles done per wave, or nullptr (no balancing)
+  int bal_me, bal_partner;
+  mutable int bal_count;
+  __device__ __forceinline__ void balance_tick() const {
+    if (bal_prog == nullptr) return;
+    ++bal_count;
+    if (lane == 0) __hip_atomic_store(bal_prog + bal_me, bal_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const int other = __builtin_amdgcn_readfirstlane(
+        __hip_atomic_load(bal_prog + bal_partner, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+    if (bal_count < other)
+      __builtin_amdgcn_s_setprio(2);
+    else if (bal_count > other)
+      __builtin_amdgcn_s_setprio(0);
+    else
+      __builtin_amdgcn_s_setprio(1);
+  }
   __device__ __forceinline__ MatAddr(const real* Xb, long long ldx, const real* Wb, long long ldw, int T_, int m,
                                      real* lds_w_ = nullptr, int lds_rows_ = 0) {
     lds_w = lds_w_;
     lds_rows = lds_rows_;
     lds_used = lds_rows_;
     h_lds = nullptr;
+    bal_prog = nullptr;
+    bal_me = bal_partner = bal_count = 0;
     lane = threadIdx.x & (WAVE - 1);
     g = lane % G;
     T = T_;
@@ -692,6 +716,7 @@ __device__ __forceinline__ void rows_update_pass(const MatAddr<real, G, CH, K>& 
       const int nb = wbase + PF * stride;
       load_tile<real, G, CH, K, WLDS>(tiles[p], ma, nb, nb < row_end);
       wbase += stride;
+      ma.balance_tick();
 #ifndef HIPNMF_NO_TILE_BARRIER
       __builtin_amdgcn_sched_barrier(0);  // keep the tiles' arithmetic from being interleaved (VGPR pressure)
 #endif
@@ -706,6 +731,7 @@ __device__ __forceinline__ void rows_update_pass(const MatAddr<real, G, CH, K>& 
         update_tile<real, G, CH, K>(tiles[p], ma, h, hht, accA, accB, l1w, l2w, update_h);
       store_w<real, G, CH, K, WLDS>(tiles[p], ma, wbase);
       wbase += stride;
+      ma.balance_tick();
     }
   }
 }
@@ -1041,6 +1067,28 @@ __global__ void __launch_bounds__((max_threads<real, G, CH, K>())) HIPNMF_OCC fi
   MatAddr<real, G, CH, K> ma(Xb, ldx, Wb, ldw, T, m, lds_w, lds_stride);
   ma.h_lds = s.H;
   ma.lds_used = lds_rows;
+#ifndef HIPNMF_NO_BALANCE
+  {  // pair up the waves that share a SIMD (HW_ID.SIMD_ID = bits 5:4 of hardware register 4)
+    __shared__ int bal_prog[HIPNMF_MAXNT / WAVE], bal_simd[HIPNMF_MAXNT / WAVE];
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    if (lane == 0) {
+      bal_prog[wv] = 0;
+      bal_simd[wv] = (int)__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4);
+    }
+    __syncthreads();
+    int partner = -1, sharing = 0;
+    for (int w = 0; w < nw; ++w)
+      if (w != wv && bal_simd[w] == bal_simd[wv]) {
+        partner = w;
+        ++sharing;
+      }
+    if (sharing == 1) {
+      ma.bal_prog = bal_prog;
+      ma.bal_me = wv;
+      ma.bal_partner = partner;
+    }
+  }
+#endif
   for (int t0 = 0; t0 < lds_rows; t0 += blockDim.x) {  // row t0 + tid is owned by this thread in every pass
     const int t = t0 + threadIdx.x;
 #pragma unroll
@@ -1158,10 +1206,17 @@ __global__ void __launch_bounds__((max_threads<real, G, CH, K>())) HIPNMF_OCC fi
     if (a.xsq_col_out) a.xsq_col_out[(long long)b * m + threadIdx.x] = s.part[MP + threadIdx.x];
   }
 #ifdef HIPNMF_TIMING
-  // development aid: average cycles per iteration of the phases, wave 0 -> sse_col_out[b][0..5], wave 1 -> xsq_col_out
-  if (lane == 0 && wave < 2 && m >= 6) {
-    real* dst = (wave == 0 ? a.sse_col_out : a.xsq_col_out) + (long long)b * m;
-    for (int q = 0; q < 6; ++q) dst[q] = (real)((double)tacc[q] / (double)n_iter);
+  // development aid (overwrites the outputs): average cycles per iteration -- sse_col_out[b][0..5] = the six
+  // phases as seen by wave 0, xsq_col_out[b][w] = row-pass cycles of wave w, xsq_col_out[b][8 + w] = its wait at
+  // the first barrier
+  __syncthreads();
+  if (lane == 0 && m >= 16) {
+    if (wave == 0)
+      for (int q = 0; q < 6; ++q) a.sse_col_out[(long long)b * m + q] = (real)((double)tacc[q] / (double)n_iter);
+    if (wave < 8) {
+      a.xsq_col_out[(long long)b * m + wave] = (real)((double)tacc[0] / (double)n_iter);
+      a.xsq_col_out[(long long)b * m + 8 + wave] = (real)((double)tacc[2] / (double)n_iter);
+    }
   }
 #endif
   if (a.update_h) {

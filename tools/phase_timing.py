@@ -14,8 +14,11 @@ for rep in range(2):
     r = ms.fit_batched(X.transpose(1, 2), W0, H0, max_iter=100, tol=0.0)
 names = ["row pass", "wave reduce", "barrier 1", "wave-0 epilogue", "barrier 2", "load H regs"]
 w0 = r.sse_col[:, :6].double().mean(dim=0).tolist()
-w1 = r.xsq_col[:, :6].double().mean(dim=0).tolist()
-print(f"kernel {r.kernel_ms:.2f} ms for {B} x 100 iterations; s_memtime ticks (100 MHz -> 10 ns each) per iteration")
-for n, a, b in zip(names, w0, w1):
-    print(f"  {n:16s} wave 0: {a:9.1f}   wave 1: {b:9.1f}")
-print(f"  total            wave 0: {sum(w0):9.1f}   wave 1: {sum(w1):9.1f}")
+print(f"kernel {r.kernel_ms:.2f} ms for {B} x 100 iterations; shader-clock cycles per iteration, wave 0:")
+for n, a in zip(names, w0):
+    print(f"  {n:16s} {a:9.1f}")
+print(f"  total            {sum(w0):9.1f}")
+rp = r.xsq_col[:, :8].double().mean(dim=0).tolist()
+wt = r.xsq_col[:, 8:16].double().mean(dim=0).tolist()
+print("row pass per wave :", " ".join(f"{v:8.0f}" for v in rp))
+print("barrier-1 wait    :", " ".join(f"{v:8.0f}" for v in wt))
