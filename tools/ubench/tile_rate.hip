@@ -7,7 +7,73 @@
 #include "nmf_kernels.hpp"
 using namespace hipnmf;
 
-template <int K>
+// local copy of update_tile with parts removable (MODE bits: 1 no reduce-scatter, 2 no group broadcast,
+// 4 no quotient, 8 no W^T W, 16 no numerator FMAs, 32 no denominator FMAs, 64 no W^T X FMAs)
+template <int MODE, int G, int CH, int K>
+__device__ __forceinline__ void tile_variant(RowTile<float, G, CH, K>& t, const MatAddr<float, G, CH, K>& ma,
+                                             const float (&h)[K][CH], const float (&hht)[K][K], float (&accA)[K][CH],
+                                             float (&accB)[Cfg<float, G, CH, K>::NB]) {
+  const int g = ma.g;
+  float pn[G][K];
+#pragma unroll
+  for (int r = 0; r < G; ++r)
+#pragma unroll
+    for (int c = 0; c < K; ++c) {
+      float s = t.x[0][r] * h[c][0];
+      if (!(MODE & 16)) {
+#pragma unroll
+        for (int cc = 1; cc < CH; ++cc) s = fma_(t.x[cc][r], h[c][cc], s);
+      }
+      pn[r][c] = s;
+    }
+  if (!(MODE & 1)) reduce_scatter<G / 2, float, G, K>(pn, g);
+  float wn[K], den[K], num[K], quo[K];
+#pragma unroll
+  for (int c = 0; c < K; ++c) {
+    float d = t.w[0] * hht[0][c];
+    if (!(MODE & 32)) {
+#pragma unroll
+      for (int c2 = 1; c2 < K; ++c2) d = fma_(t.w[c2], hht[c2][c], d);
+    }
+    den[c] = (d == 0.f) ? eps_val<float>() : d;
+    num[c] = (MODE & 1) ? pn[0][c] + pn[1][c] + pn[2][c] + pn[3][c] : pn[0][c];
+  }
+  if (!(MODE & 4)) {
+    quotients<K>(num, den, quo);
+  } else {
+#pragma unroll
+    for (int c = 0; c < K; ++c) quo[c] = num[c] + den[c];
+  }
+#pragma unroll
+  for (int c = 0; c < K; ++c) wn[c] = t.w[c] * quo[c];
+#pragma unroll
+  for (int c = 0; c < K; ++c) t.w[c] = wn[c];
+  static_for<G>([&](auto R) {
+    constexpr int r = decltype(R)::value;
+#pragma unroll
+    for (int c = 0; c < K; ++c) {
+      const float wr = (MODE & 2) ? wn[c] : group_bcast<G, r>(wn[c]);
+      if (!(MODE & 64)) {
+#pragma unroll
+        for (int cc = 0; cc < CH; ++cc) accA[c][cc] = fma_(wr, t.x[cc][r], accA[c][cc]);
+      } else {
+        accA[c][0] += wr;
+      }
+    }
+  });
+  if (!(MODE & 8)) {
+    int idx = 0;
+#pragma unroll
+    for (int c = 0; c < K; ++c)
+#pragma unroll
+      for (int c2 = c; c2 < K; ++c2) {
+        accB[idx] = fma_(wn[c], wn[c2], accB[idx]);
+        ++idx;
+      }
+  }
+}
+
+template <int K, int MODE = -1>
 __global__ void __launch_bounds__(512) k_tile(float* out, int iters, float seed) {
   constexpr int G = 4, CH = 4;
   using C = Cfg<float, G, CH, K>;
@@ -27,7 +93,10 @@ __global__ void __launch_bounds__(512) k_tile(float* out, int iters, float seed)
     for (int cc = 0; cc < CH; ++cc)
 #pragma unroll
       for (int r = 0; r < G; ++r) asm volatile("" : "+v"(t.x[cc][r]));  // opaque: no hoisting of X H^T
-    update_tile<float, G, CH, K>(t, ma, h, hht, accA, accB, 0.f, 0.f, true);
+    if constexpr (MODE < 0)
+      update_tile<float, G, CH, K>(t, ma, h, hht, accA, accB, 0.f, 0.f, true);
+    else
+      tile_variant<MODE, G, CH, K>(t, ma, h, hht, accA, accB);
     __builtin_amdgcn_sched_barrier(0);
   }
   float s = 0.f;
@@ -36,25 +105,39 @@ __global__ void __launch_bounds__(512) k_tile(float* out, int iters, float seed)
   out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
-int main() {
-  float* d;
-  hipMalloc(&d, 256 * 1024 * 4 * 4);
+template <int MODE>
+void run(float* d, const char* name) {
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
   const int iters = 20000;
   for (int threads : {256, 512}) {
-    k_tile<5><<<256, threads>>>(d, 100, 0.7f);
+    k_tile<5, MODE><<<256, threads>>>(d, 100, 0.7f);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    k_tile<5><<<256, threads>>>(d, iters, 0.7f);
+    k_tile<5, MODE><<<256, threads>>>(d, iters, 0.7f);
     hipEventRecord(e1);
     hipDeviceSynchronize();
     float ms;
     hipEventElapsedTime(&ms, e0, e1);
     const double tiles_per_simd = (double)iters * threads / 64 / 4;
-    printf("update_tile<float,4,4,5>, %d waves/SIMD: %.3f ms, %.1f ns per tile and SIMD (%.0f cycles at 2.0 GHz)\n",
-           threads / 256, ms, ms * 1e6 / tiles_per_simd, ms * 1e6 / tiles_per_simd * 2.0);
+    printf("%-34s %d waves/SIMD: %7.1f ns per tile and SIMD\n", name, threads / 256, ms * 1e6 / tiles_per_simd);
   }
+}
+
+int main() {
+  float* d;
+  hipMalloc(&d, 256 * 1024 * 4 * 4);
+  run<-1>(d, "update_tile (as shipped)");
+  run<0>(d, "local copy, everything");
+  run<1>(d, "no reduce-scatter");
+  run<2>(d, "no group broadcast");
+  run<4>(d, "no quotient");
+  run<8>(d, "no W^T W");
+  run<16>(d, "no numerator FMAs");
+  run<32>(d, "no denominator FMAs");
+  run<64>(d, "no W^T X FMAs");
+  run<3>(d, "no reduce-scatter, no broadcast");
+  run<127>(d, "nothing but the skeleton");
   return 0;
 }
