@@ -101,7 +101,13 @@ __device__ __forceinline__ void static_for(F&& f) {
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v) {
   int i = __builtin_bit_cast(int, v);
-  i = __builtin_amdgcn_update_dpp(i, i, CTRL, 0xf, 0xf, true);
+#ifdef HIPNMF_SWIZZLE
+  // quad permutes through the LDS crossbar (ds_swizzle, QDMode) instead of the VALU's DPP path
+  if constexpr (CTRL < 0x100)
+    i = __builtin_amdgcn_ds_swizzle(i, 0x8000 | CTRL);
+  else
+#endif
+    i = __builtin_amdgcn_update_dpp(i, i, CTRL, 0xf, 0xf, true);
   return __builtin_bit_cast(float, i);
 }
 template <int CTRL>
@@ -275,12 +281,12 @@ struct MatAddr {
   int lds_rows;       // stride of the cache (rows)
   int lds_used;       // rows of this matrix that live in the cache
   const real* h_lds;  // LDS copy of H ([K][MP]), read per tile by the h_in_lds instances
-  // Progress-balanced issue priority (persistent kernel).  The SIMD arbiter serves the older of its two waves
-  // first, so with equal tile counts the older wave finishes its pass ~30 % early and idles at the barrier
-  // while the younger one runs alone (measured: 44 k vs 60 k cycles).  Each wave publishes how many tiles it
-  // has done and yields (s_setprio 0) while it is ahead of the wave it shares its SIMD with, takes priority
-  // (s_setprio 2) while behind.  Only the timing changes: the tile -> wave assignment stays static, so the
-  // sums keep their fixed order.
+  // Progress-balanced issue priority (experiment, -DHIPNMF_BALANCE).  The SIMD arbiter serves the older of its
+  // two waves first, so with equal tile counts the older wave finishes its pass ~30 % early and idles at the
+  // barrier while the younger one runs alone (tools/phase_timing.py: 44 k vs 60 k cycles).  Here each wave
+  // publishes how many tiles it has done and yields (s_setprio 0) while it is ahead of the wave it shares its
+  // SIMD with.  Result: both then finish at ~61 k cycles -- the SIMD is VALU-throughput-bound, one wave running
+  // alone keeps the pipe as busy as two, so fairness buys nothing and the extra instructions cost 5 %.
   int* bal_prog;      // LDS [nw] tiles done per wave, or nullptr (no balancing)
   int bal_me, bal_partner;
   mutable int bal_count;
@@ -1067,7 +1073,7 @@ __global__ void __launch_bounds__((max_threads<real, G, CH, K>())) HIPNMF_OCC fi
   MatAddr<real, G, CH, K> ma(Xb, ldx, Wb, ldw, T, m, lds_w, lds_stride);
   ma.h_lds = s.H;
   ma.lds_used = lds_rows;
-#ifndef HIPNMF_NO_BALANCE
+#ifdef HIPNMF_BALANCE  // experiment, off: measured 8.0 vs 8.5 M matrix-it/s (see the comment in MatAddr)
   {  // pair up the waves that share a SIMD (HW_ID.SIMD_ID = bits 5:4 of hardware register 4)
     __shared__ int bal_prog[HIPNMF_MAXNT / WAVE], bal_simd[HIPNMF_MAXNT / WAVE];
     const int wv = __builtin_amdgcn_readfirstlane(wave);
