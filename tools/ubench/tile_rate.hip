@@ -48,6 +48,27 @@ __device__ __forceinline__ void tile_variant(RowTile<float, G, CH, K>& t, const 
   for (int c = 0; c < K; ++c) wn[c] = t.w[c] * quo[c];
 #pragma unroll
   for (int c = 0; c < K; ++c) t.w[c] = wn[c];
+  if constexpr ((MODE & 128) != 0) {
+    // W^T X with the group's rows of the new W fetched from LDS (one ds_read_b128 per component) instead of
+    // 4 x K DPP broadcasts
+    extern __shared__ float stage[];  // [nw][K][64]
+    float* mine = stage + (threadIdx.x / 64) * (K * 64);
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int c = 0; c < K; ++c) mine[c * 64 + lane] = wn[c];
+    float wg[K][G];
+#pragma unroll
+    for (int c = 0; c < K; ++c) {
+      const float4 v = *reinterpret_cast<const float4*>(mine + c * 64 + (lane & ~3));
+      wg[c][0] = v.x; wg[c][1] = v.y; wg[c][2] = v.z; wg[c][3] = v.w;
+    }
+#pragma unroll
+    for (int r = 0; r < G; ++r)
+#pragma unroll
+      for (int c = 0; c < K; ++c)
+#pragma unroll
+        for (int cc = 0; cc < CH; ++cc) accA[c][cc] = fma_(wg[c][r], t.x[cc][r], accA[c][cc]);
+  } else
   static_for<G>([&](auto R) {
     constexpr int r = decltype(R)::value;
 #pragma unroll
@@ -112,10 +133,10 @@ void run(float* d, const char* name) {
   hipEventCreate(&e1);
   const int iters = 20000;
   for (int threads : {256, 512}) {
-    k_tile<5, MODE><<<256, threads>>>(d, 100, 0.7f);
+    k_tile<5, MODE><<<256, threads, 8 * 5 * 64 * 4>>>(d, 100, 0.7f);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    k_tile<5, MODE><<<256, threads>>>(d, iters, 0.7f);
+    k_tile<5, MODE><<<256, threads, 8 * 5 * 64 * 4>>>(d, iters, 0.7f);
     hipEventRecord(e1);
     hipDeviceSynchronize();
     float ms;
@@ -139,5 +160,6 @@ int main() {
   run<64>(d, "no W^T X FMAs");
   run<3>(d, "no reduce-scatter, no broadcast");
   run<127>(d, "nothing but the skeleton");
+  run<128>(d, "W rows of the group via LDS");
   return 0;
 }
