@@ -386,11 +386,19 @@ __device__ __forceinline__ void reduce_scatter(real (&pn)[G][K], int g) {
 }
 
 // One step: W-update of the lane's row and accumulation of W^T X (lane's channels) and W^T W (own row).
-template <typename real, int G, int CH, int K>
+// WSTAGE (rows whose W lives in the LDS cache, G > 1): the new row goes to the cache right here (instead of
+// store_w afterwards) and the G rows of the lane's group come straight back as one vector LDS read per
+// component, replacing the G x K DPP broadcasts of the register path -- a DPP move costs ~3 plain VALU
+// instructions on gfx950 and the W^T X accumulation was stalling on each of them (tools/ubench/tile_rate.hip:
+// 537 -> 474 ns per tile and SIMD).
+#ifndef HIPNMF_WSTAGE
+#define HIPNMF_WSTAGE 1
+#endif
+template <typename real, int G, int CH, int K, bool WSTAGE = false>
 __device__ __forceinline__ void update_tile(RowTile<real, G, CH, K>& t, const MatAddr<real, G, CH, K>& ma,
                                             const real (&h)[K][CH], const real (&hht)[K][K],
                                             real (&accA)[K][CH], real (&accB)[Cfg<real, G, CH, K>::NB],
-                                            real l1w, real l2w, bool update_h) {
+                                            real l1w, real l2w, bool update_h, int wbase = 0) {
   const int g = ma.g;
   // numerator X H^T (_nmf.py:543): partial over this lane's channels, for each of the G rows
   real pn[G][K];
@@ -442,17 +450,38 @@ __device__ __forceinline__ void update_tile(RowTile<real, G, CH, K>& t, const Ma
 #pragma unroll
   for (int c = 0; c < K; ++c) t.w[c] = wn[c];
 
+  if constexpr (WSTAGE) {  // store_w<WLDS = true>, done here so that the group can read the rows back
+    real* p = ma.lds_w + wbase + ma.lane;
+#pragma unroll
+    for (int c = 0; c < K; ++c) p[c * ma.lds_rows] = wn[c];
+  }
   if (update_h) {
-    // W^T X (_nmf.py:639): rows of the group broadcast lane by lane
-    static_for<G>([&](auto R) {
-      constexpr int r = decltype(R)::value;
+    if constexpr (WSTAGE && G > 1) {
+      // W^T X (_nmf.py:639): the group's G consecutive rows of every component, one aligned vector read each
+      // (same wave wrote them just above; LDS operations of a wave execute in order)
+      const real* q = ma.lds_w + wbase + (ma.lane - g);
+      real wg[K][G];
 #pragma unroll
-      for (int c = 0; c < K; ++c) {
-        const real wr = group_bcast<G, r>(wn[c]);
+      for (int c = 0; c < K; ++c)
+        __builtin_memcpy(wg[c], __builtin_assume_aligned(q + c * ma.lds_rows, sizeof(real) * G), sizeof(real) * G);
 #pragma unroll
-        for (int cc = 0; cc < CH; ++cc) accA[c][cc] = fma_(wr, t.x[cc][r], accA[c][cc]);
-      }
-    });
+      for (int r = 0; r < G; ++r)
+#pragma unroll
+        for (int c = 0; c < K; ++c)
+#pragma unroll
+          for (int cc = 0; cc < CH; ++cc) accA[c][cc] = fma_(wg[c][r], t.x[cc][r], accA[c][cc]);
+    } else {
+      // W^T X (_nmf.py:639): rows of the group broadcast lane by lane
+      static_for<G>([&](auto R) {
+        constexpr int r = decltype(R)::value;
+#pragma unroll
+        for (int c = 0; c < K; ++c) {
+          const real wr = group_bcast<G, r>(wn[c]);
+#pragma unroll
+          for (int cc = 0; cc < CH; ++cc) accA[c][cc] = fma_(wr, t.x[cc][r], accA[c][cc]);
+        }
+      });
+    }
     // W^T W (first factor of multi_dot, _nmf.py:640), upper triangle, own row
     int idx = 0;
 #pragma unroll
@@ -714,11 +743,12 @@ __device__ __forceinline__ void rows_update_pass(const MatAddr<real, G, CH, K>& 
   for (int grp = 0; grp < nfull; ++grp) {
 #pragma unroll
     for (int p = 0; p < PF; ++p) {
+      constexpr bool STAGE = WLDS && LOSS == 0 && (HIPNMF_WSTAGE != 0) && !h_in_lds<G, CH>();
       if constexpr (LOSS == 1)
         update_tile_kl<real, G, CH, K>(tiles[p], ma, h, hht, accA, accB, l1w, l2w, update_h);
       else
-        update_tile<real, G, CH, K>(tiles[p], ma, h, hht, accA, accB, l1w, l2w, update_h);
-      store_w<real, G, CH, K, WLDS>(tiles[p], ma, wbase);
+        update_tile<real, G, CH, K, STAGE>(tiles[p], ma, h, hht, accA, accB, l1w, l2w, update_h, wbase);
+      if constexpr (!STAGE) store_w<real, G, CH, K, WLDS>(tiles[p], ma, wbase);
       const int nb = wbase + PF * stride;
       load_tile<real, G, CH, K, WLDS>(tiles[p], ma, nb, nb < row_end);
       wbase += stride;
@@ -731,11 +761,12 @@ __device__ __forceinline__ void rows_update_pass(const MatAddr<real, G, CH, K>& 
 #pragma unroll
   for (int p = 0; p < PF - 1; ++p) {
     if (p < rem) {  // wave-uniform
+      constexpr bool STAGE = WLDS && LOSS == 0 && (HIPNMF_WSTAGE != 0) && !h_in_lds<G, CH>();
       if constexpr (LOSS == 1)
         update_tile_kl<real, G, CH, K>(tiles[p], ma, h, hht, accA, accB, l1w, l2w, update_h);
       else
-        update_tile<real, G, CH, K>(tiles[p], ma, h, hht, accA, accB, l1w, l2w, update_h);
-      store_w<real, G, CH, K, WLDS>(tiles[p], ma, wbase);
+        update_tile<real, G, CH, K, STAGE>(tiles[p], ma, h, hht, accA, accB, l1w, l2w, update_h, wbase);
+      if constexpr (!STAGE) store_w<real, G, CH, K, WLDS>(tiles[p], ma, wbase);
       wbase += stride;
       ma.balance_tick();
     }
