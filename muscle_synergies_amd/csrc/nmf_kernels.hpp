@@ -389,10 +389,12 @@ __device__ __forceinline__ void reduce_scatter(real (&pn)[G][K], int g) {
 // WSTAGE (rows whose W lives in the LDS cache, G > 1): the new row goes to the cache right here (instead of
 // store_w afterwards) and the G rows of the lane's group come straight back as one vector LDS read per
 // component, replacing the G x K DPP broadcasts of the register path -- a DPP move costs ~3 plain VALU
-// instructions on gfx950 and the W^T X accumulation was stalling on each of them (tools/ubench/tile_rate.hip:
-// 537 -> 474 ns per tile and SIMD).
+// instructions on gfx950 and the W^T X accumulation stalls on each of them.  Experiment (-DHIPNMF_WSTAGE=1):
+// in isolation it saves 12 % of the tile arithmetic (tools/ubench/tile_rate.hip: 537 -> 474 ns per tile and
+// SIMD), inside the kernel the extra LDS round trip and 7 more spilled VGPRs make it slower (8.27 vs 8.54 M
+// matrix-it/s at B = 2048), so the DPP path stays the default.
 #ifndef HIPNMF_WSTAGE
-#define HIPNMF_WSTAGE 1
+#define HIPNMF_WSTAGE 0
 #endif
 template <typename real, int G, int CH, int K, bool WSTAGE = false>
 __device__ __forceinline__ void update_tile(RowTile<real, G, CH, K>& t, const MatAddr<real, G, CH, K>& ma,
