@@ -126,6 +126,85 @@ __global__ void __launch_bounds__(512) k_tile(float* out, int iters, float seed)
   out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// Row-per-lane mapping (G = 1, CH = 16) with H and H H^T wave-uniform in SGPRs: no cross-lane traffic at all and
+// every numerator / denominator FMA takes an SGPR operand.  80 accumulators per lane.
+template <int K, int HH_SGPR>
+__global__ void __launch_bounds__(512) k_tile_g1(float* out, int iters, float seed) {
+  constexpr int M = 16, NB = K * (K + 1) / 2;
+  float hs[K][M], hht[K][K];
+  for (int c = 0; c < K; ++c) {
+    for (int j = 0; j < M; ++j) hs[c][j] = uniform(seed + 0.01f * (c + j));
+    for (int c2 = 0; c2 < K; ++c2) {
+      const float v = seed * (1.f + 0.1f * (c + c2));
+      hht[c][c2] = HH_SGPR ? uniform(v) : v + 0.f * threadIdx.x;
+    }
+  }
+  float accA[K][M], accB[NB], x[M], w[K];
+  for (int c = 0; c < K; ++c)
+    for (int j = 0; j < M; ++j) accA[c][j] = 0.f;
+  for (int i = 0; i < NB; ++i) accB[i] = 0.f;
+  for (int j = 0; j < M; ++j) x[j] = seed * 0.5f + 0.001f * (threadIdx.x + j);
+  for (int c = 0; c < K; ++c) w[c] = seed + 0.002f * (threadIdx.x + c);
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int j = 0; j < M; ++j) asm volatile("" : "+v"(x[j]));
+    float num[K], den[K], quo[K], wn[K];
+#pragma unroll
+    for (int c = 0; c < K; ++c) {
+      float s = x[0] * hs[c][0];
+#pragma unroll
+      for (int j = 1; j < M; ++j) s = fma_(x[j], hs[c][j], s);
+      num[c] = s;
+      float dd = w[0] * hht[0][c];
+#pragma unroll
+      for (int c2 = 1; c2 < K; ++c2) dd = fma_(w[c2], hht[c2][c], dd);
+      den[c] = (dd == 0.f) ? eps_val<float>() : dd;
+    }
+    quotients<K>(num, den, quo);
+#pragma unroll
+    for (int c = 0; c < K; ++c) wn[c] = w[c] * quo[c];
+#pragma unroll
+    for (int c = 0; c < K; ++c) w[c] = wn[c];
+#pragma unroll
+    for (int c = 0; c < K; ++c)
+#pragma unroll
+      for (int j = 0; j < M; ++j) accA[c][j] = fma_(wn[c], x[j], accA[c][j]);
+    int idx = 0;
+#pragma unroll
+    for (int c = 0; c < K; ++c)
+#pragma unroll
+      for (int c2 = c; c2 < K; ++c2) {
+        accB[idx] = fma_(wn[c], wn[c2], accB[idx]);
+        ++idx;
+      }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  float sres = 0.f;
+  for (int c = 0; c < K; ++c) { sres += w[c]; for (int j = 0; j < M; ++j) sres += accA[c][j]; }
+  for (int i = 0; i < NB; ++i) sres += accB[i];
+  out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = sres;
+}
+
+template <int HH_SGPR>
+void run_g1(float* d, const char* name) {
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  const int iters = 20000;
+  for (int threads : {256, 512}) {
+    k_tile_g1<5, HH_SGPR><<<256, threads>>>(d, 100, 0.7f);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    k_tile_g1<5, HH_SGPR><<<256, threads>>>(d, iters, 0.7f);
+    hipEventRecord(e1);
+    hipDeviceSynchronize();
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double tiles_per_simd = (double)iters * threads / 64 / 4;
+    printf("%-34s %d waves/SIMD: %7.1f ns per tile and SIMD\n", name, threads / 256, ms * 1e6 / tiles_per_simd);
+  }
+}
+
 template <int MODE>
 void run(float* d, const char* name) {
   hipEvent_t e0, e1;
@@ -161,5 +240,7 @@ int main() {
   run<3>(d, "no reduce-scatter, no broadcast");
   run<127>(d, "nothing but the skeleton");
   run<128>(d, "W rows of the group via LDS");
+  run_g1<1>(d, "row per lane, H and HHt in SGPRs");
+  run_g1<0>(d, "row per lane, H in SGPRs");
   return 0;
 }
