@@ -133,10 +133,11 @@ __global__ void __launch_bounds__(512) k_tile_g1(float* out, int iters, float se
   constexpr int M = 16, NB = K * (K + 1) / 2;
   float hs[K][M], hht[K][K];
   for (int c = 0; c < K; ++c) {
-    for (int j = 0; j < M; ++j) hs[c][j] = uniform(seed + 0.01f * (c + j));
+    // values the compiler cannot fold: read from memory, made wave-uniform with v_readfirstlane (-> SGPRs)
+    for (int j = 0; j < M; ++j) hs[c][j] = uniform(out[c * M + j] + seed);
     for (int c2 = 0; c2 < K; ++c2) {
-      const float v = seed * (1.f + 0.1f * (c + c2));
-      hht[c][c2] = HH_SGPR ? uniform(v) : v + 0.f * threadIdx.x;
+      const float v = out[128 + c * K + c2] + seed;
+      hht[c][c2] = HH_SGPR ? uniform(v) : v;
     }
   }
   float accA[K][M], accB[NB], x[M], w[K];
