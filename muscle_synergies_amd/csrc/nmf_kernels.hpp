@@ -211,6 +211,9 @@ __device__ __forceinline__ void buf_store(rsrc_t r, unsigned voff, unsigned soff
 // re-issued per tile) instead of holding K x CH values in VGPRs: no cross-lane work at all in the row loop.
 template <int G, int CH>
 constexpr bool h_in_lds() {
+#ifdef HIPNMF_HLDS_OFF
+  return false;
+#endif
 #ifdef HIPNMF_HLDS_CH8
   return CH >= 8;
 #else
