@@ -257,7 +257,14 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
 
   // ---- workspace carve-up -----------------------------------------------------------------------
   const size_t o_desc_bytes = ragged ? sizeof(long long) * 4 * (size_t)B : 0;
-  const bool x_inplace = ragged || (p->x_layout == HIPNMF_X_CHANNEL_MAJOR && (p->ldx % ks->G) == 0 &&
+#ifdef HIPNMF_G1ROW
+  // experiment: the row-per-lane instance streams a row-major X in place
+  const bool g1row = ks->G == 1 && ks->CH == 16 && p->x_layout == HIPNMF_X_ROW_MAJOR && (p->ldx % 4) == 0 &&
+                     m == 16 && (reinterpret_cast<uintptr_t>(X) % 16) == 0;
+#else
+  const bool g1row = false;
+#endif
+  const bool x_inplace = g1row || ragged || (p->x_layout == HIPNMF_X_CHANNEL_MAJOR && (p->ldx % ks->G) == 0 &&
                                     (T % ks->G) == 0 && (reinterpret_cast<uintptr_t>(X) % 16) == 0 &&
                                     ((p->x_batch_stride * (long long)sizeof(real)) % 16) == 0);
   const bool w_inplace = p->w_layout == HIPNMF_W_COMPONENT_MAJOR;

@@ -277,6 +277,7 @@ template <typename real, int G, int CH, int K>
 struct MatAddr {
   rsrc_t xr, wr;
   unsigned xoff[CH];  // (channel*ldx + lane's group row) * sizeof(real), or OOB for padded channels
+  unsigned xrow_b;    // HIPNMF_G1ROW: bytes between consecutive rows of the row-major X
   unsigned woff;      // lane * sizeof(real)
   unsigned ldw_b;     // ldw * sizeof(real)
   int T, lane, g;
@@ -319,6 +320,14 @@ struct MatAddr {
     T = T_;
     xr = make_rsrc(Xb, (unsigned)((long long)m * ldx * (long long)sizeof(real)));
     wr = make_rsrc(Wb, (unsigned)((long long)K * ldw * (long long)sizeof(real)));
+#ifdef HIPNMF_G1ROW
+    if constexpr (G == 1 && CH == 16) {  // experiment: X row-major, row stride ldx (a multiple of 4 elements)
+      xr = make_rsrc(Xb, (unsigned)((long long)(T_ + 64) * ldx * (long long)sizeof(real)));
+      xrow_b = (unsigned)(ldx * (long long)sizeof(real));
+#pragma unroll
+      for (int cc = 0; cc < CH; ++cc) xoff[cc] = (unsigned)lane * xrow_b + (unsigned)(cc * (int)sizeof(real));
+    } else
+#endif
 #pragma unroll
     for (int cc = 0; cc < CH; ++cc) {
       const int j = g * CH + cc;
@@ -337,6 +346,15 @@ __device__ __forceinline__ void load_tile(RowTile<real, G, CH, K>& t, const MatA
                                           bool in_range) {
   const unsigned sbase = (unsigned)wbase * (unsigned)sizeof(real);
   const bool grp_ok = in_range && (wbase + (ma.lane - ma.g) < ma.T);
+#ifdef HIPNMF_G1ROW
+  if constexpr (G == 1 && CH == 16) {  // the lane's own row: CH consecutive values, 16 bytes per load
+    constexpr int V = 16 / (int)sizeof(real);
+    const unsigned srow = (unsigned)wbase * ma.xrow_b;
+#pragma unroll
+    for (int q = 0; q < CH / V; ++q)
+      buf_load<real, V>(ma.xr, grp_ok ? ma.xoff[q * V] : OOB, srow, *reinterpret_cast<real(*)[V]>(&t.x[q * V][0]));
+  } else
+#endif
 #pragma unroll
   for (int cc = 0; cc < CH; ++cc) buf_load<real, G>(ma.xr, grp_ok ? ma.xoff[cc] : OOB, sbase, t.x[cc]);
   if constexpr (WLDS) {

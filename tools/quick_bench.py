@@ -16,11 +16,14 @@ ap.add_argument("--variant", type=int, default=0)
 ap.add_argument("--reps", type=int, default=2)
 ap.add_argument("--loss", default="frobenius")
 ap.add_argument("--dtype", default="float32")
+ap.add_argument("--rowmajor", action="store_true", help="X as [B, T, m] C-contiguous (row-major) instead of channel-major")
 a = ap.parse_args()
 X, W0, H0 = emg_batch_torch(a.batch, T=a.T, device="cuda:0")
 if a.dtype == "float64":
     X, W0, H0 = X.double(), W0.double(), H0.double()
 Xv = X.transpose(1, 2)  # [B, T, m] view of channel-major storage
+if a.rowmajor:
+    Xv = Xv.contiguous()
 h = _lib.get_handle(0)
 for nt in a.threads:
     h.set_tuning(nt, 0, a.variant)
