@@ -223,6 +223,9 @@ constexpr bool h_in_lds() {
 
 template <typename real, int G, int CH, int K>
 constexpr int max_threads() {
+#ifdef HIPNMF_FORCE512
+  return 512;
+#endif
   constexpr int words = (int)(sizeof(real) / 4);
   constexpr int est = words * ((h_in_lds<G, CH>() ? 1 : 2) * K * CH + K * (K + 1) / 2 + 3 * G * CH + G * K + 40 +
                                (h_in_lds<G, CH>() ? 24 : 0));
@@ -710,6 +713,16 @@ __device__ __forceinline__ void load_h_regs(const Smem<real, G, CH, K>& s, int g
     for (int c = 0; c < K; ++c)
 #pragma unroll
       for (int cc = 0; cc < CH; ++cc) h[c][cc] = s.H[c * MP + g * CH + cc];
+#ifdef HIPNMF_G1_HSGPR
+    // row-per-lane mapping: H is the same for every lane, so (some of) its rows can live in SGPRs -- frees
+    // VGPRs and gives the numerator FMAs a scalar operand
+    if constexpr (G == 1) {
+#pragma unroll
+      for (int c = 0; c < K && c < (HIPNMF_G1_HSGPR); ++c)
+#pragma unroll
+        for (int cc = 0; cc < CH; ++cc) h[c][cc] = uniform(h[c][cc]);
+    }
+#endif
   }
 #pragma unroll
   for (int c = 0; c < K; ++c)
