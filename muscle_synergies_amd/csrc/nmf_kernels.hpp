@@ -832,12 +832,57 @@ __device__ __forceinline__ void rows_resid_pass(const MatAddr<real, G, CH, K>& m
   }
 }
 
+// Reduce-scatter of N per-lane values over the 64 lanes of a wave: afterwards v[0] of lane l holds the sum over
+// all lanes of value l and v[1] that of value 64 + l.  Each of the six stages halves the number of live
+// registers (the lanes whose bit is set keep the odd element of a pair and hand the even one to their partner),
+// so the whole reduction costs ~N cross-lane moves instead of 6 N.  Fixed association order.
+template <int MASK, int N, typename real>
+__device__ __forceinline__ void wave_reduce_scatter(real (&v)[N], int lane) {
+  if constexpr (MASK <= 32) {
+    constexpr int NH = (N + 1) / 2;
+    const bool up = (lane & MASK) != 0;
+    real nxt[NH];
+#pragma unroll
+    for (int i = 0; i < NH; ++i) {
+      const real a = v[2 * i], b = (2 * i + 1 < N) ? v[2 * i + 1] : (real)0;
+      const real keep = up ? b : a, send = up ? a : b;
+      real got;
+      if constexpr (MASK <= 2)
+        got = xor_lane<MASK>(send);
+      else
+        got = __shfl_xor(send, MASK, WAVE);
+      nxt[i] = keep + got;
+    }
+    real (&w)[NH] = nxt;
+    wave_reduce_scatter<MASK * 2, NH, real>(w, lane);
+#pragma unroll
+    for (int i = 0; i < NH; ++i) v[i] = nxt[i];
+  }
+}
+
 // wave butterfly of the accumulators, then one record per wave in LDS
 template <typename real, int G, int CH, int K>
 __device__ __forceinline__ void wave_reduce_acc(real* __restrict__ rec /* [NACC] of this wave */, real (&accA)[K][CH],
                                                 real (&accB)[Cfg<real, G, CH, K>::NB]) {
   using C = Cfg<real, G, CH, K>;
   const int lane = threadIdx.x & (WAVE - 1);
+#ifdef HIPNMF_G1ROW
+  if constexpr (G == 1) {  // row-per-lane mapping: K*CH + NB (= 95 for k = 5, m = 16) values per lane
+    real v[C::NACC];
+#pragma unroll
+    for (int c = 0; c < K; ++c)
+#pragma unroll
+      for (int cc = 0; cc < CH; ++cc) v[c * C::MP + cc] = accA[c][cc];
+#pragma unroll
+    for (int i = 0; i < C::NB; ++i) v[K * C::MP + i] = accB[i];
+    wave_reduce_scatter<1, C::NACC, real>(v, lane);
+    constexpr int NOUT = (C::NACC + WAVE - 1) / WAVE;
+#pragma unroll
+    for (int q = 0; q < NOUT; ++q)
+      if (q * WAVE + lane < C::NACC) rec[q * WAVE + lane] = v[q];
+    return;
+  }
+#endif
   // inside a 16-lane row: DPP rotations (VALU only); across the four rows: two ds_bpermute stages
 #pragma unroll
   for (int c = 0; c < K; ++c)
