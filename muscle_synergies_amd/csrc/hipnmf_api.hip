@@ -36,20 +36,22 @@ int hipnmf_fail(int code, const char* fmt, ...) {
 namespace {
 
 
+// `row_major_ok`: the caller can hand X over (or convert it) in row-major order; then fp32 problems with 9..16
+// channels and k <= 5 take the row-per-lane instance (HIPNMF_G1C16=0 keeps the channel-major (G=4, CH=4) one)
 template <typename real>
-const KernelSet<real>* select_kernels(int m, int k);
+const KernelSet<real>* select_kernels(int m, int k, bool row_major_ok);
 
 template <>
-const KernelSet<float>* select_kernels<float>(int m, int k) {
+const KernelSet<float>* select_kernels<float>(int m, int k, bool row_major_ok) {
   static const bool g2c8 = [] {
     const char* e = getenv("HIPNMF_G2C8");
     return e && atoi(e) != 0;
   }();
   static const bool g1c16 = [] {
     const char* e = getenv("HIPNMF_G1C16");
-    return e && atoi(e) != 0;
+    return !(e && atoi(e) == 0);
   }();
-  if (g1c16 && m > 8 && m <= 16) return kernels_f32_g1c16(k);
+  if (g1c16 && row_major_ok && m > 8 && m <= 16 && k <= 5) return kernels_f32_g1c16(k);
   if (m <= 4) return kernels_f32_g1c4(k);
   if (m <= 8) return kernels_f32_g2c4(k);
   if (m <= 16) return g2c8 ? kernels_f32_g2c8(k) : kernels_f32_g4c4(k);
@@ -57,7 +59,7 @@ const KernelSet<float>* select_kernels<float>(int m, int k) {
   return nullptr;
 }
 template <>
-const KernelSet<double>* select_kernels<double>(int m, int k) {
+const KernelSet<double>* select_kernels<double>(int m, int k, bool) {
   if (m <= 4) return kernels_f64_g1c4(k);
   if (m <= 8) return kernels_f64_g2c4(k);
   if (m <= 16) return kernels_f64_g4c4(k);
@@ -171,7 +173,9 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
   HIP_TRY(hipSetDevice(h->device));
   const int B = p->batch, m = p->n_features, k = p->n_components;
   const long long T = p->n_samples;
-  const KernelSet<real>* ks = select_kernels<real>(m, k);
+  const KernelSet<real>* ks = select_kernels<real>(m, k, !ragged && p->loss == HIPNMF_LOSS_FROBENIUS);
+  if (ks && ks->row_major && (T + 64) * (long long)ks->MP * (long long)sizeof(real) >= (1LL << 31))
+    ks = select_kernels<real>(m, k, false);  // rows padded to MP channels would not fit the 32-bit addressing
   if (!ks) return fail(HIPNMF_ERR_UNSUPPORTED, "no kernel for n_features=%d n_components=%d", m, k);
   rc = check_matrix_bytes<real>(p);
   if (rc) return rc;
@@ -257,18 +261,17 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
 
   // ---- workspace carve-up -----------------------------------------------------------------------
   const size_t o_desc_bytes = ragged ? sizeof(long long) * 4 * (size_t)B : 0;
-#ifdef HIPNMF_G1ROW
-  // experiment: the row-per-lane instance streams a row-major X in place
-  const bool g1row = ks->G == 1 && ks->CH == 16 && p->x_layout == HIPNMF_X_ROW_MAJOR && (p->ldx % 4) == 0 &&
-                     m == 16 && (reinterpret_cast<uintptr_t>(X) % 16) == 0;
-#else
-  const bool g1row = false;
-#endif
-  const bool x_inplace = g1row || ragged || (p->x_layout == HIPNMF_X_CHANNEL_MAJOR && (p->ldx % ks->G) == 0 &&
-                                    (T % ks->G) == 0 && (reinterpret_cast<uintptr_t>(X) % 16) == 0 &&
-                                    ((p->x_batch_stride * (long long)sizeof(real)) % 16) == 0);
+  // canonical X: channel-major with an aligned leading dimension, or -- for the row-per-lane instance -- row-major
+  // with rows of MP (= 16) values; a caller's X that already has that shape is streamed in place
+  const bool aligned = (reinterpret_cast<uintptr_t>(X) % 16) == 0 && ((p->x_batch_stride * (long long)sizeof(real)) % 16) == 0;
+  bool x_inplace;
+  if (ks->row_major)
+    x_inplace = p->x_layout == HIPNMF_X_ROW_MAJOR && m == ks->MP && (p->ldx % 4) == 0 && aligned &&
+                (long long)(T + 64) * p->ldx * (long long)sizeof(real) < (1LL << 31);
+  else
+    x_inplace = ragged || (p->x_layout == HIPNMF_X_CHANNEL_MAJOR && (p->ldx % ks->G) == 0 && (T % ks->G) == 0 && aligned);
   const bool w_inplace = p->w_layout == HIPNMF_W_COMPONENT_MAJOR;
-  const long long ldx_c = x_inplace ? p->ldx : round_up(T, 64);
+  const long long ldx_c = x_inplace ? p->ldx : (ks->row_major ? (long long)ks->MP : round_up(T, 64));
   const long long ldw_c = w_inplace ? T : round_up(T, 64);
   size_t off = 0;
   auto carve = [&](size_t bytes) {
@@ -276,7 +279,8 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
     off += (bytes + 255) / 256 * 256;
     return o;
   };
-  const size_t o_x = x_inplace ? 0 : carve(sizeof(real) * (size_t)B * m * ldx_c);
+  const size_t x_elems = ks->row_major ? (size_t)T * (size_t)ldx_c : (size_t)m * (size_t)ldx_c;  // per matrix
+  const size_t o_x = x_inplace ? 0 : carve(sizeof(real) * (size_t)B * x_elems);
   const size_t o_w = w_inplace ? 0 : carve(sizeof(real) * (size_t)B * k * ldw_c);
   const size_t o_desc = ragged ? carve(o_desc_bytes) : 0;
   size_t o_part = 0, o_sums = 0, o_col = 0, o_state = 0;
@@ -307,11 +311,17 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
   } else {
     real* xc = reinterpret_cast<real*>(ws + o_x);
     dim3 blk(32, 8);
-    dim3 grd((unsigned)((ldx_c + 31) / 32), (unsigned)((m + 31) / 32), (unsigned)B);
-    hipLaunchKernelGGL(x_to_channel_major_kernel<real>, grd, blk, 0, st, X, (long long)p->x_batch_stride,
-                       (long long)p->ldx, (int)p->x_layout, xc, (long long)m * ldx_c, ldx_c, (int)T, m);
+    if (ks->row_major) {
+      dim3 grd((unsigned)((T + 31) / 32), (unsigned)((ldx_c + 31) / 32), (unsigned)B);
+      hipLaunchKernelGGL(x_to_row_major_kernel<real>, grd, blk, 0, st, X, (long long)p->x_batch_stride,
+                         (long long)p->ldx, (int)p->x_layout, xc, (long long)x_elems, (int)ldx_c, (int)T, m);
+    } else {
+      dim3 grd((unsigned)((ldx_c + 31) / 32), (unsigned)((m + 31) / 32), (unsigned)B);
+      hipLaunchKernelGGL(x_to_channel_major_kernel<real>, grd, blk, 0, st, X, (long long)p->x_batch_stride,
+                         (long long)p->ldx, (int)p->x_layout, xc, (long long)x_elems, ldx_c, (int)T, m);
+    }
     a.X = xc;
-    a.x_bstride = (long long)m * ldx_c;
+    a.x_bstride = (long long)x_elems;
     a.ldx = ldx_c;
   }
   if (w_inplace) {
@@ -510,7 +520,7 @@ int shard_common(hipnmf_handle* h, const hipnmf_problem* p, const KernelSet<real
   HIP_TRY(hipSetDevice(h->device));
   const int B = p->batch, m = p->n_features, k = p->n_components;
   const long long T = p->n_samples;
-  const KernelSet<real>* ks = select_kernels<real>(m, k);
+  const KernelSet<real>* ks = select_kernels<real>(m, k, false);  // the shard ABI is channel-major
   if (!ks) return fail(HIPNMF_ERR_UNSUPPORTED, "no kernel for n_features=%d n_components=%d", m, k);
   if (p->w_layout != HIPNMF_W_COMPONENT_MAJOR)
     return fail(HIPNMF_ERR_UNSUPPORTED, "shard entry points need w_layout = HIPNMF_W_COMPONENT_MAJOR");

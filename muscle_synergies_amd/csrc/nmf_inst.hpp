@@ -12,6 +12,7 @@ struct KernelSet {
   Fn fit_persistent_kl;  // Kullback-Leibler loss (persistent path only); nullptr where not built
   Fn fit_coop;           // cooperative multi-workgroup fit of few long matrices (Frobenius); nullptr where not built
   int G, CH, K, MP, NACC, max_threads;
+  bool row_major;  // the instance streams X row-major (rows of MP values) instead of channel-major
   size_t (*smem_bytes)(int nw);
 };
 
@@ -19,7 +20,7 @@ template <typename real, int G, int CH, int K>
 KernelSet<real> make_kernel_set() {
   KernelSet<real> ks;
   ks.fit_persistent = fit_persistent_kernel<real, G, CH, K>;
-  if constexpr (h_in_lds<G, CH>())
+  if constexpr (h_in_lds<G, CH>() || x_row_major<G, CH>())
     ks.fit_persistent_kl = nullptr;
   else
     ks.fit_persistent_kl = fit_persistent_kernel<real, G, CH, K, 1>;
@@ -32,6 +33,7 @@ KernelSet<real> make_kernel_set() {
   ks.hupdate = hupdate_kernel<real, G, CH, K>;
   ks.slice_resid = slice_resid_kernel<real, G, CH, K>;
   ks.resid_finalize = resid_finalize_kernel<real, G, CH, K>;
+  ks.row_major = x_row_major<G, CH>();
   ks.G = G;
   ks.CH = CH;
   ks.K = K;

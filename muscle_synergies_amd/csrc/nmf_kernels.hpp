@@ -207,25 +207,28 @@ __device__ __forceinline__ void buf_store(rsrc_t r, unsigned voff, unsigned soff
 // Largest workgroup a kernel instance is compiled for.  512 threads = 2 waves/SIMD caps the allocation at 256
 // VGPRs; instances whose live state cannot fit (fp64, m > 16 or large k) are compiled for 256 threads
 // (1 wave/SIMD, up to 512 VGPRs) instead of spilling to scratch.
-// Row-per-lane instances (G == 1 with >= 16 channels per lane) read H from LDS (wave-uniform broadcast reads,
-// re-issued per tile) instead of holding K x CH values in VGPRs: no cross-lane work at all in the row loop.
+// The row-per-lane instance (G == 1, CH == 16: fp32, 9..16 channels, k <= 5) streams a ROW-MAJOR X: the lane's own
+// row is 64 contiguous bytes (four 16-byte loads), nothing crosses lanes in the row loop, H and the K x 16
+// accumulators live in VGPRs, and no tile is prefetched in software (two waves per SIMD cover the latency;
+// 160 VGPRs of H + sums leave no room for a second tile).  Measured 9.6 vs 8.5 M matrix-it/s for the (G=4, CH=4)
+// mapping on 2048 x (16 x 10 000), k = 5 (profiles/README.md).
+template <int G, int CH>
+constexpr bool x_row_major() {
+  return G == 1 && CH == 16;
+}
+// Experimental: H broadcast from LDS per tile instead of K x CH VGPRs (-DHIPNMF_HLDS_CH8, G=2/CH=8 instance)
 template <int G, int CH>
 constexpr bool h_in_lds() {
-#ifdef HIPNMF_HLDS_OFF
-  return false;
-#endif
 #ifdef HIPNMF_HLDS_CH8
-  return CH >= 8;
+  return CH >= 8 && !x_row_major<G, CH>();
 #else
-  return G == 1 && CH >= 16;
+  return false;
 #endif
 }
 
 template <typename real, int G, int CH, int K>
 constexpr int max_threads() {
-#ifdef HIPNMF_FORCE512
-  return 512;
-#endif
+  if constexpr (x_row_major<G, CH>() && sizeof(real) == 4 && K <= 5) return HIPNMF_MAXNT;  // 2 x K x 16 <= 160 VGPRs
   constexpr int words = (int)(sizeof(real) / 4);
   constexpr int est = words * ((h_in_lds<G, CH>() ? 1 : 2) * K * CH + K * (K + 1) / 2 + 3 * G * CH + G * K + 40 +
                                (h_in_lds<G, CH>() ? 24 : 0));
@@ -280,7 +283,7 @@ template <typename real, int G, int CH, int K>
 struct MatAddr {
   rsrc_t xr, wr;
   unsigned xoff[CH];  // (channel*ldx + lane's group row) * sizeof(real), or OOB for padded channels
-  unsigned xrow_b;    // HIPNMF_G1ROW: bytes between consecutive rows of the row-major X
+  unsigned xrow_b;    // row-major instances: bytes between consecutive rows of X
   unsigned woff;      // lane * sizeof(real)
   unsigned ldw_b;     // ldw * sizeof(real)
   int T, lane, g;
@@ -323,14 +326,13 @@ struct MatAddr {
     T = T_;
     xr = make_rsrc(Xb, (unsigned)((long long)m * ldx * (long long)sizeof(real)));
     wr = make_rsrc(Wb, (unsigned)((long long)K * ldw * (long long)sizeof(real)));
-#ifdef HIPNMF_G1ROW
-    if constexpr (G == 1 && CH == 16) {  // experiment: X row-major, row stride ldx (a multiple of 4 elements)
+    xrow_b = 0;
+    if constexpr (x_row_major<G, CH>()) {  // X row-major, row stride ldx (a multiple of 4 elements, >= CH)
       xr = make_rsrc(Xb, (unsigned)((long long)(T_ + 64) * ldx * (long long)sizeof(real)));
       xrow_b = (unsigned)(ldx * (long long)sizeof(real));
 #pragma unroll
       for (int cc = 0; cc < CH; ++cc) xoff[cc] = (unsigned)lane * xrow_b + (unsigned)(cc * (int)sizeof(real));
     } else
-#endif
 #pragma unroll
     for (int cc = 0; cc < CH; ++cc) {
       const int j = g * CH + cc;
@@ -349,15 +351,13 @@ __device__ __forceinline__ void load_tile(RowTile<real, G, CH, K>& t, const MatA
                                           bool in_range) {
   const unsigned sbase = (unsigned)wbase * (unsigned)sizeof(real);
   const bool grp_ok = in_range && (wbase + (ma.lane - ma.g) < ma.T);
-#ifdef HIPNMF_G1ROW
-  if constexpr (G == 1 && CH == 16) {  // the lane's own row: CH consecutive values, 16 bytes per load
+  if constexpr (x_row_major<G, CH>()) {  // the lane's own row: CH consecutive values, 16 bytes per load
     constexpr int V = 16 / (int)sizeof(real);
     const unsigned srow = (unsigned)wbase * ma.xrow_b;
 #pragma unroll
     for (int q = 0; q < CH / V; ++q)
       buf_load<real, V>(ma.xr, grp_ok ? ma.xoff[q * V] : OOB, srow, *reinterpret_cast<real(*)[V]>(&t.x[q * V][0]));
   } else
-#endif
 #pragma unroll
   for (int cc = 0; cc < CH; ++cc) buf_load<real, G>(ma.xr, grp_ok ? ma.xoff[cc] : OOB, sbase, t.x[cc]);
   if constexpr (WLDS) {
@@ -713,16 +713,6 @@ __device__ __forceinline__ void load_h_regs(const Smem<real, G, CH, K>& s, int g
     for (int c = 0; c < K; ++c)
 #pragma unroll
       for (int cc = 0; cc < CH; ++cc) h[c][cc] = s.H[c * MP + g * CH + cc];
-#ifdef HIPNMF_G1_HSGPR
-    // row-per-lane mapping: H is the same for every lane, so (some of) its rows can live in SGPRs -- frees
-    // VGPRs and gives the numerator FMAs a scalar operand
-    if constexpr (G == 1) {
-#pragma unroll
-      for (int c = 0; c < K && c < (HIPNMF_G1_HSGPR); ++c)
-#pragma unroll
-        for (int cc = 0; cc < CH; ++cc) h[c][cc] = uniform(h[c][cc]);
-    }
-#endif
   }
 #pragma unroll
   for (int c = 0; c < K; ++c)
@@ -738,16 +728,20 @@ __device__ __forceinline__ void load_h_regs(const Smem<real, G, CH, K>& s, int g
 #ifndef HIPNMF_PF_LDS
 #define HIPNMF_PF_LDS 2  // same for the rows whose W lives in LDS (16 VGPRs per tile)
 #endif
-template <bool WLDS>
+template <bool WLDS, int G = 4, int CH = 4>
 struct PipeDepth {
-  static constexpr int value = WLDS ? HIPNMF_PF_LDS : HIPNMF_PF;
+  static constexpr int value = x_row_major<G, CH>() ? 1 : (WLDS ? HIPNMF_PF_LDS : HIPNMF_PF);
 };
+// the tiles a wave keeps in flight (an alias: an array bound with template arguments confuses the parser in a
+// parameter list)
+template <typename real, int G, int CH, int K, bool WLDS>
+using TileBuf = RowTile<real, G, CH, K>[PipeDepth<WLDS, G, CH>::value];
 
 // issue the loads of this wave's first PF tiles of rows [row_begin, row_end)
 template <typename real, int G, int CH, int K, bool WLDS>
-__device__ __forceinline__ void prefetch_head(RowTile<real, G, CH, K> (&tiles)[PipeDepth<WLDS>::value],
+__device__ __forceinline__ void prefetch_head(TileBuf<real, G, CH, K, WLDS>& tiles,
                                               const MatAddr<real, G, CH, K>& ma, int row_begin, int row_end) {
-  constexpr int PF = PipeDepth<WLDS>::value;
+  constexpr int PF = PipeDepth<WLDS, G, CH>::value;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
   const int stride = (blockDim.x / WAVE) * WAVE;
   const int wbase = row_begin + wave * WAVE;
@@ -763,8 +757,8 @@ __device__ __forceinline__ void rows_update_pass(const MatAddr<real, G, CH, K>& 
                                                  const real (&h)[K][CH], const real (&hht)[K][K],
                                                  real (&accA)[K][CH], real (&accB)[Cfg<real, G, CH, K>::NB], real l1w,
                                                  real l2w, bool update_h,
-                                                 RowTile<real, G, CH, K> (&tiles)[PipeDepth<WLDS>::value]) {
-  constexpr int PF = PipeDepth<WLDS>::value;
+                                                 TileBuf<real, G, CH, K, WLDS>& tiles) {
+  constexpr int PF = PipeDepth<WLDS, G, CH>::value;
   // readfirstlane makes the wave id (hence every row base / SGPR offset) provably wave-uniform; without it
   // hipcc wraps each buffer access in a waterfall loop
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
@@ -866,8 +860,7 @@ __device__ __forceinline__ void wave_reduce_acc(real* __restrict__ rec /* [NACC]
                                                 real (&accB)[Cfg<real, G, CH, K>::NB]) {
   using C = Cfg<real, G, CH, K>;
   const int lane = threadIdx.x & (WAVE - 1);
-#ifdef HIPNMF_G1ROW
-  if constexpr (G == 1) {  // row-per-lane mapping: K*CH + NB (= 95 for k = 5, m = 16) values per lane
+  if constexpr (x_row_major<G, CH>()) {  // row-per-lane mapping: K*CH + NB (= 95 for k = 5, m = 16) values per lane
     real v[C::NACC];
 #pragma unroll
     for (int c = 0; c < K; ++c)
@@ -882,7 +875,6 @@ __device__ __forceinline__ void wave_reduce_acc(real* __restrict__ rec /* [NACC]
       if (q * WAVE + lane < C::NACC) rec[q * WAVE + lane] = v[q];
     return;
   }
-#endif
   // inside a 16-lane row: DPP rotations (VALU only); across the four rows: two ds_bpermute stages
 #pragma unroll
   for (int c = 0; c < K; ++c)
@@ -1250,7 +1242,7 @@ __global__ void __launch_bounds__((max_threads<real, G, CH, K>())) HIPNMF_OCC fi
 #ifdef HIPNMF_TIMING
   unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0};
 #endif
-  RowTile<real, G, CH, K> tiles_lds[PipeDepth<true>::value];
+  RowTile<real, G, CH, K> tiles_lds[PipeDepth<true, G, CH>::value];
   if (lds_rows > 0) prefetch_head<real, G, CH, K, true>(tiles_lds, ma, 0, lds_rows);
   for (int it = 1; it <= a.max_iter; ++it) {
     n_iter = it;
@@ -1268,7 +1260,7 @@ __global__ void __launch_bounds__((max_threads<real, G, CH, K>())) HIPNMF_OCC fi
       rows_update_pass<real, G, CH, K, true, true, LOSS>(ma, 0, lds_rows, h, hht, accA, accB, a.l1w, a.l2w,
                                                          a.update_h != 0, tiles_lds);
     {
-      RowTile<real, G, CH, K> tiles_glb[PipeDepth<false>::value];
+      RowTile<real, G, CH, K> tiles_glb[PipeDepth<false, G, CH>::value];
       rows_update_pass<real, G, CH, K, false, false, LOSS>(ma, lds_rows, row_end, h, hht, accA, accB, a.l1w, a.l2w,
                                                            a.update_h != 0, tiles_glb);
     }
@@ -1468,7 +1460,8 @@ __global__ void __launch_bounds__((max_threads<real, G, CH, K>())) HIPNMF_OCC fi
   const int row_begin = sl * a.rows_per_slice;  // multiple of blockDim.x
   int T = a.T - row_begin;                      // rows of this slice (slice-local indexing from here on)
   if (T > a.rows_per_slice) T = a.rows_per_slice;
-  const real* __restrict__ Xb = a.X + (long long)b * a.x_bstride + row_begin;
+  const real* __restrict__ Xb =
+      a.X + (long long)b * a.x_bstride + (x_row_major<G, CH>() ? (long long)row_begin * a.ldx : (long long)row_begin);
   real* __restrict__ Wb = a.W + (long long)b * a.w_bstride + row_begin;
   real* __restrict__ Hb = a.H + (long long)b * K * m;
   unsigned* counter = a.sync + b;
@@ -1523,7 +1516,7 @@ __global__ void __launch_bounds__((max_threads<real, G, CH, K>())) HIPNMF_OCC fi
     __syncthreads();
   }
   int n_iter = 0;
-  RowTile<real, G, CH, K> tiles_lds[PipeDepth<true>::value];
+  RowTile<real, G, CH, K> tiles_lds[PipeDepth<true, G, CH>::value];
   prefetch_head<real, G, CH, K, true>(tiles_lds, ma, 0, lds_rows);
   for (int it = 1; it <= a.max_iter && alive; ++it) {
     n_iter = it;
@@ -1537,7 +1530,7 @@ __global__ void __launch_bounds__((max_threads<real, G, CH, K>())) HIPNMF_OCC fi
     rows_update_pass<real, G, CH, K, true, true>(ma, 0, lds_rows, h, hht, accA, accB, a.l1w, a.l2w, a.update_h != 0,
                                                  tiles_lds);
     if (lds_rows < row_end) {
-      RowTile<real, G, CH, K> tiles_glb[PipeDepth<false>::value];
+      RowTile<real, G, CH, K> tiles_glb[PipeDepth<false, G, CH>::value];
       rows_update_pass<real, G, CH, K, false, false>(ma, lds_rows, row_end, h, hht, accA, accB, a.l1w, a.l2w,
                                                      a.update_h != 0, tiles_glb);
     }
@@ -1629,7 +1622,7 @@ __global__ void __launch_bounds__((max_threads<real, G, CH, K>())) HIPNMF_OCC sl
   for (int i = 0; i < C::NB; ++i) accB[i] = (real)0;
   MatAddr<real, G, CH, K> ma(Xb, a.ldx, Wb, a.ldw, a.T, a.m);
   ma.h_lds = s.H;
-  RowTile<real, G, CH, K> tiles_glb[PipeDepth<false>::value];
+  RowTile<real, G, CH, K> tiles_glb[PipeDepth<false, G, CH>::value];
   rows_update_pass<real, G, CH, K, false, false>(ma, row_begin, row_end, h, hht, accA, accB, a.l1w, a.l2w,
                                                  a.update_h != 0, tiles_glb);
   if (!a.update_h) return;
@@ -1866,6 +1859,34 @@ __global__ void resid_finalize_kernel(SolveArgs<real> a) {
 // =================================================================================================
 // layout conversion (once per fit, not per iteration)
 // =================================================================================================
+// any X layout -> row-major [T][ld_out] with the channels zero-padded to ld_out (the row-per-lane instance's layout)
+template <typename real>
+__global__ void x_to_row_major_kernel(const real* __restrict__ in, long long in_bstride, long long ld_in,
+                                      int in_layout, real* __restrict__ out, long long out_bstride, int ld_out,
+                                      int T, int m) {
+  __shared__ real tile[32][33];
+  const int b = blockIdx.z;
+  const real* __restrict__ ib = in + (long long)b * in_bstride;
+  real* __restrict__ ob = out + (long long)b * out_bstride;
+  const int t0 = blockIdx.x * 32, j0 = blockIdx.y * 32;
+  if (in_layout == 0) {  // already row-major: strided copy with channel padding
+    for (int tt = threadIdx.y; tt < 32; tt += blockDim.y) {
+      const int t = t0 + tt, j = j0 + threadIdx.x;
+      if (t < T && j < ld_out) ob[(long long)t * ld_out + j] = (j < m) ? ib[(long long)t * ld_in + j] : (real)0;
+    }
+    return;
+  }
+  for (int jj = threadIdx.y; jj < 32; jj += blockDim.y) {  // channel-major in: coalesced along t
+    const int j = j0 + jj, t = t0 + threadIdx.x;
+    tile[jj][threadIdx.x] = (j < m && t < T) ? ib[(long long)j * ld_in + t] : (real)0;
+  }
+  __syncthreads();
+  for (int tt = threadIdx.y; tt < 32; tt += blockDim.y) {
+    const int t = t0 + tt, j = j0 + threadIdx.x;
+    if (t < T && j < ld_out) ob[(long long)t * ld_out + j] = tile[threadIdx.x][tt];
+  }
+}
+
 // X row-major [T][ldx_in] -> channel-major [m][ldx_out] (zero padded to ldx_out)
 template <typename real>
 __global__ void x_to_channel_major_kernel(const real* __restrict__ in, long long in_bstride, long long ld_in,
