@@ -41,6 +41,8 @@ def parse_args():
     ap.add_argument("--m", type=int, default=16)
     ap.add_argument("--k", type=int, default=5)
     ap.add_argument("--threads", type=int, default=0, help="workgroup size override (0 = library default)")
+    ap.add_argument("--x-layout", choices=["row", "channel"], default="row",
+                    help="memory order of the X batch handed to the engine: [B][T][m] (C order) or [B][m][T]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="matrices in the CPU baseline sample (0 = auto)")
     return ap.parse_args()
@@ -139,9 +141,15 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=dev)
 
-    # synthetic workload, generated on the device (seeded per rank); storage is channel-major [B, m, T]
+    # synthetic workload, generated on the device (seeded per rank).  X is handed over as [B, T, m] in C order
+    # (row-major, what sklearn itself takes): the layout the fp32 16-channel kernel streams in place.
+    # --x-layout channel passes the [B, m, T] storage (a DataFrame's F order) instead; the engine then converts it
+    # once per fit inside the timed step.
     X, W0, H0 = emg_batch_torch(a.batch, T=a.T, m=a.m, k=a.k, device=dev, seed=rank)
-    Xv = X.transpose(1, 2)  # logical [B, T, m] (sklearn orientation), zero-copy
+    Xv = X.transpose(1, 2)  # logical [B, T, m] (sklearn orientation), zero-copy view of channel-major storage
+    if a.x_layout == "row":
+        Xv = Xv.contiguous()
+        del X
     handle = _lib.get_handle(local_rank)
     if a.threads:
         handle.set_tuning(a.threads, 0, 0)
@@ -211,6 +219,7 @@ def main():
                 "n_features": a.m,
                 "n_components": a.k,
                 "iters_per_step": a.iters,
+                "x_layout": "row-major [B][T][m] (C order)" if a.x_layout == "row" else "channel-major [B][m][T] (F order)",
                 "parallelism": f"independent factorisations scattered over {world} GPU(s), no collective",
                 "all_fits_ran_full_iters": n_iter_ok,
                 "all_residuals_finite": finite,
@@ -222,7 +231,7 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
-                "kernel": "fit_persistent_kernel<float,4,4,5,0>",
+                "kernel": "fit_persistent_kernel<float,1,16,5,0>" if (8 < a.m <= 16 and a.k <= 5) else "fit_persistent_kernel",
                 "kernel_ms_avg": avg_ms,
                 "algorithmic_bytes_per_unit": bytes_per_unit,
                 "units_per_launch": a.batch * a.iters,
