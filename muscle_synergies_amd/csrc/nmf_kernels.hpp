@@ -216,6 +216,28 @@ template <int G, int CH>
 constexpr bool x_row_major() {
   return G == 1 && CH == 16;
 }
+// Row-per-lane instances with k >= 4: the last HIPNMF_ROW_HLDS rows of H are re-read from LDS every tile (wave-
+// uniform 16-byte broadcast reads, issued before the tile's X is waited for) instead of living in VGPRs; the 32
+// registers this frees pay for a second tile in flight (HIPNMF_PF_ROW).
+// Measured (B = 2048 x 200 iterations): all of H in VGPRs and one tile in flight 9.7 M matrix-it/s; 2 / 3 / 4 rows
+// from LDS with two tiles in flight 7.4 / 8.5 / 7.8 M (29 / 6 / 0 spilled VGPRs) -- the per-tile LDS reads cost more
+// than the second tile buys, so both knobs default to "off".
+#ifndef HIPNMF_ROW_HLDS
+#define HIPNMF_ROW_HLDS 0
+#endif
+#ifndef HIPNMF_PF_ROW
+#define HIPNMF_PF_ROW 1
+#endif
+// Row-major instances have no register to spare for a second tile, so the tile HIPNMF_ROW_TOUCH steps ahead is
+// pulled towards the CU by a one-dword-per-lane load whose result is only consumed a tile later (64 lanes x 64-byte
+// rows = every cache line of the tile): the real 16-byte loads then hit L2 instead of HBM.  0 disables it.
+#ifndef HIPNMF_ROW_TOUCH
+#define HIPNMF_ROW_TOUCH 2
+#endif
+template <int G, int CH, int K>
+constexpr int h_lds_rows() {
+  return (x_row_major<G, CH>() && K >= 4 && (HIPNMF_ROW_HLDS) > 0) ? (HIPNMF_ROW_HLDS) : 0;
+}
 // Experimental: H broadcast from LDS per tile instead of K x CH VGPRs (-DHIPNMF_HLDS_CH8, G=2/CH=8 instance)
 template <int G, int CH>
 constexpr bool h_in_lds() {
@@ -446,15 +468,29 @@ __device__ __forceinline__ void update_tile(RowTile<real, G, CH, K>& t, const Ma
       }
     }
   } else {
+    constexpr int RL = h_lds_rows<G, CH, K>();
 #pragma unroll
     for (int r = 0; r < G; ++r)
 #pragma unroll
-      for (int c = 0; c < K; ++c) {
+      for (int c = 0; c < K - RL; ++c) {
         real s = t.x[0][r] * h[c][0];
 #pragma unroll
         for (int cc = 1; cc < CH; ++cc) s = fma_(t.x[cc][r], h[c][cc], s);
         pn[r][c] = s;
       }
+    if constexpr (RL > 0) {  // G == 1: rows K-RL .. K-1 of H from LDS
+      const real* hp = ma.h_lds;
+      asm volatile("" : "+v"(hp));  // opaque per tile: keeps the reads inside the row loop
+#pragma unroll
+      for (int c = K - RL; c < K; ++c) {
+        real hc[CH];
+        __builtin_memcpy(hc, __builtin_assume_aligned(hp + c * (G * CH), 16), sizeof(hc));
+        real s = t.x[0][0] * hc[0];
+#pragma unroll
+        for (int cc = 1; cc < CH; ++cc) s = fma_(t.x[cc][0], hc[cc], s);
+        pn[0][c] = s;
+      }
+    }
   }
   reduce_scatter<G / 2, real, G, K>(pn, g);
 
@@ -635,6 +671,15 @@ __device__ __forceinline__ void resid_tile(const RowTile<real, G, CH, K>& t, con
     });
     return;
   }
+  constexpr int RL = h_lds_rows<G, CH, K>();
+  real hx[RL > 0 ? RL : 1][CH];  // the rows of H that are not kept in registers
+  if constexpr (RL > 0) {
+    const real* hp = ma.h_lds;
+#pragma unroll
+    for (int q = 0; q < RL; ++q)
+#pragma unroll
+      for (int cc = 0; cc < CH; ++cc) hx[q][cc] = hp[(K - RL + q) * (G * CH) + cc];
+  }
   static_for<G>([&](auto R) {
     constexpr int r = decltype(R)::value;
     real wr[K];
@@ -642,9 +687,9 @@ __device__ __forceinline__ void resid_tile(const RowTile<real, G, CH, K>& t, con
     for (int c = 0; c < K; ++c) wr[c] = group_bcast<G, r>(t.w[c]);
 #pragma unroll
     for (int cc = 0; cc < CH; ++cc) {
-      real rec = wr[0] * h[0][cc];
+      real rec = wr[0] * (RL >= K ? hx[0][cc] : h[0][cc]);
 #pragma unroll
-      for (int c = 1; c < K; ++c) rec = fma_(wr[c], h[c][cc], rec);
+      for (int c = 1; c < K; ++c) rec = fma_(wr[c], (c >= K - RL) ? hx[c - (K - RL) < 0 ? 0 : c - (K - RL)][cc] : h[c][cc], rec);
       const real d = t.x[cc][r] - rec;
       sse[cc] = fma_(d, d, sse[cc]);
       xsq[cc] = fma_(t.x[cc][r], t.x[cc][r], xsq[cc]);
@@ -710,9 +755,13 @@ __device__ __forceinline__ void load_h_regs(const Smem<real, G, CH, K>& s, int g
   constexpr int MP = G * CH;
   if constexpr (!h_in_lds<G, CH>()) {
 #pragma unroll
-    for (int c = 0; c < K; ++c)
+    for (int c = 0; c < K - h_lds_rows<G, CH, K>(); ++c)
 #pragma unroll
       for (int cc = 0; cc < CH; ++cc) h[c][cc] = s.H[c * MP + g * CH + cc];
+#pragma unroll
+    for (int c = K - h_lds_rows<G, CH, K>(); c < K; ++c)  // read from LDS per tile (never used from registers)
+#pragma unroll
+      for (int cc = 0; cc < CH; ++cc) h[c][cc] = (real)0;
   }
 #pragma unroll
   for (int c = 0; c < K; ++c)
@@ -730,7 +779,7 @@ __device__ __forceinline__ void load_h_regs(const Smem<real, G, CH, K>& s, int g
 #endif
 template <bool WLDS, int G = 4, int CH = 4>
 struct PipeDepth {
-  static constexpr int value = x_row_major<G, CH>() ? 1 : (WLDS ? HIPNMF_PF_LDS : HIPNMF_PF);
+  static constexpr int value = x_row_major<G, CH>() ? (HIPNMF_PF_ROW) : (WLDS ? HIPNMF_PF_LDS : HIPNMF_PF);
 };
 // the tiles a wave keeps in flight (an alias: an array bound with template arguments confuses the parser in a
 // parameter list)
@@ -768,6 +817,7 @@ __device__ __forceinline__ void rows_update_pass(const MatAddr<real, G, CH, K>& 
   const int nsteps = (row_end - wbase + stride - 1) / stride;  // wave-uniform trip count
   const int nfull = nsteps / PF, rem = nsteps - nfull * PF;
   if constexpr (!PRELOADED) prefetch_head<real, G, CH, K, WLDS>(tiles, ma, row_begin, row_end);
+  unsigned touch_prev = 0, touch_sink = 0;  // cache-line touches of the tiles further ahead (row-major instances)
   // Main loop: PF tiles per trip, no exit in the middle (a single back edge keeps hipcc's s_waitcnt vmcnt
   // counting exact, so the tiles loaded PF-1 steps ahead really stay in flight).
   for (int grp = 0; grp < nfull; ++grp) {
@@ -781,6 +831,12 @@ __device__ __forceinline__ void rows_update_pass(const MatAddr<real, G, CH, K>& 
       if constexpr (!STAGE) store_w<real, G, CH, K, WLDS>(tiles[p], ma, wbase);
       const int nb = wbase + PF * stride;
       load_tile<real, G, CH, K, WLDS>(tiles[p], ma, nb, nb < row_end);
+      if constexpr (x_row_major<G, CH>() && (HIPNMF_ROW_TOUCH) > 0) {
+        const int tb = nb + (HIPNMF_ROW_TOUCH) * stride;
+        touch_sink ^= touch_prev;  // consumes the touch issued one tile ago: never a wait on a fresh load
+        const bool ok = tb < row_end && tb + ma.lane < ma.T;
+        touch_prev = __builtin_amdgcn_raw_buffer_load_b32(ma.xr, ok ? ma.xoff[0] : OOB, (unsigned)tb * ma.xrow_b, 0);
+      }
       wbase += stride;
       ma.balance_tick();
 #ifndef HIPNMF_NO_TILE_BARRIER
@@ -800,6 +856,10 @@ __device__ __forceinline__ void rows_update_pass(const MatAddr<real, G, CH, K>& 
       wbase += stride;
       ma.balance_tick();
     }
+  }
+  if constexpr (x_row_major<G, CH>() && (HIPNMF_ROW_TOUCH) > 0) {
+    touch_sink ^= touch_prev;
+    asm volatile("" ::"v"(touch_sink));  // keeps the touch loads alive
   }
 }
 
