@@ -228,11 +228,12 @@ constexpr bool x_row_major() {
 #ifndef HIPNMF_PF_ROW
 #define HIPNMF_PF_ROW 1
 #endif
-// Row-major instances have no register to spare for a second tile, so the tile HIPNMF_ROW_TOUCH steps ahead is
-// pulled towards the CU by a one-dword-per-lane load whose result is only consumed a tile later (64 lanes x 64-byte
-// rows = every cache line of the tile): the real 16-byte loads then hit L2 instead of HBM.  0 disables it.
+// Experiment (-DHIPNMF_ROW_TOUCH=n): row-major instances have no register to spare for a second tile, so the tile n
+// steps ahead can be pulled towards the CU by a one-dword-per-lane load whose result is only consumed a tile later
+// (64 lanes x 64-byte rows = every cache line of the tile).  Measured: n = 0 / 2 / 4 -> 9.9 / 9.4 / 7.8 M matrix-it/s:
+// with ~7.5 TB/s of L2-side traffic the memory system is the wall now, extra requests only add to it.  Off.
 #ifndef HIPNMF_ROW_TOUCH
-#define HIPNMF_ROW_TOUCH 2
+#define HIPNMF_ROW_TOUCH 0
 #endif
 template <int G, int CH, int K>
 constexpr int h_lds_rows() {
