@@ -459,3 +459,57 @@ def test_cooperative_path_with_slices_larger_than_lds(tuned_handle):
     Wt = orc.multiplicative_update_w(X[tail], ref.W[0][tail].copy(), ref.H[0].copy())
     one_more = ms.fit_batched(X, ref.W[0], ref.H[0], max_iter=1, tol=0.0, update_H=False)
     np.testing.assert_allclose(one_more.W[0][tail], Wt, rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("variant", [1, 2, 3])
+@pytest.mark.parametrize("T,m,k", [(1, 16, 1), (63, 9, 2), (65, 12, 3), (1001, 16, 5), (4096, 13, 4), (7777, 16, 5)])
+def test_row_per_lane_instance_layouts_and_paths(tuned_handle, variant, T, m, k):
+    """fp32 with 9..16 channels and k <= 5 runs on the row-per-lane kernels (row-major X, channels padded to 16):
+    C-order input is streamed in place when m == 16, F-order / narrower input is converted once; every solver path."""
+    import muscle_synergies_amd as ms
+    from muscle_synergies_amd import _lib
+    from oracle import nmf_mu_oracle as orc
+
+    if variant == 3 and T < 128:
+        pytest.skip("cooperative path needs at least two workgroup steps of rows")
+    X = emg_matrix(70 + T + m, T=T, m=m, k_true=min(5, m), dtype=np.float32)  # F-contiguous
+    W0, H0 = random_init(X, k, seed=5)
+    ref = orc.nmf_mu_fit(X, W0, H0, max_iter=25, tol=0.0)
+    xn = max(np.linalg.norm(X.astype(np.float64)), 1e-30)
+    tuned_handle.set_tuning(0, 0, variant)
+    outs = []
+    for arr in (X, np.ascontiguousarray(X)):  # channel-major and row-major memory order
+        try:
+            got = ms.fit_batched(arr, W0, H0, max_iter=25, tol=0.0)
+        except _lib.HipNmfError as e:
+            assert variant == 3 and "not applicable" in str(e)
+            return
+        wh = got.W[0].astype(np.float64) @ got.H[0].astype(np.float64)
+        assert np.linalg.norm(wh - ref["W"].astype(np.float64) @ ref["H"].astype(np.float64)) / xn <= 1e-5
+        assert abs(float(got.reconstruction_err[0]) - float(ref["reconstruction_err"])) / xn <= 1e-5
+        outs.append(got)
+    assert np.array_equal(outs[0].W, outs[1].W) and np.array_equal(outs[0].H, outs[1].H)  # same kernel, same bits
+
+
+def test_row_per_lane_instance_batch_with_padded_rows_and_strides():
+    """A batch whose row-major rows are wider than m (ldx = 20 > 16: a view into a larger array) and a stop rule."""
+    import torch
+
+    import muscle_synergies_amd as ms
+    from oracle import nmf_mu_oracle as orc
+
+    B, T, m, k = 5, 3000, 16, 4
+    big = np.zeros((B, T, 20), dtype=np.float32)
+    for b in range(B):
+        big[b, :, :m] = emg_matrix(900 + b, T=T, m=m, dtype=np.float32)
+    Xv = torch.from_numpy(big).cuda()[:, :, :m]  # row stride 20 elements, in place (a multiple of 4)
+    inits = [random_init(big[b, :, :m], k, seed=b) for b in range(B)]
+    W0, H0 = np.stack([w for w, _ in inits]), np.stack([h for _, h in inits])
+    got = ms.fit_batched(Xv, W0, H0, max_iter=400, tol=1e-4)
+    for b in (0, 4):
+        ref = orc.nmf_mu_fit(np.ascontiguousarray(big[b, :, :m]), W0[b], H0[b], max_iter=400, tol=1e-4)
+        assert abs(int(got.n_iter[b]) - ref["n_iter"]) <= 10  # fp32 stop rule: same check or the neighbouring one
+        xn = np.linalg.norm(big[b, :, :m].astype(np.float64))
+        if int(got.n_iter[b]) == ref["n_iter"]:
+            wh = got.W[b].cpu().numpy().astype(np.float64) @ got.H[b].cpu().numpy().astype(np.float64)
+            assert np.linalg.norm(wh - ref["W"].astype(np.float64) @ ref["H"].astype(np.float64)) / xn <= 1e-5
