@@ -10,6 +10,8 @@ from muscle_synergies_amd.synth import emg_batch_torch
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=1024)
 ap.add_argument("--T", type=int, default=10000)
+ap.add_argument("--m", type=int, default=16)
+ap.add_argument("--k", type=int, default=5)
 ap.add_argument("--iters", type=int, default=100)
 ap.add_argument("--threads", type=int, nargs="*", default=[256, 512])
 ap.add_argument("--variant", type=int, default=0)
@@ -18,7 +20,7 @@ ap.add_argument("--loss", default="frobenius")
 ap.add_argument("--dtype", default="float32")
 ap.add_argument("--rowmajor", action="store_true", help="X as [B, T, m] C-contiguous (row-major) instead of channel-major")
 a = ap.parse_args()
-X, W0, H0 = emg_batch_torch(a.batch, T=a.T, device="cuda:0")
+X, W0, H0 = emg_batch_torch(a.batch, T=a.T, m=a.m, k=a.k, k_true=min(5, a.m), device="cuda:0")
 if a.dtype == "float64":
     X, W0, H0 = X.double(), W0.double(), H0.double()
 Xv = X.transpose(1, 2)  # [B, T, m] view of channel-major storage
@@ -33,5 +35,5 @@ for nt in a.threads:
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         its = a.batch * a.iters / (r.kernel_ms * 1e-3)
-        gbs = its * X.element_size() * a.T * 26 / 1e9
+        gbs = its * X.element_size() * a.T * (a.m + 2 * a.k) / 1e9
         print(f"threads={nt} rep={rep} wall={dt*1e3:.1f} ms kernel={r.kernel_ms:.1f} ms  {its/1e6:.3f} M matrix-it/s  {gbs:.0f} GB/s algorithmic  err0={float(r.reconstruction_err[0]):.4f}", flush=True)
