@@ -52,7 +52,8 @@ const KernelSet<float>* select_kernels<float>(int m, int k, bool row_major_ok) {
     return !(e && atoi(e) == 0);
   }();
   if (g1c16 && row_major_ok && m > 8 && m <= 16 && k <= 5) return kernels_f32_g1c16(k);
-  if (g1c16 && row_major_ok && m > 4 && m <= 8) return kernels_f32_g1c8(k);
+  // 7..8 channels (rows padded to 8): +10 % at m = 8, k = 4; at 5..6 channels the padding costs more than it buys
+  if (g1c16 && row_major_ok && m > 6 && m <= 8) return kernels_f32_g1c8(k);
   if (m <= 4) return kernels_f32_g1c4(k);
   if (m <= 8) return kernels_f32_g2c4(k);
   if (m <= 16) return g2c8 ? kernels_f32_g2c8(k) : kernels_f32_g4c4(k);

@@ -214,7 +214,7 @@ __device__ __forceinline__ void buf_store(rsrc_t r, unsigned voff, unsigned soff
 // mapping on 2048 x (16 x 10 000), k = 5 (profiles/README.md).
 template <int G, int CH>
 constexpr bool x_row_major() {
-  return G == 1 && (CH == 16 || CH == 8);  // (1, 8): fp32, 5..8 channels, any k <= 8 (2 x 8 x 8 = 128 VGPRs)
+  return G == 1 && (CH == 16 || CH == 8);  // (1, 8): fp32, 7..8 channels, any k <= 8 (2 x 8 x 8 = 128 VGPRs)
 }
 // Row-per-lane instances with k >= 4: the last HIPNMF_ROW_HLDS rows of H are re-read from LDS every tile (wave-
 // uniform 16-byte broadcast reads, issued before the tile's X is waited for) instead of living in VGPRs; the 32
