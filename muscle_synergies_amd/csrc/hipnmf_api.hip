@@ -175,7 +175,7 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
   HIP_TRY(hipSetDevice(h->device));
   const int B = p->batch, m = p->n_features, k = p->n_components;
   const long long T = p->n_samples;
-  const KernelSet<real>* ks = select_kernels<real>(m, k, !ragged && p->loss == HIPNMF_LOSS_FROBENIUS);
+  const KernelSet<real>* ks = select_kernels<real>(m, k, !ragged);
   if (ks && ks->row_major && (T + 64) * (long long)ks->MP * (long long)sizeof(real) >= (1LL << 31))
     ks = select_kernels<real>(m, k, false);  // rows padded to MP channels would not fit the 32-bit addressing
   if (!ks) return fail(HIPNMF_ERR_UNSUPPORTED, "no kernel for n_features=%d n_components=%d", m, k);

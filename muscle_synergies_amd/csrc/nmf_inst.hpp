@@ -20,7 +20,7 @@ template <typename real, int G, int CH, int K>
 KernelSet<real> make_kernel_set() {
   KernelSet<real> ks;
   ks.fit_persistent = fit_persistent_kernel<real, G, CH, K>;
-  if constexpr (h_in_lds<G, CH>() || x_row_major<G, CH>())
+  if constexpr (h_in_lds<G, CH>())
     ks.fit_persistent_kl = nullptr;
   else
     ks.fit_persistent_kl = fit_persistent_kernel<real, G, CH, K, 1>;
