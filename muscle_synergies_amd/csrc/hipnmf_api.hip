@@ -191,7 +191,7 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
   // persistent 2.7 ns per row of one matrix, num_cu matrices at a time; sliced 9.5 us of launches +
   // 0.021 ns per row of the whole batch; cooperative (further down) 5.5 us + 2.4 us per workgroup-step of rows
   const double waves = (double)((B + h->num_cu - 1) / h->num_cu);
-  const double t_pers = waves * ((double)T * 2.7e-9 + 1e-6);
+  const double t_pers = waves * ((double)T * (ks->row_major ? 2.0e-9 : 2.7e-9) + 1e-6);  // row-per-lane: 20.8 us / 10 000 rows
   const double t_sliced = 9.5e-6 + (double)B * (double)T * 0.021e-9;
   bool persistent;
   if (h->variant == 1)
