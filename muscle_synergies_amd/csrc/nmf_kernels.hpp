@@ -314,36 +314,12 @@ struct MatAddr {
   int lds_rows;       // stride of the cache (rows)
   int lds_used;       // rows of this matrix that live in the cache
   const real* h_lds;  // LDS copy of H ([K][MP]), read per tile by the h_in_lds instances
-  // Progress-balanced issue priority (experiment, -DHIPNMF_BALANCE).  The SIMD arbiter serves the older of its
-  // two waves first, so with equal tile counts the older wave finishes its pass ~30 % early and idles at the
-  // barrier while the younger one runs alone (tools/phase_timing.py: 44 k vs 60 k cycles).  Here each wave
-  // publishes how many tiles it has done and yields (s_setprio 0) while it is ahead of the wave it shares its
-  // SIMD with.  Result: both then finish at ~61 k cycles -- the SIMD is VALU-throughput-bound, one wave running
-  // alone keeps the pipe as busy as two, so fairness buys nothing and the extra instructions cost 5 %.
-  int* bal_prog;      // LDS [nw] tiles done per wave, or nullptr (no balancing)
-  int bal_me, bal_partner;
-  mutable int bal_count;
-  __device__ __forceinline__ void balance_tick() const {
-    if (bal_prog == nullptr) return;
-    ++bal_count;
-    if (lane == 0) __hip_atomic_store(bal_prog + bal_me, bal_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    const int other = __builtin_amdgcn_readfirstlane(
-        __hip_atomic_load(bal_prog + bal_partner, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-    if (bal_count < other)
-      __builtin_amdgcn_s_setprio(2);
-    else if (bal_count > other)
-      __builtin_amdgcn_s_setprio(0);
-    else
-      __builtin_amdgcn_s_setprio(1);
-  }
   __device__ __forceinline__ MatAddr(const real* Xb, long long ldx, const real* Wb, long long ldw, int T_, int m,
                                      real* lds_w_ = nullptr, int lds_rows_ = 0) {
     lds_w = lds_w_;
     lds_rows = lds_rows_;
     lds_used = lds_rows_;
     h_lds = nullptr;
-    bal_prog = nullptr;
-    bal_me = bal_partner = bal_count = 0;
     lane = threadIdx.x & (WAVE - 1);
     g = lane % G;
     T = T_;
@@ -839,7 +815,6 @@ __device__ __forceinline__ void rows_update_pass(const MatAddr<real, G, CH, K>& 
         touch_prev = __builtin_amdgcn_raw_buffer_load_b32(ma.xr, ok ? ma.xoff[0] : OOB, (unsigned)tb * ma.xrow_b, 0);
       }
       wbase += stride;
-      ma.balance_tick();
 #ifndef HIPNMF_NO_TILE_BARRIER
       __builtin_amdgcn_sched_barrier(0);  // keep the tiles' arithmetic from being interleaved (VGPR pressure)
 #endif
@@ -855,7 +830,6 @@ __device__ __forceinline__ void rows_update_pass(const MatAddr<real, G, CH, K>& 
         update_tile<real, G, CH, K, STAGE>(tiles[p], ma, h, hht, accA, accB, l1w, l2w, update_h, wbase);
       if constexpr (!STAGE) store_w<real, G, CH, K, WLDS>(tiles[p], ma, wbase);
       wbase += stride;
-      ma.balance_tick();
     }
   }
   if constexpr (x_row_major<G, CH>() && (HIPNMF_ROW_TOUCH) > 0) {
@@ -1238,28 +1212,6 @@ __global__ void __launch_bounds__((max_threads<real, G, CH, K>())) HIPNMF_OCC fi
   MatAddr<real, G, CH, K> ma(Xb, ldx, Wb, ldw, T, m, lds_w, lds_stride);
   ma.h_lds = s.H;
   ma.lds_used = lds_rows;
-#ifdef HIPNMF_BALANCE  // experiment, off: measured 8.0 vs 8.5 M matrix-it/s (see the comment in MatAddr)
-  {  // pair up the waves that share a SIMD (HW_ID.SIMD_ID = bits 5:4 of hardware register 4)
-    __shared__ int bal_prog[HIPNMF_MAXNT / WAVE], bal_simd[HIPNMF_MAXNT / WAVE];
-    const int wv = __builtin_amdgcn_readfirstlane(wave);
-    if (lane == 0) {
-      bal_prog[wv] = 0;
-      bal_simd[wv] = (int)__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4);
-    }
-    __syncthreads();
-    int partner = -1, sharing = 0;
-    for (int w = 0; w < nw; ++w)
-      if (w != wv && bal_simd[w] == bal_simd[wv]) {
-        partner = w;
-        ++sharing;
-      }
-    if (sharing == 1) {
-      ma.bal_prog = bal_prog;
-      ma.bal_me = wv;
-      ma.bal_partner = partner;
-    }
-  }
-#endif
   for (int t0 = 0; t0 < lds_rows; t0 += blockDim.x) {  // row t0 + tid is owned by this thread in every pass
     const int t = t0 + threadIdx.x;
 #pragma unroll
