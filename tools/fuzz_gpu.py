@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Randomised cross-check of the engine against the NumPy oracle: shapes, dtypes, memory orders, solver paths,
+losses, stop rule, regularisation, transform.  Development aid (uses oracle/, like the tests)."""
+import argparse, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import muscle_synergies_amd as ms
+from muscle_synergies_amd import _lib
+from muscle_synergies_amd.synth import emg_matrix, random_init
+from oracle import nmf_mu_oracle as orc
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--cases", type=int, default=80)
+ap.add_argument("--seed", type=int, default=0)
+a = ap.parse_args()
+rng = np.random.default_rng(a.seed)
+h = _lib.get_handle(0)
+bad = 0
+for case in range(a.cases):
+    dtype = np.float32 if rng.random() < 0.6 else np.float64
+    m = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 12, 15, 16, 17, 24, 32]))
+    k = int(rng.integers(1, min(m, 8) + 1))
+    T = int(rng.choice([1, 2, 63, 64, 65, 200, 511, 513, 1000, 2049, 5000, 12345]))
+    B = int(rng.choice([1, 1, 2, 3, 7]))
+    variant = int(rng.choice([0, 0, 1, 2, 3]))
+    order = rng.choice(["C", "F"])
+    loss = "kullback-leibler" if rng.random() < 0.2 else "frobenius"
+    tol = 0.0 if rng.random() < 0.7 else 1e-3
+    update_H = rng.random() < 0.85
+    reg = (0.0, 0.0, 0.0, 0.0) if rng.random() < 0.8 else tuple(float(v) for v in rng.random(4) * 0.05)
+    iters = int(rng.choice([1, 7, 30]))
+    if tol > 0:
+        iters = 60
+    Xs = [emg_matrix(1000 * case + b, T=T, m=m, k_true=min(5, m), dtype=dtype) for b in range(B)]
+    inits = [random_init(x, k, seed=case + b) for b, x in enumerate(Xs)]
+    Xb = np.stack([np.asarray(x, order=order) for x in Xs])
+    if order == "F":
+        Xb = np.stack([np.asfortranarray(x) for x in Xs])  # np.stack makes it C again: pass a transposed view instead
+        Xb = np.ascontiguousarray(np.stack(Xs).transpose(0, 2, 1)).transpose(0, 2, 1)
+    W0, H0 = np.stack([w for w, _ in inits]), np.stack([hh for _, hh in inits])
+    desc = f"case {case}: {np.dtype(dtype).name} B={B} T={T} m={m} k={k} order={order} variant={variant} loss={loss} tol={tol} upH={update_H} reg={reg != (0.0,)*4} it={iters}"
+    h.set_tuning(0, 0, variant)
+    try:
+        got = ms.fit_batched(Xb, W0, H0, max_iter=iters, tol=tol, update_H=update_H, beta_loss=loss,
+                             l1_reg_W=reg[0], l1_reg_H=reg[1], l2_reg_W=reg[2], l2_reg_H=reg[3])
+    except _lib.HipNmfError as e:
+        if variant == 3 and "not applicable" in str(e):
+            continue
+        print("ERROR", desc, e)
+        bad += 1
+        continue
+    finally:
+        h.set_tuning(0, 0, 0)
+    for b in range(B):
+        X = Xs[b]
+        if loss == "frobenius":
+            W, H, n_it = orc.fit_multiplicative_update(X, W0[b].copy(), H0[b].copy(), iters, tol, reg[0], reg[1], reg[2], reg[3],
+                                                       update_H=update_H)
+            err = np.linalg.norm(X.astype(np.float64) - W.astype(np.float64) @ H.astype(np.float64)) if dtype == np.float64 else float(
+                orc.beta_divergence_frobenius(X, W, H)) if hasattr(orc, "beta_divergence_frobenius") else np.linalg.norm(X - W @ H)
+        else:
+            W, H, n_it = orc.fit_multiplicative_update_kl(X, W0[b].copy(), H0[b].copy(), iters, tol, reg[0], reg[1], reg[2], reg[3],
+                                                          update_H=update_H)
+        xn = max(np.linalg.norm(X.astype(np.float64)), 1e-30)
+        d = np.linalg.norm(got.W[b].astype(np.float64) @ got.H[b].astype(np.float64) - W.astype(np.float64) @ H.astype(np.float64)) / xn
+        lim = 2e-5 if dtype == np.float32 else 1e-9
+        it_ok = int(got.n_iter[b]) == n_it or (tol > 0 and dtype == np.float32 and abs(int(got.n_iter[b]) - n_it) <= 10)
+        if not (d <= lim) or not it_ok or not np.isfinite(got.reconstruction_err[b]):
+            if it_ok or tol == 0:
+                print("MISMATCH", desc, f"b={b} rel dWH={d:.3e} n_iter {int(got.n_iter[b])} vs {n_it}")
+                bad += 1
+print(f"fuzz: {a.cases} cases, {bad} problems")
+sys.exit(1 if bad else 0)
