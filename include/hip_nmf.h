@@ -41,7 +41,10 @@ extern "C" {
 #define HIPNMF_ERR_UNSUPPORTED (-3) /* shape outside the compiled kernel set (m <= 32, k <= 8) */
 #define HIPNMF_ERR_NO_DEVICE (-4)
 
-/* memory layout of one X matrix */
+/* memory layout of one X matrix.  Either is accepted everywhere; which one the kernels stream WITHOUT a one-off
+ * conversion depends on the shape: fp32 with 7..8 or 9..16 channels (k <= 8 resp. k <= 5) reads ROW_MAJOR in place
+ * when n_features is exactly 8 resp. 16, ldx % 4 == 0 and X is 16-byte aligned; every other shape (and the ragged and
+ * shard entry points) reads CHANNEL_MAJOR in place when ldx % 4 == 0 and X is 16-byte aligned. */
 #define HIPNMF_X_ROW_MAJOR 0     /* X[t*ldx + j]  (T x m, C order; ldx >= m)                          */
 #define HIPNMF_X_CHANNEL_MAJOR 1 /* X[j*ldx + t]  (m x T; = DataFrame.to_numpy() F order; ldx >= T)   */
 
@@ -157,7 +160,8 @@ int hipnmf_shard_residual_f64(hipnmf_handle* h, const hipnmf_problem* p, const d
  *     ->  normalize (analysis.py:510-525: divide each channel by its max |value|)
  * Every stage is optional.  raw: [B] matrices in the layout given by x_layout / ldx / x_batch_stride
  * (same meaning as in hipnmf_problem); out: [B][n_channels][n_out ? n_out : n_samples], channel-major
- * (= the engine's native X layout, so the result can be fed to hipnmf_fit_batched_* without a copy).
+ * (fed to hipnmf_fit_batched_* as HIPNMF_X_CHANNEL_MAJOR: in place for the channel-major kernels, one conversion
+ * per fit for the row-major ones).
  */
 typedef struct hipnmf_envelope_params {
   int32_t struct_size;    /* = sizeof(hipnmf_envelope_params)                                          */

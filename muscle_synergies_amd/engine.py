@@ -122,7 +122,8 @@ def fit_batched(X, W0, H0, *, max_iter: int = 200, tol: float = 1e-4, check_ever
     Args:
         X: ``[B, T, m]`` (or ``[T, m]``) non-negative float32/float64, NumPy or torch, any dense layout
            (C order = row-major; a transposed view of a ``[B, m, T]`` array = channel-major, the
-           engine's native streaming layout and what ``DataFrame.to_numpy()`` produces).
+           layout ``DataFrame.to_numpy()`` produces).  Whichever order the kernel for this shape streams (see
+           ``include/hip_nmf.h``) is used in place; the other one costs a single conversion per fit.
         W0: ``[B, T, k]`` initial activations; H0: ``[B, k, m]`` initial synergies (``init='custom'``).
         max_iter, tol: as ``sklearn.decomposition.NMF``; ``tol=0`` runs exactly ``max_iter`` updates.
         update_H: ``False`` keeps H fixed (``NMF.transform``).
