@@ -61,7 +61,13 @@ const KernelSet<float>* select_kernels<float>(int m, int k, bool row_major_ok) {
   return nullptr;
 }
 template <>
-const KernelSet<double>* select_kernels<double>(int m, int k, bool) {
+const KernelSet<double>* select_kernels<double>(int m, int k, bool row_major_ok) {
+  static const bool g1 = [] {
+    const char* e = getenv("HIPNMF_G1C16");
+    return !(e && atoi(e) == 0);
+  }();
+  // fp64 with 7..8 channels (the reference's own recordings: 8 muscles, float64 frames) and k <= 4: row per lane
+  if (g1 && row_major_ok && m > 6 && m <= 8 && k <= 4) return kernels_f64_g1c8(k);
   if (m <= 4) return kernels_f64_g1c4(k);
   if (m <= 8) return kernels_f64_g2c4(k);
   if (m <= 16) return kernels_f64_g4c4(k);

@@ -53,6 +53,7 @@ HIPNMF_DECLARE_TABLE(float, f32_g2c8)
 HIPNMF_DECLARE_TABLE(float, f32_g1c16)
 HIPNMF_DECLARE_TABLE(float, f32_g1c8)
 HIPNMF_DECLARE_TABLE(float, f32_g4c8)
+HIPNMF_DECLARE_TABLE(double, f64_g1c8)
 HIPNMF_DECLARE_TABLE(double, f64_g1c4)
 HIPNMF_DECLARE_TABLE(double, f64_g2c4)
 HIPNMF_DECLARE_TABLE(double, f64_g4c4)

@@ -214,7 +214,7 @@ __device__ __forceinline__ void buf_store(rsrc_t r, unsigned voff, unsigned soff
 // mapping on 2048 x (16 x 10 000), k = 5 (profiles/README.md).
 template <int G, int CH>
 constexpr bool x_row_major() {
-  return G == 1 && (CH == 16 || CH == 8);  // (1, 8): fp32, 7..8 channels, any k <= 8 (2 x 8 x 8 = 128 VGPRs)
+  return G == 1 && (CH == 16 || CH == 8);  // (1, 8): 7..8 channels; fp32 any k <= 8, fp64 k <= 4
 }
 // Row-per-lane instances with k >= 4: the last HIPNMF_ROW_HLDS rows of H are re-read from LDS every tile (wave-
 // uniform 16-byte broadcast reads, issued before the tile's X is waited for) instead of living in VGPRs; the 32
@@ -251,7 +251,8 @@ constexpr bool h_in_lds() {
 
 template <typename real, int G, int CH, int K>
 constexpr int max_threads() {
-  if constexpr (x_row_major<G, CH>() && sizeof(real) == 4 && K * CH <= 80) return HIPNMF_MAXNT;  // H + sums <= 160 VGPRs
+  if constexpr (x_row_major<G, CH>() && K * CH * (int)(sizeof(real) / 4) <= (sizeof(real) == 4 ? 80 : 64))
+    return HIPNMF_MAXNT;  // H + sums fit two waves per SIMD (fp32: k*CH <= 80; fp64 (1,8): k <= 4)
   constexpr int words = (int)(sizeof(real) / 4);
   constexpr int est = words * ((h_in_lds<G, CH>() ? 1 : 2) * K * CH + K * (K + 1) / 2 + 3 * G * CH + G * K + 40 +
                                (h_in_lds<G, CH>() ? 24 : 0));
