@@ -723,7 +723,8 @@ int hipnmf_set_stream(hipnmf_handle* h, void* hip_stream) {
 size_t hipnmf_workspace_bytes(const hipnmf_problem* p, int elem_size) {
   if (!p || (elem_size != 4 && elem_size != 8)) return 0;
   const long long ld = round_up(p->n_samples, 64);
-  size_t bytes = (size_t)elem_size * (size_t)p->batch * (size_t)(p->n_features + p->n_components) * (size_t)ld;
+  const int m_pad = p->n_features <= 8 ? 8 : (p->n_features <= 16 ? 16 : p->n_features);  // row-major copies pad the rows
+  size_t bytes = (size_t)elem_size * (size_t)p->batch * (size_t)(m_pad + p->n_components) * (size_t)ld;
   bytes += (size_t)elem_size * (size_t)p->batch * 4096 * 2;  // slice partials upper bound
   return bytes;
 }
