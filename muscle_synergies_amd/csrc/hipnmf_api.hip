@@ -181,7 +181,7 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
   HIP_TRY(hipSetDevice(h->device));
   const int B = p->batch, m = p->n_features, k = p->n_components;
   const long long T = p->n_samples;
-  const KernelSet<real>* ks = select_kernels<real>(m, k, !ragged);
+  const KernelSet<real>* ks = select_kernels<real>(m, k, true);
   if (ks && ks->row_major && (T + 64) * (long long)ks->MP * (long long)sizeof(real) >= (1LL << 31))
     ks = select_kernels<real>(m, k, false);  // rows padded to MP channels would not fit the 32-bit addressing
   if (!ks) return fail(HIPNMF_ERR_UNSUPPORTED, "no kernel for n_features=%d n_components=%d", m, k);
@@ -267,6 +267,35 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
     return fail(HIPNMF_ERR_UNSUPPORTED, "cooperative path not applicable (batch=%d, n_samples=%lld)", B, T);
   const bool coop = coop_S > 0;
 
+  // Ragged batch on a row-major instance: every distinct packed channel-major matrix (restarts of one trial share
+  // theirs) is converted once into row-major rows of MP values; the kernel then gets {T, row-major offset, ldw, woff}.
+  struct RaggedSrc {
+    long long xoff, T, ld, roff;
+  };
+  std::vector<RaggedSrc> rsrc;
+  std::vector<long long> rdesc;
+  long long ragged_x_elems = 0;
+  if (ragged && ks->row_major) {
+    rdesc.resize(4 * (size_t)B);
+    for (int b = 0; b < B; ++b) {
+      const int64_t* d = ragged + 4 * (size_t)b;
+      size_t idx = rsrc.size();
+      for (size_t q = 0; q < rsrc.size(); ++q)
+        if (rsrc[q].xoff == d[1] && rsrc[q].T == d[0] && rsrc[q].ld == d[2]) {
+          idx = q;
+          break;
+        }
+      if (idx == rsrc.size()) {
+        rsrc.push_back({(long long)d[1], (long long)d[0], (long long)d[2], ragged_x_elems});
+        ragged_x_elems += (long long)d[0] * ks->MP;
+      }
+      rdesc[4 * (size_t)b + 0] = d[0];
+      rdesc[4 * (size_t)b + 1] = rsrc[idx].roff;
+      rdesc[4 * (size_t)b + 2] = d[2];
+      rdesc[4 * (size_t)b + 3] = d[3];
+    }
+  }
+
   // ---- workspace carve-up -----------------------------------------------------------------------
   const size_t o_desc_bytes = ragged ? sizeof(long long) * 4 * (size_t)B : 0;
   // canonical X: channel-major with an aligned leading dimension, or -- for the row-per-lane instance -- row-major
@@ -274,7 +303,7 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
   const bool aligned = (reinterpret_cast<uintptr_t>(X) % 16) == 0 && ((p->x_batch_stride * (long long)sizeof(real)) % 16) == 0;
   bool x_inplace;
   if (ks->row_major)
-    x_inplace = p->x_layout == HIPNMF_X_ROW_MAJOR && m == ks->MP && (p->ldx % 4) == 0 && aligned &&
+    x_inplace = !ragged && p->x_layout == HIPNMF_X_ROW_MAJOR && m == ks->MP && (p->ldx % 4) == 0 && aligned &&
                 (long long)(T + 64) * p->ldx * (long long)sizeof(real) < (1LL << 31);
   else
     x_inplace = ragged || (p->x_layout == HIPNMF_X_CHANNEL_MAJOR && (p->ldx % ks->G) == 0 && (T % ks->G) == 0 && aligned);
@@ -288,7 +317,8 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
     return o;
   };
   const size_t x_elems = ks->row_major ? (size_t)T * (size_t)ldx_c : (size_t)m * (size_t)ldx_c;  // per matrix
-  const size_t o_x = x_inplace ? 0 : carve(sizeof(real) * (size_t)B * x_elems);
+  const size_t o_x = x_inplace ? 0
+                               : carve(sizeof(real) * (ragged ? (size_t)ragged_x_elems + 64 : (size_t)B * x_elems));
   const size_t o_w = w_inplace ? 0 : carve(sizeof(real) * (size_t)B * k * ldw_c);
   const size_t o_desc = ragged ? carve(o_desc_bytes) : 0;
   size_t o_part = 0, o_sums = 0, o_col = 0, o_state = 0;
@@ -319,7 +349,13 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
   } else {
     real* xc = reinterpret_cast<real*>(ws + o_x);
     dim3 blk(32, 8);
-    if (ks->row_major) {
+    if (ks->row_major && ragged) {
+      for (const RaggedSrc& r : rsrc) {
+        dim3 grd((unsigned)((r.T + 31) / 32), (unsigned)((ldx_c + 31) / 32), 1u);
+        hipLaunchKernelGGL(x_to_row_major_kernel<real>, grd, blk, 0, st, X + r.xoff, 0LL, r.ld, (int)HIPNMF_X_CHANNEL_MAJOR,
+                           xc + r.roff, 0LL, (int)ldx_c, (int)r.T, m);
+      }
+    } else if (ks->row_major) {
       dim3 grd((unsigned)((T + 31) / 32), (unsigned)((ldx_c + 31) / 32), (unsigned)B);
       hipLaunchKernelGGL(x_to_row_major_kernel<real>, grd, blk, 0, st, X, (long long)p->x_batch_stride,
                          (long long)p->ldx, (int)p->x_layout, xc, (long long)x_elems, (int)ldx_c, (int)T, m);
@@ -346,7 +382,8 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
     a.ldw = ldw_c;
   }
   if (ragged) {  // descriptors to the device (pageable host memory: the copy is complete on return)
-    HIP_TRY(hipMemcpyAsync(ws + o_desc, ragged, o_desc_bytes, hipMemcpyHostToDevice, st));
+    const void* src = ks->row_major ? static_cast<const void*>(rdesc.data()) : static_cast<const void*>(ragged);
+    HIP_TRY(hipMemcpyAsync(ws + o_desc, src, o_desc_bytes, hipMemcpyHostToDevice, st));
     a.ragged = reinterpret_cast<const long long*>(ws + o_desc);
   }
   a.H = H;

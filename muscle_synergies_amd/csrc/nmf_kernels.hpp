@@ -1199,7 +1199,8 @@ __global__ void __launch_bounds__((max_threads<real, G, CH, K>())) HIPNMF_OCC fi
     const long long* d = a.ragged + 4LL * b;
     T = (int)d[0];
     Xb = a.X + d[1];
-    ldx = ldw = d[2];
+    ldw = d[2];
+    if constexpr (!x_row_major<G, CH>()) ldx = d[2];  // row-major instances: rows of a.ldx (= MP) values, d[1] counts them
     Wb = a.W + d[3];
   }
   const int m = a.m;
