@@ -43,8 +43,9 @@ extern "C" {
 
 /* memory layout of one X matrix.  Either is accepted everywhere; which one the kernels stream WITHOUT a one-off
  * conversion depends on the shape: fp32 with 7..8 or 9..16 channels (k <= 8 resp. k <= 5) and fp64 with 7..8 channels
- * (k <= 4) read ROW_MAJOR in place when n_features is exactly 8 resp. 16, ldx % 4 == 0 and X is 16-byte aligned; every other shape (and the ragged and
- * shard entry points) reads CHANNEL_MAJOR in place when ldx % 4 == 0 and X is 16-byte aligned. */
+ * (k <= 4) read ROW_MAJOR in place when n_features is exactly 8 resp. 16, ldx % 4 == 0 and X is 16-byte aligned; every other shape (and the shard
+ * entry points) reads CHANNEL_MAJOR in place when ldx % 4 == 0 and X is 16-byte aligned.  The ragged entry points take
+ * channel-major packed matrices and convert each distinct one once per fit where a row-major kernel is used. */
 #define HIPNMF_X_ROW_MAJOR 0     /* X[t*ldx + j]  (T x m, C order; ldx >= m)                          */
 #define HIPNMF_X_CHANNEL_MAJOR 1 /* X[j*ldx + t]  (m x T; = DataFrame.to_numpy() F order; ldx >= T)   */
 
