@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised cross-check of the engine against the NumPy oracle: shapes, dtypes, memory orders, solver paths,
-losses, stop rule, regularisation, transform.  Development aid (uses oracle/, like the tests)."""
+losses, stop rule, regularisation, transform.  Part of the test infrastructure (it imports oracle/); run by tests/test_gpu_fuzz.py or by hand."""
 import argparse, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
