@@ -172,7 +172,10 @@ __global__ void __launch_bounds__(256) emg_output_kernel(EnvArgs a) {
 // Traffic per sample (fp32, W << tile): read x once for the mean (if centred), once (1 + W/tile) for the
 // windows, write the output once (+ read/write it once more when normalising).
 // =================================================================================================
-constexpr int ENV_TILE = 2048;
+#ifndef HIPNMF_ENV_TILE
+#define HIPNMF_ENV_TILE 2048  // measured 1024 / 2048 / 4096 outputs per tile: 2.25 / 2.08 / 2.47 ms (1024 x 16 x 20 000 fp32)
+#endif
+constexpr int ENV_TILE = HIPNMF_ENV_TILE;
 
 // exclusive block scan of n (<= capacity) fp64 values in LDS, in place: buf[i] <- sum_{j<i} buf[j]; buf[n] <- total
 __device__ __forceinline__ void lds_exclusive_scan(double* buf, int n, double* wave_tot /* [blockDim/64] */) {
