@@ -21,6 +21,23 @@ struct EnvArgs {
   int T, m, window, zero_center, n_out, normalize;
 };
 
+// per-thread part of a strided sum over x[0 .. T): four independent accumulators so that four loads are in flight
+// (a single running sum serialises on the load latency); fixed order: ((s0 + s1) + (s2 + s3))
+template <typename real>
+__device__ __forceinline__ double strided_sum(const real* __restrict__ x, int T, int first, int stride) {
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int i = first;
+  for (; i + 3 * stride < T; i += 4 * stride) {
+    const real a0 = x[i], a1 = x[i + stride], a2 = x[i + 2 * stride], a3 = x[i + 3 * stride];
+    s0 += (double)a0;
+    s1 += (double)a1;
+    s2 += (double)a2;
+    s3 += (double)a3;
+  }
+  for (; i < T; i += stride) s0 += (double)x[i];
+  return (s0 + s1) + (s2 + s3);
+}
+
 __device__ __forceinline__ double block_sum(double v, double* scratch /* [blockDim/64] */) {
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -55,8 +72,7 @@ __global__ void __launch_bounds__(256) emg_prefix_kernel(EnvArgs a) {
   double* __restrict__ ps = a.prefix + ((long long)b * a.m + ch) * ((long long)a.T + 1);
   double mean = 0.0;
   if (a.zero_center) {
-    double s = 0.0;
-    for (int i = threadIdx.x; i < a.T; i += blockDim.x) s += (double)x[i];
+    const double s = strided_sum<real>(x, a.T, threadIdx.x, blockDim.x);
     mean = block_sum(s, scratch) / (double)a.T;
   }
   if (threadIdx.x == 0) {
@@ -219,8 +235,7 @@ __global__ void __launch_bounds__(256) emg_fused_kernel(EnvArgs a) {
   real* __restrict__ o = static_cast<real*>(a.out) + cidx * (long long)n_out;
   double mean = 0.0;
   if (a.zero_center) {
-    double s = 0.0;
-    for (int i = threadIdx.x; i < T; i += blockDim.x) s += (double)x[i];
+    const double s = strided_sum<real>(x, T, threadIdx.x, blockDim.x);
     mean = block_sum(s, scratch) / (double)T;
   }
   const int hi = W > 0 ? (W - 1) / 2 : 0, lo = W > 0 ? (W - 1) - hi : 0;

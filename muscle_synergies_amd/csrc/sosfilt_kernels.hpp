@@ -77,8 +77,17 @@ __global__ void __launch_bounds__(256) sos_stats_kernel(SosArgs a, double* __res
       static_cast<const real*>(a.x) + (long long)(s / a.m) * a.bstride + (long long)(s % a.m) * a.ld;
   double mean = 0.0;
   if (a.zero_center) {
-    double acc = 0.0;
-    for (int i = threadIdx.x; i < a.T; i += 256) acc += (double)xr[i];
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;  // four loads in flight; fixed order of the sums
+    int i = threadIdx.x;
+    for (; i + 768 < a.T; i += 1024) {
+      const real a0 = xr[i], a1 = xr[i + 256], a2 = xr[i + 512], a3 = xr[i + 768];
+      s0 += (double)a0;
+      s1 += (double)a1;
+      s2 += (double)a2;
+      s3 += (double)a3;
+    }
+    for (; i < a.T; i += 256) s0 += (double)xr[i];
+    double acc = (s0 + s1) + (s2 + s3);
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
     if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = acc;
