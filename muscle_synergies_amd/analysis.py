@@ -13,6 +13,7 @@ Plotting, filtering and the Vicon loader of the reference are out of scope and n
 
 from __future__ import annotations
 
+import warnings
 from collections import OrderedDict
 from dataclasses import dataclass
 from typing import Any, Mapping, Optional, Union
@@ -56,12 +57,22 @@ def vaf(original_df: pandas.DataFrame, transformed_signal=None, components=None,
     return pandas.DataFrame({label: [value] for label, value in zip(labels, values)})
 
 
-def _make_model(n_components: int, **nmf_kwargs):
-    """The seam: HIP engine for the mu/Frobenius path, sklearn for everything else."""
-    if HipNMF.supports(**nmf_kwargs):
+def _make_model(n_components: int, n_features: Optional[int] = None, **nmf_kwargs):
+    """The seam: HIP engine for the mu path at the shapes it is compiled for, sklearn for everything else.
+
+    ``solver='mu'`` with more than 32 muscles (e.g. HD-EMG grids) or more than 8 synergies is outside the
+    compiled kernel set; such a call goes to scikit-learn like any other unsupported configuration (the
+    reference works for every shape, ``analysis.py:862-863``), with a warning saying so.
+    """
+    if HipNMF.supports(n_features=n_features, n_components=n_components, **nmf_kwargs):
         return HipNMF(n_components=n_components, **nmf_kwargs)
     from sklearn.decomposition import NMF  # the reference's own behaviour (default solver 'cd')
 
+    if HipNMF.supports(**nmf_kwargs):
+        warnings.warn(
+            f"solver='mu' with {n_features} features / {n_components} components is outside the HIP engine's "
+            f"compiled shapes (<= {HipNMF.MAX_FEATURES} features, <= {HipNMF.MAX_COMPONENTS} components): "
+            "running scikit-learn on the CPU instead", RuntimeWarning, stacklevel=3)
     nmf_kwargs.pop("device", None)
     return NMF(n_components=n_components, **nmf_kwargs)
 
@@ -80,7 +91,7 @@ def _check_component_range(df: pandas.DataFrame, n_components: int, max_componen
 
 def _single_run(df: pandas.DataFrame, n_components: int, **nmf_kwargs) -> SynergyRunResult:
     """One factorisation + its VAF row (``analysis.py:866-882``)."""
-    model = _make_model(n_components, **nmf_kwargs)
+    model = _make_model(n_components, n_features=len(df.columns), **nmf_kwargs)
     transformed = model.fit_transform(df)
     vaf_row = vaf(df, transformed_signal=transformed, components=model.components_)
     comps = pandas.DataFrame(model.components_, columns=df.columns)

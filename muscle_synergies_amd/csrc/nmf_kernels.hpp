@@ -1375,13 +1375,19 @@ __global__ void __launch_bounds__((max_threads<real, G, CH, K>())) HIPNMF_OCC fi
 // barrier number `n` (1, 2, ...) among the `S` workgroups that share `counter`; false after an abort
 __device__ __forceinline__ bool coop_barrier(unsigned* counter, unsigned* abort_flag, unsigned S, unsigned n) {
   __shared__ int ok_sh;
-  __syncthreads();  // every thread's global stores of this phase are complete (s_waitcnt vmcnt(0) + s_barrier)
+  // Every storing wave waits for its own record stores to be acknowledged BEFORE the workgroup barrier: on gfx950
+  // __syncthreads() alone is an s_barrier without a vmcnt wait (the sc1 stores could still be in flight when lane 0
+  // bumps the counter, and a peer would then sum a stale record).  This is the publish form the hardware guide
+  // lists as validated: sc1 stores -> per-wave vmcnt(0) -> workgroup barrier -> one lane's agent-scope atomic add;
+  // consumers poll with sc1 loads, pass a workgroup barrier and read the records with sc1 loads only.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
   if (threadIdx.x == 0) {
     int ok = 1;
     // No release / acquire fences: on a multi-XCD part they mean an L2 write-back / invalidate per barrier
     // (measured ~8 us).  The records exchanged around the barrier are written and read with device-scope
-    // relaxed atomics (straight to / from the coherence point), the __syncthreads above has waited for those
-    // stores to be acknowledged, and the counter itself is only ever touched atomically.
+    // relaxed atomics (sc1: straight to / from the coherence point), every wave has waited for its stores to be
+    // acknowledged before the barrier above, and the counter itself is only ever touched atomically.
     __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned target = S * n;
     unsigned spins = 0;
@@ -1664,7 +1670,8 @@ __global__ void __launch_bounds__((max_threads<real, G, CH, K>())) HIPNMF_OCC sl
   }
   __shared__ int is_last;
   __shared__ real scratch[HIPNMF_MAXNT];
-  __syncthreads();  // the record's stores are acknowledged
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's record stores are acknowledged (see coop_barrier)
+  __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned ticket = __hip_atomic_fetch_add(a.sync + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     is_last = ticket == (unsigned)a.S - 1u;

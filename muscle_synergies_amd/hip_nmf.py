@@ -96,10 +96,19 @@ class HipNMF:
         return f"HipNMF(n_components={self.n_components!r}, init={self.init!r}, tol={self.tol!r}, max_iter={self.max_iter!r})"
 
     # -- validation --------------------------------------------------------------------------------
+    MAX_FEATURES = 32    # widest lane mapping compiled into libhip_nmf.so (HIPNMF_ERR_UNSUPPORTED beyond)
+    MAX_COMPONENTS = 8
+
     @staticmethod
-    def supports(solver="cd", beta_loss="frobenius", **_ignored) -> bool:
-        """True when these NMF kwargs select the path this engine implements."""
-        return solver == "mu" and beta_loss in ("frobenius", 2, 2.0, "kullback-leibler", 1, 1.0)
+    def supports(solver="cd", beta_loss="frobenius", n_features=None, n_components=None, **_ignored) -> bool:
+        """True when these NMF kwargs (and, when given, this shape) select the path this engine implements."""
+        if not (solver == "mu" and beta_loss in ("frobenius", 2, 2.0, "kullback-leibler", 1, 1.0)):
+            return False
+        if n_features is not None and n_features > HipNMF.MAX_FEATURES:
+            return False
+        if n_components is not None and n_components > HipNMF.MAX_COMPONENTS:
+            return False
+        return True
 
     def _check_params(self):
         if self.solver != "mu":

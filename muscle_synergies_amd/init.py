@@ -1,12 +1,23 @@
 """Host-side initialisation of W and H (not part of the hot loop).
 
 ``find_synergies`` never passes ``init`` unless the user does, so the reference's default path is
-sklearn's ``_initialize_nmf`` with ``init=None`` -> NNDSVDa (``sklearn/decomposition/_nmf.py:221-373``)
-on top of a randomized SVD (``sklearn/utils/extmath.py:287-372, 531-605, 895-953``).  This module
-implements those published algorithms with NumPy/SciPy so that the product does not depend on
-sklearn's private API; drawing from the same ``RandomState`` in the same order makes the result match
-sklearn's for a given ``random_state`` (checked in ``tests/test_init.py`` against fixtures captured
-from sklearn 1.7.2).
+scikit-learn's ``_initialize_nmf`` with ``init=None`` -> NNDSVDa (``sklearn/decomposition/_nmf.py:221-373``)
+on top of a randomized SVD (``sklearn/utils/extmath.py:287-372, 531-605, 895-953``).
+
+:func:`initialize_nmf` therefore **delegates to scikit-learn's own function whenever scikit-learn is
+importable** ("reuse sklearn's own ``_initialize_nmf`` on the host") -- the reference
+depends on scikit-learn anyway, and that is the only way to be bit-identical with it for a given
+``random_state``.  Without scikit-learn (a GPU node with the library only) the built-in restatement below
+is used.
+
+Attribution: the built-in path restates algorithms published in scikit-learn (BSD-3-Clause, Copyright (c)
+2007-2024 The scikit-learn developers): NNDSVD / NNDSVDa / NNDSVDar after C. Boutsidis and E. Gallopoulos,
+"SVD based initialization: A head start for nonnegative matrix factorization", Pattern Recognition 41
+(2008), and the randomized range finder of N. Halko, P.-G. Martinsson and J. Tropp, "Finding structure
+with randomness", SIAM Review 53 (2011), in the configuration ``_initialize_nmf`` uses.  The sequence of
+``RandomState`` draws and LAPACK calls is fixed by that algorithm (drawing in another order would give a
+different, equally valid but non-matching start); ``tests/test_init.py`` pins both paths to vectors captured
+from scikit-learn 1.7.2 (fixture G4).
 """
 
 from __future__ import annotations
@@ -28,85 +39,130 @@ def check_random_state(seed):
     raise ValueError(f"{seed!r} cannot be used to seed a numpy.random.RandomState instance")
 
 
-def _norm(x):
-    """Dot-product based Euclidean norm (``_nmf.py:42-50``)."""
-    x = np.ravel(x)
-    return np.sqrt(np.dot(x, x))
+def _sklearn_initialize():
+    """scikit-learn's ``_initialize_nmf`` or None when scikit-learn (or that private name) is unavailable."""
+    try:
+        from sklearn.decomposition._nmf import _initialize_nmf
+    except Exception:  # not installed, or a future release moved the helper
+        return None
+    return _initialize_nmf
 
 
-def _svd_flip_u(u, v):
-    """Sign convention on the columns of u (``extmath.py:895-953``, u_based_decision=True)."""
-    idx = np.argmax(np.abs(u.T), axis=1)
-    signs = np.sign(u.T[np.arange(u.shape[1]), idx])
-    u *= signs[np.newaxis, :]
-    v *= signs[:, np.newaxis]
-    return u, v
-
-
-def _svd_flip_v(u, v):
-    idx = np.argmax(np.abs(v), axis=1)
-    signs = np.sign(v[np.arange(v.shape[0]), idx])
-    u *= signs[np.newaxis, :]
-    v *= signs[:, np.newaxis]
-    return u, v
+def _fix_signs(left, right_t, by_left):
+    """Deterministic signs of singular vector pairs (sklearn ``svd_flip``): the entry of largest magnitude of
+    each left vector (``by_left``) or of each right vector is made positive."""
+    ref = left.T if by_left else right_t
+    pick = np.argmax(np.abs(ref), axis=1)
+    sign = np.sign(ref[np.arange(ref.shape[0]), pick])
+    left *= sign[np.newaxis, :]
+    right_t *= sign[:, np.newaxis]
+    return left, right_t
 
 
 def randomized_svd(M, n_components, random_state, n_oversamples=10):
-    """Halko et al. randomized SVD as configured by ``_initialize_nmf`` (all defaults)."""
+    """Leading singular triplets by a randomized range finder with LU-normalised power iterations, configured
+    like ``_initialize_nmf`` configures it (k + 10 Gaussian probes, 7 iterations when k < 0.1 min(shape) else 4,
+    the wide case handled on the transpose).  Draws ``rng.normal`` once, in the same shape as sklearn."""
     rng = check_random_state(random_state)
-    n_random = n_components + n_oversamples
-    n_samples, n_features = M.shape
-    n_iter = 7 if n_components < 0.1 * min(M.shape) else 4
-    transpose = n_samples < n_features
-    A = M.T if transpose else M
-    Q = rng.normal(size=(A.shape[1], n_random)).astype(A.dtype, copy=False)
-    for _ in range(n_iter):  # LU-normalised power iterations (n_iter > 2)
-        Q, _ = linalg.lu(A @ Q, permute_l=True, check_finite=False)
-        Q, _ = linalg.lu(A.T @ Q, permute_l=True, check_finite=False)
-    Q, _ = linalg.qr(A @ Q, mode="economic", check_finite=False)
-    B = Q.T @ A
-    Uhat, s, Vt = linalg.svd(B, full_matrices=False, lapack_driver="gesdd")
-    U = Q @ Uhat
-    if not transpose:
-        U, Vt = _svd_flip_u(U, Vt)
-        return U[:, :n_components], s[:n_components], Vt[:n_components, :]
-    U, Vt = _svd_flip_v(U, Vt)
-    return Vt[:n_components, :].T, s[:n_components], U[:, :n_components].T
+    rows, cols = M.shape
+    passes = 7 if n_components < 0.1 * min(rows, cols) else 4
+    wide = rows < cols
+    A = M.T if wide else M
+    basis = rng.normal(size=(A.shape[1], n_components + n_oversamples)).astype(A.dtype, copy=False)
+    for _ in range(passes):
+        basis, _ = linalg.lu(A @ basis, permute_l=True, check_finite=False)
+        basis, _ = linalg.lu(A.T @ basis, permute_l=True, check_finite=False)
+    basis, _ = linalg.qr(A @ basis, mode="economic", check_finite=False)
+    small_u, sing, vt = linalg.svd(basis.T @ A, full_matrices=False, lapack_driver="gesdd")
+    u = basis @ small_u
+    u, vt = _fix_signs(u, vt, by_left=not wide)
+    k = n_components
+    if wide:  # triplets of M from those of M^T
+        return vt[:k].T, sing[:k], u[:, :k].T
+    return u[:, :k], sing[:k], vt[:k]
 
 
 def exact_svd(M, n_components):
-    """Leading singular triplets from LAPACK (gesdd) with sklearn's sign convention (``svd_flip``)."""
-    U, s, Vt = linalg.svd(M, full_matrices=False, lapack_driver="gesdd")
-    if M.shape[0] >= M.shape[1]:
-        U, Vt = _svd_flip_u(U, Vt)
-    else:
-        U, Vt = _svd_flip_v(U, Vt)
-    return U[:, :n_components], s[:n_components], Vt[:n_components, :]
+    """Leading singular triplets from LAPACK (gesdd) with the same sign convention."""
+    u, sing, vt = linalg.svd(M, full_matrices=False, lapack_driver="gesdd")
+    u, vt = _fix_signs(u, vt, by_left=M.shape[0] >= M.shape[1])
+    return u[:, :n_components], sing[:n_components], vt[:n_components]
 
 
-def initialize_nmf(X, n_components, init=None, eps=1e-6, random_state=None, svd_solver="randomized"):
-    """W0 (T x k), H0 (k x m) in ``X.dtype``; same options and error messages as sklearn.
+def _nndsvd_factors(U, S, Vt, eps):
+    """Boutsidis-Gallopoulos non-negative factors from singular triplets, all components at once.
 
-    ``svd_solver='randomized'`` is sklearn's behaviour; ``'exact'`` takes the triplets from a full LAPACK SVD
-    (what the on-device :func:`nndsvd_init_batched` reproduces through the Gram matrix)."""
+    Component 0: ``sqrt(s0) |u0|``, ``sqrt(s0) |v0|``.  Component j > 0: of the positive parts (u+, v+) and the
+    negative parts (u-, v-) keep the pair with the larger ``|u.||v.|``, normalised, scaled by
+    ``sqrt(s_j |u.||v.|)``.  Entries below ``eps`` become 0."""
+    k = S.shape[0]
+    up, un = np.maximum(U, 0), np.maximum(-U, 0)          # T x k
+    vp, vn = np.maximum(Vt, 0), np.maximum(-Vt, 0)        # k x m
+    nrm_up = np.sqrt(np.einsum("tj,tj->j", up, up))
+    nrm_un = np.sqrt(np.einsum("tj,tj->j", un, un))
+    nrm_vp = np.sqrt(np.einsum("jm,jm->j", vp, vp))
+    nrm_vn = np.sqrt(np.einsum("jm,jm->j", vn, vn))
+    mass_p, mass_n = nrm_up * nrm_vp, nrm_un * nrm_vn
+    take_p = mass_p > mass_n
+    W = np.empty_like(U)
+    H = np.empty_like(Vt)
+    for j in range(k):
+        if j == 0:
+            W[:, 0] = np.sqrt(S[0]) * np.abs(U[:, 0])
+            H[0] = np.sqrt(S[0]) * np.abs(Vt[0])
+            continue
+        if take_p[j]:
+            scale = np.sqrt(S[j] * mass_p[j])
+            W[:, j] = scale * (up[:, j] / nrm_up[j])
+            H[j] = scale * (vp[j] / nrm_vp[j])
+        else:
+            scale = np.sqrt(S[j] * mass_n[j])
+            W[:, j] = scale * (un[:, j] / nrm_un[j])
+            H[j] = scale * (vn[j] / nrm_vn[j])
+    W[W < eps] = 0
+    H[H < eps] = 0
+    return W, H
+
+
+_INITS = (None, "random", "nndsvd", "nndsvda", "nndsvdar")
+
+
+def initialize_nmf(X, n_components, init=None, eps=1e-6, random_state=None, svd_solver="randomized",
+                   backend="auto"):
+    """W0 (T x k), H0 (k x m) in ``X.dtype``; same options and error messages as sklearn's ``_initialize_nmf``.
+
+    ``backend='auto'`` calls scikit-learn's function when it is importable and the request is one it serves
+    (``svd_solver='randomized'``), ``'builtin'`` forces the restatement in this module, ``'sklearn'`` insists on
+    scikit-learn.  ``svd_solver='exact'`` (built-in only) takes the triplets from a full LAPACK SVD -- what the
+    on-device :func:`nndsvd_init_batched` reproduces through the Gram matrix."""
+    if backend not in ("auto", "builtin", "sklearn"):
+        raise ValueError(f"backend must be 'auto', 'builtin' or 'sklearn' (got {backend!r})")
     X = np.asarray(X)
+    if backend != "builtin" and svd_solver == "randomized" and init in _INITS:
+        sk_init = _sklearn_initialize()
+        if sk_init is not None:
+            return sk_init(X, n_components, init=init, eps=eps, random_state=random_state)
+        if backend == "sklearn":
+            raise ImportError("scikit-learn's _initialize_nmf is not importable")
+    elif backend == "sklearn" and svd_solver != "randomized":
+        raise ValueError("backend='sklearn' implements svd_solver='randomized' only")
+
     if (X < 0).any():
         raise ValueError("Negative values in data passed to NMF initialization.")
     n_samples, n_features = X.shape
-    if init is not None and init != "random" and n_components > min(n_samples, n_features):
+    full_rank_ok = n_components <= min(n_samples, n_features)
+    if init is not None and init != "random" and not full_rank_ok:
         raise ValueError(
             "init = '{}' can only be used when n_components <= min(n_samples, n_features)".format(init)
         )
     if init is None:
-        init = "nndsvda" if n_components <= min(n_samples, n_features) else "random"
+        init = "nndsvda" if full_rank_ok else "random"
 
-    if init == "random":
-        avg = np.sqrt(X.mean() / n_components)
+    if init == "random":  # sqrt(mean / k) |N(0, 1)|, H drawn before W (the order fixes the stream)
+        scale = np.sqrt(X.mean() / n_components)
         rng = check_random_state(random_state)
-        H = avg * rng.standard_normal(size=(n_components, n_features)).astype(X.dtype, copy=False)
-        W = avg * rng.standard_normal(size=(n_samples, n_components)).astype(X.dtype, copy=False)
-        np.abs(H, out=H)
-        np.abs(W, out=W)
+        H = np.abs(scale * rng.standard_normal(size=(n_components, n_features)).astype(X.dtype, copy=False))
+        W = np.abs(scale * rng.standard_normal(size=(n_samples, n_components)).astype(X.dtype, copy=False))
         return W, H
 
     if init not in ("nndsvd", "nndsvda", "nndsvdar"):
@@ -116,38 +172,20 @@ def initialize_nmf(X, n_components, init=None, eps=1e-6, random_state=None, svd_
         )
 
     if svd_solver == "exact":
-        U, S, V = exact_svd(X, n_components)
+        U, S, Vt = exact_svd(X, n_components)
     else:
-        U, S, V = randomized_svd(X, n_components, random_state)
-    W = np.zeros_like(U)
-    H = np.zeros_like(V)
-    W[:, 0] = np.sqrt(S[0]) * np.abs(U[:, 0])
-    H[0, :] = np.sqrt(S[0]) * np.abs(V[0, :])
-    for j in range(1, n_components):  # Boutsidis & Gallopoulos split of the +/- parts
-        x, y = U[:, j], V[j, :]
-        x_p, y_p = np.maximum(x, 0), np.maximum(y, 0)
-        x_n, y_n = np.abs(np.minimum(x, 0)), np.abs(np.minimum(y, 0))
-        x_p_nrm, y_p_nrm = _norm(x_p), _norm(y_p)
-        x_n_nrm, y_n_nrm = _norm(x_n), _norm(y_n)
-        m_p, m_n = x_p_nrm * y_p_nrm, x_n_nrm * y_n_nrm
-        if m_p > m_n:
-            u, v, sigma = x_p / x_p_nrm, y_p / y_p_nrm, m_p
-        else:
-            u, v, sigma = x_n / x_n_nrm, y_n / y_n_nrm, m_n
-        lbd = np.sqrt(S[j] * sigma)
-        W[:, j] = lbd * u
-        H[j, :] = lbd * v
-    W[W < eps] = 0
-    H[H < eps] = 0
-    if init == "nndsvda":
-        avg = X.mean()
-        W[W == 0] = avg
-        H[H == 0] = avg
-    elif init == "nndsvdar":
+        U, S, Vt = randomized_svd(X, n_components, random_state)
+    W, H = _nndsvd_factors(U, S, Vt, eps)
+    if init == "nndsvda":  # zeros -> mean of X
+        fill = X.mean()
+        W[W == 0] = fill
+        H[H == 0] = fill
+    elif init == "nndsvdar":  # zeros -> small random values, W's drawn first
         rng = check_random_state(random_state)
-        avg = X.mean()
-        W[W == 0] = abs(avg * rng.standard_normal(size=len(W[W == 0])) / 100)
-        H[H == 0] = abs(avg * rng.standard_normal(size=len(H[H == 0])) / 100)
+        fill = X.mean()
+        zw, zh = W == 0, H == 0
+        W[zw] = np.abs(fill * rng.standard_normal(size=int(zw.sum())) / 100)
+        H[zh] = np.abs(fill * rng.standard_normal(size=int(zh.sum())) / 100)
     return W, H
 
 

@@ -59,6 +59,31 @@ def test_mu_without_gpu_fails_loudly(V):
         ms.fit_batched(np.ones((1, 8, 4), np.float32), np.ones((1, 8, 2), np.float32), np.ones((1, 2, 4), np.float32))
 
 
+def test_mu_outside_the_compiled_shapes_falls_back_to_sklearn():
+    """The reference works for any shape (analysis.py:862-863); solver='mu' with more than 32 muscles (HD-EMG) or
+    more than 8 synergies is outside the compiled kernels and must reach scikit-learn, not an engine error."""
+    pytest.importorskip("sklearn")
+    rng = np.random.default_rng(5)
+    wide = pd.DataFrame(rng.random((60, 40)), columns=[f"ch{j}" for j in range(40)])
+    with pytest.warns(RuntimeWarning, match="outside the HIP engine's compiled shapes"):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", category=Warning)
+            warnings.simplefilter("always", category=RuntimeWarning)
+            res = ms.find_synergies(wide, 3, solver="mu", init="nndsvda", max_iter=20, tol=0)
+    assert type(res.model).__module__.startswith("sklearn") and res.model.solver == "mu"
+    assert res.components.shape == (3, 40)
+    narrow = pd.DataFrame(rng.random((60, 12)), columns=[f"ch{j}" for j in range(12)])
+    with pytest.warns(RuntimeWarning):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", category=Warning)
+            warnings.simplefilter("always", category=RuntimeWarning)
+            res = ms.find_synergies(narrow, 9, solver="mu", init="random", random_state=0, max_iter=20, tol=0)
+    assert type(res.model).__module__.startswith("sklearn")
+    assert ms.HipNMF.supports(solver="mu", n_features=32, n_components=8)
+    assert not ms.HipNMF.supports(solver="mu", n_features=33, n_components=8)
+    assert not ms.HipNMF.supports(solver="cd", n_features=8, n_components=2)
+
+
 def test_vaf_matches_reference_numbers(V, g1):
     c = g1["single_k4"]
     out = ms.vaf(V, transformed_signal=np.array(c["transformed"]), components=np.array(c["components"]))

@@ -6,12 +6,14 @@ from muscle_synergies_amd.init import initialize_nmf
 from muscle_synergies_amd.synth import emg_matrix, random_init
 
 
-def test_matches_sklearn_fixtures(g4):
+@pytest.mark.parametrize("backend", ["builtin", "auto"])
+def test_matches_sklearn_fixtures(g4, backend):
+    """Both paths -- the in-repo restatement and the delegation to scikit-learn -- against fixture G4."""
     arrays, meta = g4
     for c in meta:
         dt, T, m, k, init = c["dtype"], c["T"], c["m"], c["k"], c["init"]
         X = np.asfortranarray(arrays[f"X_{dt}_{T}_{m}"])
-        W0, H0 = initialize_nmf(X, k, init=init, random_state=c["random_state"])
+        W0, H0 = initialize_nmf(X, k, init=init, random_state=c["random_state"], backend=backend)
         Wg, Hg = arrays[f"W0_{dt}_{T}_{m}_{k}_{init}"], arrays[f"H0_{dt}_{T}_{m}_{k}_{init}"]
         assert W0.dtype == X.dtype and H0.dtype == X.dtype
         assert W0.shape == (T, k) and H0.shape == (k, m)
@@ -24,20 +26,21 @@ def test_matches_sklearn_fixtures(g4):
         assert (W0 >= 0).all() and (H0 >= 0).all()
 
 
-def test_default_init_choice_and_errors():
+@pytest.mark.parametrize("backend", ["builtin", "auto"])
+def test_default_init_choice_and_errors(backend):
     X = emg_matrix(1, T=30, m=6, k_true=3, dtype=np.float64)
-    Wd, Hd = initialize_nmf(X, 3, init=None, random_state=0)
-    Wa, Ha = initialize_nmf(X, 3, init="nndsvda", random_state=0)
+    Wd, Hd = initialize_nmf(X, 3, init=None, random_state=0, backend=backend)
+    Wa, Ha = initialize_nmf(X, 3, init="nndsvda", random_state=0, backend=backend)
     assert np.array_equal(Wd, Wa) and np.array_equal(Hd, Ha)
     assert (Wa > 0).all()  # nndsvda fills zeros with the mean
-    Wr, Hr = initialize_nmf(X, 9, init=None, random_state=0)  # k > min(T, m) falls back to 'random'
+    Wr, Hr = initialize_nmf(X, 9, init=None, random_state=0, backend=backend)  # k > min(T, m) falls back to 'random'
     assert Wr.shape == (30, 9)
     with pytest.raises(ValueError, match="can only be used when n_components <= min"):
-        initialize_nmf(X, 9, init="nndsvd")
+        initialize_nmf(X, 9, init="nndsvd", backend=backend)
     with pytest.raises(ValueError, match="Negative values in data passed to NMF initialization."):
-        initialize_nmf(-X, 2)
+        initialize_nmf(-X, 2, backend=backend)
     with pytest.raises(ValueError, match="Invalid init parameter"):
-        initialize_nmf(X, 2, init="bogus")
+        initialize_nmf(X, 2, init="bogus", backend=backend)
 
 
 def test_against_live_sklearn_when_available():
@@ -45,8 +48,10 @@ def test_against_live_sklearn_when_available():
     for dt in (np.float32, np.float64):
         X = emg_matrix(4, T=200, m=8, k_true=4, dtype=dt)
         for init in ("random", "nndsvd", "nndsvda", "nndsvdar"):
-            W0, H0 = initialize_nmf(X, 4, init=init, random_state=11)
+            W0, H0 = initialize_nmf(X, 4, init=init, random_state=11, backend="builtin")
             Ws, Hs = sk._initialize_nmf(X, 4, init=init, random_state=11)
+            Wd, Hd = initialize_nmf(X, 4, init=init, random_state=11)  # delegates: bit-identical
+            assert np.array_equal(Wd, Ws) and np.array_equal(Hd, Hs)
             tol = 1e-4 if dt == np.float32 else 1e-10
             np.testing.assert_allclose(W0, Ws, rtol=tol, atol=tol)
             np.testing.assert_allclose(H0, Hs, rtol=tol, atol=tol)
