@@ -91,6 +91,10 @@ int hipnmf_set_stream(hipnmf_handle* h, void* hip_stream);/* NULL restores the h
 size_t hipnmf_workspace_bytes(const hipnmf_problem* p, int elem_size /* 4 or 8 */);
 /* Device time (HIP events on the handle's stream) of the solver kernels of the last compute call. */
 int hipnmf_last_kernel_ms(hipnmf_handle* h, float* ms);
+/* Instance name of the solver kernel the last fit on this handle launched, e.g. "fit_rowlane_kernel<5,1,5,1>" or
+ * "fit_coop_kernel<float,1,16,5>" (as rocprofv3 --kernel-trace prints it, minus the namespace); "" before the first
+ * fit.  The string lives in the handle.  Lets a benchmark name the kernel it timed instead of guessing. */
+const char* hipnmf_last_kernel(hipnmf_handle* h);
 /* 1: compute entry points return right after enqueueing their kernels on the handle's stream (no host
  * synchronisation; hipnmf_last_kernel_ms is then unavailable).  Used with hipnmf_set_stream(torch's current
  * stream) by the time-sharded solver so that kernels and RCCL collectives are ordered by the stream alone.
@@ -98,7 +102,9 @@ int hipnmf_last_kernel_ms(hipnmf_handle* h, float* ms);
 int hipnmf_set_async(hipnmf_handle* h, int enable);
 /* Tuning knobs (0 = library default): threads per workgroup (256/512/1024), max row slices per matrix, and the
  * solver path: 0 chosen by the library, 1 one persistent workgroup per matrix, 2 row-sliced launches,
- * 3 cooperative multi-workgroup kernel (few long matrices; HIPNMF_ERR_UNSUPPORTED when not applicable). */
+ * 3 cooperative multi-workgroup kernel (few long matrices; HIPNMF_ERR_UNSUPPORTED when not applicable),
+ * 4 / 5 = 1 with the kernel instance pinned: 4 fit_persistent_kernel (VALU contractions), 5 fit_rowlane_kernel
+ * (X H^T and W H H^T on the f32 matrix pipe; fp32, 9..16 channels, Frobenius only, else HIPNMF_ERR_UNSUPPORTED). */
 int hipnmf_set_tuning(hipnmf_handle* h, int threads, int max_slices, int variant);
 
 /* ---- batched fit: replaces NMF(solver='mu').fit_transform / .transform for B matrices ------------- */

@@ -34,7 +34,8 @@ W_COMPONENT_MAJOR = 1
 #: every symbol ``include/hip_nmf.h`` declares (checked by tests/test_abi.py)
 EXPORTS = (
     "hipnmf_version", "hipnmf_last_error", "hipnmf_device_count", "hipnmf_create", "hipnmf_destroy",
-    "hipnmf_set_stream", "hipnmf_workspace_bytes", "hipnmf_last_kernel_ms", "hipnmf_set_async", "hipnmf_set_tuning",
+    "hipnmf_set_stream", "hipnmf_workspace_bytes", "hipnmf_last_kernel_ms", "hipnmf_last_kernel", "hipnmf_set_async",
+    "hipnmf_set_tuning",
     "hipnmf_fit_batched_f32", "hipnmf_fit_batched_f64", "hipnmf_fit_ragged_f32", "hipnmf_fit_ragged_f64",
     "hipnmf_shard_pass_f32", "hipnmf_shard_hupdate_f32", "hipnmf_shard_residual_f32",
     "hipnmf_shard_pass_f64", "hipnmf_shard_hupdate_f64", "hipnmf_shard_residual_f64",
@@ -100,6 +101,8 @@ def _declare(lib):
     lib.hipnmf_workspace_bytes.argtypes = [pp, ip]
     lib.hipnmf_last_kernel_ms.restype = ip
     lib.hipnmf_last_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
+    lib.hipnmf_last_kernel.restype = ctypes.c_char_p
+    lib.hipnmf_last_kernel.argtypes = [vp]
     lib.hipnmf_set_async.restype = ip
     lib.hipnmf_set_async.argtypes = [vp, ip]
     lib.hipnmf_set_tuning.restype = ip
@@ -198,6 +201,11 @@ class Handle:
         ms = ctypes.c_float()
         check(load().hipnmf_last_kernel_ms(self._h, ctypes.byref(ms)))
         return float(ms.value)
+
+    def last_kernel(self) -> str:
+        """Instance name of the solver kernel the last fit launched (``hipnmf_last_kernel``)."""
+        name = load().hipnmf_last_kernel(self._h)
+        return name.decode() if name else ""
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:

@@ -63,15 +63,28 @@ def _compile(src: str, extra, objdir: str = OBJ) -> str:
 
 
 def build(force: bool = False, jobs: int | None = None, extra_flags=(), verbose: bool = False,
-          variant: str | None = None) -> str:
+          variant: str | None = None, only=()) -> str:
     """Build the library.  ``variant`` (development aid) builds ``libhip_nmf_<variant>.so`` with
-    ``extra_flags`` in its own object directory; select it at run time with ``HIPNMF_LIBRARY``."""
+    ``extra_flags`` in its own object directory; select it at run time with ``HIPNMF_LIBRARY``.
+    ``only``: with a variant, the translation units (base names without ``.hip``) the flags apply to -- every
+    other object is taken from the default build (which is brought up to date first)."""
     objdir = OBJ if not variant else os.path.join(CSRC, "_build_" + variant)
     lib = LIB if not variant else os.path.join(LIBDIR, f"libhip_nmf_{variant}.so")
     os.makedirs(objdir, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
     hdrs = headers()
     srcs = sources()
+    if variant and only:
+        build(jobs=jobs, verbose=verbose)  # default objects for the shared translation units
+        mine = [s for s in srcs if os.path.basename(s)[:-4] in only]
+        with ThreadPoolExecutor(max_workers=jobs or min(8, os.cpu_count() or 1)) as ex:
+            list(ex.map(lambda s: _compile(s, list(extra_flags), objdir), mine))
+        objs = [os.path.join(objdir if s in mine else OBJ, os.path.basename(s)[:-4] + ".o") for s in srcs]
+        cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", lib]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+        return lib
     todo = [s for s in srcs
             if force or _stale(os.path.join(objdir, os.path.basename(s)[:-4] + ".o"), [s, *hdrs])]
     jobs = jobs or min(8, os.cpu_count() or 1)
@@ -97,5 +110,7 @@ if __name__ == "__main__":
     ap.add_argument("--jobs", type=int, default=None)
     ap.add_argument("--flag", action="append", default=[], help="extra hipcc flag (repeatable), e.g. --flag=-DHIPNMF_PF=3")
     ap.add_argument("--variant", default=None, help="build lib/libhip_nmf_<variant>.so instead of the default library")
+    ap.add_argument("--only", action="append", default=[],
+                    help="with --variant: translation unit (base name) the flags apply to (repeatable); the rest is shared")
     a = ap.parse_args()
-    print(build(force=a.force, jobs=a.jobs, extra_flags=a.flag, verbose=True, variant=a.variant))
+    print(build(force=a.force, jobs=a.jobs, extra_flags=a.flag, verbose=True, variant=a.variant, only=a.only))

@@ -18,6 +18,7 @@
 
 #include "hipnmf_internal.hpp"
 #include "nmf_inst.hpp"
+#include "nmf_rowlane_decl.hpp"
 
 using namespace hipnmf;
 
@@ -200,7 +201,7 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
   const double t_pers = waves * ((double)T * (ks->row_major ? 2.0e-9 : 2.7e-9) + 1e-6);  // row-per-lane: 20.8 us / 10 000 rows
   const double t_sliced = 9.5e-6 + (double)B * (double)T * 0.021e-9;
   bool persistent;
-  if (h->variant == 1)
+  if (h->variant == 1 || h->variant == 4 || h->variant == 5)
     persistent = true;
   else if (h->variant == 2)
     persistent = false;
@@ -266,6 +267,32 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
   if (h->variant == 3 && coop_S == 0)
     return fail(HIPNMF_ERR_UNSUPPORTED, "cooperative path not applicable (batch=%d, n_samples=%lld)", B, T);
   const bool coop = coop_S > 0;
+
+  // fp32, 9..16 channels, any k <= 8, Frobenius, one workgroup per matrix: fit_rowlane_kernel (nmf_rowlane.hpp).
+  // It streams the same row-major X as the (G=1, CH=16) instance, whose KernelSet supplies the layout handling
+  // and the LDS carve-up (HIPNMF_ROWLANE=0 keeps round 1's fit_persistent_kernel).
+  bool use_rowlane = false;
+  if constexpr (std::is_same<real, float>::value) {
+    static const int rl_env = [] {  // -1: not set
+      const char* e = getenv("HIPNMF_ROWLANE");
+      return e ? (atoi(e) != 0 ? 1 : 0) : -1;
+    }();
+    const bool rl_ok = persistent && !coop && !kl && m > 8 && m <= 16 && rowlane_kernel(k) != nullptr &&
+                       (T + 64) * 16LL * (long long)sizeof(real) < (1LL << 31);
+    // Default policy (tools/rank_sweep_bench.py, profiles/README.md): k >= 6, where round 1 had to fall back to the
+    // channel-major (G=4, CH=4) mapping; at k <= 5 round 1's VALU instance is still ahead (9.54 vs 9.24 M it/s).
+    // HIPNMF_ROWLANE=1 / 0 forces it on / off for every k; variant 5 / 4 of hipnmf_set_tuning does the same per handle.
+    const bool want = h->variant == 5 || (h->variant != 4 && (rl_env > 0 || (rl_env < 0 && k >= 6)));
+    if (h->variant == 5 && !rl_ok)
+      return fail(HIPNMF_ERR_UNSUPPORTED, "fit_rowlane_kernel needs fp32, 9..16 channels, the Frobenius loss and the "
+                  "one-workgroup-per-matrix path (n_features=%d, loss=%d)", m, (int)p->loss);
+    if (want && rl_ok) {
+      ks = kernels_f32_g1c16(k);
+      use_rowlane = true;
+    }
+  } else {
+    if (h->variant == 5) return fail(HIPNMF_ERR_UNSUPPORTED, "fit_rowlane_kernel is an fp32 kernel");
+  }
 
   // Ragged batch on a row-major instance: every distinct packed channel-major matrix (restarts of one trial share
   // theirs) is converted once into row-major rows of MP values; the kernel then gets {T, row-major offset, ldw, woff}.
@@ -424,6 +451,8 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
     if (e == hipSuccess) {
       coop_done = true;
       h->last_path = 3;
+      snprintf(h->last_kernel, sizeof(h->last_kernel), "fit_coop_kernel<%s,%d,%d,%d>",
+               sizeof(real) == 4 ? "float" : "double", ks->G, ks->CH, ks->K);
     } else {
       (void)hipGetLastError();  // not launchable as a cooperative grid on this device: use the regular paths
       if (h->variant == 3)
@@ -451,13 +480,23 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
     }
     a.lds_rows = (int)lds_rows;
     const size_t smem = base + sizeof(real) * (size_t)k * (size_t)lds_rows;
-    const auto kern = kl ? ks->fit_persistent_kl : ks->fit_persistent;
+    auto kern = kl ? ks->fit_persistent_kl : ks->fit_persistent;
+    snprintf(h->last_kernel, sizeof(h->last_kernel), "fit_persistent_kernel<%s,%d,%d,%d,%d>",
+             sizeof(real) == 4 ? "float" : "double", ks->G, ks->CH, ks->K, kl ? 1 : 0);
+    if constexpr (std::is_same<real, float>::value) {
+      if (use_rowlane) {
+        kern = rowlane_kernel(k);
+        snprintf(h->last_kernel, sizeof(h->last_kernel), "%s", rowlane_kernel_name(k));
+      }
+    }
     if (smem > 48 * 1024)
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)smem));
     launch<real>(kern, dim3(B), dim3(threads), smem, st, a);
   } else {
     h->last_path = 2;
+    snprintf(h->last_kernel, sizeof(h->last_kernel), "slice_pass_kernel<%s,%d,%d,%d>",
+             sizeof(real) == 4 ? "float" : "double", ks->G, ks->CH, ks->K);
     a.S = sg.S;
     a.rows_per_slice = sg.rows_per_slice;
     a.part = reinterpret_cast<real*>(ws + o_part);
@@ -766,6 +805,8 @@ size_t hipnmf_workspace_bytes(const hipnmf_problem* p, int elem_size) {
   return bytes;
 }
 
+const char* hipnmf_last_kernel(hipnmf_handle* h) { return h ? h->last_kernel : ""; }
+
 int hipnmf_last_kernel_ms(hipnmf_handle* h, float* ms) {
   if (!h || !ms) return fail(HIPNMF_ERR_BAD_ARG, "NULL argument");
   *ms = h->last_ms;
@@ -782,7 +823,7 @@ int hipnmf_set_tuning(hipnmf_handle* h, int threads, int max_slices, int variant
   if (!h) return fail(HIPNMF_ERR_BAD_ARG, "handle is NULL");
   if (threads != 0 && threads != 256 && threads != 512 && threads != 1024)
     return fail(HIPNMF_ERR_BAD_ARG, "threads must be 0, 256, 512 or 1024");
-  if (max_slices < 0 || variant < 0 || variant > 3) return fail(HIPNMF_ERR_BAD_ARG, "bad tuning value");
+  if (max_slices < 0 || variant < 0 || variant > 5) return fail(HIPNMF_ERR_BAD_ARG, "bad tuning value");
   h->threads = threads;
   h->max_slices = max_slices;
   h->variant = variant;

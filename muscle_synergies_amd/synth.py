@@ -112,3 +112,46 @@ def emg_batch_torch(B: int, T: int = 10_000, m: int = 16, k_true: int = 5, *, k:
         H0[lo:lo + n] = avg * torch.randn((n, k, m), generator=g, device=device).abs_()
         W0[lo:lo + n] = avg * torch.randn((n, T, k), generator=g, device=device).abs_()
     return X, W0, H0
+
+
+def emg_shard_torch(seed: int, shard: int, T_shard: int, m: int = 16, k_true: int = 5, *, k: int = 5,
+                    device="cuda", piece: int = 4_000_000, scale=None):
+    """One time shard of a very long synthetic recording, generated on the device from counter-based seeds
+    (BASELINE.json config #5: a single 16 x 2e8 matrix cannot round-trip through the host).
+
+    The recording is defined shard by shard: shard ``s`` draws from ``torch.Generator(SEED_BASE + 7919 seed + s)``,
+    so any rank can build exactly its own rows; the synergies ``S`` (``k_true x m``) depend on ``seed`` only and are
+    common to all shards.  Same recipe as :func:`emg_batch_torch` (rectified noise smoothed over 201 samples times
+    non-negative synergies plus rectified noise); channels are scaled by ``scale`` (``[m]`` tensor; default: one
+    fixed constant, since a per-channel maximum would need a pass over all shards).
+
+    Returns ``(X [1, m, ld], W0 [1, k, ld], H0 [1, k, m])`` in the engine's native layouts (channel-major /
+    component-major, ``ld = T_shard`` rounded up to a multiple of 4, padding rows zero).
+    """
+    import torch
+
+    gs = torch.Generator(device=device)
+    gs.manual_seed(SEED_BASE + 7919 * seed)
+    S = torch.rand((k_true, m), generator=gs, device=device) ** 2
+    H0 = torch.rand((1, k, m), generator=gs, device=device) * 0.5 + 0.1
+    g = torch.Generator(device=device)
+    g.manual_seed(SEED_BASE + 7919 * seed + 1 + shard)
+    ld = (T_shard + 3) // 4 * 4
+    X = torch.zeros((1, m, ld), dtype=torch.float32, device=device)
+    W0 = torch.zeros((1, k, ld), dtype=torch.float32, device=device)
+    window = 201
+    norm = 1.0 / 3.0 if scale is None else None
+    for lo in range(0, T_shard, piece):
+        n = min(piece, T_shard - lo)
+        a = torch.randn((1, k_true, n + window - 1), generator=g, device=device).abs_()
+        A = torch.nn.functional.avg_pool1d(a, window, stride=1)[0]  # k_true x n, moving average of 201 samples
+        x = 0.05 * torch.randn((m, n), generator=g, device=device).abs_()
+        x.addmm_(S.t(), A)
+        if scale is None:
+            x *= norm
+        else:
+            x /= scale.view(m, 1)
+        X[0, :, lo:lo + n] = x
+        W0[0, :, lo:lo + n] = 0.3 * torch.randn((k, n), generator=g, device=device).abs_()
+        del a, A, x
+    return X, W0, H0

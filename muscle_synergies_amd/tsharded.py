@@ -89,6 +89,45 @@ class HipShardOps:
         self._res = getattr(lib, f"hipnmf_shard_residual_{sfx}")
         torch.cuda.synchronize(self.dev)
 
+    @classmethod
+    def from_native(cls, Xc, Wc, H, *, T=None, l1_reg_W=0.0, l1_reg_H=0.0, l2_reg_W=0.0, l2_reg_H=0.0,
+                    update_H=True):
+        """Wrap device tensors that already are in the engine's layouts -- ``Xc [B, m, ld]`` channel-major,
+        ``Wc [B, k, ld]`` component-major (updated in place), ``H [B, k, m]`` (updated in place; several shards of
+        one rank may share the same tensor) -- without the padded copies the ordinary constructor makes.
+        ``ld % 4 == 0``; rows ``>= T`` (default ``ld``) must be zero in both X and W."""
+        import torch
+
+        self = cls.__new__(cls)
+        self.torch = torch
+        self.dev = Xc.device
+        if not (Xc.is_cuda and Wc.is_cuda and H.is_cuda and Xc.is_contiguous() and Wc.is_contiguous()
+                and H.is_contiguous()):
+            raise ValueError("from_native needs contiguous device tensors")
+        self.B, self.m, self.ld = Xc.shape
+        if self.ld % 4 or Wc.shape[0] != self.B or Wc.shape[2] != self.ld or H.shape != (self.B, Wc.shape[1], self.m):
+            raise ValueError("from_native: need Xc [B, m, ld], Wc [B, k, ld], H [B, k, m] with ld % 4 == 0")
+        self.T = self.ld if T is None else int(T)
+        self.dtype = Xc.dtype
+        self.k = Wc.shape[1]
+        self.Xc, self.Wc, self.H = Xc, Wc, H
+        self.sums = torch.empty((self.B, self.k * self.m + self.k * self.k), dtype=self.dtype, device=self.dev)
+        self.sse = torch.empty((self.B, self.m), dtype=self.dtype, device=self.dev)
+        self.xsq = torch.empty((self.B, self.m), dtype=self.dtype, device=self.dev)
+        self.handle = _lib.Handle(self.dev.index)
+        self.handle.set_stream(torch.cuda.current_stream(self.dev).cuda_stream)
+        self.handle.set_async(True)
+        self.p = make_problem(self.B, self.ld, self.m, self.k, x_layout=_lib.X_CHANNEL_MAJOR, ldx=self.ld,
+                              x_batch_stride=self.m * self.ld, w_layout=_lib.W_COMPONENT_MAJOR, update_H=update_H,
+                              max_iter=1, tol=0.0, l1_reg_W=l1_reg_W, l1_reg_H=l1_reg_H, l2_reg_W=l2_reg_W,
+                              l2_reg_H=l2_reg_H)
+        sfx = "f32" if self.dtype == torch.float32 else "f64"
+        lib = _lib.load()
+        self._pass = getattr(lib, f"hipnmf_shard_pass_{sfx}")
+        self._hupd = getattr(lib, f"hipnmf_shard_hupdate_{sfx}")
+        self._res = getattr(lib, f"hipnmf_shard_residual_{sfx}")
+        return self
+
     def shard_pass(self):
         _lib.check(self._pass(self.handle.ptr, ctypes.byref(self.p), self.Xc.data_ptr(), self.Wc.data_ptr(),
                               self.H.data_ptr(), self.sums.data_ptr()))
@@ -107,6 +146,49 @@ class HipShardOps:
 
     def result_H(self):
         return self.H
+
+
+class MultiShardOps:
+    """Several consecutive time shards held by ONE rank, presented to :func:`fit_tsharded` as one shard.
+
+    The engine addresses a matrix through 32-bit buffer resources (< 2 GiB of X per shard: 3.3e7 rows at 16
+    channels), so a rank that owns more rows than that -- BASELINE config #5 on fewer than 8 GPUs -- keeps them as
+    sub-shards: every pass runs over each of them with the same replicated ``H`` (the sub-shards share one ``H``
+    tensor), their ``[W^T X | W^T W]`` sums are added on the device in shard order, and the (all-reduced) result
+    updates ``H`` once."""
+
+    def __init__(self, shards):
+        if not shards:
+            raise ValueError("need at least one shard")
+        self.shards = list(shards)
+        h0 = self.shards[0].H
+        for sh in self.shards[1:]:
+            if sh.H.data_ptr() != h0.data_ptr():
+                raise ValueError("the sub-shards of a rank must share one H tensor (HipShardOps.from_native)")
+
+    def shard_pass(self):
+        total = self.shards[0].shard_pass().clone()
+        for sh in self.shards[1:]:
+            total += sh.shard_pass()
+        return total
+
+    def h_update(self, sums):
+        self.shards[0].h_update(sums)  # H is shared
+
+    def residual(self):
+        sse, xsq = self.shards[0].residual()
+        sse, xsq = sse.clone(), xsq.clone()
+        for sh in self.shards[1:]:
+            a, b = sh.residual()
+            sse += a
+            xsq += b
+        return sse, xsq
+
+    def result_W(self):
+        return [sh.Wc for sh in self.shards]  # native layout, no concatenation (may be tens of GB)
+
+    def result_H(self):
+        return self.shards[0].H
 
 
 def fit_tsharded(ops, *, max_iter: int = 200, tol: float = 1e-4, check_every: int = 10, update_H: bool = True,

@@ -1,0 +1,288 @@
+"""Round-2 GPU tests: the headline kernels at the headline shape and iteration count, the matrix-pipe instance over
+k = 1..8, one full-size time shard (config #5) with shard-count invariance, the cooperative exchange under load,
+the in-process multi-GPU scatter on every visible device, and a 2-rank RCCL run when two GPUs are visible."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from oracle import nmf_mu_oracle as orc
+from muscle_synergies_amd.synth import emg_matrix, random_init
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _rel_wh(X, W, H, ref):
+    xn = np.linalg.norm(X.astype(np.float64))
+    wh = W.astype(np.float64) @ H.astype(np.float64)
+    wr = ref["W"].astype(np.float64) @ ref["H"].astype(np.float64)
+    return np.linalg.norm(wh - wr) / xn
+
+
+# ------------------------------------------------------------------------------------------------ verdict 1(a)
+@pytest.mark.parametrize("variant", [4, 5, 1])
+def test_headline_batch_kernel_row_major_500_iterations(g2_full, variant):
+    """bench.py's exact kernel, layout and iteration count: row-major [B, 10000, 16] fp32, k = 5, 500 iterations,
+    one workgroup per matrix (variant 4: round 1's VALU instance, 5: the matrix-pipe instance, 1: the library's
+    pick), against sklearn's recorded checksums (G2, matrix 0) and the oracle (every matrix)."""
+    import torch
+
+    import muscle_synergies_amd as ms
+    from muscle_synergies_amd import _lib
+
+    B = 8
+    Xs = [np.ascontiguousarray(emg_matrix(s, dtype=np.float32)) for s in range(B)]  # C order: [T, m] row-major
+    inits = [random_init(Xs[s], 5, s) for s in range(B)]
+    X = torch.from_numpy(np.stack(Xs)).cuda()
+    assert X.is_contiguous() and X.shape == (B, 10000, 16)
+    W0 = torch.from_numpy(np.stack([i[0] for i in inits])).cuda()
+    H0 = torch.from_numpy(np.stack([i[1] for i in inits])).cuda()
+    h = _lib.Handle(0)
+    h.set_tuning(512, 0, variant)
+    res = ms.fit_batched(X, W0, H0, max_iter=500, tol=0.0, handle=h)
+    name = h.last_kernel()
+    assert name.startswith({4: "fit_persistent_kernel<float,1,16,5,0>", 5: "fit_rowlane_kernel<5,", 1: "fit_"}[variant]), name
+    W, H = res.W.cpu().numpy(), res.H.cpu().numpy()
+    err, vaf = res.reconstruction_err.cpu().numpy(), res.vaf.cpu().numpy()
+    assert (res.n_iter.cpu().numpy() == 500).all()
+    # matrix 0 is G2's case 0: sklearn 1.7.2's own output after 500 iterations
+    c = g2_full["cases"][0]
+    assert c["dtype"] == "float32" and c["init"] == "random" and c["seed"] == 0
+    g = c["iters"]["500"]
+    xn = c["X_fro"]
+    WH = W[0].astype(np.float64) @ H[0].astype(np.float64)
+    assert abs(float(err[0]) - g["reconstruction_err"]) / xn <= TOL
+    assert abs(np.sqrt((WH ** 2).sum()) - g["WH_fro"]) / xn <= TOL
+    assert np.linalg.norm(WH.sum(axis=0) - np.array(g["WH_colsum"])) / np.linalg.norm(g["WH_colsum"]) <= TOL
+    assert np.abs(WH[g2_full["rows"]] - np.array(g["WH_rows"])).max() <= 2e-4
+    assert abs(float(vaf[0, 0]) - g["vaf_all"]) <= TOL
+    np.testing.assert_allclose(vaf[0, 1:], g["vaf_col"], atol=TOL)
+    for b in range(B):
+        ref = orc.nmf_mu_fit(Xs[b], inits[b][0], inits[b][1], max_iter=500, tol=0.0)
+        assert _rel_wh(Xs[b], W[b], H[b], ref) <= TOL, b
+        assert abs(float(err[b]) - float(ref["reconstruction_err"])) / np.linalg.norm(Xs[b]) <= TOL, b
+        va, vc = orc.vaf(Xs[b].astype(np.float64), ref["W"].astype(np.float64), ref["H"].astype(np.float64))
+        assert abs(vaf[b, 0] - va) <= TOL
+        np.testing.assert_allclose(vaf[b, 1:], vc, atol=TOL)
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("m,T", [(16, 777), (9, 1000), (13, 64), (16, 5200), (12, 11000)])
+def test_matrix_pipe_instance_over_ranks_and_shapes(k, m, T):
+    """fit_rowlane_kernel<K> (forced with variant 5) vs the oracle: ragged tails, padded channels, T on both sides
+    of the LDS cache capacity, both X layouts, stop rule, transform and regularisation."""
+    import muscle_synergies_amd as ms
+    from muscle_synergies_amd import _lib
+
+    X = emg_matrix(1000 * k + m, T=T, m=m, k_true=min(5, m), dtype=np.float32)
+    W0, H0 = random_init(X, k, k)
+    h = _lib.Handle(0)
+    h.set_tuning(0, 0, 5)
+    for layout in ("F", "C"):
+        Xl = np.asfortranarray(X) if layout == "F" else np.ascontiguousarray(X)
+        res = ms.fit_batched(Xl, W0, H0, max_iter=30, tol=0.0, handle=h)
+        assert h.last_kernel().startswith(f"fit_rowlane_kernel<{k},")
+        ref = orc.nmf_mu_fit(X, W0, H0, max_iter=30, tol=0.0)
+        assert _rel_wh(X, res.W[0], res.H[0], ref) <= TOL, (layout, m, k, T)
+        assert abs(float(res.reconstruction_err[0]) - float(ref["reconstruction_err"])) / np.linalg.norm(X) <= TOL
+        np.testing.assert_allclose(res.W[0], ref["W"], rtol=3e-4, atol=1e-6)
+        np.testing.assert_allclose(res.H[0], ref["H"], rtol=3e-4, atol=1e-6)
+    if T == 1000:
+        res = ms.fit_batched(X, W0, H0, max_iter=300, tol=1e-3, handle=h)
+        ref = orc.nmf_mu_fit(X, W0, H0, max_iter=300, tol=1e-3)
+        assert int(res.n_iter[0]) == ref["n_iter"] and ref["n_iter"] % 10 == 0
+        assert _rel_wh(X, res.W[0], res.H[0], ref) <= TOL
+        res = ms.fit_batched(X, W0, H0, max_iter=40, tol=0.0, update_H=False, handle=h)
+        Wr, Hr, _ = orc.fit_multiplicative_update(X, W0.copy(), H0.copy(), 40, 0.0, 0.0, 0.0, 0.0, 0.0, update_H=False)
+        assert _rel_wh(X, res.W[0], res.H[0], {"W": Wr, "H": Hr}) <= TOL
+        np.testing.assert_array_equal(res.H[0], H0)
+        res = ms.fit_batched(X, W0, H0, max_iter=40, tol=0.0, handle=h, l1_reg_W=0.02, l1_reg_H=0.01, l2_reg_W=0.03,
+                             l2_reg_H=0.04)
+        Wr, Hr, _ = orc.fit_multiplicative_update(X, W0.copy(), H0.copy(), 40, 0.0, 0.02, 0.01, 0.03, 0.04)
+        assert _rel_wh(X, res.W[0], res.H[0], {"W": Wr, "H": Hr}) <= TOL
+
+
+def test_matrix_pipe_instance_is_bitwise_reproducible_and_batch_consistent():
+    import torch
+
+    import muscle_synergies_amd as ms
+    from muscle_synergies_amd import _lib
+
+    B = 300  # more workgroups than CUs
+    Xs = np.stack([np.ascontiguousarray(emg_matrix(50 + b % 7, T=3000, dtype=np.float32)) for b in range(B)])
+    inits = [random_init(Xs[b], 6, b % 7) for b in range(B)]
+    X = torch.from_numpy(Xs).cuda()
+    W0 = torch.from_numpy(np.stack([i[0] for i in inits])).cuda()
+    H0 = torch.from_numpy(np.stack([i[1] for i in inits])).cuda()
+    h = _lib.Handle(0)
+    h.set_tuning(0, 0, 5)
+    a = ms.fit_batched(X, W0, H0, max_iter=50, tol=0.0, handle=h)
+    b = ms.fit_batched(X, W0, H0, max_iter=50, tol=0.0, handle=h)
+    assert torch.equal(a.W, b.W) and torch.equal(a.H, b.H) and torch.equal(a.reconstruction_err, b.reconstruction_err)
+    assert torch.equal(a.W[0], a.W[7]) and torch.equal(a.H[3], a.H[290 - 290 % 7 + 3])  # same inputs, any slot
+
+
+# ------------------------------------------------------------------------------------------------ verdict 1(b)
+def test_full_size_rank_shard_is_shard_count_invariant():
+    """Config #5's per-rank share on 8 GPUs: ONE shard of 2.5e7 rows x 16 channels (1.6 GB of X, generated on the
+    device from counter seeds) through hipnmf_shard_*; the same rows as 2 and as 4 sub-shards summed on the device
+    must give the same W (bitwise: the update is row-local) and the same sums / H to rounding level (another
+    summation tree); the residual entry point is checked in fp64 on a row subset."""
+    import torch
+
+    from muscle_synergies_amd.synth import emg_shard_torch
+    from muscle_synergies_amd.tsharded import HipShardOps, MultiShardOps
+
+    T, m, k = 25_000_000, 16, 5
+    X, W0, H0 = emg_shard_torch(3, 0, T, m=m, k=k, device="cuda:0")
+    assert X.shape == (1, m, T) and float(X.min()) >= 0
+
+    def run(n_sub, iters=3):
+        H = H0.clone()
+        bounds = [(i * T // n_sub) // 4 * 4 for i in range(n_sub)] + [T]
+        shards = []
+        for lo, hi in zip(bounds[:-1], bounds[1:]):
+            Xc = X[:, :, lo:hi].contiguous() if n_sub > 1 else X
+            shards.append(HipShardOps.from_native(Xc, W0[:, :, lo:hi].clone(), H))
+        ops = MultiShardOps(shards)
+        sums = None
+        for _ in range(iters):
+            sums = ops.shard_pass()
+            ops.h_update(sums)
+        sse, xsq = ops.residual()
+        torch.cuda.synchronize()
+        W = torch.cat([s.Wc for s in shards], dim=2)
+        return W, H.clone(), sums.clone(), sse.clone(), xsq.clone()
+
+    W1, H1, S1, sse1, xsq1 = run(1)
+    for n_sub in (2, 4):
+        Wn, Hn, Sn, ssen, xsqn = run(n_sub)
+        rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+        assert rel(Sn, S1) <= 2e-6, (n_sub, rel(Sn, S1))
+        assert rel(Hn, H1) <= 2e-6
+        assert rel(Wn, W1) <= 1e-5  # H differs at rounding level after the first update, W follows
+        assert rel(ssen, sse1) <= 1e-5 and rel(xsqn, xsq1) <= 2e-6
+        del Wn
+    # first iteration alone: identical H on entry -> W bitwise identical whatever the shard count
+    Wa = run(1, iters=1)[0]
+    Wb = run(4, iters=1)[0]
+    assert torch.equal(Wa, Wb)
+    # residual of a row subset in fp64
+    n = 200_000
+    Xs, Ws = X[0, :, :n].double(), W1[0, :, :n].double()
+    r = Xs - (Ws.t() @ H1[0].double()).t()
+    sub = HipShardOps.from_native(X[:, :, :n].contiguous(), W1[:, :, :n].contiguous(), H1.clone())
+    sse_s, xsq_s = sub.residual()
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(sse_s[0].cpu().numpy(), (r * r).sum(dim=1).cpu().numpy(), rtol=2e-5)
+    np.testing.assert_allclose(xsq_s[0].cpu().numpy(), (Xs * Xs).sum(dim=1).cpu().numpy(), rtol=2e-5)
+    assert float(sse1.sum()) < float(xsq1.sum())  # three iterations already explain part of the signal
+
+
+# ------------------------------------------------------------------------------------------------ hardening
+def test_cooperative_exchange_under_load_is_bitwise_stable():
+    """200 back-to-back cooperative fits (one 16 x 10 000 matrix, many workgroups exchanging records every iteration)
+    while a second stream saturates the memory system: every result must equal the first bit for bit, and the
+    row-sliced path (no in-kernel exchange) must agree to rounding level."""
+    import torch
+
+    import muscle_synergies_amd as ms
+    from muscle_synergies_amd import _lib
+
+    X = emg_matrix(77, dtype=np.float32)
+    W0, H0 = random_init(X, 5, 77)
+    Xd = torch.from_numpy(np.ascontiguousarray(X)).cuda()[None]
+    Wd, Hd = torch.from_numpy(W0).cuda()[None], torch.from_numpy(H0).cuda()[None]
+    h = _lib.Handle(0)
+    h.set_tuning(0, 0, 3)
+    first = ms.fit_batched(Xd, Wd, Hd, max_iter=60, tol=0.0, handle=h)
+    assert h.last_kernel().startswith("fit_coop_kernel")
+    hog_stream = torch.cuda.Stream()
+    big = torch.empty(512 * 1024 * 1024 // 4, dtype=torch.float32, device="cuda")
+    other = torch.empty_like(big)
+    for rep in range(200):
+        if rep % 4 == 0:
+            with torch.cuda.stream(hog_stream):  # ~1 GB of traffic per copy, queued ahead of the fits
+                other.copy_(big)
+                big.copy_(other)
+        r = ms.fit_batched(Xd, Wd, Hd, max_iter=60, tol=0.0, handle=h)
+        assert torch.equal(r.W, first.W) and torch.equal(r.H, first.H), rep
+        assert torch.equal(r.reconstruction_err, first.reconstruction_err), rep
+    torch.cuda.synchronize()
+    h.set_tuning(0, 0, 2)
+    sliced = ms.fit_batched(Xd, Wd, Hd, max_iter=60, tol=0.0, handle=h)
+    ref = orc.nmf_mu_fit(X, W0, H0, max_iter=60, tol=0.0)
+    for r in (first, sliced):
+        assert _rel_wh(X, r.W[0].cpu().numpy(), r.H[0].cpu().numpy(), ref) <= TOL
+
+
+def test_multi_gpu_scatter_on_every_visible_device():
+    """fit_batched_multi_gpu over range(device_count()): per-device handles, workspaces and H2D staging."""
+    import torch
+
+    import muscle_synergies_amd as ms
+
+    n = torch.cuda.device_count()
+    B, T = 4 * n + 3, 900
+    Xs = np.stack([np.ascontiguousarray(emg_matrix(600 + b, T=T, dtype=np.float32)) for b in range(B)])
+    inits = [random_init(Xs[b], 5, b) for b in range(B)]
+    W0, H0 = np.stack([i[0] for i in inits]), np.stack([i[1] for i in inits])
+    ref = ms.fit_batched(Xs, W0, H0, max_iter=25, tol=0.0)
+    out = ms.fit_batched_multi_gpu(Xs, W0, H0, devices=list(range(n)), max_iter=25, tol=0.0)
+    np.testing.assert_allclose(out.W, ref.W, rtol=2e-4, atol=1e-6)
+    np.testing.assert_allclose(out.H, ref.H, rtol=2e-4, atol=1e-6)
+    np.testing.assert_array_equal(out.n_iter, ref.n_iter)
+    if n > 1:
+        for b in range(B):
+            o = orc.nmf_mu_fit(Xs[b], inits[b][0], inits[b][1], max_iter=25, tol=0.0)
+            assert _rel_wh(Xs[b], out.W[b], out.H[b], o) <= TOL
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _nccl_worker(rank, world, port, T, out_dir):
+    import torch
+    import torch.distributed as dist
+
+    from muscle_synergies_amd.tsharded import fit_tsharded_hip, shard_bounds
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    try:
+        X = emg_matrix(31, T=T, m=16, dtype=np.float32)
+        W0, H0 = random_init(X, 5, 31)
+        lo, hi = shard_bounds(T, world)[rank]
+        res = fit_tsharded_hip(np.ascontiguousarray(X[lo:hi]), W0[lo:hi], H0, max_iter=40, tol=0.0,
+                               device=torch.device("cuda", rank))
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), W=res.W_local.cpu().numpy()[0], H=res.H.cpu().numpy()[0],
+                 err=res.reconstruction_err.cpu().numpy(), lo=lo, hi=hi)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_rccl_time_sharded_fit(tmp_path):
+    """The config #5 path end to end on two GPUs: hipnmf_shard_* per rank + one RCCL all-reduce per iteration."""
+    import torch
+    import torch.multiprocessing as mp
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two visible GPUs (the driver's multi-GPU tier)")
+    T, world = 40_002, 2
+    mp.spawn(_nccl_worker, args=(world, _free_port(), T, str(tmp_path)), nprocs=world, join=True)
+    X = emg_matrix(31, T=T, m=16, dtype=np.float32)
+    W0, H0 = random_init(X, 5, 31)
+    ref = orc.nmf_mu_fit(X, W0, H0, max_iter=40, tol=0.0)
+    parts = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    W = np.concatenate([p["W"] for p in parts], axis=0)
+    np.testing.assert_array_equal(parts[0]["H"], parts[1]["H"])  # replicated
+    assert _rel_wh(X, W, parts[0]["H"], ref) <= TOL
+    assert abs(float(parts[0]["err"][0]) - float(ref["reconstruction_err"])) / np.linalg.norm(X) <= TOL
