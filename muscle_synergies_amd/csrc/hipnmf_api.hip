@@ -464,7 +464,7 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
   } else if (persistent) {
     h->last_path = 1;
     int threads = h->threads > 0 ? h->threads : 512;
-    threads = std::min(threads, ks->max_threads);
+    threads = std::min(threads, use_rowlane ? 512 : ks->max_threads);  // fit_rowlane_kernel: 512 for every k
     // a wave covers 64 rows per step: do not launch waves that would never get a row
     const long long t_pad = round_up(T, 64);
     while (threads > 256 && t_pad <= threads / 2) threads /= 2;

@@ -168,22 +168,23 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void* base, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
 }
 
-template <typename real, int N>
+// AUX: cache policy bits of the instruction (gfx940+: 1 = sc0, 2 = nt, 16 = sc1); 2 = non-temporal stream
+template <typename real, int N, int AUX = 0>
 __device__ __forceinline__ void buf_load(rsrc_t r, unsigned voff, unsigned soff, real (&out)[N]) {
   constexpr int BYTES = (int)sizeof(real) * N;
   static_assert(BYTES == 4 || BYTES == 8 || BYTES == 16 || BYTES == 32, "unsupported vector width");
   if constexpr (BYTES == 4) {
-    const unsigned v = __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0);
+    const unsigned v = __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, AUX);
     __builtin_memcpy(&out, &v, 4);
   } else if constexpr (BYTES == 8) {
-    const auto v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    const auto v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, AUX);
     __builtin_memcpy(&out, &v, 8);
   } else if constexpr (BYTES == 16) {
-    const auto v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    const auto v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, AUX);
     __builtin_memcpy(&out, &v, 16);
   } else {
-    const auto v0 = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
-    const auto v1 = __builtin_amdgcn_raw_buffer_load_b128(r, voff + 16u, soff, 0);
+    const auto v0 = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, AUX);
+    const auto v1 = __builtin_amdgcn_raw_buffer_load_b128(r, voff + 16u, soff, AUX);
     __builtin_memcpy(&out, &v0, 16);
     __builtin_memcpy(reinterpret_cast<char*>(&out) + 16, &v1, 16);
   }
@@ -346,6 +347,11 @@ struct MatAddr {
 // tile of the wave-step starting at row wbase (wave-uniform); rows >= T read as zero.
 // WLDS: this step's rows of W are resident in LDS (each row is only ever touched by its owner lane,
 // so no barrier is needed around these accesses).
+// Cache policy of the row-major X stream (see buf_load).  Experiment -DHIPNMF_X_AUX=2: stream X non-temporal so that
+// the rows of W that do not fit in LDS (re-read and re-written every iteration) stay in the XCD's L2.
+#ifndef HIPNMF_X_AUX
+#define HIPNMF_X_AUX 0
+#endif
 template <typename real, int G, int CH, int K, bool WLDS>
 __device__ __forceinline__ void load_tile(RowTile<real, G, CH, K>& t, const MatAddr<real, G, CH, K>& ma, int wbase,
                                           bool in_range) {
@@ -356,7 +362,8 @@ __device__ __forceinline__ void load_tile(RowTile<real, G, CH, K>& t, const MatA
     const unsigned srow = (unsigned)wbase * ma.xrow_b;
 #pragma unroll
     for (int q = 0; q < CH / V; ++q)
-      buf_load<real, V>(ma.xr, grp_ok ? ma.xoff[q * V] : OOB, srow, *reinterpret_cast<real(*)[V]>(&t.x[q * V][0]));
+      buf_load<real, V, (HIPNMF_X_AUX)>(ma.xr, grp_ok ? ma.xoff[q * V] : OOB, srow,
+                                        *reinterpret_cast<real(*)[V]>(&t.x[q * V][0]));
   } else
 #pragma unroll
   for (int cc = 0; cc < CH; ++cc) buf_load<real, G>(ma.xr, grp_ok ? ma.xoff[cc] : OOB, sbase, t.x[cc]);

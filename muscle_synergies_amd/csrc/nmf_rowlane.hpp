@@ -109,6 +109,15 @@ __device__ __forceinline__ void rl_store_w_global(const RlCtx<K>& cx, const floa
   for (int c = 0; c < K; ++c) buf_store<float>(cx.wr, wv, sbase + (unsigned)c * cx.ldw_b, w[c]);
 }
 
+// tile i of this wave is streamed: its X always, its W too when the rows live neither in LDS nor in registers
+// (issued one tile ahead of their use, like X)
+template <int K, int NWR>
+__device__ __forceinline__ void rl_prefetch(const RlCtx<K>& cx, float (&x)[16], float (&wg)[K], int i, int wbase,
+                                            bool valid) {
+  rl_load_x<K>(cx, x, wbase, valid);
+  if (valid && i >= cx.ilds + NWR) rl_load_w_global<K>(cx, wg, wbase);
+}
+
 // operands of the two MFMA products, rebuilt from LDS after every H update
 struct RlHops {
   float hq0, hq1;    // lane l: H[l%4][l/4], H[4 + l%4][l/4]        (0 where the component does not exist)
@@ -170,13 +179,19 @@ __device__ __forceinline__ void rl_update(const float (&x)[16], float (&w)[K], c
     for (int c = 0; c < K; ++c) den[c] = c < 4 ? d0[c & 3] : d1[c & 3];
   }
   const f4 n0 = n0a + n0b, n1 = n1a + n1b;
+  if (l1w > 0.f || l2w > 0.f) {  // wave-uniform and rare: one scalar branch instead of 4 K selects per tile
+#pragma unroll
+    for (int c = 0; c < K; ++c) {
+      float d = den[c];
+      if (l1w > 0.f) d = d + l1w;
+      if (l2w > 0.f) d = d + l2w * w[c];
+      den[c] = d;
+    }
+  }
 #pragma unroll
   for (int c = 0; c < K; ++c) {
     num[c] = c < 4 ? n0[c & 3] : n1[c & 3];
-    float d = den[c];
-    if (l1w > 0.f) d = d + l1w;
-    if (l2w > 0.f) d = d + l2w * w[c];
-    den[c] = (d == 0.f) ? eps_val<float>() : d;
+    den[c] = (den[c] == 0.f) ? eps_val<float>() : den[c];
   }
   quotients<K>(num, den, quo);
 #pragma unroll
@@ -200,9 +215,9 @@ __device__ __forceinline__ void rl_update(const float (&x)[16], float (&w)[K], c
 }
 
 // W of tile i of this wave: LDS cache, resident registers, or global memory (wave-uniform choice)
-template <int K, int NWR>
+template <int K, int NWR, bool PREFETCHED = false>
 __device__ __forceinline__ void rl_get_w(const RlCtx<K>& cx, float (&w)[K], const float (&wres)[NWR > 0 ? NWR : 1][K],
-                                         int i, int wbase) {
+                                         int i, int wbase, const float* wg = nullptr) {
   if (i < cx.ilds) {
     const float* p = cx.lds_w + wbase + cx.lane;
 #pragma unroll
@@ -216,6 +231,9 @@ __device__ __forceinline__ void rl_get_w(const RlCtx<K>& cx, float (&w)[K], cons
         for (int c = 0; c < K; ++c) w[c] = wres[qq][c];
       }
     });
+  } else if constexpr (PREFETCHED) {
+#pragma unroll
+    for (int c = 0; c < K; ++c) w[c] = wg[c];
   } else {
     rl_load_w_global<K>(cx, w, wbase);
   }
@@ -256,8 +274,11 @@ __device__ __forceinline__ void rl_resid(const float (&x)[16], const float (&w)[
   }
 }
 
+#ifndef HIPNMF_RL_THREADS
+#define HIPNMF_RL_THREADS 512  // 256: one wave per SIMD with up to 512 VGPRs (experiment: more resident tiles)
+#endif
 template <int K, int NXR = rl_nxr<K>(), int NWR = rl_nwr<K>(), int PF = (HIPNMF_RL_PF)>
-__global__ void __launch_bounds__(512) fit_rowlane_kernel(SolveArgs<float> a) {
+__global__ void __launch_bounds__(HIPNMF_RL_THREADS) fit_rowlane_kernel(SolveArgs<float> a) {
   using C = Cfg<float, 1, 16, K>;
   constexpr int MP = 16, NB = C::NB;
   constexpr int NXA = NXR > 0 ? NXR : 1, NWA = NWR > 0 ? NWR : 1;
@@ -305,7 +326,13 @@ __global__ void __launch_bounds__(512) fit_rowlane_kernel(SolveArgs<float> a) {
   cx.lds_w = lds_w;
   cx.lds_stride = lds_stride;
   cx.ilds = lds_rows / stride;
-  auto tile_base = [&](int i) __attribute__((always_inline)) { return (i * nw + wave) * WAVE; };
+  // row base of tile i of this wave.  The index is made opaque so that the bases (and everything derived from them)
+  // of the statically unrolled resident tiles are recomputed with two SALU instructions where they are used
+  // instead of being hoisted out of the iteration loop into dozens of SGPRs (which then spill).
+  auto tile_base = [&](int i) __attribute__((always_inline)) {
+    asm volatile("" : "+s"(i));
+    return (i * nw + wave) * WAVE;
+  };
 
   for (int t0 = 0; t0 < lds_rows; t0 += blockDim.x) {  // row t0 + tid is owned by this thread in every pass
     const int t = t0 + threadIdx.x;
@@ -401,8 +428,8 @@ __global__ void __launch_bounds__(512) fit_rowlane_kernel(SolveArgs<float> a) {
   }
   const bool upd = a.update_h != 0;
   int n_iter = 0;
-  float xa[16], xb[16];
-  rl_load_x<K>(cx, xa, tile_base(NXR), NXR < ntw);
+  float xa[16], xb[16], wga[K], wgb[K];
+  rl_prefetch<K, NWR>(cx, xa, wga, NXR, tile_base(NXR), NXR < ntw);
   for (int it = 1; it <= a.max_iter; ++it) {
     n_iter = it;
     float accA[K][16], accB[NB];
@@ -427,20 +454,20 @@ __global__ void __launch_bounds__(512) fit_rowlane_kernel(SolveArgs<float> a) {
         }
       }
     });
-    // streamed tiles: xa holds (or has in flight) tile i
+    // streamed tiles: xa (and wga for the tail rows of W) holds, or has in flight, tile i
     int i = NXR;
     if constexpr (PF >= 2) {
       for (; i + 1 < ntw; i += 2) {
         float w[K];
-        rl_load_x<K>(cx, xb, tile_base(i + 1), true);
+        rl_prefetch<K, NWR>(cx, xb, wgb, i + 1, tile_base(i + 1), true);
         int wb = tile_base(i);
-        rl_get_w<K, NWR>(cx, w, wres, i, wb);
+        rl_get_w<K, NWR, true>(cx, w, wres, i, wb, wga);
         rl_update<K>(xa, w, ho, hht, accA, accB, a.l1w, a.l2w, upd);
         rl_put_w<K, NWR>(cx, w, wres, i, wb);
         __builtin_amdgcn_sched_barrier(0);
-        rl_load_x<K>(cx, xa, tile_base(i + 2), i + 2 < ntw);
+        rl_prefetch<K, NWR>(cx, xa, wga, i + 2, tile_base(i + 2), i + 2 < ntw);
         wb = tile_base(i + 1);
-        rl_get_w<K, NWR>(cx, w, wres, i + 1, wb);
+        rl_get_w<K, NWR, true>(cx, w, wres, i + 1, wb, wgb);
         rl_update<K>(xb, w, ho, hht, accA, accB, a.l1w, a.l2w, upd);
         rl_put_w<K, NWR>(cx, w, wres, i + 1, wb);
         __builtin_amdgcn_sched_barrier(0);
@@ -448,7 +475,7 @@ __global__ void __launch_bounds__(512) fit_rowlane_kernel(SolveArgs<float> a) {
       if (i < ntw) {
         float w[K];
         const int wb = tile_base(i);
-        rl_get_w<K, NWR>(cx, w, wres, i, wb);
+        rl_get_w<K, NWR, true>(cx, w, wres, i, wb, wga);
         rl_update<K>(xa, w, ho, hht, accA, accB, a.l1w, a.l2w, upd);
         rl_put_w<K, NWR>(cx, w, wres, i, wb);
         __builtin_amdgcn_sched_barrier(0);
@@ -457,15 +484,16 @@ __global__ void __launch_bounds__(512) fit_rowlane_kernel(SolveArgs<float> a) {
       for (; i < ntw; ++i) {
         float w[K];
         const int wb = tile_base(i);
-        rl_get_w<K, NWR>(cx, w, wres, i, wb);
+        rl_get_w<K, NWR, true>(cx, w, wres, i, wb, wga);
         rl_update<K>(xa, w, ho, hht, accA, accB, a.l1w, a.l2w, upd);
         rl_put_w<K, NWR>(cx, w, wres, i, wb);
-        rl_load_x<K>(cx, xa, tile_base(i + 1), i + 1 < ntw);
+        rl_prefetch<K, NWR>(cx, xa, wga, i + 1, tile_base(i + 1), i + 1 < ntw);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    // X does not depend on H: start streaming the next iteration's first tile now, under the reduction
-    if (it < a.max_iter) rl_load_x<K>(cx, xa, tile_base(NXR), NXR < ntw);
+    // X does not depend on H (and the first streamed tile's W, if it streams at all, is final): start the next
+    // iteration's first tile now, under the reduction
+    if (it < a.max_iter) rl_prefetch<K, NWR>(cx, xa, wga, NXR, tile_base(NXR), NXR < ntw);
     if (upd) {
       // s.part was last read before the previous iteration's second barrier (or by a residual pass that ends with
       // a barrier), so the records can be written right away: two workgroup barriers per iteration
@@ -479,7 +507,7 @@ __global__ void __launch_bounds__(512) fit_rowlane_kernel(SolveArgs<float> a) {
       const float err = residual();
       if ((prev - err) / err0 < a.tol) break;
       prev = err;
-      rl_load_x<K>(cx, xa, tile_base(NXR), NXR < ntw);  // the residual pass used the buffers
+      rl_prefetch<K, NWR>(cx, xa, wga, NXR, tile_base(NXR), NXR < ntw);  // the residual pass used the buffers
     }
   }
   // reconstruction_err_ (_nmf.py:1628-1630) + per-column SSE / sum X^2 for VAF (analysis.py:654-662)

@@ -1,9 +1,11 @@
-set -x
+# usage: bash tools/run_variants.sh <threads> <ROWLANE 0|1> <variant-suffix|default>...   (libraries built with
+# python -m muscle_synergies_amd.build --variant <suffix> --only <tu> --flag=...)
 cd $GRAFT_REPO_ROOT
-export HIPNMF_ROWLANE=0
-python tools/quick_bench.py --batch 2048 --iters 200 --rowmajor --threads 512 --reps 2 2>&1 | grep -v amdgpu.ids
-export HIPNMF_ROWLANE=1
-for v in "" _rl_x0w0p1 _rl_x0w5p1 _rl_x1w5p1 _rl_x2w4p1 _rl_x0w0p2 _rl_x0w5p2; do
-  echo "== variant $v"
-  HIPNMF_LIBRARY=$GRAFT_REPO_ROOT/muscle_synergies_amd/lib/libhip_nmf$v.so python tools/quick_bench.py --batch 2048 --iters 200 --rowmajor --threads 512 --reps 2 2>&1 | grep -v amdgpu.ids
+threads=$1; shift
+export HIPNMF_ROWLANE=$1; shift
+for v in "$@"; do
+  lib=$GRAFT_REPO_ROOT/muscle_synergies_amd/lib/libhip_nmf_$v.so
+  [ "$v" = default ] && lib=$GRAFT_REPO_ROOT/muscle_synergies_amd/lib/libhip_nmf.so
+  echo "== variant $v threads=$threads rowlane=$HIPNMF_ROWLANE"
+  HIPNMF_LIBRARY=$lib python tools/quick_bench.py --batch ${BATCH:-2048} --iters 200 --rowmajor --threads $threads --reps 3 2>&1 | grep "rep=[12]"
 done

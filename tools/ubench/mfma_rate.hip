@@ -223,6 +223,127 @@ __global__ void __launch_bounds__(512) k_tile_mfma(float* out, int iters, float 
   out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = sres;
 }
 
+// v2 of the row-per-lane tile: everything that is an FMA over pairs of adjacent channels is a v_pk_fma_f32 (one
+// wave alone issues a packed FMA every ~2.4 ns = 1.2 ns per FMA against 1.9 ns for v_fmac_f32: tools/ubench/
+// vgpr_bank.hip), X H^T for components 0..3 (and optionally W H H^T) on the matrix pipe, component 4 packed.
+//   NUMV: 0 all on VALU packed (H as 40 VGPR pairs) | 1 MFMA c < 4 + packed c = 4 (H row 4 as 8 VGPR pairs)
+//   DENV: 0 VALU scalar with H H^T in SGPRs | 1 MFMA c < 4 + VALU c = 4
+//   ASM:  1 broadcast of wn[c] through op_sel in inline assembly | 0 compiler splat (v_mov per component)
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 pk_fma_lo(f2 w, f2 x, f2 acc) {  // acc += {w.x, w.x} * x
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(w), "v"(x));
+  return acc;
+}
+__device__ __forceinline__ f2 pk_fma_hi(f2 w, f2 x, f2 acc) {  // acc += {w.y, w.y} * x
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(w), "v"(x));
+  return acc;
+}
+template <int NUMV, int DENV, int ASM>
+__global__ void __launch_bounds__(512) k_tile_v2(float* out, int iters, float seed) {
+  constexpr int K = 5, M = 16, NB = 15;
+  const int lane = threadIdx.x & 63;
+  f2 hp[K][8];      // NUMV == 0: all of H as pairs; NUMV == 1: only row 4 is used
+  float hht[K][K];
+  for (int c = 0; c < K; ++c) {
+    for (int p = 0; p < 8; ++p) hp[c][p] = f2{out[c * M + 2 * p] + seed, out[c * M + 2 * p + 1] + seed};
+    for (int c2 = 0; c2 < K; ++c2) hht[c][c2] = uniform(out[128 + c * K + c2] + seed);
+  }
+  const float hq0 = out[(lane % 4) * M + lane / 4] + seed;
+  const float hhq0 = (lane / 4 < K) ? out[128 + (lane / 4) * K + lane % 4] + seed : 0.f;
+  f2 accA[K][8];
+  float accB[NB];
+  f2 x2[8];
+  float w[K];
+  for (int c = 0; c < K; ++c)
+    for (int p = 0; p < 8; ++p) accA[c][p] = f2{0.f, 0.f};
+  for (int i = 0; i < NB; ++i) accB[i] = 0.f;
+  for (int p = 0; p < 8; ++p) x2[p] = f2{seed * 0.5f + 0.001f * (threadIdx.x + p), seed * 0.4f + 0.002f * (threadIdx.x + p)};
+  for (int c = 0; c < K; ++c) w[c] = seed + 0.002f * (threadIdx.x + c);
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int p = 0; p < 8; ++p) asm volatile("" : "+v"(x2[p]));
+    float num[K], den[K], quo[K];
+    if constexpr (NUMV == 0) {
+#pragma unroll
+      for (int c = 0; c < K; ++c) {
+        f2 s2 = x2[0] * hp[c][0];
+#pragma unroll
+        for (int p = 1; p < 8; ++p) s2 = __builtin_elementwise_fma(x2[p], hp[c][p], s2);
+        num[c] = s2.x + s2.y;
+      }
+    } else {
+      f4 na = {0.f, 0.f, 0.f, 0.f}, nb = na;
+      static_for<8>([&](auto P) {
+        constexpr int p = decltype(P)::value;
+        na = __builtin_amdgcn_mfma_f32_4x4x1f32(hq0, x2[p].x, na, 4, 2 * p, 0);
+        nb = __builtin_amdgcn_mfma_f32_4x4x1f32(hq0, x2[p].y, nb, 4, 2 * p + 1, 0);
+      });
+      f2 s2 = x2[0] * hp[4][0];
+#pragma unroll
+      for (int p = 1; p < 8; ++p) s2 = __builtin_elementwise_fma(x2[p], hp[4][p], s2);
+      const f4 n = na + nb;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) num[c] = n[c];
+      num[4] = s2.x + s2.y;
+    }
+    if constexpr (DENV == 0) {
+#pragma unroll
+      for (int c = 0; c < K; ++c) {
+        float dd = w[0] * hht[0][c];
+#pragma unroll
+        for (int c2 = 1; c2 < K; ++c2) dd = fma_(w[c2], hht[c2][c], dd);
+        den[c] = dd;
+      }
+    } else {
+      f4 d0 = {0.f, 0.f, 0.f, 0.f};
+      static_for<K>([&](auto C2) {
+        constexpr int c2 = decltype(C2)::value;
+        d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(hhq0, w[c2], d0, 4, c2, 0);
+      });
+#pragma unroll
+      for (int c = 0; c < 4; ++c) den[c] = d0[c];
+      float dd = w[0] * hht[0][4];
+#pragma unroll
+      for (int c2 = 1; c2 < K; ++c2) dd = fma_(w[c2], hht[c2][4], dd);
+      den[4] = dd;
+    }
+#pragma unroll
+    for (int c = 0; c < K; ++c) den[c] = (den[c] == 0.f) ? eps_val<float>() : den[c];
+    quotients<K>(num, den, quo);
+    f2 wn2[3];
+    wn2[0] = f2{w[0] * quo[0], w[1] * quo[1]};
+    wn2[1] = f2{w[2] * quo[2], w[3] * quo[3]};
+    wn2[2] = f2{w[4] * quo[4], 0.f};
+#pragma unroll
+    for (int c = 0; c < K; ++c) w[c] = wn2[c / 2][c % 2];
+#pragma unroll
+    for (int c = 0; c < K; ++c)
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        if constexpr (ASM) {
+          accA[c][p] = (c % 2) ? pk_fma_hi(wn2[c / 2], x2[p], accA[c][p]) : pk_fma_lo(wn2[c / 2], x2[p], accA[c][p]);
+        } else {
+          accA[c][p] = __builtin_elementwise_fma(f2{w[c], w[c]}, x2[p], accA[c][p]);
+        }
+      }
+    int idx = 0;
+#pragma unroll
+    for (int c = 0; c < K; ++c)
+#pragma unroll
+      for (int c2 = c; c2 < K; ++c2) {
+        accB[idx] = fma_(w[c], w[c2], accB[idx]);
+        ++idx;
+      }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  float sres = 0.f;
+  for (int c = 0; c < K; ++c) { sres += w[c]; for (int p = 0; p < 8; ++p) sres += accA[c][p].x + accA[c][p].y; }
+  for (int i = 0; i < NB; ++i) sres += accB[i];
+  out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = sres;
+}
+template <int NUMV, int DENV, int ASM>
+void run_tile_v2(float* d, const char* name);
+
 // 16x16x4 formulations (operands assumed to be in MFMA layout already; 64 rows = 4 sub-tiles of 16 rows):
 //  STEP1: X H^T = 4 MFMAs per 16 rows (A = X sub-tile, K = channels; B = H^T padded to 16 columns);
 //  STEP2: W^T [X | W] = per 4 rows one MFMA for the X block and one for the W block (M = k padded to 16),
@@ -343,6 +464,11 @@ void run_tile16(float* d, const char* name) {
   time_tile([&](int threads, int iters) { k_tile_16<K, S1, S2><<<256, threads>>>(d, iters, 0.7f); }, name);
 }
 
+template <int NUMV, int DENV, int ASM>
+void run_tile_v2(float* d, const char* name) {
+  time_tile([&](int threads, int iters) { k_tile_v2<NUMV, DENV, ASM><<<256, threads>>>(d, iters, 0.7f); }, name);
+}
+
 int main() {
   float* d;
   CK(hipMalloc(&d, 256 * 1024 * 4 * 4));
@@ -378,6 +504,11 @@ int main() {
   run_tile<5, 2, 2, 0, 2>(d, "num + den: MFMA both groups (2 chains)");
   run_tile<5, 0, 0, 1, 1>(d, "VALU, no W^T X / W^T W (step 1 only)");
   run_tile<5, 2, 2, 1, 1>(d, "num + den MFMA, no W^T X / W^T W (step 1 only)");
+  run_tile_v2<0, 0, 0>(d, "v2: packed VALU everything (compiler splat)");
+  run_tile_v2<0, 0, 1>(d, "v2: packed VALU everything (op_sel broadcast)");
+  run_tile_v2<1, 0, 1>(d, "v2: num MFMA c<4 + packed c=4, den VALU");
+  run_tile_v2<1, 1, 1>(d, "v2: num + den MFMA c<4, packed / VALU c=4");
+  run_tile_v2<1, 1, 0>(d, "v2: same, compiler splat");
   run_tile<4, 0, 0, 0, 1>(d, "k=4: VALU everything");
   run_tile<4, 2, 2, 0, 1>(d, "k=4: num + den MFMA");
   run_tile16<5, 1, 0>(d, "16x16x4: X H^T on MFMA, rest VALU");
