@@ -1,21 +1,29 @@
 #!/usr/bin/env python3
-"""Headline benchmark: NMF mu-update iterations/sec on a batch of synthetic EMG matrices.
+"""Benchmarks of the NMF multiplicative-update hot path on MI355X (BASELINE.json metric and configs).
 
-    python bench.py --gpus 1 --steps 3 --warmup 1
+    python bench.py --gpus 1 --steps 3 --warmup 1                       # headline: config #3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W [--config 3|4|5|2]
 
-One *step* = one batched fit (``hipnmf_fit_batched_f32`` through the Python host): ``--iters`` (500)
-Lee-Seung multiplicative-update iterations (tol = 0, so exactly that many, as sklearn does) on every
-matrix of the rank's batch, from a fixed ``init='custom'`` W0/H0, inputs already resident in HBM.
-Workload = BASELINE.json configs[2]: 4096 synthetic EMG matrices 16 ch x 10 000 samples, k = 5, fp32,
-per GPU.  The factorisations are independent, so ranks share nothing: no data-path collective, weak
-scaling (the batch per GPU is fixed); the only collectives are the timing barrier and the max over ranks.
+--config 3 (default, BASELINE.json configs[2], the configuration the metric is quoted on): one *step* = one batched
+    fit (``hipnmf_fit_batched_f32`` through the Python host) of 4096 synthetic EMG matrices 16 ch x 10 000 samples
+    per GPU, k = 5, fp32, ``--iters`` (500) Lee-Seung iterations (tol = 0, so exactly that many, as sklearn does)
+    from a fixed ``init='custom'`` W0/H0, inputs resident in HBM.  The factorisations are independent: ranks share
+    nothing, no data-path collective, weak scaling (4096 matrices per GPU).
+--config 4 (configs[3]): per-trial rank sweep k = 2..8 (500 iterations each, random init drawn on the device, VAF >=
+    0.90 selection) over 1024 trials IN TOTAL, scattered by trial over the ranks (strong scaling, no collective).
+--config 5 (configs[4]): ONE matrix 16 x 2e8 (``--T5``), rows sharded over the ranks (strong scaling), generated shard
+    by shard on the device from counter seeds; one step = ``--iters5`` (20) iterations of the time-sharded solver:
+    ``hipnmf_shard_pass`` on every sub-shard of the rank, ONE packed all-reduce of k*m + k*k = 105 floats over RCCL,
+    ``hipnmf_shard_hupdate``.  A unit is one iteration of the whole matrix (20.8 GB of algorithmic traffic).
+--config 2 (configs[1]): one 16 x 10 000 matrix, 500 iterations per step (cooperative kernel); N > 1 = replicas.
 
 Rank 0 prints ONE JSON line (fields: see the task contract) including
-  roofline     -- algorithmic bytes per launch / HIP-event duration of the solver kernel vs HBM peak
-  cpu_baseline -- scikit-learn's NMF(solver='mu') (the reference's arithmetic) on this host's cores,
-                  bounded sample, N = 1 only; run BEFORE the GPU is initialised (worker processes).
+  roofline     -- config 3/4/2: fp32 issue roof (f32 MFMA = f32 VALU = 157.3 TFLOP/s): algorithmic FLOPs per launch /
+                  HIP-event duration of the solver kernel, plus ``memory``: the byte model (algorithmic bytes, bytes the
+                  design really moves, the measured Infinity-Cache stream rate that binds); config 5: HBM.
+  cpu_baseline -- scikit-learn's NMF(solver='mu') (the reference's arithmetic) on this host's cores, bounded sample,
+                  N = 1 only; run BEFORE the GPU is initialised (worker processes).
 """
 import argparse
 import json
@@ -27,7 +35,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md:36); 6290 GB/s measured copy
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md:36); 6290 GB/s measured copy
+FP32_PEAK_TFLOPS = 157.3   # fp32 vector = fp32 matrix peak (MI355X_MICROARCH.md:41-42)
+STREAM_PEAK_GBS = 7800.0   # measured: 256 workgroups re-reading "their" 640 KB region (tools/ubench/mall_stream.hip,
+                           # profiles/README.md): 7.2 - 8.1 TB/s whatever the loads in flight -- the roof that binds
 
 
 def parse_args():
@@ -35,22 +46,26 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=4096, help="matrices per GPU")
-    ap.add_argument("--iters", type=int, default=500, help="mu iterations per fit (= per step)")
+    ap.add_argument("--config", type=int, default=3, choices=[2, 3, 4, 5], help="BASELINE.json configuration (1-based)")
+    ap.add_argument("--batch", type=int, default=None, help="config 3: matrices per GPU (4096); config 4: trials in total (1024)")
+    ap.add_argument("--iters", type=int, default=500, help="mu iterations per fit (configs 2-4)")
     ap.add_argument("--T", type=int, default=10_000)
     ap.add_argument("--m", type=int, default=16)
     ap.add_argument("--k", type=int, default=5)
+    ap.add_argument("--T5", type=int, default=200_000_000, help="config 5: rows of the single long matrix")
+    ap.add_argument("--iters5", type=int, default=20, help="config 5: iterations per step")
+    ap.add_argument("--subshard", type=int, default=25_000_000, help="config 5: rows per sub-shard (< 2 GiB of X each)")
     ap.add_argument("--threads", type=int, default=0, help="workgroup size override (0 = library default)")
     ap.add_argument("--x-layout", choices=["row", "channel"], default="row",
-                    help="memory order of the X batch handed to the engine: [B][T][m] (C order) or [B][m][T]")
+                    help="config 3: memory order of the X batch handed to the engine: [B][T][m] (C order) or [B][m][T]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="matrices in the CPU baseline sample (0 = auto)")
     return ap.parse_args()
 
 
 # ------------------------------------------------------------------------------------------------
-# CPU baseline: sklearn (the dependency that holds the reference's NMF arithmetic), one BLAS thread per
-# worker process, all host cores.  Runs before anything touches the GPU.
+# CPU baseline: sklearn (the dependency that holds the reference's NMF arithmetic).  Runs before anything touches
+# the GPU.  (i) one matrix, 1 BLAS thread and all cores, best of 3; (ii) one worker process per core x 1 BLAS thread.
 def _cpu_worker(job):
     seeds, T, m, k, iters = job
     import warnings
@@ -76,6 +91,29 @@ def _cpu_worker(job):
     return len(seeds), dt
 
 
+def _cpu_single(job):
+    T, m, k, iters, nthreads = job
+    import warnings
+
+    import numpy as np
+    from threadpoolctl import threadpool_limits
+
+    from muscle_synergies_amd.synth import emg_matrix, random_init
+
+    warnings.simplefilter("ignore")
+    from sklearn.decomposition import NMF
+
+    X = emg_matrix(0, T=T, m=m, dtype=np.float32)
+    W0, H0 = random_init(X, k, 0)
+    best = float("inf")
+    with threadpool_limits(limits=nthreads):
+        for _ in range(3):
+            t0 = time.perf_counter()
+            NMF(k, solver="mu", init="custom", tol=0, max_iter=iters).fit_transform(X, W=W0.copy(), H=H0.copy())
+            best = min(best, time.perf_counter() - t0)
+    return iters / best
+
+
 def cpu_baseline(a):
     import multiprocessing as mp
 
@@ -94,6 +132,9 @@ def cpu_baseline(a):
     per = n // cores
     jobs = [(list(range(1000 + w * per, 1000 + (w + 1) * per)), a.T, a.m, a.k, a.iters) for w in range(cores)]
     ctx = mp.get_context("spawn")
+    with ctx.Pool(1) as pool:  # single-matrix numbers in a fresh process each
+        one = pool.apply(_cpu_single, ((a.T, a.m, a.k, a.iters, 1),))
+        allc = pool.apply(_cpu_single, ((a.T, a.m, a.k, a.iters, cores),))
     t0 = time.perf_counter()
     with ctx.Pool(cores) as pool:
         out = pool.map(_cpu_worker, jobs)
@@ -105,142 +146,350 @@ def cpu_baseline(a):
         "unit": "matrix-iterations/s",
         "cores": cores,
         "kind": "reference",
+        "single_matrix_1_thread": one,
+        "single_matrix_all_cores": allc,
         "sample": (f"scikit-learn {sklearn.__version__} NMF(solver='mu', init='custom', tol=0, max_iter={a.iters}) "
                    f"on {total} of the synthetic {a.m}x{a.T} k={a.k} fp32 matrices, {cores} worker processes x 1 BLAS "
-                   f"thread; fit time of the slowest worker {slowest:.2f} s (pool wall {wall:.1f} s incl. data generation)"),
+                   f"thread; fit time of the slowest worker {slowest:.2f} s (pool wall {wall:.1f} s incl. data "
+                   f"generation).  One matrix alone, best of 3: {one:.0f} it/s with 1 BLAS thread, {allc:.0f} it/s "
+                   f"with {cores} BLAS threads"),
     }
+
+
+# ------------------------------------------------------------------------------------------------
+class Ctx:
+    """Rank / device / process-group plumbing shared by the configurations."""
+
+    def __init__(self, a):
+        self.a = a
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        if self.world != a.gpus and self.world > 1:
+            raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={self.world}")
+        self.distributed = self.world > 1 or "TORCHELASTIC_RUN_ID" in os.environ  # under torchrun: always a group
+
+    def init_gpu(self):
+        import torch
+
+        self.torch = torch
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: no ROCm GPU visible (the engine has no CPU fallback)")
+        torch.cuda.set_device(self.local_rank)
+        self.dev = torch.device("cuda", self.local_rank)
+        if self.distributed:
+            import torch.distributed as dist
+
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group(backend="nccl", device_id=self.dev)
+            self.dist = dist
+
+    def barrier(self):
+        if self.distributed:
+            self.dist.barrier()
+        self.torch.cuda.synchronize(self.dev)
+
+    def timed(self, step):
+        """W untimed warm-up steps, then EXACTLY K steps between barrier + synchronize, max over ranks."""
+        a = self.a
+        for _ in range(a.warmup):
+            step()
+        self.barrier()
+        t0 = time.perf_counter()
+        outs = [step() for _ in range(a.steps)]
+        self.torch.cuda.synchronize(self.dev)
+        elapsed = time.perf_counter() - t0
+        self.barrier()
+        if self.distributed:
+            t = self.torch.tensor([elapsed], dtype=self.torch.float64, device=self.dev)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed, outs
+
+    def finish(self):
+        if self.distributed:
+            self.dist.destroy_process_group()
+
+
+def _traffic(kernel, **key):
+    """Bytes per launch measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE for exactly this kernel instance and
+    workload (tools/measure_traffic.sh writes profiles/traffic.json); None when no matching measurement is committed."""
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(tpath) as f:
+            entries = json.load(f)
+        for e in entries if isinstance(entries, list) else [entries]:
+            if e.get("kernel") == kernel and all(e.get(k) == v for k, v in key.items()):
+                return e.get("l2_fabric_bytes_per_launch")
+    except Exception:  # noqa: BLE001
+        pass
+    return None
+
+
+def flops_per_unit(T, m, k):
+    """One mu iteration of one matrix: 4 T k (m + k) + 2 T k + 4 k^2 m + 2 k m."""
+    return 4 * T * k * (m + k) + 2 * T * k + 4 * k * k * m + 2 * k * m
+
+
+def compute_roofline(kernel, kernel_ms, units_per_launch, T, m, k, traffic=None, moved_bytes_per_unit=None):
+    fl = flops_per_unit(T, m, k)
+    by = 4 * T * (m + 2 * k)  # read X once, read + write W once (SURVEY 8d)
+    sec = kernel_ms * 1e-3
+    tf = fl * units_per_launch / sec / 1e12
+    mem = {
+        "algorithmic_bytes_per_unit": by,
+        "algorithmic_gbs": by * units_per_launch / sec / 1e9,
+        "hbm_peak_gbs": HBM_PEAK_GBS,
+        "l2_fabric_bytes_per_launch": traffic,
+        "note": ("the 256 matrices being worked on (~190 MB) sit in the 256 MiB Infinity Cache and most rows of W in "
+                 "LDS, so algorithmic bytes / time may exceed the HBM line; what binds is the rate at which the XCDs "
+                 "can re-read their matrices: stream_peak_gbs, measured by tools/ubench/mall_stream.hip"),
+        "stream_peak_gbs": STREAM_PEAK_GBS,
+    }
+    if traffic:
+        mem["l2_fabric_gbs"] = traffic / sec / 1e9
+        mem["frac_of_stream_peak"] = traffic / sec / 1e9 / STREAM_PEAK_GBS
+    elif moved_bytes_per_unit:
+        mem["design_bytes_per_unit"] = moved_bytes_per_unit
+        mem["design_gbs"] = moved_bytes_per_unit * units_per_launch / sec / 1e9
+        mem["frac_of_stream_peak"] = mem["design_gbs"] / STREAM_PEAK_GBS
+    return {
+        "bound": "mfma",
+        "bound_detail": "fp32 issue: f32 MFMA = f32 VALU = 157.3 TFLOP/s on gfx950 (the kernels use both)",
+        "achieved": tf,
+        "peak": FP32_PEAK_TFLOPS,
+        "unit": "TFLOP/s",
+        "frac": tf / FP32_PEAK_TFLOPS,
+        "traffic": traffic,
+        "kernel": kernel,
+        "kernel_ms_avg": kernel_ms,
+        "flops_per_unit": fl,
+        "units_per_launch": units_per_launch,
+        "memory": mem,
+    }
+
+
+def lds_rows_of_w(k, threads=512):
+    """Rows of W the one-workgroup-per-matrix kernels keep in LDS (hipnmf_api.hip): the design's own byte count."""
+    nw = threads // 64
+    nacc = 16 * k + k * (k + 1) // 2
+    base = 4 * (2 * k * 16 + 2 * k * k + nw * max(nacc, 33) + 8)
+    base = (base + 15) // 16 * 16
+    return (160 * 1024 - base) // (4 * k) // threads * threads
+
+
+# ------------------------------------------------------------------------------------------------ config 3 / 2
+def run_batch(cx, single):
+    a, torch = cx.a, cx.torch
+    import muscle_synergies_amd as ms
+    from muscle_synergies_amd import _lib
+    from muscle_synergies_amd.synth import emg_batch_torch
+
+    B = 1 if single else (a.batch or 4096)
+    # synthetic workload, generated on the device (seeded per rank).  X is handed over as [B, T, m] in C order
+    # (row-major, what sklearn itself takes): the layout the fp32 16-channel kernels stream in place.  The
+    # [B, m, T] storage (a DataFrame's F order, SURVEY 8d) is timed too: the engine then converts it once per fit.
+    X, W0, H0 = emg_batch_torch(B, T=a.T, m=a.m, k=a.k, device=cx.dev, seed=cx.rank)
+    Xc = X.transpose(1, 2)  # logical [B, T, m] view of channel-major storage
+    Xr = Xc.contiguous()
+    handle = _lib.get_handle(cx.local_rank)
+    if a.threads:
+        handle.set_tuning(a.threads, 0, 0)
+    Xv = Xr if a.x_layout == "row" else Xc
+    kernel_ms = []
+
+    def step():
+        r = ms.fit_batched(Xv, W0, H0, max_iter=a.iters, tol=0.0, device=cx.dev, handle=handle)
+        kernel_ms.append(r.kernel_ms)
+        return r
+
+    elapsed, outs = cx.timed(step)
+    kernel = handle.last_kernel()
+    kernel_ms = kernel_ms[a.warmup:]
+    other = None
+    if cx.rank == 0 and not single:  # the other input layout, one untimed + one timed fit, reported beside `value`
+        Xo = Xc if a.x_layout == "row" else Xr
+        ms.fit_batched(Xo, W0, H0, max_iter=a.iters, tol=0.0, device=cx.dev, handle=handle)
+        torch.cuda.synchronize(cx.dev)
+        t0 = time.perf_counter()
+        ms.fit_batched(Xo, W0, H0, max_iter=a.iters, tol=0.0, device=cx.dev, handle=handle)
+        torch.cuda.synchronize(cx.dev)
+        other = B * a.iters / (time.perf_counter() - t0)
+    if cx.rank != 0:
+        return None
+    r = outs[-1]
+    units_per_launch = B * a.iters
+    avg_ms = sum(kernel_ms) / len(kernel_ms)
+    layout = "row-major [B][T][m] (C order)" if a.x_layout == "row" else "channel-major [B][m][T] (F order)"
+    traffic = _traffic(kernel, batch=B, iters=a.iters, T=a.T, m=a.m, k=a.k, x_layout=a.x_layout)
+    moved = 4 * (a.T * 16 + 2 * a.k * max(0, a.T - lds_rows_of_w(a.k))) if (a.m > 8 and not single) else None
+    cfg = {
+        "workload": (f"one synthetic EMG matrix {a.m} ch x {a.T} samples per GPU, k={a.k}, fp32, {a.iters} mu iterations "
+                     f"per fit (BASELINE.json configs[1]; N > 1 = independent replicas)") if single else
+                    (f"batch of {B} synthetic EMG matrices {a.m} ch x {a.T} samples per GPU, k={a.k}, fp32, "
+                     f"{a.iters} mu iterations per fit, tol=0, init='custom' (BASELINE.json configs[2])"),
+        "batch_per_gpu": B, "global_batch": B * cx.world, "n_samples": a.T, "n_features": a.m, "n_components": a.k,
+        "iters_per_step": a.iters, "x_layout": layout,
+        "parallelism": f"independent factorisations scattered over {cx.world} GPU(s), no collective",
+        "all_fits_ran_full_iters": bool((r.n_iter == a.iters).all().item()),
+        "all_residuals_finite": bool(torch.isfinite(r.reconstruction_err).all().item()),
+    }
+    if other is not None:
+        cfg["value_other_x_layout"] = {"x_layout": "channel-major [B][m][T] (F order, DataFrame.to_numpy())"
+                                       if a.x_layout == "row" else "row-major [B][T][m]",
+                                       "matrix_iterations_per_s_1gpu": other,
+                                       "note": "one conversion kernel per fit inside the timed call"}
+    return {"units": cx.world * B * a.iters * a.steps, "elapsed": elapsed, "scaling": "weak", "config": cfg,
+            "roofline": compute_roofline(kernel, avg_ms, units_per_launch, a.T, a.m, a.k, traffic, moved)}
+
+
+# ------------------------------------------------------------------------------------------------ config 4
+def run_rank_sweep(cx):
+    a, torch = cx.a, cx.torch
+    import muscle_synergies_amd as ms
+    from muscle_synergies_amd.engine import partition
+    from muscle_synergies_amd.synth import emg_batch_torch
+
+    total = a.batch or 1024
+    lo, hi = partition(total, cx.world)[cx.rank]  # scattered by trial: contiguous slices, no collective
+    B = hi - lo
+    X, _, _ = emg_batch_torch(B, T=a.T, m=a.m, k=a.k, device=cx.dev, seed=1000 + cx.rank)
+    Xv = X.transpose(1, 2).contiguous()
+    kmin, kmax = 2, 8
+    kms = []
+
+    def step():
+        r = ms.rank_sweep_batched(Xv, kmin, kmax, vaf_threshold=0.90, max_iter=a.iters, tol=0.0, seed=1, device=cx.dev)
+        kms.append(r.kernel_ms)
+        return r
+
+    elapsed, outs = cx.timed(step)
+    if cx.rank != 0:
+        return None
+    r = outs[-1]
+    nk = kmax - kmin + 1
+    kms = kms[a.warmup:]
+    avg_ms = sum(kms) / len(kms)
+    fl = sum(flops_per_unit(a.T, a.m, k) for k in range(kmin, kmax + 1)) * B * a.iters
+    tf = fl / (avg_ms * 1e-3) / 1e12
+    hist = torch.bincount(r.selected.clamp(min=0), minlength=kmax + 1).tolist()
+    return {"units": total * nk * a.iters * a.steps, "elapsed": elapsed, "scaling": "strong",
+            "config": {"workload": (f"rank sweep k={kmin}..{kmax} ({a.iters} mu iterations each, random init drawn on the "
+                                    f"device, smallest k with VAF >= 0.90 selected) over {total} synthetic EMG trials "
+                                    f"{a.m} ch x {a.T} samples in total, fp32 (BASELINE.json configs[3])"),
+                       "trials_total": total, "trials_rank0": B, "n_samples": a.T, "n_features": a.m,
+                       "ranks": [kmin, kmax], "iters_per_fit": a.iters,
+                       "parallelism": f"trials scattered over {cx.world} GPU(s), no collective",
+                       "selected_rank_histogram_rank0": hist},
+            "roofline": {"bound": "mfma", "bound_detail": "fp32 issue (f32 MFMA = f32 VALU = 157.3 TFLOP/s); seven kernels, one per rank",
+                         "achieved": tf, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_PEAK_TFLOPS,
+                         "traffic": None, "kernel": "fit_persistent_kernel<float,1,16,k,0> (k <= 5), fit_rowlane_kernel<k,...> (k >= 6)",
+                         "kernel_ms_avg": avg_ms, "units_per_launch": B * nk * a.iters}}
+
+
+# ------------------------------------------------------------------------------------------------ config 5
+def run_tsharded(cx):
+    a, torch = cx.a, cx.torch
+    from muscle_synergies_amd.synth import emg_shard_torch
+    from muscle_synergies_amd.tsharded import HipShardOps, MultiShardOps, fit_tsharded, shard_bounds
+
+    T, m, k = a.T5, a.m, a.k
+    lo, hi = shard_bounds(T, cx.world)[cx.rank]
+    # this rank's rows as sub-shards of at most --subshard rows (the engine addresses < 2 GiB of X per shard);
+    # sub-shard s of rank r is shard number (global start row // subshard) of the synthetic recording
+    H = None
+    shards = []
+    t = lo
+    while t < hi:
+        n = min(a.subshard, hi - t)
+        # shard number of the synthetic recording: the global sub-shard index when the rank's rows start on a
+        # sub-shard boundary (N = 1, 2, 4, 8 with the defaults: the same data for every N), a per-rank id otherwise
+        sid = t // a.subshard if t % a.subshard == 0 else 10_000 + 100 * cx.rank + len(shards)
+        Xs, Ws, H0 = emg_shard_torch(5, sid, n, m=m, k=k, device=cx.dev)
+        if H is None:
+            H = H0.clone()
+        shards.append(HipShardOps.from_native(Xs, Ws, H))
+        t += n
+    ops = MultiShardOps(shards)
+    torch.cuda.synchronize(cx.dev)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    pass_ms = []
+
+    def step():
+        # the solver runs on torch's current stream (handles are bound to it), so torch events see its kernels
+        ev[0].record()
+        r = fit_tsharded(ops, max_iter=a.iters5, tol=0.0)
+        ev[1].record()
+        torch.cuda.synchronize(cx.dev)
+        pass_ms.append(ev[0].elapsed_time(ev[1]))
+        return r
+
+    elapsed, outs = cx.timed(step)
+    if cx.rank != 0:
+        return None
+    r = outs[-1]
+    pass_ms = pass_ms[a.warmup:]
+    by = 4 * T * (m + 2 * k)  # per iteration of the whole matrix
+    rows_rank0 = hi - lo
+    by_rank = 4 * rows_rank0 * (m + 2 * k)
+    # one fit_tsharded call = iters5 passes + the final residual pass (reads X and W once more): per-iteration device
+    # time of the dominant kernel (slice_pass) is estimated from the step's event time over iters5 + 0.6 passes
+    it_ms = (sum(pass_ms) / len(pass_ms)) / (a.iters5 + 0.6)
+    achieved = by_rank / (it_ms * 1e-3) / 1e9
+    return {"units": a.iters5 * a.steps, "elapsed": elapsed, "scaling": "strong",
+            "config": {"workload": (f"ONE synthetic EMG matrix {m} ch x {T} samples, k={k}, fp32, rows sharded over "
+                                    f"{cx.world} GPU(s) ({rows_rank0} rows on rank 0 in {len(shards)} sub-shard(s)), "
+                                    f"{a.iters5} mu iterations per step, tol=0 (BASELINE.json configs[4])"),
+                       "n_samples": T, "n_features": m, "n_components": k, "iters_per_step": a.iters5,
+                       "unit_of_work": "one mu iteration of the whole matrix",
+                       "parallelism": (f"time-sharded over {cx.world} GPU(s): one all-reduce of {k * m + k * k} floats per "
+                                       f"iteration (RCCL over xGMI), H replicated"),
+                       "reconstruction_err": float(r.reconstruction_err[0]), "vaf_all": float(r.vaf[0, 0])},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "slice_pass_kernel<float,4,4,5> (+ reduce_slices, hupdate, all-reduce per iteration)",
+                         "kernel_ms_avg": it_ms, "algorithmic_bytes_per_unit": by,
+                         "algorithmic_bytes_per_iteration_rank0": by_rank, "units_per_launch": 1,
+                         "note": "per-GPU rate of rank 0: its rows x 4 (m + 2k) bytes per iteration / iteration time "
+                                 "(torch events around the whole step on the solver's stream)"}}
 
 
 # ------------------------------------------------------------------------------------------------
 def main():
     a = parse_args()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != a.gpus and world > 1:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
-    distributed = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ  # under torchrun always use the process group
-
+    cx = Ctx(a)
     cpu = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+    if cx.rank == 0 and cx.world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline(a)  # before the GPU is initialised (spawns worker processes)
-
-    import torch
-
-    import muscle_synergies_amd as ms
-    from muscle_synergies_amd import _lib
-    from muscle_synergies_amd.synth import emg_batch_torch
-
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: no ROCm GPU visible (the engine has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if distributed:
-        import torch.distributed as dist
-
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
-
-    # synthetic workload, generated on the device (seeded per rank).  X is handed over as [B, T, m] in C order
-    # (row-major, what sklearn itself takes): the layout the fp32 16-channel kernel streams in place.
-    # --x-layout channel passes the [B, m, T] storage (a DataFrame's F order) instead; the engine then converts it
-    # once per fit inside the timed step.
-    X, W0, H0 = emg_batch_torch(a.batch, T=a.T, m=a.m, k=a.k, device=dev, seed=rank)
-    Xv = X.transpose(1, 2)  # logical [B, T, m] (sklearn orientation), zero-copy view of channel-major storage
-    if a.x_layout == "row":
-        Xv = Xv.contiguous()
-        del X
-    handle = _lib.get_handle(local_rank)
-    if a.threads:
-        handle.set_tuning(a.threads, 0, 0)
-
-    def step():
-        return ms.fit_batched(Xv, W0, H0, max_iter=a.iters, tol=0.0, device=dev, handle=handle)
-
-    def barrier():
-        if distributed:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
-    for _ in range(a.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    kernel_ms = []
-    for _ in range(a.steps):
-        r = step()
-        kernel_ms.append(r.kernel_ms)
-    torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
-    barrier()
-    if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    if rank == 0:
-        n_iter_ok = bool((r.n_iter == a.iters).all().item())
-        finite = bool(torch.isfinite(r.reconstruction_err).all().item())
-        total_units = world * a.batch * a.iters * a.steps
-        value = total_units / elapsed
-        bytes_per_unit = 4 * a.T * (a.m + 2 * a.k)  # read X once, read + write W once
-        bytes_per_launch = a.batch * a.iters * bytes_per_unit
-        avg_ms = sum(kernel_ms) / len(kernel_ms)
-        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                with open(tpath) as f:
-                    tj = json.load(f)
-                if tj.get("batch") == a.batch and tj.get("iters") == a.iters and tj.get("T") == a.T:
-                    traffic = tj.get("hbm_bytes_per_launch")
-            except Exception:  # noqa: BLE001
-                traffic = None
+    cx.init_gpu()
+    if a.config == 3:
+        res = run_batch(cx, single=False)
+    elif a.config == 2:
+        res = run_batch(cx, single=True)
+    elif a.config == 4:
+        res = run_rank_sweep(cx)
+    else:
+        res = run_tsharded(cx)
+    if cx.rank == 0:
         out = {
             "metric": "NMF mu-iters/sec",
-            "value": value,
+            "value": res["units"] / res["elapsed"],
             "unit": "matrix-iterations/s",
-            "n_gpus": world,
+            "n_gpus": cx.world,
             "steps": a.steps,
             "warmup": a.warmup,
-            "ms_per_step": elapsed / a.steps * 1e3,
+            "ms_per_step": res["elapsed"] / a.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": res["scaling"],
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {
-                "workload": (f"batch of {a.batch} synthetic EMG matrices {a.m} ch x {a.T} samples per GPU, k={a.k}, fp32, "
-                             f"{a.iters} mu iterations per fit, tol=0, init='custom' (BASELINE.json configs[2])"),
-                "batch_per_gpu": a.batch,
-                "global_batch": a.batch * world,
-                "n_samples": a.T,
-                "n_features": a.m,
-                "n_components": a.k,
-                "iters_per_step": a.iters,
-                "x_layout": "row-major [B][T][m] (C order)" if a.x_layout == "row" else "channel-major [B][m][T] (F order)",
-                "parallelism": f"independent factorisations scattered over {world} GPU(s), no collective",
-                "all_fits_ran_full_iters": n_iter_ok,
-                "all_residuals_finite": finite,
-            },
-            "roofline": {
-                "bound": "hbm",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
-                "kernel": "fit_persistent_kernel<float,1,16,5,0>" if (8 < a.m <= 16 and a.k <= 5) else "fit_persistent_kernel",
-                "kernel_ms_avg": avg_ms,
-                "algorithmic_bytes_per_unit": bytes_per_unit,
-                "units_per_launch": a.batch * a.iters,
-            },
+            "config": res["config"],
+            "roofline": res["roofline"],
             "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
-    if distributed:
-        dist.destroy_process_group()
+    cx.finish()
 
 
 if __name__ == "__main__":

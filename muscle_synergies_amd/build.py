@@ -77,13 +77,20 @@ def build(force: bool = False, jobs: int | None = None, extra_flags=(), verbose:
     if variant and only:
         build(jobs=jobs, verbose=verbose)  # default objects for the shared translation units
         mine = [s for s in srcs if os.path.basename(s)[:-4] in only]
+        stamp = os.path.join(objdir, "flags.txt")  # same flags + objects newer than the sources: nothing to do
+        same_flags = os.path.exists(stamp) and open(stamp).read() == " ".join(extra_flags)
+        todo = [s for s in mine if force or not same_flags
+                or _stale(os.path.join(objdir, os.path.basename(s)[:-4] + ".o"), [s, *hdrs])]
         with ThreadPoolExecutor(max_workers=jobs or min(8, os.cpu_count() or 1)) as ex:
-            list(ex.map(lambda s: _compile(s, list(extra_flags), objdir), mine))
+            list(ex.map(lambda s: _compile(s, list(extra_flags), objdir), todo))
+        with open(stamp, "w") as f:
+            f.write(" ".join(extra_flags))
         objs = [os.path.join(objdir if s in mine else OBJ, os.path.basename(s)[:-4] + ".o") for s in srcs]
-        cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", lib]
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+        if todo or _stale(lib, objs):
+            cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", lib]
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
         return lib
     todo = [s for s in srcs
             if force or _stale(os.path.join(objdir, os.path.basename(s)[:-4] + ".o"), [s, *hdrs])]

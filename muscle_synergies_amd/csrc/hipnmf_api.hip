@@ -94,7 +94,7 @@ int hipnmf_ensure_ws(hipnmf_handle* h, size_t bytes) {
 
 namespace {
 
-int validate(const hipnmf_problem* p, bool shard) {
+int validate(const hipnmf_problem* p, bool shard, bool ragged = false) {
   if (!p) return fail(HIPNMF_ERR_BAD_ARG, "problem is NULL");
   if (p->struct_size != (int32_t)sizeof(hipnmf_problem))
     return fail(HIPNMF_ERR_BAD_ARG, "hipnmf_problem.struct_size = %d, library expects %d", p->struct_size,
@@ -115,9 +115,11 @@ int validate(const hipnmf_problem* p, bool shard) {
     return fail(HIPNMF_ERR_BAD_ARG, "bad loss %d", p->loss);
   if (shard && p->loss != HIPNMF_LOSS_FROBENIUS)
     return fail(HIPNMF_ERR_UNSUPPORTED, "the time-shard entry points implement the Frobenius loss only");
-  const long long min_ld = (p->x_layout == HIPNMF_X_ROW_MAJOR) ? p->n_features : p->n_samples;
-  if (p->ldx < min_ld) return fail(HIPNMF_ERR_BAD_ARG, "ldx=%lld smaller than %lld", (long long)p->ldx, min_ld);
-  if (p->batch > 1 && p->x_batch_stride < 1) return fail(HIPNMF_ERR_BAD_ARG, "x_batch_stride must be >= 1");
+  if (!ragged) {  // the ragged entry points take leading dimension and offsets per matrix from the descriptors
+    const long long min_ld = (p->x_layout == HIPNMF_X_ROW_MAJOR) ? p->n_features : p->n_samples;
+    if (p->ldx < min_ld) return fail(HIPNMF_ERR_BAD_ARG, "ldx=%lld smaller than %lld", (long long)p->ldx, min_ld);
+    if (p->batch > 1 && p->x_batch_stride < 1) return fail(HIPNMF_ERR_BAD_ARG, "x_batch_stride must be >= 1");
+  }
   if (!shard) {
     if (p->max_iter < 1) return fail(HIPNMF_ERR_BAD_ARG, "max_iter must be >= 1 (got %d)", p->max_iter);
     if (p->check_every < 1) return fail(HIPNMF_ERR_BAD_ARG, "check_every must be >= 1 (got %d)", p->check_every);
@@ -176,7 +178,7 @@ template <typename real>
 int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, real* W, real* H, real* err_out,
                      int32_t* n_iter_out, real* sse_col_out, real* xsq_col_out, const int64_t* ragged = nullptr) {
   if (!h) return fail(HIPNMF_ERR_BAD_ARG, "handle is NULL");
-  int rc = validate(p, false);
+  int rc = validate(p, false, ragged != nullptr);
   if (rc) return rc;
   if (!X || !W || !H) return fail(HIPNMF_ERR_BAD_ARG, "X, W and H must be non-NULL device pointers");
   HIP_TRY(hipSetDevice(h->device));
@@ -208,6 +210,13 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
   else
     persistent = t_pers <= t_sliced;
   if (!persistent && sg.S == 1 && h->variant != 2) persistent = true;
+  // grid.y carries the batch on the sliced / cooperative launches (HIP limit 65535): larger batches always have
+  // more matrices than CUs and take the one-workgroup-per-matrix path (grid.x = batch)
+  if (B > 65535) {
+    if (h->variant == 2 || h->variant == 3)
+      return fail(HIPNMF_ERR_UNSUPPORTED, "batch=%d: the row-sliced / cooperative paths take at most 65535 matrices", B);
+    persistent = true;
+  }
   const bool kl = p->loss == HIPNMF_LOSS_KL;
   if (kl) {
     // the KL iteration exists as the one-workgroup-per-matrix kernel only (every batch size, any T < 2 GiB)
@@ -225,6 +234,9 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
       if (d[0] < 1 || d[0] > p->n_samples || d[2] < d[0] || (d[2] % 4) != 0 || (d[1] % 4) != 0 || d[1] < 0 || d[3] < 0)
         return fail(HIPNMF_ERR_BAD_ARG, "bad ragged descriptor for matrix %d (T=%lld, xoff=%lld, ld=%lld, woff=%lld)", b,
                     (long long)d[0], (long long)d[1], (long long)d[2], (long long)d[3]);
+      if ((long long)std::max(m, k) * (d[2] + 64) * (long long)sizeof(real) >= (1LL << 31))
+        return fail(HIPNMF_ERR_UNSUPPORTED, "ragged matrix %d: ld=%lld needs >= 2 GiB of 32-bit addressing per matrix", b,
+                    (long long)d[2]);
     }
   }
 
@@ -238,7 +250,7 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
   // costs ~8 us (L2 write-back / invalidate on a multi-XCD part); with the fence-free exchange the kernel uses
   // (device-scope relaxed atomics for the records and the counter) an iteration of one 16 x 10 000 matrix takes
   // 7.1 us against 10.2 us for the sliced path and 27 us for one persistent workgroup.
-  if (!ragged && !kl && ks->fit_coop && (h->variant == 3 || (h->variant == 0 && h->use_coop)) && B <= h->num_cu / 2) {
+  if (!ragged && !kl && ks->fit_coop && (h->variant == 3 || (h->variant == 0 && h->use_coop)) && B <= h->num_cu / 2 && B <= 65535) {
     int threads = std::min(h->threads > 0 ? h->threads : 512, ks->max_threads);
     const long long t_pad = round_up(T, 64);
     while (threads > 64 && t_pad < 2LL * threads) threads /= 2;  // at least two workgroup-steps of rows in total
@@ -382,14 +394,21 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
         hipLaunchKernelGGL(x_to_row_major_kernel<real>, grd, blk, 0, st, X + r.xoff, 0LL, r.ld, (int)HIPNMF_X_CHANNEL_MAJOR,
                            xc + r.roff, 0LL, (int)ldx_c, (int)r.T, m);
       }
-    } else if (ks->row_major) {
-      dim3 grd((unsigned)((T + 31) / 32), (unsigned)((ldx_c + 31) / 32), (unsigned)B);
-      hipLaunchKernelGGL(x_to_row_major_kernel<real>, grd, blk, 0, st, X, (long long)p->x_batch_stride,
-                         (long long)p->ldx, (int)p->x_layout, xc, (long long)x_elems, (int)ldx_c, (int)T, m);
     } else {
-      dim3 grd((unsigned)((ldx_c + 31) / 32), (unsigned)((m + 31) / 32), (unsigned)B);
-      hipLaunchKernelGGL(x_to_channel_major_kernel<real>, grd, blk, 0, st, X, (long long)p->x_batch_stride,
-                         (long long)p->ldx, (int)p->x_layout, xc, (long long)x_elems, ldx_c, (int)T, m);
+      for (int b0 = 0; b0 < B; b0 += 65535) {  // the batch rides on grid.z (HIP limit 65535)
+        const unsigned nb = (unsigned)std::min(65535, B - b0);
+        const real* xin = X + (long long)b0 * p->x_batch_stride;
+        real* xout = xc + (size_t)b0 * x_elems;
+        if (ks->row_major) {
+          dim3 grd((unsigned)((T + 31) / 32), (unsigned)((ldx_c + 31) / 32), nb);
+          hipLaunchKernelGGL(x_to_row_major_kernel<real>, grd, blk, 0, st, xin, (long long)p->x_batch_stride,
+                             (long long)p->ldx, (int)p->x_layout, xout, (long long)x_elems, (int)ldx_c, (int)T, m);
+        } else {
+          dim3 grd((unsigned)((ldx_c + 31) / 32), (unsigned)((m + 31) / 32), nb);
+          hipLaunchKernelGGL(x_to_channel_major_kernel<real>, grd, blk, 0, st, xin, (long long)p->x_batch_stride,
+                             (long long)p->ldx, (int)p->x_layout, xout, (long long)x_elems, ldx_c, (int)T, m);
+        }
+      }
     }
     a.X = xc;
     a.x_bstride = (long long)x_elems;
@@ -402,8 +421,11 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
   } else {
     real* wc = reinterpret_cast<real*>(ws + o_w);
     const long long n = (long long)k * ldw_c;
-    dim3 grd((unsigned)std::min<long long>((n + 255) / 256, 1024), (unsigned)B);
-    hipLaunchKernelGGL(w_convert_kernel<real>, grd, dim3(256), 0, st, W, wc, ldw_c, (int)T, k, 0);
+    for (int b0 = 0; b0 < B; b0 += 65535) {  // the batch rides on grid.y
+      dim3 grd((unsigned)std::min<long long>((n + 255) / 256, 1024), (unsigned)std::min(65535, B - b0));
+      hipLaunchKernelGGL(w_convert_kernel<real>, grd, dim3(256), 0, st, W + (long long)b0 * T * k,
+                         wc + (long long)b0 * k * ldw_c, ldw_c, (int)T, k, 0);
+    }
     a.W = wc;
     a.w_bstride = (long long)k * ldw_c;
     a.ldw = ldw_c;
@@ -544,23 +566,36 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
     int it_done = 0;
     bool converged = false;
     if (h->use_graph && p->max_iter >= 2 * chunk) {
+      // No early return between BeginCapture and the clean-up: a failure ends the capture (the stream may be the
+      // caller's own, e.g. torch's current stream after hipnmf_set_stream), destroys graph and executable, and the
+      // plain launch loop below takes over from wherever the replay stopped.
       hipGraph_t graph = nullptr;
       hipGraphExec_t exec = nullptr;
-      HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-      enqueue(chunk, stop_rule);
-      HIP_TRY(hipStreamEndCapture(st, &graph));
-      HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-      while (!converged && it_done + chunk <= p->max_iter) {
-        HIP_TRY(hipGraphLaunch(exec, st));
+      hipError_t ge = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+      if (ge == hipSuccess) {
+        enqueue(chunk, stop_rule);
+        ge = hipStreamEndCapture(st, &graph);  // also leaves capture mode when an enqueued launch was invalid
+      }
+      if (ge == hipSuccess) ge = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+      int graph_rc = HIPNMF_OK;
+      while (ge == hipSuccess && !converged && it_done + chunk <= p->max_iter) {
+        ge = hipGraphLaunch(exec, st);
+        if (ge != hipSuccess) break;
         it_done += chunk;
         if (stop_rule) {
-          rc = all_converged(&converged);
-          if (rc) return rc;
+          graph_rc = all_converged(&converged);
+          if (graph_rc) break;
         }
       }
-      HIP_TRY(hipStreamSynchronize(st));
-      (void)hipGraphExecDestroy(exec);
-      (void)hipGraphDestroy(graph);
+      if (ge == hipSuccess && !graph_rc) ge = hipStreamSynchronize(st);
+      if (exec) (void)hipGraphExecDestroy(exec);
+      if (graph) (void)hipGraphDestroy(graph);
+      if (graph_rc) return graph_rc;
+      if (ge != hipSuccess) {
+        (void)hipGetLastError();
+        if (it_done > 0)  // part of the replay ran: the state on the device is no longer a whole number of chunks
+          return fail(HIPNMF_ERR_HIP, "hipGraph replay failed after %d iterations: %s", it_done, hipGetErrorString(ge));
+      }
     }
     while (!converged && it_done < p->max_iter) {
       const int n = std::min(chunk, p->max_iter - it_done);
@@ -580,8 +615,11 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
   if (!w_inplace) {
     real* wc = reinterpret_cast<real*>(ws + o_w);
     const long long n = (long long)k * ldw_c;
-    dim3 grd((unsigned)std::min<long long>((n + 255) / 256, 1024), (unsigned)B);
-    hipLaunchKernelGGL(w_convert_kernel<real>, grd, dim3(256), 0, st, W, wc, ldw_c, (int)T, k, 1);
+    for (int b0 = 0; b0 < B; b0 += 65535) {
+      dim3 grd((unsigned)std::min<long long>((n + 255) / 256, 1024), (unsigned)std::min(65535, B - b0));
+      hipLaunchKernelGGL(w_convert_kernel<real>, grd, dim3(256), 0, st, W + (long long)b0 * T * k,
+                         wc + (long long)b0 * k * ldw_c, ldw_c, (int)T, k, 1);
+    }
   }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(st));

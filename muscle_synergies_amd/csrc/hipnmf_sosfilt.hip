@@ -62,6 +62,7 @@ int sosfilt_impl(hipnmf_handle* h, const hipnmf_sosfilt_params* p, const double*
     return fail(HIPNMF_ERR_BAD_ARG, "bad shape: batch=%d n_samples=%lld n_channels=%d", p->batch,
                 (long long)p->n_samples, p->n_channels);
   if ((long long)p->batch * p->n_channels > 2000000000LL) return fail(HIPNMF_ERR_BAD_ARG, "too many series");
+  if (p->reserved0 != 0) return fail(HIPNMF_ERR_BAD_ARG, "hipnmf_sosfilt_params.reserved0 must be 0 (got %d)", p->reserved0);
   if (p->n_sections < 1) return fail(HIPNMF_ERR_BAD_ARG, "n_sections must be >= 1 (got %d)", p->n_sections);
   if (p->n_sections > SOS_MAX_SECTIONS)
     return fail(HIPNMF_ERR_UNSUPPORTED, "n_sections=%d outside the compiled kernel set (max %d)", p->n_sections,

@@ -286,3 +286,70 @@ def test_two_rank_rccl_time_sharded_fit(tmp_path):
     np.testing.assert_array_equal(parts[0]["H"], parts[1]["H"])  # replicated
     assert _rel_wh(X, W, parts[0]["H"], ref) <= TOL
     assert abs(float(parts[0]["err"][0]) - float(ref["reconstruction_err"])) / np.linalg.norm(X) <= TOL
+
+
+# ------------------------------------------------------------------------------------------------ ABI hardening
+def test_batch_larger_than_the_grid_y_limit():
+    """B > 65535 with sklearn-ordered W (T x k): the layout conversions ride on grid.y / grid.z and are chunked; the
+    solver itself puts the batch on grid.x."""
+    import torch
+
+    import muscle_synergies_amd as ms
+
+    B, T, m, k = 70_001, 40, 4, 2
+    g = torch.Generator(device="cuda").manual_seed(5)
+    X = torch.rand((B, T, m), generator=g, device="cuda") + 0.05
+    W0 = torch.rand((B, T, k), generator=g, device="cuda") + 0.1
+    H0 = torch.rand((B, k, m), generator=g, device="cuda") + 0.1
+    res = ms.fit_batched(X, W0, H0, max_iter=12, tol=0.0)
+    for b in (0, 1, 65_534, 65_535, 65_536, B - 1):
+        ref = orc.nmf_mu_fit(X[b].cpu().numpy(), W0[b].cpu().numpy(), H0[b].cpu().numpy(), max_iter=12, tol=0.0)
+        np.testing.assert_allclose(res.W[b].cpu().numpy(), ref["W"], rtol=2e-4, atol=1e-6)
+        np.testing.assert_allclose(res.H[b].cpu().numpy(), ref["H"], rtol=2e-4, atol=1e-6)
+    Xc = X.transpose(1, 2).contiguous().transpose(1, 2)  # channel-major storage: the X converter is chunked too
+    res2 = ms.fit_batched(Xc, W0, H0, max_iter=12, tol=0.0)
+    assert torch.allclose(res2.W, res.W, rtol=2e-4, atol=1e-6)
+
+
+def test_ragged_entry_point_ignores_ldx_and_checks_reserved_fields():
+    """hip_nmf.h: ldx / x_batch_stride are ignored by hipnmf_fit_ragged_*; hipnmf_sosfilt_params.reserved0 must be 0."""
+    import ctypes
+
+    import torch
+
+    from muscle_synergies_amd import _lib
+    from muscle_synergies_amd.engine import make_problem
+    from muscle_synergies_amd.preprocess import SosfiltParams
+
+    lib = _lib.load()
+    h = _lib.Handle(0)
+    Ts, m, k = [100, 52], 6, 3
+    lds = [(t + 3) // 4 * 4 for t in Ts]
+    Xs = [emg_matrix(70 + i, T=t, m=m, k_true=3, dtype=np.float64) for i, t in enumerate(Ts)]
+    inits = [random_init(Xs[i], k, i) for i in range(2)]
+    xo = [0, m * lds[0]]
+    wo = [0, k * lds[0]]
+    Xp = torch.zeros(m * sum(lds), dtype=torch.float64, device="cuda")
+    Wp = torch.zeros(k * sum(lds), dtype=torch.float64, device="cuda")
+    for i in range(2):
+        Xp[xo[i]:xo[i] + m * lds[i]].view(m, lds[i])[:, :Ts[i]] = torch.from_numpy(np.ascontiguousarray(Xs[i].T)).cuda()
+        Wp[wo[i]:wo[i] + k * lds[i]].view(k, lds[i])[:, :Ts[i]] = torch.from_numpy(np.ascontiguousarray(inits[i][0].T)).cuda()
+    Hp = torch.from_numpy(np.stack([i[1] for i in inits])).cuda()
+    desc = (ctypes.c_int64 * 8)(Ts[0], xo[0], lds[0], wo[0], Ts[1], xo[1], lds[1], wo[1])
+    p = make_problem(2, max(Ts), m, k, x_layout=_lib.X_CHANNEL_MAJOR, ldx=0, x_batch_stride=0,
+                     w_layout=_lib.W_COMPONENT_MAJOR, max_iter=25, tol=0.0)
+    err = torch.empty(2, dtype=torch.float64, device="cuda")
+    rc = lib.hipnmf_fit_ragged_f64(h.ptr, ctypes.byref(p), desc, ctypes.c_void_p(Xp.data_ptr()),
+                                   ctypes.c_void_p(Wp.data_ptr()), ctypes.c_void_p(Hp.data_ptr()),
+                                   ctypes.c_void_p(err.data_ptr()), None, None, None)
+    assert rc == 0, lib.hipnmf_last_error()
+    for i in range(2):
+        ref = orc.nmf_mu_fit(Xs[i], inits[i][0], inits[i][1], max_iter=25, tol=0.0)
+        W = Wp[wo[i]:wo[i] + k * lds[i]].view(k, lds[i])[:, :Ts[i]].t().cpu().numpy()
+        np.testing.assert_allclose(W, ref["W"], rtol=1e-9, atol=1e-13)
+        np.testing.assert_allclose(float(err[i]), ref["reconstruction_err"], rtol=1e-9)
+    sp = SosfiltParams(ctypes.sizeof(SosfiltParams), 1, 100, 4, 0, 4, 400, 1, 0, -1, 0, 0, 1)  # reserved0 = 1
+    sos = (ctypes.c_double * 6)(1, 0, 0, 1, 0, 0)
+    x = torch.zeros(400, dtype=torch.float32, device="cuda")
+    rc = lib.hipnmf_sosfilt_f32(h.ptr, ctypes.byref(sp), sos, None, ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(x.data_ptr()))
+    assert rc == _lib.HIPNMF_ERR_BAD_ARG and b"reserved0" in lib.hipnmf_last_error()

@@ -46,6 +46,24 @@ class OracleShardOps:
         return torch.from_numpy(self.H)[None]
 
 
+class SharedHOracleShardOps(OracleShardOps):
+    """Sub-shard flavour for MultiShardOps: ``H`` is a torch tensor shared by all sub-shards of a rank."""
+
+    def __init__(self, X_s, W_s, H_shared):
+        self.X = np.ascontiguousarray(X_s)
+        self.W = np.array(W_s, copy=True)
+        self.Ht = H_shared            # torch tensor [1, k, m] (float64), updated in place
+        self.H = self.Ht.numpy()[0]   # NumPy view of the same memory
+        self.k, self.m = self.H.shape
+
+    @property
+    def Wc(self):
+        return torch.from_numpy(self.W)[None]
+
+    def result_H(self):
+        return self.Ht
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -88,6 +106,51 @@ def test_two_rank_sharded_equals_unsharded(tmp_path, tol, max_iter):
     np.testing.assert_allclose(W, ref["W"], rtol=1e-9)
     if tol > 0:
         assert ref["n_iter"] % 10 == 0 and ref["n_iter"] < max_iter
+
+
+def _multi_worker(rank, world, port, T, out_dir):
+    from muscle_synergies_amd.tsharded import MultiShardOps
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        X = emg_matrix(22, T=T, m=16, dtype=np.float64)
+        W0, H0 = random_init(X, 5, 22)
+        lo, hi = shard_bounds(T, world)[rank]
+        cuts = [lo, lo + (hi - lo) // 3, lo + 2 * (hi - lo) // 3, hi]  # three sub-shards per rank
+        H = torch.from_numpy(H0.copy())[None]
+
+        class _Sub(SharedHOracleShardOps):
+            pass
+
+        subs = [_Sub(X[a:b], W0[a:b], H) for a, b in zip(cuts[:-1], cuts[1:])]
+        for sub in subs:  # MultiShardOps checks that the sub-shards share one H tensor
+            sub.H_tensor = H
+        ops = MultiShardOps.__new__(MultiShardOps)
+        ops.shards = subs
+        res = fit_tsharded(ops, max_iter=30, tol=0.0)
+        W = np.concatenate([sub.W for sub in subs], axis=0)
+        Hn = np.asarray(res.H)  # MultiShardOps hands back the shared H of its first sub-shard
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), W=W, H=Hn[0] if Hn.ndim == 3 else Hn,
+                 err=res.reconstruction_err.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_with_three_sub_shards_each_equal_unsharded(tmp_path):
+    """bench.py --config 5 on fewer than 8 GPUs: every rank holds several sub-shards (MultiShardOps) that share
+    the replicated H; sums are added per rank, then all-reduced."""
+    T, world = 3003, 2
+    mp.spawn(_multi_worker, args=(world, _free_port(), T, str(tmp_path)), nprocs=world, join=True)
+    X = emg_matrix(22, T=T, m=16, dtype=np.float64)
+    W0, H0 = random_init(X, 5, 22)
+    ref = orc.nmf_mu_fit(X, W0, H0, max_iter=30, tol=0.0)
+    parts = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    np.testing.assert_allclose(np.concatenate([p["W"] for p in parts], axis=0), ref["W"], rtol=1e-9)
+    for p in parts:
+        np.testing.assert_allclose(p["H"], ref["H"], rtol=1e-9)
+        np.testing.assert_allclose(p["err"][0], ref["reconstruction_err"], rtol=1e-9)
 
 
 def test_shard_bounds_cover_and_align():

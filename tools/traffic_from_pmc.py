@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""profiles/traffic.json from the two PMC passes of tools/measure_traffic.sh.
+
+FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half of the bytes of a 16-byte-per-lane streaming
+read (/opt/skills/guides/MI355X_MICROARCH.md, HBM section), so it is doubled; WRITE_SIZE is exact for dword stores.
+The counters sit on the L2's fabric side: Infinity-Cache hits are included -- this is traffic beyond L2, not HBM."""
+import argparse
+import csv
+import glob
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ap = argparse.ArgumentParser()
+ap.add_argument("dir")
+ap.add_argument("--batch", type=int, default=4096)
+ap.add_argument("--iters", type=int, default=500)
+ap.add_argument("--T", type=int, default=10000)
+ap.add_argument("--m", type=int, default=16)
+ap.add_argument("--k", type=int, default=5)
+ap.add_argument("--x-layout", default="row")
+a, _ = ap.parse_known_args()
+
+
+def biggest(sub, counter):
+    best = {}
+    for f in glob.glob(os.path.join(a.dir, sub, "**", "*_counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == counter and r["Kernel_Name"].startswith("void hipnmf::fit_"):
+                key = (r["Kernel_Name"], r.get("Dispatch_Id"))
+                best[key] = float(r["Counter_Value"])
+    if not best:
+        sys.exit(f"no {counter} rows for a fit kernel under {a.dir}/{sub}")
+    name = max(best, key=best.get)[0]
+    vals = [v for (n, _), v in best.items() if n == name]
+    return name, sum(vals) / len(vals), len(vals)
+
+
+kname, fetch_kib, n1 = biggest("fetch", "FETCH_SIZE")
+_, write_kib, n2 = biggest("write", "WRITE_SIZE")
+short = kname.split("hipnmf::", 1)[1].split("(", 1)[0].replace(" ", "")
+entry = {
+    "kernel": short, "batch": a.batch, "iters": a.iters, "T": a.T, "m": a.m, "k": a.k, "x_layout": a.x_layout,
+    "fetch_size_kib_avg": fetch_kib, "write_size_kib_avg": write_kib, "launches_averaged": [n1, n2],
+    "l2_fabric_bytes_per_launch": 2.0 * fetch_kib * 1024 + write_kib * 1024,
+    "l2_fabric_bytes_per_unit": (2.0 * fetch_kib * 1024 + write_kib * 1024) / (a.batch * a.iters),
+    "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE -- python3 bench.py --steps 1 --warmup 1 "
+              "(tools/measure_traffic.sh); FETCH_SIZE x 2 (gfx950, 16 B/lane streams); includes Infinity-Cache hits",
+}
+path = os.path.join(ROOT, "profiles", "traffic.json")
+entries = []
+if os.path.exists(path):
+    try:
+        old = json.load(open(path))
+        entries = old if isinstance(old, list) else []
+    except Exception:
+        entries = []
+entries = [e for e in entries if not all(e.get(k) == entry[k] for k in ("kernel", "batch", "iters", "T", "m", "k", "x_layout"))]
+entries.append(entry)
+os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+for p in (path, os.path.join(ROOT, "gpurun_out", "traffic.json")):
+    json.dump(entries, open(p, "w"), indent=1)
+print(json.dumps(entry, indent=1))
