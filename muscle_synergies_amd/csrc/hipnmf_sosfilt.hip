@@ -3,6 +3,7 @@
 // (src/muscle_synergies/analysis.py:252-432).
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstdint>
 
 #include "hipnmf_internal.hpp"
@@ -46,6 +47,20 @@ hipError_t launch_ns(const SosArgs& a, const double* stat, hipStream_t st) {
   // at most four of these one-wave workgroups per CU (160 KiB of LDS / 40 KiB)
   constexpr size_t smem = sos_smem_bytes<S>() > 40960 ? sos_smem_bytes<S>() : 40960;
   hipLaunchKernelGGL((sosfilt_kernel<real, NS, S>), dim3((a.N + S - 1) / S), dim3(64), smem, st, a, stat);
+  return hipSuccess;
+}
+
+// round 2 kernel: LPS lanes per series (sections rounded up to a power of two), a second wave moves the data
+template <typename real, int LPS>
+hipError_t launch_v2(const SosArgs& a, const double* stat, int ns, hipStream_t st) {
+  constexpr int S = sos2_series<LPS>();
+  constexpr size_t smem = sos2_smem_bytes<LPS>();
+  const void* kern = reinterpret_cast<const void*>(&sosfilt2_kernel<real, LPS>);
+  if (smem > 48 * 1024) {
+    const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL((sosfilt2_kernel<real, LPS>), dim3((a.N + S - 1) / S), dim3(128), smem, st, a, stat, ns);
   return hipSuccess;
 }
 
@@ -98,7 +113,8 @@ int sosfilt_impl(hipnmf_handle* h, const hipnmf_sosfilt_params* p, const double*
   const bool inplace = p->x_layout == HIPNMF_X_CHANNEL_MAJOR;
   const size_t o_x = inplace ? 0 : carve(sizeof(real) * (size_t)N * T);
   // forward output of the zero-lag filter: SOS_SERIES rows per wave, so the last wave needs no row guards
-  const size_t o_ws = zero_lag ? carve(sizeof(double) * (size_t)round_up(N, SOS_SERIES) * (size_t)L) : 0;
+  // forward output of the zero-lag filter: whole 64-sample tiles, 64 rows per workgroup-group (both kernels fit)
+  const size_t o_ws = zero_lag ? carve(sizeof(double) * (size_t)round_up(N, 64) * (size_t)round_up(L, 64)) : 0;
   const size_t o_stat = carve(sizeof(double) * (size_t)N * 3);
   int rc = hipnmf_ensure_ws(h, std::max<size_t>(off, 256));
   if (rc) return rc;
@@ -146,6 +162,21 @@ int sosfilt_impl(hipnmf_handle* h, const hipnmf_sosfilt_params* p, const double*
   if (!async) HIP_TRY(hipEventRecord(h->ev0, st));
   double* stat = reinterpret_cast<double*>(ws + o_stat);
   hipLaunchKernelGGL(sos_stats_kernel<real>, dim3((unsigned)N), dim3(256), 0, st, a, stat);
+  static const bool sos_v1 = [] {
+    const char* e = getenv("HIPNMF_SOS_V1");
+    return e && atoi(e) != 0;
+  }();
+  if (!sos_v1) {
+    const int ns = p->n_sections;
+    if (ns == 1)
+      HIP_TRY((launch_v2<real, 1>(a, stat, ns, st)));
+    else if (ns == 2)
+      HIP_TRY((launch_v2<real, 2>(a, stat, ns, st)));
+    else if (ns <= 4)
+      HIP_TRY((launch_v2<real, 4>(a, stat, ns, st)));
+    else
+      HIP_TRY((launch_v2<real, 8>(a, stat, ns, st)));
+  } else
   switch (p->n_sections) {
     case 1: HIP_TRY((launch_ns<real, 1>(a, stat, st))); break;
     case 2: HIP_TRY((launch_ns<real, 2>(a, stat, st))); break;
