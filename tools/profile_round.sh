@@ -1,0 +1,24 @@
+#!/bin/bash
+# rocprofv3 kernel statistics of the round's benchmarks (run on the GPU box: gpurun -- 'bash tools/profile_round.sh r02')
+tag=${1:-r02}
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/prof_$tag
+rm -rf $O && mkdir -p $O
+run() {  # name, program args...
+  name=$1; shift
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/$name -- python3 "$@" > $O/$name.log 2>&1
+  f=$(find $O/$name -name "*kernel_stats.csv" | head -1)
+  [ -n "$f" ] && cp $f $O/${tag}_kernel_stats_$name.csv
+}
+run bench_steps2 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline
+run bench_config4 $R/bench.py --config 4 --steps 1 --warmup 1 --no-cpu-baseline
+run bench_config5 $R/bench.py --config 5 --steps 1 --warmup 1 --no-cpu-baseline
+run bench_config2 $R/bench.py --config 2 --steps 2 --warmup 1 --no-cpu-baseline
+run filter_bench $R/tools/filter_bench.py --orders 4 --dtypes float32
+run envelope_bench $R/tools/envelope_bench.py
+grep -h '^{' $O/bench_steps2.log > $O/${tag}_bench.json
+grep -h '^{' $O/bench_config4.log > $O/${tag}_bench_config4.json
+grep -h '^{' $O/bench_config5.log > $O/${tag}_bench_config5.json
+grep -h '^{' $O/bench_config2.log > $O/${tag}_bench_config2.json
+ls $O/*.csv $O/*.json
