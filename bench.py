@@ -39,6 +39,8 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROA
 FP32_PEAK_TFLOPS = 157.3   # fp32 vector = fp32 matrix peak (MI355X_MICROARCH.md:41-42)
 STREAM_PEAK_GBS = 7800.0   # measured: 256 workgroups re-reading "their" 640 KB region (tools/ubench/mall_stream.hip,
                            # profiles/README.md): 7.2 - 8.1 TB/s whatever the loads in flight -- the roof that binds
+SHARD_STREAM_GBS = 5100.0  # measured: the shard pass's traffic (64 B X + 20 B W read, 20 B W written per row, channel-
+                           # major, 2.5e7 rows) with no arithmetic: 5.0 - 5.2 TB/s (tools/ubench/shard_stream.hip)
 
 
 def parse_args():
@@ -447,7 +449,9 @@ def run_tsharded(cx):
                        "reconstruction_err": float(r.reconstruction_err[0]), "vaf_all": float(r.vaf[0, 0])},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "slice_pass_kernel<float,4,4,5> (+ reduce_slices, hupdate, all-reduce per iteration)",
+                         "kernel": "slice_pass_rowlane_kernel<5> (+ reduce_slices, hupdate, all-reduce per iteration)",
+                         "measured_stream_ceiling_gbs": SHARD_STREAM_GBS,
+                         "frac_of_measured_ceiling": achieved / SHARD_STREAM_GBS,
                          "kernel_ms_avg": it_ms, "algorithmic_bytes_per_unit": by,
                          "algorithmic_bytes_per_iteration_rank0": by_rank, "units_per_launch": 1,
                          "note": "per-GPU rate of rank 0: its rows x 4 (m + 2k) bytes per iteration / iteration time "

@@ -27,6 +27,28 @@ template <typename real>
 __device__ __forceinline__ double strided_sum(const real* __restrict__ x, int T, int first, int stride) {
   double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
   int i = first;
+  if ((reinterpret_cast<unsigned long long>(x) & 15ull) == 0) {  // 16-byte loads, two in flight per thread
+    constexpr int V = 16 / (int)sizeof(real);
+    struct alignas(16) Vec { real v[V]; };
+    const Vec* __restrict__ xv = reinterpret_cast<const Vec*>(x);
+    const int nv = T / V;
+    int q = first;
+    for (; q + stride < nv; q += 2 * stride) {
+      const Vec a0 = xv[q], a1 = xv[q + stride];
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        s0 += (double)a0.v[e];
+        s1 += (double)a1.v[e];
+      }
+    }
+    for (; q < nv; q += stride) {
+      const Vec a0 = xv[q];
+#pragma unroll
+      for (int e = 0; e < V; ++e) s2 += (double)a0.v[e];
+    }
+    for (i = nv * V + first; i < T; i += stride) s3 += (double)x[i];
+    return (s0 + s1) + (s2 + s3);
+  }
   for (; i + 3 * stride < T; i += 4 * stride) {
     const real a0 = x[i], a1 = x[i + stride], a2 = x[i + 2 * stride], a3 = x[i + 3 * stride];
     s0 += (double)a0;
@@ -244,16 +266,44 @@ __global__ void __launch_bounds__(256) emg_fused_kernel(EnvArgs a) {
   const double step_out = (n_out > 1) ? 1.0 / (double)(n_out - 1) : 0.0;
   const double step_in = (T > 1) ? 1.0 / (double)(T - 1) : 0.0;
   auto knot = [&](int i) { return (i == T - 1) ? 1.0 : (double)i * step_in; };  // np.linspace(0, 1, T)[i]
+  // raw samples of a tile (+ window halo) are requested one tile ahead, so that their latency hides behind the scan
+  // and the output loop of the tile before (round 2; PFN values per thread)
+  constexpr int PFN = (ENV_TILE + 1 + 1024 + 255) / 256;  // covers windows up to 1024 samples; longer ones load late
+  real pf[PFN];
+  const bool can_pf = W > 0 && ENV_TILE + W <= PFN * 256;
+  auto issue = [&](int t0) {
+#pragma unroll
+    for (int q = 0; q < PFN; ++q) {
+      int j = t0 - lo + threadIdx.x + q * 256;
+      j = j < 0 ? 0 : (j >= T ? T - 1 : j);  // branch-free: out-of-range positions are masked when committed
+      pf[q] = x[j];
+    }
+  };
+  const double inv_w = W > 0 ? 1.0 / (double)W : 0.0;  // np.convolve(x^2, ones(W) / W): products by 1/W, no division
+  if (can_pf) issue(0);
   for (int t0 = 0; t0 < T; t0 += ENV_TILE) {
     const int nout_t = (T - t0 < ENV_TILE) ? T - t0 : ENV_TILE;
     const int nval = nout_t + 1;  // one value past the tile: right neighbour for the interpolation
     if (W > 0) {
       const int nbuf = nval + W - 1;  // buf[e] <-> squared centred sample t0 - lo + e (0 outside [0, T))
       __syncthreads();
-      for (int e = threadIdx.x; e < nbuf; e += blockDim.x) {
-        const int j = t0 - lo + e;
-        const double d = (j >= 0 && j < T) ? (double)x[j] - mean : 0.0;
-        buf[e] = d * d;
+      if (can_pf) {
+#pragma unroll
+        for (int q = 0; q < PFN; ++q) {
+          const int e = threadIdx.x + q * 256;
+          const int j = t0 - lo + e;
+          if (e < nbuf) {
+            const double d = (j >= 0 && j < T) ? (double)pf[q] - mean : 0.0;
+            buf[e] = d * d;
+          }
+        }
+        if (t0 + ENV_TILE < T) issue(t0 + ENV_TILE);
+      } else {
+        for (int e = threadIdx.x; e < nbuf; e += blockDim.x) {
+          const int j = t0 - lo + e;
+          const double d = (j >= 0 && j < T) ? (double)x[j] - mean : 0.0;
+          buf[e] = d * d;
+        }
       }
       __syncthreads();
       lds_exclusive_scan(buf, nbuf, scratch);
@@ -261,11 +311,28 @@ __global__ void __launch_bounds__(256) emg_fused_kernel(EnvArgs a) {
     auto value = [&](int i) -> double {  // i in [t0, t0 + nout_t]
       if (W > 0) {
         const double s = buf[i - t0 + W] - buf[i - t0];
-        return sqrt((s > 0.0 ? s : 0.0) / (double)W);
+        return sqrt((s > 0.0 ? s : 0.0) * inv_w);
       }
       return (i < T) ? (double)x[i] - mean : 0.0;
     };
     if (!resample) {
+      if constexpr (sizeof(real) == 4) {
+        if (W > 0) {
+          // fp32 output: the fp64 window sum is rounded to float once and the root is taken in fp32 (v_sqrt_f32,
+          // <= 1 ulp): within 1.5 ulp of rounding the fp64 root, at ~6 instructions per output instead of the ~25 of
+          // the fp64 square root
+          const float inv_wf = (float)inv_w;
+          float vm = 0.f;
+          for (int i = threadIdx.x; i < nout_t; i += blockDim.x) {
+            const double sd = buf[i + W] - buf[i];
+            const float y = __builtin_sqrtf(fmaxf((float)sd, 0.f) * inv_wf);
+            o[t0 + i] = y;
+            vm = fmaxf(vm, y);
+          }
+          vmax = fmax(vmax, (double)vm);
+          continue;
+        }
+      }
       for (int i = threadIdx.x; i < nout_t; i += blockDim.x) {
         const double y = value(t0 + i);
         o[t0 + i] = (real)y;

@@ -705,7 +705,24 @@ int shard_pass_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
   hipStream_t st = h->stream;
   const bool async = h->async_mode != 0;
   if (!async) HIP_TRY(hipEventRecord(h->ev0, st));
-  launch<real>(ks->slice_pass, dim3(sg.S, p->batch), dim3(sg.threads), ks->smem_bytes(sg.threads / 64), st, a);
+  // fp32, 9..16 channels: the row-per-lane matrix-pipe pass (four rows per lane, 1 KB per load instruction);
+  // HIPNMF_SHARD_ROWLANE=0 keeps slice_pass_kernel<float, 4, 4, K>.  Same slice records either way.
+  bool rl_pass = false;
+  if constexpr (std::is_same<real, float>::value) {
+    static const bool rl_env = [] {
+      const char* e = getenv("HIPNMF_SHARD_ROWLANE");
+      return !(e && atoi(e) == 0);
+    }();
+    rl_pass = rl_env && p->n_features > 8 && p->n_features <= 16 && ks->MP == 16 && slice_pass_rowlane(p->n_components) &&
+              (p->ldx % 4) == 0 && (p->n_samples % 4) == 0 && (sg.rows_per_slice % 256) == 0 &&
+              (reinterpret_cast<uintptr_t>(W) % 16) == 0;
+    if (rl_pass) {
+      const KernelSet<float>* k16 = kernels_f32_g1c16(p->n_components);
+      hipLaunchKernelGGL(slice_pass_rowlane(p->n_components), dim3(sg.S, p->batch), dim3(256), k16->smem_bytes(4), st, a);
+    }
+  }
+  if (!rl_pass)
+    launch<real>(ks->slice_pass, dim3(sg.S, p->batch), dim3(sg.threads), ks->smem_bytes(sg.threads / 64), st, a);
   if (a.update_h) launch<real>(ks->reduce_slices, dim3(p->batch), dim3(1024), 0, st, a);
   HIP_TRY(hipGetLastError());
   if (!async) {

@@ -9,6 +9,12 @@ RowLaneFn rowlane_kernel(int K) {
                                    fit_rowlane_kernel<7>, fit_rowlane_kernel<8>};
   return (K >= 1 && K <= 8) ? tbl[K - 1] : nullptr;
 }
+RowLaneFn slice_pass_rowlane(int K) {
+  static const RowLaneFn tbl[8] = {slice_pass_rowlane_kernel<1>, slice_pass_rowlane_kernel<2>, slice_pass_rowlane_kernel<3>,
+                                   slice_pass_rowlane_kernel<4>, slice_pass_rowlane_kernel<5>, slice_pass_rowlane_kernel<6>,
+                                   slice_pass_rowlane_kernel<7>, slice_pass_rowlane_kernel<8>};
+  return (K >= 1 && K <= 8) ? tbl[K - 1] : nullptr;
+}
 template <int K>
 static void fill_name(char (&buf)[64]) {
   snprintf(buf, sizeof(buf), "fit_rowlane_kernel<%d,%d,%d,%d>", K, rl_nxr<K>(), rl_nwr<K>(), (int)(HIPNMF_RL_PF));

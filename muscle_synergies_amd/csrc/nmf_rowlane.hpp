@@ -542,4 +542,101 @@ __global__ void __launch_bounds__(HIPNMF_RL_THREADS) fit_rowlane_kernel(SolveArg
   });
 }
 
+
+// =================================================================================================
+// slice_pass_rowlane_kernel<K>: the time-shard / row-sliced pass (hipnmf_shard_pass_f32; BASELINE config #5) with
+// the row-per-lane matrix-pipe arithmetic, reading the CHANNEL-MAJOR X and component-major W of the shard ABI in
+// place.  Every lane owns FOUR consecutive rows: per channel one 16-byte load per lane = 1 KB contiguous per wave
+// instruction (round 1's (G=4, CH=4) mapping touched four channels x 256 bytes per instruction, 26 streams of
+// 256-byte pieces per workgroup, and reached 0.59 of the HBM line); W is read and written back the same way.  The
+// four rows are then updated one after the other with rl_update.  Output: one record of [W^T X | W^T W] sums per
+// slice in a.part, the same layout slice_pass_kernel<float, 4, 4, K> writes (reduce_slices / hupdate are unchanged).
+// Requirements (checked by the caller): fp32, 9..16 channels, ldx % 4 == 0, T % 4 == 0, 16-byte aligned X and W,
+// rows_per_slice % 256 == 0.
+__device__ __forceinline__ void buf_store4(rsrc_t r, unsigned voff, unsigned soff, const float (&v)[4]) {
+  using u32x4 = unsigned int __attribute__((ext_vector_type(4)));
+  u32x4 u;
+  __builtin_memcpy(&u, &v, 16);
+  __builtin_amdgcn_raw_buffer_store_b128(u, r, voff, soff, 0);
+}
+
+template <int K>
+__global__ void __launch_bounds__(256) slice_pass_rowlane_kernel(SolveArgs<float> a) {
+  using C = Cfg<float, 1, 16, K>;
+  constexpr int NB = C::NB, R = 4, STEP = WAVE * R;  // rows per wave-step
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int nw = blockDim.x / WAVE;
+  Smem<float, 1, 16, K> s(smem_raw, nw);
+  const int b = blockIdx.y, sl = blockIdx.x;
+  if (a.state && a.state[(long long)b * 8 + 3] != 0.f) return;  // matrix already converged
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
+  const float* __restrict__ Xb = a.X + (long long)b * a.x_bstride;
+  float* __restrict__ Wb = a.W + (long long)b * a.w_bstride;
+  const float* __restrict__ Hb = a.H + (long long)b * K * a.m;
+  const int m = a.m, T = a.T;
+  const int row_begin = sl * a.rows_per_slice;
+  int row_end = row_begin + a.rows_per_slice;
+  if (row_end > T) row_end = T;
+
+  load_h_to_lds(s, Hb, m);
+  __syncthreads();
+  compute_hht(s);
+  __syncthreads();
+  RlHops ho;
+  float hht[K][K];
+  rl_load_hops<K>(s, lane, ho, hht);
+  float accA[K][16], accB[NB];
+#pragma unroll
+  for (int c = 0; c < K; ++c)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) accA[c][j] = 0.f;
+#pragma unroll
+  for (int i = 0; i < NB; ++i) accB[i] = 0.f;
+
+  const rsrc_t xr = make_rsrc(Xb, (unsigned)((long long)m * a.ldx * 4LL));
+  const rsrc_t wr = make_rsrc(Wb, (unsigned)((long long)K * a.ldw * 4LL));
+  const unsigned ldx_b = (unsigned)(a.ldx * 4LL), ldw_b = (unsigned)(a.ldw * 4LL);
+  const bool upd = a.update_h != 0;
+  for (int wbase = row_begin + wave * STEP; wbase < row_end; wbase += nw * STEP) {
+    // the lane's four rows wbase + 4 lane .. + 3 are inside the matrix together or not at all (T % 4 == 0)
+    const unsigned v = (wbase + R * lane < row_end) ? (unsigned)(R * lane) * 4u : OOB;
+    const unsigned sb = (unsigned)wbase * 4u;
+    float x4[16][R], w4[K][R];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      if (j < m) {
+        buf_load<float, R>(xr, v, sb + (unsigned)j * ldx_b, x4[j]);
+      } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) x4[j][r] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < K; ++c) buf_load<float, R>(wr, v, sb + (unsigned)c * ldw_b, w4[c]);
+    static_for<R>([&](auto RR) {
+      constexpr int r = decltype(RR)::value;
+      float x[16], w[K];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) x[j] = x4[j][r];
+#pragma unroll
+      for (int c = 0; c < K; ++c) w[c] = w4[c][r];
+      rl_update<K>(x, w, ho, hht, accA, accB, a.l1w, a.l2w, upd);
+#pragma unroll
+      for (int c = 0; c < K; ++c) w4[c][r] = w[c];
+    });
+#pragma unroll
+    for (int c = 0; c < K; ++c) buf_store4(wr, v, sb + (unsigned)c * ldw_b, w4[c]);
+  }
+  if (!upd) return;
+  wave_reduce_acc<float, 1, 16, K>(s.part + wave * C::NACC, accA, accB);
+  __syncthreads();
+  float* __restrict__ out = a.part + ((long long)b * a.S + sl) * C::NACC;
+  for (int i = threadIdx.x; i < C::NACC; i += blockDim.x) {
+    float acc = s.part[i];
+    for (int w2 = 1; w2 < nw; ++w2) acc += s.part[w2 * C::NACC + i];
+    out[i] = acc;
+  }
+}
+
 }  // namespace hipnmf

@@ -1,0 +1,40 @@
+"""bench.py's bookkeeping (no GPU): the per-unit FLOP / byte model of SURVEY.md section 8(d), the LDS-capacity
+formula the byte model relies on, the roofline object's fields, and the command-line contract."""
+import importlib.util
+import os
+import subprocess
+import sys
+
+from conftest import ROOT
+
+spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+bench = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(bench)
+
+
+def test_unit_of_work_model_matches_the_survey():
+    assert 4 * 10_000 * (16 + 2 * 5) == 1_040_000                       # algorithmic bytes per matrix-iteration
+    assert bench.flops_per_unit(10_000, 16, 5) == 4 * 10_000 * 5 * 21 + 2 * 10_000 * 5 + 4 * 25 * 16 + 2 * 5 * 16
+    assert abs(bench.flops_per_unit(10_000, 16, 5) - 4.30e6) < 0.01e6
+    assert bench.lds_rows_of_w(5) == 7680                                # rows of W resident in LDS at k = 5
+    assert bench.lds_rows_of_w(2) >= 10_240 and bench.lds_rows_of_w(4) == 9728
+    assert 4 * (10_000 * 16 + 2 * 5 * (10_000 - bench.lds_rows_of_w(5))) == 732_800   # design bytes per unit
+
+
+def test_roofline_object_is_against_the_binding_roofs():
+    r = bench.compute_roofline("fit_persistent_kernel<float,1,16,5,0>", 200.0, 4096 * 500, 10_000, 16, 5,
+                               traffic=1.5185e12)
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 157.3
+    assert 0 < r["frac"] < 1 and abs(r["achieved"] - 4301760 * 2048000 / 0.2 / 1e12) < 1e-6
+    mem = r["memory"]
+    assert mem["algorithmic_bytes_per_unit"] == 1_040_000 and mem["l2_fabric_bytes_per_launch"] == 1.5185e12
+    assert 0.9 < mem["frac_of_stream_peak"] < 1.05
+    r2 = bench.compute_roofline("k", 200.0, 4096 * 500, 10_000, 16, 5, traffic=None, moved_bytes_per_unit=732_800)
+    assert r2["traffic"] is None and "design_gbs" in r2["memory"]
+
+
+def test_command_line_contract():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True)
+    assert out.returncode == 0
+    for flag in ("--gpus", "--steps", "--warmup", "--config"):
+        assert flag in out.stdout
