@@ -1,29 +1,30 @@
-// nmf_rowlane.hpp -- the headline instance of the batch path: fp32, up to 16 channels, k <= 8, one 512-thread
-// workgroup per matrix, every iteration inside the kernel (round 2 successor of fit_persistent_kernel<float,1,16,K>).
+// nmf_rowlane.hpp -- the matrix-pipe instances of the solver (round 2): fp32, 9..16 channels, k = 1..8.
+//   fit_rowlane_kernel<K>          batch path: one 512-thread workgroup per matrix, every iteration inside the kernel;
+//                                  the library's default for k >= 6 (hipnmf_set_tuning variant 5 / HIPNMF_ROWLANE=1: any k)
+//   slice_pass_rowlane_kernel<K>   the time-shard / row-sliced pass on channel-major X (hipnmf_shard_pass_f32, config #5)
 //
 // Arithmetic replaced: sklearn/decomposition/_nmf.py (1.7.2) _multiplicative_update_w (:526-631),
 // _multiplicative_update_h (:634-728), _beta_divergence (:85-134), loop + stop rule (:731-893), reached from the
 // reference at src/muscle_synergies/analysis.py:862-863.  sklearn notation: X (T x m) ~ W (T x k) H (k x m).
-//
-// What bounds this shape (tools/ubench/mall_stream.hip, profiles/README.md): 256 workgroups each re-reading "their"
-// 640 KB matrix every iteration are served by the Infinity Cache at 7.3 - 8.1 TB/s whatever the number of loads in
-// flight; round 1's kernel moved 741 KB per matrix-iteration at 7.5 TB/s, i.e. it sat on that roof.  The only way up
-// is to move fewer bytes: keep more of X and W on the CU.  Round 1 spent 160 of its 256 VGPRs on 80 copies-per-lane
-// of H and on the 80 W^T X accumulators, so there was no room.  Here:
 //
 //   * X H^T and W (H H^T) run on the matrix pipe as v_mfma_f32_4x4x1_16b_f32 (16 independent 4x4 outer products per
 //     instruction, K = 1): with the row-per-lane X register of channel j as the B operand (block b = rows 4b..4b+3)
 //     and ONE register holding H for all 16 channels as the A operand (lane 4j + c <-> H[c][j]; CBSZ = 4 broadcasts
 //     block ABID = j to all blocks), 16 instructions leave  sum_j H[c][j] X[row][j]  for c = 0..3 in the 4 accumulator
 //     registers of the lane that owns the row -- the row-per-lane layout in and out, no transposes.  Components 4..7
-//     take a second group.  Exact fp32 (an fmaf chain).  The f32 matrix pipe has the VALU's FLOP rate and shares
-//     its issue (tools/ubench/mfma_rate.hip: nothing overlaps), so this is NOT faster than the VALU form -- at k = 5
-//     it costs ~15 % more time per tile -- but H shrinks from 80 VGPRs to 2 (+2 for H H^T).
-//   * The freed registers hold data instead: the rows of W that do not fit in LDS (NWR tiles per wave) and the first
-//     NXR tiles per wave of X stay in VGPRs for the whole fit.  At 16 x 10 000, k = 5 only (20 - NXR) / 20 of X is
-//     streamed per iteration and W never leaves the CU.
-//   * W^T X / W^T W stay on the VALU (95 accumulators per lane): with the rows on the lanes no MFMA shape contracts
-//     over them (every f32 MFMA keeps the non-contracted index on the low lane bits).
+//     take a second group.  Exact fp32 (an fmaf chain).
+//   * W^T X / W^T W stay on the VALU (16 k + k (k + 1) / 2 accumulators per lane): with the rows on the lanes no MFMA
+//     shape contracts over them (every f32 MFMA keeps the non-contracted index on the low lane bits).
+//   * What this buys, measured (tools/ubench/mfma_rate.hip, tools/run_ksweep.sh, profiles/README.md): NOT arithmetic
+//     speed -- the f32 matrix pipe has the VALU's FLOP rate and the two do not overlap, so at k = 5 the tile costs
+//     ~15 % more time than the VALU form and the kernel runs 9.9 vs 10.15 M matrix-it/s -- but registers: H shrinks
+//     from 16 k VGPRs to 2 (+2 for H H^T), so k = 6, 7, 8 fit two waves per SIMD (228 / 239 / 256 VGPRs, no scratch),
+//     which the VALU form cannot (96..128 VGPRs of H): 8.9 / 8.1 / 7.3 M it/s against 7.0 / 5.3 / 4.1 M for the
+//     channel-major fallback, 0.93 - 0.95 of their byte roofs.
+//   * The batch kernel is bound by the rate at which the XCDs can re-read their Infinity-Cache-resident matrices
+//     (7.2 - 8.1 TB/s, tools/ubench/mall_stream.hip), so the freed registers were also tried as storage -- the rows of
+//     W that do not fit in LDS (NWR tiles per wave) and the first NXR tiles of X resident in VGPRs for the whole fit:
+//     it loses (numbers at HIPNMF_RL_NXR below) and is compiled out by default.
 //
 // Everything else (LDS-resident W, SRD loads with hardware range checks, reduce-scatter of the per-lane sums, the
 // iteration epilogue by wave 0, stop rule, residual / VAF statistics) follows nmf_kernels.hpp.
@@ -44,7 +45,7 @@ __device__ __forceinline__ f4 mfma_4x4_bcast(float a, float b, f4 c) {
 // Resident tiles per wave (compile-time: registers are indexed statically): NWR tiles of W that follow the LDS cache
 // and the first NXR tiles of X can stay in VGPRs for the whole fit.  Measured at 16 x 10 000, k = 5, B = 2048
 // (tools/run_variants.sh, profiles/README.md): (NXR, NWR) = (0, 0) 9.24 M matrix-it/s, (0, 5) 8.69 M, (1, 5) 8.83 M,
-// (2, 4) 8.16 M -- the kernel needs 205 VGPRs before any resident tile (accumulators 95, MFMA results 24, one X tile
+// (2, 4) 8.16 M; one wave per SIMD (HIPNMF_RL_THREADS=256) with (10, 10): 6.13 M -- the kernel needs 195 VGPRs before any resident tile (accumulators 95, MFMA results 24, one X tile
 // 16, quotient temporaries), so more than ~3 tiles spill, and the wave-uniform register selects cost more issue
 // slots than the 13 % of traffic they remove buys back.  Default: nothing resident.
 #ifndef HIPNMF_RL_NXR
