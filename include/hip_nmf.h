@@ -104,7 +104,8 @@ int hipnmf_set_async(hipnmf_handle* h, int enable);
  * solver path: 0 chosen by the library, 1 one persistent workgroup per matrix, 2 row-sliced launches,
  * 3 cooperative multi-workgroup kernel (few long matrices; HIPNMF_ERR_UNSUPPORTED when not applicable),
  * 4 / 5 = 1 with the kernel instance pinned: 4 fit_persistent_kernel (VALU contractions), 5 fit_rowlane_kernel
- * (X H^T and W H H^T on the f32 matrix pipe; fp32, 9..16 channels, Frobenius only, else HIPNMF_ERR_UNSUPPORTED). */
+ * (X H^T and W H H^T on the f32 matrix pipe; fp32, 9..16 channels, Frobenius only, else HIPNMF_ERR_UNSUPPORTED),
+ * 6 fit_small_kernel (one wave per matrix, n_samples <= 256; HIPNMF_ERR_UNSUPPORTED otherwise; picked automatically). */
 int hipnmf_set_tuning(hipnmf_handle* h, int threads, int max_slices, int variant);
 
 /* ---- batched fit: replaces NMF(solver='mu').fit_transform / .transform for B matrices ------------- */

@@ -19,6 +19,7 @@
 #include "hipnmf_internal.hpp"
 #include "nmf_inst.hpp"
 #include "nmf_rowlane_decl.hpp"
+#include "nmf_small_decl.hpp"
 
 using namespace hipnmf;
 
@@ -203,7 +204,7 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
   const double t_pers = waves * ((double)T * (ks->row_major ? 2.0e-9 : 2.7e-9) + 1e-6);  // row-per-lane: 20.8 us / 10 000 rows
   const double t_sliced = 9.5e-6 + (double)B * (double)T * 0.021e-9;
   bool persistent;
-  if (h->variant == 1 || h->variant == 4 || h->variant == 5)
+  if (h->variant == 1 || h->variant == 4 || h->variant == 5 || h->variant == 6)
     persistent = true;
   else if (h->variant == 2)
     persistent = false;
@@ -240,6 +241,26 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
     }
   }
 
+  // Short recordings (the reference's own matrices are 200 x 8 after time_normalize): one WAVE per matrix, everything
+  // in registers, no barrier and no memory traffic inside an iteration (nmf_small.hpp).  Chosen automatically when it
+  // applies (HIPNMF_SMALL=0 disables it; hipnmf_set_tuning variant 6 insists on it).
+  bool use_small = false;
+  {
+    static const bool small_env = [] {
+      const char* e = getenv("HIPNMF_SMALL");
+      return !(e && atoi(e) == 0);
+    }();
+    const bool small_ok = !kl && T <= 256 && small_kernel<real>(m, k) != nullptr && !(sizeof(real) == 8 && k > 6);
+    if (h->variant == 6 && !small_ok)
+      return fail(HIPNMF_ERR_UNSUPPORTED, "fit_small_kernel needs n_samples <= 256, the Frobenius loss and n_features <= %d "
+                  "(n_samples=%lld, n_features=%d, n_components=%d)", sizeof(real) == 8 ? 8 : 16, T, m, k);
+    use_small = small_ok && (h->variant == 6 || (h->variant == 0 && small_env));
+    if (use_small) {
+      persistent = true;
+      ks = select_kernels<real>(m, k, false);  // the channel-major family drives the layout handling below
+    }
+  }
+
   // cooperative multi-workgroup fit: few matrices, each long enough to keep several workgroups busy, the slice
   // of W of every workgroup resident in LDS.  S workgroups per matrix, S * B <= number of CUs (co-residency is
   // what hipLaunchCooperativeKernel guarantees; it refuses the launch otherwise and the sliced path runs).
@@ -250,7 +271,7 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
   // costs ~8 us (L2 write-back / invalidate on a multi-XCD part); with the fence-free exchange the kernel uses
   // (device-scope relaxed atomics for the records and the counter) an iteration of one 16 x 10 000 matrix takes
   // 7.1 us against 10.2 us for the sliced path and 27 us for one persistent workgroup.
-  if (!ragged && !kl && ks->fit_coop && (h->variant == 3 || (h->variant == 0 && h->use_coop)) && B <= h->num_cu / 2 && B <= 65535) {
+  if (!use_small && !ragged && !kl && ks->fit_coop && (h->variant == 3 || (h->variant == 0 && h->use_coop)) && B <= h->num_cu / 2 && B <= 65535) {
     int threads = std::min(h->threads > 0 ? h->threads : 512, ks->max_threads);
     const long long t_pad = round_up(T, 64);
     while (threads > 64 && t_pad < 2LL * threads) threads /= 2;  // at least two workgroup-steps of rows in total
@@ -289,7 +310,7 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
       const char* e = getenv("HIPNMF_ROWLANE");
       return e ? (atoi(e) != 0 ? 1 : 0) : -1;
     }();
-    const bool rl_ok = persistent && !coop && !kl && m > 8 && m <= 16 && rowlane_kernel(k) != nullptr &&
+    const bool rl_ok = persistent && !coop && !use_small && !kl && m > 8 && m <= 16 && rowlane_kernel(k) != nullptr &&
                        (T + 64) * 16LL * (long long)sizeof(real) < (1LL << 31);
     // Default policy (tools/rank_sweep_bench.py, profiles/README.md): k >= 6, where round 1 had to fall back to the
     // channel-major (G=4, CH=4) mapping; at k <= 5 round 1's VALU instance is still ahead (9.54 vs 9.24 M it/s).
@@ -483,6 +504,11 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
   }
   if (coop_done) {
     // nothing else to enqueue
+  } else if (use_small) {
+    h->last_path = 1;
+    snprintf(h->last_kernel, sizeof(h->last_kernel), "fit_small_kernel<%s,%d,%d>", sizeof(real) == 4 ? "float" : "double",
+             m <= 8 ? 8 : 16, k);
+    hipLaunchKernelGGL(small_kernel<real>(m, k), dim3(B), dim3(64), small_smem_bytes<real>(m, k), st, a);
   } else if (persistent) {
     h->last_path = 1;
     int threads = h->threads > 0 ? h->threads : 512;
@@ -878,7 +904,7 @@ int hipnmf_set_tuning(hipnmf_handle* h, int threads, int max_slices, int variant
   if (!h) return fail(HIPNMF_ERR_BAD_ARG, "handle is NULL");
   if (threads != 0 && threads != 256 && threads != 512 && threads != 1024)
     return fail(HIPNMF_ERR_BAD_ARG, "threads must be 0, 256, 512 or 1024");
-  if (max_slices < 0 || variant < 0 || variant > 5) return fail(HIPNMF_ERR_BAD_ARG, "bad tuning value");
+  if (max_slices < 0 || variant < 0 || variant > 6) return fail(HIPNMF_ERR_BAD_ARG, "bad tuning value");
   h->threads = threads;
   h->max_slices = max_slices;
   h->variant = variant;

@@ -1,0 +1,32 @@
+// fit_small_kernel<real, CH, K>: one wave per short matrix (nmf_small.hpp); fp32 with 8 / 16 channels, fp64 with 8
+#include "nmf_small.hpp"
+namespace hipnmf {
+#define SMALL_TABLE(REAL, CH)                                                                                        \
+  {fit_small_kernel<REAL, CH, 1>, fit_small_kernel<REAL, CH, 2>, fit_small_kernel<REAL, CH, 3>,                     \
+   fit_small_kernel<REAL, CH, 4>, fit_small_kernel<REAL, CH, 5>, fit_small_kernel<REAL, CH, 6>,                     \
+   fit_small_kernel<REAL, CH, 7>, fit_small_kernel<REAL, CH, 8>}
+template <>
+SmallFn<float> small_kernel<float>(int m, int K) {
+  static const SmallFn<float> t8[8] = SMALL_TABLE(float, 8);
+  static const SmallFn<float> t16[8] = SMALL_TABLE(float, 16);
+  if (K < 1 || K > 8 || m < 1 || m > 16) return nullptr;
+  return m <= 8 ? t8[K - 1] : t16[K - 1];
+}
+template <>
+SmallFn<double> small_kernel<double>(int m, int K) {
+  static const SmallFn<double> t8[8] = SMALL_TABLE(double, 8);
+  if (K < 1 || K > 8 || m < 1 || m > 8) return nullptr;
+  return t8[K - 1];
+}
+template <typename real>
+static size_t smem_of(int m, int K) {
+  const int CH = m <= 8 ? 8 : 16;
+  const int nacc = K * CH + K * (K + 1) / 2;
+  const int nrec = nacc > 2 * CH + 1 ? nacc : 2 * CH + 1;
+  return sizeof(real) * (size_t)(2 * K * CH + 2 * K * K + nrec + 8);  // = Smem<real, 1, CH, K>::bytes(1)
+}
+template <>
+size_t small_smem_bytes<float>(int m, int K) { return smem_of<float>(m, K); }
+template <>
+size_t small_smem_bytes<double>(int m, int K) { return smem_of<double>(m, K); }
+}  // namespace hipnmf

@@ -147,6 +147,56 @@ def test_ragged_batch_and_restarts_on_the_matrix_pipe_instance():
     np.testing.assert_allclose(best, err.min(axis=1), rtol=1e-6)
 
 
+@pytest.mark.parametrize("dtype,m,k,T", [(np.float64, 8, 3, 200), (np.float64, 8, 6, 256), (np.float64, 5, 2, 1),
+                                        (np.float32, 8, 8, 130), (np.float32, 16, 5, 200), (np.float32, 13, 8, 255),
+                                        (np.float32, 2, 1, 64)])
+def test_one_wave_per_matrix_kernel(dtype, m, k, T):
+    """fit_small_kernel (picked automatically for n_samples <= 256; variant 6 pins it): the reference's own matrix
+    sizes (200 x 8 after time_normalize), stop rule, transform, regularisation, batch of unequal trials."""
+    import muscle_synergies_amd as ms
+    from muscle_synergies_amd import _lib
+
+    B = 5
+    Xs = [emg_matrix(300 + b, T=T, m=m, k_true=min(3, m), dtype=dtype) for b in range(B)]
+    inits = [random_init(Xs[b], k, b) for b in range(B)]
+    X = np.stack([np.ascontiguousarray(x) for x in Xs])
+    W0, H0 = np.stack([i[0] for i in inits]), np.stack([i[1] for i in inits])
+    h = _lib.Handle(0)
+    h.set_tuning(0, 0, 6)
+    lim = TOL if dtype == np.float32 else 1e-10
+    for kw, okw in (({}, {}), ({"update_H": False}, {"update_H": False}),
+                    ({"l1_reg_W": 0.02, "l1_reg_H": 0.01, "l2_reg_W": 0.03, "l2_reg_H": 0.04}, None)):
+        res = ms.fit_batched(X, W0, H0, max_iter=60, tol=0.0, handle=h, **kw)
+        assert h.last_kernel().startswith("fit_small_kernel<" + ("float" if dtype == np.float32 else "double"))
+        for b in range(B):
+            if okw is None:
+                Wr, Hr, _ = orc.fit_multiplicative_update(Xs[b], W0[b].copy(), H0[b].copy(), 60, 0.0, 0.02, 0.01, 0.03, 0.04)
+            else:
+                Wr, Hr, _ = orc.fit_multiplicative_update(Xs[b], W0[b].copy(), H0[b].copy(), 60, 0.0, 0.0, 0.0, 0.0, 0.0, **okw)
+            assert _rel_wh(Xs[b], res.W[b], res.H[b], {"W": Wr, "H": Hr}) <= lim, (kw, b)
+    if T >= 64:
+        res = ms.fit_batched(X, W0, H0, max_iter=2000, tol=1e-4, handle=h)
+        for b in range(B):
+            ref = orc.nmf_mu_fit(Xs[b], W0[b], H0[b], max_iter=2000, tol=1e-4)
+            if dtype == np.float64:
+                assert int(res.n_iter[b]) == ref["n_iter"]
+            assert abs(float(res.reconstruction_err[b]) - float(ref["reconstruction_err"])) / np.linalg.norm(Xs[b]) <= max(lim, 1e-6)
+    # the automatic choice takes it too, and the ragged entry point (trials of unequal length)
+    auto = ms.fit_batched(X, W0, H0, max_iter=10, tol=0.0)
+    assert _lib.get_handle(0).last_kernel().startswith("fit_small_kernel<")
+    if T >= 8:
+        Tr = [T, max(1, T // 2), max(1, T - 3)]
+        rr = ms.fit_ragged([Xs[i][:Tr[i]] for i in range(3)], [W0[i][:Tr[i]] for i in range(3)], [H0[i] for i in range(3)],
+                           max_iter=25, tol=0.0)
+        for i in range(3):
+            ref = orc.nmf_mu_fit(np.ascontiguousarray(Xs[i][:Tr[i]]), W0[i][:Tr[i]], H0[i], max_iter=25, tol=0.0)
+            assert _rel_wh(Xs[i][:Tr[i]], np.asarray(rr.W[i].cpu()), np.asarray(rr.H[i].cpu()), ref) <= lim
+    with pytest.raises(_lib.HipNmfError, match="fit_small_kernel"):
+        big = emg_matrix(1, T=300, m=m, k_true=min(3, m), dtype=dtype)
+        wb, hb = random_init(big, k, 1)
+        ms.fit_batched(big, wb, hb, max_iter=2, tol=0.0, handle=h)
+
+
 # ------------------------------------------------------------------------------------------------ verdict 1(b)
 def test_full_size_rank_shard_is_shard_count_invariant():
     """Config #5's per-rank share on 8 GPUs: ONE shard of 2.5e7 rows x 16 channels (1.6 GB of X, generated on the
