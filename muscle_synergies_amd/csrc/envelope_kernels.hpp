@@ -369,4 +369,457 @@ __global__ void __launch_bounds__(256) emg_fused_kernel(EnvArgs a) {
   }
 }
 
+// =================================================================================================
+// Wave-per-series version (round 2, default for 1 <= window and T >= 2): one WAVE owns a channel of a recording.
+// PMC counters of emg_fused_kernel (profiles/README.md) showed it bound by instruction issue, not by memory: 77 VALU
+// + 27 SALU instructions per sample and lane (index clamps of the halo loads, a runtime-length LDS scan, three
+// workgroup barriers per tile, the halo of W - 1 samples squared twice).  Here
+//   * a lane owns SPL CONSECUTIVE samples of a 64 SPL tile: the prefix over its samples is SPL register adds, the
+//     prefix over the lanes six DPP steps, nothing of the scan goes through LDS and there is no barrier at all
+//     (a single wave executes its LDS operations in order);
+//   * the prefix is a RUNNING one (carried from tile to tile), so no halo is recomputed; the last `ring` >= tile + W
+//     prefix values live in an LDS ring (8 values per 9 slots: conflict-free for the blocked writes and for the
+//     consecutive reads); every ENV_REBASE samples the carry is subtracted from the W live entries (exact by
+//     Sterbenz' lemma) and reset, which bounds the relative error of a window sum at eps * ENV_REBASE;
+//   * outputs trail the inputs by (W - 1) / 2 + 1 samples and are produced 64 consecutive ones per instruction
+//     (coalesced stores), each from two LDS reads.
+// Same semantics as emg_fused_kernel (np.convolve "same" alignment, zero padding, NumPy's linspace knots, scipy's
+// linear interp1d, division by the channel maximum); the summation order differs, results agree to ~1e-13 relative.
+// =================================================================================================
+constexpr int ENV_REBASE = 1 << 16;
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double env_dpp_pull(double v) {  // lanes without a source, or in rows masked off, get 0
+  const unsigned long long s = __builtin_bit_cast(unsigned long long, v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)s, CTRL, ROW_MASK, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(s >> 32), CTRL, ROW_MASK, 0xf, false);
+  return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+
+__device__ __forceinline__ double env_wave_inclusive_scan(double v) {
+  v += env_dpp_pull<0x111, 0xf>(v);  // row_shr:1
+  v += env_dpp_pull<0x112, 0xf>(v);  // row_shr:2
+  v += env_dpp_pull<0x114, 0xf>(v);  // row_shr:4
+  v += env_dpp_pull<0x118, 0xf>(v);  // row_shr:8  -> inclusive scan within each row of 16 lanes
+  v += env_dpp_pull<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+  v += env_dpp_pull<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3
+  return v;
+}
+
+__device__ __forceinline__ void env_wave_sync() {  // LDS operations of one wave execute in order: only the compiler needs telling
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+}
+
+// State of one wave walking a series tile by tile (shared by emg_wave_kernel and emg_wg_kernel).
+template <typename real, int SPL>
+struct EnvWave {
+  static constexpr int TILE = 64 * SPL, V = 16 / (int)sizeof(real), NV = SPL / V;
+  static_assert(SPL == 4 || SPL == 8, "a lane's samples must stay inside one group of 8 ring entries");
+  struct alignas(16) Vec { real v[V]; };
+  const real* __restrict__ x;
+  double* P;  // ring: prefix value j (sum of the squared centred samples before j) lives at slot(j)
+  int T, W, lo, hi, mask, lane, first;  // first: the tile the walk started at (no prefix values exist before it)
+  bool vec_ok;
+  double mean, carry;
+  real pf[SPL];
+
+  __device__ __forceinline__ void init(const real* x_, double* P_, int ring, int T_, int W_, double mean_, int lane_, int first_) {
+    x = x_;
+    P = P_;
+    T = T_;
+    W = W_;
+    hi = (W - 1) / 2;
+    lo = (W - 1) - hi;
+    mask = ring - 1;
+    lane = lane_;
+    first = first_;
+    vec_ok = (reinterpret_cast<unsigned long long>(x_) & 15ull) == 0;
+    mean = mean_;
+    carry = 0.0;
+    issue(first_);
+  }
+  __device__ __forceinline__ void set_mean(double mean_) { mean = mean_; }  // may follow init: the first request does not need it
+  __device__ __forceinline__ int slot(int j) const {
+    const int s_ = j & mask;
+    return s_ + (s_ >> 3);
+  }
+  // request the lane's SPL consecutive samples of the tile at t0 (zero past the end of the series)
+  __device__ __forceinline__ void load(int t0, real (&v)[SPL]) const {
+    const int j0 = t0 + lane * SPL;
+    if (vec_ok && j0 + SPL <= T) {
+#pragma unroll
+      for (int q = 0; q < NV; ++q) {
+        const Vec t = *reinterpret_cast<const Vec*>(x + j0 + q * V);
+#pragma unroll
+        for (int e = 0; e < V; ++e) v[q * V + e] = t.v[e];
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < SPL; ++c) v[c] = (j0 + c < T) ? x[j0 + c] : (real)0;
+    }
+  }
+  __device__ __forceinline__ void issue(int t0) { load(t0, pf); }
+  // streaming walk: the tile at t0 from the prefetch registers, the next tile requested as soon as they are free
+  __device__ __forceinline__ void tile(int t0) {
+    tile_core(t0, pf, [&]() __attribute__((always_inline)) {
+      if (t0 + TILE < T) issue(t0 + TILE);  // its latency hides behind the scan and the outputs
+    });
+  }
+  // prefix values of the tile at t0 (samples v) into the ring; afterwards P[j] is available for j < t0 + TILE
+  template <typename F>
+  __device__ __forceinline__ void tile_core(int t0, const real (&v)[SPL], F after_consume) {
+    if (t0 > first && (t0 & (ENV_REBASE - 1)) == 0) {
+      // re-base the running prefix: the live entries are P[t0 - W .. t0 - 1]
+      for (int e = 1 + lane; e <= W; e += 64) {
+        const int j = t0 - e;
+        if (j >= first) P[slot(j)] -= carry;
+      }
+      carry = 0.0;
+      env_wave_sync();
+    }
+    // exclusive prefix over the lane's samples, then over the lanes
+    double ex[SPL], run = 0.0;
+    if (t0 + TILE <= T) {
+#pragma unroll
+      for (int c = 0; c < SPL; ++c) {
+        const double d = (double)v[c] - mean;
+        ex[c] = run;
+        run += d * d;
+      }
+    } else {
+      const int j0 = t0 + lane * SPL;
+#pragma unroll
+      for (int c = 0; c < SPL; ++c) {
+        const double d = (j0 + c < T) ? (double)v[c] - mean : 0.0;
+        ex[c] = run;
+        run += d * d;
+      }
+    }
+    after_consume();
+    const double inc = env_wave_inclusive_scan(run);
+    const double up = __shfl_up(inc, 1, 64);
+    const double base = carry + (lane ? up : 0.0);
+    {
+      const int s0 = (t0 + lane * SPL) & mask;
+      double* dst = P + s0 + (s0 >> 3);
+#pragma unroll
+      for (int c = 0; c < SPL; ++c) dst[c] = base + ex[c];
+    }
+    carry += __shfl(inc, 63, 64);
+    env_wave_sync();
+  }
+  // sum of the squared centred samples in the window around i (np.convolve "same" alignment, zeros outside [0, T))
+  __device__ __forceinline__ double window_sum(int i) const {
+    const int jb = i - lo;
+    return P[slot(i + hi + 1)] - P[slot(jb < 0 ? 0 : jb)];
+  }
+  // full tile of outputs emitted .. emitted + TILE (no clamping needed: emitted >= lo): all ring reads are issued
+  // before the first use; the ring entry of slot j is 9 (j >> 3) + (j & 7) and j advances by 64 between a lane's outputs
+  __device__ __forceinline__ void window_sums_full_tile(int emitted, double (&sd)[SPL]) const {
+    const unsigned ja = (unsigned)(emitted + hi + 1 + lane), jb = (unsigned)(emitted - lo + lane);
+    const unsigned ga = ja >> 3, gb = jb >> 3, gm = (unsigned)mask >> 3, ca = ja & 7u, cb = jb & 7u;
+    double pa[SPL], pb[SPL];
+#pragma unroll
+    for (int u = 0; u < SPL; ++u) {
+      const unsigned ta = (ga + 8u * u) & gm, tb = (gb + 8u * u) & gm;  // 9 t + c as shifts (no v_mul_lo_u32)
+      pa[u] = P[(ta << 3) + (ta + ca)];
+      pb[u] = P[(tb << 3) + (tb + cb)];
+    }
+#pragma unroll
+    for (int u = 0; u < SPL; ++u) sd[u] = pa[u] - pb[u];
+  }
+};
+
+// y / vmax as the reference does it (float64 division): for fp32 outputs the correctly rounded fp32 quotient of two
+// floats equals the fp64 quotient rounded to float (53 >= 2 * 24 + 2 bits: double rounding is innocuous), at a third
+// of the cost; vmax is a maximum of floats there, hence exact in fp32
+template <typename real>
+__device__ __forceinline__ real env_scaled(real y, double vmax, float vmf) {
+  if constexpr (sizeof(real) == 4) return y / vmf;
+  else return (real)((double)y / vmax);
+}
+
+template <typename real, int SPL>
+__global__ void __launch_bounds__(64) emg_wave_kernel(EnvArgs a, int ring /* power of two >= 64 SPL + window */) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char env_smem[];
+  using Wv = EnvWave<real, SPL>;
+  using Vec = typename Wv::Vec;
+  constexpr int TILE = Wv::TILE, V = Wv::V;
+  const int lane = threadIdx.x;
+  const int ch = blockIdx.x, b = blockIdx.y;
+  const long long cidx = (long long)b * a.m + ch;
+  const real* __restrict__ x = static_cast<const real*>(a.raw) + (long long)b * a.bstride + (long long)ch * a.ld;
+  const int T = a.T, W = a.window;
+  const int n_out = a.n_out > 0 ? a.n_out : T;
+  real* __restrict__ o = static_cast<real*>(a.out) + cidx * (long long)n_out;
+
+  Wv wv;
+  wv.init(x, reinterpret_cast<double*>(env_smem), ring, T, W, 0.0, lane, 0);  // first tile requested before the mean pass
+  double mean = 0.0;
+  if (a.zero_center) {
+    // eight 16-byte loads in flight per lane; fixed summation order
+    double acc[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc[q] = 0.0;
+    int done = 0;
+    if ((reinterpret_cast<unsigned long long>(x) & 15ull) == 0) {
+      const Vec* __restrict__ xv = reinterpret_cast<const Vec*>(x);
+      const int nv = T / V;
+      int q0 = 0;
+      for (; q0 + 8 * 64 <= nv; q0 += 8 * 64) {
+        Vec t[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t[q] = xv[q0 + q * 64 + lane];
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+#pragma unroll
+          for (int e = 0; e < V; ++e) acc[q] += (double)t[q].v[e];
+      }
+      for (int q = q0 + lane; q < nv; q += 64)
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[0] += (double)xv[q].v[e];
+      done = nv * V;
+    }
+    for (int i = done + lane; i < T; i += 64) acc[1] += (double)x[i];
+    double s_ = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s_ += __shfl_xor(s_, off, 64);
+    mean = s_ / (double)T;
+  }
+
+  wv.set_mean(mean);
+  const int hi = wv.hi;
+  const bool resample = a.n_out > 0 && a.n_out != T;
+  const double step_out = (n_out > 1) ? 1.0 / (double)(n_out - 1) : 0.0;
+  const double step_in = 1.0 / (double)(T - 1);  // T >= 2 (the launcher routes T == 1 to emg_fused_kernel)
+  auto knot = [&](int i) { return (i == T - 1) ? 1.0 : (double)i * step_in; };  // np.linspace(0, 1, T)[i]
+  const double inv_w = 1.0 / (double)W;  // np.convolve(x^2, ones(W) / W): products by 1/W, no division
+  const float inv_wf = (float)inv_w;
+  auto value = [&](int i) -> double {
+    const double sd = wv.window_sum(i);
+    return sqrt((sd > 0.0 ? sd : 0.0) * inv_w);
+  };
+
+  double vmax = 0.0;
+  float vmaxf = 0.f;
+  int emitted = 0;
+  const int end_all = resample ? T - 1 : T;  // resampling: `emitted` counts left knots i0 in [0, T - 1)
+  for (int t0 = 0; emitted < end_all; t0 += TILE) {
+    wv.tile(t0);
+    const int avail = t0 + TILE;  // P[j] is in the ring for j < avail (zeros past T: P[j] = P[T] there)
+    if (!resample) {
+      int end = avail - hi - 1;
+      if (end > T) end = T;
+      if (end - emitted == TILE && emitted >= wv.lo) {
+        // steady state: a full tile of outputs, no clamping
+        double sd[SPL];
+        wv.window_sums_full_tile(emitted, sd);
+        real* __restrict__ op = o + emitted + lane;
+#pragma unroll
+        for (int u = 0; u < SPL; ++u) {
+          if constexpr (sizeof(real) == 4) {
+            // fp32 output: the fp64 window sum is rounded to float once, the root is the bare v_sqrt_f32 (1 ulp; the
+            // correctly rounded one of the ragged tiles below pays ~18 instructions for the last half ulp)
+            const float y = __builtin_amdgcn_sqrtf(fmaxf((float)sd[u], 0.f) * inv_wf);
+            op[64 * u] = y;
+            vmaxf = fmaxf(vmaxf, y);
+          } else {
+            const double y = sqrt((sd[u] > 0.0 ? sd[u] : 0.0) * inv_w);
+            op[64 * u] = (real)y;
+            vmax = fmax(vmax, y);
+          }
+        }
+      } else {
+        for (int i = emitted + lane; i < end; i += 64) {
+          if constexpr (sizeof(real) == 4) {
+            const float y = __builtin_sqrtf(fmaxf((float)wv.window_sum(i), 0.f) * inv_wf);
+            o[i] = y;
+            vmaxf = fmaxf(vmaxf, y);
+          } else {
+            const double y = value(i);
+            o[i] = (real)y;
+            vmax = fmax(vmax, y);
+          }
+        }
+      }
+      if (end > emitted) emitted = end;
+    } else {
+      // scipy interp1d(kind="linear") from linspace(0,1,T) onto linspace(0,1,n_out): output q is produced by the
+      // tile whose range [emitted, end) holds its left knot i0 (both neighbours' windows are in the ring then)
+      int end = avail - hi - 2;
+      if (end > T - 1) end = T - 1;
+      if (end > emitted) {
+        const double scale = (double)(n_out - 1);
+        int q_lo = (int)floor(knot(emitted) * scale) - 1, q_hi = (int)ceil(knot(end) * scale) + 2;
+        if (q_lo < 0) q_lo = 0;
+        if (q_hi > n_out) q_hi = n_out;
+        for (int q = q_lo + lane; q < q_hi; q += 64) {
+          const double xn = (q == n_out - 1 && n_out > 1) ? 1.0 : (double)q * step_out;
+          int i0 = (int)floor(xn * (double)(T - 1));
+          if (i0 > T - 2) i0 = T - 2;
+          if (i0 < 0) i0 = 0;
+          while (i0 > 0 && knot(i0) >= xn) --i0;  // searchsorted(side="left") - 1, clipped to >= 0
+          while (i0 < T - 2 && knot(i0 + 1) < xn) ++i0;
+          if (i0 < emitted || i0 >= end) continue;
+          const double x0 = knot(i0), x1 = knot(i0 + 1);
+          const double y0 = value(i0), y1 = value(i0 + 1);
+          const double y = (y1 - y0) / (x1 - x0) * (xn - x0) + y0;
+          o[q] = (real)y;
+          vmax = fmax(vmax, fabs(y));
+        }
+        emitted = end;
+      }
+    }
+    env_wave_sync();  // the next tile overwrites ring entries only after these reads
+  }
+  if (a.normalize) {
+    vmax = fmax(vmax, (double)vmaxf);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) vmax = fmax(vmax, __shfl_xor(vmax, off, 64));
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // the outputs were written by other lanes of this wave
+    const float vmf = (float)vmax;
+    int q0 = 0;
+    if ((reinterpret_cast<unsigned long long>(o) & 15ull) == 0) {  // 16-byte accesses, four in flight per lane
+      Vec* __restrict__ ov = reinterpret_cast<Vec*>(o);
+      const int nv = n_out / V;
+      int qv = 0;
+      for (; qv + 4 * 64 <= nv; qv += 4 * 64) {
+        Vec t[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) t[u] = ov[qv + u * 64 + lane];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+          for (int e = 0; e < V; ++e) t[u].v[e] = env_scaled<real>(t[u].v[e], vmax, vmf);
+          ov[qv + u * 64 + lane] = t[u];
+        }
+      }
+      for (int q = qv + lane; q < nv; q += 64) {
+        Vec t = ov[q];
+#pragma unroll
+        for (int e = 0; e < V; ++e) t.v[e] = env_scaled<real>(t.v[e], vmax, vmf);
+        ov[q] = t;
+      }
+      q0 = nv * V;
+    }
+    for (int q = q0 + lane; q < n_out; q += 64) o[q] = env_scaled<real>(o[q], vmax, vmf);
+  }
+}
+
+// =================================================================================================
+// Workgroup-per-series version for the full-length output (no time normalisation) of series of up to ~20 K samples.
+// emg_wave_kernel is bound by memory traffic there (measured 5.1 TB/s): raw read twice (mean, tiles), output written,
+// read back and written again once the channel maximum is known = 5 sizeof(real) per sample.  Here the NW waves of a
+// workgroup split the series into NW segments (each re-runs the prefix over the W samples before its segment) and
+// keep BOTH their samples and their outputs in registers: all samples are requested at once (one memory latency per
+// series), the mean comes from the same registers, and the envelope goes to memory once, already divided by the
+// maximum: 2 sizeof(real) per sample, the algorithmic minimum.  LDS holds only the rings, so two workgroups share a
+// CU and one's memory wait / barriers overlap the other's arithmetic.
+// =================================================================================================
+constexpr int ENV_WG_WAVES = 8, ENV_WG_SPL = 4;
+#define ENV_WG_MAXT(real) (sizeof(real) == 4 ? 12 : 6)  // tiles of 256 samples a wave can hold in registers
+
+template <typename real>
+__global__ void __launch_bounds__(64 * ENV_WG_WAVES) emg_wg_kernel(EnvArgs a, int ring) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char env_smem[];
+  constexpr int SPL = ENV_WG_SPL;
+  using Wv = EnvWave<real, SPL>;
+  constexpr int TILE = Wv::TILE, NW = ENV_WG_WAVES, MAXT = ENV_WG_MAXT(real);
+  const int ring_entries = ring + ring / 8;
+  double* rings = reinterpret_cast<double*>(env_smem);  // [NW][ring_entries]
+  double* scratch = rings + (size_t)NW * ring_entries;  // [NW]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ch = blockIdx.x, b = blockIdx.y;
+  const long long cidx = (long long)b * a.m + ch;
+  const real* __restrict__ x = static_cast<const real*>(a.raw) + (long long)b * a.bstride + (long long)ch * a.ld;
+  const int T = a.T, W = a.window;
+  real* __restrict__ o = static_cast<real*>(a.out) + cidx * (long long)T;
+
+  // segment of this wave: whole tiles; the walk starts far enough before it for the first window and ends far enough
+  // behind it for the last one (at most MAXT tiles: the launcher checks)
+  const int seg_len = ((T + NW - 1) / NW + TILE - 1) / TILE * TILE;
+  const int seg_b = wave * seg_len;
+  const int seg_e = (seg_b + seg_len < T) ? seg_b + seg_len : T;
+  int first = seg_b - (W + TILE - 1) / TILE * TILE;
+  if (first < 0) first = 0;
+  Wv wv;
+  wv.init(x, rings + (size_t)wave * ring_entries, ring, T, W, 0.0, lane, first);
+  int nt = (seg_b < T) ? (seg_e + wv.hi + 1 - first + TILE - 1) / TILE : 0;
+  if (nt > MAXT) nt = MAXT;
+  real xs[MAXT][SPL];  // samples, then (tile by tile, as they are consumed) outputs
+#pragma unroll
+  for (int k = 0; k < MAXT; ++k)
+    if (k < nt) wv.load(first + k * TILE, xs[k]);
+  if (a.zero_center) {
+    double acc = 0.0;  // the wave's own samples (zeros past the end of the series), fixed order
+#pragma unroll
+    for (int k = 0; k < MAXT; ++k) {
+      const int t0 = first + k * TILE;
+      if (k < nt && t0 >= seg_b && t0 < seg_e) {
+#pragma unroll
+        for (int c = 0; c < SPL; ++c) acc += (double)xs[k][c];
+      }
+    }
+    wv.set_mean(block_sum(acc, scratch) / (double)T);
+  }
+  const double inv_w = 1.0 / (double)W;
+  const float inv_wf = (float)inv_w;
+  double vmax = 0.0;
+  float vmaxf = 0.f;
+  int eb[MAXT], ee[MAXT];  // outputs eb[k] .. ee[k] were produced after tile k: output eb[k] + lane + 64 u sits in xs[k][u]
+  int emitted = seg_b;
+  const int hi = wv.hi;
+#pragma unroll
+  for (int k = 0; k < MAXT; ++k) {
+    eb[k] = ee[k] = 0;
+    if (k < nt) {
+      const int t0 = first + k * TILE;
+      wv.tile_core(t0, xs[k], []() {});
+      int end = t0 + TILE - hi - 1;
+      if (end > seg_e) end = seg_e;
+      if (end > emitted) {
+        double sd[SPL];
+        if (end - emitted == TILE && emitted >= wv.lo) {
+          wv.window_sums_full_tile(emitted, sd);
+        } else {
+#pragma unroll
+          for (int u = 0; u < SPL; ++u) {
+            const int i = emitted + lane + 64 * u;
+            sd[u] = (i < end) ? wv.window_sum(i) : 0.0;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < SPL; ++u) {
+          // fp32 output: the fp64 window sum is rounded to float once and the root is v_sqrt_f32 (1 ulp)
+          if constexpr (sizeof(real) == 4) {
+            const float y = __builtin_amdgcn_sqrtf(fmaxf((float)sd[u], 0.f) * inv_wf);
+            xs[k][u] = y;
+            vmaxf = fmaxf(vmaxf, y);  // lanes past `end` hold 0
+          } else {
+            const double y = sqrt((sd[u] > 0.0 ? sd[u] : 0.0) * inv_w);
+            xs[k][u] = (real)y;
+            vmax = fmax(vmax, y);
+          }
+        }
+        eb[k] = emitted;
+        ee[k] = end;
+        emitted = end;
+      }
+      env_wave_sync();  // the next tile overwrites ring entries only after these reads
+    }
+  }
+  const bool norm = a.normalize != 0;
+  if (norm) vmax = block_max(fmax(vmax, (double)vmaxf), scratch);
+  const float vmf = (float)vmax;
+#pragma unroll
+  for (int k = 0; k < MAXT; ++k) {
+#pragma unroll
+    for (int u = 0; u < SPL; ++u) {
+      const int i = eb[k] + lane + 64 * u;
+      if (i < ee[k]) o[i] = norm ? env_scaled<real>(xs[k][u], vmax, vmf) : xs[k][u];
+    }
+  }
+}
+
 }  // namespace hipnmf

@@ -46,7 +46,36 @@ int envelope_impl(hipnmf_handle* h, const hipnmf_envelope_params* p, const real*
     return !(e && atoi(e) == 0);
   }();
   const size_t fused_lds = sizeof(double) * (size_t)(ENV_TILE + p->window + 16);
-  const bool fused = fused_ok && fused_lds <= 96 * 1024;
+  // one wave per series with a running prefix in an LDS ring (emg_wave_kernel): the default whenever there is a window
+  // that fits a 4096-entry ring beside a 512-sample tile; HIPNMF_ENV_WAVE=0 falls back to the workgroup kernels
+  static const bool wave_ok = [] {
+    const char* e = getenv("HIPNMF_ENV_WAVE");
+    return !(e && atoi(e) == 0);
+  }();
+  static const int wave_spl = [] {  // samples per lane and tile: 8 (default) or 4 (HIPNMF_ENV_SPL=4: smaller ring, more waves per CU)
+    const char* e = getenv("HIPNMF_ENV_SPL");
+    return (e && atoi(e) == 4) ? 4 : 8;
+  }();
+  int ring = 512;
+  while (ring < 64 * wave_spl + p->window && ring < 8192) ring *= 2;
+  const bool wave = wave_ok && p->window >= 1 && T >= 2 && ring <= 4096 && 64 * wave_spl + p->window <= ring;
+  // full-length output of a series short enough for the registers of one workgroup (emg_wg_kernel: samples and
+  // outputs stay on chip, 2 instead of up to 5 sizeof(real) of traffic per sample); HIPNMF_ENV_WG=0 leaves those to
+  // emg_wave_kernel
+  static const bool wg_ok = [] {
+    const char* e = getenv("HIPNMF_ENV_WG");
+    return !(e && atoi(e) == 0);
+  }();
+  constexpr int WG_TILE = 64 * ENV_WG_SPL;
+  int ring4 = 512;
+  while (ring4 < WG_TILE + p->window && ring4 < 8192) ring4 *= 2;
+  const size_t wg_lds = sizeof(double) * ((size_t)ENV_WG_WAVES * (ring4 + ring4 / 8) + ENV_WG_WAVES);
+  // tiles a wave walks: those before its segment (first window), its segment, those behind it (last window)
+  const long long wg_seg = ((T + ENV_WG_WAVES - 1) / ENV_WG_WAVES + WG_TILE - 1) / WG_TILE;
+  const long long wg_tiles = (p->window + WG_TILE - 1) / WG_TILE + wg_seg + ((p->window - 1) / 2 + 1 + WG_TILE - 1) / WG_TILE;
+  const bool wg = wave && wg_ok && (p->n_out == 0 || p->n_out == T) && WG_TILE + p->window <= ring4 && ring4 <= 4096 &&
+                  T >= 2LL * ENV_WG_WAVES * WG_TILE && wg_tiles <= ENV_WG_MAXT(real);
+  const bool fused = wave || (fused_ok && fused_lds <= 96 * 1024);
   const size_t o_ps = fused ? 0 : carve(sizeof(double) * (size_t)B * m * (T + 1));
   const size_t o_st = fused ? 0 : carve(sizeof(double) * (size_t)B * m * 2);
   int rc = hipnmf_ensure_ws(h, std::max<size_t>(off, 256));
@@ -79,7 +108,18 @@ int envelope_impl(hipnmf_handle* h, const hipnmf_envelope_params* p, const real*
   a.normalize = p->normalize ? 1 : 0;
   const bool async = h->async_mode != 0;
   if (!async) HIP_TRY(hipEventRecord(h->ev0, st));
-  if (fused) {
+  if (wg) {
+    if (wg_lds > 48 * 1024)
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(emg_wg_kernel<real>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)wg_lds));
+    hipLaunchKernelGGL((emg_wg_kernel<real>), dim3(m, B), dim3(64 * ENV_WG_WAVES), wg_lds, st, a, ring4);
+  } else if (wave) {
+    const size_t lds = sizeof(double) * (size_t)(ring + ring / 8);
+    if (wave_spl == 4)
+      hipLaunchKernelGGL((emg_wave_kernel<real, 4>), dim3(m, B), dim3(64), lds, st, a, ring);
+    else
+      hipLaunchKernelGGL((emg_wave_kernel<real, 8>), dim3(m, B), dim3(64), lds, st, a, ring);
+  } else if (fused) {
     if (fused_lds > 48 * 1024)
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(emg_fused_kernel<real>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds));

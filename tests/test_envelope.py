@@ -99,3 +99,50 @@ def test_gpu_batch_feeds_the_solver_without_a_copy():
     W0, H0 = ms.random_init_batched(env, 3, seed=0)
     r = ms.fit_batched(env, W0, H0, max_iter=50, tol=0.0)
     assert bool(torch.isfinite(r.reconstruction_err).all()) and float(r.vaf[:, 0].min()) > 0.5
+
+
+# Shapes chosen to reach every envelope kernel (hipnmf_envelope.hip picks by shape): emg_wg_kernel (full-length
+# output of a series that fits in the registers of a workgroup), emg_wave_kernel (everything else with a window: ragged tiles, long windows,
+# up-sampling, the re-basing of the running prefix past 65 536 samples, unaligned channel rows) and
+# emg_fused_kernel (no window / window too long for the ring).
+_KERNEL_CASES = [
+    # T, m, W, reduce_to, normalize, zero_center, dtype
+    (8000, 3, 201, None, True, True, np.float64),     # workgroup kernel, fp64, odd window
+    (8001, 2, 200, None, True, False, np.float64),    # workgroup kernel, ragged last tile, unaligned rows (F layout)
+    (20000, 2, 200, None, True, True, np.float32),    # workgroup kernel, fp32 (the benchmark shape)
+    (20480, 1, 256, None, False, True, np.float32),   # workgroup kernel at its register limit, not normalised
+    (4096, 2, 50, None, True, True, np.float32),      # workgroup kernel, shortest series it takes
+    (9000, 3, 200, None, False, True, np.float64),    # wave kernel, full length (fp64 series too long for the registers)
+    (70001, 2, 150, None, True, True, np.float64),    # wave kernel, prefix re-based past 65 536 samples
+    (70000, 2, 150, 1000, True, True, np.float64),    # wave kernel, time-normalised, re-based
+    (70000, 1, 150, None, True, True, np.float32),    # wave kernel fp32 (too long for the workgroup kernel)
+    (1000, 3, 37, 2500, True, True, np.float64),      # up-sampling
+    (513, 2, 500, None, True, True, np.float64),      # window almost as long as the series
+    (300, 2, 1, 50, False, False, np.float64),        # window of one sample
+    (5000, 2, 3000, None, True, True, np.float64),    # largest ring
+    (5000, 2, 4000, None, True, True, np.float64),    # beyond the ring: emg_fused_kernel
+    (2, 2, 2, None, True, False, np.float64),         # two samples
+    (1, 2, 1, None, False, False, np.float64),        # one sample: emg_fused_kernel
+    (4096, 16, 200, 200, True, True, np.float32),     # tutorial-like chain in fp32
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", _KERNEL_CASES, ids=lambda c: f"T{c[0]}-m{c[1]}-W{c[2]}-r{c[3]}-n{int(c[4])}-z{int(c[5])}-{np.dtype(c[6]).name}")
+@pytest.mark.parametrize("layout", ["C", "F"])
+def test_gpu_envelope_kernels_match_oracle(case, layout):
+    from muscle_synergies_amd.preprocess import emg_envelope_batched
+
+    T, m, W, reduce_to, norm, zc, dtype = case
+    B = 2
+    raw = np.stack([raw_emg(300 + 7 * b + T % 97, T, m) for b in range(B)]).astype(dtype)
+    raw[1] += 0.37  # a DC offset that zero_center has to remove
+    x = np.ascontiguousarray(raw) if layout == "C" else np.ascontiguousarray(raw.transpose(0, 2, 1)).transpose(0, 2, 1)
+    out = emg_envelope_batched(x, W, reduce_to=reduce_to, normalize=norm, zero_center=zc).cpu().numpy()
+    assert out.dtype == dtype
+    for b in range(B):
+        ref = eo.envelope(raw[b].astype(np.float64), W, reduce_to, do_zero_center=zc, do_normalize=norm)
+        if dtype == np.float32:
+            np.testing.assert_allclose(out[b], ref, rtol=3e-5, atol=3e-6 * np.abs(ref).max())
+        else:
+            np.testing.assert_allclose(out[b], ref, rtol=1e-9, atol=1e-12)

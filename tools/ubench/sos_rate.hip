@@ -3,6 +3,7 @@
 //   A  one lane per series, NS sections in sequence per sample (round 1)          : 9 NS fp64 instructions per sample
 //   B  NS lanes per series, one section each, the intermediate handed to the next lane by DPP row_shr:1 (round 2):
 //      9 fp64 + 2 DPP instructions per sample whatever NS
+//   C  as B with part of the wave masked off (EXEC): measures whether idle 16-lane groups are skipped
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/ubench/sos_rate.hip -o tools/ubench/bin/sos_rate
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -49,8 +50,9 @@ __global__ void __launch_bounds__(64) k_seq(double* out, int n, double seed) {
 }
 
 template <int LPS>
-__global__ void __launch_bounds__(64) k_lanes(double* out, int n, double seed) {
+__global__ void __launch_bounds__(64) k_lanes(double* out, int n, double seed, int active = 64) {
 #pragma clang fp contract(off)
+  if ((int)threadIdx.x >= active) return;  // C: does a partly filled wave run its fp64 passes faster?
   constexpr int BM = LPS == 2 ? 0xA : (LPS == 4 ? 0xE : 0xF);
   const int s = threadIdx.x % LPS;
   double c0 = seed * 0.01 * (1 + s), c1 = seed * 0.02 * (1 + s), c2 = seed * 0.03, c3 = seed * 0.04, c4 = seed * 0.05;
@@ -98,5 +100,7 @@ int main() {
   run([&](int w, int n) { k_lanes<1><<<w, 64>>>(d, n, 0.7); }, "B one lane per section", 1);
   run([&](int w, int n) { k_lanes<2><<<w, 64>>>(d, n, 0.7); }, "B one lane per section", 2);
   run([&](int w, int n) { k_lanes<4><<<w, 64>>>(d, n, 0.7); }, "B one lane per section", 4);
+  run([&](int w, int n) { k_lanes<2><<<w, 64>>>(d, n, 0.7, 32); }, "C as B, 32 of 64 lanes active", 2);
+  run([&](int w, int n) { k_lanes<2><<<w, 64>>>(d, n, 0.7, 16); }, "C as B, 16 of 64 lanes active", 2);
   return 0;
 }
