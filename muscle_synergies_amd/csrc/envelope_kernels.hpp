@@ -4,9 +4,14 @@
 // (np.sqrt(np.convolve(x**2, ones(W)/W, "same"))), time_normalize :551-594 (scipy interp1d, linear, on
 // linspace(0,1,T) -> linspace(0,1,n_out)), normalize :510-525 (divide by max |.| per column).
 //
-// One workgroup per (channel, recording).  The sliding-window mean is taken from an fp64 prefix sum of the
+// One series = one channel of one recording.  The sliding-window mean is taken from an fp64 prefix sum of the
 // squared (centred) samples, so every global access is coalesced and the window sum costs two loads per
 // output regardless of W; sums are accumulated in fp64 for both fp32 and fp64 I/O.
+// Kernels, in the order the launcher (hipnmf_envelope.hip) prefers them:
+//   emg_wg_kernel     8 waves per series, samples and outputs in registers (full-length output, T <= ~20 K)
+//   emg_wave_kernel   one wave per series, running prefix in an LDS ring, no barrier (any T, window <= 3584)
+//   emg_fused_kernel  round 1: one 256-thread workgroup per series, tile + halo scanned in LDS (no window, long windows)
+//   emg_prefix_kernel + emg_output_kernel   prefix array in HBM (windows that do not fit in LDS at all)
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -19,6 +24,10 @@ struct EnvArgs {
   double* chan_stat;   // workspace [B][m][2]: mean, max |out|
   void* out;           // [B][m][n_out]
   int T, m, window, zero_center, n_out, normalize;
+  // time normalisation table (env_resample_table_kernel -> emg_wave_kernel): per output q its left knot i0 and the
+  // weight (xn - x0) / (x1 - x0) -- they depend on (T, n_out) only, not on the data
+  const int* tab_i0;
+  const double* tab_w;
 };
 
 // per-thread part of a strided sum over x[0 .. T): four independent accumulators so that four loads are in flight
@@ -540,6 +549,56 @@ __device__ __forceinline__ real env_scaled(real y, double vmax, float vmf) {
   else return (real)((double)y / vmax);
 }
 
+// scipy interp1d(kind="linear") from the knots linspace(0,1,T) onto linspace(0,1,n_out), knots built as NumPy builds
+// them (i * step with the end point pinned to 1.0): left knot i0 = searchsorted(knots, xn, "left") - 1 clipped to
+// [0, T - 2].  One thread per output; the table serves every series of the call.
+__global__ void __launch_bounds__(256) env_resample_table_kernel(int T, int n_out, int* tab_i0, double* tab_w) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n_out) return;
+  const double step_out = (n_out > 1) ? 1.0 / (double)(n_out - 1) : 0.0;
+  const double step_in = 1.0 / (double)(T - 1);  // T >= 2
+  auto knot = [&](int i) { return (i == T - 1) ? 1.0 : (double)i * step_in; };
+  const double xn = (q == n_out - 1 && n_out > 1) ? 1.0 : (double)q * step_out;
+  int i0 = (int)floor(xn * (double)(T - 1));
+  if (i0 > T - 2) i0 = T - 2;
+  if (i0 < 0) i0 = 0;
+  while (i0 > 0 && knot(i0) >= xn) --i0;
+  while (i0 < T - 2 && knot(i0 + 1) < xn) ++i0;
+  tab_i0[q] = i0;
+  tab_w[q] = (xn - knot(i0)) / (knot(i0 + 1) - knot(i0));
+}
+
+// Output q belongs to the tile whose range [emitted, end) of left knots holds its i0; both neighbours' windows are in
+// the ring then.  y = y0 + (y1 - y0) w with w = (xn - x0) / (x1 - x0) from the table (scipy evaluates
+// (y1 - y0) / (x1 - x0) * (xn - x0) + y0: the same to an ulp of float64).  For fp32 outputs the two roots are taken in
+// fp32 like everywhere else in this file.  Returns false when q is another tile's.
+template <typename real, int SPL>
+__device__ __forceinline__ bool env_resample_one(const EnvWave<real, SPL>& wv, const EnvArgs& a, int q, int emitted, int end,
+                                                 double inv_w, double& y) {
+  const int i0 = a.tab_i0[q];
+  if (i0 < emitted || i0 >= end) return false;
+  const double s0 = wv.window_sum(i0), s1 = wv.window_sum(i0 + 1);
+  double y0, y1;
+  if constexpr (sizeof(real) == 4) {
+    const float inv_wf = (float)inv_w;
+    y0 = (double)__builtin_amdgcn_sqrtf(fmaxf((float)s0, 0.f) * inv_wf);
+    y1 = (double)__builtin_amdgcn_sqrtf(fmaxf((float)s1, 0.f) * inv_wf);
+  } else {
+    y0 = sqrt((s0 > 0.0 ? s0 : 0.0) * inv_w);
+    y1 = sqrt((s1 > 0.0 ? s1 : 0.0) * inv_w);
+  }
+  y = (y1 - y0) * a.tab_w[q] + y0;
+  return true;
+}
+// candidate outputs of the left knots [emitted, end): q_lo .. q_hi (a superset; env_resample_one decides)
+__device__ __forceinline__ void env_resample_range(int T, int n_out, int emitted, int end, int& q_lo, int& q_hi) {
+  const double step_in = 1.0 / (double)(T - 1), scale = (double)(n_out - 1);
+  q_lo = (int)floor((double)emitted * step_in * scale) - 1;
+  q_hi = (int)ceil((end == T - 1 ? 1.0 : (double)end * step_in) * scale) + 2;
+  if (q_lo < 0) q_lo = 0;
+  if (q_hi > n_out) q_hi = n_out;
+}
+
 template <typename real, int SPL>
 __global__ void __launch_bounds__(64) emg_wave_kernel(EnvArgs a, int ring /* power of two >= 64 SPL + window */) {
   extern __shared__ __attribute__((aligned(16))) unsigned char env_smem[];
@@ -591,9 +650,6 @@ __global__ void __launch_bounds__(64) emg_wave_kernel(EnvArgs a, int ring /* pow
   wv.set_mean(mean);
   const int hi = wv.hi;
   const bool resample = a.n_out > 0 && a.n_out != T;
-  const double step_out = (n_out > 1) ? 1.0 / (double)(n_out - 1) : 0.0;
-  const double step_in = 1.0 / (double)(T - 1);  // T >= 2 (the launcher routes T == 1 to emg_fused_kernel)
-  auto knot = [&](int i) { return (i == T - 1) ? 1.0 : (double)i * step_in; };  // np.linspace(0, 1, T)[i]
   const double inv_w = 1.0 / (double)W;  // np.convolve(x^2, ones(W) / W): products by 1/W, no division
   const float inv_wf = (float)inv_w;
   auto value = [&](int i) -> double {
@@ -645,26 +701,14 @@ __global__ void __launch_bounds__(64) emg_wave_kernel(EnvArgs a, int ring /* pow
       }
       if (end > emitted) emitted = end;
     } else {
-      // scipy interp1d(kind="linear") from linspace(0,1,T) onto linspace(0,1,n_out): output q is produced by the
-      // tile whose range [emitted, end) holds its left knot i0 (both neighbours' windows are in the ring then)
       int end = avail - hi - 2;
       if (end > T - 1) end = T - 1;
       if (end > emitted) {
-        const double scale = (double)(n_out - 1);
-        int q_lo = (int)floor(knot(emitted) * scale) - 1, q_hi = (int)ceil(knot(end) * scale) + 2;
-        if (q_lo < 0) q_lo = 0;
-        if (q_hi > n_out) q_hi = n_out;
+        int q_lo, q_hi;
+        env_resample_range(T, n_out, emitted, end, q_lo, q_hi);
         for (int q = q_lo + lane; q < q_hi; q += 64) {
-          const double xn = (q == n_out - 1 && n_out > 1) ? 1.0 : (double)q * step_out;
-          int i0 = (int)floor(xn * (double)(T - 1));
-          if (i0 > T - 2) i0 = T - 2;
-          if (i0 < 0) i0 = 0;
-          while (i0 > 0 && knot(i0) >= xn) --i0;  // searchsorted(side="left") - 1, clipped to >= 0
-          while (i0 < T - 2 && knot(i0 + 1) < xn) ++i0;
-          if (i0 < emitted || i0 >= end) continue;
-          const double x0 = knot(i0), x1 = knot(i0 + 1);
-          const double y0 = value(i0), y1 = value(i0 + 1);
-          const double y = (y1 - y0) / (x1 - x0) * (xn - x0) + y0;
+          double y;
+          if (!env_resample_one(wv, a, q, emitted, end, inv_w, y)) continue;
           o[q] = (real)y;
           vmax = fmax(vmax, fabs(y));
         }
@@ -709,6 +753,8 @@ __global__ void __launch_bounds__(64) emg_wave_kernel(EnvArgs a, int ring /* pow
 
 // =================================================================================================
 // Workgroup-per-series version for the full-length output (no time normalisation) of series of up to ~20 K samples.
+// (Time-normalised outputs stay with emg_wave_kernel: measured, the interpolation step per 256-sample tile costs this
+// kernel more than the second read of the samples costs that one: 0.76 vs 0.56 ms.)
 // emg_wave_kernel is bound by memory traffic there (measured 5.1 TB/s): raw read twice (mean, tiles), output written,
 // read back and written again once the channel maximum is known = 5 sizeof(real) per sample.  Here the NW waves of a
 // workgroup split the series into NW segments (each re-runs the prefix over the W samples before its segment) and
@@ -741,11 +787,13 @@ __global__ void __launch_bounds__(64 * ENV_WG_WAVES) emg_wg_kernel(EnvArgs a, in
   const int seg_len = ((T + NW - 1) / NW + TILE - 1) / TILE * TILE;
   const int seg_b = wave * seg_len;
   const int seg_e = (seg_b + seg_len < T) ? seg_b + seg_len : T;
+  const int seg_end = seg_e;
+  const int lag = (W - 1) / 2 + 1;  // output i needs the prefix up to i + lag
   int first = seg_b - (W + TILE - 1) / TILE * TILE;
   if (first < 0) first = 0;
   Wv wv;
   wv.init(x, rings + (size_t)wave * ring_entries, ring, T, W, 0.0, lane, first);
-  int nt = (seg_b < T) ? (seg_e + wv.hi + 1 - first + TILE - 1) / TILE : 0;
+  int nt = (seg_b < seg_end) ? (seg_end + lag - first + TILE - 1) / TILE : 0;
   if (nt > MAXT) nt = MAXT;
   real xs[MAXT][SPL];  // samples, then (tile by tile, as they are consumed) outputs
 #pragma unroll
@@ -769,15 +817,14 @@ __global__ void __launch_bounds__(64 * ENV_WG_WAVES) emg_wg_kernel(EnvArgs a, in
   float vmaxf = 0.f;
   int eb[MAXT], ee[MAXT];  // outputs eb[k] .. ee[k] were produced after tile k: output eb[k] + lane + 64 u sits in xs[k][u]
   int emitted = seg_b;
-  const int hi = wv.hi;
 #pragma unroll
   for (int k = 0; k < MAXT; ++k) {
     eb[k] = ee[k] = 0;
     if (k < nt) {
       const int t0 = first + k * TILE;
       wv.tile_core(t0, xs[k], []() {});
-      int end = t0 + TILE - hi - 1;
-      if (end > seg_e) end = seg_e;
+      int end = t0 + TILE - lag;
+      if (end > seg_end) end = seg_end;
       if (end > emitted) {
         double sd[SPL];
         if (end - emitted == TILE && emitted >= wv.lo) {

@@ -76,6 +76,9 @@ int envelope_impl(hipnmf_handle* h, const hipnmf_envelope_params* p, const real*
   const bool wg = wave && wg_ok && (p->n_out == 0 || p->n_out == T) && WG_TILE + p->window <= ring4 && ring4 <= 4096 &&
                   T >= 2LL * ENV_WG_WAVES * WG_TILE && wg_tiles <= ENV_WG_MAXT(real);
   const bool fused = wave || (fused_ok && fused_lds <= 96 * 1024);
+  const bool resample_tab = wave && p->n_out > 0 && p->n_out != T;
+  const size_t o_ti = resample_tab ? carve(sizeof(int) * (size_t)p->n_out) : 0;
+  const size_t o_tw = resample_tab ? carve(sizeof(double) * (size_t)p->n_out) : 0;
   const size_t o_ps = fused ? 0 : carve(sizeof(double) * (size_t)B * m * (T + 1));
   const size_t o_st = fused ? 0 : carve(sizeof(double) * (size_t)B * m * 2);
   int rc = hipnmf_ensure_ws(h, std::max<size_t>(off, 256));
@@ -100,6 +103,8 @@ int envelope_impl(hipnmf_handle* h, const hipnmf_envelope_params* p, const real*
   a.prefix = reinterpret_cast<double*>(ws + o_ps);
   a.chan_stat = reinterpret_cast<double*>(ws + o_st);
   a.out = out;
+  a.tab_i0 = reinterpret_cast<const int*>(ws + o_ti);
+  a.tab_w = reinterpret_cast<const double*>(ws + o_tw);
   a.T = (int)T;
   a.m = m;
   a.window = p->window;
@@ -108,6 +113,9 @@ int envelope_impl(hipnmf_handle* h, const hipnmf_envelope_params* p, const real*
   a.normalize = p->normalize ? 1 : 0;
   const bool async = h->async_mode != 0;
   if (!async) HIP_TRY(hipEventRecord(h->ev0, st));
+  if (resample_tab)
+    hipLaunchKernelGGL(env_resample_table_kernel, dim3((unsigned)((p->n_out + 255) / 256)), dim3(256), 0, st, (int)T, (int)p->n_out,
+                       reinterpret_cast<int*>(ws + o_ti), reinterpret_cast<double*>(ws + o_tw));
   if (wg) {
     if (wg_lds > 48 * 1024)
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(emg_wg_kernel<real>),

@@ -112,6 +112,9 @@ _KERNEL_CASES = [
     (20000, 2, 200, None, True, True, np.float32),    # workgroup kernel, fp32 (the benchmark shape)
     (20480, 1, 256, None, False, True, np.float32),   # workgroup kernel at its register limit, not normalised
     (4096, 2, 50, None, True, True, np.float32),      # workgroup kernel, shortest series it takes
+    (20000, 2, 200, 200, True, True, np.float32),     # wave kernel, time-normalised (the tutorial's chain)
+    (8000, 3, 201, 150, True, True, np.float64),      # wave kernel, time-normalised, fp64
+    (8192, 2, 100, 2000, False, True, np.float64),    # wave kernel, dense time normalisation
     (9000, 3, 200, None, False, True, np.float64),    # wave kernel, full length (fp64 series too long for the registers)
     (70001, 2, 150, None, True, True, np.float64),    # wave kernel, prefix re-based past 65 536 samples
     (70000, 2, 150, 1000, True, True, np.float64),    # wave kernel, time-normalised, re-based
