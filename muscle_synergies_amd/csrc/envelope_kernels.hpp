@@ -386,16 +386,18 @@ __global__ void __launch_bounds__(256) emg_fused_kernel(EnvArgs a) {
 //   * a lane owns SPL CONSECUTIVE samples of a 64 SPL tile: the prefix over its samples is SPL register adds, the
 //     prefix over the lanes six DPP steps, nothing of the scan goes through LDS and there is no barrier at all
 //     (a single wave executes its LDS operations in order);
-//   * the prefix is a RUNNING one (carried from tile to tile), so no halo is recomputed; the last `ring` >= tile + W
+//   * the prefix is a RUNNING one (carried from tile to tile), so no halo is recomputed; the last `ring` > tile + W
 //     prefix values live in an LDS ring (8 values per 9 slots: conflict-free for the blocked writes and for the
-//     consecutive reads); every ENV_REBASE samples the carry is subtracted from the W live entries (exact by
-//     Sterbenz' lemma) and reset, which bounds the relative error of a window sum at eps * ENV_REBASE;
+//     consecutive reads); every ENV_REBASE samples the carry is subtracted from the W + 1 live entries (exact by
+//     Sterbenz' lemma) and reset, so a window sum carries an absolute error of at most ~eps times the sum of
+//     ENV_REBASE + W squared samples (round 1's tiles: 2048 + W) -- invisible for real windows, but the root
+//     amplifies it for windows of a few samples whose mean square is orders of magnitude below the signal's;
 //   * outputs trail the inputs by (W - 1) / 2 + 1 samples and are produced 64 consecutive ones per instruction
 //     (coalesced stores), each from two LDS reads.
 // Same semantics as emg_fused_kernel (np.convolve "same" alignment, zero padding, NumPy's linspace knots, scipy's
 // linear interp1d, division by the channel maximum); the summation order differs, results agree to ~1e-13 relative.
 // =================================================================================================
-constexpr int ENV_REBASE = 1 << 16;
+constexpr int ENV_REBASE = 1 << 12;  // a multiple of every tile size
 
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double env_dpp_pull(double v) {  // lanes without a source, or in rows masked off, get 0
@@ -479,8 +481,9 @@ struct EnvWave {
   template <typename F>
   __device__ __forceinline__ void tile_core(int t0, const real (&v)[SPL], F after_consume) {
     if (t0 > first && (t0 & (ENV_REBASE - 1)) == 0) {
-      // re-base the running prefix: the live entries are P[t0 - W .. t0 - 1]
-      for (int e = 1 + lane; e <= W; e += 64) {
+      // re-base the running prefix: the live entries are P[t0 - W - 1 .. t0 - 1] (the time normalisation reads the
+      // windows of two neighbouring samples, hence one entry more than W)
+      for (int e = 1 + lane; e <= W + 1; e += 64) {
         const int j = t0 - e;
         if (j >= first) P[slot(j)] -= carry;
       }
@@ -600,7 +603,7 @@ __device__ __forceinline__ void env_resample_range(int T, int n_out, int emitted
 }
 
 template <typename real, int SPL>
-__global__ void __launch_bounds__(64) emg_wave_kernel(EnvArgs a, int ring /* power of two >= 64 SPL + window */) {
+__global__ void __launch_bounds__(64) emg_wave_kernel(EnvArgs a, int ring /* power of two > 64 SPL + window */) {
   extern __shared__ __attribute__((aligned(16))) unsigned char env_smem[];
   using Wv = EnvWave<real, SPL>;
   using Vec = typename Wv::Vec;

@@ -57,8 +57,8 @@ int envelope_impl(hipnmf_handle* h, const hipnmf_envelope_params* p, const real*
     return (e && atoi(e) == 4) ? 4 : 8;
   }();
   int ring = 512;
-  while (ring < 64 * wave_spl + p->window && ring < 8192) ring *= 2;
-  const bool wave = wave_ok && p->window >= 1 && T >= 2 && ring <= 4096 && 64 * wave_spl + p->window <= ring;
+  while (ring < 64 * wave_spl + p->window + 1 && ring < 8192) ring *= 2;  // tile + window + 1 live prefix values
+  const bool wave = wave_ok && p->window >= 1 && T >= 2 && ring <= 4096 && 64 * wave_spl + p->window + 1 <= ring;
   // full-length output of a series short enough for the registers of one workgroup (emg_wg_kernel: samples and
   // outputs stay on chip, 2 instead of up to 5 sizeof(real) of traffic per sample); HIPNMF_ENV_WG=0 leaves those to
   // emg_wave_kernel
@@ -68,12 +68,12 @@ int envelope_impl(hipnmf_handle* h, const hipnmf_envelope_params* p, const real*
   }();
   constexpr int WG_TILE = 64 * ENV_WG_SPL;
   int ring4 = 512;
-  while (ring4 < WG_TILE + p->window && ring4 < 8192) ring4 *= 2;
+  while (ring4 < WG_TILE + p->window + 1 && ring4 < 8192) ring4 *= 2;
   const size_t wg_lds = sizeof(double) * ((size_t)ENV_WG_WAVES * (ring4 + ring4 / 8) + ENV_WG_WAVES);
   // tiles a wave walks: those before its segment (first window), its segment, those behind it (last window)
   const long long wg_seg = ((T + ENV_WG_WAVES - 1) / ENV_WG_WAVES + WG_TILE - 1) / WG_TILE;
   const long long wg_tiles = (p->window + WG_TILE - 1) / WG_TILE + wg_seg + ((p->window - 1) / 2 + 1 + WG_TILE - 1) / WG_TILE;
-  const bool wg = wave && wg_ok && (p->n_out == 0 || p->n_out == T) && WG_TILE + p->window <= ring4 && ring4 <= 4096 &&
+  const bool wg = wave && wg_ok && (p->n_out == 0 || p->n_out == T) && WG_TILE + p->window + 1 <= ring4 && ring4 <= 4096 &&
                   T >= 2LL * ENV_WG_WAVES * WG_TILE && wg_tiles <= ENV_WG_MAXT(real);
   const bool fused = wave || (fused_ok && fused_lds <= 96 * 1024);
   const bool resample_tab = wave && p->n_out > 0 && p->n_out != T;

@@ -120,6 +120,8 @@ _KERNEL_CASES = [
     (70000, 2, 150, 1000, True, True, np.float64),    # wave kernel, time-normalised, re-based
     (70000, 1, 150, None, True, True, np.float32),    # wave kernel fp32 (too long for the workgroup kernel)
     (1000, 3, 37, 2500, True, True, np.float64),      # up-sampling
+    (1023, 2, 511, 3070, True, True, np.float32),     # ring exactly tile + window + 1 with both neighbours' windows live
+    (8200, 2, 257, 9000, True, True, np.float64),     # time-normalised across a re-basing of the prefix (every 4096 samples)
     (513, 2, 500, None, True, True, np.float64),      # window almost as long as the series
     (300, 2, 1, 50, False, False, np.float64),        # window of one sample
     (5000, 2, 3000, None, True, True, np.float64),    # largest ring
@@ -149,3 +151,19 @@ def test_gpu_envelope_kernels_match_oracle(case, layout):
             np.testing.assert_allclose(out[b], ref, rtol=3e-5, atol=3e-6 * np.abs(ref).max())
         else:
             np.testing.assert_allclose(out[b], ref, rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.gpu
+def test_gpu_envelope_fuzz():
+    """tests/fuzz_envelope_gpu.py with a fixed seed: 150 random shapes / windows / options against the oracle."""
+    import os
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz_envelope_gpu.py"), "--cases", "150", "--seed", "3"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "0 problems" in r.stdout
+
