@@ -57,7 +57,9 @@ for case in range(a.cases):
         if dtype == np.float32:
             ok = np.allclose(out[b], ref, rtol=3e-5, atol=3e-6 * scale + 1e-30, equal_nan=True)
         else:
-            ok = np.allclose(out[b], ref, rtol=1e-9, atol=(1e-12 + 2e-9 / max(W, 1)) * max(scale, 1e-300), equal_nan=True)
+            # W <= 8: single samples next to a zero crossing are ~1e-6 of the signal's power; sqrt(eps * 4096) ~ 1e-6
+            atol = 1e-6 if 0 < W <= 8 else 1e-12 + 2e-9 / max(W, 1)
+            ok = np.allclose(out[b], ref, rtol=1e-9, atol=atol * max(scale, 1e-300), equal_nan=True)
         if not ok or out[b].shape != ref.shape:
             err = np.nanmax(np.abs(out[b] - ref)) if out[b].shape == ref.shape else float("nan")
             print("MISMATCH", desc, f"b={b} max|diff|={err:.3e} scale={scale:.3e} shapes {out[b].shape} {ref.shape}")
