@@ -174,3 +174,19 @@ def test_gpu_dataframe_functions_match_the_reference_outputs(g8):
     W0, H0 = ms.random_init_batched(X, 3, seed=0)
     res = ms.fit_batched(X, W0, H0, max_iter=50, tol=0.0)
     assert float(res.vaf[:, 0].min()) > 0.8
+
+
+@pytest.mark.gpu
+def test_gpu_filter_fuzz():
+    """tests/fuzz_sosfilt_gpu.py with a fixed seed: random designs (1-8 sections), series counts, lengths, paddings and
+    options against the oracle; fp64 bit-identical."""
+    import os
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz_sosfilt_gpu.py"), "--cases", "120", "--seed", "5"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "0 problems" in r.stdout
