@@ -31,23 +31,36 @@ for case in range(a.cases):
     iters = int(rng.choice([1, 7, 30]))
     if tol > 0:
         iters = 60
-    Xs = [emg_matrix(1000 * case + b, T=T, m=m, k_true=min(5, m), dtype=dtype) for b in range(B)]
+    # a quarter of the cases: trials of unequal length through the ragged entry point (paths 1: variants 0, 1, 4, 5, 6)
+    ragged = rng.random() < 0.25 and variant not in (2, 3) and loss == "frobenius"
+    Ts = [T] * B
+    if ragged:
+        B = int(rng.choice([2, 3, 5]))
+        Ts = [max(1, int(T * rng.uniform(0.3, 1.0))) for _ in range(B)]
+    Xs = [emg_matrix(1000 * case + b, T=Ts[b], m=m, k_true=min(5, m), dtype=dtype) for b in range(B)]
     inits = [random_init(x, k, seed=case + b) for b, x in enumerate(Xs)]
-    Xb = np.stack([np.asarray(x, order=order) for x in Xs])
-    if order == "F":
+    Xb = None if ragged else np.stack([np.asarray(x, order=order) for x in Xs])
+    if order == "F" and not ragged:
         Xb = np.stack([np.asfortranarray(x) for x in Xs])  # np.stack makes it C again: pass a transposed view instead
         Xb = np.ascontiguousarray(np.stack(Xs).transpose(0, 2, 1)).transpose(0, 2, 1)
-    W0, H0 = np.stack([w for w, _ in inits]), np.stack([hh for _, hh in inits])
-    desc = f"case {case}: {np.dtype(dtype).name} B={B} T={T} m={m} k={k} order={order} variant={variant} loss={loss} tol={tol} upH={update_H} reg={reg != (0.0,)*4} it={iters}"
+    if ragged:
+        W0, H0 = [w for w, _ in inits], [hh for _, hh in inits]
+    else:
+        W0, H0 = np.stack([w for w, _ in inits]), np.stack([hh for _, hh in inits])
+    desc = f"case {case}: {'ragged T=' + str(Ts) + ' ' if ragged else ''} {np.dtype(dtype).name} B={B} T={T} m={m} k={k} order={order} variant={variant} loss={loss} tol={tol} upH={update_H} reg={reg != (0.0,)*4} it={iters}"
     h.set_tuning(0, 0, variant)
     try:
-        got = ms.fit_batched(Xb, W0, H0, max_iter=iters, tol=tol, update_H=update_H, beta_loss=loss,
-                             l1_reg_W=reg[0], l1_reg_H=reg[1], l2_reg_W=reg[2], l2_reg_H=reg[3])
+        if ragged:
+            got = ms.fit_ragged([np.asarray(x, order=order) for x in Xs], W0, H0, max_iter=iters, tol=tol, update_H=update_H,
+                                beta_loss=loss, l1_reg_W=reg[0], l1_reg_H=reg[1], l2_reg_W=reg[2], l2_reg_H=reg[3])
+        else:
+            got = ms.fit_batched(Xb, W0, H0, max_iter=iters, tol=tol, update_H=update_H, beta_loss=loss,
+                                 l1_reg_W=reg[0], l1_reg_H=reg[1], l2_reg_W=reg[2], l2_reg_H=reg[3])
     except _lib.HipNmfError as e:
         if variant == 3 and "not applicable" in str(e):
             continue
         if variant == 6 and ("fit_small_kernel" in str(e)):  # n_samples <= 256, Frobenius, m <= 16 (fp32) / 8 (fp64, k <= 6)
-            assert not (T <= 256 and loss == "frobenius" and m <= (16 if dtype == np.float32 else 8)
+            assert not (max(Ts) <= 256 and loss == "frobenius" and m <= (16 if dtype == np.float32 else 8)
                         and not (dtype == np.float64 and k > 6)), desc
             continue
         if variant == 5 and ("fit_rowlane_kernel" in str(e)):  # fp32, 9..16 channels, Frobenius only
@@ -58,6 +71,8 @@ for case in range(a.cases):
         continue
     finally:
         h.set_tuning(0, 0, 0)
+    tonp = lambda v: v.cpu().numpy() if hasattr(v, "cpu") else np.asarray(v)  # fit_ragged hands back device tensors
+    g_iter, g_err = tonp(got.n_iter), tonp(got.reconstruction_err)
     for b in range(B):
         X = Xs[b]
         if loss == "frobenius":
@@ -69,12 +84,13 @@ for case in range(a.cases):
             W, H, n_it = orc.fit_multiplicative_update_kl(X, W0[b].copy(), H0[b].copy(), iters, tol, reg[0], reg[1], reg[2], reg[3],
                                                           update_H=update_H)
         xn = max(np.linalg.norm(X.astype(np.float64)), 1e-30)
-        d = np.linalg.norm(got.W[b].astype(np.float64) @ got.H[b].astype(np.float64) - W.astype(np.float64) @ H.astype(np.float64)) / xn
+        gW, gH = tonp(got.W[b]), tonp(got.H[b])
+        d = np.linalg.norm(gW.astype(np.float64) @ gH.astype(np.float64) - W.astype(np.float64) @ H.astype(np.float64)) / xn
         lim = 2e-5 if dtype == np.float32 else 1e-9
-        it_ok = int(got.n_iter[b]) == n_it or (tol > 0 and dtype == np.float32 and abs(int(got.n_iter[b]) - n_it) <= 10)
-        if not (d <= lim) or not it_ok or not np.isfinite(got.reconstruction_err[b]):
+        it_ok = int(g_iter[b]) == n_it or (tol > 0 and dtype == np.float32 and abs(int(g_iter[b]) - n_it) <= 10)
+        if not (d <= lim) or not it_ok or not np.isfinite(g_err[b]):
             if it_ok or tol == 0:
-                print("MISMATCH", desc, f"b={b} rel dWH={d:.3e} n_iter {int(got.n_iter[b])} vs {n_it}")
+                print("MISMATCH", desc, f"b={b} rel dWH={d:.3e} n_iter {int(g_iter[b])} vs {n_it}")
                 bad += 1
 print(f"fuzz: {a.cases} cases, {bad} problems")
 sys.exit(1 if bad else 0)
