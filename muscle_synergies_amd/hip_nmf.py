@@ -17,7 +17,7 @@ import warnings
 
 import numpy as np
 
-from . import engine
+from . import _lib, engine
 from .init import initialize_nmf
 
 
@@ -184,9 +184,14 @@ class HipNMF:
                               RuntimeWarning)
             W0, H0 = initialize_nmf(X, k, init=self.init, random_state=self.random_state)
         l1w, l1h, l2w, l2h = self._regularization(T, m)
-        res = engine.fit_batched(X, W0, H0, max_iter=self.max_iter, tol=self.tol, l1_reg_W=l1w, l1_reg_H=l1h,
-                                 l2_reg_W=l2w, l2_reg_H=l2h, beta_loss=self.beta_loss, device=self.device,
-                                 return_numpy=True)
+        try:
+            res = engine.fit_batched(X, W0, H0, max_iter=self.max_iter, tol=self.tol, l1_reg_W=l1w, l1_reg_H=l1h,
+                                     l2_reg_W=l2w, l2_reg_H=l2h, beta_loss=self.beta_loss, device=self.device,
+                                     return_numpy=True)
+        except _lib.HipNmfError as e:
+            if e.code != _lib.HIPNMF_ERR_UNSUPPORTED:
+                raise
+            return self._fit_transform_sklearn(X, W0, H0, columns, str(e))
         n_iter = int(res.n_iter[0])
         if n_iter == self.max_iter and self.tol > 0:
             warnings.warn("Maximum number of iterations %d reached. Increase it to improve convergence." % self.max_iter,
@@ -201,6 +206,28 @@ class HipNMF:
         self.vaf_ = res.vaf[0]
         self.kernel_ms_ = res.kernel_ms
         return res.W[0]
+
+    def _fit_transform_sklearn(self, X, W0, H0, columns, why):
+        """A configuration the library refuses (``HIPNMF_ERR_UNSUPPORTED``) runs on scikit-learn's own mu solver from
+        the same starting point, as every other unsupported configuration of the reference's call does -- loudly."""
+        from sklearn.decomposition import NMF
+
+        warnings.warn(f"{why}; running scikit-learn on the CPU instead", RuntimeWarning, stacklevel=3)
+        model = NMF(n_components=W0.shape[1], init="custom", solver="mu", beta_loss=self.beta_loss, tol=self.tol,
+                    max_iter=self.max_iter, alpha_W=self.alpha_W, alpha_H=self.alpha_H, l1_ratio=self.l1_ratio)
+        W = model.fit_transform(X, W=np.array(W0, dtype=X.dtype, order="C"), H=np.array(H0, dtype=X.dtype, order="C"))
+        self.reconstruction_err_ = model.reconstruction_err_
+        self.n_components_ = model.n_components_
+        self.components_ = model.components_
+        self.n_iter_ = model.n_iter_
+        self.n_features_in_ = X.shape[1]
+        if columns is not None:
+            self.feature_names_in_ = np.asarray(columns, dtype=object)
+        sse = ((X - W @ model.components_) ** 2).sum(axis=0)
+        xsq = (X ** 2).sum(axis=0)
+        self.vaf_ = np.concatenate([[1.0 - sse.sum() / xsq.sum()], 1.0 - sse / xsq])
+        self.kernel_ms_ = None
+        return W
 
     def fit(self, X, y=None, **params):
         self.fit_transform(X, **params)

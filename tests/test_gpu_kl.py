@@ -176,3 +176,32 @@ def test_kl_ragged_trials_and_rank_sweep():
     sw = ms.rank_sweep_batched(Xb, 2, 5, max_iter=100, tol=0.0, beta_loss="kullback-leibler")
     assert tuple(sw.vaf_all.shape) == (5, 4) and bool(torch.isfinite(sw.vaf_all).all())
     assert bool((sw.vaf_all[:, 1:] >= sw.vaf_all[:, :-1] - 1e-2).all())
+
+
+def test_kl_float64_wide_with_stop_rule_is_refused_loudly_and_runs_on_sklearn():
+    """fit_persistent_kernel<double,4,8,K,KL> with tol > 0 does not terminate on gfx950 (found by tests/fuzz_gpu.py,
+    tools/repro/case69.py): the library refuses the combination, the estimator runs scikit-learn with a warning; with
+    tol = 0 the same instance is fine."""
+    import warnings
+
+    import muscle_synergies_amd as ms
+    from muscle_synergies_amd import _lib
+    from muscle_synergies_amd.synth import emg_matrix, random_init
+
+    X = emg_matrix(4242, T=300, m=24, k_true=5, dtype=np.float64)
+    W0, H0 = random_init(X, 4, seed=1)
+    with pytest.raises(_lib.HipNmfError, match="tol > 0 is not available") as ei:
+        ms.fit_batched(X[None], W0[None], H0[None], max_iter=40, tol=1e-4, beta_loss="kullback-leibler")
+    assert ei.value.code == _lib.HIPNMF_ERR_UNSUPPORTED
+    fixed = ms.fit_batched(X[None], W0[None], H0[None], max_iter=40, tol=0.0, beta_loss="kullback-leibler")
+    Wo, Ho, _ = orc.fit_multiplicative_update_kl(X, W0.copy(), H0.copy(), 40, 0.0)
+    np.testing.assert_allclose(np.asarray(fixed.W[0]) @ np.asarray(fixed.H[0]), Wo @ Ho, rtol=1e-9, atol=1e-12)
+    model = ms.HipNMF(n_components=4, init="custom", solver="mu", beta_loss="kullback-leibler", tol=1e-4, max_iter=300)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        W = model.fit_transform(X, W=W0.copy(), H=H0.copy())
+    assert any("running scikit-learn on the CPU instead" in str(w.message) for w in rec)
+    Ws, Hs, n_it = orc.fit_multiplicative_update_kl(X, W0.copy(), H0.copy(), 300, 1e-4)
+    assert model.n_iter_ == n_it
+    np.testing.assert_allclose(W @ model.components_, Ws @ Hs, rtol=1e-8, atol=1e-11)
+    assert model.vaf_.shape == (25,)
