@@ -426,3 +426,18 @@ def test_ragged_entry_point_ignores_ldx_and_checks_reserved_fields():
     x = torch.zeros(400, dtype=torch.float32, device="cuda")
     rc = lib.hipnmf_sosfilt_f32(h.ptr, ctypes.byref(sp), sos, None, ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(x.data_ptr()))
     assert rc == _lib.HIPNMF_ERR_BAD_ARG and b"reserved0" in lib.hipnmf_last_error()
+
+
+@pytest.mark.gpu
+def test_shard_fuzz():
+    """tests/fuzz_shard_gpu.py with a fixed seed: one matrix cut into 1-4 shards of arbitrary lengths, both constructors,
+    every channel mapping of the shard kernels, against the oracle."""
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz_shard_gpu.py"), "--cases", "80", "--seed", "4"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "0 problems" in r.stdout
