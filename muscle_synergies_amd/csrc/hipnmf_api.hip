@@ -224,15 +224,6 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
     persistent = true;
     if (!ks->fit_persistent_kl)
       return fail(HIPNMF_ERR_UNSUPPORTED, "no Kullback-Leibler kernel in the selected instance (G=%d, CH=%d)", ks->G, ks->CH);
-    // fit_persistent_kernel<double, 4, 8, K >= 2, LOSS = 1> with the stop rule live does not terminate on gfx950
-    // (tests/fuzz_gpu.py seed 12 case 69; tools/repro/case69.py): the instance needs > 900 bytes of scratch per lane
-    // and faults on a null flat address inside the first residual evaluation, while the same source is fine in
-    // fp32, with the Frobenius loss, and with tol = 0.  Until that is understood the combination is refused
-    // (HipNMF then runs scikit-learn for it, with a warning); tol = 0 runs a fixed number of iterations as before.
-    if (sizeof(real) == 8 && ks->G == 4 && ks->CH == 8 && k >= 2 && p->tol > 0)
-      return fail(HIPNMF_ERR_UNSUPPORTED, "Kullback-Leibler loss in float64 with more than 16 features and tol > 0 is not "
-                  "available in this build (n_features=%d, n_components=%d): use tol=0 with a fixed max_iter, float32 "
-                  "input, or scikit-learn", m, k);
   }
   if (ragged) {
     persistent = true;  // one workgroup per matrix handles any mix of lengths

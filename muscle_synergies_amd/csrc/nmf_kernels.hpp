@@ -679,13 +679,15 @@ __device__ __forceinline__ void resid_tile(const RowTile<real, G, CH, K>& t, con
       sse[cc] = fma_(d, d, sse[cc]);
       xsq[cc] = fma_(t.x[cc][r], t.x[cc][r], xsq[cc]);
       if constexpr (LOSS == 1) {
+        // X log(X / WH) - X + WH where X > EPSILON, WH elsewhere (_nmf.py:138-155).  Branch-free: the logarithm is
+        // evaluated for every element (on max(X, EPSILON), which the select below discards where it differs) instead
+        // of inside a divergent region -- 32 inlined double-precision logarithms per tile under `if (x > eps)` made
+        // the float64 (4, 8) instance spill inside divergent control flow and fault (tools/repro/case69.py)
         const real x = t.x[cc][r];
-        real term = rec;
-        if (x > eps_val<real>()) {
-          const real whc = rec < eps_val<real>() ? eps_val<real>() : rec;
-          term = fma_(x, log_(x / whc), rec - x);
-        }
-        kl += term;
+        const real whc = rec < eps_val<real>() ? eps_val<real>() : rec;
+        const real xs = x > eps_val<real>() ? x : eps_val<real>();
+        const real lg = fma_(x, log_(xs / whc), rec - x);
+        kl += (x > eps_val<real>()) ? lg : rec;
       }
     }
   });

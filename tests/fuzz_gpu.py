@@ -66,9 +66,6 @@ for case in range(a.cases):
             assert not (max(Ts) <= 256 and loss == "frobenius" and m <= (16 if dtype == np.float32 else 8)
                         and not (dtype == np.float64 and k > 6)), desc
             continue
-        if "tol > 0 is not available in this build" in str(e):  # float64 KL with > 16 features and the stop rule live
-            assert dtype == np.float64 and loss == "kullback-leibler" and m > 16 and k >= 2 and tol > 0, desc
-            continue
         if variant == 5 and ("fit_rowlane_kernel" in str(e)):  # fp32, 9..16 channels, Frobenius only
             assert not (dtype == np.float32 and 8 < m <= 16 and loss == "frobenius"), desc
             continue
@@ -94,6 +91,8 @@ for case in range(a.cases):
         d = np.linalg.norm(gW.astype(np.float64) @ gH.astype(np.float64) - W.astype(np.float64) @ H.astype(np.float64)) / xn
         lim = 2e-5 if dtype == np.float32 else 1e-9
         it_ok = int(g_iter[b]) == n_it or (tol > 0 and dtype == np.float32 and abs(int(g_iter[b]) - n_it) <= 10)
+        if tol > 0 and dtype == np.float32 and it_ok and int(g_iter[b]) != n_it:
+            continue  # the stop rule fired one check earlier / later in float32: W H is that of another iteration count
         if not (d <= lim) or not it_ok or not np.isfinite(g_err[b]):
             if it_ok or tol == 0:
                 print("MISMATCH", desc, f"b={b} rel dWH={d:.3e} n_iter {int(g_iter[b])} vs {n_it}")
