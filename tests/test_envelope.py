@@ -163,7 +163,7 @@ def test_gpu_envelope_fuzz():
     from conftest import ROOT
 
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz_envelope_gpu.py"), "--cases", "150", "--seed", "3"],
-                       capture_output=True, text=True, timeout=900)
+                       capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "0 problems" in r.stdout
 

@@ -187,6 +187,6 @@ def test_gpu_filter_fuzz():
     from conftest import ROOT
 
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz_sosfilt_gpu.py"), "--cases", "120", "--seed", "5"],
-                       capture_output=True, text=True, timeout=900)
+                       capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "0 problems" in r.stdout
