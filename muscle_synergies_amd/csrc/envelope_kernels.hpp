@@ -433,7 +433,6 @@ struct EnvWave {
   int T, W, lo, hi, mask, lane, first;  // first: the tile the walk started at (no prefix values exist before it)
   bool vec_ok;
   double mean, carry;
-  real pf[SPL];
 
   __device__ __forceinline__ void init(const real* x_, double* P_, int ring, int T_, int W_, double mean_, int lane_, int first_) {
     x = x_;
@@ -448,9 +447,8 @@ struct EnvWave {
     vec_ok = (reinterpret_cast<unsigned long long>(x_) & 15ull) == 0;
     mean = mean_;
     carry = 0.0;
-    issue(first_);
   }
-  __device__ __forceinline__ void set_mean(double mean_) { mean = mean_; }  // may follow init: the first request does not need it
+  __device__ __forceinline__ void set_mean(double mean_) { mean = mean_; }  // may follow init and the first loads: they do not need it
   __device__ __forceinline__ int slot(int j) const {
     const int s_ = j & mask;
     return s_ + (s_ >> 3);
@@ -469,13 +467,6 @@ struct EnvWave {
 #pragma unroll
       for (int c = 0; c < SPL; ++c) v[c] = (j0 + c < T) ? x[j0 + c] : (real)0;
     }
-  }
-  __device__ __forceinline__ void issue(int t0) { load(t0, pf); }
-  // streaming walk: the tile at t0 from the prefetch registers, the next tile requested as soon as they are free
-  __device__ __forceinline__ void tile(int t0) {
-    tile_core(t0, pf, [&]() __attribute__((always_inline)) {
-      if (t0 + TILE < T) issue(t0 + TILE);  // its latency hides behind the scan and the outputs
-    });
   }
   // prefix values of the tile at t0 (samples v) into the ring; afterwards P[j] is available for j < t0 + TILE
   template <typename F>
@@ -571,15 +562,11 @@ __global__ void __launch_bounds__(256) env_resample_table_kernel(int T, int n_ou
   tab_w[q] = (xn - knot(i0)) / (knot(i0 + 1) - knot(i0));
 }
 
-// Output q belongs to the tile whose range [emitted, end) of left knots holds its i0; both neighbours' windows are in
-// the ring then.  y = y0 + (y1 - y0) w with w = (xn - x0) / (x1 - x0) from the table (scipy evaluates
-// (y1 - y0) / (x1 - x0) * (xn - x0) + y0: the same to an ulp of float64).  For fp32 outputs the two roots are taken in
-// fp32 like everywhere else in this file.  Returns false when q is another tile's.
+// Time-normalised output with left knot i0 and weight w = (xn - x0) / (x1 - x0) from the table: y = y0 + (y1 - y0) w
+// (scipy evaluates (y1 - y0) / (x1 - x0) * (xn - x0) + y0: the same to an ulp of float64); both neighbours' windows
+// must be in the ring.  For fp32 outputs the two roots are taken in fp32 like everywhere else in this file.
 template <typename real, int SPL>
-__device__ __forceinline__ bool env_resample_one(const EnvWave<real, SPL>& wv, const EnvArgs& a, int q, int emitted, int end,
-                                                 double inv_w, double& y) {
-  const int i0 = a.tab_i0[q];
-  if (i0 < emitted || i0 >= end) return false;
+__device__ __forceinline__ double env_interp(const EnvWave<real, SPL>& wv, int i0, double w, double inv_w) {
   const double s0 = wv.window_sum(i0), s1 = wv.window_sum(i0 + 1);
   double y0, y1;
   if constexpr (sizeof(real) == 4) {
@@ -590,16 +577,7 @@ __device__ __forceinline__ bool env_resample_one(const EnvWave<real, SPL>& wv, c
     y0 = sqrt((s0 > 0.0 ? s0 : 0.0) * inv_w);
     y1 = sqrt((s1 > 0.0 ? s1 : 0.0) * inv_w);
   }
-  y = (y1 - y0) * a.tab_w[q] + y0;
-  return true;
-}
-// candidate outputs of the left knots [emitted, end): q_lo .. q_hi (a superset; env_resample_one decides)
-__device__ __forceinline__ void env_resample_range(int T, int n_out, int emitted, int end, int& q_lo, int& q_hi) {
-  const double step_in = 1.0 / (double)(T - 1), scale = (double)(n_out - 1);
-  q_lo = (int)floor((double)emitted * step_in * scale) - 1;
-  q_hi = (int)ceil((end == T - 1 ? 1.0 : (double)end * step_in) * scale) + 2;
-  if (q_lo < 0) q_lo = 0;
-  if (q_hi > n_out) q_hi = n_out;
+  return (y1 - y0) * w + y0;
 }
 
 template <typename real, int SPL>
@@ -617,7 +595,14 @@ __global__ void __launch_bounds__(64) emg_wave_kernel(EnvArgs a, int ring /* pow
   real* __restrict__ o = static_cast<real*>(a.out) + cidx * (long long)n_out;
 
   Wv wv;
-  wv.init(x, reinterpret_cast<double*>(env_smem), ring, T, W, 0.0, lane, 0);  // first tile requested before the mean pass
+  wv.init(x, reinterpret_cast<double*>(env_smem), ring, T, W, 0.0, lane, 0);
+  // Samples are requested TWO tiles ahead (two register sets, the loop below handles a pair of tiles per trip): with
+  // one tile per wave in flight the 4096 waves of the chip keep 8 MB outstanding, which at 2-4 us of loaded memory
+  // latency is 2.5-3 TB/s -- exactly what the time-normalised path measured.  The first two are requested here,
+  // before the mean pass.
+  real pfa[SPL], pfb[SPL];
+  wv.load(0, pfa);
+  wv.load(TILE, pfb);
   double mean = 0.0;
   if (a.zero_center) {
     // eight 16-byte loads in flight per lane; fixed summation order
@@ -664,8 +649,21 @@ __global__ void __launch_bounds__(64) emg_wave_kernel(EnvArgs a, int ring /* pow
   float vmaxf = 0.f;
   int emitted = 0;
   const int end_all = resample ? T - 1 : T;  // resampling: `emitted` counts left knots i0 in [0, T - 1)
-  for (int t0 = 0; emitted < end_all; t0 += TILE) {
-    wv.tile(t0);
+  // time normalisation: the window of outputs qw .. qw + 63 and the one after it (table of env_resample_table_kernel)
+  auto load_window = [&](int q0, int& i0v, double& wgt) __attribute__((always_inline)) {
+    const int q = q0 + lane;
+    const bool ok = resample && q < n_out;
+    i0v = ok ? a.tab_i0[q] : 0x7fffffff;  // end marker: never inside a tile's range
+    wgt = ok ? a.tab_w[q] : 0.0;
+  };
+  int qw = 0, i0_l, i0_n;
+  double w_l, w_n;
+  load_window(0, i0_l, w_l);
+  load_window(64, i0_n, w_n);
+  auto step = [&](int t0, real (&buf)[SPL]) __attribute__((always_inline)) {
+    wv.tile_core(t0, buf, [&]() __attribute__((always_inline)) {
+      if (t0 + 2 * TILE < T) wv.load(t0 + 2 * TILE, buf);  // the set is free again: request the tile after next
+    });
     const int avail = t0 + TILE;  // P[j] is in the ring for j < avail (zeros past T: P[j] = P[T] there)
     if (!resample) {
       int end = avail - hi - 1;
@@ -704,21 +702,33 @@ __global__ void __launch_bounds__(64) emg_wave_kernel(EnvArgs a, int ring /* pow
       }
       if (end > emitted) emitted = end;
     } else {
+      // outputs are consumed in order: a window of 64 consecutive ones sits in registers (left knot, weight); a lane
+      // fires when its left knot falls into this tile's range [emitted, end) of complete windows, and once the last
+      // lane's knot is behind `end` the next window (requested when this one was installed) takes over
       int end = avail - hi - 2;
       if (end > T - 1) end = T - 1;
       if (end > emitted) {
-        int q_lo, q_hi;
-        env_resample_range(T, n_out, emitted, end, q_lo, q_hi);
-        for (int q = q_lo + lane; q < q_hi; q += 64) {
-          double y;
-          if (!env_resample_one(wv, a, q, emitted, end, inv_w, y)) continue;
-          o[q] = (real)y;
-          vmax = fmax(vmax, fabs(y));
+        while (true) {
+          if (i0_l >= emitted && i0_l < end) {
+            const double y = env_interp(wv, i0_l, w_l, inv_w);
+            o[qw + lane] = (real)y;
+            vmax = fmax(vmax, fabs(y));
+          }
+          if (__builtin_amdgcn_readlane(i0_l, 63) >= end) break;  // later tiles' outputs (or the end marker) remain
+          qw += 64;
+          i0_l = i0_n;
+          w_l = w_n;
+          load_window(qw + 64, i0_n, w_n);
         }
         emitted = end;
       }
     }
     env_wave_sync();  // the next tile overwrites ring entries only after these reads
+  };
+  for (int t0 = 0; emitted < end_all; t0 += 2 * TILE) {
+    step(t0, pfa);
+    if (emitted >= end_all) break;
+    step(t0 + TILE, pfb);
   }
   if (a.normalize) {
     vmax = fmax(vmax, (double)vmaxf);
