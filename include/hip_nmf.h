@@ -159,6 +159,26 @@ int hipnmf_shard_hupdate_f64(hipnmf_handle* h, const hipnmf_problem* p, double* 
 int hipnmf_shard_residual_f64(hipnmf_handle* h, const hipnmf_problem* p, const double* X, const double* W,
                               const double* H, double* sse_col, double* xsq_col);
 
+/*
+ * The whole time-sharded fit on this rank's rows in one call (SURVEY.md section 8b's hipnmf_fit_tsharded; the loop
+ * muscle_synergies_amd/tsharded.py drives from Python, for hosts that are not Python).  *p describes the LOCAL shard
+ * (n_samples = its rows; same layout requirements as the building blocks); max_iter, tol, check_every and update_h are
+ * honoured as in hipnmf_fit_batched (sklearn's stop rule on the GLOBAL residual, _nmf.py:872-884; with batch > 1 every
+ * matrix must have converged).  `allreduce` sums `count` elements of `elem_size` bytes IN PLACE in a device buffer
+ * over all ranks; it is called once per iteration with k*m + k*k elements per matrix and once per stop-rule check /
+ * at the end with 2*m, always after the producing kernels have been enqueued on `hip_stream`: either enqueue the
+ * collective on that stream (RCCL: ncclAllReduce(buf, buf, count, type, ncclSum, comm, (hipStream_t)hip_stream)) or
+ * synchronise it, reduce, and return.  0 = success.  NULL = single rank.  err_out / n_iter_out [B], sse_col_out /
+ * xsq_col_out [B][m] (global sums, may be NULL) are device buffers.
+ */
+typedef int (*hipnmf_allreduce_fn)(void* device_buf, size_t count, int elem_size, void* hip_stream, void* user);
+int hipnmf_fit_tsharded_f32(hipnmf_handle* h, const hipnmf_problem* p, const float* X, float* W, float* H,
+                            hipnmf_allreduce_fn allreduce, void* user, float* err_out, int32_t* n_iter_out,
+                            float* sse_col_out, float* xsq_col_out);
+int hipnmf_fit_tsharded_f64(hipnmf_handle* h, const hipnmf_problem* p, const double* X, double* W, double* H,
+                            hipnmf_allreduce_fn allreduce, void* user, double* err_out, int32_t* n_iter_out,
+                            double* sse_col_out, double* xsq_col_out);
+
 /* ---- EMG envelope preprocessing: the producer of X ------------------ */
 /*
  * Batched GPU version of the tutorial pipeline that builds the matrix handed to find_synergies

@@ -39,10 +39,15 @@ EXPORTS = (
     "hipnmf_fit_batched_f32", "hipnmf_fit_batched_f64", "hipnmf_fit_ragged_f32", "hipnmf_fit_ragged_f64",
     "hipnmf_shard_pass_f32", "hipnmf_shard_hupdate_f32", "hipnmf_shard_residual_f32",
     "hipnmf_shard_pass_f64", "hipnmf_shard_hupdate_f64", "hipnmf_shard_residual_f64",
+    "hipnmf_fit_tsharded_f32", "hipnmf_fit_tsharded_f64",
     "hipnmf_emg_envelope_f32", "hipnmf_emg_envelope_f64", "hipnmf_sosfilt_f32", "hipnmf_sosfilt_f64",
     "hipnmf_gram_f32", "hipnmf_gram_f64", "hipnmf_nndsvd_stats_f32", "hipnmf_nndsvd_stats_f64",
     "hipnmf_nndsvd_write_f32", "hipnmf_nndsvd_write_f64",
 )
+
+
+# int (*hipnmf_allreduce_fn)(void* device_buf, size_t count, int elem_size, void* hip_stream, void* user)
+ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p)
 
 
 class HipNmfError(RuntimeError):

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -807,10 +808,127 @@ int shard_residual_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X
   return HIPNMF_OK;
 }
 
+// The whole time-sharded fit on this rank's rows (the loop muscle_synergies_amd/tsharded.py::fit_tsharded drives from
+// Python, for hosts that are not Python): sklearn's iteration order and stop rule (_nmf.py:826-884) with the two sums
+// that span all rows -- [W^T X | W^T W] once per iteration, the per-column residual at every stop-rule check -- handed
+// to the caller's all-reduce.  Everything is enqueued on the handle's stream; the host waits only where the stop rule
+// needs the residual.
+template <typename real>
+int tsharded_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, real* W, real* H, hipnmf_allreduce_fn allreduce,
+                  void* user, real* err_out, int32_t* n_iter_out, real* sse_col_out, real* xsq_col_out) {
+  if (!h) return fail(HIPNMF_ERR_BAD_ARG, "handle is NULL");
+  if (!p) return fail(HIPNMF_ERR_BAD_ARG, "problem is NULL");
+  if (!X || !W || !H) return fail(HIPNMF_ERR_BAD_ARG, "X, W and H must be non-NULL device pointers");
+  if (p->struct_size != (int32_t)sizeof(hipnmf_problem))
+    return fail(HIPNMF_ERR_BAD_ARG, "hipnmf_problem.struct_size = %d, library expects %d", p->struct_size, (int)sizeof(hipnmf_problem));
+  if (p->max_iter < 1) return fail(HIPNMF_ERR_BAD_ARG, "max_iter must be >= 1 (got %d)", p->max_iter);
+  if (p->batch < 1 || p->n_features < 1 || p->n_components < 1) return fail(HIPNMF_ERR_BAD_ARG, "bad shape");
+  HIP_TRY(hipSetDevice(h->device));
+  const int B = p->batch, m = p->n_features, k = p->n_components;
+  const size_t n_sums = (size_t)B * ((size_t)k * m + (size_t)k * k), n_res = (size_t)B * 2 * m;
+  const int check_every = p->check_every > 0 ? p->check_every : 10;
+  const bool stop_rule = p->tol > 0;
+  hipStream_t st = h->stream;
+
+  real* dbuf = nullptr;  // [sums | sse, xsq packed per matrix as the all-reduce wants them: one buffer, one call]
+  HIP_TRY(hipMalloc(&dbuf, sizeof(real) * (n_sums + 2 * n_res)));
+  real* sums = dbuf;
+  real* packed = dbuf + n_sums;        // [B][2 m]: sse | xsq
+  real* cols = dbuf + n_sums + n_res;  // scratch the residual kernels write: sse [B][m], xsq [B][m]
+  std::vector<real> host(n_res);
+  std::vector<double> err(B, 0.0), err_init(B, 0.0), prev(B, 0.0);
+  const int saved_async = h->async_mode;
+  h->async_mode = 1;  // the building blocks only enqueue; this function decides where the host waits
+  int rc = HIPNMF_OK, n_iter = 0;
+  auto reduce = [&](real* buf, size_t count) -> int {
+    if (!allreduce) return HIPNMF_OK;
+    const int e = allreduce(buf, count, (int)sizeof(real), (void*)st, user);
+    return e == 0 ? HIPNMF_OK : fail(HIPNMF_ERR_HIP, "the all-reduce callback returned %d", e);
+  };
+  // global ||X - W H||_F per matrix (and the per-column sums for VAF), in the arithmetic type like the other paths
+  auto global_error = [&]() -> int {
+    int r = shard_residual_impl<real>(h, p, X, W, H, cols, cols + (size_t)B * m);
+    if (r) return r;
+    for (int b = 0; b < B && !r; ++b) {  // pack [sse_b | xsq_b]
+      if (hipMemcpyAsync(packed + (size_t)b * 2 * m, cols + (size_t)b * m, sizeof(real) * m, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+          hipMemcpyAsync(packed + (size_t)b * 2 * m + m, cols + (size_t)B * m + (size_t)b * m, sizeof(real) * m, hipMemcpyDeviceToDevice, st) != hipSuccess)
+        r = fail(HIPNMF_ERR_HIP, "hipMemcpyAsync failed");
+    }
+    if (r) return r;
+    r = reduce(packed, n_res);
+    if (r) return r;
+    if (hipMemcpyAsync(host.data(), packed, sizeof(real) * n_res, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess)
+      return fail(HIPNMF_ERR_HIP, "reading the residual back failed: %s", hipGetErrorString(hipGetLastError()));
+    for (int b = 0; b < B; ++b) {
+      real tot = (real)0;
+      for (int j = 0; j < m; ++j) tot += host[(size_t)b * 2 * m + j];
+      err[b] = (double)(real)std::sqrt((double)tot);
+    }
+    return HIPNMF_OK;
+  };
+  // reconstruction_err_ / n_iter_ per matrix and the global per-column sums (for VAF) to the caller's device buffers
+  auto write_outputs = [&]() -> int {
+    std::vector<real> e(B);
+    std::vector<int32_t> it(B, n_iter);
+    for (int b = 0; b < B; ++b) e[b] = (real)err[b];
+    if (err_out) HIP_TRY(hipMemcpyAsync(err_out, e.data(), sizeof(real) * B, hipMemcpyHostToDevice, st));
+    if (n_iter_out) HIP_TRY(hipMemcpyAsync(n_iter_out, it.data(), sizeof(int32_t) * B, hipMemcpyHostToDevice, st));
+    for (int b = 0; b < B; ++b) {
+      if (sse_col_out)
+        HIP_TRY(hipMemcpyAsync(sse_col_out + (size_t)b * m, packed + (size_t)b * 2 * m, sizeof(real) * m, hipMemcpyDeviceToDevice, st));
+      if (xsq_col_out)
+        HIP_TRY(hipMemcpyAsync(xsq_col_out + (size_t)b * m, packed + (size_t)b * 2 * m + m, sizeof(real) * m, hipMemcpyDeviceToDevice, st));
+    }
+    HIP_TRY(hipStreamSynchronize(st));  // e / it are host temporaries
+    return HIPNMF_OK;
+  };
+  do {
+    if (stop_rule) {
+      if ((rc = global_error())) break;
+      err_init = err;
+      prev = err;
+    }
+    for (n_iter = 1; n_iter <= p->max_iter; ++n_iter) {
+      if ((rc = shard_pass_impl<real>(h, p, X, W, H, sums))) break;
+      if (p->update_h) {
+        if ((rc = reduce(sums, n_sums))) break;
+        if ((rc = shard_hupdate_impl<real>(h, p, H, sums))) break;
+      }
+      if (stop_rule && n_iter % check_every == 0) {
+        if ((rc = global_error())) break;
+        bool all_done = true;  // every matrix of the (small) batch must have converged; B == 1: sklearn's rule
+        for (int b = 0; b < B; ++b) all_done = all_done && ((real)((prev[b] - err[b]) / err_init[b]) < (real)p->tol);
+        if (all_done) break;
+        prev = err;
+      }
+    }
+    if (rc) break;
+    if (n_iter > p->max_iter) n_iter = p->max_iter;
+    if ((rc = global_error())) break;
+    rc = write_outputs();
+  } while (false);
+  h->async_mode = saved_async;
+  (void)hipStreamSynchronize(st);
+  (void)hipFree(dbuf);
+  return rc;
+}
+
 }  // namespace
 
 // =================================================================================================
 extern "C" {
+
+int hipnmf_fit_tsharded_f32(hipnmf_handle* h, const hipnmf_problem* p, const float* X, float* W, float* H,
+                            hipnmf_allreduce_fn allreduce, void* user, float* err_out, int32_t* n_iter_out,
+                            float* sse_col_out, float* xsq_col_out) {
+  return tsharded_impl<float>(h, p, X, W, H, allreduce, user, err_out, n_iter_out, sse_col_out, xsq_col_out);
+}
+int hipnmf_fit_tsharded_f64(hipnmf_handle* h, const hipnmf_problem* p, const double* X, double* W, double* H,
+                            hipnmf_allreduce_fn allreduce, void* user, double* err_out, int32_t* n_iter_out,
+                            double* sse_col_out, double* xsq_col_out) {
+  return tsharded_impl<double>(h, p, X, W, H, allreduce, user, err_out, n_iter_out, sse_col_out, xsq_col_out);
+}
 
 int hipnmf_version(void) { return HIPNMF_VERSION; }
 

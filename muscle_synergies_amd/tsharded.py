@@ -128,6 +128,55 @@ class HipShardOps:
         self._res = getattr(lib, f"hipnmf_shard_residual_{sfx}")
         return self
 
+    def fit_native(self, *, max_iter: int = 200, tol: float = 1e-4, check_every: int = 10, group=None,
+                   all_reduce: Optional[Callable] = None) -> "ShardedResult":
+        """The whole sharded fit inside the library (``hipnmf_fit_tsharded_*``): same loop, same kernels and the same
+        collective as :func:`fit_tsharded`, but driven from C++ -- the per-iteration Python overhead (three ctypes
+        calls, a tensor clone) is gone and the entry point is usable from any host language.  ``all_reduce(tensor)``
+        must sum ``tensor`` in place over all ranks; the default is ``torch.distributed.all_reduce`` over ``group``
+        when a process group is initialised, nothing otherwise.  Collective: every rank calls it."""
+        torch = self.torch
+        if all_reduce is None:
+            import torch.distributed as dist
+
+            if dist.is_available() and dist.is_initialized():
+                def all_reduce(t):
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        dev, dtype = self.dev, self.dtype
+        failure = []
+
+        class _DeviceBuffer:  # zero-copy view of the library's buffer for torch (CUDA array interface, version 2)
+            def __init__(self, ptr, count):
+                self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": "<f4" if dtype == torch.float32 else "<f8",
+                                                 "data": (int(ptr), False), "version": 2}
+
+        def _cb(buf, count, elem_size, stream, user):
+            try:  # the handle runs on torch's current stream (see __init__): the collective is ordered behind the kernels
+                all_reduce(torch.as_tensor(_DeviceBuffer(buf, count), device=dev))
+                return 0
+            except Exception as e:  # noqa: BLE001 -- must not propagate through the C frames
+                failure.append(e)
+                return 1
+
+        cb = _lib.ALLREDUCE_FN(_cb) if all_reduce is not None else _lib.ALLREDUCE_FN()  # NULL: single rank
+        p = _lib.Problem.from_buffer_copy(self.p)
+        p.max_iter, p.tol, p.check_every = int(max_iter), float(tol), int(check_every)
+        err = torch.empty((self.B,), dtype=dtype, device=dev)
+        n_iter = torch.empty((self.B,), dtype=torch.int32, device=dev)
+        sse = torch.empty((self.B, self.m), dtype=dtype, device=dev)
+        xsq = torch.empty((self.B, self.m), dtype=dtype, device=dev)
+        fn = getattr(_lib.load(), "hipnmf_fit_tsharded_f32" if dtype == torch.float32 else "hipnmf_fit_tsharded_f64")
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _lib.ALLREDUCE_FN,
+                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        fn.restype = ctypes.c_int
+        rc = fn(self.handle.ptr, ctypes.addressof(p), self.Xc.data_ptr(), self.Wc.data_ptr(), self.H.data_ptr(), cb, None,
+                err.data_ptr(), n_iter.data_ptr(), sse.data_ptr(), xsq.data_ptr())
+        if failure:
+            raise failure[0]
+        _lib.check(rc)
+        vaf = torch.cat([(1 - sse.sum(dim=1) / xsq.sum(dim=1)).unsqueeze(1), 1 - sse / xsq], dim=1)
+        return ShardedResult(self.result_W(), self.result_H(), int(n_iter[0]), err, vaf)
+
     def shard_pass(self):
         _lib.check(self._pass(self.handle.ptr, ctypes.byref(self.p), self.Xc.data_ptr(), self.Wc.data_ptr(),
                               self.H.data_ptr(), self.sums.data_ptr()))

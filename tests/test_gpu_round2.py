@@ -441,3 +441,103 @@ def test_shard_fuzz():
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "0 problems" in r.stdout
+
+
+# ------------------------------------------------------------------------------------------------ native sharded loop
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_native_tsharded_fit_single_rank(dtype):
+    """hipnmf_fit_tsharded_* (the sharded loop inside the library, no callback = one rank) against the oracle and
+    against the Python-driven loop over the same building blocks: fixed iteration count and the stop rule."""
+    from muscle_synergies_amd.tsharded import HipShardOps, fit_tsharded
+
+    T = 20_003
+    X = emg_matrix(77, T=T, m=16, dtype=dtype)
+    W0, H0 = random_init(X, 5, 77)
+    res = HipShardOps(np.ascontiguousarray(X), W0, H0).fit_native(max_iter=30, tol=0.0)
+    ref = orc.nmf_mu_fit(X, W0, H0, max_iter=30, tol=0.0)
+    W, H = res.W_local.cpu().numpy()[0], res.H.cpu().numpy()[0]
+    lim = TOL if dtype == np.float32 else 1e-9
+    assert res.n_iter == 30 and W.shape == (T, 5)
+    assert _rel_wh(X, W, H, ref) <= lim
+    assert abs(float(res.reconstruction_err[0]) - float(ref["reconstruction_err"])) / np.linalg.norm(X) <= lim
+    py = fit_tsharded(HipShardOps(np.ascontiguousarray(X), W0, H0), max_iter=30, tol=0.0)
+    np.testing.assert_array_equal(py.W_local.cpu().numpy(), res.W_local.cpu().numpy())  # same kernels, same order
+    np.testing.assert_array_equal(py.H.cpu().numpy(), res.H.cpu().numpy())
+    np.testing.assert_allclose(res.vaf.cpu().numpy(), py.vaf.cpu().numpy(), rtol=1e-6, atol=1e-7)
+    # stop rule live (float64: the iteration count is reproducible to the check)
+    if dtype == np.float64:
+        res2 = HipShardOps(np.ascontiguousarray(X), W0, H0).fit_native(max_iter=400, tol=1e-3)
+        ref2 = orc.nmf_mu_fit(X, W0, H0, max_iter=400, tol=1e-3)
+        assert res2.n_iter == ref2["n_iter"] and res2.n_iter < 400
+        assert _rel_wh(X, res2.W_local.cpu().numpy()[0], res2.H.cpu().numpy()[0], ref2) <= lim
+
+
+@pytest.mark.gpu
+def test_native_tsharded_fit_callback_plumbing():
+    """Two identical ranks emulated in one process: the all-reduce callback doubles the buffer, which is the sum over
+    two ranks holding the same rows -- the fit must equal the oracle's on the matrix with every row twice."""
+    from muscle_synergies_amd.tsharded import HipShardOps
+
+    T = 3_001
+    X = emg_matrix(78, T=T, m=12, dtype=np.float64)
+    W0, H0 = random_init(X, 4, 78)
+    calls = []
+
+    def double(t):
+        calls.append(tuple(t.shape))
+        t.mul_(2.0)
+
+    res = HipShardOps(np.ascontiguousarray(X), W0, H0).fit_native(max_iter=25, tol=0.0, all_reduce=double)
+    ref = orc.nmf_mu_fit(np.vstack([X, X]), np.vstack([W0, W0]), H0, max_iter=25, tol=0.0)
+    np.testing.assert_allclose(res.W_local.cpu().numpy()[0], ref["W"][:T], rtol=1e-9, atol=1e-13)
+    np.testing.assert_allclose(res.H.cpu().numpy()[0], ref["H"], rtol=1e-9, atol=1e-13)
+    np.testing.assert_allclose(float(res.reconstruction_err[0]), float(ref["reconstruction_err"]), rtol=1e-9)
+    assert calls.count((4 * 12 + 4 * 4,)) == 25 and calls.count((2 * 12,)) == 1  # one per iteration + the final residual
+
+    def broken(t):
+        raise RuntimeError("transport down")
+
+    with pytest.raises(RuntimeError, match="transport down"):
+        HipShardOps(np.ascontiguousarray(X), W0, H0).fit_native(max_iter=5, tol=0.0, all_reduce=broken)
+
+
+def _gloo_native_worker(rank, world, port, T, out_dir):
+    import torch
+    import torch.distributed as dist
+
+    from muscle_synergies_amd.tsharded import HipShardOps, shard_bounds
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)  # both ranks share the one GPU of the test box
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        X = emg_matrix(79, T=T, m=16, dtype=np.float64)
+        W0, H0 = random_init(X, 5, 79)
+        lo, hi = shard_bounds(T, world)[rank]
+        res = HipShardOps(np.ascontiguousarray(X[lo:hi]), W0[lo:hi], H0).fit_native(max_iter=300, tol=1e-3)
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), W=res.W_local.cpu().numpy()[0], H=res.H.cpu().numpy()[0],
+                 err=res.reconstruction_err.cpu().numpy(), n_iter=res.n_iter)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_native_tsharded_fit_two_processes_over_gloo(tmp_path):
+    """Two ranks (two processes on the one GPU, gloo as the transport) through hipnmf_fit_tsharded_f64 with
+    torch.distributed's all-reduce as the callback: rows sharded, H replicated, sklearn's stop rule on the global
+    residual -- against the unsharded oracle."""
+    import torch.multiprocessing as mp
+
+    T, world = 30_001, 2
+    mp.spawn(_gloo_native_worker, args=(world, _free_port(), T, str(tmp_path)), nprocs=world, join=True)
+    X = emg_matrix(79, T=T, m=16, dtype=np.float64)
+    W0, H0 = random_init(X, 5, 79)
+    ref = orc.nmf_mu_fit(X, W0, H0, max_iter=300, tol=1e-3)
+    parts = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    np.testing.assert_array_equal(parts[0]["H"], parts[1]["H"])  # replicated
+    assert int(parts[0]["n_iter"]) == int(parts[1]["n_iter"]) == ref["n_iter"]
+    W = np.concatenate([p["W"] for p in parts], axis=0)
+    assert _rel_wh(X, W, parts[0]["H"], ref) <= 1e-9
+    assert abs(float(parts[0]["err"][0]) - float(ref["reconstruction_err"])) / np.linalg.norm(X) <= 1e-9

@@ -24,7 +24,8 @@ bad.struct_size = 7
 nul = [None] * 9
 for sfx in ("f32", "f64"):
     for fn, nargs in ((f"hipnmf_fit_batched_{sfx}", 7), (f"hipnmf_shard_pass_{sfx}", 4), (f"hipnmf_shard_hupdate_{sfx}", 2),
-                      (f"hipnmf_shard_residual_{sfx}", 5), (f"hipnmf_gram_{sfx}", 3), (f"hipnmf_nndsvd_stats_{sfx}", 4)):
+                      (f"hipnmf_shard_residual_{sfx}", 5), (f"hipnmf_gram_{sfx}", 3), (f"hipnmf_nndsvd_stats_{sfx}", 4),
+                      (f"hipnmf_fit_tsharded_{sfx}", 9)):
         f = getattr(lib, fn)
         f.restype = ctypes.c_int
         assert f(None, ctypes.byref(p), *nul[:nargs]) < 0, fn          # NULL handle
