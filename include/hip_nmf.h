@@ -179,6 +179,33 @@ int hipnmf_fit_tsharded_f64(hipnmf_handle* h, const hipnmf_problem* p, const dou
                             hipnmf_allreduce_fn allreduce, void* user, double* err_out, int32_t* n_iter_out,
                             double* sse_col_out, double* xsq_col_out);
 
+/* ---- rank sweep: find_synergies(df, k_min, k_max) for a batch of trials (BASELINE.json config #4) -- */
+/*
+ * init='random' of sklearn (_nmf.py:303-314) drawn on the device: avg = sqrt(mean(X) / k), H0 = avg |N(0,1)|,
+ * W0 = avg |N(0,1)| from a counter-based generator (Philox4x32-10 + Box-Muller) keyed by (seed, first_matrix + b,
+ * element), so the values depend neither on the layout nor on how a batch is scattered over GPUs.  Not the stream of
+ * numpy's RandomState: same distribution, other numbers.  W per p->w_layout, H [B][k][m].
+ */
+int hipnmf_random_init_f32(hipnmf_handle* h, const hipnmf_problem* p, uint64_t seed, int32_t first_matrix, const float* X,
+                           float* W, float* H);
+int hipnmf_random_init_f64(hipnmf_handle* h, const hipnmf_problem* p, uint64_t seed, int32_t first_matrix, const double* X,
+                           double* W, double* H);
+/*
+ * For every k in [k_min, k_max]: hipnmf_random_init(seed + k) -> hipnmf_fit_batched (p->max_iter, tol, ... honoured;
+ * p->n_components ignored) -> VAF over all muscles per trial (analysis.py:654-662).  The reference computes every rank
+ * and leaves the choice to the user (analysis.py:753-756); selected_out is the smallest k with VAF >= vaf_threshold
+ * (-1: none).  W_ws: workspace of B * T * k_max elements (holds W of rank k_max on return, per p->w_layout);
+ * H_out: the components of every rank, rank after rank: [B][k][m] for k = k_min .. k_max;
+ * vaf_out / err_out / n_iter_out: [B][k_max - k_min + 1]; selected_out [B].  All device pointers; err_out, n_iter_out
+ * and selected_out may be NULL.
+ */
+int hipnmf_rank_sweep_f32(hipnmf_handle* h, const hipnmf_problem* p, int32_t k_min, int32_t k_max, double vaf_threshold,
+                          uint64_t seed, int32_t first_matrix, const float* X, float* W_ws, float* H_out, float* vaf_out,
+                          int32_t* selected_out, float* err_out, int32_t* n_iter_out);
+int hipnmf_rank_sweep_f64(hipnmf_handle* h, const hipnmf_problem* p, int32_t k_min, int32_t k_max, double vaf_threshold,
+                          uint64_t seed, int32_t first_matrix, const double* X, double* W_ws, double* H_out, double* vaf_out,
+                          int32_t* selected_out, double* err_out, int32_t* n_iter_out);
+
 /* ---- EMG envelope preprocessing: the producer of X ------------------ */
 /*
  * Batched GPU version of the tutorial pipeline that builds the matrix handed to find_synergies

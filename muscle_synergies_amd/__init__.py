@@ -13,7 +13,7 @@ Importing this package never loads the HIP library; the first compute call does,
 
 from .analysis import SynergyRunResult, find_synergies, find_synergies_batched, vaf
 from .engine import (BatchedResult, RankSweepResult, RestartResult, fit_batched, fit_batched_multi_gpu, fit_ragged,
-                     fit_restarts, random_init_batched, rank_sweep_batched)
+                     fit_restarts, random_init_batched, random_init_device, rank_sweep_batched, rank_sweep_native)
 from .hip_nmf import HipNMF
 from .preprocess import (digital_filter, emg_envelope_batched, linear_envelope, linear_envelope_batched, normalize,
                          rms, sosfilt_batched, time_normalize, zero_center)
@@ -37,6 +37,8 @@ __all__ = [
     "RestartResult",
     "BatchedResult",
     "rank_sweep_batched",
+    "rank_sweep_native",
+    "random_init_device",
     "random_init_batched",
     "RankSweepResult",
     "HipNmfError",

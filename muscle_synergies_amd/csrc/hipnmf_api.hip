@@ -914,10 +914,92 @@ int tsharded_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, real
   return rc;
 }
 
+// Rank sweep (BASELINE.json config #4; find_synergies(df, k_min, k_max) for a batch of trials, analysis.py:848-914):
+// one batched fit per rank from init='random' starting points drawn on the device, VAF per trial and rank
+// (analysis.py:654-662), and the smallest rank whose VAF reaches the threshold.  Host-side loop over the library's own
+// entry points; the per-rank results are read back (B (m + 2) numbers per rank) for the VAF table.
+template <typename real>
+int rank_sweep_impl(hipnmf_handle* h, const hipnmf_problem* p, int k_min, int k_max, double vaf_threshold, uint64_t seed,
+                    int first_matrix, const real* X, real* W_ws, real* H_out, real* vaf_out, int32_t* selected_out,
+                    real* err_out, int32_t* n_iter_out) {
+  if (!h) return fail(HIPNMF_ERR_BAD_ARG, "handle is NULL");
+  if (!p || p->struct_size != (int32_t)sizeof(hipnmf_problem)) return fail(HIPNMF_ERR_BAD_ARG, "bad hipnmf_problem");
+  if (!X || !W_ws || !H_out || !vaf_out) return fail(HIPNMF_ERR_BAD_ARG, "X, W_ws, H_out and vaf_out must be non-NULL");
+  if (k_min < 1 || k_max < k_min || k_max > p->n_features)
+    return fail(HIPNMF_ERR_BAD_ARG, "invalid number of components: need 1 <= k_min <= k_max <= n_features (got %d..%d, %d features)",
+                k_min, k_max, p->n_features);
+  HIP_TRY(hipSetDevice(h->device));
+  const int B = p->batch, m = p->n_features, nk = k_max - k_min + 1;
+  real* cols = nullptr;  // [2][B][m] sse | xsq, [B] err, then n_iter
+  HIP_TRY(hipMalloc(&cols, sizeof(real) * ((size_t)2 * B * m + B) + sizeof(int32_t) * (size_t)B));
+  real* d_err = cols + (size_t)2 * B * m;
+  int32_t* d_it = reinterpret_cast<int32_t*>(d_err + B);
+  std::vector<real> hs((size_t)2 * B * m), vaf((size_t)B * nk), herr((size_t)B * nk), e(B);
+  std::vector<int32_t> hit((size_t)B * nk), it(B), sel(B, -1);
+  int rc = HIPNMF_OK;
+  size_t h_off = 0;
+  for (int k = k_min; k <= k_max && !rc; ++k) {
+    hipnmf_problem q = *p;
+    q.n_components = k;
+    real* Hk = H_out + h_off;
+    h_off += (size_t)B * k * m;
+    if (p->n_features > 32 || k > 8) {
+      rc = fail(HIPNMF_ERR_UNSUPPORTED, "rank %d with %d features is outside the compiled kernel set", k, m);
+      break;
+    }
+    rc = sizeof(real) == 4 ? hipnmf_random_init_f32(h, &q, seed + (uint64_t)k, first_matrix, (const float*)X, (float*)W_ws, (float*)Hk)
+                           : hipnmf_random_init_f64(h, &q, seed + (uint64_t)k, first_matrix, (const double*)X, (double*)W_ws, (double*)Hk);
+    if (rc) break;
+    rc = fit_batched_impl<real>(h, &q, X, W_ws, Hk, d_err, d_it, cols, cols + (size_t)B * m);
+    if (rc) break;
+    if (hipMemcpy(hs.data(), cols, sizeof(real) * hs.size(), hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(e.data(), d_err, sizeof(real) * B, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(it.data(), d_it, sizeof(int32_t) * B, hipMemcpyDeviceToHost) != hipSuccess) {
+      rc = fail(HIPNMF_ERR_HIP, "reading the results of rank %d back failed", k);
+      break;
+    }
+    const int ki = k - k_min;
+    for (int b = 0; b < B; ++b) {
+      real sse = (real)0, xsq = (real)0;
+      for (int j = 0; j < m; ++j) {
+        sse += hs[(size_t)b * m + j];
+        xsq += hs[(size_t)B * m + (size_t)b * m + j];
+      }
+      const real v = (real)1 - sse / xsq;  // VAF over all muscles (analysis.py:660-662)
+      vaf[(size_t)b * nk + ki] = v;
+      herr[(size_t)b * nk + ki] = e[b];
+      hit[(size_t)b * nk + ki] = it[b];
+      if (sel[b] < 0 && (double)v >= vaf_threshold) sel[b] = k;
+    }
+  }
+  if (!rc) {
+    if (hipMemcpy(vaf_out, vaf.data(), sizeof(real) * vaf.size(), hipMemcpyHostToDevice) != hipSuccess ||
+        (selected_out && hipMemcpy(selected_out, sel.data(), sizeof(int32_t) * B, hipMemcpyHostToDevice) != hipSuccess) ||
+        (err_out && hipMemcpy(err_out, herr.data(), sizeof(real) * herr.size(), hipMemcpyHostToDevice) != hipSuccess) ||
+        (n_iter_out && hipMemcpy(n_iter_out, hit.data(), sizeof(int32_t) * hit.size(), hipMemcpyHostToDevice) != hipSuccess))
+      rc = fail(HIPNMF_ERR_HIP, "writing the sweep results failed");
+  }
+  (void)hipFree(cols);
+  return rc;
+}
+
 }  // namespace
 
 // =================================================================================================
 extern "C" {
+
+int hipnmf_rank_sweep_f32(hipnmf_handle* h, const hipnmf_problem* p, int32_t k_min, int32_t k_max, double vaf_threshold,
+                          uint64_t seed, int32_t first_matrix, const float* X, float* W_ws, float* H_out, float* vaf_out,
+                          int32_t* selected_out, float* err_out, int32_t* n_iter_out) {
+  return rank_sweep_impl<float>(h, p, k_min, k_max, vaf_threshold, seed, first_matrix, X, W_ws, H_out, vaf_out, selected_out,
+                                err_out, n_iter_out);
+}
+int hipnmf_rank_sweep_f64(hipnmf_handle* h, const hipnmf_problem* p, int32_t k_min, int32_t k_max, double vaf_threshold,
+                          uint64_t seed, int32_t first_matrix, const double* X, double* W_ws, double* H_out, double* vaf_out,
+                          int32_t* selected_out, double* err_out, int32_t* n_iter_out) {
+  return rank_sweep_impl<double>(h, p, k_min, k_max, vaf_threshold, seed, first_matrix, X, W_ws, H_out, vaf_out, selected_out,
+                                 err_out, n_iter_out);
+}
 
 int hipnmf_fit_tsharded_f32(hipnmf_handle* h, const hipnmf_problem* p, const float* X, float* W, float* H,
                             hipnmf_allreduce_fn allreduce, void* user, float* err_out, int32_t* n_iter_out,

@@ -98,9 +98,65 @@ int write_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, const d
   return finish(h);
 }
 
+template <typename real>
+int random_init_impl(hipnmf_handle* h, const hipnmf_problem* p, uint64_t seed, int first_matrix, const real* X, real* W, real* H) {
+  if (!W || !H) return fail(HIPNMF_ERR_BAD_ARG, "W and H must be non-NULL");
+  if (p && p->w_layout != HIPNMF_W_ROW_MAJOR && p->w_layout != HIPNMF_W_COMPONENT_MAJOR)
+    return fail(HIPNMF_ERR_BAD_ARG, "bad w_layout %d", p->w_layout);
+  InitArgs a{};
+  int rc;
+  size_t x_bytes = 0;
+  // column sums through the Gram kernel (fp64, fixed order); they live behind a possibly converted X in the workspace,
+  // which therefore gets its final size BEFORE canonical_x converts into it (growing it afterwards would lose X)
+  if (h && p && p->struct_size == (int32_t)sizeof(hipnmf_problem) && p->batch >= 1 && p->n_samples >= 1 &&
+      p->n_samples <= 2000000000LL && p->n_features >= 1 && p->n_features <= GRAM_MAXM) {
+    const size_t Bm = (size_t)p->batch * p->n_features;
+    x_bytes = (p->x_layout == HIPNMF_X_CHANNEL_MAJOR) ? 0 : (sizeof(real) * Bm * (size_t)p->n_samples + 255) / 256 * 256;
+    HIP_TRY(hipSetDevice(h->device));
+    rc = hipnmf_ensure_ws(h, x_bytes + sizeof(double) * (Bm * p->n_features + Bm));
+    if (rc) return rc;
+  }
+  rc = canonical_x<real>(h, p, X, &a);  // validates everything (and reports what the shortcut above skipped)
+  if (rc) return rc;
+  const int B = p->batch, m = p->n_features;
+  a.gram = reinterpret_cast<double*>(static_cast<char*>(h->ws) + x_bytes);
+  a.colsum = a.gram + (size_t)B * m * m;
+  hipLaunchKernelGGL(gram_kernel<real>, dim3(B), dim3(256), 0, h->stream, a);
+  RandomInitArgs r{};
+  r.colsum = a.colsum;
+  r.W = W;
+  r.H = H;
+  r.seed = seed;
+  r.T = p->n_samples;
+  r.m = m;
+  r.k = p->n_components;
+  r.w_component_major = p->w_layout == HIPNMF_W_COMPONENT_MAJOR;
+  r.first_matrix = first_matrix;
+  const long long n = p->n_samples * r.k + (long long)r.k * m;
+  const unsigned gx = (unsigned)std::min<long long>((n + 255) / 256, 1024);
+  for (int b0 = 0; b0 < B; b0 += 65535) {  // grid.y carries the batch
+    const int nb = std::min(65535, B - b0);
+    RandomInitArgs rb = r;
+    rb.colsum = r.colsum + (size_t)b0 * m;
+    rb.W = static_cast<real*>(W) + (size_t)b0 * p->n_samples * r.k;
+    rb.H = static_cast<real*>(H) + (size_t)b0 * r.k * m;
+    rb.first_matrix = first_matrix + b0;
+    hipLaunchKernelGGL(random_init_kernel<real>, dim3(gx, nb), dim3(256), 0, h->stream, rb);
+  }
+  return finish(h);
+}
+
 }  // namespace
 
 extern "C" {
+int hipnmf_random_init_f32(hipnmf_handle* h, const hipnmf_problem* p, uint64_t seed, int32_t first_matrix, const float* X, float* W,
+                           float* H) {
+  return random_init_impl<float>(h, p, seed, first_matrix, X, W, H);
+}
+int hipnmf_random_init_f64(hipnmf_handle* h, const hipnmf_problem* p, uint64_t seed, int32_t first_matrix, const double* X,
+                           double* W, double* H) {
+  return random_init_impl<double>(h, p, seed, first_matrix, X, W, H);
+}
 int hipnmf_gram_f32(hipnmf_handle* h, const hipnmf_problem* p, const float* X, double* gram, double* colsum) {
   return gram_impl<float>(h, p, X, gram, colsum);
 }

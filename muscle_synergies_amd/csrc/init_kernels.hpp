@@ -172,4 +172,64 @@ __global__ void __launch_bounds__(256) nndsvd_write_kernel(InitArgs a) {
   }
 }
 
+
+// -------------------------------------------------------------------------------------------------
+// init='random' of sklearn (_nmf.py:303-314) on the device: avg = sqrt(X.mean() / k), H = avg |N(0,1)|, W = avg |N(0,1)|.
+// Counter-based (Philox4x32-10 keyed by the seed; the counter is the LOGICAL element index, so the values do not
+// depend on the layout, the launch geometry or the batch split over GPUs) with Box-Muller; stream 0 = H, 1 = W.
+__device__ __forceinline__ void philox4x32_10(unsigned (&c)[4], unsigned k0, unsigned k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = 0xD2511F53ull * c[0], p1 = 0xCD9E8D57ull * c[2];
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c[3] ^ k1, n3 = (unsigned)p0;
+    c[0] = n0;
+    c[1] = n1;
+    c[2] = n2;
+    c[3] = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+}
+// |N(0,1)| number `idx` of stream (matrix, which) under `seed`: one Philox block yields 4 normals, idx picks its own
+__device__ __forceinline__ double abs_normal(unsigned long long seed, unsigned matrix, unsigned which, unsigned long long idx) {
+  unsigned c[4] = {(unsigned)(idx >> 2), (unsigned)((idx >> 2) >> 32), matrix, which};
+  philox4x32_10(c, (unsigned)seed, (unsigned)(seed >> 32));
+  const int pair = (int)(idx & 2);  // elements 0,1 of a block share (c0, c1), elements 2,3 share (c2, c3)
+  const double u1 = ((double)c[pair] + 0.5) * (1.0 / 4294967296.0), u2 = ((double)c[pair + 1] + 0.5) * (1.0 / 4294967296.0);
+  const double r = sqrt(-2.0 * log(u1)), a = 6.283185307179586476925 * u2;
+  return fabs((idx & 1) ? r * sin(a) : r * cos(a));
+}
+
+struct RandomInitArgs {
+  const double* colsum;  // [B][m] (gram_kernel)
+  void* W;               // per w_layout: [B][T][k] or [B][k][T]
+  void* H;               // [B][k][m]
+  unsigned long long seed;
+  long long T;
+  int m, k, w_component_major, first_matrix;  // first_matrix: global index of matrix 0 (batches scattered over GPUs)
+};
+
+template <typename real>
+__global__ void __launch_bounds__(256) random_init_kernel(RandomInitArgs a) {
+  const int b = blockIdx.y;
+  double tot = 0.0;
+  for (int j = 0; j < a.m; ++j) tot += a.colsum[(long long)b * a.m + j];
+  const double avg = sqrt(tot / ((double)a.T * (double)a.m) / (double)a.k);
+  const unsigned matrix = (unsigned)(a.first_matrix + b);
+  real* W = static_cast<real*>(a.W) + (long long)b * a.T * a.k;
+  real* H = static_cast<real*>(a.H) + (long long)b * a.k * a.m;
+  const long long nw = a.T * a.k, nh = (long long)a.k * a.m;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nw + nh; i += (long long)gridDim.x * blockDim.x) {
+    if (i < nh) {
+      H[i] = (real)(avg * abs_normal(a.seed, matrix, 0u, (unsigned long long)i));  // logical index c * m + j
+    } else {
+      const long long e = i - nh;  // logical index t * k + c
+      const long long t = e / a.k;
+      const int c = (int)(e % a.k);
+      const real v = (real)(avg * abs_normal(a.seed, matrix, 1u, (unsigned long long)e));
+      W[a.w_component_major ? (long long)c * a.T + t : e] = v;
+    }
+  }
+}
+
 }  // namespace hipnmf

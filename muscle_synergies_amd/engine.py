@@ -253,6 +253,69 @@ def random_init_batched(X, k: int, *, seed: int = 0):
     return W0, H0
 
 
+def random_init_device(X, k: int, *, seed: int = 0, first_matrix: int = 0, handle: Optional[_lib.Handle] = None):
+    """The same starting points from the library's own generator (``hipnmf_random_init_*``: Philox4x32-10 keyed by
+    ``(seed, first_matrix + b, element)``), i.e. independent of the layout and of how a batch is split over GPUs;
+    this is what ``hipnmf_rank_sweep_*`` draws internally.  ``X [B, T, m]`` device tensor (any dense layout).
+    Returns ``(W0 [B, T, k], H0 [B, k, m])``."""
+    torch = _torch()
+    Xt = X if X.dim() == 3 else X.unsqueeze(0)
+    B, T, m = Xt.shape
+    layout, ldx, xbs, Xt = _x_layout(Xt)
+    p = make_problem(B, T, m, k, x_layout=layout, ldx=ldx, x_batch_stride=xbs, w_layout=_lib.W_ROW_MAJOR)
+    W0 = torch.empty((B, T, k), dtype=Xt.dtype, device=Xt.device)
+    H0 = torch.empty((B, k, m), dtype=Xt.dtype, device=Xt.device)
+    h = handle if handle is not None else _lib.get_handle(Xt.device.index)
+    fn = getattr(_lib.load(), "hipnmf_random_init_f32" if Xt.dtype == torch.float32 else "hipnmf_random_init_f64")
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    fn.restype = ctypes.c_int
+    torch.cuda.synchronize(Xt.device)
+    _lib.check(fn(h.ptr, ctypes.addressof(p), int(seed), int(first_matrix), Xt.data_ptr(), W0.data_ptr(), H0.data_ptr()))
+    return W0, H0
+
+
+def rank_sweep_native(X, k_min: int, k_max: int, *, vaf_threshold: float = 0.90, max_iter: int = 500, tol: float = 1e-4,
+                      seed: int = 0, first_matrix: int = 0, device=None, handle: Optional[_lib.Handle] = None) -> "RankSweepResult":
+    """:func:`rank_sweep_batched` as ONE library call (``hipnmf_rank_sweep_*``: random starting points, fits, VAF
+    table and threshold selection inside the library; usable from any host language).  Frobenius loss,
+    ``init='random'`` from the library's generator; ``vaf[k]`` holds the all-muscles column only."""
+    torch = _torch()
+    dev = resolve_device(device)
+    Xt = _as_device_tensor(X, dev)
+    if Xt.dim() == 2:
+        Xt = Xt.unsqueeze(0)
+    if Xt.dtype not in (torch.float32, torch.float64):
+        Xt = Xt.to(torch.float64)
+    B, T, m = Xt.shape
+    if not 1 <= k_min <= k_max <= m:
+        raise ValueError("invalid number of components")
+    layout, ldx, xbs, Xt = _x_layout(Xt)
+    nk = k_max - k_min + 1
+    p = make_problem(B, T, m, k_max, x_layout=layout, ldx=ldx, x_batch_stride=xbs, w_layout=_lib.W_ROW_MAJOR,
+                     max_iter=max_iter, tol=tol)
+    W_ws = torch.empty((B, T, k_max), dtype=Xt.dtype, device=dev)
+    H_all = torch.empty((B * m * sum(range(k_min, k_max + 1)),), dtype=Xt.dtype, device=dev)
+    vaf = torch.empty((B, nk), dtype=Xt.dtype, device=dev)
+    err = torch.empty((B, nk), dtype=Xt.dtype, device=dev)
+    n_iter = torch.empty((B, nk), dtype=torch.int32, device=dev)
+    sel = torch.empty((B,), dtype=torch.int32, device=dev)
+    h = handle if handle is not None else _lib.get_handle(dev.index)
+    fn = getattr(_lib.load(), "hipnmf_rank_sweep_f32" if Xt.dtype == torch.float32 else "hipnmf_rank_sweep_f64")
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_double, ctypes.c_uint64, ctypes.c_int32] + \
+                  [ctypes.c_void_p] * 7
+    fn.restype = ctypes.c_int
+    torch.cuda.synchronize(dev)
+    _lib.check(fn(h.ptr, ctypes.addressof(p), int(k_min), int(k_max), float(vaf_threshold), int(seed), int(first_matrix),
+                  Xt.data_ptr(), W_ws.data_ptr(), H_all.data_ptr(), vaf.data_ptr(), sel.data_ptr(), err.data_ptr(), n_iter.data_ptr()))
+    ranks = list(range(k_min, k_max + 1))
+    comps, off = {}, 0
+    for k in ranks:
+        comps[k] = H_all[off:off + B * k * m].view(B, k, m)
+        off += B * k * m
+    return RankSweepResult(ranks, vaf, {k: vaf[:, i:i + 1] for i, k in enumerate(ranks)}, {k: n_iter[:, i] for i, k in enumerate(ranks)},
+                           {k: err[:, i] for i, k in enumerate(ranks)}, comps, sel.to(torch.int64), float("nan"))
+
+
 @dataclass
 class RankSweepResult:
     """Per-trial rank sweep: ``vaf_all[b, i]`` is the "All signals" VAF of trial ``b`` at rank ``ranks[i]``;

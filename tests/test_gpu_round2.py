@@ -541,3 +541,69 @@ def test_native_tsharded_fit_two_processes_over_gloo(tmp_path):
     W = np.concatenate([p["W"] for p in parts], axis=0)
     assert _rel_wh(X, W, parts[0]["H"], ref) <= 1e-9
     assert abs(float(parts[0]["err"][0]) - float(ref["reconstruction_err"])) / np.linalg.norm(X) <= 1e-9
+
+
+# ------------------------------------------------------------------------------------------------ native init / rank sweep
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_device_random_init_law_and_invariances(dtype):
+    """hipnmf_random_init_*: sklearn's init='random' law (sqrt(mean(X)/k) |N(0,1)|, _nmf.py:303-314) from the library's
+    counter-based generator -- moments of the half-normal, independence of the X layout and of the batch split."""
+    import torch
+
+    import muscle_synergies_amd as ms
+    from muscle_synergies_amd.synth import emg_batch
+
+    B, T, m, k = 6, 4000, 16, 5
+    Xb = emg_batch(range(200, 200 + B), T=T, m=m).astype(dtype)  # [B, m, T]
+    Xc = torch.from_numpy(Xb).cuda().transpose(1, 2)             # channel-major storage
+    Xr = Xc.contiguous()                                         # row-major storage
+    W0, H0 = ms.random_init_device(Xc, k, seed=11)
+    W1, H1 = ms.random_init_device(Xr, k, seed=11)
+    assert torch.equal(W0, W1) and torch.equal(H0, H1)           # layout of X does not matter
+    Wa, Ha = ms.random_init_device(Xc[:2], k, seed=11)
+    Wb, Hb = ms.random_init_device(Xc[2:], k, seed=11, first_matrix=2)
+    assert torch.equal(torch.cat([Wa, Wb]), W0) and torch.equal(torch.cat([Ha, Hb]), H0)  # nor does the batch split
+    W2, _ = ms.random_init_device(Xc, k, seed=12)
+    assert not torch.equal(W0, W2)
+    for b in range(B):
+        avg = np.sqrt(Xb[b].astype(np.float64).mean() / k)
+        w = W0[b].double().cpu().numpy() / avg
+        assert (w > 0).all() and abs(w.mean() - np.sqrt(2 / np.pi)) < 0.02 and abs((w ** 2).mean() - 1.0) < 0.03
+        assert abs(np.corrcoef(w[:-1, 0], w[1:, 0])[0, 1]) < 0.05 and abs(np.corrcoef(w[:, 0], w[:, 1])[0, 1]) < 0.05
+        hh = H0[b].double().cpu().numpy() / avg
+        assert (hh > 0).all() and 0.4 < hh.mean() < 1.3
+
+
+@pytest.mark.gpu
+def test_native_rank_sweep_equals_its_parts_and_the_oracle():
+    """hipnmf_rank_sweep_f32 (config #4 as one library call) = hipnmf_random_init + hipnmf_fit_batched per rank, bit for
+    bit; the VAF table, the threshold selection, and one trial against the oracle from the same starting point."""
+    import torch
+
+    import muscle_synergies_amd as ms
+    from muscle_synergies_amd.synth import emg_batch
+
+    B, T, m = 10, 1500, 16
+    Xb = emg_batch(range(300, 300 + B), T=T, m=m, k_true=4)
+    X = torch.from_numpy(Xb).cuda().transpose(1, 2)
+    sw = ms.rank_sweep_native(X, 2, 6, vaf_threshold=0.9, max_iter=120, tol=0.0, seed=5)
+    assert sw.ranks == [2, 3, 4, 5, 6] and tuple(sw.vaf_all.shape) == (B, 5)
+    for i, k in enumerate(sw.ranks):
+        W0, H0 = ms.random_init_device(X, k, seed=5 + k)
+        r = ms.fit_batched(X, W0, H0, max_iter=120, tol=0.0)
+        assert torch.equal(r.H, sw.components[k])
+        torch.testing.assert_close(r.vaf[:, 0], sw.vaf_all[:, i], rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(r.reconstruction_err, sw.reconstruction_err[k])
+        assert int(sw.n_iter[k][0]) == 120
+        if k == 4:
+            ref = orc.nmf_mu_fit(X[3].cpu().numpy(), W0[3].cpu().numpy(), H0[3].cpu().numpy(), max_iter=120, tol=0.0)
+            assert abs(float(sw.reconstruction_err[k][3]) - float(ref["reconstruction_err"])) / np.linalg.norm(Xb[3]) <= TOL
+    v = sw.vaf_all.cpu().numpy()
+    sel = sw.selected.cpu().numpy()
+    for b in range(B):
+        ok = np.nonzero(v[b] >= 0.9)[0]
+        assert sel[b] == (sw.ranks[ok[0]] if len(ok) else -1)
+    assert (np.diff(v, axis=1) > -5e-3).all()  # VAF grows with the rank (up to local-minimum noise)
+    with pytest.raises(ValueError, match="invalid number of components"):
+        ms.rank_sweep_native(X, 3, 17)

@@ -33,6 +33,17 @@ for sfx in ("f32", "f64"):
         if have_gpu:
             assert f(h, ctypes.byref(bad), *nul[:nargs]) < 0, fn        # ABI guard
             assert f(h, ctypes.byref(p), *nul[:nargs]) < 0, fn          # NULL arrays
+    f = getattr(lib, f"hipnmf_random_init_{sfx}")
+    f.restype = ctypes.c_int
+    f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int32] + [ctypes.c_void_p] * 3
+    assert f(None, ctypes.byref(p), 1, 0, None, None, None) < 0
+    f = getattr(lib, f"hipnmf_rank_sweep_{sfx}")
+    f.restype = ctypes.c_int
+    f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_double, ctypes.c_uint64, ctypes.c_int32] + \
+                 [ctypes.c_void_p] * 7
+    assert f(None, ctypes.byref(p), 2, 4, 0.9, 1, 0, *([None] * 7)) < 0
+    if have_gpu:
+        assert f(h, ctypes.byref(p), 4, 2, 0.9, 1, 0, *([None] * 7)) < 0
     f = getattr(lib, f"hipnmf_fit_ragged_{sfx}")
     f.restype = ctypes.c_int
     assert f(None, ctypes.byref(p), None, *nul[:7]) < 0
