@@ -20,14 +20,8 @@ template <typename real, int G, int CH, int K>
 KernelSet<real> make_kernel_set() {
   KernelSet<real> ks;
   ks.fit_persistent = fit_persistent_kernel<real, G, CH, K>;
-  if constexpr (h_in_lds<G, CH>())
-    ks.fit_persistent_kl = nullptr;
-  else
-    ks.fit_persistent_kl = fit_persistent_kernel<real, G, CH, K, 1>;
-  if constexpr (h_in_lds<G, CH>())
-    ks.fit_coop = nullptr;
-  else
-    ks.fit_coop = fit_coop_kernel<real, G, CH, K>;
+  ks.fit_persistent_kl = fit_persistent_kernel<real, G, CH, K, 1>;  // H in registers whatever the Frobenius kernels do
+  ks.fit_coop = fit_coop_kernel<real, G, CH, K>;
   ks.slice_pass = slice_pass_kernel<real, G, CH, K>;
   ks.reduce_slices = reduce_slices_kernel<real, G, CH, K>;
   ks.hupdate = hupdate_kernel<real, G, CH, K>;

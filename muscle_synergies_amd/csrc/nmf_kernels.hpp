@@ -240,14 +240,17 @@ template <int G, int CH, int K>
 constexpr int h_lds_rows() {
   return (x_row_major<G, CH>() && K >= 4 && (HIPNMF_ROW_HLDS) > 0) ? (HIPNMF_ROW_HLDS) : 0;
 }
-// Experimental: H broadcast from LDS per tile instead of K x CH VGPRs (-DHIPNMF_HLDS_CH8, G=2/CH=8 instance)
-template <int G, int CH>
+// H broadcast from LDS per tile instead of K x CH VGPRs per lane: the Frobenius kernels of the float64 (G=4, CH=8)
+// mapping (17..32 channels), where H alone would take 2 K CH = 80..128 registers and the instance spilled up to
+// 1.8 KB per lane (tools/quick_bench.py, 32 channels: k = 5 1.18 -> 1.53, k = 8 0.21 -> 0.39 M matrix-it/s).  The KL
+// iteration (LOSS = 1) keeps H in registers.  -DHIPNMF_HLDS_CH8 extends it to every CH = 8 channel-major instance.
+template <typename real, int G, int CH, int LOSS = 0>
 constexpr bool h_in_lds() {
+  if (LOSS != 0) return false;
 #ifdef HIPNMF_HLDS_CH8
-  return CH >= 8 && !x_row_major<G, CH>();
-#else
-  return false;
+  if (CH >= 8 && !x_row_major<G, CH>()) return true;
 #endif
+  return sizeof(real) == 8 && G == 4 && CH == 8;
 }
 
 template <typename real, int G, int CH, int K>
@@ -255,8 +258,8 @@ constexpr int max_threads() {
   if constexpr (x_row_major<G, CH>() && K * CH * (int)(sizeof(real) / 4) <= (sizeof(real) == 4 ? 80 : 64))
     return HIPNMF_MAXNT;  // H + sums fit two waves per SIMD (fp32: k*CH <= 80; fp64 (1,8): k <= 4)
   constexpr int words = (int)(sizeof(real) / 4);
-  constexpr int est = words * ((h_in_lds<G, CH>() ? 1 : 2) * K * CH + K * (K + 1) / 2 + 3 * G * CH + G * K + 40 +
-                               (h_in_lds<G, CH>() ? 24 : 0));
+  constexpr int est = words * ((h_in_lds<real, G, CH>() ? 1 : 2) * K * CH + K * (K + 1) / 2 + 3 * G * CH + G * K + 40 +
+                               (h_in_lds<real, G, CH>() ? 24 : 0));
   return est > 215 ? 256 : (HIPNMF_MAXNT);
 }
 
@@ -435,7 +438,7 @@ __device__ __forceinline__ void update_tile(RowTile<real, G, CH, K>& t, const Ma
   const int g = ma.g;
   // numerator X H^T (_nmf.py:543): partial over this lane's channels, for each of the G rows
   real pn[G][K];
-  if constexpr (h_in_lds<G, CH>()) {
+  if constexpr (h_in_lds<real, G, CH>()) {
     constexpr int MP = G * CH;
     const real* hp = ma.h_lds + g * CH;
     asm volatile("" : "+v"(hp));  // opaque per tile: keeps the K*CH broadcast reads inside the row loop
@@ -630,7 +633,7 @@ __device__ __forceinline__ double log_(double a) { return ::log(a); }
 template <typename real, int G, int CH, int K, int LOSS = 0>
 __device__ __forceinline__ void resid_tile(const RowTile<real, G, CH, K>& t, const MatAddr<real, G, CH, K>& ma,
                                            const real (&h)[K][CH], real (&sse)[CH], real (&xsq)[CH], real& kl) {
-  if constexpr (h_in_lds<G, CH>()) {
+  if constexpr (h_in_lds<real, G, CH, LOSS>()) {
     constexpr int MP = G * CH;
     const real* hp = ma.h_lds + ma.g * CH;
     asm volatile("" : "+v"(hp));
@@ -737,10 +740,10 @@ __device__ __forceinline__ void compute_hht(Smem<real, G, CH, K>& s) {
   }
 }
 
-template <typename real, int G, int CH, int K>
+template <typename real, int G, int CH, int K, int LOSS = 0>
 __device__ __forceinline__ void load_h_regs(const Smem<real, G, CH, K>& s, int g, real (&h)[K][CH], real (&hht)[K][K]) {
   constexpr int MP = G * CH;
-  if constexpr (!h_in_lds<G, CH>()) {
+  if constexpr (!h_in_lds<real, G, CH, LOSS>()) {
 #pragma unroll
     for (int c = 0; c < K - h_lds_rows<G, CH, K>(); ++c)
 #pragma unroll
@@ -810,7 +813,7 @@ __device__ __forceinline__ void rows_update_pass(const MatAddr<real, G, CH, K>& 
   for (int grp = 0; grp < nfull; ++grp) {
 #pragma unroll
     for (int p = 0; p < PF; ++p) {
-      constexpr bool STAGE = WLDS && LOSS == 0 && (HIPNMF_WSTAGE != 0) && !h_in_lds<G, CH>();
+      constexpr bool STAGE = WLDS && LOSS == 0 && (HIPNMF_WSTAGE != 0) && !h_in_lds<real, G, CH, LOSS>();
       if constexpr (LOSS == 1)
         update_tile_kl<real, G, CH, K>(tiles[p], ma, h, hht, accA, accB, l1w, l2w, update_h);
       else
@@ -833,7 +836,7 @@ __device__ __forceinline__ void rows_update_pass(const MatAddr<real, G, CH, K>& 
 #pragma unroll
   for (int p = 0; p < PF - 1; ++p) {
     if (p < rem) {  // wave-uniform
-      constexpr bool STAGE = WLDS && LOSS == 0 && (HIPNMF_WSTAGE != 0) && !h_in_lds<G, CH>();
+      constexpr bool STAGE = WLDS && LOSS == 0 && (HIPNMF_WSTAGE != 0) && !h_in_lds<real, G, CH, LOSS>();
       if constexpr (LOSS == 1)
         update_tile_kl<real, G, CH, K>(tiles[p], ma, h, hht, accA, accB, l1w, l2w, update_h);
       else
@@ -1237,7 +1240,7 @@ __global__ void __launch_bounds__((max_threads<real, G, CH, K>())) HIPNMF_OCC fi
     compute_hht(s);
   __syncthreads();
   real h[K][CH], hht[K][K];
-  load_h_regs(s, g, h, hht);
+  load_h_regs<real, G, CH, K, LOSS>(s, g, h, hht);
 
   // reconstruction error from the block sums in s.part: ||X - WH||_F, or sqrt(2 KL(X || WH)) (_nmf.py:185-189)
   auto error_from_part = [&]() -> real {
@@ -1317,7 +1320,7 @@ __global__ void __launch_bounds__((max_threads<real, G, CH, K>())) HIPNMF_OCC fi
 #ifdef HIPNMF_TIMING
       const unsigned long long tm5 = __builtin_readcyclecounter();
 #endif
-      load_h_regs(s, g, h, hht);
+      load_h_regs<real, G, CH, K, LOSS>(s, g, h, hht);
 #ifdef HIPNMF_TIMING
       const unsigned long long tm6 = __builtin_readcyclecounter();
       tacc[0] += tm1 - tm0; tacc[1] += tm2 - tm1; tacc[2] += tm3 - tm2; tacc[3] += tm4 - tm3; tacc[4] += tm5 - tm4; tacc[5] += tm6 - tm5;
