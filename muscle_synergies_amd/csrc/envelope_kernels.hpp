@@ -773,18 +773,20 @@ __global__ void __launch_bounds__(64) emg_wave_kernel(EnvArgs a, int ring /* pow
 // workgroup split the series into NW segments (each re-runs the prefix over the W samples before its segment) and
 // keep BOTH their samples and their outputs in registers: all samples are requested at once (one memory latency per
 // series), the mean comes from the same registers, and the envelope goes to memory once, already divided by the
-// maximum: 2 sizeof(real) per sample, the algorithmic minimum.  LDS holds only the rings, so two workgroups share a
-// CU and one's memory wait / barriers overlap the other's arithmetic.
+// maximum: 2 sizeof(real) per sample, the algorithmic minimum.  LDS holds only the rings, so (float) two workgroups
+// share a CU and one's memory wait / barriers overlap the other's arithmetic.
 // =================================================================================================
-constexpr int ENV_WG_WAVES = 8, ENV_WG_SPL = 4;
-#define ENV_WG_MAXT(real) (sizeof(real) == 4 ? 12 : 6)  // tiles of 256 samples a wave can hold in registers
+// Instances (NW waves x MAXT tiles of 256 samples in registers): float 8 x 12 (two workgroups per CU, <= 128 VGPRs);
+// double 8 x 6 for series of up to 8192 samples, and 16 x 7 -- one 1024-thread workgroup per CU, no overlap between
+// workgroups, but 2 instead of 5 sizeof(double) of traffic per sample -- up to 20 480.
+constexpr int ENV_WG_SPL = 4;
 
-template <typename real>
-__global__ void __launch_bounds__(64 * ENV_WG_WAVES) emg_wg_kernel(EnvArgs a, int ring) {
+template <typename real, int NW, int MAXT>
+__global__ void __launch_bounds__(64 * NW) emg_wg_kernel(EnvArgs a, int ring) {
   extern __shared__ __attribute__((aligned(16))) unsigned char env_smem[];
   constexpr int SPL = ENV_WG_SPL;
   using Wv = EnvWave<real, SPL>;
-  constexpr int TILE = Wv::TILE, NW = ENV_WG_WAVES, MAXT = ENV_WG_MAXT(real);
+  constexpr int TILE = Wv::TILE;
   const int ring_entries = ring + ring / 8;
   double* rings = reinterpret_cast<double*>(env_smem);  // [NW][ring_entries]
   double* scratch = rings + (size_t)NW * ring_entries;  // [NW]

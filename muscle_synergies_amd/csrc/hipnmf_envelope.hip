@@ -69,12 +69,25 @@ int envelope_impl(hipnmf_handle* h, const hipnmf_envelope_params* p, const real*
   constexpr int WG_TILE = 64 * ENV_WG_SPL;
   int ring4 = 512;
   while (ring4 < WG_TILE + p->window + 1 && ring4 < 8192) ring4 *= 2;
-  const size_t wg_lds = sizeof(double) * ((size_t)ENV_WG_WAVES * (ring4 + ring4 / 8) + ENV_WG_WAVES);
   // tiles a wave walks: those before its segment (first window), its segment, those behind it (last window)
-  const long long wg_seg = ((T + ENV_WG_WAVES - 1) / ENV_WG_WAVES + WG_TILE - 1) / WG_TILE;
-  const long long wg_tiles = (p->window + WG_TILE - 1) / WG_TILE + wg_seg + ((p->window - 1) / 2 + 1 + WG_TILE - 1) / WG_TILE;
-  const bool wg = wave && wg_ok && (p->n_out == 0 || p->n_out == T) && WG_TILE + p->window + 1 <= ring4 && ring4 <= 4096 &&
-                  T >= 2LL * ENV_WG_WAVES * WG_TILE && wg_tiles <= ENV_WG_MAXT(real);
+  auto wg_tiles = [&](int nw) -> long long {
+    const long long seg = ((T + nw - 1) / nw + WG_TILE - 1) / WG_TILE;
+    return (p->window + WG_TILE - 1) / WG_TILE + seg + ((p->window - 1) / 2 + 1 + WG_TILE - 1) / WG_TILE;
+  };
+  // instance: float 8 waves x 12 tiles; double 8 x 6 while the series fits, else 16 x 7 (envelope_kernels.hpp).
+  // Measured against emg_wave_kernel (tools/envelope_wg_sweep.sh): float wins from ~9 K samples on (the walk before /
+  // behind a wave's segment costs two extra tiles per wave, and the wave kernel's working set still fits the Infinity
+  // Cache below that); double moves twice the bytes and wins from 4 K samples on with 8 waves.
+  int wg_nw = 0;
+  if (sizeof(real) == 4) {
+    if (T >= 9216 && wg_tiles(8) <= 12) wg_nw = 8;
+  } else {
+    if (T >= 4096 && wg_tiles(8) <= 6) wg_nw = 8;
+    else if (T > 8192 && wg_tiles(16) <= 7) wg_nw = 16;
+  }
+  const size_t wg_lds = sizeof(double) * ((size_t)wg_nw * (ring4 + ring4 / 8) + (size_t)wg_nw);
+  const bool wg = wave && wg_ok && wg_nw > 0 && (p->n_out == 0 || p->n_out == T) && WG_TILE + p->window + 1 <= ring4 &&
+                  ring4 <= 4096 && wg_lds <= (size_t)h->lds_per_block;
   const bool fused = wave || (fused_ok && fused_lds <= 96 * 1024);
   const bool resample_tab = wave && p->n_out > 0 && p->n_out != T;
   const size_t o_ti = resample_tab ? carve(sizeof(int) * (size_t)p->n_out) : 0;
@@ -117,10 +130,18 @@ int envelope_impl(hipnmf_handle* h, const hipnmf_envelope_params* p, const real*
     hipLaunchKernelGGL(env_resample_table_kernel, dim3((unsigned)((p->n_out + 255) / 256)), dim3(256), 0, st, (int)T, (int)p->n_out,
                        reinterpret_cast<int*>(ws + o_ti), reinterpret_cast<double*>(ws + o_tw));
   if (wg) {
-    if (wg_lds > 48 * 1024)
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(emg_wg_kernel<real>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)wg_lds));
-    hipLaunchKernelGGL((emg_wg_kernel<real>), dim3(m, B), dim3(64 * ENV_WG_WAVES), wg_lds, st, a, ring4);
+    auto launch_wg = [&](auto kern) -> int {
+      if (wg_lds > 48 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wg_lds));
+      hipLaunchKernelGGL(kern, dim3(m, B), dim3(64 * wg_nw), wg_lds, st, a, ring4);
+      return HIPNMF_OK;
+    };
+    int rcw;
+    if constexpr (sizeof(real) == 4)
+      rcw = launch_wg(emg_wg_kernel<real, 8, 12>);
+    else
+      rcw = wg_nw == 8 ? launch_wg(emg_wg_kernel<real, 8, 6>) : launch_wg(emg_wg_kernel<real, 16, 7>);
+    if (rcw) return rcw;
   } else if (wave) {
     const size_t lds = sizeof(double) * (size_t)(ring + ring / 8);
     if (wave_spl == 4)

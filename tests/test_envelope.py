@@ -111,11 +111,17 @@ _KERNEL_CASES = [
     (8001, 2, 200, None, True, False, np.float64),    # workgroup kernel, ragged last tile, unaligned rows (F layout)
     (20000, 2, 200, None, True, True, np.float32),    # workgroup kernel, fp32 (the benchmark shape)
     (20480, 1, 256, None, False, True, np.float32),   # workgroup kernel at its register limit, not normalised
-    (4096, 2, 50, None, True, True, np.float32),      # workgroup kernel, shortest series it takes
+    (9216, 2, 50, None, True, True, np.float32),      # workgroup kernel, shortest float series it takes
+    (9215, 2, 50, None, True, True, np.float32),      # ... one sample shorter: wave kernel
+    (20000, 2, 200, None, True, True, np.float64),    # workgroup kernel, float64: 16 waves x 7 tiles
+    (20480, 1, 255, None, True, False, np.float64),   # ... at its register limit
+    (8193, 2, 64, None, True, True, np.float64),      # ... shortest series of the 16-wave instance
+    (4096, 2, 64, None, True, True, np.float64),      # float64 with 8 waves x 6 tiles: shortest series
+    (4096, 2, 1000, None, False, True, np.float64),   # window too long for the 8-wave instance's six tiles: wave kernel
     (20000, 2, 200, 200, True, True, np.float32),     # wave kernel, time-normalised (the tutorial's chain)
     (8000, 3, 201, 150, True, True, np.float64),      # wave kernel, time-normalised, fp64
     (8192, 2, 100, 2000, False, True, np.float64),    # wave kernel, dense time normalisation
-    (9000, 3, 200, None, False, True, np.float64),    # wave kernel, full length (fp64 series too long for the registers)
+    (21000, 2, 200, None, False, True, np.float64),   # wave kernel, full length (series too long for the registers)
     (70001, 2, 150, None, True, True, np.float64),    # wave kernel, prefix re-based past 65 536 samples
     (70000, 2, 150, 1000, True, True, np.float64),    # wave kernel, time-normalised, re-based
     (70000, 1, 150, None, True, True, np.float32),    # wave kernel fp32 (too long for the workgroup kernel)
