@@ -387,7 +387,7 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
   if (coop) {
     o_cpart = carve(sizeof(real) * (size_t)B * 2 * coop_S * ks->NACC);
     o_ccol = carve(sizeof(real) * (size_t)B * 2 * coop_S * 2 * ks->MP);
-    o_sync = carve(sizeof(unsigned) * ((size_t)B + 1));
+    o_sync = carve(sizeof(unsigned) * ((size_t)B + 2 + 10 * (size_t)B + 1024 * (size_t)B));  // + same-XCD mode: 'updates began', tickets, target, flags
   }
   size_t o_fsync = 0;
   if (!persistent) o_fsync = carve(sizeof(unsigned) * (size_t)B);
@@ -476,7 +476,7 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
   a.rows_per_slice = (int)round_up(T, 64);
 
   HIP_TRY(hipEventRecord(h->ev0, st));
-  bool coop_done = false;
+  bool coop_done = false, coop_xcd_used = false;
   if (coop) {
     SolveArgs<real> c = a;
     c.S = coop_S;
@@ -485,18 +485,27 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
     c.part = reinterpret_cast<real*>(ws + o_cpart);
     c.colpart = reinterpret_cast<real*>(ws + o_ccol);
     c.sync = reinterpret_cast<unsigned*>(ws + o_sync);
-    HIP_TRY(hipMemsetAsync(c.sync, 0, sizeof(unsigned) * ((size_t)B + 1), st));
-    const void* kern = reinterpret_cast<const void*>(ks->fit_coop);
+    // Same-XCD mode (one matrix: BASELINE config #2): the S workgroups are picked on ONE XCD out of a grid of 8 S and
+    // exchange their records through that XCD's L2 (fit_coop_kernel, coop_barrier_xcd): 7.4 -> 6.5 us per iteration.
+    // HIPNMF_COOP_XCD=0 keeps the device-scope exchange.
+    static const int coop_xcd_env = [] {  // 0 off, 1 on (default), 2 test hook: one slice stays away from the head count
+      const char* e = getenv("HIPNMF_COOP_XCD");
+      return e ? atoi(e) : 1;
+    }();
+    c.coop_xcd = (coop_xcd_env > 0 && !h->coop_xcd_failed && B == 1 && coop_S >= 2 && coop_S <= 32 && 8 * coop_S <= h->num_cu) ? coop_xcd_env : 0;
+    const void* kern = reinterpret_cast<const void*>(c.coop_xcd ? ks->fit_coop_xcd : ks->fit_coop);
     if (coop_smem > 48 * 1024)
       HIP_TRY(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)coop_smem));
+    HIP_TRY(hipMemsetAsync(c.sync, 0, sizeof(unsigned) * ((size_t)B + 2 + 10 * (size_t)B + 1024 * (size_t)B), st));
     void* args[] = {&c};
-    const hipError_t e = hipLaunchCooperativeKernel(kern, dim3(coop_S, B), dim3(coop_threads), args,
+    const hipError_t e = hipLaunchCooperativeKernel(kern, dim3(c.coop_xcd ? 8 * coop_S : coop_S, B), dim3(coop_threads), args,
                                                     (unsigned)coop_smem, st);
+    coop_xcd_used = c.coop_xcd != 0;
     if (e == hipSuccess) {
       coop_done = true;
       h->last_path = 3;
-      snprintf(h->last_kernel, sizeof(h->last_kernel), "fit_coop_kernel<%s,%d,%d,%d>",
-               sizeof(real) == 4 ? "float" : "double", ks->G, ks->CH, ks->K);
+      snprintf(h->last_kernel, sizeof(h->last_kernel), "fit_coop_kernel<%s,%d,%d,%d%s>",
+               sizeof(real) == 4 ? "float" : "double", ks->G, ks->CH, ks->K, c.coop_xcd ? ",xcd" : "");
     } else {
       (void)hipGetLastError();  // not launchable as a cooperative grid on this device: use the regular paths
       if (h->variant == 3)
@@ -652,9 +661,16 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
   HIP_TRY(hipStreamSynchronize(st));
   HIP_TRY(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
   if (coop_done) {  // a barrier that gave up (workgroups not co-resident after all) leaves the abort flag set
-    unsigned aborted = 0;
-    HIP_TRY(hipMemcpy(&aborted, reinterpret_cast<unsigned*>(ws + o_sync) + B, sizeof(unsigned), hipMemcpyDeviceToHost));
-    if (aborted) return fail(HIPNMF_ERR_HIP, "cooperative fit: a grid barrier timed out (results are invalid)");
+    unsigned flags2[2] = {0, 0};  // abort flag, 'updates began' word of the same-XCD mode
+    HIP_TRY(hipMemcpy(flags2, reinterpret_cast<unsigned*>(ws + o_sync) + B, sizeof(flags2), hipMemcpyDeviceToHost));
+    if (flags2[0] && coop_xcd_used && !flags2[1]) {
+      // same-XCD mode: fewer than S workgroups turned up on the chosen XCD, the head count timed out before anything was
+      // updated (W, H and the layout round trip of W are value-preserving): run again with the device-scope exchange,
+      // and do not try the same-XCD mode again on this handle
+      h->coop_xcd_failed = true;
+      return fit_batched_impl<real>(h, p, X, W, H, err_out, n_iter_out, sse_col_out, xsq_col_out, ragged);
+    }
+    if (flags2[0]) return fail(HIPNMF_ERR_HIP, "cooperative fit: a grid barrier timed out (results are invalid)");
   }
   return HIPNMF_OK;
 }

@@ -18,6 +18,7 @@ struct hipnmf_handle {
   int max_slices = 0;  // 0 = default
   int variant = 0;     // 0 auto, 1 force persistent, 2 force sliced, 3 force cooperative
   int last_path = 0;   // path the last fit took: 1 persistent, 2 sliced, 3 cooperative
+  bool coop_xcd_failed = false;  // the same-XCD cooperative mode found fewer workgroups than slices once: not tried again
   char last_kernel[96] = {0};  // instance name of the solver kernel the last fit launched (hipnmf_last_kernel)
   int num_cu = 256;
   int lds_per_block = 65536;  // hipDeviceProp_t::maxSharedMemoryPerMultiProcessor (160 KiB on MI355X)

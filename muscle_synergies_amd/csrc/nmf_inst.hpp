@@ -10,6 +10,7 @@ struct KernelSet {
   using Fn = void (*)(SolveArgs<real>);
   Fn fit_persistent, slice_pass, reduce_slices, hupdate, slice_resid, resid_finalize;
   Fn fit_persistent_kl;  // Kullback-Leibler loss (persistent path only); nullptr where not built
+  Fn fit_coop_xcd;      // cooperative kernel, same-XCD exchange (one matrix)
   Fn fit_coop;           // cooperative multi-workgroup fit of few long matrices (Frobenius); nullptr where not built
   int G, CH, K, MP, NACC, max_threads;
   bool row_major;  // the instance streams X row-major (rows of MP values) instead of channel-major
@@ -22,6 +23,7 @@ KernelSet<real> make_kernel_set() {
   ks.fit_persistent = fit_persistent_kernel<real, G, CH, K>;
   ks.fit_persistent_kl = fit_persistent_kernel<real, G, CH, K, 1>;  // H in registers whatever the Frobenius kernels do
   ks.fit_coop = fit_coop_kernel<real, G, CH, K>;
+  ks.fit_coop_xcd = fit_coop_kernel<real, G, CH, K, true>;
   ks.slice_pass = slice_pass_kernel<real, G, CH, K>;
   ks.reduce_slices = reduce_slices_kernel<real, G, CH, K>;
   ks.hupdate = hupdate_kernel<real, G, CH, K>;

@@ -293,6 +293,8 @@ struct SolveArgs {
   const long long* ragged;  // [B][4] = {T_b, X offset, leading dimension, W offset} (elements) or nullptr
   unsigned* sync;     // cooperative kernel: [B] arrival counters (zeroed before the launch) followed by one abort flag;
                       // sliced path with fuse_h: [B] arrival counters (the last slice to finish updates H)
+  int coop_xcd;       // fit_coop_kernel<..., XCD = true> (the S workgroups of a matrix picked on ONE XCD, exchange through its L2): 2 = test hook
+                      // (sync then continues with an 'updates began' word, [B][8] tickets, [B] target XCD + 1, [B][32] generation flags 32 words apart)
   int fuse_h;         // slice_pass_kernel: 1 = the last workgroup of a matrix sums the records and updates H itself
   real tol, l1w, l2w, l1h, l2h;
 };
@@ -1419,6 +1421,42 @@ __device__ __forceinline__ bool coop_barrier(unsigned* counter, unsigned* abort_
   return ok_sh != 0;
 }
 
+// Same-XCD flavour (a.coop_xcd): every workgroup of the matrix runs on one XCD, whose L2 all of them share.  Records
+// are PLAIN stores (written through this CU's L1 into that L2, where the line stays), every storing wave waits for
+// them (vmcnt(0)), then the workgroup barrier, then ONE lane publishes the workgroup's generation number the same way;
+// the peers poll the S generation words and read the records with L1-bypassing loads (sc1: served by the L2).  No
+// atomic, no write-through to memory, no fabric round trip.
+__device__ __forceinline__ bool coop_barrier_xcd(unsigned* flags /* [32 * 32] words: workgroup i owns word 32 i */, unsigned* abort_flag,
+                                                 unsigned S, unsigned sl, unsigned n) {
+  __shared__ int ok_xcd_sh;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x < WAVE) {
+    if (threadIdx.x == 0) {
+      *reinterpret_cast<volatile unsigned*>(flags + 32u * sl) = n;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    int ok = 1;
+    unsigned spins = 0;
+    const unsigned* mine = flags + 32u * (threadIdx.x < S ? threadIdx.x : 0u);
+    while (true) {
+      const unsigned v = __hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sc1: L2-served
+      if (__all((int)(v >= n))) break;
+      __builtin_amdgcn_s_sleep(1);
+      if ((++spins & 1023u) == 0) {
+        if (spins > HIPNMF_COOP_SPIN_LIMIT) __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__any((int)(__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u))) {
+          ok = 0;
+          break;
+        }
+      }
+    }
+    if (threadIdx.x == 0) ok_xcd_sh = ok;
+  }
+  __syncthreads();
+  return ok_xcd_sh != 0;
+}
+
 // record exchanged between workgroups: device-scope relaxed atomic store / load (no cache holds a stale copy)
 template <typename real>
 __device__ __forceinline__ void coop_store(real* p, real v) {
@@ -1478,14 +1516,51 @@ __device__ __forceinline__ void coop_sum_records(const real* __restrict__ in, in
   }
 }
 
-template <typename real, int G, int CH, int K>
+// XCD: the same-XCD exchange (a compile-time flavour: with both protocols in one body the register allocation of the
+// tile loop suffered -- 14 -> 60 spilled registers, 7.4 -> 9.2 us per iteration)
+template <typename real, int G, int CH, int K, bool XCD = false>
 __global__ void __launch_bounds__((max_threads<real, G, CH, K>())) HIPNMF_OCC fit_coop_kernel(SolveArgs<real> a) {
   using C = Cfg<real, G, CH, K>;
   constexpr int MP = C::MP;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int nw = blockDim.x / WAVE;
   Smem<real, G, CH, K> s(smem_raw, nw);
-  const int b = blockIdx.y, sl = blockIdx.x, S = a.S;
+  const int b = blockIdx.y, S = a.S;
+  int sl = blockIdx.x;
+  unsigned* abort_flag = a.sync + gridDim.y;
+  unsigned* xflags = nullptr;
+  if constexpr (XCD) {
+    // Same-XCD mode: the grid holds 8 S workgroups per matrix; those that run on the XCD of the matrix's workgroup 0
+    // draw a ticket, the first S of them are the slices, everybody else leaves.  Placement (observed: workgroups
+    // are dealt round-robin over the XCDs) only decides whether S workgroups turn up -- the head count below is
+    // taken with the ordinary device-scope barrier BEFORE anything is updated; if it fails the launch aborts with
+    // W and H untouched and the host runs the ordinary cooperative kernel.
+    __shared__ int sl_sh;
+    unsigned* tickets = a.sync + gridDim.y + 2 + 8 * b;        // [B][8] (after the abort flag and the 'updates began' word)
+    unsigned* target = a.sync + gridDim.y + 2 + 8 * gridDim.y + b;  // [B]: XCD id + 1 of the matrix
+    xflags = a.sync + gridDim.y + 2 + 9 * gridDim.y + 32 * 32 * b;  // [B][32 * 32]
+    if (threadIdx.x == 0) {
+      unsigned xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      xcc &= 7u;
+      if (blockIdx.x == 0) __hip_atomic_store(target, xcc + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      unsigned tgt = 0, spins = 0;
+      while ((tgt = __hip_atomic_load(target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u && ++spins < HIPNMF_COOP_SPIN_LIMIT)
+        __builtin_amdgcn_s_sleep(1);
+      int mine = -1;
+      if (tgt == xcc + 1u) {
+        const unsigned t = __hip_atomic_fetch_add(tickets + xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t < (unsigned)(a.coop_xcd == 2 ? S - 1 : S)) mine = (int)t;  // 2: test hook, one slice stays away
+      }
+      sl_sh = mine;
+    }
+    __syncthreads();
+    sl = sl_sh;
+    if (sl < 0) return;
+    if (!coop_barrier(a.sync + b, abort_flag, (unsigned)S, 1u)) return;  // head count: S slices present, or nothing happens
+    if (sl == 0 && threadIdx.x == 0)  // from here on W and H change: the host may no longer fall back silently
+      __hip_atomic_store(abort_flag + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   const int lane = threadIdx.x & (WAVE - 1);
   const int wave = threadIdx.x / WAVE;
   const int g = lane % G;
@@ -1498,8 +1573,21 @@ __global__ void __launch_bounds__((max_threads<real, G, CH, K>())) HIPNMF_OCC fi
   real* __restrict__ Wb = a.W + (long long)b * a.w_bstride + row_begin;
   real* __restrict__ Hb = a.H + (long long)b * K * m;
   unsigned* counter = a.sync + b;
-  unsigned* abort_flag = a.sync + gridDim.y;
-  unsigned nbar = 0;
+  unsigned nbar = XCD ? 1u : 0u;  // the head count was barrier 1
+  // records: device-scope atomics through the fabric, or (same-XCD mode) plain stores kept in the shared L2
+  auto put = [&](real* p_, real v_) __attribute__((always_inline)) {
+    if constexpr (XCD)
+      *p_ = v_;
+    else
+      coop_store(p_, v_);
+  };
+  auto barrier = [&]() __attribute__((always_inline)) -> bool {
+    ++nbar;
+    if constexpr (XCD)
+      return coop_barrier_xcd(xflags, abort_flag, (unsigned)S, (unsigned)sl, nbar);
+    else
+      return coop_barrier(counter, abort_flag, (unsigned)S, nbar);
+  };
   const int row_end = ((T + WAVE - 1) / WAVE) * WAVE;
   // rows [0, lds_rows) of the slice live in LDS for the whole fit (all of them when the slice fits), the rest
   // of W streams from global memory as in the persistent kernel
@@ -1530,8 +1618,8 @@ __global__ void __launch_bounds__((max_threads<real, G, CH, K>())) HIPNMF_OCC fi
   auto residual_all = [&]() {
     block_residual<real, G, CH, K>(s, ma, 0, row_end, h);
     real* mine = gcol + ((long long)(nres & 1) * S + sl) * (2 * MP);
-    if (threadIdx.x < 2 * MP) coop_store(mine + threadIdx.x, s.part[threadIdx.x]);
-    alive = coop_barrier(counter, abort_flag, (unsigned)S, ++nbar) && alive;
+    if (threadIdx.x < 2 * MP) put(mine + threadIdx.x, s.part[threadIdx.x]);
+    alive = barrier() && alive;
     coop_sum_records_atomic<real>(gcol + (long long)(nres & 1) * S * (2 * MP), S, 2 * MP, scratch, s.part);
     ++nres;
   };
@@ -1575,9 +1663,9 @@ __global__ void __launch_bounds__((max_threads<real, G, CH, K>())) HIPNMF_OCC fi
       for (int i = threadIdx.x; i < C::NACC; i += blockDim.x) {
         real acc = s.part[i];
         for (int w = 1; w < nw; ++w) acc += s.part[w * C::NACC + i];
-        coop_store(mine + i, acc);
+        put(mine + i, acc);
       }
-      alive = coop_barrier(counter, abort_flag, (unsigned)S, ++nbar) && alive;
+      alive = barrier() && alive;
       coop_sum_records_atomic<real>(gpart + (long long)(it & 1) * S * C::NACC, S, C::NACC, scratch, s.part);  // one record
       if (wave == 0) wave0_combine_and_update_h(s, 1, m, a.l1h, a.l2h);
       __syncthreads();

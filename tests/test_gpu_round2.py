@@ -607,3 +607,42 @@ def test_native_rank_sweep_equals_its_parts_and_the_oracle():
     assert (np.diff(v, axis=1) > -5e-3).all()  # VAF grows with the rank (up to local-minimum noise)
     with pytest.raises(ValueError, match="invalid number of components"):
         ms.rank_sweep_native(X, 3, 17)
+
+
+@pytest.mark.gpu
+def test_same_xcd_cooperative_mode_and_its_fallback(tmp_path):
+    """One matrix on the cooperative kernel: by default its workgroups are picked on one XCD and exchange through that
+    XCD's L2; HIPNMF_COOP_XCD=0 keeps the device-scope exchange; HIPNMF_COOP_XCD=2 makes one slice stay away, so the
+    head count times out BEFORE anything is updated and the library silently runs the device-scope exchange.  All
+    three must give bit-identical factors (same kernels, same summation order)."""
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r)\n"
+        "import muscle_synergies_amd as ms\n"
+        "from muscle_synergies_amd import _lib\n"
+        "from muscle_synergies_amd.synth import emg_matrix, random_init\n"
+        "X = emg_matrix(5, T=10000, m=16, dtype=np.float32); W0, H0 = random_init(X, 5, 5)\n"
+        "h = _lib.get_handle(0); h.set_tuning(0, 0, 3)\n"
+        "r = ms.fit_batched(X[None], W0[None], H0[None], max_iter=200, tol=0.0)\n"
+        "r2 = ms.fit_batched(X[None], W0[None], H0[None], max_iter=200, tol=0.0)\n"
+        "assert np.array_equal(np.asarray(r.W), np.asarray(r2.W))\n"
+        "np.savez(sys.argv[1], W=np.asarray(r.W), H=np.asarray(r.H), ms=r2.kernel_ms, kern=h.last_kernel())\n" % ROOT)
+    out = {}
+    for mode in ("1", "0", "2"):
+        path = str(tmp_path / f"mode{mode}.npz")
+        env = dict(os.environ, HIPNMF_COOP_XCD=mode)
+        r = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        out[mode] = np.load(path)
+        assert "fit_coop_kernel" in str(out[mode]["kern"])
+    for mode in ("0", "2"):
+        np.testing.assert_array_equal(out[mode]["W"], out["1"]["W"])
+        np.testing.assert_array_equal(out[mode]["H"], out["1"]["H"])
+    X = emg_matrix(5, T=10000, m=16, dtype=np.float32)
+    W0, H0 = random_init(X, 5, 5)
+    ref = orc.nmf_mu_fit(X, W0, H0, max_iter=200, tol=0.0)
+    assert _rel_wh(X, out["1"]["W"][0], out["1"]["H"][0], ref) <= TOL
