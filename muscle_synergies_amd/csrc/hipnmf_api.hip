@@ -385,7 +385,7 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
   size_t o_part = 0, o_sums = 0, o_col = 0, o_state = 0;
   size_t o_cpart = 0, o_ccol = 0, o_sync = 0;
   if (coop) {
-    o_cpart = carve(sizeof(real) * (size_t)B * 2 * coop_S * ks->NACC);
+    o_cpart = carve(2 * sizeof(real) * (size_t)B * 2 * coop_S * ks->NACC);  // x 2: 8-byte {value, generation} granules (same-XCD float flavour)
     o_ccol = carve(sizeof(real) * (size_t)B * 2 * coop_S * 2 * ks->MP);
     o_sync = carve(sizeof(unsigned) * ((size_t)B + 2 + 10 * (size_t)B + 1024 * (size_t)B));  // + same-XCD mode: 'updates began', tickets, target, flags
   }
@@ -497,6 +497,8 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
     if (coop_smem > 48 * 1024)
       HIP_TRY(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)coop_smem));
     HIP_TRY(hipMemsetAsync(c.sync, 0, sizeof(unsigned) * ((size_t)B + 2 + 10 * (size_t)B + 1024 * (size_t)B), st));
+    if (c.coop_xcd)  // generations of a previous fit must not look fresh
+      HIP_TRY(hipMemsetAsync(c.part, 0, 2 * sizeof(real) * (size_t)B * 2 * coop_S * ks->NACC, st));
     void* args[] = {&c};
     const hipError_t e = hipLaunchCooperativeKernel(kern, dim3(c.coop_xcd ? 8 * coop_S : coop_S, B), dim3(coop_threads), args,
                                                     (unsigned)coop_smem, st);

@@ -1504,6 +1504,64 @@ __device__ __forceinline__ void coop_sum_records_atomic(const real* __restrict__
   }
 }
 
+// Same-XCD flavour, float records: every element travels as one 8-byte granule {value, generation}, written with ONE
+// plain store -- the consumer needs neither a barrier nor a flag: it polls the granules it sums (L1-bypassing loads)
+// until their generation matches, which saves the publish / poll round trip of coop_barrier_xcd (~0.8 us of 6.4).
+// Same summation order as coop_sum_records_atomic.  Returns false after an abort.
+__device__ __forceinline__ bool coop_sum_records_tagged(const unsigned long long* __restrict__ in, int S, int nout, unsigned gen,
+                                                        float* scratch, float* __restrict__ out, unsigned* abort_flag) {
+  __shared__ int ok_tag_sh;
+  if (threadIdx.x == 0) ok_tag_sh = 1;
+  for (int o0 = 0; o0 < nout; o0 += blockDim.x) {
+    const int n = (nout - o0 < (int)blockDim.x) ? nout - o0 : (int)blockDim.x;
+    const int nq = (int)blockDim.x / n > 0 ? (int)blockDim.x / n : 1;
+    const int o = threadIdx.x % n, q = threadIdx.x / n;
+    float acc = 0.f;
+    bool ok = true;
+    if (q < nq) {
+      const unsigned long long* p = in + o0 + o;
+      for (int s0 = q; s0 < S && ok; s0 += 8 * nq) {
+        unsigned long long g[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {  // all of this thread's granules of the chunk in flight
+          const int sl = s0 + u * nq;
+          g[u] = sl < S ? __hip_atomic_load(p + (long long)sl * nout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int sl = s0 + u * nq;
+          if (sl < S) {
+            unsigned spins = 0;
+            while ((unsigned)(g[u] >> 32) != gen) {  // not published yet: poll this one
+              __builtin_amdgcn_s_sleep(1);
+              g[u] = __hip_atomic_load(p + (long long)sl * nout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              if ((++spins & 1023u) == 0) {
+                if (spins > HIPNMF_COOP_SPIN_LIMIT) __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                  ok = false;
+                  break;
+                }
+              }
+            }
+            acc += __uint_as_float((unsigned)g[u]);
+          }
+        }
+      }
+    }
+    if (!ok) ok_tag_sh = 0;
+    __syncthreads();
+    if (q < nq) scratch[q * n + o] = acc;
+    __syncthreads();
+    if ((int)threadIdx.x < n) {
+      float tot = 0.f;
+      for (int i2 = 0; i2 < nq; ++i2) tot += scratch[i2 * n + threadIdx.x];
+      out[o0 + threadIdx.x] = tot;
+    }
+    __syncthreads();
+  }
+  return ok_tag_sh != 0;
+}
+
 // out[o] = sum over the S records of in[record][o], o < nout (fixed order; nout may exceed the workgroup size)
 template <typename real>
 __device__ __forceinline__ void coop_sum_records(const real* __restrict__ in, int S, int nout, real* scratch,
@@ -1610,7 +1668,7 @@ __global__ void __launch_bounds__((max_threads<real, G, CH, K>())) HIPNMF_OCC fi
   real h[K][CH], hht[K][K];
   load_h_regs(s, g, h, hht);
 
-  real* __restrict__ gpart = a.part + (long long)b * S * 2 * C::NACC;  // [2][S][NACC], alternating per exchange
+  real* __restrict__ gpart = a.part + (long long)b * S * 2 * C::NACC * (XCD && sizeof(real) == 4 ? 2 : 1);  // [2][S][NACC], alternating per exchange (8-byte granules in the same-XCD float flavour)
   real* __restrict__ gcol = a.colpart + (long long)b * S * 2 * (2 * MP);  // [2][S][2*MP]
   unsigned nres = 0;
   bool alive = true;
@@ -1659,14 +1717,28 @@ __global__ void __launch_bounds__((max_threads<real, G, CH, K>())) HIPNMF_OCC fi
     if (a.update_h) {
       wave_reduce_acc<real, G, CH, K>(s.part + wave * C::NACC, accA, accB);
       __syncthreads();
-      real* mine = gpart + ((long long)(it & 1) * S + sl) * C::NACC;
-      for (int i = threadIdx.x; i < C::NACC; i += blockDim.x) {
-        real acc = s.part[i];
-        for (int w = 1; w < nw; ++w) acc += s.part[w * C::NACC + i];
-        put(mine + i, acc);
+      if constexpr (XCD && sizeof(real) == 4) {
+        // tagged granules {value, generation}: one plain 8-byte store per element, no barrier, no flag
+        unsigned long long* g64 = reinterpret_cast<unsigned long long*>(gpart) + (long long)(it & 1) * S * C::NACC;
+        const unsigned long long tag = (unsigned long long)((unsigned)it + 1u) << 32;
+        for (int i = threadIdx.x; i < C::NACC; i += blockDim.x) {
+          real acc = s.part[i];
+          for (int w = 1; w < nw; ++w) acc += s.part[w * C::NACC + i];
+          g64[(long long)sl * C::NACC + i] = tag | (unsigned long long)__float_as_uint((float)acc);
+        }
+        __syncthreads();  // s.part is about to be overwritten by the sums
+        alive = coop_sum_records_tagged(g64, S, C::NACC, (unsigned)it + 1u, reinterpret_cast<float*>(scratch),
+                                        reinterpret_cast<float*>(s.part), abort_flag) && alive;
+      } else {
+        real* mine = gpart + ((long long)(it & 1) * S + sl) * C::NACC;
+        for (int i = threadIdx.x; i < C::NACC; i += blockDim.x) {
+          real acc = s.part[i];
+          for (int w = 1; w < nw; ++w) acc += s.part[w * C::NACC + i];
+          put(mine + i, acc);
+        }
+        alive = barrier() && alive;
+        coop_sum_records_atomic<real>(gpart + (long long)(it & 1) * S * C::NACC, S, C::NACC, scratch, s.part);  // one record
       }
-      alive = barrier() && alive;
-      coop_sum_records_atomic<real>(gpart + (long long)(it & 1) * S * C::NACC, S, C::NACC, scratch, s.part);  // one record
       if (wave == 0) wave0_combine_and_update_h(s, 1, m, a.l1h, a.l2h);
       __syncthreads();
       load_h_regs(s, g, h, hht);
