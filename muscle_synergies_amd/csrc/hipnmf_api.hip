@@ -200,7 +200,7 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
   SliceGeom sg = slice_geometry(h, T, B);
   // per-iteration cost models fitted to tools/config2_bench.py on MI355X (k = 5, m = 16, fp32):
   // persistent 2.7 ns per row of one matrix, num_cu matrices at a time; sliced 9.5 us of launches +
-  // 0.021 ns per row of the whole batch; cooperative (further down) 5.5 us + 2.4 us per workgroup-step of rows
+  // 0.021 ns per row of the whole batch; cooperative (further down) 3.7-5.5 us + 2.4 us per workgroup-step of rows
   const double waves = (double)((B + h->num_cu - 1) / h->num_cu);
   const double t_pers = waves * ((double)T * (ks->row_major ? 2.0e-9 : 2.7e-9) + 1e-6);  // row-per-lane: 20.8 us / 10 000 rows
   const double t_sliced = 9.5e-6 + (double)B * (double)T * 0.021e-9;
@@ -287,7 +287,10 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
       long long lds_rows = lds_cap > base ? (long long)((lds_cap - base) / (sizeof(real) * (size_t)k)) / threads * threads : 0;
       lds_rows = std::min(lds_rows, rps);
       const size_t smem = base + sizeof(real) * (size_t)k * (size_t)lds_rows;
-      const double t_coop = 5.5e-6 + 2.4e-6 * (double)(rps / threads) + 0.022e-6 * (double)S;
+      // fixed part: float records travel as {value, generation} granules (no barrier round trip): 4.5 us, 3.7 us when
+      // the one matrix's workgroups share an XCD; float64 keeps the flag barrier: 5.5 us (tools/config2_bench.py)
+      const double t_fixed = sizeof(real) == 4 ? (B == 1 ? 3.7e-6 : 4.5e-6) : 5.5e-6;
+      const double t_coop = t_fixed + 2.4e-6 * (double)(rps / threads) + 0.022e-6 * (double)S;
       const bool wins = h->variant == 3 || t_coop < std::min(t_pers, t_sliced);
       if (S >= 2 && lds_rows >= threads && wins) {
         coop_S = (int)S;
@@ -385,7 +388,7 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
   size_t o_part = 0, o_sums = 0, o_col = 0, o_state = 0;
   size_t o_cpart = 0, o_ccol = 0, o_sync = 0;
   if (coop) {
-    o_cpart = carve(2 * sizeof(real) * (size_t)B * 2 * coop_S * ks->NACC);  // x 2: 8-byte {value, generation} granules (same-XCD float flavour)
+    o_cpart = carve(2 * sizeof(real) * (size_t)B * 2 * coop_S * ks->NACC);  // x 2: float records travel as 8-byte {value, generation} granules
     o_ccol = carve(sizeof(real) * (size_t)B * 2 * coop_S * 2 * ks->MP);
     o_sync = carve(sizeof(unsigned) * ((size_t)B + 2 + 10 * (size_t)B + 1024 * (size_t)B));  // + same-XCD mode: 'updates began', tickets, target, flags
   }
@@ -497,7 +500,7 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
     if (coop_smem > 48 * 1024)
       HIP_TRY(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)coop_smem));
     HIP_TRY(hipMemsetAsync(c.sync, 0, sizeof(unsigned) * ((size_t)B + 2 + 10 * (size_t)B + 1024 * (size_t)B), st));
-    if (c.coop_xcd)  // generations of a previous fit must not look fresh
+    if (sizeof(real) == 4)  // float records travel as {value, generation} granules: those of a previous fit must not look fresh
       HIP_TRY(hipMemsetAsync(c.part, 0, 2 * sizeof(real) * (size_t)B * 2 * coop_S * ks->NACC, st));
     void* args[] = {&c};
     const hipError_t e = hipLaunchCooperativeKernel(kern, dim3(c.coop_xcd ? 8 * coop_S : coop_S, B), dim3(coop_threads), args,

@@ -1504,8 +1504,9 @@ __device__ __forceinline__ void coop_sum_records_atomic(const real* __restrict__
   }
 }
 
-// Same-XCD flavour, float records: every element travels as one 8-byte granule {value, generation}, written with ONE
-// plain store -- the consumer needs neither a barrier nor a flag: it polls the granules it sums (L1-bypassing loads)
+// Float records: every element travels as one 8-byte granule {value, generation}, written with ONE store (plain in
+// the same-XCD flavour, device-scope write-through otherwise: 8-byte stores arrive untorn) -- the consumer needs neither
+// a barrier nor a flag: it polls the granules it sums (L1-bypassing loads)
 // until their generation matches, which saves the publish / poll round trip of coop_barrier_xcd (~0.8 us of 6.4).
 // Same summation order as coop_sum_records_atomic.  Returns false after an abort.
 __device__ __forceinline__ bool coop_sum_records_tagged(const unsigned long long* __restrict__ in, int S, int nout, unsigned gen,
@@ -1668,7 +1669,7 @@ __global__ void __launch_bounds__((max_threads<real, G, CH, K>())) HIPNMF_OCC fi
   real h[K][CH], hht[K][K];
   load_h_regs(s, g, h, hht);
 
-  real* __restrict__ gpart = a.part + (long long)b * S * 2 * C::NACC * (XCD && sizeof(real) == 4 ? 2 : 1);  // [2][S][NACC], alternating per exchange (8-byte granules in the same-XCD float flavour)
+  real* __restrict__ gpart = a.part + (long long)b * S * 2 * C::NACC * (sizeof(real) == 4 ? 2 : 1);  // [2][S][NACC], alternating per exchange (float: 8-byte {value, generation} granules)
   real* __restrict__ gcol = a.colpart + (long long)b * S * 2 * (2 * MP);  // [2][S][2*MP]
   unsigned nres = 0;
   bool alive = true;
@@ -1717,14 +1718,19 @@ __global__ void __launch_bounds__((max_threads<real, G, CH, K>())) HIPNMF_OCC fi
     if (a.update_h) {
       wave_reduce_acc<real, G, CH, K>(s.part + wave * C::NACC, accA, accB);
       __syncthreads();
-      if constexpr (XCD && sizeof(real) == 4) {
-        // tagged granules {value, generation}: one plain 8-byte store per element, no barrier, no flag
+      if constexpr (sizeof(real) == 4) {
+        // tagged granules {value, generation}: ONE 8-byte store per element (plain into the shared L2, or written
+        // through to the coherence point in the device-scope flavour), no barrier, no flag
         unsigned long long* g64 = reinterpret_cast<unsigned long long*>(gpart) + (long long)(it & 1) * S * C::NACC;
         const unsigned long long tag = (unsigned long long)((unsigned)it + 1u) << 32;
         for (int i = threadIdx.x; i < C::NACC; i += blockDim.x) {
           real acc = s.part[i];
           for (int w = 1; w < nw; ++w) acc += s.part[w * C::NACC + i];
-          g64[(long long)sl * C::NACC + i] = tag | (unsigned long long)__float_as_uint((float)acc);
+          const unsigned long long gran = tag | (unsigned long long)__float_as_uint((float)acc);
+          if constexpr (XCD)
+            g64[(long long)sl * C::NACC + i] = gran;
+          else
+            __hip_atomic_store(g64 + (long long)sl * C::NACC + i, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();  // s.part is about to be overwritten by the sums
         alive = coop_sum_records_tagged(g64, S, C::NACC, (unsigned)it + 1u, reinterpret_cast<float*>(scratch),
