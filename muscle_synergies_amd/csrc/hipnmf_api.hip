@@ -287,9 +287,9 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
       long long lds_rows = lds_cap > base ? (long long)((lds_cap - base) / (sizeof(real) * (size_t)k)) / threads * threads : 0;
       lds_rows = std::min(lds_rows, rps);
       const size_t smem = base + sizeof(real) * (size_t)k * (size_t)lds_rows;
-      // fixed part: float records travel as {value, generation} granules (no barrier round trip): 4.5 us, 3.7 us when
-      // the one matrix's workgroups share an XCD; float64 keeps the flag barrier: 5.5 us (tools/config2_bench.py)
-      const double t_fixed = sizeof(real) == 4 ? (B == 1 ? 3.7e-6 : 4.5e-6) : 5.5e-6;
+      // fixed part: records travel as {value bits, generation} granules (no barrier round trip): 4.5 us, 3.7 us when the
+      // one matrix's workgroups share an XCD (tools/config2_bench.py)
+      const double t_fixed = B == 1 ? 3.7e-6 : 4.5e-6;
       const double t_coop = t_fixed + 2.4e-6 * (double)(rps / threads) + 0.022e-6 * (double)S;
       const bool wins = h->variant == 3 || t_coop < std::min(t_pers, t_sliced);
       if (S >= 2 && lds_rows >= threads && wins) {
@@ -500,8 +500,8 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
     if (coop_smem > 48 * 1024)
       HIP_TRY(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)coop_smem));
     HIP_TRY(hipMemsetAsync(c.sync, 0, sizeof(unsigned) * ((size_t)B + 2 + 10 * (size_t)B + 1024 * (size_t)B), st));
-    if (sizeof(real) == 4)  // float records travel as {value, generation} granules: those of a previous fit must not look fresh
-      HIP_TRY(hipMemsetAsync(c.part, 0, 2 * sizeof(real) * (size_t)B * 2 * coop_S * ks->NACC, st));
+    // records travel as {value bits, generation} granules: those of a previous fit must not look fresh
+    HIP_TRY(hipMemsetAsync(c.part, 0, 2 * sizeof(real) * (size_t)B * 2 * coop_S * ks->NACC, st));
     void* args[] = {&c};
     const hipError_t e = hipLaunchCooperativeKernel(kern, dim3(c.coop_xcd ? 8 * coop_S : coop_S, B), dim3(coop_threads), args,
                                                     (unsigned)coop_smem, st);

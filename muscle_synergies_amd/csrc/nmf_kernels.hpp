@@ -1504,47 +1504,61 @@ __device__ __forceinline__ void coop_sum_records_atomic(const real* __restrict__
   }
 }
 
-// Float records: every element travels as one 8-byte granule {value, generation}, written with ONE store (plain in
-// the same-XCD flavour, device-scope write-through otherwise: 8-byte stores arrive untorn) -- the consumer needs neither
-// a barrier nor a flag: it polls the granules it sums (L1-bypassing loads)
-// until their generation matches, which saves the publish / poll round trip of coop_barrier_xcd (~0.8 us of 6.4).
-// Same summation order as coop_sum_records_atomic.  Returns false after an abort.
+// Records travel as 8-byte granules {32 value bits, generation}, each written with ONE store (plain in the same-XCD
+// flavour, device-scope write-through otherwise: 8-byte stores arrive untorn) -- a float is one granule, a double two
+// (low and high word, each with the generation).  The consumer needs neither a barrier nor a flag: it polls the
+// granules it sums (L1-bypassing loads) until their generation matches, which saves the publish / poll round trip of
+// the flag barrier (~0.8 us per iteration).  Same summation order as coop_sum_records_atomic.  False after an abort.
+__device__ __forceinline__ unsigned long long coop_poll_granule(const unsigned long long* p, unsigned long long g, unsigned gen,
+                                                                unsigned* abort_flag, bool& ok) {
+  unsigned spins = 0;
+  while ((unsigned)(g >> 32) != gen) {  // not published yet: poll this one
+    __builtin_amdgcn_s_sleep(1);
+    g = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((++spins & 1023u) == 0) {
+      if (spins > HIPNMF_COOP_SPIN_LIMIT) __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+        ok = false;
+        break;
+      }
+    }
+  }
+  return g;
+}
+template <typename real>
 __device__ __forceinline__ bool coop_sum_records_tagged(const unsigned long long* __restrict__ in, int S, int nout, unsigned gen,
-                                                        float* scratch, float* __restrict__ out, unsigned* abort_flag) {
+                                                        real* scratch, real* __restrict__ out, unsigned* abort_flag) {
+  constexpr int GP = (int)sizeof(real) / 4;  // granules per element
   __shared__ int ok_tag_sh;
   if (threadIdx.x == 0) ok_tag_sh = 1;
   for (int o0 = 0; o0 < nout; o0 += blockDim.x) {
     const int n = (nout - o0 < (int)blockDim.x) ? nout - o0 : (int)blockDim.x;
     const int nq = (int)blockDim.x / n > 0 ? (int)blockDim.x / n : 1;
     const int o = threadIdx.x % n, q = threadIdx.x / n;
-    float acc = 0.f;
+    real acc = (real)0;
     bool ok = true;
     if (q < nq) {
-      const unsigned long long* p = in + o0 + o;
+      const unsigned long long* p = in + (long long)(o0 + o) * GP;
+      const long long stride = (long long)nout * GP;
       for (int s0 = q; s0 < S && ok; s0 += 8 * nq) {
-        unsigned long long g[8];
+        unsigned long long g[8][GP];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {  // all of this thread's granules of the chunk in flight
           const int sl = s0 + u * nq;
-          g[u] = sl < S ? __hip_atomic_load(p + (long long)sl * nout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+#pragma unroll
+          for (int w = 0; w < GP; ++w)
+            g[u][w] = sl < S ? __hip_atomic_load(p + sl * stride + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
           const int sl = s0 + u * nq;
           if (sl < S) {
-            unsigned spins = 0;
-            while ((unsigned)(g[u] >> 32) != gen) {  // not published yet: poll this one
-              __builtin_amdgcn_s_sleep(1);
-              g[u] = __hip_atomic_load(p + (long long)sl * nout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              if ((++spins & 1023u) == 0) {
-                if (spins > HIPNMF_COOP_SPIN_LIMIT) __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-                  ok = false;
-                  break;
-                }
-              }
-            }
-            acc += __uint_as_float((unsigned)g[u]);
+#pragma unroll
+            for (int w = 0; w < GP; ++w) g[u][w] = coop_poll_granule(p + sl * stride + w, g[u][w], gen, abort_flag, ok);
+            if constexpr (GP == 1)
+              acc += (real)__uint_as_float((unsigned)g[u][0]);
+            else
+              acc += (real)__longlong_as_double((long long)(((g[u][GP - 1] & 0xffffffffull) << 32) | (g[u][0] & 0xffffffffull)));
           }
         }
       }
@@ -1554,7 +1568,7 @@ __device__ __forceinline__ bool coop_sum_records_tagged(const unsigned long long
     if (q < nq) scratch[q * n + o] = acc;
     __syncthreads();
     if ((int)threadIdx.x < n) {
-      float tot = 0.f;
+      real tot = (real)0;
       for (int i2 = 0; i2 < nq; ++i2) tot += scratch[i2 * n + threadIdx.x];
       out[o0 + threadIdx.x] = tot;
     }
@@ -1669,7 +1683,7 @@ __global__ void __launch_bounds__((max_threads<real, G, CH, K>())) HIPNMF_OCC fi
   real h[K][CH], hht[K][K];
   load_h_regs(s, g, h, hht);
 
-  real* __restrict__ gpart = a.part + (long long)b * S * 2 * C::NACC * (sizeof(real) == 4 ? 2 : 1);  // [2][S][NACC], alternating per exchange (float: 8-byte {value, generation} granules)
+  real* __restrict__ gpart = a.part + (long long)b * S * 2 * C::NACC * 2;  // [2][S][NACC] elements of 8 bytes per 32 value bits ({value bits, generation} granules), alternating per exchange
   real* __restrict__ gcol = a.colpart + (long long)b * S * 2 * (2 * MP);  // [2][S][2*MP]
   unsigned nres = 0;
   bool alive = true;
@@ -1718,32 +1732,32 @@ __global__ void __launch_bounds__((max_threads<real, G, CH, K>())) HIPNMF_OCC fi
     if (a.update_h) {
       wave_reduce_acc<real, G, CH, K>(s.part + wave * C::NACC, accA, accB);
       __syncthreads();
-      if constexpr (sizeof(real) == 4) {
-        // tagged granules {value, generation}: ONE 8-byte store per element (plain into the shared L2, or written
-        // through to the coherence point in the device-scope flavour), no barrier, no flag
-        unsigned long long* g64 = reinterpret_cast<unsigned long long*>(gpart) + (long long)(it & 1) * S * C::NACC;
+      {
+        // tagged granules {32 value bits, generation}: ONE 8-byte store each (plain into the shared L2, or written through
+        // to the coherence point in the device-scope flavour), no barrier, no flag
+        constexpr int GP = (int)sizeof(real) / 4;
+        unsigned long long* g64 = reinterpret_cast<unsigned long long*>(gpart) + (long long)(it & 1) * S * C::NACC * GP;
         const unsigned long long tag = (unsigned long long)((unsigned)it + 1u) << 32;
         for (int i = threadIdx.x; i < C::NACC; i += blockDim.x) {
           real acc = s.part[i];
           for (int w = 1; w < nw; ++w) acc += s.part[w * C::NACC + i];
-          const unsigned long long gran = tag | (unsigned long long)__float_as_uint((float)acc);
-          if constexpr (XCD)
-            g64[(long long)sl * C::NACC + i] = gran;
+          unsigned long long bits;
+          if constexpr (GP == 1)
+            bits = (unsigned long long)__float_as_uint((float)acc);
           else
-            __hip_atomic_store(g64 + (long long)sl * C::NACC + i, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            bits = (unsigned long long)__double_as_longlong((double)acc);
+#pragma unroll
+          for (int w = 0; w < GP; ++w) {
+            const unsigned long long gran = tag | ((bits >> (32 * w)) & 0xffffffffull);
+            unsigned long long* dst = g64 + ((long long)sl * C::NACC + i) * GP + w;
+            if constexpr (XCD)
+              *dst = gran;
+            else
+              __hip_atomic_store(dst, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
         }
         __syncthreads();  // s.part is about to be overwritten by the sums
-        alive = coop_sum_records_tagged(g64, S, C::NACC, (unsigned)it + 1u, reinterpret_cast<float*>(scratch),
-                                        reinterpret_cast<float*>(s.part), abort_flag) && alive;
-      } else {
-        real* mine = gpart + ((long long)(it & 1) * S + sl) * C::NACC;
-        for (int i = threadIdx.x; i < C::NACC; i += blockDim.x) {
-          real acc = s.part[i];
-          for (int w = 1; w < nw; ++w) acc += s.part[w * C::NACC + i];
-          put(mine + i, acc);
-        }
-        alive = barrier() && alive;
-        coop_sum_records_atomic<real>(gpart + (long long)(it & 1) * S * C::NACC, S, C::NACC, scratch, s.part);  // one record
+        alive = coop_sum_records_tagged<real>(g64, S, C::NACC, (unsigned)it + 1u, scratch, s.part, abort_flag) && alive;
       }
       if (wave == 0) wave0_combine_and_update_h(s, 1, m, a.l1h, a.l2h);
       __syncthreads();
