@@ -106,9 +106,13 @@ int validate(const hipnmf_problem* p, bool shard, bool ragged = false) {
     return fail(HIPNMF_ERR_BAD_ARG, "n_samples must be in [1, 2e9] (got %lld)", (long long)p->n_samples);
   if (p->n_features < 1) return fail(HIPNMF_ERR_BAD_ARG, "n_features must be >= 1 (got %d)", p->n_features);
   if (p->n_components < 1) return fail(HIPNMF_ERR_BAD_ARG, "n_components must be >= 1 (got %d)", p->n_components);
-  if (p->n_features > 32 || p->n_components > 8)
-    return fail(HIPNMF_ERR_UNSUPPORTED, "shape outside the compiled kernel set: n_features=%d (max 32), n_components=%d (max 8)",
-                p->n_features, p->n_components);
+  {  // the time-shard building blocks exist for the narrow lane mappings only
+    const int max_m = shard ? HIPNMF_NARROW_MAX_FEATURES : HIPNMF_MAX_FEATURES;
+    const int max_k = shard ? HIPNMF_NARROW_MAX_COMPONENTS : HIPNMF_MAX_COMPONENTS;
+    if (p->n_features > max_m || p->n_components > max_k)
+      return fail(HIPNMF_ERR_UNSUPPORTED, "shape outside the compiled kernel set%s: n_features=%d (max %d), n_components=%d (max %d)",
+                  shard ? " of the time-shard entry points" : "", p->n_features, max_m, p->n_components, max_k);
+  }
   if (p->x_layout != HIPNMF_X_ROW_MAJOR && p->x_layout != HIPNMF_X_CHANNEL_MAJOR)
     return fail(HIPNMF_ERR_BAD_ARG, "bad x_layout %d", p->x_layout);
   if (p->w_layout != HIPNMF_W_ROW_MAJOR && p->w_layout != HIPNMF_W_COMPONENT_MAJOR)
@@ -186,6 +190,8 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
   HIP_TRY(hipSetDevice(h->device));
   const int B = p->batch, m = p->n_features, k = p->n_components;
   const long long T = p->n_samples;
+  if (m > HIPNMF_NARROW_MAX_FEATURES || k > HIPNMF_NARROW_MAX_COMPONENTS)  // matrix-pipe instances of nmf_wide.hpp
+    return hipnmf_fit_wide<real>(h, p, X, W, H, err_out, n_iter_out, sse_col_out, xsq_col_out, ragged);
   const KernelSet<real>* ks = select_kernels<real>(m, k, true);
   if (ks && ks->row_major && (T + 64) * (long long)ks->MP * (long long)sizeof(real) >= (1LL << 31))
     ks = select_kernels<real>(m, k, false);  // rows padded to MP channels would not fit the 32-bit addressing

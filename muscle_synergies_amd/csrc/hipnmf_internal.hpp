@@ -50,4 +50,11 @@ int hipnmf_ensure_ws(hipnmf_handle* h, size_t bytes);
 
 inline long long round_up(long long v, long long q) { return (v + q - 1) / q * q; }
 
+// wide shapes (n_features > 32 or n_components > 8; hipnmf_wide.hip): the whole fit of a validated problem
+template <typename real>
+int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, real* W, real* H, real* err_out,
+                    int32_t* n_iter_out, real* sse_col_out, real* xsq_col_out, const int64_t* ragged);
+constexpr int HIPNMF_NARROW_MAX_FEATURES = 32, HIPNMF_NARROW_MAX_COMPONENTS = 8;  // nmf_kernels.hpp lane mappings
+constexpr int HIPNMF_MAX_FEATURES = 128, HIPNMF_MAX_COMPONENTS = 16;              // nmf_wide.hpp
+
 // X layout canonicalisation kernel (nmf_kernels.hpp) reused by the envelope entry point

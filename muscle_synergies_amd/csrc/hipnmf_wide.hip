@@ -1,0 +1,223 @@
+// hipnmf_wide.hip -- host driver of the wide-shape kernels (nmf_wide.hpp): n_features up to 128 and n_components up
+// to 16, fp32 and fp64, reached from hipnmf_fit_batched_* / hipnmf_fit_ragged_* for every shape outside the narrow
+// kernel set of hipnmf_api.hip (n_features > 32 or n_components > 8).  The reference accepts any
+// 1 <= n_components <= n_features (src/muscle_synergies/analysis.py:829-846, :862-863); sklearn's solver is shape-
+// agnostic (sklearn/decomposition/_nmf.py:540-554, 638-640).
+//
+// Layout canonicalisation, once per fit: X row-major with 16-byte aligned rows (a caller's C-order X with
+// n_features * sizeof(real) % 16 == 0 is streamed in place), W row-major with rows of ks = round_up(k, 4) values
+// (a caller's row-major W with k % 4 == 0 is updated in place).
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "hipnmf_internal.hpp"
+#include "nmf_wide_inst.hpp"
+
+using namespace hipnmf;
+
+namespace hipnmf {
+static int wide_mp(int m) { return m <= 16 ? 16 : m <= 32 ? 32 : m <= 48 ? 48 : m <= 64 ? 64 : m <= 96 ? 96 : m <= 128 ? 128 : 0; }
+const WideKernel<float>* wide_kernel_f32(int m, int k) {
+  const int MP = wide_mp(m), KP = k <= 16 ? 16 : 0;
+  if (!MP || !KP) return nullptr;
+  return MP <= 48 ? wide_kernel_f32_lo(MP, KP) : wide_kernel_f32_hi(MP, KP);
+}
+const WideKernel<double>* wide_kernel_f64(int m, int k) {
+  const int MP = wide_mp(m), KP = k <= 16 ? 16 : 0;
+  if (!MP || !KP) return nullptr;
+  return MP <= 48 ? wide_kernel_f64_lo(MP, KP) : wide_kernel_f64_hi(MP, KP);
+}
+}  // namespace hipnmf
+
+namespace {
+template <typename real>
+const WideKernel<real>* pick(int m, int k);
+template <>
+const WideKernel<float>* pick<float>(int m, int k) {
+  return wide_kernel_f32(m, k);
+}
+template <>
+const WideKernel<double>* pick<double>(int m, int k) {
+  return wide_kernel_f64(m, k);
+}
+}  // namespace
+
+// `p` has passed validate() of hipnmf_api.hip.  `ragged`: host copy of the caller's descriptors or nullptr.
+template <typename real>
+int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, real* W, real* H, real* err_out,
+                    int32_t* n_iter_out, real* sse_col_out, real* xsq_col_out, const int64_t* ragged) {
+  const int B = p->batch, m = p->n_features, k = p->n_components;
+  const long long T = p->n_samples;
+  const WideKernel<real>* wk = pick<real>(m, k);
+  if (!wk) return fail(HIPNMF_ERR_UNSUPPORTED, "no kernel for n_features=%d (max 128) n_components=%d (max 16)", m, k);
+  if (p->loss != HIPNMF_LOSS_FROBENIUS)
+    return fail(HIPNMF_ERR_UNSUPPORTED, "the wide-shape kernels (n_features > 32 or n_components > 8) implement the Frobenius loss only");
+  if (h->variant == 2 || h->variant == 3 || h->variant == 5 || h->variant == 6)
+    return fail(HIPNMF_ERR_UNSUPPORTED, "tuning variant %d does not exist for wide shapes (n_features=%d, n_components=%d)",
+                h->variant, m, k);
+  constexpr int VEC = 16 / (int)sizeof(real);
+  const int ks = (int)round_up(k, 4);
+  hipStream_t st = h->stream;
+
+  if (ragged) {
+    if (p->x_layout != HIPNMF_X_CHANNEL_MAJOR || p->w_layout != HIPNMF_W_COMPONENT_MAJOR)
+      return fail(HIPNMF_ERR_UNSUPPORTED, "ragged batches use the packed native layouts (channel-major X, component-major W)");
+    for (int b = 0; b < B; ++b) {
+      const int64_t* d = ragged + 4 * (size_t)b;
+      if (d[0] < 1 || d[0] > p->n_samples || d[2] < d[0] || d[1] < 0 || d[3] < 0)
+        return fail(HIPNMF_ERR_BAD_ARG, "bad ragged descriptor for matrix %d (T=%lld, xoff=%lld, ld=%lld, woff=%lld)", b,
+                    (long long)d[0], (long long)d[1], (long long)d[2], (long long)d[3]);
+    }
+  }
+
+  // ---- canonical layouts ----------------------------------------------------------------------------------------
+  const bool aligned = (reinterpret_cast<uintptr_t>(X) % 16) == 0 && ((p->x_batch_stride * (long long)sizeof(real)) % 16) == 0;
+  const bool x_inplace = !ragged && p->x_layout == HIPNMF_X_ROW_MAJOR && (m % VEC) == 0 && (p->ldx % VEC) == 0 && aligned;
+  const long long ldx_c = x_inplace ? p->ldx : round_up(m, 4);
+  const bool w_inplace = !ragged && p->w_layout == HIPNMF_W_ROW_MAJOR && ks == k && (reinterpret_cast<uintptr_t>(W) % 16) == 0;
+  if ((T + 16) * ldx_c * (long long)sizeof(real) >= (1LL << 31) || (T + 16) * (long long)ks * (long long)sizeof(real) >= (1LL << 31))
+    return fail(HIPNMF_ERR_UNSUPPORTED, "one matrix needs >= 2 GiB of X or W; the engine addresses < 2 GiB per matrix");
+
+  // ragged: distinct source matrices are converted once (the restarts of one trial share theirs)
+  struct Src {
+    long long xoff, T, ld, roff;
+  };
+  std::vector<Src> srcs;
+  std::vector<long long> kdesc;  // kernel descriptors {T_b, X offset, -, W offset}
+  long long ragged_x_elems = 0, ragged_w_elems = 0;
+  if (ragged) {
+    kdesc.resize(4 * (size_t)B);
+    for (int b = 0; b < B; ++b) {
+      const int64_t* d = ragged + 4 * (size_t)b;
+      size_t idx = srcs.size();
+      for (size_t q = 0; q < srcs.size(); ++q)
+        if (srcs[q].xoff == d[1] && srcs[q].T == d[0] && srcs[q].ld == d[2]) {
+          idx = q;
+          break;
+        }
+      if (idx == srcs.size()) {
+        srcs.push_back({(long long)d[1], (long long)d[0], (long long)d[2], ragged_x_elems});
+        ragged_x_elems += (long long)d[0] * ldx_c;
+      }
+      kdesc[4 * (size_t)b + 0] = d[0];
+      kdesc[4 * (size_t)b + 1] = srcs[idx].roff;
+      kdesc[4 * (size_t)b + 2] = 0;
+      kdesc[4 * (size_t)b + 3] = ragged_w_elems;
+      ragged_w_elems += (long long)d[0] * ks;
+    }
+  }
+
+  size_t off = 0;
+  auto carve = [&](size_t bytes) {
+    size_t o = off;
+    off += (bytes + 255) / 256 * 256;
+    return o;
+  };
+  const size_t x_elems = (size_t)T * (size_t)ldx_c, w_elems = (size_t)T * (size_t)ks;  // per matrix (uniform batches)
+  const size_t o_x = x_inplace ? 0 : carve(sizeof(real) * (ragged ? (size_t)ragged_x_elems + 64 : (size_t)B * x_elems + 64));
+  const size_t o_w = w_inplace ? 0 : carve(sizeof(real) * (ragged ? (size_t)ragged_w_elems + 64 : (size_t)B * w_elems + 64));
+  const size_t o_kdesc = ragged ? carve(sizeof(long long) * 4 * (size_t)B) : 0;
+  const size_t o_cdesc = ragged ? carve(sizeof(long long) * 4 * (size_t)B) : 0;
+  int rc = hipnmf_ensure_ws(h, std::max<size_t>(off, 256));
+  if (rc) return rc;
+  char* ws = static_cast<char*>(h->ws);
+
+  WideArgs<real> a;
+  std::memset(&a, 0, sizeof(a));
+  if (x_inplace) {
+    a.X = X;
+    a.x_bstride = p->x_batch_stride;
+    a.ldx = p->ldx;
+  } else {
+    real* xc = reinterpret_cast<real*>(ws + o_x);
+    dim3 blk(32, 8);
+    if (ragged) {
+      for (const Src& r : srcs) {
+        dim3 grd((unsigned)((r.T + 31) / 32), (unsigned)((ldx_c + 31) / 32), 1u);
+        hipLaunchKernelGGL(x_to_row_major_kernel<real>, grd, blk, 0, st, X + r.xoff, 0LL, r.ld, (int)HIPNMF_X_CHANNEL_MAJOR,
+                           xc + r.roff, 0LL, (int)ldx_c, (int)r.T, m);
+      }
+    } else {
+      for (int b0 = 0; b0 < B; b0 += 65535) {  // the batch rides on grid.z (HIP limit 65535)
+        const unsigned nb = (unsigned)std::min(65535, B - b0);
+        dim3 grd((unsigned)((T + 31) / 32), (unsigned)((ldx_c + 31) / 32), nb);
+        hipLaunchKernelGGL(x_to_row_major_kernel<real>, grd, blk, 0, st, X + (long long)b0 * p->x_batch_stride,
+                           (long long)p->x_batch_stride, (long long)p->ldx, (int)p->x_layout, xc + (size_t)b0 * x_elems,
+                           (long long)x_elems, (int)ldx_c, (int)T, m);
+      }
+    }
+    a.X = xc;
+    a.x_bstride = (long long)x_elems;
+    a.ldx = ldx_c;
+  }
+  const long long* d_cdesc = nullptr;  // device copies: caller's descriptors, kernel descriptors
+  const long long* d_kdesc = nullptr;
+  if (ragged) {
+    HIP_TRY(hipMemcpyAsync(ws + o_cdesc, ragged, sizeof(long long) * 4 * (size_t)B, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(ws + o_kdesc, kdesc.data(), sizeof(long long) * 4 * (size_t)B, hipMemcpyHostToDevice, st));
+    d_cdesc = reinterpret_cast<const long long*>(ws + o_cdesc);
+    d_kdesc = reinterpret_cast<const long long*>(ws + o_kdesc);
+    a.ragged = d_kdesc;
+  }
+  real* wc = w_inplace ? W : reinterpret_cast<real*>(ws + o_w);
+  auto convert_w = [&](int dir) {
+    const long long n = T * ks;
+    for (int b0 = 0; b0 < B; b0 += 65535) {  // the batch rides on grid.y
+      const int nb = std::min(65535, B - b0);
+      dim3 grd((unsigned)std::min<long long>((n + 255) / 256, 1024), (unsigned)nb);
+      if (ragged)
+        hipLaunchKernelGGL(wide_w_convert_kernel<real>, grd, dim3(256), 0, st, W, 1, 0LL, 0LL, wc, 0LL, ks, (int)T, k, dir,
+                           d_cdesc + 4LL * b0, d_kdesc + 4LL * b0);
+      else if (p->w_layout == HIPNMF_W_ROW_MAJOR)
+        hipLaunchKernelGGL(wide_w_convert_kernel<real>, grd, dim3(256), 0, st, W + (long long)b0 * T * k, 0, (long long)T * k, 0LL,
+                           wc + (size_t)b0 * w_elems, (long long)w_elems, ks, (int)T, k, dir, (const long long*)nullptr,
+                           (const long long*)nullptr);
+      else
+        hipLaunchKernelGGL(wide_w_convert_kernel<real>, grd, dim3(256), 0, st, W + (long long)b0 * T * k, 1, (long long)T * k,
+                           (long long)T, wc + (size_t)b0 * w_elems, (long long)w_elems, ks, (int)T, k, dir,
+                           (const long long*)nullptr, (const long long*)nullptr);
+    }
+  };
+  if (!w_inplace) convert_w(0);
+  a.W = wc;
+  a.w_bstride = (long long)w_elems;
+  a.H = H;
+  a.err_out = err_out;
+  a.n_iter_out = n_iter_out;
+  a.sse_col_out = sse_col_out;
+  a.xsq_col_out = xsq_col_out;
+  a.T = (int)T;
+  a.m = m;
+  a.k = k;
+  a.ks = ks;
+  a.xchunks = (m + VEC - 1) / VEC;
+  a.max_iter = p->max_iter;
+  a.check_every = p->check_every;
+  a.update_h = p->update_h ? 1 : 0;
+  a.tol = (real)p->tol;
+  a.l1w = (real)p->l1_reg_W;
+  a.l2w = (real)p->l2_reg_W;
+  a.l1h = (real)p->l1_reg_H;
+  a.l2h = (real)p->l2_reg_H;
+
+  HIP_TRY(hipEventRecord(h->ev0, st));
+  h->last_path = 1;
+  snprintf(h->last_kernel, sizeof(h->last_kernel), "%s", wk->name);
+  if (wk->smem > 48 * 1024)
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(wk->fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wk->smem));
+  hipLaunchKernelGGL(wk->fn, dim3(B), dim3(wk->NW * 64), wk->smem, st, a);
+  HIP_TRY(hipEventRecord(h->ev1, st));
+  if (!w_inplace) convert_w(1);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(st));
+  HIP_TRY(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
+  return HIPNMF_OK;
+}
+
+template int hipnmf_fit_wide<float>(hipnmf_handle*, const hipnmf_problem*, const float*, float*, float*, float*, int32_t*,
+                                    float*, float*, const int64_t*);
+template int hipnmf_fit_wide<double>(hipnmf_handle*, const hipnmf_problem*, const double*, double*, double*, double*, int32_t*,
+                                     double*, double*, const int64_t*);

@@ -1,0 +1,18 @@
+// nmf_wide_decl.hpp -- host-side view of the wide-shape kernels of nmf_wide.hpp (instantiated in inst_wide_*.hip)
+#pragma once
+#include <cstddef>
+
+#include "nmf_wide.hpp"
+
+namespace hipnmf {
+template <typename real>
+struct WideKernel {
+  void (*fn)(WideArgs<real>);
+  size_t smem;  // dynamic LDS bytes
+  int MP, KP, NW;
+  const char* name;  // "fit_wide_kernel<real,MP,KP,NW>"
+};
+// smallest compiled instance that holds n_features x n_components, nullptr beyond 128 channels / 16 components
+const WideKernel<float>* wide_kernel_f32(int n_features, int n_components);
+const WideKernel<double>* wide_kernel_f64(int n_features, int n_components);
+}  // namespace hipnmf

@@ -1,0 +1,27 @@
+// nmf_wide_inst.hpp -- instantiation helper of the wide-shape kernels (one translation unit per dtype and half of the
+// channel paddings, so that the build compiles them in parallel)
+#pragma once
+#include "nmf_wide_decl.hpp"
+
+namespace hipnmf {
+// H operands of H X^T in registers when they take at most 16 VGPRs, re-read from LDS per subtile otherwise
+template <typename real, int MP, int KP>
+constexpr bool wide_hreg() {
+  return (KP / 16) * (MP / 4) * (int)(sizeof(real) / 4) <= 16;
+}
+template <typename real, int MP, int KP, int NW>
+WideKernel<real> make_wide_kernel(const char* name) {
+  WideKernel<real> w;
+  w.fn = fit_wide_kernel<real, MP, KP, NW, wide_hreg<real, MP, KP>()>;
+  w.smem = WideCfg<real, MP, KP>::smem_bytes(NW);
+  w.MP = MP;
+  w.KP = KP;
+  w.NW = NW;
+  w.name = name;
+  return w;
+}
+const WideKernel<float>* wide_kernel_f32_lo(int MP, int KP);
+const WideKernel<float>* wide_kernel_f32_hi(int MP, int KP);
+const WideKernel<double>* wide_kernel_f64_lo(int MP, int KP);
+const WideKernel<double>* wide_kernel_f64_hi(int MP, int KP);
+}  // namespace hipnmf

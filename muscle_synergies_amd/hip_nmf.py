@@ -96,8 +96,8 @@ class HipNMF:
         return f"HipNMF(n_components={self.n_components!r}, init={self.init!r}, tol={self.tol!r}, max_iter={self.max_iter!r})"
 
     # -- validation --------------------------------------------------------------------------------
-    MAX_FEATURES = 32    # widest lane mapping compiled into libhip_nmf.so (HIPNMF_ERR_UNSUPPORTED beyond)
-    MAX_COMPONENTS = 8
+    MAX_FEATURES = 128   # widest instance compiled into libhip_nmf.so (nmf_wide.hpp; HIPNMF_ERR_UNSUPPORTED beyond)
+    MAX_COMPONENTS = 16
 
     @staticmethod
     def supports(solver="cd", beta_loss="frobenius", n_features=None, n_components=None, **_ignored) -> bool:

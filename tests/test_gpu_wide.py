@@ -1,0 +1,173 @@
+"""GPU parity of the wide-shape matrix-pipe kernels (nmf_wide.hpp): n_features up to 128, n_components up to 16 --
+every shape the reference's validation accepts (analysis.py:829-846) beyond the narrow lane mappings -- against the
+NumPy oracle, through the same host API the narrow shapes use."""
+import numpy as np
+import pytest
+
+from oracle import nmf_mu_oracle as orc
+from muscle_synergies_amd.synth import emg_matrix, random_init
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _rel(X, W, H, ref):
+    xn = np.linalg.norm(X.astype(np.float64))
+    wh = W.astype(np.float64) @ H.astype(np.float64)
+    wr = ref["W"].astype(np.float64) @ ref["H"].astype(np.float64)
+    return np.linalg.norm(wh - wr) / xn
+
+
+def _case(T, m, k, dtype, seed=0):
+    X = emg_matrix(seed, T=T, m=m, k_true=min(6, m), dtype=dtype)
+    W0, H0 = random_init(X, k, seed)
+    return X, W0, H0
+
+
+def _last_kernel():
+    from muscle_synergies_amd import _lib
+
+    return _lib.get_handle(0).last_kernel()
+
+
+SHAPES = [(33, 8), (40, 3), (48, 12), (64, 8), (64, 16), (65, 9), (96, 16), (100, 5), (128, 16), (128, 1),
+          (16, 12), (12, 9), (24, 16), (32, 10), (9, 9)]
+
+
+@pytest.mark.parametrize("m,k", SHAPES)
+@pytest.mark.parametrize("T", [5, 16, 250, 1003])
+def test_wide_shape_sweep_fp32(m, k, T):
+    import muscle_synergies_amd as ms
+
+    X, W0, H0 = _case(T, m, k, np.float32, seed=m * 100 + k)
+    ref = orc.nmf_mu_fit(X, W0, H0, max_iter=20, tol=0.0)
+    for layout in ("F", "C"):
+        Xl = np.asfortranarray(X) if layout == "F" else np.ascontiguousarray(X)
+        res = ms.fit_batched(Xl, W0, H0, max_iter=20, tol=0.0)
+        assert _last_kernel().startswith("fit_wide_kernel<float"), _last_kernel()
+        assert int(res.n_iter[0]) == 20
+        assert _rel(X, res.W[0], res.H[0], ref) <= TOL, (layout, m, k, T)
+        assert abs(float(res.reconstruction_err[0]) - float(ref["reconstruction_err"])) / np.linalg.norm(X) <= TOL
+        np.testing.assert_allclose(res.W[0], ref["W"], rtol=5e-4, atol=1e-6)
+        np.testing.assert_allclose(res.H[0], ref["H"], rtol=5e-4, atol=1e-6)
+        assert (res.W[0] >= 0).all() and (res.H[0] >= 0).all()
+        va, vc = orc.vaf(X.astype(np.float64), ref["W"].astype(np.float64), ref["H"].astype(np.float64))
+        assert abs(res.vaf[0, 0] - va) <= TOL
+        np.testing.assert_allclose(res.vaf[0, 1:], vc, atol=5e-5)
+
+
+@pytest.mark.parametrize("m,k,T", [(33, 8, 130), (64, 16, 777), (128, 16, 300), (100, 7, 64), (16, 12, 500), (48, 4, 33)])
+def test_wide_shape_sweep_fp64(m, k, T):
+    import muscle_synergies_amd as ms
+
+    X, W0, H0 = _case(T, m, k, np.float64, seed=7)
+    ref = orc.nmf_mu_fit(X, W0, H0, max_iter=40, tol=0.0)
+    for layout in ("F", "C"):
+        Xl = np.asfortranarray(X) if layout == "F" else np.ascontiguousarray(X)
+        res = ms.fit_batched(Xl, W0, H0, max_iter=40, tol=0.0)
+        assert _last_kernel().startswith("fit_wide_kernel<double"), _last_kernel()
+        np.testing.assert_allclose(res.W[0], ref["W"], rtol=1e-9, atol=1e-13)
+        np.testing.assert_allclose(res.H[0], ref["H"], rtol=1e-9, atol=1e-13)
+        np.testing.assert_allclose(res.reconstruction_err[0], ref["reconstruction_err"], rtol=1e-9)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("m,k", [(64, 8), (40, 12)])
+def test_wide_stop_rule_and_batch(dtype, m, k):
+    """sklearn's stop rule (every 10th iteration, _nmf.py:872-884) per matrix of a batch whose members converge
+    at different iterations."""
+    import muscle_synergies_amd as ms
+
+    Xs, Ws, Hs, refs = [], [], [], []
+    for s in range(5):
+        X, W0, H0 = _case(600, m, k, dtype, seed=40 + s)
+        Xs.append(X), Ws.append(W0), Hs.append(H0)
+        refs.append(orc.nmf_mu_fit(X, W0, H0, max_iter=300, tol=1e-3 if s % 2 else 3e-4))
+    for tol, sel in ((1e-3, [1, 3]), (3e-4, [0, 2, 4])):
+        res = ms.fit_batched(np.stack([Xs[i] for i in sel]), np.stack([Ws[i] for i in sel]), np.stack([Hs[i] for i in sel]),
+                             max_iter=300, tol=tol)
+        for q, i in enumerate(sel):
+            assert int(res.n_iter[q]) == refs[i]["n_iter"], (i, int(res.n_iter[q]), refs[i]["n_iter"])
+            assert _rel(Xs[i], res.W[q], res.H[q], refs[i]) <= (TOL if dtype == np.float32 else 1e-9)
+            assert abs(float(res.reconstruction_err[q]) - float(refs[i]["reconstruction_err"])) / np.linalg.norm(Xs[i]) <= TOL
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_wide_transform_and_regularisation(dtype):
+    import muscle_synergies_amd as ms
+
+    X, W0, H0 = _case(400, 64, 10, dtype, seed=11)
+    regs = dict(l1_reg_W=0.02, l1_reg_H=0.03, l2_reg_W=0.05, l2_reg_H=0.01)
+    Wr, Hr, _ = orc.fit_multiplicative_update(X, W0.copy(), H0.copy(), max_iter=30, tol=0.0, **regs)
+    res = ms.fit_batched(X, W0, H0, max_iter=30, tol=0.0, **regs)
+    assert _rel(X, res.W[0], res.H[0], {"W": Wr, "H": Hr}) <= (TOL if dtype == np.float32 else 1e-9)
+    Wt = np.full_like(W0, np.sqrt(X.mean() / 10))
+    Wt_ref, _, _ = orc.fit_multiplicative_update(X, Wt.copy(), Hr.copy(), max_iter=25, tol=0.0, update_H=False)
+    res_t = ms.fit_batched(X, Wt, Hr, max_iter=25, tol=0.0, update_H=False)
+    np.testing.assert_array_equal(res_t.H[0], Hr)
+    np.testing.assert_allclose(res_t.W[0], Wt_ref, rtol=5e-4 if dtype == np.float32 else 1e-9, atol=1e-7)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_wide_ragged_batch(dtype):
+    """Trials of unequal length through hipnmf_fit_ragged_* (packed channel-major X, component-major W)."""
+    import muscle_synergies_amd as ms
+
+    m, k = 64, 9
+    Ts = [17, 300, 64, 1025, 5]
+    Xs, Ws, Hs = [], [], []
+    for s, T in enumerate(Ts):
+        X, W0, H0 = _case(T, m, k, dtype, seed=70 + s)
+        Xs.append(X), Ws.append(W0), Hs.append(H0)
+    res = ms.fit_ragged(Xs, Ws, Hs, max_iter=25, tol=0.0)
+    assert _last_kernel().startswith("fit_wide_kernel")
+    for b, T in enumerate(Ts):
+        ref = orc.nmf_mu_fit(Xs[b], Ws[b], Hs[b], max_iter=25, tol=0.0)
+        W = res.W[b].cpu().numpy()
+        H = res.H[b].cpu().numpy()
+        assert W.shape == (T, k)
+        assert _rel(Xs[b], W, H, ref) <= (TOL if dtype == np.float32 else 1e-9), b
+        assert abs(float(res.reconstruction_err[b]) - float(ref["reconstruction_err"])) / np.linalg.norm(Xs[b]) <= TOL
+
+
+def test_wide_padded_leading_dimension_and_in_place_layouts():
+    """A row-major X with ldx > m (a column slice of a wider array) and a W whose k is a multiple of 4 are used in
+    place; other layouts are converted -- same numbers either way."""
+    import torch
+
+    import muscle_synergies_amd as ms
+
+    X, W0, H0 = _case(700, 64, 8, np.float32, seed=3)
+    ref = orc.nmf_mu_fit(X, W0, H0, max_iter=30, tol=0.0)
+    big = torch.zeros((1, 700, 80), dtype=torch.float32, device="cuda")
+    big[0, :, :64] = torch.from_numpy(np.ascontiguousarray(X)).cuda()
+    big[0, :, 64:] = 7.0  # must never be read
+    res = ms.fit_batched(big[:, :, :64], torch.from_numpy(W0).cuda()[None], torch.from_numpy(H0).cuda()[None], max_iter=30, tol=0.0)
+    assert _rel(X, res.W[0].cpu().numpy(), res.H[0].cpu().numpy(), ref) <= TOL
+    res2 = ms.fit_batched(np.asfortranarray(X), W0, H0, max_iter=30, tol=0.0)
+    np.testing.assert_array_equal(res.W[0].cpu().numpy(), res2.W[0])
+    np.testing.assert_array_equal(res.H[0].cpu().numpy(), res2.H[0])
+
+
+def test_wide_find_synergies_does_not_fall_back():
+    """find_synergies(df 64 channels, solver='mu') stays on the GPU (round 2 handed it to scikit-learn)."""
+    import warnings
+
+    import pandas as pd
+
+    import muscle_synergies_amd as ms
+    from muscle_synergies_amd.hip_nmf import HipNMF
+
+    X = emg_matrix(5, T=500, m=64, k_true=6, dtype=np.float64)
+    df = pd.DataFrame(X, columns=[f"ch{i}" for i in range(64)])
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", RuntimeWarning)  # the fallback announces itself with a RuntimeWarning
+        res = ms.find_synergies(df, 10, solver="mu", max_iter=60, tol=0.0, init="nndsvda", random_state=0)
+    assert isinstance(res.model, HipNMF)
+    assert _last_kernel().startswith("fit_wide_kernel<double")
+    assert res.components.shape == (10, 64)
+    from muscle_synergies_amd.init import initialize_nmf
+
+    W0, H0 = initialize_nmf(X, 10, init="nndsvda", random_state=0)
+    ref = orc.nmf_mu_fit(X, W0, H0, max_iter=60, tol=0.0)
+    np.testing.assert_allclose(res.model.components_, ref["H"], rtol=1e-8, atol=1e-12)
