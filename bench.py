@@ -255,8 +255,21 @@ def compute_roofline(kernel, kernel_ms, units_per_launch, T, m, k, traffic=None,
         mem["design_bytes_per_unit"] = moved_bytes_per_unit
         mem["design_gbs"] = moved_bytes_per_unit * units_per_launch / sec / 1e9
         mem["frac_of_stream_peak"] = mem["design_gbs"] / STREAM_PEAK_GBS
+    if m > 32 or k > 8:
+        # wide shapes (nmf_wide.hpp): the batch does not fit the Infinity Cache (2.56 MB of X per 64-channel matrix, one
+        # matrix per workgroup, several hundred in flight) and W streams too: HBM-bound, reported against the 8 TB/s line
+        mem.pop("note"), mem.pop("stream_peak_gbs")
+        gbs = by * units_per_launch / sec / 1e9
+        return {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                "traffic": traffic, "kernel": kernel, "kernel_ms_avg": kernel_ms, "algorithmic_bytes_per_unit": by,
+                "units_per_launch": units_per_launch,
+                "matrix_pipe": {"achieved_tflops_useful": tf, "peak_tflops": FP32_PEAK_TFLOPS, "frac_useful": tf / FP32_PEAK_TFLOPS,
+                                "issued_tflops": tf * (16.0 / k) * ((m + 15) // 16 * 16 + 16.0) / (m + k),
+                                "note": "all four contractions on v_mfma_f32_16x16x4_f32 with components padded to 16 and "
+                                        "channels to a multiple of 16 (issued = useful x padding)"},
+                "memory": mem}
     return {
-        "bound": "mfma",
+        "bound": "fp32_issue",
         "bound_detail": "fp32 issue: f32 MFMA = f32 VALU = 157.3 TFLOP/s on gfx950 (the kernels use both)",
         "achieved": tf,
         "peak": FP32_PEAK_TFLOPS,
@@ -287,7 +300,8 @@ def run_batch(cx, single):
     from muscle_synergies_amd import _lib
     from muscle_synergies_amd.synth import emg_batch_torch
 
-    B = 1 if single else (a.batch or 4096)
+    wide = a.m > 32 or a.k > 8
+    B = 1 if single else (a.batch or (4096 if not wide else max(256, 4096 * 16 // max(a.m, 16))))
     # synthetic workload, generated on the device (seeded per rank).  X is handed over as [B, T, m] in C order
     # (row-major, what sklearn itself takes): the layout the fp32 16-channel kernels stream in place.  The
     # [B, m, T] storage (a DataFrame's F order) is timed too: the engine then converts it once per fit.
@@ -324,7 +338,7 @@ def run_batch(cx, single):
     avg_ms = sum(kernel_ms) / len(kernel_ms)
     layout = "row-major [B][T][m] (C order)" if a.x_layout == "row" else "channel-major [B][m][T] (F order)"
     traffic = _traffic(kernel, batch=B, iters=a.iters, T=a.T, m=a.m, k=a.k, x_layout=a.x_layout)
-    moved = 4 * (a.T * 16 + 2 * a.k * max(0, a.T - lds_rows_of_w(a.k))) if (a.m > 8 and not single) else None
+    moved = 4 * (a.T * 16 + 2 * a.k * max(0, a.T - lds_rows_of_w(a.k))) if (a.m > 8 and not single and not wide) else None
     cfg = {
         "workload": (f"one synthetic EMG matrix {a.m} ch x {a.T} samples per GPU, k={a.k}, fp32, {a.iters} mu iterations "
                      f"per fit (BASELINE.json configs[1]; N > 1 = independent replicas)") if single else
@@ -383,7 +397,7 @@ def run_rank_sweep(cx):
                        "ranks": [kmin, kmax], "iters_per_fit": a.iters,
                        "parallelism": f"trials scattered over {cx.world} GPU(s), no collective",
                        "selected_rank_histogram_rank0": hist},
-            "roofline": {"bound": "mfma", "bound_detail": "fp32 issue (f32 MFMA = f32 VALU = 157.3 TFLOP/s); seven kernels, one per rank",
+            "roofline": {"bound": "fp32_issue", "bound_detail": "fp32 issue (f32 MFMA = f32 VALU = 157.3 TFLOP/s); seven kernels, one per rank",
                          "achieved": tf, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_PEAK_TFLOPS,
                          "traffic": None, "kernel": "fit_persistent_kernel<float,1,16,k,0> (k <= 5), fit_rowlane_kernel<k,...> (k >= 6)",
                          "kernel_ms_avg": avg_ms, "units_per_launch": B * nk * a.iters}}

@@ -126,6 +126,14 @@ __device__ __forceinline__ void wide_store4(rsrc_t r, unsigned voff, unsigned so
 // executes a wave's operations in order)
 __device__ __forceinline__ void wide_wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
 
+// Cache policy of the X stream (buf_load: 2 = non-temporal).  The matrices being worked on do not fit the Infinity Cache
+// (2.56 MB of X each at 64 channels, two per CU), but their W does (320 KB each at k = 8): streamed non-temporal, X no
+// longer evicts it and the read-modify-write of W stays on the die.  tools/ubench/wide_stream.hip, this traffic with no
+// arithmetic: 4.97 TB/s with the default policy, 5.88 TB/s non-temporal (X alone: 6.3 -> 7.0 TB/s).
+#ifndef HIPNMF_WIDE_X_AUX
+#define HIPNMF_WIDE_X_AUX 2
+#endif
+
 template <typename real, int MP, int KP>
 struct WideTile {
   using C = WideCfg<real, MP, KP>;
@@ -133,12 +141,14 @@ struct WideTile {
   real w[C::NKB][4];        // W fragment: row j, components 16 kb + 4 g .. + 3
 };
 
-#ifndef HIPNMF_WIDE_OCC
-#define HIPNMF_WIDE_OCC
-#endif
-
-template <typename real, int MP, int KP, int NW, bool HREG>
-__global__ void __launch_bounds__(NW * 64) HIPNMF_WIDE_OCC fit_wide_kernel(WideArgs<real> a) {
+// WPE: waves per SIMD the instance is compiled for.  2 caps the allocation at 256 registers, which also makes hipcc
+// select the VGPR-destination form of the MFMAs (with 512 registers available it parks the accumulators in AGPRs and
+// pays a v_accvgpr_read / _write per value the VALU touches: 46 of ~100 VALU instructions per subtile in the first build).
+// NSET: register sets of subtile loads a wave keeps in flight (the subtile being worked on has been staged, so NSET
+// further ones are on their way).
+template <typename real, int MP, int KP, int NW, bool HREG, int WPE, int NSET>
+__global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WPE > 1 ? 8 : 1)))
+fit_wide_kernel(WideArgs<real> a) {
   using C = WideCfg<real, MP, KP>;
   using M = WideMma<real>;
   using acc = typename M::acc;
@@ -173,31 +183,40 @@ __global__ void __launch_bounds__(NW * 64) HIPNMF_WIDE_OCC fit_wide_kernel(WideA
   const int ntiles = (T + 15) / 16;
   const unsigned ldx_b = (unsigned)(a.ldx * (long long)sizeof(real));
   const unsigned ldw_b = (unsigned)ks * (unsigned)sizeof(real);
-  const rsrc_t xr = make_rsrc(Xb, (unsigned)((long long)(T + 16) * ldx_b));
-  const rsrc_t wr = make_rsrc(Wb, (unsigned)((long long)(T + 16) * ldw_b));
 
-  // per-lane addressing
+  // per-lane addressing.  Rows beyond the matrix are masked by the buffer descriptors, not by the lanes: the
+  // descriptor of a subtile starts at its first row and ends with the matrix (scalar arithmetic), so a lane offset is
+  // in range exactly when its row exists; pieces of a row beyond the data get the out-of-range sentinel once.
   const int xl_row = lane / CPR, xl_chunk = lane % CPR;
   const bool xl_active = lane < RPL * CPR;
-  const unsigned xvoff = (xl_active && xl_chunk < a.xchunks) ? (unsigned)xl_row * ldx_b + (unsigned)xl_chunk * 16u : OOB;
+  unsigned xvoff[NLD];
+#pragma unroll
+  for (int n = 0; n < NLD; ++n)
+    xvoff[n] = (xl_active && xl_chunk < a.xchunks) ? (unsigned)(n * RPL + xl_row) * ldx_b + (unsigned)xl_chunk * 16u : OOB;
   real* const xs_put = xs + xl_row * SX + xl_chunk * VEC;
   unsigned wvoff[NKB];
 #pragma unroll
   for (int kb = 0; kb < NKB; ++kb)
     wvoff[kb] = (16 * kb + 4 * g < ks) ? (unsigned)((j * ks + 16 * kb + 4 * g) * (int)sizeof(real)) : OOB;
   const int ar = M::arow(j);  // logical row this lane carries in an A operand
+  const char* const xbase = reinterpret_cast<const char*>(Xb);
+  char* const wbase = reinterpret_cast<char*>(Wb);
+  auto x_rsrc = [&](int i) __attribute__((always_inline)) {  // rows [16 i, T) of X; empty beyond the matrix
+    const int rows = i < ntiles ? T - 16 * i : 0;
+    return make_rsrc(xbase + (long long)(rows > 0 ? 16 * i : 0) * ldx_b, (unsigned)rows * ldx_b);
+  };
+  auto w_rsrc = [&](int i) __attribute__((always_inline)) {
+    const int rows = i < ntiles ? T - 16 * i : 0;
+    return make_rsrc(wbase + (long long)(rows > 0 ? 16 * i : 0) * ldw_b, (unsigned)rows * ldw_b);
+  };
 
   auto issue = [&](Tile& t, int i) __attribute__((always_inline)) {  // loads of subtile i (i >= ntiles: nothing moves)
-    const int t0 = i * 16;
-    const bool in = i < ntiles;
+    const rsrc_t xr = x_rsrc(i);
+    const rsrc_t wr = w_rsrc(i);
 #pragma unroll
-    for (int n = 0; n < NLD; ++n) {
-      const bool ok = in && (t0 + n * RPL + xl_row < T);
-      buf_load<real, VEC>(xr, ok ? xvoff : OOB, (unsigned)(t0 + n * RPL) * ldx_b, t.xg[n]);
-    }
-    const bool wok = in && (t0 + j < T);
+    for (int n = 0; n < NLD; ++n) buf_load<real, VEC, (HIPNMF_WIDE_X_AUX)>(xr, xvoff[n], 0u, t.xg[n]);
 #pragma unroll
-    for (int kb = 0; kb < NKB; ++kb) buf_load<real, 4>(wr, wok ? wvoff[kb] : OOB, (unsigned)t0 * ldw_b, t.w[kb]);
+    for (int kb = 0; kb < NKB; ++kb) buf_load<real, 4>(wr, wvoff[kb], 0u, t.w[kb]);
   };
   auto stage_x = [&](const Tile& t) __attribute__((always_inline)) {
     if (xl_active) {
@@ -246,7 +265,6 @@ __global__ void __launch_bounds__(NW * 64) HIPNMF_WIDE_OCC fit_wide_kernel(WideA
 
   // ---- one subtile: W update (_nmf.py:540-554, 615-631) and the sums of W^T X / W^T W (:638-640) ------------------
   auto update_subtile = [&](Tile& t, int i, int inext, bool upd) __attribute__((always_inline)) {
-    const int t0 = i * 16;
     stage_x(t);
     real wold[NKB][4];
 #pragma unroll
@@ -311,9 +329,11 @@ __global__ void __launch_bounds__(NW * 64) HIPNMF_WIDE_OCC fit_wide_kernel(WideA
 #pragma unroll
       for (int r = 0; r < 4; ++r) wn[kb][r] = wold[kb][r] * qq[r];
     }
-    const bool wok = t0 + j < T;
+    {
+      const rsrc_t wr = w_rsrc(i);
 #pragma unroll
-    for (int kb = 0; kb < NKB; ++kb) wide_store4<real>(wr, wok ? wvoff[kb] : OOB, (unsigned)t0 * ldw_b, wn[kb]);
+      for (int kb = 0; kb < NKB; ++kb) wide_store4<real>(wr, wvoff[kb], 0u, wn[kb]);
+    }
     if (upd) {
       // transpose the new rows through the wave's W stage: A operand lane (c, g), k-step s <-> W[row 4 g + s][c]
 #pragma unroll
@@ -428,7 +448,7 @@ __global__ void __launch_bounds__(NW * 64) HIPNMF_WIDE_OCC fit_wide_kernel(WideA
   int n_iter = 0;
   Tile ta, tb;
   issue(ta, wave);
-  issue(tb, wave + NW);
+  if constexpr (NSET > 1) issue(tb, wave + NW);
   for (int it = 1; it <= a.max_iter; ++it) {
     n_iter = it;
 #pragma unroll
@@ -438,16 +458,23 @@ __global__ void __launch_bounds__(NW * 64) HIPNMF_WIDE_OCC fit_wide_kernel(WideA
 #pragma unroll
       for (int kb2 = 0; kb2 < NKB; ++kb2) accB[kb][kb2] = zero;
     }
-    for (int i = wave; i < ntiles; i += 2 * NW) {
-      update_subtile(ta, i, i + 2 * NW, upd);
-      __builtin_amdgcn_sched_barrier(0);
-      if (i + NW < ntiles) update_subtile(tb, i + NW, i + 3 * NW, upd);
-      __builtin_amdgcn_sched_barrier(0);
+    if constexpr (NSET > 1) {
+      for (int i = wave; i < ntiles; i += 2 * NW) {
+        update_subtile(ta, i, i + 2 * NW, upd);
+        __builtin_amdgcn_sched_barrier(0);
+        if (i + NW < ntiles) update_subtile(tb, i + NW, i + 3 * NW, upd);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+      for (int i = wave; i < ntiles; i += NW) {
+        update_subtile(ta, i, i + NW, upd);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     // X does not depend on H, and this wave's first rows of W are final: request the next pass's first subtiles now
     if (it < a.max_iter) {
       issue(ta, wave);
-      issue(tb, wave + NW);
+      if constexpr (NSET > 1) issue(tb, wave + NW);
     }
     if (upd) {
       // per-wave record [W^T X | W^T W] over the wave's stages (idle between passes), fixed-order sum over the waves

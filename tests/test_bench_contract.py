@@ -24,13 +24,21 @@ def test_unit_of_work_model_matches_the_survey():
 def test_roofline_object_is_against_the_binding_roofs():
     r = bench.compute_roofline("fit_persistent_kernel<float,1,16,5,0>", 200.0, 4096 * 500, 10_000, 16, 5,
                                traffic=1.5185e12)
-    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 157.3
+    assert r["bound"] == "fp32_issue" and r["unit"] == "TFLOP/s" and r["peak"] == 157.3
     assert 0 < r["frac"] < 1 and abs(r["achieved"] - 4301760 * 2048000 / 0.2 / 1e12) < 1e-6
     mem = r["memory"]
     assert mem["algorithmic_bytes_per_unit"] == 1_040_000 and mem["l2_fabric_bytes_per_launch"] == 1.5185e12
     assert 0.9 < mem["frac_of_stream_peak"] < 1.05
     r2 = bench.compute_roofline("k", 200.0, 4096 * 500, 10_000, 16, 5, traffic=None, moved_bytes_per_unit=732_800)
     assert r2["traffic"] is None and "design_gbs" in r2["memory"]
+
+
+def test_wide_shapes_report_against_the_hbm_line():
+    r = bench.compute_roofline("fit_wide_kernel<float,64,16,4>", 26.6, 1024 * 40, 10_000, 64, 8)
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert r["algorithmic_bytes_per_unit"] == 4 * 10_000 * (64 + 16)
+    assert abs(r["achieved"] - 3_200_000 * 40960 / 26.6e-3 / 1e9) < 1e-6 and 0 < r["frac"] < 1
+    assert r["matrix_pipe"]["issued_tflops"] > r["matrix_pipe"]["achieved_tflops_useful"]
 
 
 def test_command_line_contract():
