@@ -502,6 +502,11 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
       return e ? atoi(e) : 1;
     }();
     c.coop_xcd = (coop_xcd_env > 0 && !h->coop_xcd_failed && B == 1 && coop_S >= 2 && coop_S <= 32 && 8 * coop_S <= h->num_cu) ? coop_xcd_env : 0;
+    static const unsigned gen_base_env = [] {  // test hook: start the exchange's generation numbers next to the 32-bit wrap
+      const char* e = getenv("HIPNMF_COOP_GEN_BASE");
+      return e ? (unsigned)strtoul(e, nullptr, 0) : 0u;
+    }();
+    c.gen_base = gen_base_env;
     const void* kern = reinterpret_cast<const void*>(c.coop_xcd ? ks->fit_coop_xcd : ks->fit_coop);
     if (coop_smem > 48 * 1024)
       HIP_TRY(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)coop_smem));

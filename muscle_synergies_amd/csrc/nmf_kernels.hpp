@@ -297,6 +297,7 @@ struct SolveArgs {
                       // (sync then continues with an 'updates began' word, [B][8] tickets, [B] target XCD + 1, [B][32] generation flags 32 words apart)
   int fuse_h;         // slice_pass_kernel: 1 = the last workgroup of a matrix sums the records and updates H itself
   real tol, l1w, l2w, l1h, l2h;
+  unsigned gen_base;  // cooperative kernel: offset of the exchange's generation numbers (0; a test hook moves it next to the 32-bit wrap)
 };
 
 template <typename real, int G, int CH, int K>
@@ -1421,6 +1422,42 @@ __device__ __forceinline__ bool coop_barrier(unsigned* counter, unsigned* abort_
   return ok_sh != 0;
 }
 
+// Head count of the same-XCD mode: all or nothing.  Every slice arrives at `counter`; the arrival that completes the
+// count and a slice that gives up waiting race for ONE state word (compare-and-swap 0 -> 1 "go" / 0 -> 2 "abort"), and
+// every slice follows whatever that word holds -- the S slices always take the same branch, however a time-out and the
+// last arrival interleave.  The wait is short (the workgroups of a cooperative launch start together): a head count
+// that fails costs milliseconds, not the ~1 s of the in-fit barriers.
+// Scope of the same-XCD flavour's record / flag stores.  Workgroup scope is a global_store with sc0 (coherent in the
+// XCD's L2, which is where the peers read it with L1-bypassing loads); -DHIPNMF_COOP_XCD_SCOPE=__HIP_MEMORY_SCOPE_WAVEFRONT
+// gives round 2's store without cache-policy bits (measured: no difference, 6.3 us per iteration either way).
+#ifndef HIPNMF_COOP_XCD_SCOPE
+#define HIPNMF_COOP_XCD_SCOPE __HIP_MEMORY_SCOPE_WORKGROUP
+#endif
+#ifndef HIPNMF_COOP_HEAD_SPIN_LIMIT
+#define HIPNMF_COOP_HEAD_SPIN_LIMIT (1u << 16)
+#endif
+__device__ __forceinline__ bool coop_head_count(unsigned* counter, unsigned* state, unsigned* abort_flag, unsigned S) {
+  __shared__ int go_sh;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned expected = 0u;
+    if (__hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == S)
+      __hip_atomic_compare_exchange_strong(state, &expected, 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned st, spins = 0;
+    while ((st = __hip_atomic_load(state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > HIPNMF_COOP_HEAD_SPIN_LIMIT) {
+        expected = 0u;
+        __hip_atomic_compare_exchange_strong(state, &expected, 2u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    if (st != 1u) __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    go_sh = st == 1u;
+  }
+  __syncthreads();
+  return go_sh != 0;
+}
+
 // Same-XCD flavour (a.coop_xcd): every workgroup of the matrix runs on one XCD, whose L2 all of them share.  Records
 // are PLAIN stores (written through this CU's L1 into that L2, where the line stays), every storing wave waits for
 // them (vmcnt(0)), then the workgroup barrier, then ONE lane publishes the workgroup's generation number the same way;
@@ -1433,7 +1470,7 @@ __device__ __forceinline__ bool coop_barrier_xcd(unsigned* flags /* [32 * 32] wo
   __syncthreads();
   if (threadIdx.x < WAVE) {
     if (threadIdx.x == 0) {
-      *reinterpret_cast<volatile unsigned*>(flags + 32u * sl) = n;
+      __hip_atomic_store(flags + 32u * sl, n, __ATOMIC_RELAXED, HIPNMF_COOP_XCD_SCOPE);  // a plain store into the shared L2
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     int ok = 1;
@@ -1509,6 +1546,12 @@ __device__ __forceinline__ void coop_sum_records_atomic(const real* __restrict__
 // (low and high word, each with the generation).  The consumer needs neither a barrier nor a flag: it polls the
 // granules it sums (L1-bypassing loads) until their generation matches, which saves the publish / poll round trip of
 // the flag barrier (~0.8 us per iteration).  Same summation order as coop_sum_records_atomic.  False after an abort.
+// Generation number of iteration `it`: never 0 (the cleared state of the record buffers) and different for any two
+// iterations less than 2^32 - 1 apart, wherever the sequence starts -- in particular two iterations apart, which is the
+// age of the granules an exchange overwrites.
+__device__ __forceinline__ unsigned coop_generation(unsigned base, int it) {
+  return (unsigned)(((unsigned long long)base + (unsigned long long)(unsigned)it) % 0xffffffffull) + 1u;
+}
 __device__ __forceinline__ unsigned long long coop_poll_granule(const unsigned long long* p, unsigned long long g, unsigned gen,
                                                                 unsigned* abort_flag, bool& ok) {
   unsigned spins = 0;
@@ -1630,7 +1673,8 @@ __global__ void __launch_bounds__((max_threads<real, G, CH, K>())) HIPNMF_OCC fi
     __syncthreads();
     sl = sl_sh;
     if (sl < 0) return;
-    if (!coop_barrier(a.sync + b, abort_flag, (unsigned)S, 1u)) return;  // head count: S slices present, or nothing happens
+    unsigned* head_state = a.sync + gridDim.y + 2 + 9 * gridDim.y + 32 * 32 * gridDim.y + b;  // [B] behind the flags
+    if (!coop_head_count(a.sync + b, head_state, abort_flag, (unsigned)S)) return;  // S slices present, or nothing happens
     if (sl == 0 && threadIdx.x == 0)  // from here on W and H change: the host may no longer fall back silently
       __hip_atomic_store(abort_flag + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
@@ -1649,8 +1693,8 @@ __global__ void __launch_bounds__((max_threads<real, G, CH, K>())) HIPNMF_OCC fi
   unsigned nbar = XCD ? 1u : 0u;  // the head count was barrier 1
   // records: device-scope atomics through the fabric, or (same-XCD mode) plain stores kept in the shared L2
   auto put = [&](real* p_, real v_) __attribute__((always_inline)) {
-    if constexpr (XCD)
-      *p_ = v_;
+    if constexpr (XCD)  // a plain global store in the ISA (no sc bits), but single-copy atomic and not the compiler's to split or sink
+      __hip_atomic_store(p_, v_, __ATOMIC_RELAXED, HIPNMF_COOP_XCD_SCOPE);
     else
       coop_store(p_, v_);
   };
@@ -1736,8 +1780,11 @@ __global__ void __launch_bounds__((max_threads<real, G, CH, K>())) HIPNMF_OCC fi
         // tagged granules {32 value bits, generation}: ONE 8-byte store each (plain into the shared L2, or written through
         // to the coherence point in the device-scope flavour), no barrier, no flag
         constexpr int GP = (int)sizeof(real) / 4;
+        // (gpart is 256-byte aligned workspace and every granule index is a whole number of 8-byte elements)
+        static_assert(sizeof(unsigned long long) == 8 && alignof(unsigned long long) == 8, "granules are 8-byte objects");
         unsigned long long* g64 = reinterpret_cast<unsigned long long*>(gpart) + (long long)(it & 1) * S * C::NACC * GP;
-        const unsigned long long tag = (unsigned long long)((unsigned)it + 1u) << 32;
+        const unsigned gen = coop_generation(a.gen_base, it);
+        const unsigned long long tag = (unsigned long long)gen << 32;
         for (int i = threadIdx.x; i < C::NACC; i += blockDim.x) {
           real acc = s.part[i];
           for (int w = 1; w < nw; ++w) acc += s.part[w * C::NACC + i];
@@ -1750,14 +1797,17 @@ __global__ void __launch_bounds__((max_threads<real, G, CH, K>())) HIPNMF_OCC fi
           for (int w = 0; w < GP; ++w) {
             const unsigned long long gran = tag | ((bits >> (32 * w)) & 0xffffffffull);
             unsigned long long* dst = g64 + ((long long)sl * C::NACC + i) * GP + w;
+            // ONE 8-byte store either way (formally an atomic: the tag and the value can neither tear nor be merged, split
+            // or sunk by the compiler).  Workgroup scope = a plain global_store_dwordx2 that stays in the XCD's L2, agent
+            // scope = the same store written through to the coherence point.
             if constexpr (XCD)
-              *dst = gran;
+              __hip_atomic_store(dst, gran, __ATOMIC_RELAXED, HIPNMF_COOP_XCD_SCOPE);
             else
               __hip_atomic_store(dst, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
         }
         __syncthreads();  // s.part is about to be overwritten by the sums
-        alive = coop_sum_records_tagged<real>(g64, S, C::NACC, (unsigned)it + 1u, scratch, s.part, abort_flag) && alive;
+        alive = coop_sum_records_tagged<real>(g64, S, C::NACC, gen, scratch, s.part, abort_flag) && alive;
       }
       if (wave == 0) wave0_combine_and_update_h(s, 1, m, a.l1h, a.l2h);
       __syncthreads();
