@@ -364,12 +364,15 @@ def run_rank_sweep(cx):
     a, torch = cx.a, cx.torch
     import muscle_synergies_amd as ms
     from muscle_synergies_amd.engine import partition
-    from muscle_synergies_amd.synth import emg_batch_torch
+    from muscle_synergies_amd.engine import rank_sweep_native
+    from muscle_synergies_amd.synth import emg_rank_trials_torch
 
     total = a.batch or 1024
     lo, hi = partition(total, cx.world)[cx.rank]  # scattered by trial: contiguous slices, no collective
     B = hi - lo
-    X, _, _ = emg_batch_torch(B, T=a.T, m=a.m, k=a.k, device=cx.dev, seed=1000 + cx.rank)
+    # trials whose smallest sufficient rank differs (bursting synergies, k_true = 2..6: synth.emg_rank_trials_torch); round
+    # 2's smoothed-noise batch selected k = 2 for every trial and could not tell a real stop from a post-hoc one
+    X, k_true = emg_rank_trials_torch(B, T=a.T, m=a.m, device=cx.dev, seed=1000 + cx.rank)
     Xv = X.transpose(1, 2).contiguous()
     kmin, kmax = 2, 8
     kms = []
@@ -380,10 +383,25 @@ def run_rank_sweep(cx):
         return r
 
     elapsed, outs = cx.timed(step)
+    # the same sweep as one library call, computing every rank (the reference's behaviour, analysis.py:907-912) and with
+    # the real stop (hipnmf_rank_sweep_stop_*): untimed warm-up + one timed call each, on every rank; reported by rank 0
+    native = {}
+    for stop in (False, True):
+        for rep in range(2):
+            torch.cuda.synchronize(cx.dev)
+            t0 = time.perf_counter()
+            rn = rank_sweep_native(Xv, kmin, kmax, vaf_threshold=0.90, max_iter=a.iters, tol=0.0, seed=1, device=cx.dev,
+                                   stop_at_threshold=stop)
+            torch.cuda.synchronize(cx.dev)
+            native[stop] = (rn, time.perf_counter() - t0)
+    cx.barrier()
     if cx.rank != 0:
         return None
     r = outs[-1]
     nk = kmax - kmin + 1
+    r_all, t_all = native[False]
+    r_stop, t_stop = native[True]
+    fits_run = sum(int((r_stop.n_iter[k] > 0).sum().item()) for k in r_stop.ranks)
     kms = kms[a.warmup:]
     avg_ms = sum(kms) / len(kms)
     fl = sum(flops_per_unit(a.T, a.m, k) for k in range(kmin, kmax + 1)) * B * a.iters
@@ -396,7 +414,15 @@ def run_rank_sweep(cx):
                        "trials_total": total, "trials_rank0": B, "n_samples": a.T, "n_features": a.m,
                        "ranks": [kmin, kmax], "iters_per_fit": a.iters,
                        "parallelism": f"trials scattered over {cx.world} GPU(s), no collective",
-                       "selected_rank_histogram_rank0": hist},
+                       "selected_rank_histogram_rank0": hist,
+                       "true_rank_histogram_rank0": torch.bincount(k_true, minlength=kmax + 1).tolist(),
+                       "native_sweep_rank0": {
+                           "compute_all_ms": t_all * 1e3, "stop_at_threshold_ms": t_stop * 1e3,
+                           "fits_run_with_stop": fits_run, "fits_total": B * nk,
+                           "selected_identical": bool(torch.equal(r_all.selected, r_stop.selected)),
+                           "matrix_iterations_per_s_compute_all": B * nk * a.iters / t_all,
+                           "note": "hipnmf_rank_sweep_* vs hipnmf_rank_sweep_stop_* (one library call each, random init "
+                                   "drawn inside); `value` above is the compute-all sweep through the Python host"}},
             "roofline": {"bound": "fp32_issue", "bound_detail": "fp32 issue (f32 MFMA = f32 VALU = 157.3 TFLOP/s); seven kernels, one per rank",
                          "achieved": tf, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_PEAK_TFLOPS,
                          "traffic": None, "kernel": "fit_persistent_kernel<float,1,16,k,0> (k <= 5), fit_rowlane_kernel<k,...> (k >= 6)",

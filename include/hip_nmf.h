@@ -38,7 +38,7 @@ extern "C" {
 #define HIPNMF_OK 0
 #define HIPNMF_ERR_BAD_ARG (-1)
 #define HIPNMF_ERR_HIP (-2)
-#define HIPNMF_ERR_UNSUPPORTED (-3) /* shape outside the compiled kernel set (m <= 32, k <= 8) */
+#define HIPNMF_ERR_UNSUPPORTED (-3) /* shape outside the compiled kernel set (m <= 128, k <= 16; shard entries m <= 32, k <= 8) */
 #define HIPNMF_ERR_NO_DEVICE (-4)
 
 /* memory layout of one X matrix.  Either is accepted everywhere; which one the kernels stream WITHOUT a one-off
@@ -65,8 +65,8 @@ typedef struct hipnmf_problem {
   int32_t struct_size;    /* = sizeof(hipnmf_problem), ABI guard                                       */
   int32_t batch;          /* B  >= 1 independent factorisations                                        */
   int64_t n_samples;      /* T  rows of X (time samples)                                               */
-  int32_t n_features;     /* m  columns of X (muscles), 1..32                                          */
-  int32_t n_components;   /* k  rank, 1..8                                                             */
+  int32_t n_features;     /* m  columns of X (muscles), 1..128 (time-shard entry points: 1..32)        */
+  int32_t n_components;   /* k  rank, 1..16 (time-shard entry points: 1..8)                            */
   int32_t x_layout;       /* HIPNMF_X_*                                                                */
   int32_t update_h;       /* 1: fit (W and H updated, _nmf.py:854); 0: transform (H fixed, :1736-1763) */
   int32_t w_layout;       /* HIPNMF_W_*                                                                */
@@ -205,6 +205,21 @@ int hipnmf_rank_sweep_f32(hipnmf_handle* h, const hipnmf_problem* p, int32_t k_m
 int hipnmf_rank_sweep_f64(hipnmf_handle* h, const hipnmf_problem* p, int32_t k_min, int32_t k_max, double vaf_threshold,
                           uint64_t seed, int32_t first_matrix, const double* X, double* W_ws, double* H_out, double* vaf_out,
                           int32_t* selected_out, double* err_out, int32_t* n_iter_out);
+/*
+ * The same sweep with the "stop" of BASELINE.json config #4 ("k = 2..8 with VAF >= 0.90 stop", Rabbi et al. 2020): a
+ * trial whose VAF has reached vaf_threshold at rank k is NOT fitted at the higher ranks.  After every rank the
+ * still-unexplained trials are compacted and only they are launched at rank k + 1; every fit that runs is bit-identical
+ * to the one hipnmf_rank_sweep_* runs for that (trial, rank) -- same starting point (keyed by the original trial index),
+ * same kernel and launch geometry (chosen as for the full batch) -- so selected_out is identical by construction.
+ * (trial, rank) pairs that were skipped report vaf = err = NaN, n_iter = 0 and all-zero components.  The reference
+ * itself computes every rank (analysis.py:907-912) and leaves the thresholding to the user (:753-756).
+ */
+int hipnmf_rank_sweep_stop_f32(hipnmf_handle* h, const hipnmf_problem* p, int32_t k_min, int32_t k_max, double vaf_threshold,
+                               uint64_t seed, int32_t first_matrix, const float* X, float* W_ws, float* H_out, float* vaf_out,
+                               int32_t* selected_out, float* err_out, int32_t* n_iter_out);
+int hipnmf_rank_sweep_stop_f64(hipnmf_handle* h, const hipnmf_problem* p, int32_t k_min, int32_t k_max, double vaf_threshold,
+                               uint64_t seed, int32_t first_matrix, const double* X, double* W_ws, double* H_out, double* vaf_out,
+                               int32_t* selected_out, double* err_out, int32_t* n_iter_out);
 
 /* ---- EMG envelope preprocessing: the producer of X ------------------ */
 /*

@@ -41,6 +41,7 @@ EXPORTS = (
     "hipnmf_shard_pass_f64", "hipnmf_shard_hupdate_f64", "hipnmf_shard_residual_f64",
     "hipnmf_fit_tsharded_f32", "hipnmf_fit_tsharded_f64",
     "hipnmf_random_init_f32", "hipnmf_random_init_f64", "hipnmf_rank_sweep_f32", "hipnmf_rank_sweep_f64",
+    "hipnmf_rank_sweep_stop_f32", "hipnmf_rank_sweep_stop_f64",
     "hipnmf_emg_envelope_f32", "hipnmf_emg_envelope_f64", "hipnmf_sosfilt_f32", "hipnmf_sosfilt_f64",
     "hipnmf_gram_f32", "hipnmf_gram_f64", "hipnmf_nndsvd_stats_f32", "hipnmf_nndsvd_stats_f64",
     "hipnmf_nndsvd_write_f32", "hipnmf_nndsvd_write_f64",

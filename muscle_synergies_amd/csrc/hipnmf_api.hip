@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <string>
 #include <vector>
 
@@ -203,13 +204,14 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
   // ---- path selection ---------------------------------------------------------------------------
   // persistent: one workgroup per matrix, ~1.2 ns per row-iteration per workgroup, num_cu in flight;
   // sliced: ~3 launches (~7 us) per iteration, rows spread over the whole chip.
-  SliceGeom sg = slice_geometry(h, T, B);
+  const int Bsel = h->path_batch_hint > B ? h->path_batch_hint : B;  // rank sweep on a compacted sub-batch: path and geometry of the full batch
+  SliceGeom sg = slice_geometry(h, T, Bsel);
   // per-iteration cost models fitted to tools/config2_bench.py on MI355X (k = 5, m = 16, fp32):
   // persistent 2.7 ns per row of one matrix, num_cu matrices at a time; sliced 9.5 us of launches +
   // 0.021 ns per row of the whole batch; cooperative (further down) 3.7-5.5 us + 2.4 us per workgroup-step of rows
-  const double waves = (double)((B + h->num_cu - 1) / h->num_cu);
+  const double waves = (double)((Bsel + h->num_cu - 1) / h->num_cu);
   const double t_pers = waves * ((double)T * (ks->row_major ? 2.0e-9 : 2.7e-9) + 1e-6);  // row-per-lane: 20.8 us / 10 000 rows
-  const double t_sliced = 9.5e-6 + (double)B * (double)T * 0.021e-9;
+  const double t_sliced = 9.5e-6 + (double)Bsel * (double)T * 0.021e-9;
   bool persistent;
   if (h->variant == 1 || h->variant == 4 || h->variant == 5 || h->variant == 6)
     persistent = true;
@@ -278,11 +280,11 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
   // costs ~8 us (L2 write-back / invalidate on a multi-XCD part); with the fence-free exchange the kernel uses
   // (device-scope relaxed atomics for the records and the counter) an iteration of one 16 x 10 000 matrix takes
   // 7.1 us against 10.2 us for the sliced path and 27 us for one persistent workgroup.
-  if (!use_small && !ragged && !kl && ks->fit_coop && (h->variant == 3 || (h->variant == 0 && h->use_coop)) && B <= h->num_cu / 2 && B <= 65535) {
+  if (!use_small && !ragged && !kl && ks->fit_coop && (h->variant == 3 || (h->variant == 0 && h->use_coop)) && Bsel <= h->num_cu / 2 && B <= 65535) {
     int threads = std::min(h->threads > 0 ? h->threads : 512, ks->max_threads);
     const long long t_pad = round_up(T, 64);
     while (threads > 64 && t_pad < 2LL * threads) threads /= 2;  // at least two workgroup-steps of rows in total
-    long long S = std::min<long long>(h->num_cu / B, (t_pad + threads - 1) / threads);
+    long long S = std::min<long long>(h->num_cu / Bsel, (t_pad + threads - 1) / threads);
     if (h->max_slices > 0) S = std::min<long long>(S, h->max_slices);
     if (S >= 2) {
       const long long rps = round_up((T + S - 1) / S, threads);
@@ -950,68 +952,139 @@ int tsharded_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, real
 // one batched fit per rank from init='random' starting points drawn on the device, VAF per trial and rank
 // (analysis.py:654-662), and the smallest rank whose VAF reaches the threshold.  Host-side loop over the library's own
 // entry points; the per-rank results are read back (B (m + 2) numbers per rank) for the VAF table.
+//
+// stop_at_threshold: the Rabbi et al. protocol proper -- a trial whose VAF has reached the threshold is not fitted at
+// the higher ranks.  After every rank the still-unexplained trials are compacted (their X gathered into workspace, their
+// starting points drawn with the ORIGINAL trial indices as keys, the solver path chosen as for the full batch), so
+// every fit that does run is bit-identical to the one the compute-all mode runs and `selected` cannot differ.
+template <typename real>
+__global__ void gather_matrices_kernel(const real* __restrict__ src, long long src_bstride, const int* __restrict__ index,
+                                       real* __restrict__ dst, long long dst_bstride, long long span) {
+  const real* s = src + (long long)index[blockIdx.y] * src_bstride;
+  real* d = dst + (long long)blockIdx.y * dst_bstride;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < span; i += (long long)gridDim.x * blockDim.x) d[i] = s[i];
+}
+
 template <typename real>
 int rank_sweep_impl(hipnmf_handle* h, const hipnmf_problem* p, int k_min, int k_max, double vaf_threshold, uint64_t seed,
                     int first_matrix, const real* X, real* W_ws, real* H_out, real* vaf_out, int32_t* selected_out,
-                    real* err_out, int32_t* n_iter_out) {
+                    real* err_out, int32_t* n_iter_out, bool stop_at_threshold) {
   if (!h) return fail(HIPNMF_ERR_BAD_ARG, "handle is NULL");
   if (!p || p->struct_size != (int32_t)sizeof(hipnmf_problem)) return fail(HIPNMF_ERR_BAD_ARG, "bad hipnmf_problem");
   if (!X || !W_ws || !H_out || !vaf_out) return fail(HIPNMF_ERR_BAD_ARG, "X, W_ws, H_out and vaf_out must be non-NULL");
   if (k_min < 1 || k_max < k_min || k_max > p->n_features)
     return fail(HIPNMF_ERR_BAD_ARG, "invalid number of components: need 1 <= k_min <= k_max <= n_features (got %d..%d, %d features)",
                 k_min, k_max, p->n_features);
+  if (p->n_features > HIPNMF_MAX_FEATURES || k_max > HIPNMF_MAX_COMPONENTS)
+    return fail(HIPNMF_ERR_UNSUPPORTED, "rank %d with %d features is outside the compiled kernel set (max %d x %d)", k_max,
+                p->n_features, HIPNMF_MAX_COMPONENTS, HIPNMF_MAX_FEATURES);
+  if (p->batch < 1) return fail(HIPNMF_ERR_BAD_ARG, "batch must be >= 1");
   HIP_TRY(hipSetDevice(h->device));
   const int B = p->batch, m = p->n_features, nk = k_max - k_min + 1;
+  const long long T = p->n_samples;
+  // one matrix of the caller's X as a flat span (gathered as it lies: same layout and leading dimension)
+  const long long span = (p->x_layout == HIPNMF_X_ROW_MAJOR ? T : (long long)m) * p->ldx;
+  const long long cstride = round_up(span, 16 / (long long)sizeof(real));
   real* cols = nullptr;  // [2][B][m] sse | xsq, [B] err, then n_iter
   HIP_TRY(hipMalloc(&cols, sizeof(real) * ((size_t)2 * B * m + B) + sizeof(int32_t) * (size_t)B));
   real* d_err = cols + (size_t)2 * B * m;
   int32_t* d_it = reinterpret_cast<int32_t*>(d_err + B);
-  std::vector<real> hs((size_t)2 * B * m), vaf((size_t)B * nk), herr((size_t)B * nk), e(B);
-  std::vector<int32_t> hit((size_t)B * nk), it(B), sel(B, -1);
+  real* xc = nullptr;    // compacted X, compacted H and the index list (stop mode, allocated when first needed)
+  real* hc = nullptr;
+  int* d_index = nullptr;
+  const real nan = std::numeric_limits<real>::quiet_NaN();
+  std::vector<real> hs((size_t)2 * B * m), vaf((size_t)B * nk, nan), herr((size_t)B * nk, nan), e(B);
+  std::vector<int32_t> hit((size_t)B * nk, 0), it(B), sel(B, -1);
+  std::vector<int> active(B);
+  for (int b = 0; b < B; ++b) active[b] = b;
   int rc = HIPNMF_OK;
   size_t h_off = 0;
+  const int saved_hint = h->path_batch_hint;
+  h->path_batch_hint = B;
   for (int k = k_min; k <= k_max && !rc; ++k) {
-    hipnmf_problem q = *p;
-    q.n_components = k;
     real* Hk = H_out + h_off;
     h_off += (size_t)B * k * m;
-    if (p->n_features > 32 || k > 8) {
-      rc = fail(HIPNMF_ERR_UNSUPPORTED, "rank %d with %d features is outside the compiled kernel set", k, m);
+    const int nA = (int)active.size();
+    const bool compact = stop_at_threshold && nA < B;
+    if (compact && hipMemsetAsync(Hk, 0, sizeof(real) * (size_t)B * k * m, h->stream) != hipSuccess) {
+      rc = fail(HIPNMF_ERR_HIP, "hipMemsetAsync failed");
       break;
     }
-    rc = sizeof(real) == 4 ? hipnmf_random_init_f32(h, &q, seed + (uint64_t)k, first_matrix, (const float*)X, (float*)W_ws, (float*)Hk)
-                           : hipnmf_random_init_f64(h, &q, seed + (uint64_t)k, first_matrix, (const double*)X, (double*)W_ws, (double*)Hk);
+    if (nA == 0) continue;  // every trial is explained: the remaining ranks report NaN / 0 iterations / zero components
+    hipnmf_problem q = *p;
+    q.n_components = k;
+    q.batch = nA;
+    const real* Xk = X;
+    real* Hfit = Hk;
+    if (compact) {
+      if (!xc) {
+        if (hipMalloc(&xc, sizeof(real) * (size_t)B * cstride) != hipSuccess ||
+            hipMalloc(&hc, sizeof(real) * (size_t)B * k_max * m) != hipSuccess || hipMalloc(&d_index, sizeof(int) * (size_t)B) != hipSuccess) {
+          rc = fail(HIPNMF_ERR_HIP, "hipMalloc of the compaction buffers failed");
+          break;
+        }
+      }
+      if (hipMemcpyAsync(d_index, active.data(), sizeof(int) * (size_t)nA, hipMemcpyHostToDevice, h->stream) != hipSuccess) {
+        rc = fail(HIPNMF_ERR_HIP, "copying the trial list failed");
+        break;
+      }
+      for (int b0 = 0; b0 < nA; b0 += 65535) {
+        dim3 grd((unsigned)std::min<long long>((span + 255) / 256, 256), (unsigned)std::min(65535, nA - b0));
+        hipLaunchKernelGGL(gather_matrices_kernel<real>, grd, dim3(256), 0, h->stream, X, (long long)p->x_batch_stride, d_index + b0,
+                           xc + (size_t)b0 * cstride, cstride, span);
+      }
+      q.x_batch_stride = cstride;
+      Xk = xc;
+      Hfit = hc;
+    }
+    rc = hipnmf_random_init_indexed<real>(h, &q, seed + (uint64_t)k, first_matrix, compact ? d_index : nullptr, Xk, W_ws, Hfit);
     if (rc) break;
-    rc = fit_batched_impl<real>(h, &q, X, W_ws, Hk, d_err, d_it, cols, cols + (size_t)B * m);
+    rc = fit_batched_impl<real>(h, &q, Xk, W_ws, Hfit, d_err, d_it, cols, cols + (size_t)nA * m);
     if (rc) break;
-    if (hipMemcpy(hs.data(), cols, sizeof(real) * hs.size(), hipMemcpyDeviceToHost) != hipSuccess ||
-        hipMemcpy(e.data(), d_err, sizeof(real) * B, hipMemcpyDeviceToHost) != hipSuccess ||
-        hipMemcpy(it.data(), d_it, sizeof(int32_t) * B, hipMemcpyDeviceToHost) != hipSuccess) {
+    if (hipMemcpy(hs.data(), cols, sizeof(real) * (size_t)2 * nA * m, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(e.data(), d_err, sizeof(real) * nA, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(it.data(), d_it, sizeof(int32_t) * nA, hipMemcpyDeviceToHost) != hipSuccess) {
       rc = fail(HIPNMF_ERR_HIP, "reading the results of rank %d back failed", k);
       break;
     }
     const int ki = k - k_min;
-    for (int b = 0; b < B; ++b) {
+    std::vector<int> still;
+    for (int a = 0; a < nA; ++a) {
+      const int b = active[a];
+      if (compact &&  // components of the trials fitted at this rank to their own slots (the others stay zero)
+          hipMemcpyAsync(Hk + (size_t)b * k * m, hc + (size_t)a * k * m, sizeof(real) * (size_t)k * m, hipMemcpyDeviceToDevice,
+                         h->stream) != hipSuccess) {
+        rc = fail(HIPNMF_ERR_HIP, "hipMemcpyAsync failed");
+        break;
+      }
       real sse = (real)0, xsq = (real)0;
       for (int j = 0; j < m; ++j) {
-        sse += hs[(size_t)b * m + j];
-        xsq += hs[(size_t)B * m + (size_t)b * m + j];
+        sse += hs[(size_t)a * m + j];
+        xsq += hs[(size_t)nA * m + (size_t)a * m + j];
       }
       const real v = (real)1 - sse / xsq;  // VAF over all muscles (analysis.py:660-662)
       vaf[(size_t)b * nk + ki] = v;
-      herr[(size_t)b * nk + ki] = e[b];
-      hit[(size_t)b * nk + ki] = it[b];
+      herr[(size_t)b * nk + ki] = e[a];
+      hit[(size_t)b * nk + ki] = it[a];
       if (sel[b] < 0 && (double)v >= vaf_threshold) sel[b] = k;
+      if (!stop_at_threshold || sel[b] < 0) still.push_back(b);
     }
+    if (stop_at_threshold) active.swap(still);
   }
+  h->path_batch_hint = saved_hint;
   if (!rc) {
-    if (hipMemcpy(vaf_out, vaf.data(), sizeof(real) * vaf.size(), hipMemcpyHostToDevice) != hipSuccess ||
+    if (hipStreamSynchronize(h->stream) != hipSuccess ||
+        hipMemcpy(vaf_out, vaf.data(), sizeof(real) * vaf.size(), hipMemcpyHostToDevice) != hipSuccess ||
         (selected_out && hipMemcpy(selected_out, sel.data(), sizeof(int32_t) * B, hipMemcpyHostToDevice) != hipSuccess) ||
         (err_out && hipMemcpy(err_out, herr.data(), sizeof(real) * herr.size(), hipMemcpyHostToDevice) != hipSuccess) ||
         (n_iter_out && hipMemcpy(n_iter_out, hit.data(), sizeof(int32_t) * hit.size(), hipMemcpyHostToDevice) != hipSuccess))
       rc = fail(HIPNMF_ERR_HIP, "writing the sweep results failed");
   }
+  (void)hipStreamSynchronize(h->stream);
   (void)hipFree(cols);
+  if (xc) (void)hipFree(xc);
+  if (hc) (void)hipFree(hc);
+  if (d_index) (void)hipFree(d_index);
   return rc;
 }
 
@@ -1024,13 +1097,25 @@ int hipnmf_rank_sweep_f32(hipnmf_handle* h, const hipnmf_problem* p, int32_t k_m
                           uint64_t seed, int32_t first_matrix, const float* X, float* W_ws, float* H_out, float* vaf_out,
                           int32_t* selected_out, float* err_out, int32_t* n_iter_out) {
   return rank_sweep_impl<float>(h, p, k_min, k_max, vaf_threshold, seed, first_matrix, X, W_ws, H_out, vaf_out, selected_out,
-                                err_out, n_iter_out);
+                                err_out, n_iter_out, false);
+}
+int hipnmf_rank_sweep_stop_f32(hipnmf_handle* h, const hipnmf_problem* p, int32_t k_min, int32_t k_max, double vaf_threshold,
+                               uint64_t seed, int32_t first_matrix, const float* X, float* W_ws, float* H_out, float* vaf_out,
+                               int32_t* selected_out, float* err_out, int32_t* n_iter_out) {
+  return rank_sweep_impl<float>(h, p, k_min, k_max, vaf_threshold, seed, first_matrix, X, W_ws, H_out, vaf_out, selected_out,
+                                err_out, n_iter_out, true);
 }
 int hipnmf_rank_sweep_f64(hipnmf_handle* h, const hipnmf_problem* p, int32_t k_min, int32_t k_max, double vaf_threshold,
                           uint64_t seed, int32_t first_matrix, const double* X, double* W_ws, double* H_out, double* vaf_out,
                           int32_t* selected_out, double* err_out, int32_t* n_iter_out) {
   return rank_sweep_impl<double>(h, p, k_min, k_max, vaf_threshold, seed, first_matrix, X, W_ws, H_out, vaf_out, selected_out,
-                                 err_out, n_iter_out);
+                                 err_out, n_iter_out, false);
+}
+int hipnmf_rank_sweep_stop_f64(hipnmf_handle* h, const hipnmf_problem* p, int32_t k_min, int32_t k_max, double vaf_threshold,
+                               uint64_t seed, int32_t first_matrix, const double* X, double* W_ws, double* H_out, double* vaf_out,
+                               int32_t* selected_out, double* err_out, int32_t* n_iter_out) {
+  return rank_sweep_impl<double>(h, p, k_min, k_max, vaf_threshold, seed, first_matrix, X, W_ws, H_out, vaf_out, selected_out,
+                                 err_out, n_iter_out, true);
 }
 
 int hipnmf_fit_tsharded_f32(hipnmf_handle* h, const hipnmf_problem* p, const float* X, float* W, float* H,

@@ -12,13 +12,13 @@ namespace {
 
 // validates the shape fields of *p and returns X in channel-major form (in place or converted into workspace)
 template <typename real>
-int canonical_x(hipnmf_handle* h, const hipnmf_problem* p, const real* X, InitArgs* a) {
+int canonical_x(hipnmf_handle* h, const hipnmf_problem* p, const real* X, InitArgs* a, bool any_shape = false) {
   if (!h) return fail(HIPNMF_ERR_BAD_ARG, "handle is NULL");
   if (!p || p->struct_size != (int32_t)sizeof(hipnmf_problem)) return fail(HIPNMF_ERR_BAD_ARG, "bad hipnmf_problem");
   if (!X) return fail(HIPNMF_ERR_BAD_ARG, "X is NULL");
   if (p->batch < 1 || p->n_samples < 1 || p->n_samples > 2000000000LL || p->n_features < 1 || p->n_components < 1)
     return fail(HIPNMF_ERR_BAD_ARG, "bad shape");
-  if (p->n_features > GRAM_MAXM || p->n_components > 8)
+  if (!any_shape && (p->n_features > GRAM_MAXM || p->n_components > 8))
     return fail(HIPNMF_ERR_UNSUPPORTED, "init kernels support n_features <= %d and n_components <= 8", GRAM_MAXM);
   if (p->x_layout != HIPNMF_X_ROW_MAJOR && p->x_layout != HIPNMF_X_CHANNEL_MAJOR)
     return fail(HIPNMF_ERR_BAD_ARG, "bad x_layout %d", p->x_layout);
@@ -40,9 +40,12 @@ int canonical_x(hipnmf_handle* h, const hipnmf_problem* p, const real* X, InitAr
   if (rc) return rc;
   real* xc = static_cast<real*>(h->ws);
   dim3 blk(32, 8);
-  dim3 grd((unsigned)((T + 31) / 32), (unsigned)((m + 31) / 32), (unsigned)B);
-  hipLaunchKernelGGL(x_to_channel_major_kernel<real>, grd, blk, 0, h->stream, X, (long long)p->x_batch_stride,
-                     (long long)p->ldx, (int)p->x_layout, xc, (long long)m * T, T, (int)T, m);
+  for (int b0 = 0; b0 < B; b0 += 65535) {  // the batch rides on grid.z (HIP limit 65535)
+    dim3 grd((unsigned)((T + 31) / 32), (unsigned)((m + 31) / 32), (unsigned)std::min(65535, B - b0));
+    hipLaunchKernelGGL(x_to_channel_major_kernel<real>, grd, blk, 0, h->stream, X + (long long)b0 * p->x_batch_stride,
+                       (long long)p->x_batch_stride, (long long)p->ldx, (int)p->x_layout, xc + (size_t)b0 * m * T, (long long)m * T, T,
+                       (int)T, m);
+  }
   a->X = xc;
   a->bstride = (long long)m * T;
   a->ld = T;
@@ -99,7 +102,8 @@ int write_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, const d
 }
 
 template <typename real>
-int random_init_impl(hipnmf_handle* h, const hipnmf_problem* p, uint64_t seed, int first_matrix, const real* X, real* W, real* H) {
+int random_init_impl(hipnmf_handle* h, const hipnmf_problem* p, uint64_t seed, int first_matrix, const real* X, real* W, real* H,
+                     const int* index = nullptr) {
   if (!W || !H) return fail(HIPNMF_ERR_BAD_ARG, "W and H must be non-NULL");
   if (p && p->w_layout != HIPNMF_W_ROW_MAJOR && p->w_layout != HIPNMF_W_COMPONENT_MAJOR)
     return fail(HIPNMF_ERR_BAD_ARG, "bad w_layout %d", p->w_layout);
@@ -109,19 +113,25 @@ int random_init_impl(hipnmf_handle* h, const hipnmf_problem* p, uint64_t seed, i
   // column sums through the Gram kernel (fp64, fixed order); they live behind a possibly converted X in the workspace,
   // which therefore gets its final size BEFORE canonical_x converts into it (growing it afterwards would lose X)
   if (h && p && p->struct_size == (int32_t)sizeof(hipnmf_problem) && p->batch >= 1 && p->n_samples >= 1 &&
-      p->n_samples <= 2000000000LL && p->n_features >= 1 && p->n_features <= GRAM_MAXM) {
+      p->n_samples <= 2000000000LL && p->n_features >= 1 && p->n_features <= HIPNMF_MAX_FEATURES) {
     const size_t Bm = (size_t)p->batch * p->n_features;
     x_bytes = (p->x_layout == HIPNMF_X_CHANNEL_MAJOR) ? 0 : (sizeof(real) * Bm * (size_t)p->n_samples + 255) / 256 * 256;
     HIP_TRY(hipSetDevice(h->device));
     rc = hipnmf_ensure_ws(h, x_bytes + sizeof(double) * (Bm * p->n_features + Bm));
     if (rc) return rc;
   }
-  rc = canonical_x<real>(h, p, X, &a);  // validates everything (and reports what the shortcut above skipped)
+  if (p && (p->n_features > HIPNMF_MAX_FEATURES || p->n_components > HIPNMF_MAX_COMPONENTS))
+    return fail(HIPNMF_ERR_UNSUPPORTED, "shape outside the compiled kernel set: n_features=%d (max %d), n_components=%d (max %d)",
+                p->n_features, HIPNMF_MAX_FEATURES, p->n_components, HIPNMF_MAX_COMPONENTS);
+  rc = canonical_x<real>(h, p, X, &a, true);  // validates everything (and reports what the shortcut above skipped)
   if (rc) return rc;
   const int B = p->batch, m = p->n_features;
   a.gram = reinterpret_cast<double*>(static_cast<char*>(h->ws) + x_bytes);
   a.colsum = a.gram + (size_t)B * m * m;
-  hipLaunchKernelGGL(gram_kernel<real>, dim3(B), dim3(256), 0, h->stream, a);
+  if (m <= GRAM_MAXM)
+    hipLaunchKernelGGL(gram_kernel<real>, dim3(B), dim3(256), 0, h->stream, a);
+  else  // only the column sums are needed here
+    hipLaunchKernelGGL(colsum_kernel<real>, dim3(B), dim3(256), 0, h->stream, a);
   RandomInitArgs r{};
   r.colsum = a.colsum;
   r.W = W;
@@ -140,13 +150,23 @@ int random_init_impl(hipnmf_handle* h, const hipnmf_problem* p, uint64_t seed, i
     rb.colsum = r.colsum + (size_t)b0 * m;
     rb.W = static_cast<real*>(W) + (size_t)b0 * p->n_samples * r.k;
     rb.H = static_cast<real*>(H) + (size_t)b0 * r.k * m;
-    rb.first_matrix = first_matrix + b0;
+    rb.first_matrix = first_matrix + (index ? 0 : b0);
+    rb.index = index ? index + b0 : nullptr;
     hipLaunchKernelGGL(random_init_kernel<real>, dim3(gx, nb), dim3(256), 0, h->stream, rb);
   }
   return finish(h);
 }
 
 }  // namespace
+
+template <typename real>
+int hipnmf_random_init_indexed(hipnmf_handle* h, const hipnmf_problem* p, uint64_t seed, int first_matrix, const int* index,
+                               const real* X, real* W, real* H) {
+  return random_init_impl<real>(h, p, seed, first_matrix, X, W, H, index);
+}
+template int hipnmf_random_init_indexed<float>(hipnmf_handle*, const hipnmf_problem*, uint64_t, int, const int*, const float*, float*, float*);
+template int hipnmf_random_init_indexed<double>(hipnmf_handle*, const hipnmf_problem*, uint64_t, int, const int*, const double*, double*,
+                                                double*);
 
 extern "C" {
 int hipnmf_random_init_f32(hipnmf_handle* h, const hipnmf_problem* p, uint64_t seed, int32_t first_matrix, const float* X, float* W,

@@ -32,6 +32,8 @@ struct hipnmf_handle {
   int slice_threads_ok512 = 0;  // experiment: let hipnmf_set_tuning(threads=512) also apply to the sliced kernels
   int use_coop = 1;    // HIPNMF_COOP=0: never pick the cooperative kernel automatically
   int async_mode = 0;
+  int path_batch_hint = 0;  // > 0: choose the solver path as for a batch of this size (rank sweep on a compacted sub-batch:
+                            // every trial is fitted by the kernel the full batch would have used)
 };
 
 // sets the thread-local error text returned by hipnmf_last_error() and returns `code`
@@ -54,6 +56,10 @@ inline long long round_up(long long v, long long q) { return (v + q - 1) / q * q
 template <typename real>
 int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, real* W, real* H, real* err_out,
                     int32_t* n_iter_out, real* sse_col_out, real* xsq_col_out, const int64_t* ragged);
+// hipnmf_random_init_* for a compacted sub-batch: matrix b draws the numbers of matrix first_matrix + index[b] (hipnmf_init.hip)
+template <typename real>
+int hipnmf_random_init_indexed(hipnmf_handle* h, const hipnmf_problem* p, uint64_t seed, int first_matrix, const int* index,
+                               const real* X, real* W, real* H);
 constexpr int HIPNMF_NARROW_MAX_FEATURES = 32, HIPNMF_NARROW_MAX_COMPONENTS = 8;  // nmf_kernels.hpp lane mappings
 constexpr int HIPNMF_MAX_FEATURES = 128, HIPNMF_MAX_COMPONENTS = 16;              // nmf_wide.hpp
 

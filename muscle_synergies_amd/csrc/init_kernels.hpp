@@ -207,7 +207,29 @@ struct RandomInitArgs {
   unsigned long long seed;
   long long T;
   int m, k, w_component_major, first_matrix;  // first_matrix: global index of matrix 0 (batches scattered over GPUs)
+  const int* index;      // [B] or nullptr: matrix b of this (compacted) batch is matrix index[b] of the original one
 };
+
+// colsum[b][j] = sum_t X[t][j] for any number of channels (the Gram kernel above stops at GRAM_MAXM): one workgroup per
+// matrix, channel-major X, fp64 sums in a fixed order
+template <typename real>
+__global__ void __launch_bounds__(256) colsum_kernel(InitArgs a) {
+  __shared__ double part[256];
+  const int b = blockIdx.x;
+  const real* __restrict__ Xb = static_cast<const real*>(a.X) + (long long)b * a.bstride;
+  for (int j = 0; j < a.m; ++j) {
+    double s = 0.0;
+    for (int t = threadIdx.x; t < a.T; t += 256) s += (double)Xb[(long long)j * a.ld + t];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+      if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) a.colsum[(long long)b * a.m + j] = part[0];
+    __syncthreads();
+  }
+}
 
 template <typename real>
 __global__ void __launch_bounds__(256) random_init_kernel(RandomInitArgs a) {
@@ -215,7 +237,7 @@ __global__ void __launch_bounds__(256) random_init_kernel(RandomInitArgs a) {
   double tot = 0.0;
   for (int j = 0; j < a.m; ++j) tot += a.colsum[(long long)b * a.m + j];
   const double avg = sqrt(tot / ((double)a.T * (double)a.m) / (double)a.k);
-  const unsigned matrix = (unsigned)(a.first_matrix + b);
+  const unsigned matrix = (unsigned)(a.first_matrix + (a.index ? a.index[b] : b));
   real* W = static_cast<real*>(a.W) + (long long)b * a.T * a.k;
   real* H = static_cast<real*>(a.H) + (long long)b * a.k * a.m;
   const long long nw = a.T * a.k, nh = (long long)a.k * a.m;

@@ -275,10 +275,16 @@ def random_init_device(X, k: int, *, seed: int = 0, first_matrix: int = 0, handl
 
 
 def rank_sweep_native(X, k_min: int, k_max: int, *, vaf_threshold: float = 0.90, max_iter: int = 500, tol: float = 1e-4,
-                      seed: int = 0, first_matrix: int = 0, device=None, handle: Optional[_lib.Handle] = None) -> "RankSweepResult":
+                      seed: int = 0, first_matrix: int = 0, device=None, handle: Optional[_lib.Handle] = None,
+                      stop_at_threshold: bool = False) -> "RankSweepResult":
     """:func:`rank_sweep_batched` as ONE library call (``hipnmf_rank_sweep_*``: random starting points, fits, VAF
     table and threshold selection inside the library; usable from any host language).  Frobenius loss,
-    ``init='random'`` from the library's generator; ``vaf[k]`` holds the all-muscles column only."""
+    ``init='random'`` from the library's generator; ``vaf[k]`` holds the all-muscles column only.
+
+    ``stop_at_threshold=True`` (``hipnmf_rank_sweep_stop_*``): a trial whose VAF has reached ``vaf_threshold`` is not
+    fitted at the higher ranks (BASELINE.json config #4's "stop"); the skipped (trial, rank) pairs report NaN VAF /
+    residual, 0 iterations and zero components, ``selected`` is identical to the compute-all mode.  ``kernel_ms``
+    is not available from the native sweep (several launches); time the call."""
     torch = _torch()
     dev = resolve_device(device)
     Xt = _as_device_tensor(X, dev)
@@ -300,7 +306,8 @@ def rank_sweep_native(X, k_min: int, k_max: int, *, vaf_threshold: float = 0.90,
     n_iter = torch.empty((B, nk), dtype=torch.int32, device=dev)
     sel = torch.empty((B,), dtype=torch.int32, device=dev)
     h = handle if handle is not None else _lib.get_handle(dev.index)
-    fn = getattr(_lib.load(), "hipnmf_rank_sweep_f32" if Xt.dtype == torch.float32 else "hipnmf_rank_sweep_f64")
+    name = "hipnmf_rank_sweep_stop" if stop_at_threshold else "hipnmf_rank_sweep"
+    fn = getattr(_lib.load(), name + ("_f32" if Xt.dtype == torch.float32 else "_f64"))
     fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_double, ctypes.c_uint64, ctypes.c_int32] + \
                   [ctypes.c_void_p] * 7
     fn.restype = ctypes.c_int

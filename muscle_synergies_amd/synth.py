@@ -114,6 +114,45 @@ def emg_batch_torch(B: int, T: int = 10_000, m: int = 16, k_true: int = 5, *, k:
     return X, W0, H0
 
 
+def emg_rank_trials_torch(B: int, T: int = 10_000, m: int = 16, *, k_lo: int = 2, k_hi: int = 6, noise: float = 0.05,
+                          device="cuda", seed: int = 0, chunk: int = 256):
+    """Trials for the rank-sweep workload (BASELINE.json config #4) whose answer is not the same for everybody: trial
+    ``b`` is built from ``k_true[b]`` synergies, ``k_true`` cycling through ``k_lo..k_hi``.  Unlike the smoothed-noise
+    activations of :func:`emg_batch_torch` (whose large common mean lets two components reach an uncentered VAF of
+    0.9 whatever the true rank), the synergies here fire in bursts at different phases of a gait-like cycle (five
+    cycles per trial, ``relu(sin)^3`` envelopes with 30 % trial-to-trial amplitude jitter) and each dominates its own
+    group of channels, so a factorisation with fewer components than synergies misses whole bursts: the smallest rank
+    with VAF >= 0.90 follows ``k_true`` and a sweep that stops at the threshold skips a trial-dependent number of
+    ranks.  Rectified noise of relative size ``noise``; channels max-normalised as everywhere.
+
+    Returns ``(X [B, m, T] float32 on ``device``, k_true [B] int64)``."""
+    import math
+
+    import torch
+
+    g = torch.Generator(device=device)
+    g.manual_seed(SEED_BASE + 4049 + seed)
+    X = torch.empty((B, m, T), dtype=torch.float32, device=device)
+    k_true = torch.arange(B, device=device) % (k_hi - k_lo + 1) + k_lo
+    t = torch.arange(T, device=device, dtype=torch.float32).view(1, 1, T)
+    comp = torch.arange(k_hi, device=device, dtype=torch.float32).view(1, k_hi, 1)
+    for lo in range(0, B, chunk):
+        n = min(chunk, B - lo)
+        kt = k_true[lo:lo + n]
+        S = torch.rand((n, k_hi, m), generator=g, device=device) ** 2
+        own = (torch.arange(m, device=device).view(1, 1, m) % k_hi) == torch.arange(k_hi, device=device).view(1, k_hi, 1)
+        S = 0.15 * S + own.float()
+        live = (torch.arange(k_hi, device=device).view(1, k_hi) < kt.view(n, 1)).float().view(n, k_hi, 1)
+        jitter = 1.0 + 0.3 * (torch.rand((n, k_hi, 1), generator=g, device=device) - 0.5)
+        phase = torch.rand((n, 1, 1), generator=g, device=device)
+        A = torch.sin(2 * math.pi * (5.0 * t / T - comp / k_hi + phase)).clamp_(min=0) ** 3 * jitter * live
+        x = noise * torch.randn((n, m, T), generator=g, device=device).abs_()
+        x += torch.einsum("nkm,nkt->nmt", S, A)
+        x /= x.amax(dim=2, keepdim=True)
+        X[lo:lo + n] = x
+    return X, k_true
+
+
 def emg_shard_torch(seed: int, shard: int, T_shard: int, m: int = 16, k_true: int = 5, *, k: int = 5,
                     device="cuda", piece: int = 4_000_000, scale=None):
     """One time shard of a very long synthetic recording, generated on the device from counter-based seeds

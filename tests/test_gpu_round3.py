@@ -63,3 +63,57 @@ def test_cooperative_fit_matches_oracle_after_protocol_change():
         wh = res.W[0].astype(np.float64) @ res.H[0].astype(np.float64)
         wr = ref["W"].astype(np.float64) @ ref["H"].astype(np.float64)
         assert np.linalg.norm(wh - wr) / np.linalg.norm(X) <= tol
+
+
+# ------------------------------------------------------------------------------------------------ rank sweep with a real stop
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+def test_rank_sweep_stop_at_threshold_matches_compute_all(dtype):
+    """hipnmf_rank_sweep_stop_* (BASELINE config #4's "k = 2..8 with VAF >= 0.90 stop"): trials that reached the
+    threshold are not fitted at higher ranks, everything that IS fitted is bit-identical to the compute-all sweep,
+    `selected` is identical, and the workload really discriminates (several different ranks get selected)."""
+    import torch
+
+    from muscle_synergies_amd.engine import rank_sweep_native
+    from muscle_synergies_amd.synth import emg_rank_trials_torch
+
+    X, k_true = emg_rank_trials_torch(60, T=1500, device="cuda:0", seed=3)
+    Xv = X.transpose(1, 2).contiguous()
+    if dtype == "float64":
+        Xv = Xv.double()
+    ra = rank_sweep_native(Xv, 2, 8, vaf_threshold=0.90, max_iter=120, tol=0.0, seed=5)
+    rs = rank_sweep_native(Xv, 2, 8, vaf_threshold=0.90, max_iter=120, tol=0.0, seed=5, stop_at_threshold=True)
+    assert torch.equal(ra.selected, rs.selected)
+    assert len(set(ra.selected.tolist())) >= 3, ra.selected.tolist()  # the histogram is not degenerate
+    assert ra.ranks == rs.ranks == [2, 3, 4, 5, 6, 7, 8]
+    n_skipped = 0
+    for i, k in enumerate(ra.ranks):
+        ran = rs.n_iter[k] > 0
+        # a trial runs at rank k exactly when no smaller rank reached the threshold
+        expect = (ra.selected < 0) | (ra.selected >= k)
+        assert torch.equal(ran, expect), k
+        assert torch.equal(rs.vaf_all[ran, i], ra.vaf_all[ran, i])
+        assert torch.equal(rs.components[k][ran], ra.components[k][ran])
+        assert torch.equal(rs.reconstruction_err[k][ran], ra.reconstruction_err[k][ran])
+        assert torch.isnan(rs.vaf_all[~ran, i]).all() and (rs.components[k][~ran] == 0).all()
+        n_skipped += int((~ran).sum())
+    assert n_skipped > 60  # most of the work past the stop is really skipped
+
+
+def test_rank_sweep_native_up_to_rank_8_and_wide_matches_oracle():
+    """The native sweep through every rank k = 2..8 (round 2's test stopped at 6) and on a wide batch (48 channels,
+    k up to 10: nmf_wide.hpp), each (trial, rank) against the oracle from the same starting point."""
+    import torch
+
+    from muscle_synergies_amd.engine import random_init_device, rank_sweep_native
+
+    for m, kmax, T in ((16, 8, 700), (48, 10, 300)):
+        Xs = np.stack([np.ascontiguousarray(emg_matrix(900 + b, T=T, m=m, k_true=5, dtype=np.float32)) for b in range(3)])
+        Xd = torch.from_numpy(Xs).cuda()
+        r = rank_sweep_native(Xd, 2, kmax, vaf_threshold=0.9, max_iter=40, tol=0.0, seed=11)
+        for i, k in enumerate(r.ranks):
+            W0, H0 = random_init_device(Xd, k, seed=11 + k)
+            for b in range(3):
+                ref = orc.nmf_mu_fit(Xs[b], W0[b].cpu().numpy(), H0[b].cpu().numpy(), max_iter=40, tol=0.0)
+                va, _ = orc.vaf(Xs[b].astype(np.float64), ref["W"].astype(np.float64), ref["H"].astype(np.float64))
+                assert abs(float(r.vaf_all[b, i]) - va) <= 2e-5, (m, k, b)
+                np.testing.assert_allclose(r.components[k][b].cpu().numpy(), ref["H"], rtol=2e-3, atol=1e-5)
