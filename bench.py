@@ -433,25 +433,18 @@ def run_rank_sweep(cx):
 def run_tsharded(cx):
     a, torch = cx.a, cx.torch
     from muscle_synergies_amd.synth import emg_shard_torch
-    from muscle_synergies_amd.tsharded import HipShardOps, MultiShardOps, fit_tsharded, shard_bounds
+    from muscle_synergies_amd.tsharded import HipShardOps, MultiShardOps, fit_tsharded, plan_subshards, shard_bounds
 
     T, m, k = a.T5, a.m, a.k
     lo, hi = shard_bounds(T, cx.world)[cx.rank]
-    # this rank's rows as sub-shards of at most --subshard rows (the engine addresses < 2 GiB of X per shard);
-    # sub-shard s of rank r is shard number (global start row // subshard) of the synthetic recording
+    # this rank's rows as sub-shards of at most --subshard rows (tsharded.plan_subshards: the same recording for every N)
     H = None
     shards = []
-    t = lo
-    while t < hi:
-        n = min(a.subshard, hi - t)
-        # shard number of the synthetic recording: the global sub-shard index when the rank's rows start on a
-        # sub-shard boundary (N = 1, 2, 4, 8 with the defaults: the same data for every N), a per-rank id otherwise
-        sid = t // a.subshard if t % a.subshard == 0 else 10_000 + 100 * cx.rank + len(shards)
+    for _t0, n, sid in plan_subshards(T, cx.world, cx.rank, a.subshard):
         Xs, Ws, H0 = emg_shard_torch(5, sid, n, m=m, k=k, device=cx.dev)
         if H is None:
             H = H0.clone()
         shards.append(HipShardOps.from_native(Xs, Ws, H))
-        t += n
     ops = MultiShardOps(shards)
     torch.cuda.synchronize(cx.dev)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]

@@ -45,6 +45,23 @@ def shard_bounds(n_samples: int, world_size: int, align: int = 4):
     return [(min(lo * align, n_samples), min(hi * align, n_samples)) for lo, hi in blocks]
 
 
+def plan_subshards(n_samples: int, world_size: int, rank: int, subshard: int):
+    """Sub-shards of rank ``rank`` for one recording of ``n_samples`` rows time-sharded over ``world_size`` ranks
+    (``bench.py --config 5``): the rank's rows (:func:`shard_bounds`) cut into pieces of at most ``subshard`` rows
+    (the engine addresses < 2 GiB of X per shard).  Returns ``[(first_row, n_rows, shard_id), ...]``; ``shard_id``
+    names the piece of the synthetic recording to generate: the global sub-shard index when the piece starts on a
+    sub-shard boundary -- with ``n_samples / world_size`` a multiple of ``subshard`` (N = 1, 2, 4, 8 at the defaults)
+    every N therefore generates the very same recording -- and a per-rank id otherwise."""
+    lo, hi = shard_bounds(n_samples, world_size)[rank]
+    out, t = [], lo
+    while t < hi:
+        n = min(subshard, hi - t)
+        sid = t // subshard if t % subshard == 0 else 10_000 + 100 * rank + len(out)
+        out.append((t, n, sid))
+        t += n
+    return out
+
+
 class HipShardOps:
     """Shard-local compute on one GPU through the C ABI (native layouts: X ``[B, m, T_local]``
     channel-major, W ``[B, k, T_local]`` component-major)."""
