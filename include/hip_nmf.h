@@ -245,7 +245,17 @@ typedef struct hipnmf_envelope_params {
   int32_t zero_center;    /* 1: subtract the per-channel mean first                                    */
   int32_t n_out;          /* 0: keep n_samples rows; > 0: time-normalise to n_out rows                 */
   int32_t normalize;      /* 1: divide every channel by its max absolute value                         */
+  int32_t resample_kind;  /* HIPNMF_RESAMPLE_*: interp1d `kind` of the time normalisation (n_out > 0)  */
+  int32_t reserved0;      /* must be 0                                                                 */
 } hipnmf_envelope_params;
+/* time_normalize forwards `kind` to scipy.interpolate.interp1d (analysis.py:551-594).  On the device: */
+#define HIPNMF_RESAMPLE_LINEAR 0     /* 'linear' (the reference's default; 'slinear' is the same interpolant) */
+#define HIPNMF_RESAMPLE_NEAREST 1    /* 'nearest': nearest knot, a tie goes down                              */
+#define HIPNMF_RESAMPLE_NEAREST_UP 2 /* 'nearest-up': a tie goes up                                           */
+#define HIPNMF_RESAMPLE_PREVIOUS 3   /* 'previous' and 'zero' (order-0 spline): last knot <= the abscissa     */
+#define HIPNMF_RESAMPLE_NEXT 4       /* 'next': first knot >= the abscissa                                    */
+/* ('quadratic' / 'cubic' splines couple all samples of a channel through a banded solve: the Python host hands those
+ * to scipy itself.) */
 
 int hipnmf_emg_envelope_f32(hipnmf_handle* h, const hipnmf_envelope_params* p, const float* raw, float* out);
 int hipnmf_emg_envelope_f64(hipnmf_handle* h, const hipnmf_envelope_params* p, const double* raw, double* out);

@@ -24,11 +24,54 @@ struct EnvArgs {
   double* chan_stat;   // workspace [B][m][2]: mean, max |out|
   void* out;           // [B][m][n_out]
   int T, m, window, zero_center, n_out, normalize;
+  int resample_kind;   // HIPNMF_RESAMPLE_*: interp1d kind of the time normalisation (env_knot)
   // time normalisation table (env_resample_table_kernel -> emg_wave_kernel): per output q its left knot i0 and the
   // weight (xn - x0) / (x1 - x0) -- they depend on (T, n_out) only, not on the data
   const int* tab_i0;
   const double* tab_w;
 };
+
+// Time normalisation (analysis.py:551-594 -> scipy.interpolate.interp1d(linspace(0,1,T), y, kind=...) evaluated on
+// linspace(0,1,n_out)): output q as  y = y[i0] + (y[i0+1] - y[i0]) * w  with 0 <= i0 <= T - 2.  Knots and abscissae as
+// NumPy builds them (i * step, end point pinned to 1.0).  kind (HIPNMF_RESAMPLE_*):
+//   0 linear     i0 = searchsorted(knots, xn, "left") - 1 clipped, w = (xn - x0) / (x1 - x0)   (interp1d._call_linear)
+//   1 nearest    index = searchsorted(midpoints, xn, "left")  -- a tie goes DOWN (_call_nearest; midpoints = x[i]/2 + x[i+1]/2)
+//   2 nearest-up                                  "right" -- a tie goes up
+//   3 previous   last knot <= xn (_call_previousnext; also what kind="zero", the order-0 spline, evaluates to)
+//   4 next       first knot >= xn
+// The index kinds come out as (index, 0) or, for the last knot, (T - 2, 1); env_lerp returns the end values exactly.
+__device__ __forceinline__ void env_knot(int T, int n_out, int q, int kind, int& i0, double& w) {
+  const double step_out = (n_out > 1) ? 1.0 / (double)(n_out - 1) : 0.0;
+  const double step_in = 1.0 / (double)(T - 1);  // T >= 2
+  auto knot = [&](int i) { return (i == T - 1) ? 1.0 : (double)i * step_in; };
+  const double xn = (q == n_out - 1 && n_out > 1) ? 1.0 : (double)q * step_out;
+  int i = (int)floor(xn * (double)(T - 1));
+  if (i > T - 2) i = T - 2;
+  if (i < 0) i = 0;
+  while (i > 0 && knot(i) >= xn) --i;  // i = searchsorted(side="left") - 1, clipped to [0, T - 2]
+  while (i < T - 2 && knot(i + 1) < xn) ++i;
+  if (kind == 0) {
+    i0 = i;
+    w = (xn - knot(i)) / (knot(i + 1) - knot(i));
+    return;
+  }
+  int idx;  // the knot whose value is taken; knot(i) < xn <= knot(i + 1) here, except xn <= knot(0) at i = 0
+  if (kind == 3) {
+    idx = (knot(i + 1) <= xn) ? i + 1 : i;
+  } else if (kind == 4) {
+    idx = (knot(i) >= xn) ? i : i + 1;
+  } else {
+    const double mid = knot(i) / 2.0 + knot(i + 1) / 2.0;
+    const bool up = kind == 2 ? (xn >= mid) : (xn > mid);
+    idx = up ? i + 1 : i;
+  }
+  i0 = idx <= T - 2 ? idx : T - 2;
+  w = idx <= T - 2 ? 0.0 : 1.0;
+}
+__device__ __forceinline__ double env_lerp(double y0, double y1, double w) {
+  const double y = (y1 - y0) * w + y0;
+  return w == 0.0 ? y0 : (w == 1.0 ? y1 : y);
+}
 
 // per-thread part of a strided sum over x[0 .. T): four independent accumulators so that four loads are in flight
 // (a single running sum serialises on the load latency); fixed order: ((s0 + s1) + (s2 + s3))
@@ -189,14 +232,12 @@ __global__ void __launch_bounds__(256) emg_output_kernel(EnvArgs a) {
       } else {
         const double step_in = 1.0 / (double)(a.T - 1);
         auto knot = [&](int i) { return (i == a.T - 1) ? 1.0 : (double)i * step_in; };
-        int i0 = (int)floor(xn * (double)(a.T - 1));
-        if (i0 > a.T - 2) i0 = a.T - 2;
-        if (i0 < 0) i0 = 0;
-        while (i0 > 0 && knot(i0) >= xn) --i0;           // searchsorted(side="left") - 1, clipped to >= 0
-        while (i0 < a.T - 2 && knot(i0 + 1) < xn) ++i0;
+        int i0;
+        double wq;
+        env_knot(a.T, n_out, q, a.resample_kind, i0, wq);
         const double x0 = knot(i0), x1 = knot(i0 + 1);
         const double y0 = value(i0), y1 = value(i0 + 1);
-        y = (y1 - y0) / (x1 - x0) * (xn - x0) + y0;
+        y = a.resample_kind == 0 ? (y1 - y0) / (x1 - x0) * (xn - x0) + y0 : env_lerp(y0, y1, wq);
       }
     } else {
       y = value(q);
@@ -357,15 +398,13 @@ __global__ void __launch_bounds__(256) emg_fused_kernel(EnvArgs a) {
           if (t0 != 0) continue;
           y = value(0);
         } else {
-          int i0 = (int)floor(xn * (double)(T - 1));
-          if (i0 > T - 2) i0 = T - 2;
-          if (i0 < 0) i0 = 0;
-          while (i0 > 0 && knot(i0) >= xn) --i0;  // searchsorted(side="left") - 1, clipped to >= 0
-          while (i0 < T - 2 && knot(i0 + 1) < xn) ++i0;
+          int i0;
+          double wq;
+          env_knot(T, n_out, q, a.resample_kind, i0, wq);
           if (i0 < t0 || i0 >= t0 + nout_t) continue;
           const double x0 = knot(i0), x1 = knot(i0 + 1);
           const double y0 = value(i0), y1 = value(i0 + 1);
-          y = (y1 - y0) / (x1 - x0) * (xn - x0) + y0;
+          y = a.resample_kind == 0 ? (y1 - y0) / (x1 - x0) * (xn - x0) + y0 : env_lerp(y0, y1, wq);
         }
         o[q] = (real)y;
         vmax = fmax(vmax, fabs(y));
@@ -546,20 +585,14 @@ __device__ __forceinline__ real env_scaled(real y, double vmax, float vmf) {
 // scipy interp1d(kind="linear") from the knots linspace(0,1,T) onto linspace(0,1,n_out), knots built as NumPy builds
 // them (i * step with the end point pinned to 1.0): left knot i0 = searchsorted(knots, xn, "left") - 1 clipped to
 // [0, T - 2].  One thread per output; the table serves every series of the call.
-__global__ void __launch_bounds__(256) env_resample_table_kernel(int T, int n_out, int* tab_i0, double* tab_w) {
+__global__ void __launch_bounds__(256) env_resample_table_kernel(int T, int n_out, int kind, int* tab_i0, double* tab_w) {
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= n_out) return;
-  const double step_out = (n_out > 1) ? 1.0 / (double)(n_out - 1) : 0.0;
-  const double step_in = 1.0 / (double)(T - 1);  // T >= 2
-  auto knot = [&](int i) { return (i == T - 1) ? 1.0 : (double)i * step_in; };
-  const double xn = (q == n_out - 1 && n_out > 1) ? 1.0 : (double)q * step_out;
-  int i0 = (int)floor(xn * (double)(T - 1));
-  if (i0 > T - 2) i0 = T - 2;
-  if (i0 < 0) i0 = 0;
-  while (i0 > 0 && knot(i0) >= xn) --i0;
-  while (i0 < T - 2 && knot(i0 + 1) < xn) ++i0;
+  int i0;
+  double w;
+  env_knot(T, n_out, q, kind, i0, w);
   tab_i0[q] = i0;
-  tab_w[q] = (xn - knot(i0)) / (knot(i0 + 1) - knot(i0));
+  tab_w[q] = w;
 }
 
 // Time-normalised output with left knot i0 and weight w = (xn - x0) / (x1 - x0) from the table: y = y0 + (y1 - y0) w
@@ -577,7 +610,7 @@ __device__ __forceinline__ double env_interp(const EnvWave<real, SPL>& wv, int i
     y0 = sqrt((s0 > 0.0 ? s0 : 0.0) * inv_w);
     y1 = sqrt((s1 > 0.0 ? s1 : 0.0) * inv_w);
   }
-  return (y1 - y0) * w + y0;
+  return env_lerp(y0, y1, w);
 }
 
 template <typename real, int SPL>

@@ -23,6 +23,9 @@ int envelope_impl(hipnmf_handle* h, const hipnmf_envelope_params* p, const real*
     return fail(HIPNMF_ERR_BAD_ARG, "bad shape: batch=%d n_samples=%lld n_channels=%d", p->batch,
                 (long long)p->n_samples, p->n_channels);
   if (p->window < 0 || p->n_out < 0) return fail(HIPNMF_ERR_BAD_ARG, "window and n_out must be >= 0");
+  if (p->resample_kind < HIPNMF_RESAMPLE_LINEAR || p->resample_kind > HIPNMF_RESAMPLE_NEXT)
+    return fail(HIPNMF_ERR_BAD_ARG, "bad resample_kind %d", p->resample_kind);
+  if (p->reserved0 != 0) return fail(HIPNMF_ERR_BAD_ARG, "hipnmf_envelope_params.reserved0 must be 0");
   if (p->x_layout != HIPNMF_X_ROW_MAJOR && p->x_layout != HIPNMF_X_CHANNEL_MAJOR)
     return fail(HIPNMF_ERR_BAD_ARG, "bad x_layout %d", p->x_layout);
   const long long min_ld = (p->x_layout == HIPNMF_X_ROW_MAJOR) ? p->n_channels : p->n_samples;
@@ -123,11 +126,12 @@ int envelope_impl(hipnmf_handle* h, const hipnmf_envelope_params* p, const real*
   a.window = p->window;
   a.zero_center = p->zero_center ? 1 : 0;
   a.n_out = p->n_out;
+  a.resample_kind = p->resample_kind;
   a.normalize = p->normalize ? 1 : 0;
   const bool async = h->async_mode != 0;
   if (!async) HIP_TRY(hipEventRecord(h->ev0, st));
   if (resample_tab)
-    hipLaunchKernelGGL(env_resample_table_kernel, dim3((unsigned)((p->n_out + 255) / 256)), dim3(256), 0, st, (int)T, (int)p->n_out,
+    hipLaunchKernelGGL(env_resample_table_kernel, dim3((unsigned)((p->n_out + 255) / 256)), dim3(256), 0, st, (int)T, (int)p->n_out, (int)p->resample_kind,
                        reinterpret_cast<int*>(ws + o_ti), reinterpret_cast<double*>(ws + o_tw));
   if (wg) {
     auto launch_wg = [&](auto kern) -> int {

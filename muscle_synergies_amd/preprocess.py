@@ -39,7 +39,17 @@ class EnvelopeParams(ctypes.Structure):
         ("zero_center", ctypes.c_int32),
         ("n_out", ctypes.c_int32),
         ("normalize", ctypes.c_int32),
+        ("resample_kind", ctypes.c_int32),
+        ("reserved0", ctypes.c_int32),
     ]
+
+
+#: ``interp1d`` kinds evaluated on the device (``HIPNMF_RESAMPLE_*`` of include/hip_nmf.h).  ``'zero'`` / ``0`` (the
+#: order-0 spline) takes the last knot <= the abscissa like ``'previous'``; ``'slinear'`` / ``1`` (the order-1 spline)
+#: is the linear interpolant.  ``'quadratic'`` / ``'cubic'`` (orders 2, 3) couple all samples of a channel through a
+#: banded solve and are evaluated by scipy itself on the host.
+RESAMPLE_KINDS = {"linear": 0, "slinear": 0, 1: 0, "nearest": 1, "nearest-up": 2, "previous": 3, "zero": 3, 0: 3, "next": 4}
+SPLINE_KINDS = ("quadratic", "cubic", 2, 3)
 
 
 class SosfiltParams(ctypes.Structure):
@@ -71,13 +81,14 @@ def window_in_samples(window_size: Union[int, float], sampling_frequency: Option
 
 def emg_envelope_batched(raw, window_size: Union[int, float] = 0, *, sampling_frequency: Optional[int] = None,
                          zero_center: bool = True, reduce_to: Optional[int] = None, normalize: bool = True,
-                         device=None):
+                         device=None, kind="linear"):
     """``zero_center -> rms -> time_normalize -> normalize`` for a batch of recordings on one GPU.
 
     Args:
         raw: ``[B, T, m]`` (or ``[T, m]``) float32/float64, NumPy or torch, any dense layout.
         window_size: RMS window (samples, or seconds when ``sampling_frequency`` is given); 0 skips the RMS.
-        reduce_to: number of rows after linear time normalisation (``None`` keeps ``T``).
+        reduce_to: number of rows after time normalisation (``None`` keeps ``T``).
+        kind: ``interp1d`` kind of the time normalisation, one of :data:`RESAMPLE_KINDS`.
     Returns:
         tensor ``[B, T_out, m]`` on the device (a transposed view of channel-major storage, which
         ``fit_batched`` streams without any copy).
@@ -99,8 +110,10 @@ def emg_envelope_batched(raw, window_size: Union[int, float] = 0, *, sampling_fr
     if W < 0:
         raise ValueError("window_size must be >= 0")
     n_out = int(reduce_to) if reduce_to else 0
+    if kind not in RESAMPLE_KINDS or isinstance(kind, bool):
+        raise NotImplementedError(f"kind={kind!r}: the device evaluates {sorted(map(str, RESAMPLE_KINDS))}")
     p = EnvelopeParams(ctypes.sizeof(EnvelopeParams), B, T, m, layout, ldx, xbs, W, int(bool(zero_center)), n_out,
-                       int(bool(normalize)))
+                       int(bool(normalize)), RESAMPLE_KINDS[kind], 0)
     out = torch.empty((B, m, n_out if n_out else T), dtype=Xt.dtype, device=dev)
     h = _lib.get_handle(dev.index)
     lib = _lib.load()
@@ -146,10 +159,31 @@ def normalize(signal_df: pandas.DataFrame, inplace: bool = False) -> pandas.Data
 
 def time_normalize(signal_df: pandas.DataFrame, reduce_to: int, kind="linear",
                    fill_value="extrapolate") -> pandas.DataFrame:
-    """Resample to ``reduce_to`` rows on a 0..1 time axis (``analysis.py:551-594``); linear only."""
-    if kind != "linear":
-        raise NotImplementedError("the GPU time_normalize implements kind='linear' only")
-    vals = _frame_through_gpu(signal_df, window_size=0, zero_center=False, normalize=False, reduce_to=reduce_to)
+    """Resample to ``reduce_to`` rows on a 0..1 time axis (``analysis.py:551-594``: ``interp1d(linspace(0, 1, T), df,
+    kind=kind)`` evaluated on ``linspace(0, 1, reduce_to)``).
+
+    ``kind`` is forwarded like the reference does: ``'linear'`` (default), ``'slinear'``, ``'nearest'``,
+    ``'nearest-up'``, ``'previous'``, ``'next'`` and ``'zero'`` run on the GPU (:data:`RESAMPLE_KINDS`);
+    ``'quadratic'`` / ``'cubic'`` (or the spline orders 2, 3) are evaluated by scipy on the host, with a warning --
+    they solve a banded system over all samples of a channel, which is not a streaming operation.  ``fill_value``
+    is accepted for signature compatibility: both axes span exactly [0, 1], so nothing is ever extrapolated.
+    """
+    if kind in SPLINE_KINDS and not isinstance(kind, bool):
+        import warnings
+
+        from scipy import interpolate
+
+        warnings.warn(f"time_normalize(kind={kind!r}): spline kinds are evaluated by scipy on the CPU", RuntimeWarning,
+                      stacklevel=2)
+        T = signal_df.shape[0]
+        f = interpolate.interp1d(np.linspace(0, 1, T), signal_df, axis=0, copy=False, kind=kind, fill_value=fill_value)
+        domain = np.linspace(0, 1, reduce_to)
+        return pandas.DataFrame(f(domain), index=domain, columns=signal_df.columns)
+    if kind not in RESAMPLE_KINDS or isinstance(kind, bool):
+        raise NotImplementedError(f"interp1d kind {kind!r} is not understood")
+    if signal_df.shape[0] < 2:
+        raise ValueError("time_normalize needs at least two rows")
+    vals = _frame_through_gpu(signal_df, window_size=0, zero_center=False, normalize=False, reduce_to=reduce_to, kind=kind)
     return pandas.DataFrame(vals, index=np.linspace(0, 1, reduce_to), columns=signal_df.columns)
 
 

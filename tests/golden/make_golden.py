@@ -19,6 +19,7 @@ Fixture sets:
   G7  Kullback-Leibler loss (beta_loss='kullback-leibler') -- row f-4
   G8  IIR filters: ``digital_filter`` / ``linear_envelope`` (scipy sosfilt / sosfiltfilt) -- row f-1
   G9  ``DeviceData`` (frame, subframe) -> row indexing of the abridged recording (segment glue) -- row f-3
+  G10 ``time_normalize`` with every ``interp1d`` kind the reference forwards (analysis.py:551-594) -- row f-1
 """
 
 import json
@@ -408,7 +409,29 @@ def g9():
     print("G9 done")
 
 
+# --------------------------------------------------------------------------- G10
+def g10(only=True):
+    """time_normalize(kind=...) of the reference for every kind scipy's interp1d knows: shrinking, same length, stretching."""
+    import pandas as pd
+
+    arrays = {}
+    raw = np.abs(raw_emg(10, 97, 3))
+    arrays["raw"] = raw
+    df = pd.DataFrame(raw, columns=list("abc"))
+    kinds = ["linear", "slinear", "nearest", "nearest-up", "previous", "next", "zero", "quadratic", "cubic"]
+    for reduce_to in (40, 97, 230, 2, 193):
+        for kind in kinds:
+            arrays[f"{kind}_{reduce_to}"] = ms.time_normalize(df, reduce_to=reduce_to, kind=kind).to_numpy()
+    arrays["kinds"] = np.array(kinds)
+    np.savez_compressed(os.path.join(HERE, "g10_time_normalize_kinds.npz"), **arrays)
+    print("G10 done")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1:  # e.g. `make_golden.py g10`: regenerate the named sets only
+        for name in sys.argv[1:]:
+            globals()[name]()
+        sys.exit(0)
     g1()
     g2_small()
     g2_full()
@@ -419,3 +442,4 @@ if __name__ == "__main__":
     g7()
     g8()
     g9()
+    g10()

@@ -54,7 +54,7 @@ def test_version_and_struct_layout(lib):
     from muscle_synergies_amd.preprocess import EnvelopeParams
 
     assert struct_fields("hipnmf_envelope_params") == [f[0] for f in EnvelopeParams._fields_]
-    assert ctypes.sizeof(EnvelopeParams) == 56
+    assert ctypes.sizeof(EnvelopeParams) == 64
     from muscle_synergies_amd.preprocess import SosfiltParams
 
     assert struct_fields("hipnmf_sosfilt_params") == [f[0] for f in SosfiltParams._fields_]

@@ -76,7 +76,7 @@ def test_gpu_dataframe_mirrors_and_fp32(g6):
     r2 = pp.rms(df, 0.0125, sampling_frequency=2000)  # 25 samples
     np.testing.assert_allclose(r2.to_numpy(), eo.rms(raw, 25), rtol=1e-10)
     with pytest.raises(NotImplementedError):
-        pp.time_normalize(r, 10, kind="cubic")
+        pp.time_normalize(r, 10, kind="lagrange")
     # fp32 I/O (fp64 accumulation inside)
     out32 = pp.emg_envelope_batched(raw.astype(np.float32), win, reduce_to=reduce_to)[0].cpu().numpy()
     assert out32.dtype == np.float32
@@ -173,3 +173,70 @@ def test_gpu_envelope_fuzz():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "0 problems" in r.stdout
 
+
+
+# ------------------------------------------------------------------------------------------------ time_normalize kinds (round 3)
+INDEX_KINDS = ["linear", "slinear", "nearest", "nearest-up", "previous", "next", "zero"]
+
+
+@pytest.fixture(scope="module")
+def g10():
+    from conftest import load_npz
+
+    return load_npz("g10_time_normalize_kinds.npz")
+
+
+def test_oracle_time_normalize_kinds_match_the_reference(g10):
+    """G10: outputs of the reference's time_normalize (scipy interp1d) for every kind it forwards."""
+    raw = g10["raw"]
+    for reduce_to in (40, 97, 230, 2, 193):
+        for kind in INDEX_KINDS:
+            got = eo.time_normalize(raw, reduce_to, kind)
+            if kind in ("linear", "slinear"):
+                np.testing.assert_allclose(got, g10[f"{kind}_{reduce_to}"], rtol=1e-12, atol=1e-15)
+            else:
+                np.testing.assert_array_equal(got, g10[f"{kind}_{reduce_to}"], err_msg=f"{kind} {reduce_to}")
+
+
+@pytest.mark.gpu
+def test_gpu_time_normalize_kinds(g10):
+    """Every interp1d kind the reference forwards: index kinds and (s)linear on the device, spline kinds through scipy
+    with a warning; the frames carry the reference's index / columns."""
+    from muscle_synergies_amd import preprocess as pp
+
+    raw = g10["raw"]
+    df = pd.DataFrame(raw, columns=list("abc"))
+    for reduce_to in (40, 97, 230, 2, 193):
+        for kind in INDEX_KINDS:
+            out = pp.time_normalize(df, reduce_to, kind=kind)
+            assert list(out.columns) == list("abc")
+            np.testing.assert_allclose(out.index.to_numpy(), np.linspace(0, 1, reduce_to))
+            if kind in ("linear", "slinear"):
+                np.testing.assert_allclose(out.to_numpy(), g10[f"{kind}_{reduce_to}"], rtol=1e-12, atol=1e-15)
+            else:
+                np.testing.assert_array_equal(out.to_numpy(), g10[f"{kind}_{reduce_to}"], err_msg=f"{kind} {reduce_to}")
+        for kind in ("quadratic", "cubic"):
+            with pytest.warns(RuntimeWarning, match="evaluated by scipy"):
+                out = pp.time_normalize(df, reduce_to, kind=kind) if reduce_to > 3 else pp.time_normalize(df, 40, kind=kind)
+            np.testing.assert_allclose(out.to_numpy(), g10[f"{kind}_{reduce_to if reduce_to > 3 else 40}"], rtol=1e-12)
+    with pytest.raises(NotImplementedError):
+        pp.time_normalize(df, 10, kind="lagrange")
+    assert pp.time_normalize(df, 10, kind=0).equals(pp.time_normalize(df, 10, kind="zero"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_gpu_index_kinds_fused_with_rms_over_many_lengths(dtype):
+    """The kinds inside the fused chain (zero_center -> rms -> time_normalize(kind) -> normalize) for series lengths
+    and output counts that reach every envelope kernel, against the oracle."""
+    from muscle_synergies_amd.preprocess import emg_envelope_batched
+
+    rng = np.random.default_rng(3)
+    for T, n_out, win in ((2, 5, 0), (3, 2, 0), (100, 33, 5), (513, 1000, 25), (2049, 200, 200), (9300, 77, 0), (700, 701, 64),
+                          (5000, 4999, 4000)):
+        raw = raw_emg(int(rng.integers(1000)), T, 3).astype(dtype)
+        for kind in ("nearest", "nearest-up", "previous", "next", "zero", "linear"):
+            got = emg_envelope_batched(raw, win, reduce_to=n_out, kind=kind)[0].cpu().numpy()
+            ref = eo.envelope(raw.astype(np.float64), win, n_out, kind=kind)
+            tol = dict(rtol=1e-9, atol=1e-12) if dtype == np.float64 else dict(rtol=3e-5, atol=1e-6)
+            np.testing.assert_allclose(got, ref, err_msg=f"T={T} n_out={n_out} win={win} {kind}", **tol)
