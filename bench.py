@@ -222,10 +222,15 @@ def _traffic(kernel, **key):
             entries = json.load(f)
         for e in entries if isinstance(entries, list) else [entries]:
             if e.get("kernel") == kernel and all(e.get(k) == v for k, v in key.items()):
+                _traffic.source = {"file": "profiles/traffic.json", "measured_round": e.get("measured_round"),
+                                   "source_commit": e.get("source_commit"), "method": e.get("method")}
                 return e.get("l2_fabric_bytes_per_launch")
     except Exception:  # noqa: BLE001
         pass
     return None
+
+
+_traffic.source = None
 
 
 def flops_per_unit(T, m, k):
@@ -248,7 +253,9 @@ def compute_roofline(kernel, kernel_ms, units_per_launch, T, m, k, traffic=None,
                  "can re-read their matrices: stream_peak_gbs, measured by tools/ubench/mall_stream.hip"),
         "stream_peak_gbs": STREAM_PEAK_GBS,
     }
+    mem["stream_peak_source"] = "tools/ubench/mall_stream.hip, profiles/r02_ubench_mall_stream.log (round 2, commit 6cd19eb); a constant, not re-measured in this run"
     if traffic:
+        mem["l2_fabric_source"] = _traffic.source  # a PMC measurement committed under profiles/, not taken in this run
         mem["l2_fabric_gbs"] = traffic / sec / 1e9
         mem["frac_of_stream_peak"] = traffic / sec / 1e9 / STREAM_PEAK_GBS
     elif moved_bytes_per_unit:

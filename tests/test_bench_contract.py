@@ -41,6 +41,20 @@ def test_wide_shapes_report_against_the_hbm_line():
     assert r["matrix_pipe"]["issued_tflops"] > r["matrix_pipe"]["achieved_tflops_useful"]
 
 
+def test_committed_traffic_measurements_name_their_kernel_and_source():
+    """profiles/traffic.json feeds roofline.traffic: every entry names the kernel instance and workload it was measured
+    on and the commit it was measured at (the -m gpu suite checks that the library still launches that instance)."""
+    import json
+
+    entries = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    assert entries
+    for e in entries:
+        for key in ("kernel", "batch", "iters", "T", "m", "k", "x_layout", "l2_fabric_bytes_per_launch", "source_commit", "method"):
+            assert key in e, key
+        assert e["kernel"].startswith(("fit_persistent_kernel<", "fit_rowlane_kernel<", "fit_wide_kernel<"))
+    assert bench._traffic("no-such-kernel", batch=1) is None
+
+
 def test_command_line_contract():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True)
     assert out.returncode == 0

@@ -117,3 +117,22 @@ def test_rank_sweep_native_up_to_rank_8_and_wide_matches_oracle():
                 va, _ = orc.vaf(Xs[b].astype(np.float64), ref["W"].astype(np.float64), ref["H"].astype(np.float64))
                 assert abs(float(r.vaf_all[b, i]) - va) <= 2e-5, (m, k, b)
                 np.testing.assert_allclose(r.components[k][b].cpu().numpy(), ref["H"], rtol=2e-3, atol=1e-5)
+
+
+def test_traffic_measurements_still_name_the_kernel_the_library_launches():
+    """bench.py copies roofline.traffic from profiles/traffic.json, keyed on the kernel instance: if the library no
+    longer launches that instance for the entry's workload, the number must not be reported for it."""
+    import json
+
+    import torch
+
+    import muscle_synergies_amd as ms
+    from muscle_synergies_amd import _lib
+
+    for e in json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))):
+        B = min(int(e["batch"]), 320)  # the instance depends on the shape and on "more matrices than CUs", not on B itself
+        X = torch.rand((B, e["T"], e["m"]), device="cuda") if e["x_layout"] == "row" else torch.rand((B, e["m"], e["T"]), device="cuda").transpose(1, 2)
+        W0 = torch.rand((B, e["T"], e["k"]), device="cuda")
+        H0 = torch.rand((B, e["k"], e["m"]), device="cuda")
+        ms.fit_batched(X, W0, H0, max_iter=2, tol=0.0)
+        assert _lib.get_handle(0).last_kernel() == e["kernel"], (e["kernel"], _lib.get_handle(0).last_kernel())
