@@ -39,6 +39,9 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROA
 FP32_PEAK_TFLOPS = 157.3   # fp32 vector = fp32 matrix peak (MI355X_MICROARCH.md:41-42)
 STREAM_PEAK_GBS = 7800.0   # measured: 256 workgroups re-reading "their" 640 KB region (tools/ubench/mall_stream.hip,
                            # profiles/README.md): 7.2 - 8.1 TB/s whatever the loads in flight -- the roof that binds
+WIDE_STREAM_GBS = 5880.0   # measured: the wide-shape kernel's traffic (256 B of X non-temporal + 32 B of W read + 32 B of W written
+                           # per row, 1024 matrices of 64 x 10 000) with no arithmetic: 5.85 - 5.89 TB/s; 4.97 with the default
+                           # cache policy on X; X alone 6.3 (7.0 non-temporal) (tools/ubench/wide_stream.hip, profiles/r03_ubench_wide_stream.log)
 SHARD_STREAM_GBS = 5100.0  # measured: the shard pass's traffic (64 B X + 20 B W read, 20 B W written per row, channel-
                            # major, 2.5e7 rows) with no arithmetic: 5.0 - 5.2 TB/s (tools/ubench/shard_stream.hip)
 
@@ -253,7 +256,8 @@ def compute_roofline(kernel, kernel_ms, units_per_launch, T, m, k, traffic=None,
                  "can re-read their matrices: stream_peak_gbs, measured by tools/ubench/mall_stream.hip"),
         "stream_peak_gbs": STREAM_PEAK_GBS,
     }
-    mem["stream_peak_source"] = "tools/ubench/mall_stream.hip, profiles/r02_ubench_mall_stream.log (round 2, commit 6cd19eb); a constant, not re-measured in this run"
+    if "stream_peak_gbs" in mem:
+        mem["stream_peak_source"] = "tools/ubench/mall_stream.hip, profiles/r02_ubench_mall_stream.log (round 2, commit 6cd19eb); a constant, not re-measured in this run"
     if traffic:
         mem["l2_fabric_source"] = _traffic.source  # a PMC measurement committed under profiles/, not taken in this run
         mem["l2_fabric_gbs"] = traffic / sec / 1e9
@@ -265,8 +269,13 @@ def compute_roofline(kernel, kernel_ms, units_per_launch, T, m, k, traffic=None,
     if m > 32 or k > 8:
         # wide shapes (nmf_wide.hpp): the batch does not fit the Infinity Cache (2.56 MB of X per 64-channel matrix, one
         # matrix per workgroup, several hundred in flight) and W streams too: HBM-bound, reported against the 8 TB/s line
-        mem.pop("note"), mem.pop("stream_peak_gbs")
+        mem.pop("note"), mem.pop("stream_peak_gbs"), mem.pop("stream_peak_source", None)
         gbs = by * units_per_launch / sec / 1e9
+        mem["measured_stream_ceiling_gbs"] = WIDE_STREAM_GBS
+        mem["frac_of_measured_ceiling"] = gbs / WIDE_STREAM_GBS
+        mem["measured_stream_ceiling_source"] = ("tools/ubench/wide_stream.hip, profiles/r03_ubench_wide_stream.log: the same bytes "
+                                                 "per row (X read non-temporal, W read and written back) with no arithmetic, at the "
+                                                 "64-channel k = 8 mix; a constant, not re-measured in this run")
         return {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                 "traffic": traffic, "kernel": kernel, "kernel_ms_avg": kernel_ms, "algorithmic_bytes_per_unit": by,
                 "units_per_launch": units_per_launch,
