@@ -20,28 +20,28 @@ using namespace hipnmf;
 
 namespace hipnmf {
 static int wide_mp(int m) { return m <= 16 ? 16 : m <= 32 ? 32 : m <= 48 ? 48 : m <= 64 ? 64 : m <= 96 ? 96 : m <= 128 ? 128 : 0; }
-const WideKernel<float>* wide_kernel_f32(int m, int k) {
+const WideKernel<float>* wide_kernel_f32(int m, int k, int nw) {
   const int MP = wide_mp(m), KP = k <= 16 ? 16 : 0;
   if (!MP || !KP) return nullptr;
-  return MP <= 48 ? wide_kernel_f32_lo(MP, KP) : wide_kernel_f32_hi(MP, KP);
+  return MP <= 48 ? wide_kernel_f32_lo(MP, KP, nw) : wide_kernel_f32_hi(MP, KP, nw);
 }
-const WideKernel<double>* wide_kernel_f64(int m, int k) {
+const WideKernel<double>* wide_kernel_f64(int m, int k, int nw) {
   const int MP = wide_mp(m), KP = k <= 16 ? 16 : 0;
   if (!MP || !KP) return nullptr;
-  return MP <= 48 ? wide_kernel_f64_lo(MP, KP) : wide_kernel_f64_hi(MP, KP);
+  return MP <= 48 ? wide_kernel_f64_lo(MP, KP, nw) : wide_kernel_f64_hi(MP, KP, nw);
 }
 }  // namespace hipnmf
 
 namespace {
 template <typename real>
-const WideKernel<real>* pick(int m, int k);
+const WideKernel<real>* pick(int m, int k, int nw);
 template <>
-const WideKernel<float>* pick<float>(int m, int k) {
-  return wide_kernel_f32(m, k);
+const WideKernel<float>* pick<float>(int m, int k, int nw) {
+  return wide_kernel_f32(m, k, nw);
 }
 template <>
-const WideKernel<double>* pick<double>(int m, int k) {
-  return wide_kernel_f64(m, k);
+const WideKernel<double>* pick<double>(int m, int k, int nw) {
+  return wide_kernel_f64(m, k, nw);
 }
 }  // namespace
 
@@ -51,7 +51,16 @@ int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
                     int32_t* n_iter_out, real* sse_col_out, real* xsq_col_out, const int64_t* ragged) {
   const int B = p->batch, m = p->n_features, k = p->n_components;
   const long long T = p->n_samples;
-  const WideKernel<real>* wk = pick<real>(m, k);
+  // Instance: 512 threads (one workgroup per CU, two waves per SIMD) with every byte of LDS the stages leave as W cache,
+  // wherever that instance exists; 256 threads (two workgroups per CU, small cache) otherwise, or on request
+  // (hipnmf_set_tuning threads = 256 / 512; HIPNMF_LDS_W=0 turns the cache off).
+  // Measured (tools/quick_bench.py, 1024 x T = 10 000, 100 iterations, TB/s algorithmic, 512 vs 256 threads): 64 ch k = 8
+  // 5.70 / 5.83, 64 ch k = 16 6.31 / 6.12, 128 ch k = 16 5.57 / 5.39, 32 ch k = 12 5.76 / 5.94 -- the bigger cache pays
+  // once W is a third of the traffic or the stages of two workgroups leave no room for a cache at all.
+  const int ks_ = (int)round_up(k, 4);
+  const bool want512 = h->threads == 512 || (h->threads == 0 && ks_ >= 12 && m > 48);
+  const WideKernel<real>* wk = want512 ? pick<real>(m, k, 8) : nullptr;
+  if (!wk) wk = pick<real>(m, k, 4);
   if (!wk) return fail(HIPNMF_ERR_UNSUPPORTED, "no kernel for n_features=%d (max 128) n_components=%d (max 16)", m, k);
   if (p->loss != HIPNMF_LOSS_FROBENIUS)
     return fail(HIPNMF_ERR_UNSUPPORTED, "the wide-shape kernels (n_features > 32 or n_components > 8) implement the Frobenius loss only");
@@ -203,12 +212,23 @@ int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
   a.l1h = (real)p->l1_reg_H;
   a.l2h = (real)p->l2_reg_H;
 
+  // W cache: whole 16-row subtiles in what LDS is left (512 threads: of the whole CU; 256 threads: of half of it, so that
+  // two workgroups stay resident)
+  size_t smem = wk->smem;
+  {
+    const size_t lds_cap = (h->lds_budget > 0 ? (size_t)h->lds_budget : (size_t)h->lds_per_block) / (wk->NW == 8 ? 1 : 2);
+    long long rows = 0;
+    if (h->use_lds_w && lds_cap > smem + 1024) rows = (long long)((lds_cap - smem - 256) / (sizeof(real) * (size_t)ks)) / 16 * 16;
+    rows = std::min<long long>(rows, round_up(T, 16));
+    a.lds_rows = (int)rows;
+    smem += sizeof(real) * (size_t)ks * (size_t)rows;
+  }
   HIP_TRY(hipEventRecord(h->ev0, st));
   h->last_path = 1;
   snprintf(h->last_kernel, sizeof(h->last_kernel), "%s", wk->name);
-  if (wk->smem > 48 * 1024)
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(wk->fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wk->smem));
-  hipLaunchKernelGGL(wk->fn, dim3(B), dim3(wk->NW * 64), wk->smem, st, a);
+  if (smem > 48 * 1024)
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(wk->fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  hipLaunchKernelGGL(wk->fn, dim3(B), dim3(wk->NW * 64), smem, st, a);
   HIP_TRY(hipEventRecord(h->ev1, st));
   if (!w_inplace) convert_w(1);
   HIP_TRY(hipGetLastError());

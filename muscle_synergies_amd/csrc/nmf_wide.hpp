@@ -27,6 +27,11 @@
 // iteration needs once (X H^T contracts channels, W^T X contracts rows).  No workgroup barrier inside a pass: a
 // wave's LDS operations execute in order and the stages are private to the wave.
 //
+// W cache.  Rows [0, lds_rows) of W live in LDS for the whole fit (row-major, ks values per row; every cached subtile is
+// only ever touched by the wave that owns it, so no barrier is involved): they cost neither the read nor the write-back
+// per iteration.  The write-back is what this kernel's traffic pays most for -- tools/ubench/wide_stream.hip: 256 B of X
+// per row alone stream at 7.0 TB/s, with 32 B of W read and written back beside them the same rows take 1.49x as long.
+//
 // Padding: components are padded to KP (16 or 32) and channels to MP (a multiple of 16) with exact zeros, which the
 // updates preserve (0 * 0 / EPSILON), so the padded problem's leading k x m block IS the unpadded iteration.
 #pragma once
@@ -49,6 +54,7 @@ struct WideArgs {
   const long long* ragged;  // [B][4] = {T_b, X offset, unused, W offset} (elements) or nullptr
   int T, m, k, ks, xchunks;  // xchunks: 16-byte pieces of a row of X that hold data (the rest of MP reads as zero)
   int max_iter, check_every, update_h;
+  int lds_rows;  // rows [0, lds_rows) of W (a multiple of 16) stay in LDS for the whole fit; launch-wide capacity
   real tol, l1w, l2w, l1h, l2h;
 };
 
@@ -181,6 +187,8 @@ fit_wide_kernel(WideArgs<real> a) {
   }
   const int m = a.m, k = a.k, ks = a.ks;
   const int ntiles = (T + 15) / 16;
+  real* const wcache = wv0 + NW * C::PERWAVE;  // [lds_rows][ks]
+  const int ncached = (a.lds_rows / 16 < ntiles) ? a.lds_rows / 16 : ntiles;  // subtiles whose W lives in LDS
   const unsigned ldx_b = (unsigned)(a.ldx * (long long)sizeof(real));
   const unsigned ldw_b = (unsigned)ks * (unsigned)sizeof(real);
 
@@ -199,14 +207,34 @@ fit_wide_kernel(WideArgs<real> a) {
   for (int kb = 0; kb < NKB; ++kb)
     wvoff[kb] = (16 * kb + 4 * g < ks) ? (unsigned)((j * ks + 16 * kb + 4 * g) * (int)sizeof(real)) : OOB;
   const int ar = M::arow(j);  // logical row this lane carries in an A operand
+  real* const wc_lane = wcache + j * ks + 4 * g;  // this lane's fragment of cached subtile 0, component block 0
+  // this lane's W fragment of subtile i: from / to the LDS cache or (already requested by issue) global memory
+  auto get_w = [&](const Tile& t, int i, real (&w)[NKB][4]) __attribute__((always_inline)) {
+    if (i < ncached) {
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb) {
+        if (16 * kb + 4 * g < ks) {
+          wide_lds_read<real, 4>(wc_lane + i * 16 * ks + 16 * kb, w[kb]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) w[kb][r] = (real)0;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) w[kb][r] = t.w[kb][r];
+    }
+  };
   const char* const xbase = reinterpret_cast<const char*>(Xb);
   char* const wbase = reinterpret_cast<char*>(Wb);
   auto x_rsrc = [&](int i) __attribute__((always_inline)) {  // rows [16 i, T) of X; empty beyond the matrix
     const int rows = i < ntiles ? T - 16 * i : 0;
     return make_rsrc(xbase + (long long)(rows > 0 ? 16 * i : 0) * ldx_b, (unsigned)rows * ldx_b);
   };
-  auto w_rsrc = [&](int i) __attribute__((always_inline)) {
-    const int rows = i < ntiles ? T - 16 * i : 0;
+  auto w_rsrc = [&](int i) __attribute__((always_inline)) {  // (subtiles cached in LDS: empty, their loads move nothing)
+    const int rows = (i < ntiles && i >= ncached) ? T - 16 * i : 0;
     return make_rsrc(wbase + (long long)(rows > 0 ? 16 * i : 0) * ldw_b, (unsigned)rows * ldw_b);
   };
 
@@ -226,6 +254,8 @@ fit_wide_kernel(WideArgs<real> a) {
     wide_wave_lds_fence();
   };
 
+  // ---- the cached rows of W -> LDS (the copy is the row-major image itself; rows past the matrix are zero) ---------
+  for (int idx = tid; idx < ncached * 16 * ks; idx += NT) wcache[idx] = (idx < T * ks) ? Wb[idx] : (real)0;
   // ---- H -> LDS (zero padded), H H^T ----------------------------------------------------------------------------
   for (int idx = tid; idx < KP * SX; idx += NT) {
     const int c = idx / SX, jj = idx % SX;
@@ -267,10 +297,7 @@ fit_wide_kernel(WideArgs<real> a) {
   auto update_subtile = [&](Tile& t, int i, int inext, bool upd) __attribute__((always_inline)) {
     stage_x(t);
     real wold[NKB][4];
-#pragma unroll
-    for (int kb = 0; kb < NKB; ++kb)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) wold[kb][r] = t.w[kb][r];
+    get_w(t, i, wold);
     issue(t, inext);  // the registers of this subtile are free again: request the one PF steps ahead
     // numerator^T = H X^T, two accumulation chains per component block
     acc num0[NKB], num1[NKB];
@@ -329,7 +356,11 @@ fit_wide_kernel(WideArgs<real> a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) wn[kb][r] = wold[kb][r] * qq[r];
     }
-    {
+    if (i < ncached) {
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb)
+        if (16 * kb + 4 * g < ks) wide_lds_write<real, 4>(wc_lane + i * 16 * ks + 16 * kb, wn[kb]);
+    } else {
       const rsrc_t wr = w_rsrc(i);
 #pragma unroll
       for (int kb = 0; kb < NKB; ++kb) wide_store4<real>(wr, wvoff[kb], 0u, wn[kb]);
@@ -381,6 +412,8 @@ fit_wide_kernel(WideArgs<real> a) {
       Tile t;
       issue(t, i);
       stage_x(t);
+      real wr_[NKB][4];
+      get_w(t, i, wr_);
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb) {
         // R block = W H[:, 16 cb ..]: A = H^T block (lane (channel i, g), k-step r <-> H[16 kb + 4 g + r][16 cb + arow(i)])
@@ -388,7 +421,7 @@ fit_wide_kernel(WideArgs<real> a) {
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) rec = M::mma(sH[(16 * kb + 4 * g + r) * SX + 16 * cb + ar], t.w[kb][r], rec);
+          for (int r = 0; r < 4; ++r) rec = M::mma(sH[(16 * kb + 4 * g + r) * SX + 16 * cb + ar], wr_[kb][r], rec);
         real xv[4];
         wide_lds_read<real, 4>(xs + j * SX + 16 * cb + 4 * g, xv);
 #pragma unroll
@@ -546,6 +579,8 @@ fit_wide_kernel(WideArgs<real> a) {
   if (upd) {
     for (int idx = tid; idx < k * m; idx += NT) Hb[idx] = sH[(idx / m) * SX + idx % m];
   }
+  // the cached rows of W back to global memory (block_resid above ended with a barrier: every wave's rows are final)
+  for (int idx = tid; idx < ncached * 16 * ks && idx < T * ks; idx += NT) Wb[idx] = wcache[idx];
 }
 
 // ---- W between the caller's layout and the kernel's row-major [T][ks] rows (once per fit each way) -----------------

@@ -12,7 +12,8 @@ struct WideKernel {
   int MP, KP, NW;
   const char* name;  // "fit_wide_kernel<real,MP,KP,NW>"
 };
-// smallest compiled instance that holds n_features x n_components, nullptr beyond 128 channels / 16 components
-const WideKernel<float>* wide_kernel_f32(int n_features, int n_components);
-const WideKernel<double>* wide_kernel_f64(int n_features, int n_components);
+// smallest compiled instance that holds n_features x n_components, nullptr beyond 128 channels / 16 components;
+// nw = 8: the 512-thread instance (one workgroup per CU, the rest of LDS as W cache), nullptr where it does not exist
+const WideKernel<float>* wide_kernel_f32(int n_features, int n_components, int nw);
+const WideKernel<double>* wide_kernel_f64(int n_features, int n_components, int nw);
 }  // namespace hipnmf

@@ -34,8 +34,33 @@ WideKernel<real> make_wide_kernel(const char* name) {
   w.name = name;
   return w;
 }
-const WideKernel<float>* wide_kernel_f32_lo(int MP, int KP);
-const WideKernel<float>* wide_kernel_f32_hi(int MP, int KP);
-const WideKernel<double>* wide_kernel_f64_lo(int MP, int KP);
-const WideKernel<double>* wide_kernel_f64_hi(int MP, int KP);
+// NW = 4 (256 threads) or 8 (512 threads, where the instance is compiled for two waves per SIMD): nullptr otherwise
+const WideKernel<float>* wide_kernel_f32_lo(int MP, int KP, int NW);
+const WideKernel<float>* wide_kernel_f32_hi(int MP, int KP, int NW);
+const WideKernel<double>* wide_kernel_f64_lo(int MP, int KP, int NW);
+const WideKernel<double>* wide_kernel_f64_hi(int MP, int KP, int NW);
+// the 512-thread instance exists only where the kernel is compiled for two waves per SIMD (256 registers)
+template <typename real, int MP>
+WideKernel<real> make_wide_kernel8(const char* name) {
+  if constexpr (wide_wpe<real, MP, 16>() == 2) {
+    return make_wide_kernel<real, MP, 16, 8>(name);
+  } else {
+    WideKernel<real> w{};
+    return w;
+  }
+}
+// the table of one translation unit: three channel paddings x {4, 8} waves (8 only for the two-waves-per-SIMD instances)
+template <typename real, int MPA, int MPB, int MPC>
+const WideKernel<real>* wide_table_lookup(int MP, int KP, int NW, const char* const (&names)[6]) {
+  static const WideKernel<real> t4[3] = {make_wide_kernel<real, MPA, 16, 4>(names[0]), make_wide_kernel<real, MPB, 16, 4>(names[1]),
+                                         make_wide_kernel<real, MPC, 16, 4>(names[2])};
+  static const WideKernel<real> t8[3] = {make_wide_kernel8<real, MPA>(names[3]), make_wide_kernel8<real, MPB>(names[4]),
+                                         make_wide_kernel8<real, MPC>(names[5])};
+  static const bool ok8[3] = {wide_wpe<real, MPA, 16>() == 2, wide_wpe<real, MPB, 16>() == 2, wide_wpe<real, MPC, 16>() == 2};
+  if (KP != 16 || (NW != 4 && NW != 8)) return nullptr;
+  const int q = MP == MPA ? 0 : MP == MPB ? 1 : MP == MPC ? 2 : -1;
+  if (q < 0) return nullptr;
+  if (NW == 8) return ok8[q] ? &t8[q] : nullptr;
+  return &t4[q];
+}
 }  // namespace hipnmf
