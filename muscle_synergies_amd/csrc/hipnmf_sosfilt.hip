@@ -64,6 +64,20 @@ hipError_t launch_v2(const SosArgs& a, const double* stat, int ns, hipStream_t s
   return hipSuccess;
 }
 
+// round 3 kernel (zero-lag only): section states checkpointed per tile, forward output recomputed in the backward pass
+template <typename real, int LPS>
+hipError_t launch_v3(const SosArgs& a, const double* stat, int ns, hipStream_t st) {
+  constexpr int S = sos2_series<LPS>();
+  constexpr size_t smem = sos3_smem_bytes<LPS>();
+  const void* kern = reinterpret_cast<const void*>(&sosfilt3_kernel<real, LPS>);
+  if (smem > 48 * 1024) {
+    const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL((sosfilt3_kernel<real, LPS>), dim3((a.N + S - 1) / S), dim3(192), smem, st, a, stat, ns);
+  return hipSuccess;
+}
+
 template <typename real>
 int sosfilt_impl(hipnmf_handle* h, const hipnmf_sosfilt_params* p, const double* sos, const double* zi, const real* x,
                  real* y) {
@@ -114,7 +128,20 @@ int sosfilt_impl(hipnmf_handle* h, const hipnmf_sosfilt_params* p, const double*
   const size_t o_x = inplace ? 0 : carve(sizeof(real) * (size_t)N * T);
   // forward output of the zero-lag filter: SOS_SERIES rows per wave, so the last wave needs no row guards
   // forward output of the zero-lag filter: whole 64-sample tiles, 64 rows per workgroup-group (both kernels fit)
-  const size_t o_ws = zero_lag ? carve(sizeof(double) * (size_t)round_up(N, 64) * (size_t)round_up(L, 64)) : 0;
+  // HIPNMF_SOS_V3=1: sosfilt3_kernel (section states checkpointed, forward output recomputed in the backward pass: half the
+  // traffic).  Not the default: measured 2.40 vs 2.08 ms at 1024 x 16 x 20 000 fp32 order 4 -- the filter is bound by the
+  // dependent fp64 chain of the recursion (25 ns per step, two passes of 41 200 steps), not by the bytes it moves, and a
+  // second recursion wave per workgroup slows the first.
+  static const bool sos_v3 = [] {
+    const char* e = getenv("HIPNMF_SOS_V3");
+    return e && atoi(e) != 0;
+  }();
+  const bool use_v3 = zero_lag && sos_v3;
+  // v2: forward output over the extended signal (whole 64-sample tiles, 64 rows per workgroup group);
+  // v3: section states per workgroup and tile only: [workgroups <= N / 8 + 1][tiles + 1][64 lanes][2]
+  const size_t ws_v2 = sizeof(double) * (size_t)round_up(N, 64) * (size_t)round_up(L, 64);
+  const size_t ws_v3 = sizeof(double) * (size_t)(N / 8 + 1) * (size_t)(round_up(L, 64) / 64 + 1) * 128;
+  const size_t o_ws = zero_lag ? carve(use_v3 ? ws_v3 : ws_v2) : 0;
   const size_t o_stat = carve(sizeof(double) * (size_t)N * 3);
   int rc = hipnmf_ensure_ws(h, std::max<size_t>(off, 256));
   if (rc) return rc;
@@ -166,7 +193,17 @@ int sosfilt_impl(hipnmf_handle* h, const hipnmf_sosfilt_params* p, const double*
     const char* e = getenv("HIPNMF_SOS_V1");
     return e && atoi(e) != 0;
   }();
-  if (!sos_v1) {
+  if (use_v3 && !sos_v1) {
+    const int ns = p->n_sections;
+    if (ns == 1)
+      HIP_TRY((launch_v3<real, 1>(a, stat, ns, st)));
+    else if (ns == 2)
+      HIP_TRY((launch_v3<real, 2>(a, stat, ns, st)));
+    else if (ns <= 4)
+      HIP_TRY((launch_v3<real, 4>(a, stat, ns, st)));
+    else
+      HIP_TRY((launch_v3<real, 8>(a, stat, ns, st)));
+  } else if (!sos_v1) {
     const int ns = p->n_sections;
     if (ns == 1)
       HIP_TRY((launch_v2<real, 1>(a, stat, ns, st)));

@@ -58,12 +58,11 @@ int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
   // 5.70 / 5.83, 64 ch k = 16 6.31 / 6.12, 128 ch k = 16 5.57 / 5.39, 32 ch k = 12 5.76 / 5.94 -- the bigger cache pays
   // once W is a third of the traffic or the stages of two workgroups leave no room for a cache at all.
   const int ks_ = (int)round_up(k, 4);
-  const bool want512 = h->threads == 512 || (h->threads == 0 && ks_ >= 12 && m > 48);
+  const bool kl = p->loss == HIPNMF_LOSS_KL;  // the Kullback-Leibler flavour exists as the 256-thread instance
+  const bool want512 = !kl && (h->threads == 512 || (h->threads == 0 && ks_ >= 12 && m > 48));
   const WideKernel<real>* wk = want512 ? pick<real>(m, k, 8) : nullptr;
   if (!wk) wk = pick<real>(m, k, 4);
   if (!wk) return fail(HIPNMF_ERR_UNSUPPORTED, "no kernel for n_features=%d (max 128) n_components=%d (max 16)", m, k);
-  if (p->loss != HIPNMF_LOSS_FROBENIUS)
-    return fail(HIPNMF_ERR_UNSUPPORTED, "the wide-shape kernels (n_features > 32 or n_components > 8) implement the Frobenius loss only");
   if (h->variant == 2 || h->variant == 3 || h->variant == 5 || h->variant == 6)
     return fail(HIPNMF_ERR_UNSUPPORTED, "tuning variant %d does not exist for wide shapes (n_features=%d, n_components=%d)",
                 h->variant, m, k);
@@ -225,10 +224,12 @@ int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
   }
   HIP_TRY(hipEventRecord(h->ev0, st));
   h->last_path = 1;
-  snprintf(h->last_kernel, sizeof(h->last_kernel), "%s", wk->name);
+  snprintf(h->last_kernel, sizeof(h->last_kernel), "%s%s", wk->name, kl ? "[kl]" : "");
+  const auto kern = kl ? wk->fn_kl : wk->fn;
+  if (!kern) return fail(HIPNMF_ERR_UNSUPPORTED, "no Kullback-Leibler instance of %s", wk->name);
   if (smem > 48 * 1024)
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(wk->fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-  hipLaunchKernelGGL(wk->fn, dim3(B), dim3(wk->NW * 64), smem, st, a);
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  hipLaunchKernelGGL(kern, dim3(B), dim3(wk->NW * 64), smem, st, a);
   HIP_TRY(hipEventRecord(h->ev1, st));
   if (!w_inplace) convert_w(1);
   HIP_TRY(hipGetLastError());

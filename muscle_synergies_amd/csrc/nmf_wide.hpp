@@ -152,7 +152,9 @@ struct WideTile {
 // pays a v_accvgpr_read / _write per value the VALU touches: 46 of ~100 VALU instructions per subtile in the first build).
 // NSET: register sets of subtile loads a wave keeps in flight (the subtile being worked on has been staged, so NSET
 // further ones are on their way).
-template <typename real, int MP, int KP, int NW, bool HREG, int WPE, int NSET>
+// LOSS: 0 = Frobenius (beta_loss = 2), 1 = Kullback-Leibler (beta_loss = 1; _nmf.py:556-591, 642-684): W *= ((X / WH) H^T) /
+// rowsum(H), H *= (W^T (X / W'H)) / colsum(W') with W' the updated W; both reconstructions and both products on the pipe.
+template <typename real, int MP, int KP, int NW, bool HREG, int WPE, int NSET, int LOSS = 0>
 __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WPE > 1 ? 8 : 1)))
 fit_wide_kernel(WideArgs<real> a) {
   using C = WideCfg<real, MP, KP>;
@@ -263,6 +265,14 @@ fit_wide_kernel(WideArgs<real> a) {
   }
   __syncthreads();
   auto compute_hht_lds = [&]() __attribute__((always_inline)) {  // call between barriers
+    if constexpr (LOSS == 1) {  // rowsum(H), the W update's denominator (_nmf.py:577-581), in sHHt[0 .. KP)
+      for (int c = tid; c < KP; c += NT) {
+        real s = (real)0;
+        for (int jj = 0; jj < MP; ++jj) s += sH[c * SX + jj];
+        sHHt[c] = s;
+      }
+      return;
+    }
     for (int idx = tid; idx < KP * KP; idx += NT) {
       const int c = idx / KP, c2 = idx % KP;
       real s = (real)0;
@@ -276,7 +286,13 @@ fit_wide_kernel(WideArgs<real> a) {
   // A operands that change once per iteration
   real hha[NKB][NKB][4];  // H H^T: lane (i, g), k-step r of input block kbi <-> HHt[16 kbo + arow(i)][16 kbi + 4 g + r]
   real hreg[HREG ? NKB : 1][HREG ? NS1 : 1][VEC];
+  real hsum[NKB][4];  // KL: rowsum(H) of the components this lane holds in the D layout (16 kb + 4 g + r)
   auto load_operands = [&]() __attribute__((always_inline)) {
+    if constexpr (LOSS == 1) {
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb) wide_lds_read<real, 4>(sHHt + 16 * kb + 4 * g, hsum[kb]);
+      return;
+    }
 #pragma unroll
     for (int kbo = 0; kbo < NKB; ++kbo)
 #pragma unroll
@@ -291,7 +307,25 @@ fit_wide_kernel(WideArgs<real> a) {
   load_operands();
 
   acc accA[NKB][NCB], accB[NKB][NKB];
+  real wsum[NKB][4];  // KL: this lane's share of colsum(W) (its row, the components of its D registers)
   const acc zero = {(real)0, (real)0, (real)0, (real)0};
+  // W H for the lane's row and channel block cb: A = H^T block (lane (channel i, g), k-step r <-> H[16 kb + 4 g + r][16 cb +
+  // arow(i)]), B = the W fragment; D: lane (row j, g), register r <-> channel 16 cb + 4 g + r
+  auto wh_block = [&](const real (&w)[NKB][4], int cb) __attribute__((always_inline)) -> acc {
+    acc rec = zero;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) rec = M::mma(sH[(16 * kb + 4 * g + r) * SX + 16 * cb + ar], w[kb][r], rec);
+    return rec;
+  };
+  auto kl_quot = [&](real x, real wh) __attribute__((always_inline)) -> real {  // X / max(WH, EPSILON) (_nmf.py:574-575)
+    const real d = wh < eps_val<real>() ? eps_val<real>() : wh;
+    if constexpr (sizeof(real) == 4)
+      return fast_div(x, d);
+    else
+      return x / d;
+  };
 
   // ---- one subtile: W update (_nmf.py:540-554, 615-631) and the sums of W^T X / W^T W (:638-640) ------------------
   auto update_subtile = [&](Tile& t, int i, int inext, bool upd) __attribute__((always_inline)) {
@@ -299,6 +333,87 @@ fit_wide_kernel(WideArgs<real> a) {
     real wold[NKB][4];
     get_w(t, i, wold);
     issue(t, inext);  // the registers of this subtile are free again: request the one PF steps ahead
+    if constexpr (LOSS == 1) {
+      // numerator^T = H Q^T with Q = X / max(W H, eps): Q comes out of wh_block's D layout (lane (row j, g), register r <->
+      // channel 16 cb + 4 g + r), which is the B operand of k-step (cb, r); A: lane (i, g) <-> H[16 kb + arow(i)][16 cb + 4 g + r]
+      acc num[NKB];
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb) num[kb] = zero;
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) {
+        const acc wh = wh_block(wold, cb);
+        real xv[4];
+        wide_lds_read<real, 4>(xs + j * SX + 16 * cb + 4 * g, xv);
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+          real ha[4];
+          wide_lds_read<real, 4>(sH + (16 * kb + ar) * SX + 16 * cb + 4 * g, ha);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) num[kb] = M::mma(ha[r], kl_quot(xv[r], wh[r]), num[kb]);
+        }
+      }
+      real wn[NKB][4];
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb) {
+        real nn[4], dd[4], qq[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          real d = hsum[kb][r];
+          if (a.l1w > (real)0) d = d + a.l1w;
+          if (a.l2w > (real)0) d = d + a.l2w * wold[kb][r];
+          dd[r] = (d == (real)0) ? eps_val<real>() : d;
+          nn[r] = num[kb][r];
+        }
+        quotients<4>(nn, dd, qq);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) wn[kb][r] = wold[kb][r] * qq[r];
+      }
+      if (i < ncached) {
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+          if (16 * kb + 4 * g < ks) wide_lds_write<real, 4>(wc_lane + i * 16 * ks + 16 * kb, wn[kb]);
+      } else {
+        const rsrc_t wr = w_rsrc(i);
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) wide_store4<real>(wr, wvoff[kb], 0u, wn[kb]);
+      }
+      if (upd) {
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+          wide_lds_write<real, 4>(wst + j * SW + 16 * kb + 4 * g, wn[kb]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) wsum[kb][r] += wn[kb][r];
+        }
+        // Q' = X / max(W' H, eps) with the updated rows, written over X in the stage (each lane replaces exactly what it
+        // read), then W'^T Q' like the Frobenius W^T X
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+          const acc wh = wh_block(wn, cb);
+          real xv[4], qv[4];
+          wide_lds_read<real, 4>(xs + j * SX + 16 * cb + 4 * g, xv);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) qv[r] = kl_quot(xv[r], wh[r]);
+          wide_lds_write<real, 4>(xs + j * SX + 16 * cb + 4 * g, qv);
+        }
+        wide_wave_lds_fence();
+        real wa[NKB][4];
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) wa[kb][s] = wst[(4 * g + s) * SW + 16 * kb + ar];
+        const real* xcol = xs + 4 * g * SX + j;
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const real xb = xcol[s * SX + 16 * cb];
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) accA[kb][cb] = M::mma(wa[kb][s], xb, accA[kb][cb]);
+          }
+      }
+      wide_wave_lds_fence();
+      return;
+    }
     // numerator^T = H X^T, two accumulation chains per component block
     acc num0[NKB], num1[NKB];
 #pragma unroll
@@ -404,6 +519,7 @@ fit_wide_kernel(WideArgs<real> a) {
   // ---- ||X - W H||_F^2 per column and sum X^2 per column of the whole matrix -> sPart[0 .. 2 MP); barriers inside ----
   auto block_resid = [&]() __attribute__((always_inline)) {
     real sse[NCB][4], xsq[NCB][4];
+    real kl = (real)0;  // LOSS == 1: generalised KL divergence, element by element as x log(x / wh) - x + wh (_nmf.py:138-161)
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
@@ -417,11 +533,7 @@ fit_wide_kernel(WideArgs<real> a) {
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb) {
         // R block = W H[:, 16 cb ..]: A = H^T block (lane (channel i, g), k-step r <-> H[16 kb + 4 g + r][16 cb + arow(i)])
-        acc rec = zero;
-#pragma unroll
-        for (int kb = 0; kb < NKB; ++kb)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) rec = M::mma(sH[(16 * kb + 4 * g + r) * SX + 16 * cb + ar], wr_[kb][r], rec);
+        const acc rec = wh_block(wr_, cb);
         real xv[4];
         wide_lds_read<real, 4>(xs + j * SX + 16 * cb + 4 * g, xv);
 #pragma unroll
@@ -429,6 +541,13 @@ fit_wide_kernel(WideArgs<real> a) {
           const real d = xv[r] - rec[r];
           sse[cb][r] = fma_(d, d, sse[cb][r]);
           xsq[cb][r] = fma_(xv[r], xv[r], xsq[cb][r]);
+          if constexpr (LOSS == 1) {  // branch-free, as in resid_tile (nmf_kernels.hpp)
+            const real x = xv[r], whv = rec[r];
+            const real whc = whv < eps_val<real>() ? eps_val<real>() : whv;
+            const real xs_ = x > eps_val<real>() ? x : eps_val<real>();
+            const real lg = fma_(x, log_(xs_ / whc), whv - x);
+            kl += (x > eps_val<real>()) ? lg : whv;
+          }
         }
       }
       wide_wave_lds_fence();
@@ -447,7 +566,12 @@ fit_wide_kernel(WideArgs<real> a) {
         sse[cb][r] = s1;
         xsq[cb][r] = s2;
       }
-    real* rec = xs;  // [2][MP] record of this wave (the stage is idle now)
+    if constexpr (LOSS == 1) {
+#pragma unroll
+      for (int off = 1; off < WAVE; off <<= 1) kl += __shfl_xor(kl, off, WAVE);
+    }
+    real* rec = xs;  // [2][MP] (+ 1) record of this wave (the stage is idle now)
+    if (LOSS == 1 && lane == 0) rec[2 * MP] = kl;
     if (j == 0) {
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb)
@@ -458,7 +582,7 @@ fit_wide_kernel(WideArgs<real> a) {
         }
     }
     __syncthreads();
-    for (int idx = tid; idx < 2 * MP; idx += NT) {
+    for (int idx = tid; idx < 2 * MP + (LOSS == 1 ? 1 : 0); idx += NT) {
       real s = wv0[idx];
       for (int w2 = 1; w2 < NW; ++w2) s += wv0[w2 * C::PERWAVE + idx];
       sPart[idx] = s;
@@ -466,6 +590,10 @@ fit_wide_kernel(WideArgs<real> a) {
     __syncthreads();
   };
   auto error_from_part = [&]() __attribute__((always_inline)) -> real {
+    if constexpr (LOSS == 1) {  // sqrt(2 KL(X || WH)) (_nmf.py:185-189)
+      const real d = sPart[2 * MP];
+      return sqrt_((real)2 * (d > (real)0 ? d : (real)0));
+    }
     real tot = (real)0;
     for (int jj = 0; jj < MP; ++jj) tot += sPart[jj];
     return sqrt_(tot);
@@ -490,6 +618,8 @@ fit_wide_kernel(WideArgs<real> a) {
       for (int cb = 0; cb < NCB; ++cb) accA[kb][cb] = zero;
 #pragma unroll
       for (int kb2 = 0; kb2 < NKB; ++kb2) accB[kb][kb2] = zero;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) wsum[kb][r] = (real)0;
     }
     if constexpr (NSET > 1) {
       for (int i = wave; i < ntiles; i += 2 * NW) {
@@ -518,13 +648,23 @@ fit_wide_kernel(WideArgs<real> a) {
         for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
           for (int r = 0; r < 4; ++r) rec[(16 * kb + 4 * g + r) * MP + 16 * cb + j] = accA[kb][cb][r];
+        if constexpr (LOSS == 1) {  // colsum(W): the 16 lanes j of one g hold the rows, butterfly over the low lane bits
 #pragma unroll
-        for (int kb2 = 0; kb2 < NKB; ++kb2)
+          for (int r = 0; r < 4; ++r) {
+            real sw = wsum[kb][r];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) rec[KP * MP + (16 * kb + 4 * g + r) * KP + 16 * kb2 + j] = accB[kb][kb2][r];
+            for (int off = 1; off < 16; off <<= 1) sw += __shfl_xor(sw, off, WAVE);
+            if (j == 0) rec[KP * MP + 16 * kb + 4 * g + r] = sw;
+          }
+        } else {
+#pragma unroll
+          for (int kb2 = 0; kb2 < NKB; ++kb2)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rec[KP * MP + (16 * kb + 4 * g + r) * KP + 16 * kb2 + j] = accB[kb][kb2][r];
+        }
       }
       __syncthreads();
-      for (int idx = tid; idx < C::REC; idx += NT) {
+      for (int idx = tid; idx < (LOSS == 1 ? KP * MP + KP : C::REC); idx += NT) {
         real s = wv0[idx];
         for (int w2 = 1; w2 < NW; ++w2) s += wv0[w2 * C::PERWAVE + idx];
         sA[idx] = s;  // sB follows sA
@@ -539,13 +679,22 @@ fit_wide_kernel(WideArgs<real> a) {
         const int c = idx / MP, jj = idx % MP;
         nh[q] = (real)0;
         if (idx < KP * MP && c < k && jj < m) {
-          real d = sB[c * KP] * sH[jj];
-          for (int c2 = 1; c2 < k; ++c2) d = fma_(sB[c * KP + c2], sH[c2 * SX + jj], d);
+          real d;
+          if constexpr (LOSS == 1) {  // H *= (W^T Q') / colsum(W)   (_nmf.py:663-684; colsum 0 -> 1)
+            d = sB[c];
+            if (d == (real)0) d = (real)1;
+          } else {
+            d = sB[c * KP] * sH[jj];
+            for (int c2 = 1; c2 < k; ++c2) d = fma_(sB[c * KP + c2], sH[c2 * SX + jj], d);
+          }
           const real hold = sH[c * SX + jj];
           if (a.l1h > (real)0) d = d + a.l1h;
           if (a.l2h > (real)0) d = d + a.l2h * hold;
           d = (d == (real)0) ? eps_val<real>() : d;
           nh[q] = hold * (sA[idx] / d);
+          if constexpr (LOSS == 1) {
+            if (nh[q] < (real)2.220446049250313e-16) nh[q] = (real)0;  // H[H < float64 eps] = 0 (_nmf.py:866-868)
+          }
         }
       }
       __syncthreads();

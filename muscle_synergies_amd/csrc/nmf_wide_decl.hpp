@@ -8,6 +8,7 @@ namespace hipnmf {
 template <typename real>
 struct WideKernel {
   void (*fn)(WideArgs<real>);
+  void (*fn_kl)(WideArgs<real>);  // Kullback-Leibler flavour (256-thread instances only), nullptr otherwise
   size_t smem;  // dynamic LDS bytes
   int MP, KP, NW;
   const char* name;  // "fit_wide_kernel<real,MP,KP,NW>"

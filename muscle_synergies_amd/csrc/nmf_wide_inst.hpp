@@ -27,6 +27,9 @@ template <typename real, int MP, int KP, int NW>
 WideKernel<real> make_wide_kernel(const char* name) {
   WideKernel<real> w;
   w.fn = fit_wide_kernel<real, MP, KP, NW, wide_hreg<real, MP, KP>(), wide_wpe<real, MP, KP>(), wide_nset<real, MP, KP>()>;
+  w.fn_kl = nullptr;
+  if constexpr (NW == 4)  // (H is re-read from LDS in the KL flavour: no register copy, one set of loads in flight)
+    w.fn_kl = fit_wide_kernel<real, MP, KP, NW, false, wide_wpe<real, MP, KP>(), 1, 1>;
   w.smem = WideCfg<real, MP, KP>::smem_bytes(NW);
   w.MP = MP;
   w.KP = KP;

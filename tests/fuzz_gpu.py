@@ -72,8 +72,6 @@ for case in range(a.cases):
             continue
         if wide and variant in (2, 3, 5, 6) and "does not exist for wide shapes" in str(e):
             continue
-        if wide and loss != "frobenius" and "Frobenius loss only" in str(e):
-            continue
         if variant == 6 and ("fit_small_kernel" in str(e)):  # n_samples <= 256, Frobenius, m <= 16 (fp32) / 8 (fp64, k <= 6)
             assert not (max(Ts) <= 256 and loss == "frobenius" and m <= (16 if dtype == np.float32 else 8)
                         and not (dtype == np.float64 and k > 6)), desc
