@@ -171,3 +171,46 @@ def test_wide_find_synergies_does_not_fall_back():
     W0, H0 = initialize_nmf(X, 10, init="nndsvda", random_state=0)
     ref = orc.nmf_mu_fit(X, W0, H0, max_iter=60, tol=0.0)
     np.testing.assert_allclose(res.model.components_, ref["H"], rtol=1e-8, atol=1e-12)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("m,k,T", [(33, 8, 130), (64, 16, 400), (128, 5, 77), (16, 12, 300), (100, 9, 1003)])
+def test_wide_kullback_leibler(dtype, m, k, T):
+    """beta_loss='kullback-leibler' on the wide shapes (both W H reconstructions and both products on the matrix pipe)
+    against the oracle's restatement of _nmf.py:556-591, 642-684: fixed iteration count, stop rule, regularisation."""
+    import muscle_synergies_amd as ms
+
+    X, W0, H0 = _case(T, m, k, dtype, seed=m + k)
+    tol = 3e-5 if dtype == np.float32 else 1e-9
+    Wr, Hr, _ = orc.fit_multiplicative_update_kl(X, W0.copy(), H0.copy(), 25, 0.0)
+    for layout in ("F", "C"):
+        Xl = np.asfortranarray(X) if layout == "F" else np.ascontiguousarray(X)
+        res = ms.fit_batched(Xl, W0, H0, max_iter=25, tol=0.0, beta_loss="kullback-leibler")
+        assert _last_kernel().endswith("[kl]") and _last_kernel().startswith("fit_wide_kernel"), _last_kernel()
+        assert _rel(X, res.W[0], res.H[0], {"W": Wr, "H": Hr}) <= tol, layout
+        err = orc.kl_divergence(X, Wr, Hr, square_root=True)
+        assert abs(float(res.reconstruction_err[0]) - err) <= (2e-3 if dtype == np.float32 else 1e-9) * max(err, 1e-30)
+    Ws, Hs, n_it = orc.fit_multiplicative_update_kl(X, W0.copy(), H0.copy(), 150, 1e-3, 0.01, 0.02, 0.03, 0.01)
+    res = ms.fit_batched(X, W0, H0, max_iter=150, tol=1e-3, beta_loss="kullback-leibler", l1_reg_W=0.01, l1_reg_H=0.02,
+                         l2_reg_W=0.03, l2_reg_H=0.01)
+    if dtype == np.float64:
+        assert int(res.n_iter[0]) == n_it
+        assert _rel(X, res.W[0], res.H[0], {"W": Ws, "H": Hs}) <= 1e-9
+    else:
+        assert abs(int(res.n_iter[0]) - n_it) <= 10
+
+
+def test_wide_kl_through_the_estimator():
+    """HipNMF(beta_loss='kullback-leibler') on a 64-channel frame stays on the GPU."""
+    import warnings
+
+    import muscle_synergies_amd as ms
+
+    X = emg_matrix(9, T=300, m=64, k_true=6, dtype=np.float64)
+    W0, H0 = random_init(X, 10, seed=2)
+    model = ms.HipNMF(n_components=10, init="custom", solver="mu", beta_loss="kullback-leibler", tol=0.0, max_iter=40)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", RuntimeWarning)
+        W = model.fit_transform(X, W=W0.copy(), H=H0.copy())
+    Wr, Hr, _ = orc.fit_multiplicative_update_kl(X, W0.copy(), H0.copy(), 40, 0.0)
+    np.testing.assert_allclose(W @ model.components_, Wr @ Hr, rtol=1e-8, atol=1e-11)
