@@ -38,7 +38,7 @@ extern "C" {
 #define HIPNMF_OK 0
 #define HIPNMF_ERR_BAD_ARG (-1)
 #define HIPNMF_ERR_HIP (-2)
-#define HIPNMF_ERR_UNSUPPORTED (-3) /* shape outside the compiled kernel set (m <= 128, k <= 16; shard entries m <= 32, k <= 8) */
+#define HIPNMF_ERR_UNSUPPORTED (-3) /* shape outside the compiled kernel set (m <= 128, k <= 32; shard entries m <= 32, k <= 8) */
 #define HIPNMF_ERR_NO_DEVICE (-4)
 
 /* memory layout of one X matrix.  Either is accepted everywhere; which one the kernels stream WITHOUT a one-off
@@ -66,7 +66,7 @@ typedef struct hipnmf_problem {
   int32_t batch;          /* B  >= 1 independent factorisations                                        */
   int64_t n_samples;      /* T  rows of X (time samples)                                               */
   int32_t n_features;     /* m  columns of X (muscles), 1..128 (time-shard entry points: 1..32)        */
-  int32_t n_components;   /* k  rank, 1..16 (time-shard entry points: 1..8)                            */
+  int32_t n_components;   /* k  rank, 1..32 (time-shard entry points: 1..8)                            */
   int32_t x_layout;       /* HIPNMF_X_*                                                                */
   int32_t update_h;       /* 1: fit (W and H updated, _nmf.py:854); 0: transform (H fixed, :1736-1763) */
   int32_t w_layout;       /* HIPNMF_W_*                                                                */

@@ -61,6 +61,6 @@ template <typename real>
 int hipnmf_random_init_indexed(hipnmf_handle* h, const hipnmf_problem* p, uint64_t seed, int first_matrix, const int* index,
                                const real* X, real* W, real* H);
 constexpr int HIPNMF_NARROW_MAX_FEATURES = 32, HIPNMF_NARROW_MAX_COMPONENTS = 8;  // nmf_kernels.hpp lane mappings
-constexpr int HIPNMF_MAX_FEATURES = 128, HIPNMF_MAX_COMPONENTS = 16;              // nmf_wide.hpp
+constexpr int HIPNMF_MAX_FEATURES = 128, HIPNMF_MAX_COMPONENTS = 32;              // nmf_wide.hpp
 
 // X layout canonicalisation kernel (nmf_kernels.hpp) reused by the envelope entry point

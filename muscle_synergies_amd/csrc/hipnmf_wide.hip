@@ -1,5 +1,5 @@
 // hipnmf_wide.hip -- host driver of the wide-shape kernels (nmf_wide.hpp): n_features up to 128 and n_components up
-// to 16, fp32 and fp64, reached from hipnmf_fit_batched_* / hipnmf_fit_ragged_* for every shape outside the narrow
+// to 32 (float64 with more than 16 components: up to 64 channels), fp32 and fp64, reached from hipnmf_fit_batched_* / hipnmf_fit_ragged_* for every shape outside the narrow
 // kernel set of hipnmf_api.hip (n_features > 32 or n_components > 8).  The reference accepts any
 // 1 <= n_components <= n_features (src/muscle_synergies/analysis.py:829-846, :862-863); sklearn's solver is shape-
 // agnostic (sklearn/decomposition/_nmf.py:540-554, 638-640).
@@ -21,14 +21,16 @@ using namespace hipnmf;
 namespace hipnmf {
 static int wide_mp(int m) { return m <= 16 ? 16 : m <= 32 ? 32 : m <= 48 ? 48 : m <= 64 ? 64 : m <= 96 ? 96 : m <= 128 ? 128 : 0; }
 const WideKernel<float>* wide_kernel_f32(int m, int k, int nw) {
-  const int MP = wide_mp(m), KP = k <= 16 ? 16 : 0;
-  if (!MP || !KP) return nullptr;
-  return MP <= 48 ? wide_kernel_f32_lo(MP, KP, nw) : wide_kernel_f32_hi(MP, KP, nw);
+  const int MP = wide_mp(m);
+  if (!MP || k > 32) return nullptr;
+  if (k > 16) return nw == 4 ? wide_kernel_f32_k32(MP < 32 ? 32 : MP) : nullptr;
+  return MP <= 48 ? wide_kernel_f32_lo(MP, 16, nw) : wide_kernel_f32_hi(MP, 16, nw);
 }
 const WideKernel<double>* wide_kernel_f64(int m, int k, int nw) {
-  const int MP = wide_mp(m), KP = k <= 16 ? 16 : 0;
-  if (!MP || !KP) return nullptr;
-  return MP <= 48 ? wide_kernel_f64_lo(MP, KP, nw) : wide_kernel_f64_hi(MP, KP, nw);
+  const int MP = wide_mp(m);
+  if (!MP || k > 32) return nullptr;
+  if (k > 16) return nw == 4 ? wide_kernel_f64_k32(MP < 32 ? 32 : MP) : nullptr;
+  return MP <= 48 ? wide_kernel_f64_lo(MP, 16, nw) : wide_kernel_f64_hi(MP, 16, nw);
 }
 }  // namespace hipnmf
 
@@ -62,7 +64,10 @@ int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
   const bool want512 = !kl && (h->threads == 512 || (h->threads == 0 && ks_ >= 12 && m > 48));
   const WideKernel<real>* wk = want512 ? pick<real>(m, k, 8) : nullptr;
   if (!wk) wk = pick<real>(m, k, 4);
-  if (!wk) return fail(HIPNMF_ERR_UNSUPPORTED, "no kernel for n_features=%d (max 128) n_components=%d (max 16)", m, k);
+  if (!wk) return fail(HIPNMF_ERR_UNSUPPORTED, "no kernel for n_features=%d (max 128) n_components=%d (max 32)", m, k);
+  if (wk->smem > (size_t)h->lds_per_block)  // float64 with more than 16 components and more than 64 channels
+    return fail(HIPNMF_ERR_UNSUPPORTED, "%s needs %zu bytes of LDS (the CU has %d): n_features=%d n_components=%d in this precision is outside "
+                "the compiled kernel set", wk->name, wk->smem, h->lds_per_block, m, k);
   if (h->variant == 2 || h->variant == 3 || h->variant == 5 || h->variant == 6)
     return fail(HIPNMF_ERR_UNSUPPORTED, "tuning variant %d does not exist for wide shapes (n_features=%d, n_components=%d)",
                 h->variant, m, k);

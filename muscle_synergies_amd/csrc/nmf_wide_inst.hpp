@@ -12,6 +12,7 @@ constexpr bool wide_hreg() {
 // two waves per SIMD wherever the live state fits 256 registers (fp32 up to 128 channels, fp64 up to 48)
 template <typename real, int MP, int KP>
 constexpr int wide_wpe() {
+  if (KP == 32 && sizeof(real) == 8) return 1;  // (32 channels would spill 6 registers at two waves per SIMD)
   return (KP / 16) * MP * (int)(sizeof(real) / 4) <= 128 ? 2 : 1;
 }
 // register sets of loads in flight per wave: two while a set is at most 20 registers
@@ -42,6 +43,9 @@ const WideKernel<float>* wide_kernel_f32_lo(int MP, int KP, int NW);
 const WideKernel<float>* wide_kernel_f32_hi(int MP, int KP, int NW);
 const WideKernel<double>* wide_kernel_f64_lo(int MP, int KP, int NW);
 const WideKernel<double>* wide_kernel_f64_hi(int MP, int KP, int NW);
+// 17..32 components (KP = 32): 256-thread instances for 32, 48, 64, 96, 128 channels
+const WideKernel<float>* wide_kernel_f32_k32(int MP);
+const WideKernel<double>* wide_kernel_f64_k32(int MP);
 // the 512-thread instance exists only where the kernel is compiled for two waves per SIMD (256 registers)
 template <typename real, int MP>
 WideKernel<real> make_wide_kernel8(const char* name) {

@@ -97,7 +97,7 @@ class HipNMF:
 
     # -- validation --------------------------------------------------------------------------------
     MAX_FEATURES = 128   # widest instance compiled into libhip_nmf.so (nmf_wide.hpp; HIPNMF_ERR_UNSUPPORTED beyond)
-    MAX_COMPONENTS = 16
+    MAX_COMPONENTS = 32  # (float64 beyond 16 components: up to 64 channels; the library says UNSUPPORTED otherwise)
 
     @staticmethod
     def supports(solver="cd", beta_loss="frobenius", n_features=None, n_components=None, **_ignored) -> bool:

@@ -21,9 +21,9 @@ bad = 0
 for case in range(a.cases):
     dtype = np.float32 if rng.random() < 0.6 else np.float64
     wide = rng.random() < a.wide_frac
-    if wide:  # the matrix-pipe instances: up to 128 channels, up to 16 components (also narrow m with k > 8)
+    if wide:  # the matrix-pipe instances: up to 128 channels, up to 32 components (also narrow m with k > 8)
         m = int(rng.choice([9, 12, 16, 24, 32, 33, 40, 48, 49, 64, 65, 80, 96, 100, 127, 128]))
-        k = int(rng.integers(9 if m <= 32 else 1, min(m, 16) + 1))
+        k = int(rng.integers(9 if m <= 32 else 1, min(m, 32) + 1))
     else:
         m = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 12, 15, 16, 17, 24, 32]))
         k = int(rng.integers(1, min(m, 8) + 1))
@@ -71,6 +71,8 @@ for case in range(a.cases):
         if variant == 3 and "not applicable" in str(e):
             continue
         if wide and variant in (2, 3, 5, 6) and "does not exist for wide shapes" in str(e):
+            continue
+        if wide and dtype == np.float64 and k > 16 and m > 64 and "bytes of LDS" in str(e):
             continue
         if variant == 6 and ("fit_small_kernel" in str(e)):  # n_samples <= 256, Frobenius, m <= 16 (fp32) / 8 (fp64, k <= 6)
             assert not (max(Ts) <= 256 and loss == "frobenius" and m <= (16 if dtype == np.float32 else 8)

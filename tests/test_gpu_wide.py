@@ -214,3 +214,30 @@ def test_wide_kl_through_the_estimator():
         W = model.fit_transform(X, W=W0.copy(), H=H0.copy())
     Wr, Hr, _ = orc.fit_multiplicative_update_kl(X, W0.copy(), H0.copy(), 40, 0.0)
     np.testing.assert_allclose(W @ model.components_, Wr @ Hr, rtol=1e-8, atol=1e-11)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("m,k,T", [(24, 20, 200), (40, 32, 333), (64, 17, 1001), (128, 32, 150), (48, 24, 64)])
+def test_wide_17_to_32_components(dtype, m, k, T):
+    """17..32 components (two 16-component blocks on the matrix pipe), Frobenius and Kullback-Leibler, both layouts;
+    float64 beyond 64 channels does not fit LDS in this configuration and is refused (HIPNMF_ERR_UNSUPPORTED)."""
+    import muscle_synergies_amd as ms
+    from muscle_synergies_amd import _lib
+
+    X, W0, H0 = _case(T, m, k, dtype, seed=3 * m + k)
+    if dtype == np.float64 and m > 64:
+        with pytest.raises(_lib.HipNmfError) as e:
+            ms.fit_batched(X, W0, H0, max_iter=5, tol=0.0)
+        assert e.value.code == _lib.HIPNMF_ERR_UNSUPPORTED and "LDS" in str(e.value)
+        return
+    ref = orc.nmf_mu_fit(X, W0, H0, max_iter=25, tol=0.0)
+    tol = TOL if dtype == np.float32 else 1e-9
+    for layout in ("F", "C"):
+        Xl = np.asfortranarray(X) if layout == "F" else np.ascontiguousarray(X)
+        res = ms.fit_batched(Xl, W0, H0, max_iter=25, tol=0.0)
+        assert ",32,4>" in _last_kernel(), _last_kernel()
+        assert _rel(X, res.W[0], res.H[0], ref) <= tol, layout
+        assert abs(float(res.reconstruction_err[0]) - float(ref["reconstruction_err"])) / np.linalg.norm(X) <= TOL
+    Wr, Hr, _ = orc.fit_multiplicative_update_kl(X, W0.copy(), H0.copy(), 15, 0.0)
+    res = ms.fit_batched(X, W0, H0, max_iter=15, tol=0.0, beta_loss="kullback-leibler")
+    assert _rel(X, res.W[0], res.H[0], {"W": Wr, "H": Hr}) <= (3e-5 if dtype == np.float32 else 1e-9)

@@ -61,8 +61,8 @@ def test_mu_without_gpu_fails_loudly(V):
 
 def test_mu_outside_the_compiled_shapes_falls_back_to_sklearn():
     """The reference works for any shape (analysis.py:862-863); solver='mu' with more than 128 channels or more than
-    16 synergies is outside the compiled kernels (narrow lane mappings up to 32 x 8, matrix-pipe instances up to
-    128 x 16) and must reach scikit-learn, not an engine error."""
+    32 synergies is outside the compiled kernels (narrow lane mappings up to 32 x 8, matrix-pipe instances up to
+    128 x 32) and must reach scikit-learn, not an engine error."""
     pytest.importorskip("sklearn")
     rng = np.random.default_rng(5)
     wide = pd.DataFrame(rng.random((60, 129)), columns=[f"ch{j}" for j in range(129)])
@@ -78,13 +78,13 @@ def test_mu_outside_the_compiled_shapes_falls_back_to_sklearn():
         with warnings.catch_warnings():
             warnings.simplefilter("ignore", category=Warning)
             warnings.simplefilter("always", category=RuntimeWarning)
-            res = ms.find_synergies(narrow, 17, solver="mu", init="random", random_state=0, max_iter=20, tol=0)
+            res = ms.find_synergies(narrow, 33, solver="mu", init="random", random_state=0, max_iter=20, tol=0)
     assert type(res.model).__module__.startswith("sklearn")
     assert ms.HipNMF.supports(solver="mu", n_features=32, n_components=8)
     assert ms.HipNMF.supports(solver="mu", n_features=33, n_components=8)
-    assert ms.HipNMF.supports(solver="mu", n_features=128, n_components=16)
+    assert ms.HipNMF.supports(solver="mu", n_features=128, n_components=32)
     assert not ms.HipNMF.supports(solver="mu", n_features=129, n_components=8)
-    assert not ms.HipNMF.supports(solver="mu", n_features=64, n_components=17)
+    assert not ms.HipNMF.supports(solver="mu", n_features=64, n_components=33)
     assert not ms.HipNMF.supports(solver="cd", n_features=8, n_components=2)
 
 
