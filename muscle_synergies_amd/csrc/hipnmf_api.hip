@@ -181,6 +181,20 @@ SliceGeom slice_geometry(const hipnmf_handle* h, long long T, int B) {
   return g;
 }
 
+// Narrow shapes the matrix-pipe instances of nmf_wide.hpp handle better than the lane mappings.  Measured with
+// tools/quick_bench.py, 1024 x (m x 10 000), HIPNMF_FORCE_WIDE=0 / 1, M matrix-it/s (lane mapping -> matrix pipe):
+//   float64, 17..32 channels: the (G=4, CH=8) instances spill from k = 7 on (0.5-0.7 KB per lane): 32 ch k = 8 0.39 -> 1.40,
+//   32 ch k = 7 0.51 -> 1.40, 24 ch k = 7 0.54 -> 1.52, 17 ch k = 8 0.44 -> 1.54; k = 6: 1.24 -> 1.42 (32 ch), 1.39 -> 1.53 (24 ch);
+//   k = 5: 1.53 -> 1.49 (32 ch), 1.86 -> 1.55 (24 ch): the lane mapping stays;
+//   float32, 17..32 channels: k = 8 2.23 -> 2.59 (32 ch), 2.46 -> 2.81 (20 ch); k = 7 2.83 -> 2.61, k = 6 3.24 -> 2.63: stays.
+// Only where one workgroup per matrix is the path anyway (many matrices, or a ragged batch) and for the Frobenius loss.
+template <typename real>
+bool wide_preferred(int m, int k, const hipnmf_problem* p, const hipnmf_handle* h, bool ragged) {
+  if (m <= 16 || m > HIPNMF_NARROW_MAX_FEATURES || p->loss != HIPNMF_LOSS_FROBENIUS || h->variant != 0) return false;
+  if (!(ragged || p->batch >= h->num_cu / 2 || h->path_batch_hint >= h->num_cu / 2)) return false;
+  return sizeof(real) == 8 ? k >= 6 : k >= 8;
+}
+
 template <typename real>
 int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, real* W, real* H, real* err_out,
                      int32_t* n_iter_out, real* sse_col_out, real* xsq_col_out, const int64_t* ragged = nullptr) {
@@ -191,7 +205,11 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
   HIP_TRY(hipSetDevice(h->device));
   const int B = p->batch, m = p->n_features, k = p->n_components;
   const long long T = p->n_samples;
-  if (m > HIPNMF_NARROW_MAX_FEATURES || k > HIPNMF_NARROW_MAX_COMPONENTS)  // matrix-pipe instances of nmf_wide.hpp
+  static const int force_wide = [] {  // HIPNMF_FORCE_WIDE=1: every shape on the matrix-pipe instances, -1: only the shapes the lane mappings cannot hold (measurement / tests)
+    const char* e = getenv("HIPNMF_FORCE_WIDE");
+    return e ? atoi(e) : 0;
+  }();
+  if (m > HIPNMF_NARROW_MAX_FEATURES || k > HIPNMF_NARROW_MAX_COMPONENTS || force_wide == 1 || (force_wide != -1 && wide_preferred<real>(m, k, p, h, ragged != nullptr)))
     return hipnmf_fit_wide<real>(h, p, X, W, H, err_out, n_iter_out, sse_col_out, xsq_col_out, ragged);
   const KernelSet<real>* ks = select_kernels<real>(m, k, true);
   if (ks && ks->row_major && (T + 64) * (long long)ks->MP * (long long)sizeof(real) >= (1LL << 31))
