@@ -243,9 +243,14 @@ def test_bad_arguments_are_reported():
         p = make_problem(1, 10, 8, 2, **kwargs)
         assert lib.hipnmf_fit_batched_f32(h.ptr, ctypes.byref(p), d.data_ptr(), d.data_ptr(), d.data_ptr(), None, None,
                                           None, None) == code
-    p = make_problem(1, 10, 40, 2, x_layout=_lib.X_ROW_MAJOR, ldx=40, x_batch_stride=400)
-    assert lib.hipnmf_fit_batched_f32(h.ptr, ctypes.byref(p), d.data_ptr(), d.data_ptr(), d.data_ptr(), None, None, None,
-                                      None) == _lib.HIPNMF_ERR_UNSUPPORTED
+    big = torch.zeros(10 * 129, device="cuda")
+    for m, k in ((129, 2), (40, 33)):  # beyond the widest instances (128 channels, 32 components)
+        p = make_problem(1, 10, m, k, x_layout=_lib.X_ROW_MAJOR, ldx=m, x_batch_stride=10 * m)
+        assert lib.hipnmf_fit_batched_f32(h.ptr, ctypes.byref(p), big.data_ptr(), big.data_ptr(), big.data_ptr(), None, None, None,
+                                          None) == _lib.HIPNMF_ERR_UNSUPPORTED
+    p = make_problem(1, 10, 40, 2, x_layout=_lib.X_CHANNEL_MAJOR, ldx=12, x_batch_stride=480)  # time-shard entries: narrow shapes only
+    assert lib.hipnmf_shard_pass_f32(h.ptr, ctypes.byref(p), big.data_ptr(), big.data_ptr(), big.data_ptr(), big.data_ptr()) == \
+        _lib.HIPNMF_ERR_UNSUPPORTED
     p = make_problem(1, 10, 8, 2, **ok)
     p.struct_size = 8
     assert lib.hipnmf_fit_batched_f32(h.ptr, ctypes.byref(p), d.data_ptr(), d.data_ptr(), d.data_ptr(), None, None, None,

@@ -1,7 +1,8 @@
 #!/bin/bash
 # Bytes the headline kernel moves beyond L2 per launch: two PMC passes over bench.py itself (program directly after
 # `--`), then profiles/traffic.json keyed on the kernel instance and the workload.  Run on the GPU box:
-#   gpurun -- 'bash tools/measure_traffic.sh'            (optional: extra bench.py flags after the script name)
+#   gpurun -- 'HIPNMF_SOURCE_COMMIT=<git rev-parse --short HEAD> bash tools/measure_traffic.sh'   (optional: extra bench.py flags
+#   after the script name, e.g. --m 64 --k 8 --batch 1024 for the wide-shape kernel)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 out=$R/gpurun_out/traffic

@@ -20,6 +20,8 @@ ap.add_argument("--T", type=int, default=10000)
 ap.add_argument("--m", type=int, default=16)
 ap.add_argument("--k", type=int, default=5)
 ap.add_argument("--x-layout", default="row")
+ap.add_argument("--commit", default=os.environ.get("HIPNMF_SOURCE_COMMIT", "unknown"), help="source commit the library was built from")
+ap.add_argument("--round", default=os.environ.get("HIPNMF_ROUND", "r03"))
 a, _ = ap.parse_known_args()
 
 
@@ -45,6 +47,7 @@ entry = {
     "fetch_size_kib_avg": fetch_kib, "write_size_kib_avg": write_kib, "launches_averaged": [n1, n2],
     "l2_fabric_bytes_per_launch": 2.0 * fetch_kib * 1024 + write_kib * 1024,
     "l2_fabric_bytes_per_unit": (2.0 * fetch_kib * 1024 + write_kib * 1024) / (a.batch * a.iters),
+    "measured_round": a.round, "source_commit": a.commit,
     "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE -- python3 bench.py --steps 1 --warmup 1 "
               "(tools/measure_traffic.sh); FETCH_SIZE x 2 (gfx950, 16 B/lane streams); includes Infinity-Cache hits",
 }
