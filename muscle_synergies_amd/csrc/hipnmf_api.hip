@@ -340,12 +340,13 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
       const char* e = getenv("HIPNMF_ROWLANE");
       return e ? (atoi(e) != 0 ? 1 : 0) : -1;
     }();
-    const bool rl_ok = persistent && !coop && !use_small && !kl && m > 8 && m <= 16 && rowlane_kernel(k) != nullptr &&
+    const bool rl_ok = persistent && !coop && !use_small && m > 8 && m <= 16 && rowlane_kernel(k) != nullptr &&
                        (T + 64) * 16LL * (long long)sizeof(real) < (1LL << 31);
     // Default policy (tools/rank_sweep_bench.py, profiles/README.md): k >= 6, where round 1 had to fall back to the
     // channel-major (G=4, CH=4) mapping; at k <= 5 round 1's VALU instance is still ahead (9.54 vs 9.24 M it/s).
     // HIPNMF_ROWLANE=1 / 0 forces it on / off for every k; variant 5 / 4 of hipnmf_set_tuning does the same per handle.
-    const bool want = h->variant == 5 || (h->variant != 4 && (rl_env > 0 || (rl_env < 0 && k >= 6)));
+    // Kullback-Leibler: the matrix-pipe flavour for every k (its two W H reconstructions leave the VALU: DESIGN.md 3.5)
+    const bool want = h->variant == 5 || (h->variant != 4 && (rl_env > 0 || (rl_env < 0 && (k >= 6 || kl))));
     if (h->variant == 5 && !rl_ok)
       return fail(HIPNMF_ERR_UNSUPPORTED, "fit_rowlane_kernel needs fp32, 9..16 channels, the Frobenius loss and the "
                   "one-workgroup-per-matrix path (n_features=%d, loss=%d)", m, (int)p->loss);
@@ -579,8 +580,8 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
              sizeof(real) == 4 ? "float" : "double", ks->G, ks->CH, ks->K, kl ? 1 : 0);
     if constexpr (std::is_same<real, float>::value) {
       if (use_rowlane) {
-        kern = rowlane_kernel(k);
-        snprintf(h->last_kernel, sizeof(h->last_kernel), "%s", rowlane_kernel_name(k));
+        kern = kl ? rowlane_kernel_kl(k) : rowlane_kernel(k);
+        snprintf(h->last_kernel, sizeof(h->last_kernel), "%s%s", rowlane_kernel_name(k), kl ? "[kl]" : "");
       }
     }
     if (smem > 48 * 1024)

@@ -9,6 +9,13 @@ RowLaneFn rowlane_kernel(int K) {
                                    fit_rowlane_kernel<7>, fit_rowlane_kernel<8>};
   return (K >= 1 && K <= 8) ? tbl[K - 1] : nullptr;
 }
+RowLaneFn rowlane_kernel_kl(int K) {  // Kullback-Leibler flavour (both reconstructions on the matrix pipe)
+  static const RowLaneFn tbl[8] = {
+      fit_rowlane_kernel<1, 0, 0, 1, 1>, fit_rowlane_kernel<2, 0, 0, 1, 1>, fit_rowlane_kernel<3, 0, 0, 1, 1>,
+      fit_rowlane_kernel<4, 0, 0, 1, 1>, fit_rowlane_kernel<5, 0, 0, 1, 1>, fit_rowlane_kernel<6, 0, 0, 1, 1>,
+      fit_rowlane_kernel<7, 0, 0, 1, 1>, fit_rowlane_kernel<8, 0, 0, 1, 1>};
+  return (K >= 1 && K <= 8) ? tbl[K - 1] : nullptr;
+}
 RowLaneFn slice_pass_rowlane(int K) {
   static const RowLaneFn tbl[8] = {slice_pass_rowlane_kernel<1>, slice_pass_rowlane_kernel<2>, slice_pass_rowlane_kernel<3>,
                                    slice_pass_rowlane_kernel<4>, slice_pass_rowlane_kernel<5>, slice_pass_rowlane_kernel<6>,

@@ -215,6 +215,96 @@ __device__ __forceinline__ void rl_update(const float (&x)[16], float (&w)[K], c
   }
 }
 
+// ---- Kullback-Leibler loss on the same mapping (round 3; _nmf.py:556-591, 642-684) ----------------------------------
+// Both reconstructions W H of a tile run on the pipe as well: for channels 4 q .. 4 q + 3 of the lane's row,
+//   WH[row][4 q + i] = sum_c H[c][4 q + i] W[row][c]   =   K instructions  D += A_{block (c, q)} x B  with B = the lane's w[c]
+// and A broadcast from ONE register that holds H[c][4 q + i] at lane 4 (4 c + q) + i (a second register from c = 4 on);
+// the result is row-per-lane again (4 channels per accumulator).  Q = X / max(WH, eps) stays on the VALU (16 quotients),
+// Q H^T is the X H^T form with Q in X's place, W'^T Q' / colsum(W') accumulate on the VALU like W^T X.  What moved off the
+// VALU per tile: 2 x 16 K FMAs of the reconstructions and 16 K of Q H^T; measured in DESIGN.md section 3.5.
+struct RlKlOps {
+  float hr0, hr1;  // lane l: H[c][4 q + l % 4] with 4 c + q = l / 4 (hr0) or 16 + l / 4 (hr1); 0 where c >= k
+};
+template <int K>
+__device__ __forceinline__ void rl_load_klops(const Smem<float, 1, 16, K>& s, int lane, RlKlOps& o, float (&hsum)[K]) {
+  const int i = lane & 3, p = lane >> 2;
+  const int c0 = p >> 2, q0 = p & 3, c1 = 4 + (p >> 2);
+  o.hr0 = (c0 < K) ? s.H[c0 * 16 + 4 * q0 + i] : 0.f;
+  o.hr1 = (c1 < K) ? s.H[c1 * 16 + 4 * q0 + i] : 0.f;
+#pragma unroll
+  for (int c = 0; c < K; ++c) hsum[c] = uniform(s.HHt[c]);  // rowsum(H): compute_hsum / wave0_combine_and_update_h_kl
+}
+// W H of the lane's row: wh[q][i] = (W H)[row][4 q + i]
+template <int K>
+__device__ __forceinline__ void rl_reconstruct(const float (&w)[K], const RlKlOps& ko, f4 (&wh)[4]) {
+  static_for<4>([&](auto Q) {
+    constexpr int q = decltype(Q)::value;
+    f4 acc = {0.f, 0.f, 0.f, 0.f};
+    static_for<K>([&](auto Cc) {
+      constexpr int c = decltype(Cc)::value;
+      constexpr int p = 4 * c + q;
+      if constexpr (p < 16)
+        acc = mfma_4x4_bcast<p>(ko.hr0, w[c], acc);
+      else
+        acc = mfma_4x4_bcast<p - 16>(ko.hr1, w[c], acc);
+    });
+    wh[q] = acc;
+  });
+}
+template <int K>
+__device__ __forceinline__ void rl_update_kl(const float (&x)[16], float (&w)[K], const RlHops& ho, const RlKlOps& ko,
+                                             const float (&hsum)[K], float (&accA)[K][16], float (&accB)[K * (K + 1) / 2],
+                                             float l1w, float l2w, bool update_h) {
+  constexpr bool TWO = K > 4;
+  f4 wh[4];
+  rl_reconstruct<K>(w, ko, wh);
+  float q[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const float r = wh[j >> 2][j & 3];
+    q[j] = fast_div(x[j], r < eps_val<float>() ? eps_val<float>() : r);
+  }
+  // numerator Q H^T: the X H^T form of rl_update with Q in the place of X
+  f4 n0a = {0.f, 0.f, 0.f, 0.f}, n0b = n0a, n1a = n0a, n1b = n0a;
+  static_for<16>([&](auto J) {
+    constexpr int j = decltype(J)::value;
+    if constexpr ((j & 1) == 0) {
+      n0a = mfma_4x4_bcast<j>(ho.hq0, q[j], n0a);
+      if constexpr (TWO) n1a = mfma_4x4_bcast<j>(ho.hq1, q[j], n1a);
+    } else {
+      n0b = mfma_4x4_bcast<j>(ho.hq0, q[j], n0b);
+      if constexpr (TWO) n1b = mfma_4x4_bcast<j>(ho.hq1, q[j], n1b);
+    }
+  });
+  const f4 n0 = n0a + n0b, n1 = n1a + n1b;
+  float num[K], den[K], quo[K];
+#pragma unroll
+  for (int c = 0; c < K; ++c) {
+    float d = hsum[c];
+    if (l1w > 0.f) d = d + l1w;
+    if (l2w > 0.f) d = d + l2w * w[c];
+    den[c] = (d == 0.f) ? eps_val<float>() : d;
+    num[c] = c < 4 ? n0[c & 3] : n1[c & 3];
+  }
+  quotients<K>(num, den, quo);
+#pragma unroll
+  for (int c = 0; c < K; ++c) w[c] = w[c] * quo[c];
+  if (update_h) {
+    rl_reconstruct<K>(w, ko, wh);  // with the updated row (_nmf.py:642-684)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const float r = wh[j >> 2][j & 3];
+      q[j] = fast_div(x[j], r < eps_val<float>() ? eps_val<float>() : r);
+    }
+#pragma unroll
+    for (int c = 0; c < K; ++c) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) accA[c][j] = fma_(w[c], q[j], accA[c][j]);
+      accB[c] += w[c];
+    }
+  }
+}
+
 // W of tile i of this wave: LDS cache, resident registers, or global memory (wave-uniform choice)
 template <int K, int NWR, bool PREFETCHED = false>
 __device__ __forceinline__ void rl_get_w(const RlCtx<K>& cx, float (&w)[K], const float (&wres)[NWR > 0 ? NWR : 1][K],
@@ -261,9 +351,9 @@ __device__ __forceinline__ void rl_put_w(const RlCtx<K>& cx, const float (&w)[K]
 }
 
 // residual of the lane's row: sse[j] += (x - w.h)^2, xsq[j] += x^2   (H in VGPRs: only inside residual passes)
-template <int K>
+template <int K, int LOSS = 0>
 __device__ __forceinline__ void rl_resid(const float (&x)[16], const float (&w)[K], const float (&h)[K][16],
-                                         float (&sse)[16], float (&xsq)[16]) {
+                                         float (&sse)[16], float (&xsq)[16], float& kl) {
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
     float rec = w[0] * h[0][j];
@@ -272,13 +362,19 @@ __device__ __forceinline__ void rl_resid(const float (&x)[16], const float (&w)[
     const float d = x[j] - rec;
     sse[j] = fma_(d, d, sse[j]);
     xsq[j] = fma_(x[j], x[j], xsq[j]);
+    if constexpr (LOSS == 1) {  // as resid_tile (nmf_kernels.hpp): x log(x / wh) - x + wh, branch-free
+      const float whc = rec < eps_val<float>() ? eps_val<float>() : rec;
+      const float xs = x[j] > eps_val<float>() ? x[j] : eps_val<float>();
+      const float lg = fma_(x[j], log_(xs / whc), rec - x[j]);
+      kl += (x[j] > eps_val<float>()) ? lg : rec;
+    }
   }
 }
 
 #ifndef HIPNMF_RL_THREADS
 #define HIPNMF_RL_THREADS 512  // 256: one wave per SIMD with up to 512 VGPRs (experiment: more resident tiles)
 #endif
-template <int K, int NXR = rl_nxr<K>(), int NWR = rl_nwr<K>(), int PF = (HIPNMF_RL_PF)>
+template <int K, int NXR = rl_nxr<K>(), int NWR = rl_nwr<K>(), int PF = (HIPNMF_RL_PF), int LOSS = 0>
 __global__ void __launch_bounds__(HIPNMF_RL_THREADS) fit_rowlane_kernel(SolveArgs<float> a) {
   using C = Cfg<float, 1, 16, K>;
   constexpr int MP = 16, NB = C::NB;
@@ -361,16 +457,39 @@ __global__ void __launch_bounds__(HIPNMF_RL_THREADS) fit_rowlane_kernel(SolveArg
 
   load_h_to_lds(s, Hb, m);
   __syncthreads();
-  compute_hht(s);
+  if constexpr (LOSS == 1)
+    compute_hsum(s);
+  else
+    compute_hht(s);
   __syncthreads();
   RlHops ho;
-  float hht[K][K];
-  rl_load_hops<K>(s, lane, ho, hht);
+  RlKlOps ko;
+  float hht[K][K], hsum[K];
+  // operands of the tile arithmetic, rebuilt from LDS after every H update (KL: s.HHt holds rowsum(H), not H H^T)
+  auto load_ops = [&]() __attribute__((always_inline)) {
+    if constexpr (LOSS == 1) {
+      const int lo = lane & 3, hi = lane >> 2;
+      ho.hq0 = (lo < K) ? s.H[lo * 16 + hi] : 0.f;
+      ho.hq1 = (4 + lo < K) ? s.H[(4 + lo) * 16 + hi] : 0.f;
+      ho.hhq0 = ho.hhq1 = 0.f;
+      rl_load_klops<K>(s, lane, ko, hsum);
+    } else {
+      rl_load_hops<K>(s, lane, ho, hht);
+    }
+  };
+  load_ops();
+  auto update = [&](const float (&x)[16], float (&w)[K], float (&accA)[K][16], float (&accB)[NB], bool upd_)
+                    __attribute__((always_inline)) {
+    if constexpr (LOSS == 1)
+      rl_update_kl<K>(x, w, ho, ko, hsum, accA, accB, a.l1w, a.l2w, upd_);
+    else
+      rl_update<K>(x, w, ho, hht, accA, accB, a.l1w, a.l2w, upd_);
+  };
 
   // ||X - W H||_F^2 per column (+ sum X^2) of the whole matrix -> s.part[0 .. 2 MP); barriers inside
   // (always_inline: a real call would force every captured register array into scratch memory)
   auto block_resid = [&]() __attribute__((always_inline)) {
-    float h[K][16], sse[16], xsq[16];
+    float h[K][16], sse[16], xsq[16], kl = 0.f;
 #pragma unroll
     for (int c = 0; c < K; ++c)
 #pragma unroll
@@ -383,7 +502,7 @@ __global__ void __launch_bounds__(HIPNMF_RL_THREADS) fit_rowlane_kernel(SolveArg
         if (q < ntw) {
           float w[K];
           rl_get_w<K, NWR>(cx, w, wres, q, tile_base(q));
-          rl_resid<K>(xres[q], w, h, sse, xsq);
+          rl_resid<K, LOSS>(xres[q], w, h, sse, xsq, kl);
         }
       }
     });
@@ -391,7 +510,7 @@ __global__ void __launch_bounds__(HIPNMF_RL_THREADS) fit_rowlane_kernel(SolveArg
       float x[16], w[K];
       rl_load_x<K>(cx, x, tile_base(i), true);
       rl_get_w<K, NWR>(cx, w, wres, i, tile_base(i));
-      rl_resid<K>(x, w, h, sse, xsq);
+      rl_resid<K, LOSS>(x, w, h, sse, xsq, kl);
     }
     float v[32];
 #pragma unroll
@@ -400,17 +519,26 @@ __global__ void __launch_bounds__(HIPNMF_RL_THREADS) fit_rowlane_kernel(SolveArg
       v[16 + j] = xsq[j];
     }
     wave_reduce_scatter<1, 32, float>(v, lane);  // lane l < 32: sum over the wave of value l
+    if constexpr (LOSS == 1) {
+#pragma unroll
+      for (int off = 1; off < WAVE; off <<= 1) kl += __shfl_xor(kl, off, WAVE);
+    }
     __syncthreads();                             // s.part may still be read by a previous phase
-    if (lane < 32) s.part[wave * 32 + lane] = v[0];
+    if (lane < 32) s.part[wave * 33 + lane] = v[0];
+    if (LOSS == 1 && lane == 0) s.part[wave * 33 + 32] = kl;
     __syncthreads();
-    if (threadIdx.x < 32) {
+    if (threadIdx.x < 33) {
       float acc = s.part[threadIdx.x];
-      for (int w2 = 1; w2 < nw; ++w2) acc += s.part[w2 * 32 + threadIdx.x];
+      for (int w2 = 1; w2 < nw; ++w2) acc += s.part[w2 * 33 + threadIdx.x];
       s.part[threadIdx.x] = acc;
     }
     __syncthreads();
   };
   auto error_from_part = [&]() __attribute__((always_inline)) -> float {
+    if constexpr (LOSS == 1) {  // sqrt(2 KL(X || WH)) (_nmf.py:185-189)
+      const float d = s.part[2 * MP];
+      return sqrt_(2.f * (d > 0.f ? d : 0.f));
+    }
     float tot = 0.f;
     for (int j = 0; j < MP; ++j) tot += s.part[j];
     return sqrt_(tot);
@@ -449,7 +577,7 @@ __global__ void __launch_bounds__(HIPNMF_RL_THREADS) fit_rowlane_kernel(SolveArg
           float w[K];
           const int wb = tile_base(q);
           rl_get_w<K, NWR>(cx, w, wres, q, wb);
-          rl_update<K>(xres[q], w, ho, hht, accA, accB, a.l1w, a.l2w, upd);
+          update(xres[q], w, accA, accB, upd);
           rl_put_w<K, NWR>(cx, w, wres, q, wb);
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -463,13 +591,13 @@ __global__ void __launch_bounds__(HIPNMF_RL_THREADS) fit_rowlane_kernel(SolveArg
         rl_prefetch<K, NWR>(cx, xb, wgb, i + 1, tile_base(i + 1), true);
         int wb = tile_base(i);
         rl_get_w<K, NWR, true>(cx, w, wres, i, wb, wga);
-        rl_update<K>(xa, w, ho, hht, accA, accB, a.l1w, a.l2w, upd);
+        update(xa, w, accA, accB, upd);
         rl_put_w<K, NWR>(cx, w, wres, i, wb);
         __builtin_amdgcn_sched_barrier(0);
         rl_prefetch<K, NWR>(cx, xa, wga, i + 2, tile_base(i + 2), i + 2 < ntw);
         wb = tile_base(i + 1);
         rl_get_w<K, NWR, true>(cx, w, wres, i + 1, wb, wgb);
-        rl_update<K>(xb, w, ho, hht, accA, accB, a.l1w, a.l2w, upd);
+        update(xb, w, accA, accB, upd);
         rl_put_w<K, NWR>(cx, w, wres, i + 1, wb);
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -477,7 +605,7 @@ __global__ void __launch_bounds__(HIPNMF_RL_THREADS) fit_rowlane_kernel(SolveArg
         float w[K];
         const int wb = tile_base(i);
         rl_get_w<K, NWR, true>(cx, w, wres, i, wb, wga);
-        rl_update<K>(xa, w, ho, hht, accA, accB, a.l1w, a.l2w, upd);
+        update(xa, w, accA, accB, upd);
         rl_put_w<K, NWR>(cx, w, wres, i, wb);
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -486,7 +614,7 @@ __global__ void __launch_bounds__(HIPNMF_RL_THREADS) fit_rowlane_kernel(SolveArg
         float w[K];
         const int wb = tile_base(i);
         rl_get_w<K, NWR, true>(cx, w, wres, i, wb, wga);
-        rl_update<K>(xa, w, ho, hht, accA, accB, a.l1w, a.l2w, upd);
+        update(xa, w, accA, accB, upd);
         rl_put_w<K, NWR>(cx, w, wres, i, wb);
         rl_prefetch<K, NWR>(cx, xa, wga, i + 1, tile_base(i + 1), i + 1 < ntw);
         __builtin_amdgcn_sched_barrier(0);
@@ -500,9 +628,14 @@ __global__ void __launch_bounds__(HIPNMF_RL_THREADS) fit_rowlane_kernel(SolveArg
       // a barrier), so the records can be written right away: two workgroup barriers per iteration
       wave_reduce_acc<float, 1, 16, K>(s.part + wave * C::NACC, accA, accB);
       __syncthreads();
-      if (wave == 0) wave0_combine_and_update_h(s, nw, m, a.l1h, a.l2h);
+      if (wave == 0) {
+        if constexpr (LOSS == 1)
+          wave0_combine_and_update_h_kl(s, nw, m, a.l1h, a.l2h);
+        else
+          wave0_combine_and_update_h(s, nw, m, a.l1h, a.l2h);
+      }
       __syncthreads();
-      rl_load_hops<K>(s, lane, ho, hht);
+      load_ops();
     }
     if (a.tol > 0.f && (it % a.check_every) == 0) {
       const float err = residual();
