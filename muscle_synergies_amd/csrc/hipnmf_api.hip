@@ -345,10 +345,13 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
     // Default policy (tools/rank_sweep_bench.py, profiles/README.md): k >= 6, where round 1 had to fall back to the
     // channel-major (G=4, CH=4) mapping; at k <= 5 round 1's VALU instance is still ahead (9.54 vs 9.24 M it/s).
     // HIPNMF_ROWLANE=1 / 0 forces it on / off for every k; variant 5 / 4 of hipnmf_set_tuning does the same per handle.
-    // Kullback-Leibler: the matrix-pipe flavour for every k (its two W H reconstructions leave the VALU: DESIGN.md 3.5)
-    const bool want = h->variant == 5 || (h->variant != 4 && (rl_env > 0 || (rl_env < 0 && (k >= 6 || kl))));
+    // Kullback-Leibler: the same policy.  Measured (tools/quick_bench.py --loss kullback-leibler, B = 2048, M matrix-it/s,
+    // VALU instance -> matrix-pipe flavour with both W H reconstructions on the pipe): k = 3 6.59 -> 6.29, k = 5 5.24 -> 4.95,
+    // k = 8 3.05 -> 3.87: the f32 pipe has the VALU's FLOP rate and the two do not overlap, so moving 3 x 16 k FMAs per row
+    // across buys nothing until the VALU form runs out of registers.
+    const bool want = h->variant == 5 || (h->variant != 4 && (rl_env > 0 || (rl_env < 0 && k >= 6)));
     if (h->variant == 5 && !rl_ok)
-      return fail(HIPNMF_ERR_UNSUPPORTED, "fit_rowlane_kernel needs fp32, 9..16 channels, the Frobenius loss and the "
+      return fail(HIPNMF_ERR_UNSUPPORTED, "fit_rowlane_kernel needs fp32, 9..16 channels and the "
                   "one-workgroup-per-matrix path (n_features=%d, loss=%d)", m, (int)p->loss);
     if (want && rl_ok) {
       ks = kernels_f32_g1c16(k);

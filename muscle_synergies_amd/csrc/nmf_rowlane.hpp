@@ -221,7 +221,9 @@ __device__ __forceinline__ void rl_update(const float (&x)[16], float (&w)[K], c
 // and A broadcast from ONE register that holds H[c][4 q + i] at lane 4 (4 c + q) + i (a second register from c = 4 on);
 // the result is row-per-lane again (4 channels per accumulator).  Q = X / max(WH, eps) stays on the VALU (16 quotients),
 // Q H^T is the X H^T form with Q in X's place, W'^T Q' / colsum(W') accumulate on the VALU like W^T X.  What moved off the
-// VALU per tile: 2 x 16 K FMAs of the reconstructions and 16 K of Q H^T; measured in DESIGN.md section 3.5.
+// VALU per tile: 2 x 16 K FMAs of the reconstructions and 16 K of Q H^T.  Measured (B = 2048 x (16 x 10 000), M matrix-it/s,
+// VALU instance -> this one): k = 3 6.59 -> 6.29, k = 5 5.24 -> 4.95, k = 8 3.05 -> 3.87 -- like the Frobenius flavour it pays
+// from k = 6 on, where the VALU form no longer fits two waves per SIMD; the library picks it there.
 struct RlKlOps {
   float hr0, hr1;  // lane l: H[c][4 q + l % 4] with 4 c + q = l / 4 (hr0) or 16 + l / 4 (hr1); 0 where c >= k
 };

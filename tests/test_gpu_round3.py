@@ -146,3 +146,33 @@ def test_checkpointed_filter_kernel_is_bit_exact_too():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz_sosfilt_gpu.py"), "--cases", "150", "--seed", "21"],
                        capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0 and "0 problems" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 5, 6, 7, 8])
+def test_kullback_leibler_on_the_matrix_pipe(k):
+    """fit_rowlane_kernel's Kullback-Leibler flavour (both W H reconstructions and Q H^T on v_mfma_f32_4x4x1; the library's
+    choice from k = 6 on, forced here with variant 5 for every k) vs the oracle: ragged tail, padded channels, stop rule."""
+    import muscle_synergies_amd as ms
+    from muscle_synergies_amd import _lib
+
+    h = _lib.Handle(0)
+    h.set_tuning(0, 0, 5)
+    for m, T in ((16, 1001), (11, 333), (9, 12000)):
+        X = emg_matrix(500 + k, T=T, m=m, k_true=min(5, m), dtype=np.float32)
+        W0, H0 = random_init(X, k, seed=k)
+        res = ms.fit_batched(X, W0, H0, max_iter=30, tol=0.0, beta_loss="kullback-leibler", handle=h)
+        assert h.last_kernel().startswith("fit_rowlane_kernel<") and h.last_kernel().endswith("[kl]"), h.last_kernel()
+        Wr, Hr, _ = orc.fit_multiplicative_update_kl(X, W0.copy(), H0.copy(), 30, 0.0)
+        wh = res.W[0].astype(np.float64) @ res.H[0].astype(np.float64)
+        assert np.linalg.norm(wh - Wr.astype(np.float64) @ Hr.astype(np.float64)) / np.linalg.norm(X) <= 3e-5, (m, T)
+        err = orc.kl_divergence(X, Wr, Hr, square_root=True)
+        assert abs(float(res.reconstruction_err[0]) - err) <= 5e-3 * err  # (the float32 oracle sums three large cancelling terms)
+    X = emg_matrix(77, T=2000, m=16, dtype=np.float32)
+    W0, H0 = random_init(X, k, seed=3)
+    res = ms.fit_batched(X, W0, H0, max_iter=200, tol=1e-3, beta_loss="kullback-leibler", l1_reg_W=0.01, l2_reg_H=0.02, handle=h)
+    _, _, n_it = orc.fit_multiplicative_update_kl(X, W0.copy(), H0.copy(), 200, 1e-3, 0.01, 0.0, 0.0, 0.02)
+    assert abs(int(res.n_iter[0]) - n_it) <= 10
+    h.set_tuning(0, 0, 0)
+    if k >= 6:  # the library's own choice
+        ms.fit_batched(np.stack([X] * 3), np.stack([W0] * 3), np.stack([H0] * 3), max_iter=3, tol=0.0, beta_loss="kullback-leibler", handle=h)
+        assert h.last_kernel().endswith("[kl]") and "rowlane" in h.last_kernel()

@@ -189,7 +189,7 @@ def test_wide_kullback_leibler(dtype, m, k, T):
         assert _last_kernel().endswith("[kl]") and _last_kernel().startswith("fit_wide_kernel"), _last_kernel()
         assert _rel(X, res.W[0], res.H[0], {"W": Wr, "H": Hr}) <= tol, layout
         err = orc.kl_divergence(X, Wr, Hr, square_root=True)
-        assert abs(float(res.reconstruction_err[0]) - err) <= (2e-3 if dtype == np.float32 else 1e-9) * max(err, 1e-30)
+        assert abs(float(res.reconstruction_err[0]) - err) <= (5e-3 if dtype == np.float32 else 1e-9) * max(err, 1e-30)
     Ws, Hs, n_it = orc.fit_multiplicative_update_kl(X, W0.copy(), H0.copy(), 150, 1e-3, 0.01, 0.02, 0.03, 0.01)
     res = ms.fit_batched(X, W0, H0, max_iter=150, tol=1e-3, beta_loss="kullback-leibler", l1_reg_W=0.01, l1_reg_H=0.02,
                          l2_reg_W=0.03, l2_reg_H=0.01)
