@@ -306,7 +306,7 @@ def lds_rows_of_w(k, threads=512):
     nacc = 16 * k + k * (k + 1) // 2
     base = 4 * (2 * k * 16 + 2 * k * k + nw * max(nacc, 33) + 8)
     base = (base + 15) // 16 * 16
-    return (160 * 1024 - base) // (4 * k) // threads * threads
+    return (160 * 1024 - base) // (4 * k) // 64 * 64  # whole 64-row wave tiles (round 2: whole workgroup-steps)
 
 
 # ------------------------------------------------------------------------------------------------ config 3 / 2

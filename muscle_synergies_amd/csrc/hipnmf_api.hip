@@ -572,9 +572,10 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
     const size_t lds_cap = h->lds_budget > 0 ? (size_t)h->lds_budget : (size_t)h->lds_per_block;
     long long lds_rows = 0;
     if (lds_cap > base + 1024 && h->use_lds_w) {
-      lds_rows = (long long)((lds_cap - base) / (sizeof(real) * (size_t)k)) / threads * threads;
-      lds_rows = std::min<long long>(lds_rows, round_up(T, threads));
-      if (lds_rows > t_pad) lds_rows = t_pad / threads * threads;
+      // whole 64-row wave tiles (round 2 cached whole workgroup-steps of `threads` rows: 7680 instead of 8000 of the
+      // headline's 10 000 rows; a tile is cached or not per wave, so the granule is the wave's)
+      lds_rows = (long long)((lds_cap - base) / (sizeof(real) * (size_t)k)) / 64 * 64;
+      lds_rows = std::min<long long>(lds_rows, t_pad);
     }
     a.lds_rows = (int)lds_rows;
     const size_t smem = base + sizeof(real) * (size_t)k * (size_t)lds_rows;

@@ -1231,8 +1231,10 @@ __global__ void __launch_bounds__((max_threads<real, G, CH, K>())) HIPNMF_OCC fi
   ma.lds_used = lds_rows;
   for (int t0 = 0; t0 < lds_rows; t0 += blockDim.x) {  // row t0 + tid is owned by this thread in every pass
     const int t = t0 + threadIdx.x;
+    if (t < lds_rows) {  // (lds_rows is a multiple of 64, not necessarily of the workgroup size)
 #pragma unroll
-    for (int c = 0; c < K; ++c) lds_w[c * lds_stride + t] = (t < T) ? Wb[(long long)c * ldw + t] : (real)0;
+      for (int c = 0; c < K; ++c) lds_w[c * lds_stride + t] = (t < T) ? Wb[(long long)c * ldw + t] : (real)0;
+    }
   }
 
   load_h_to_lds(s, Hb, m);
@@ -1367,7 +1369,7 @@ __global__ void __launch_bounds__((max_threads<real, G, CH, K>())) HIPNMF_OCC fi
   }
   for (int t0 = 0; t0 < lds_rows; t0 += blockDim.x) {  // write the cached rows of W back
     const int t = t0 + threadIdx.x;
-    if (t < T) {
+    if (t < T && t < lds_rows) {
 #pragma unroll
       for (int c = 0; c < K; ++c) Wb[(long long)c * ldw + t] = lds_w[c * lds_stride + t];
     }

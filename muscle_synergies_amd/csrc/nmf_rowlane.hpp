@@ -424,7 +424,8 @@ __global__ void __launch_bounds__(HIPNMF_RL_THREADS) fit_rowlane_kernel(SolveArg
   cx.stride = stride;
   cx.lds_w = lds_w;
   cx.lds_stride = lds_stride;
-  cx.ilds = lds_rows / stride;
+  // tiles i < ilds of THIS wave (rows (i nw + wave) 64 ...) lie inside the cached rows [0, lds_rows), a multiple of 64
+  cx.ilds = wave < lds_rows / WAVE ? (lds_rows / WAVE - wave + nw - 1) / nw : 0;
   // row base of tile i of this wave.  The index is made opaque so that the bases (and everything derived from them)
   // of the statically unrolled resident tiles are recomputed with two SALU instructions where they are used
   // instead of being hoisted out of the iteration loop into dozens of SGPRs (which then spill).
@@ -435,8 +436,10 @@ __global__ void __launch_bounds__(HIPNMF_RL_THREADS) fit_rowlane_kernel(SolveArg
 
   for (int t0 = 0; t0 < lds_rows; t0 += blockDim.x) {  // row t0 + tid is owned by this thread in every pass
     const int t = t0 + threadIdx.x;
+    if (t < lds_rows) {
 #pragma unroll
-    for (int c = 0; c < K; ++c) lds_w[c * lds_stride + t] = (t < T) ? Wb[(long long)c * ldw + t] : 0.f;
+      for (int c = 0; c < K; ++c) lds_w[c * lds_stride + t] = (t < T) ? Wb[(long long)c * ldw + t] : 0.f;
+    }
   }
   // register-resident state: the first NXR tiles of X, and the NWR tiles of W that follow the LDS cache
   float xres[NXA][16], wres[NWA][K];
@@ -664,7 +667,7 @@ __global__ void __launch_bounds__(HIPNMF_RL_THREADS) fit_rowlane_kernel(SolveArg
   }
   for (int t0 = 0; t0 < lds_rows; t0 += blockDim.x) {  // write the cached rows of W back
     const int t = t0 + threadIdx.x;
-    if (t < T) {
+    if (t < T && t < lds_rows) {
 #pragma unroll
       for (int c = 0; c < K; ++c) Wb[(long long)c * ldw + t] = lds_w[c * lds_stride + t];
     }

@@ -16,9 +16,9 @@ def test_unit_of_work_model_matches_the_survey():
     assert 4 * 10_000 * (16 + 2 * 5) == 1_040_000                       # algorithmic bytes per matrix-iteration
     assert bench.flops_per_unit(10_000, 16, 5) == 4 * 10_000 * 5 * 21 + 2 * 10_000 * 5 + 4 * 25 * 16 + 2 * 5 * 16
     assert abs(bench.flops_per_unit(10_000, 16, 5) - 4.30e6) < 0.01e6
-    assert bench.lds_rows_of_w(5) == 7680                                # rows of W resident in LDS at k = 5
-    assert bench.lds_rows_of_w(2) >= 10_240 and bench.lds_rows_of_w(4) == 9728
-    assert 4 * (10_000 * 16 + 2 * 5 * (10_000 - bench.lds_rows_of_w(5))) == 732_800   # design bytes per unit
+    assert bench.lds_rows_of_w(5) == 7936                                # rows of W resident in LDS at k = 5 (64-row granule)
+    assert bench.lds_rows_of_w(2) >= 10_240 and bench.lds_rows_of_w(4) >= 10_000
+    assert 4 * (10_000 * 16 + 2 * 5 * (10_000 - bench.lds_rows_of_w(5))) == 722_560   # design bytes per unit
 
 
 def test_roofline_object_is_against_the_binding_roofs():
@@ -29,7 +29,7 @@ def test_roofline_object_is_against_the_binding_roofs():
     mem = r["memory"]
     assert mem["algorithmic_bytes_per_unit"] == 1_040_000 and mem["l2_fabric_bytes_per_launch"] == 1.5185e12
     assert 0.9 < mem["frac_of_stream_peak"] < 1.05
-    r2 = bench.compute_roofline("k", 200.0, 4096 * 500, 10_000, 16, 5, traffic=None, moved_bytes_per_unit=732_800)
+    r2 = bench.compute_roofline("k", 200.0, 4096 * 500, 10_000, 16, 5, traffic=None, moved_bytes_per_unit=722_560)
     assert r2["traffic"] is None and "design_gbs" in r2["memory"]
 
 
