@@ -229,7 +229,7 @@ int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
   }
   HIP_TRY(hipEventRecord(h->ev0, st));
   h->last_path = 1;
-  snprintf(h->last_kernel, sizeof(h->last_kernel), "%s%s", wk->name, kl ? "[kl]" : "");
+  snprintf(h->last_kernel, sizeof(h->last_kernel), "%s", kl ? wk->name_kl : wk->name);
   const auto kern = kl ? wk->fn_kl : wk->fn;
   if (!kern) return fail(HIPNMF_ERR_UNSUPPORTED, "no Kullback-Leibler instance of %s", wk->name);
   if (smem > 48 * 1024)

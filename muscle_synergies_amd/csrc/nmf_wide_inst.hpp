@@ -1,6 +1,8 @@
 // nmf_wide_inst.hpp -- instantiation helper of the wide-shape kernels (one translation unit per dtype and half of the
 // channel paddings, so that the build compiles them in parallel)
 #pragma once
+#include <cstdio>
+
 #include "nmf_wide_decl.hpp"
 
 namespace hipnmf {
@@ -24,21 +26,38 @@ constexpr int wide_nset() {
   if (HIPNMF_WIDE_NSET) return HIPNMF_WIDE_NSET;
   return (MP / 4 + 4 * (KP / 16)) * (int)(sizeof(real) / 4) <= 20 ? 2 : 1;
 }
+// name as rocprofv3 --kernel-trace prints the instance (minus namespace and argument list): what hipnmf_last_kernel reports
+// and what profiles/traffic.json is keyed on
+template <typename real, int MP, int KP, int NW, bool HREG, int WPE, int NSET, int LOSS>
+const char* wide_kernel_name() {
+  static char buf[96];
+  static const bool once = [] {
+    snprintf(buf, sizeof(buf), "fit_wide_kernel<%s,%d,%d,%d,%s,%d,%d,%d>", sizeof(real) == 4 ? "float" : "double", MP, KP, NW,
+             HREG ? "true" : "false", WPE, NSET, LOSS);
+    return true;
+  }();
+  (void)once;
+  return buf;
+}
 template <typename real, int MP, int KP, int NW>
-WideKernel<real> make_wide_kernel(const char* name) {
+WideKernel<real> make_wide_kernel(const char* = nullptr) {
   WideKernel<real> w;
-  w.fn = fit_wide_kernel<real, MP, KP, NW, wide_hreg<real, MP, KP>(), wide_wpe<real, MP, KP>(), wide_nset<real, MP, KP>()>;
+  constexpr bool HREG = wide_hreg<real, MP, KP>();
+  constexpr int WPE = wide_wpe<real, MP, KP>(), NSET = wide_nset<real, MP, KP>();
+  w.fn = fit_wide_kernel<real, MP, KP, NW, HREG, WPE, NSET>;
   w.fn_kl = nullptr;
-  if constexpr (NW == 4)  // (H is re-read from LDS in the KL flavour: no register copy, one set of loads in flight)
-    w.fn_kl = fit_wide_kernel<real, MP, KP, NW, false, wide_wpe<real, MP, KP>(), 1, 1>;
+  w.name_kl = "";
+  if constexpr (NW == 4) {  // (H is re-read from LDS in the KL flavour: no register copy, one set of loads in flight)
+    w.fn_kl = fit_wide_kernel<real, MP, KP, NW, false, WPE, 1, 1>;
+    w.name_kl = wide_kernel_name<real, MP, KP, NW, false, WPE, 1, 1>();
+  }
   w.smem = WideCfg<real, MP, KP>::smem_bytes(NW);
   w.MP = MP;
   w.KP = KP;
   w.NW = NW;
-  w.name = name;
+  w.name = wide_kernel_name<real, MP, KP, NW, HREG, WPE, NSET, 0>();
   return w;
 }
-// NW = 4 (256 threads) or 8 (512 threads, where the instance is compiled for two waves per SIMD): nullptr otherwise
 const WideKernel<float>* wide_kernel_f32_lo(int MP, int KP, int NW);
 const WideKernel<float>* wide_kernel_f32_hi(int MP, int KP, int NW);
 const WideKernel<double>* wide_kernel_f64_lo(int MP, int KP, int NW);
