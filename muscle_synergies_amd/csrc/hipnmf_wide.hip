@@ -68,7 +68,7 @@ int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
   if (wk->smem > (size_t)h->lds_per_block)  // float64 with more than 16 components and more than 64 channels
     return fail(HIPNMF_ERR_UNSUPPORTED, "%s needs %zu bytes of LDS (the CU has %d): n_features=%d n_components=%d in this precision is outside "
                 "the compiled kernel set", wk->name, wk->smem, h->lds_per_block, m, k);
-  if (h->variant == 2 || h->variant == 3 || h->variant == 5 || h->variant == 6)
+  if (h->variant == 3 || h->variant == 5 || h->variant == 6)
     return fail(HIPNMF_ERR_UNSUPPORTED, "tuning variant %d does not exist for wide shapes (n_features=%d, n_components=%d)",
                 h->variant, m, k);
   constexpr int VEC = 16 / (int)sizeof(real);
@@ -123,6 +123,29 @@ int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
     }
   }
 
+  // ---- path: one workgroup per matrix, or row slices over the whole chip (few long matrices: the reference's own
+  // single-DataFrame call).  Estimates from tools/quick_bench.py: a 256-thread workgroup needs ~0.7 us per round of four
+  // 16-row subtiles at 64 channels; a sliced iteration is two graph-replayed launches (~10 us) plus one slice.
+  const WideKernel<real>* wk4 = pick<real>(m, k, 4);
+  int S = 1;
+  long long rps = 0;
+  bool sliced = false;
+  if (!ragged && !kl && wk4 && wk4->smem <= (size_t)h->lds_per_block && h->variant != 1 && h->variant != 4 && B <= 65535) {
+    const long long target = std::max<long long>(1, 2LL * h->num_cu / B);
+    long long s_try = std::min<long long>(target, (T + 63) / 64);
+    if (h->max_slices > 0) s_try = std::min<long long>(s_try, h->max_slices);
+    s_try = std::max<long long>(s_try, 1);
+    rps = round_up((T + s_try - 1) / s_try, 16);
+    S = (int)((T + rps - 1) / rps);
+    const double unit = 0.7e-6 * (double)wk4->MP / 64.0;
+    const double t_pers = (double)((B + 2 * h->num_cu - 1) / (2 * h->num_cu)) * (double)T / 16.0 / (double)wk->NW * unit;
+    const double t_sliced = 10e-6 + (double)((rps / 16 + 3) / 4) * unit;
+    sliced = h->variant == 2 ? S >= 1 : (S >= 2 && t_sliced < 0.7 * t_pers);
+  } else if (h->variant == 2) {
+    return fail(HIPNMF_ERR_UNSUPPORTED, "the row-sliced wide path handles uniform Frobenius batches only");
+  }
+  if (sliced) wk = wk4;
+
   size_t off = 0;
   auto carve = [&](size_t bytes) {
     size_t o = off;
@@ -134,6 +157,10 @@ int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
   const size_t o_w = w_inplace ? 0 : carve(sizeof(real) * (ragged ? (size_t)ragged_w_elems + 64 : (size_t)B * w_elems + 64));
   const size_t o_kdesc = ragged ? carve(sizeof(long long) * 4 * (size_t)B) : 0;
   const size_t o_cdesc = ragged ? carve(sizeof(long long) * 4 * (size_t)B) : 0;
+  const size_t rec = (size_t)wk->KP * wk->MP + (size_t)wk->KP * wk->KP;
+  const size_t o_part = sliced ? carve(sizeof(real) * (size_t)B * S * rec) : 0;
+  const size_t o_col = sliced ? carve(sizeof(real) * (size_t)B * S * 2 * wk->MP) : 0;
+  const size_t o_state = sliced ? carve(sizeof(real) * (size_t)B * 8) : 0;
   int rc = hipnmf_ensure_ws(h, std::max<size_t>(off, 256));
   if (rc) return rc;
   char* ws = static_cast<char*>(h->ws);
@@ -217,9 +244,9 @@ int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
   a.l2h = (real)p->l2_reg_H;
 
   // W cache: whole 16-row subtiles in what LDS is left (512 threads: of the whole CU; 256 threads: of half of it, so that
-  // two workgroups stay resident)
+  // two workgroups stay resident); none in the sliced mode (a slice lives for one pass)
   size_t smem = wk->smem;
-  {
+  if (!sliced) {
     const size_t lds_cap = (h->lds_budget > 0 ? (size_t)h->lds_budget : (size_t)h->lds_per_block) / (wk->NW == 8 ? 1 : 2);
     long long rows = 0;
     if (h->use_lds_w && lds_cap > smem + 1024) rows = (long long)((lds_cap - smem - 256) / (sizeof(real) * (size_t)ks)) / 16 * 16;
@@ -228,13 +255,121 @@ int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
     smem += sizeof(real) * (size_t)ks * (size_t)rows;
   }
   HIP_TRY(hipEventRecord(h->ev0, st));
-  h->last_path = 1;
-  snprintf(h->last_kernel, sizeof(h->last_kernel), "%s", kl ? wk->name_kl : wk->name);
   const auto kern = kl ? wk->fn_kl : wk->fn;
   if (!kern) return fail(HIPNMF_ERR_UNSUPPORTED, "no Kullback-Leibler instance of %s", wk->name);
   if (smem > 48 * 1024)
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-  hipLaunchKernelGGL(kern, dim3(B), dim3(wk->NW * 64), smem, st, a);
+  if (!sliced) {
+    h->last_path = 1;
+    snprintf(h->last_kernel, sizeof(h->last_kernel), "%s", kl ? wk->name_kl : wk->name);
+    hipLaunchKernelGGL(kern, dim3(B), dim3(wk->NW * 64), smem, st, a);
+  } else {
+    // ---- row-sliced: per iteration one pass over all slices (mode 1) and the H update; the stop rule's residual (mode 2 +
+    // finalize) every check_every iterations with the done flags on the device; chunks of iterations replayed as a hipGraph
+    h->last_path = 2;
+    snprintf(h->last_kernel, sizeof(h->last_kernel), "%s[sliced]", wk->name);
+    WideArgs<real> pa = a, ra = a;
+    pa.mode = 1;
+    ra.mode = 2;
+    pa.S = ra.S = S;
+    pa.rows_per_slice = ra.rows_per_slice = (int)rps;
+    pa.part = reinterpret_cast<real*>(ws + o_part);
+    ra.colpart = reinterpret_cast<real*>(ws + o_col);
+    const bool stop_rule = p->tol > 0;
+    real* d_state = reinterpret_cast<real*>(ws + o_state);
+    HIP_TRY(hipMemsetAsync(d_state, 0, sizeof(real) * (size_t)B * 8, st));
+    pa.state = ra.state = d_state;  // zeroed: nothing is done yet (also read without a stop rule)
+    WideSliceArgs<real> sa;
+    std::memset(&sa, 0, sizeof(sa));
+    sa.H = H;
+    sa.part = pa.part;
+    sa.colpart = ra.colpart;
+    sa.state = d_state;
+    sa.err_out = err_out;
+    sa.n_iter_out = n_iter_out;
+    sa.sse_col_out = sse_col_out;
+    sa.xsq_col_out = xsq_col_out;
+    sa.m = m;
+    sa.k = k;
+    sa.MP = wk->MP;
+    sa.KP = wk->KP;
+    sa.S = S;
+    sa.max_iter = p->max_iter;
+    sa.check_every = p->check_every;
+    sa.tol = (real)p->tol;
+    sa.l1h = (real)p->l1_reg_H;
+    sa.l2h = (real)p->l2_reg_H;
+    const dim3 grid(B, S), block(wk->NW * 64);
+    const size_t hsmem = sizeof(real) * (rec + (size_t)k * m);
+    if (hsmem > 48 * 1024)
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(wide_hupdate_kernel<real>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)hsmem));
+    auto residual = [&](int it) {
+      hipLaunchKernelGGL(kern, grid, block, smem, st, ra);
+      WideSliceArgs<real> f = sa;
+      f.it = it;
+      hipLaunchKernelGGL(wide_resid_finalize_kernel<real>, dim3(B), dim3(256), 0, st, f);
+    };
+    auto enqueue = [&](int n, bool check) {
+      for (int i = 0; i < n; ++i) {
+        hipLaunchKernelGGL(kern, grid, block, smem, st, pa);
+        if (a.update_h) hipLaunchKernelGGL(wide_hupdate_kernel<real>, dim3(B), dim3(256), hsmem, st, sa);
+      }
+      if (check) residual(1);
+    };
+    std::vector<real> host_state((size_t)B * 8);
+    auto all_converged = [&](bool* done) -> int {
+      HIP_TRY(hipMemcpyAsync(host_state.data(), d_state, sizeof(real) * (size_t)B * 8, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      *done = true;
+      for (int b = 0; b < B; ++b) *done = *done && host_state[(size_t)b * 8 + 3] != (real)0;
+      return HIPNMF_OK;
+    };
+    if (stop_rule) residual(0);
+    const int chunk = stop_rule ? p->check_every : std::min(p->max_iter, 64);
+    int it_done = 0;
+    bool converged = false;
+    if (h->use_graph && p->max_iter >= 2 * chunk) {
+      hipGraph_t graph = nullptr;
+      hipGraphExec_t exec = nullptr;
+      hipError_t ge = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+      if (ge == hipSuccess) {
+        enqueue(chunk, stop_rule);
+        ge = hipStreamEndCapture(st, &graph);
+      }
+      if (ge == hipSuccess) ge = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+      int graph_rc = HIPNMF_OK;
+      while (ge == hipSuccess && !converged && it_done + chunk <= p->max_iter) {
+        ge = hipGraphLaunch(exec, st);
+        if (ge != hipSuccess) break;
+        it_done += chunk;
+        if (stop_rule) {
+          graph_rc = all_converged(&converged);
+          if (graph_rc) break;
+        }
+      }
+      if (ge == hipSuccess && !graph_rc) ge = hipStreamSynchronize(st);
+      if (exec) (void)hipGraphExecDestroy(exec);
+      if (graph) (void)hipGraphDestroy(graph);
+      if (graph_rc) return graph_rc;
+      if (ge != hipSuccess) {
+        (void)hipGetLastError();
+        if (it_done > 0)
+          return fail(HIPNMF_ERR_HIP, "hipGraph replay failed after %d iterations: %s", it_done, hipGetErrorString(ge));
+      }
+    }
+    while (!converged && it_done < p->max_iter) {
+      const int n = std::min(chunk, p->max_iter - it_done);
+      const bool check = stop_rule && n == chunk;
+      enqueue(n, check);
+      it_done += n;
+      if (check) {
+        rc = all_converged(&converged);
+        if (rc) return rc;
+      }
+    }
+    residual(-1);
+  }
   HIP_TRY(hipEventRecord(h->ev1, st));
   if (!w_inplace) convert_w(1);
   HIP_TRY(hipGetLastError());

@@ -55,6 +55,14 @@ struct WideArgs {
   int T, m, k, ks, xchunks;  // xchunks: 16-byte pieces of a row of X that hold data (the rest of MP reads as zero)
   int max_iter, check_every, update_h;
   int lds_rows;  // rows [0, lds_rows) of W (a multiple of 16) stay in LDS for the whole fit; launch-wide capacity
+  // row-sliced mode (few long matrices: grid (S, B), one launch per phase -- the wide counterpart of slice_pass / hupdate /
+  // slice_resid of nmf_kernels.hpp):  mode 0 = the whole fit in one workgroup per matrix;  1 = ONE update pass over rows
+  // [slice * rows_per_slice, ...) and the slice's record [W^T X | W^T W] to part[(b S + slice) REC];  2 = the residual pass
+  // over the slice, per-column sse | xsq to colpart[(b S + slice) 2 MP]
+  int mode, S, rows_per_slice;
+  real* part;
+  real* colpart;
+  const real* state;  // [B][8]: entry 3 != 0 = matrix converged (its slices return at once), or nullptr
   real tol, l1w, l2w, l1h, l2h;
 };
 
@@ -188,6 +196,17 @@ fit_wide_kernel(WideArgs<real> a) {
     Wb = a.W + d[3];
   }
   const int m = a.m, k = a.k, ks = a.ks;
+  const int slice = blockIdx.y;
+  if (a.mode != 0) {  // a slice is a matrix of its own for everything row-local
+    if (a.state && a.state[(long long)b * 8 + 3] != (real)0) return;
+    const int row_begin = slice * a.rows_per_slice;
+    int rows = T - row_begin;
+    if (rows > a.rows_per_slice) rows = a.rows_per_slice;
+    if (rows <= 0) rows = 0;
+    Xb += (long long)row_begin * a.ldx;
+    Wb += (long long)row_begin * ks;
+    T = rows;
+  }
   const int ntiles = (T + 15) / 16;
   real* const wcache = wv0 + NW * C::PERWAVE;  // [lds_rows][ks]
   const int ncached = (a.lds_rows / 16 < ntiles) ? a.lds_rows / 16 : ntiles;  // subtiles whose W lives in LDS
@@ -599,6 +618,50 @@ fit_wide_kernel(WideArgs<real> a) {
     return sqrt_(tot);
   };
 
+  if (a.mode == 2) {  // residual of the slice: per-column sums to global memory, summed over the slices by wide_resid_finalize_kernel
+    block_resid();
+    real* out = a.colpart + ((long long)b * a.S + slice) * (2 * MP);
+    for (int idx = tid; idx < 2 * MP; idx += NT) out[idx] = sPart[idx];
+    return;
+  }
+  if (a.mode == 1) {  // one update pass over the slice, its record to global memory (wide_hupdate_kernel sums the slices)
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) accA[kb][cb] = zero;
+#pragma unroll
+      for (int kb2 = 0; kb2 < NKB; ++kb2) accB[kb][kb2] = zero;
+    }
+    const bool upd1 = a.update_h != 0;
+    Tile t1;
+    issue(t1, wave);
+    for (int i = wave; i < ntiles; i += NW) {
+      update_subtile(t1, i, i + NW, upd1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (!upd1) return;
+    real* rec = xs;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rec[(16 * kb + 4 * g + r) * MP + 16 * cb + j] = accA[kb][cb][r];
+#pragma unroll
+      for (int kb2 = 0; kb2 < NKB; ++kb2)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rec[KP * MP + (16 * kb + 4 * g + r) * KP + 16 * kb2 + j] = accB[kb][kb2][r];
+    }
+    __syncthreads();
+    real* out = a.part + ((long long)b * a.S + slice) * C::REC;
+    for (int idx = tid; idx < C::REC; idx += NT) {
+      real sacc = wv0[idx];
+      for (int w2 = 1; w2 < NW; ++w2) sacc += wv0[w2 * C::PERWAVE + idx];
+      out[idx] = sacc;
+    }
+    return;
+  }
+
   real err0 = (real)0, prev = (real)0;
   if (a.tol > (real)0) {
     block_resid();
@@ -730,6 +793,99 @@ fit_wide_kernel(WideArgs<real> a) {
   }
   // the cached rows of W back to global memory (block_resid above ended with a barrier: every wave's rows are final)
   for (int idx = tid; idx < ncached * 16 * ks && idx < T * ks; idx += NT) Wb[idx] = wcache[idx];
+}
+
+// ---- row-sliced mode: the phases between the slice passes ----------------------------------------------------------------
+template <typename real>
+struct WideSliceArgs {
+  real* H;            // [B][k][m]
+  const real* part;   // [B][S][rec]      rec = KP MP + KP KP:  [W^T X | W^T W] per slice
+  const real* colpart;  // [B][S][2 MP]   sse | xsq per slice
+  real* state;        // [B][8]: err0, prev, err, done, checks so far
+  real* err_out;
+  int* n_iter_out;
+  real* sse_col_out;
+  real* xsq_col_out;
+  int m, k, MP, KP, S, max_iter, check_every, it;  // it: 0 = error at init, 1 = stop-rule check, -1 = final outputs
+  real tol, l1h, l2h;
+};
+
+// H *= (W^T X) / ((W^T W) H) from the slice records, summed in slice order (_nmf.py:638-640, 701-728).  One workgroup per matrix.
+template <typename real>
+__global__ void __launch_bounds__(256) wide_hupdate_kernel(WideSliceArgs<real> a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char wide_h_smem[];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (a.state && a.state[(long long)b * 8 + 3] != (real)0) return;
+  const int rec = a.KP * a.MP + a.KP * a.KP;
+  real* sAB = reinterpret_cast<real*>(wide_h_smem);  // [rec]
+  real* sHo = sAB + rec;                               // [k][m] the old H
+  real* Hb = a.H + (long long)b * a.k * a.m;
+  const real* pb = a.part + (long long)b * a.S * rec;
+  for (int idx = tid; idx < rec; idx += 256) {
+    real s = pb[idx];
+    for (int q = 1; q < a.S; ++q) s += pb[(long long)q * rec + idx];
+    sAB[idx] = s;
+  }
+  for (int idx = tid; idx < a.k * a.m; idx += 256) sHo[idx] = Hb[idx];
+  __syncthreads();
+  const real* sB = sAB + a.KP * a.MP;
+  for (int idx = tid; idx < a.k * a.m; idx += 256) {
+    const int c = idx / a.m, jj = idx % a.m;
+    real d = sB[c * a.KP] * sHo[jj];
+    for (int c2 = 1; c2 < a.k; ++c2) d = fma_(sB[c * a.KP + c2], sHo[c2 * a.m + jj], d);
+    const real hold = sHo[idx];
+    if (a.l1h > (real)0) d = d + a.l1h;
+    if (a.l2h > (real)0) d = d + a.l2h * hold;
+    d = (d == (real)0) ? eps_val<real>() : d;
+    Hb[idx] = hold * (sAB[c * a.MP + jj] / d);
+  }
+}
+
+// per-column sums over the slices -> error, stop rule (_nmf.py:872-884), outputs.  One workgroup per matrix.
+template <typename real>
+__global__ void __launch_bounds__(256) wide_resid_finalize_kernel(WideSliceArgs<real> a) {
+  __shared__ real cols[2 * 128];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  real* st = a.state + (long long)b * 8;
+  const bool done = st[3] != (real)0;
+  if (done && a.it != -1) return;
+  if (!done || a.it == -1) {
+    const real* cb = a.colpart + (long long)b * a.S * 2 * a.MP;
+    for (int idx = tid; idx < 2 * a.MP; idx += 256) {
+      real s = cb[idx];
+      for (int q = 1; q < a.S; ++q) s += cb[(long long)q * 2 * a.MP + idx];
+      cols[idx] = s;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    real tot = (real)0;
+    for (int jj = 0; jj < a.MP; ++jj) tot += cols[jj];
+    const real err = sqrt_(tot);
+    if (a.it == 0) {
+      st[0] = err;
+      st[1] = err;
+    } else if (a.it == 1) {
+      st[4] += (real)1;
+      if ((st[1] - err) / st[0] < a.tol) {
+        st[3] = (real)1;
+        st[5] = st[4] * (real)a.check_every;  // n_iter_ of this matrix
+      }
+      st[1] = err;
+    } else {
+      if (a.err_out) a.err_out[b] = err;
+      if (a.n_iter_out) a.n_iter_out[b] = done ? (int)st[5] : a.max_iter;
+    }
+    st[2] = err;
+  }
+  if (a.it == -1) {
+    // (a converged matrix's slices returned at once from the last residual pass: its sums are those of the check that
+    //  stopped it -- W and H have not changed since)
+    for (int jj = tid; jj < a.m; jj += 256) {
+      if (a.sse_col_out) a.sse_col_out[(long long)b * a.m + jj] = cols[jj];
+      if (a.xsq_col_out) a.xsq_col_out[(long long)b * a.m + jj] = cols[a.MP + jj];
+    }
+  }
 }
 
 // ---- W between the caller's layout and the kernel's row-major [T][ks] rows (once per fit each way) -----------------

@@ -241,3 +241,56 @@ def test_wide_17_to_32_components(dtype, m, k, T):
     Wr, Hr, _ = orc.fit_multiplicative_update_kl(X, W0.copy(), H0.copy(), 15, 0.0)
     res = ms.fit_batched(X, W0, H0, max_iter=15, tol=0.0, beta_loss="kullback-leibler")
     assert _rel(X, res.W[0], res.H[0], {"W": Wr, "H": Hr}) <= (3e-5 if dtype == np.float32 else 1e-9)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("m,k,T", [(64, 8, 5000), (40, 12, 1003), (128, 16, 777), (33, 20, 2048)])
+def test_wide_row_sliced_path(dtype, m, k, T):
+    """Few long matrices (the reference's own single-DataFrame call): rows sliced over the whole chip, one pass + one H
+    update per iteration (graph replay), stop rule with per-matrix done flags -- forced with variant 2 and compared with
+    the one-workgroup-per-matrix path (variant 1) and the oracle; the library picks it by itself for B = 1."""
+    import muscle_synergies_amd as ms
+    from muscle_synergies_amd import _lib
+
+    if dtype == np.float64 and k > 16 and m > 64:
+        pytest.skip("outside the compiled kernel set")
+    h = _lib.Handle(0)
+    Xs, Ws, Hs = [], [], []
+    for s in range(2):
+        X, W0, H0 = _case(T - 37 * s if s == 0 else T, m, k, dtype, seed=90 + s)
+        Xs.append(X), Ws.append(W0), Hs.append(H0)
+    X3, W3, H3 = np.stack(Xs), np.stack(Ws), np.stack(Hs)
+    tol = TOL if dtype == np.float32 else 1e-9
+    out = {}
+    for variant in (1, 2):
+        h.set_tuning(0, 0, variant)
+        out[variant] = ms.fit_batched(X3, W3, H3, max_iter=45, tol=0.0, handle=h)
+        assert ("[sliced]" in h.last_kernel()) == (variant == 2), h.last_kernel()
+    for b in range(2):
+        ref = orc.nmf_mu_fit(Xs[b], Ws[b], Hs[b], max_iter=45, tol=0.0)
+        for variant in (1, 2):
+            r = out[variant]
+            assert int(r.n_iter[b]) == 45
+            assert _rel(Xs[b], r.W[b], r.H[b], ref) <= tol, (variant, b)
+            assert abs(float(r.reconstruction_err[b]) - float(ref["reconstruction_err"])) / np.linalg.norm(Xs[b]) <= TOL
+            va, vc = orc.vaf(Xs[b].astype(np.float64), ref["W"].astype(np.float64), ref["H"].astype(np.float64))
+            assert abs(r.vaf[b, 0] - va) <= TOL
+    # stop rule: the two matrices converge at different checks
+    h.set_tuning(0, 0, 2)
+    r = ms.fit_batched(X3, W3, H3, max_iter=400, tol=2e-4, handle=h)
+    for b in range(2):
+        ref = orc.nmf_mu_fit(Xs[b], Ws[b], Hs[b], max_iter=400, tol=2e-4)
+        if dtype == np.float64:
+            assert int(r.n_iter[b]) == ref["n_iter"]
+            assert _rel(Xs[b], r.W[b], r.H[b], ref) <= 1e-9
+        else:
+            assert abs(int(r.n_iter[b]) - ref["n_iter"]) <= 10
+    # transform (H fixed) through the sliced path
+    rt = ms.fit_batched(X3, W3, out[1].H, max_iter=20, tol=0.0, update_H=False, handle=h)
+    h.set_tuning(0, 0, 1)
+    rt1 = ms.fit_batched(X3, W3, out[1].H, max_iter=20, tol=0.0, update_H=False, handle=h)
+    np.testing.assert_allclose(rt.W, rt1.W, rtol=1e-6 if dtype == np.float32 else 1e-12, atol=1e-9)
+    # the library's own choice for one long matrix
+    h.set_tuning(0, 0, 0)
+    ms.fit_batched(X3[:1], W3[:1], H3[:1], max_iter=3, tol=0.0, handle=h)
+    assert "[sliced]" in h.last_kernel(), h.last_kernel()
