@@ -124,23 +124,24 @@ int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
   }
 
   // ---- path: one workgroup per matrix, or row slices over the whole chip (few long matrices: the reference's own
-  // single-DataFrame call).  Estimates from tools/quick_bench.py: a 256-thread workgroup needs ~0.7 us per round of four
-  // 16-row subtiles at 64 channels; a sliced iteration is two graph-replayed launches (~10 us) plus one slice.
+  // single-DataFrame call)
   const WideKernel<real>* wk4 = pick<real>(m, k, 4);
   int S = 1;
   long long rps = 0;
   bool sliced = false;
   if (!ragged && !kl && wk4 && wk4->smem <= (size_t)h->lds_per_block && h->variant != 1 && h->variant != 4 && B <= 65535) {
-    const long long target = std::max<long long>(1, 2LL * h->num_cu / B);
-    long long s_try = std::min<long long>(target, (T + 63) / 64);
+    const long long target = std::min<long long>(128, std::max<long long>(1, 2LL * h->num_cu / B));  // (the H update sums S records per launch)
+    long long s_try = std::min<long long>(target, (T + 127) / 128);  // at least two subtiles per wave and slice
     if (h->max_slices > 0) s_try = std::min<long long>(s_try, h->max_slices);
     s_try = std::max<long long>(s_try, 1);
     rps = round_up((T + s_try - 1) / s_try, 16);
     S = (int)((T + rps - 1) / rps);
-    const double unit = 0.7e-6 * (double)wk4->MP / 64.0;
-    const double t_pers = (double)((B + 2 * h->num_cu - 1) / (2 * h->num_cu)) * (double)T / 16.0 / (double)wk->NW * unit;
-    const double t_sliced = 10e-6 + (double)((rps / 16 + 3) / 4) * unit;
-    sliced = h->variant == 2 ? S >= 1 : (S >= 2 && t_sliced < 0.7 * t_pers);
+    // fitted to tools/quick_bench.py --batch 1 --m 64 --k 8 (us per iteration, one workgroup / sliced): T = 1 000 20 / 12.7,
+    // 4 000 71 / 11, 10 000 171 / 20.6, 100 000 1 692 / 28.7; 8 x (128 x 20 000), k = 16: 480 / 39
+    const double unit = 1.1e-6 * (double)wk4->MP / 64.0;  // one round of four 16-row subtiles on a workgroup that has its CU to itself
+    const double t_pers = 3e-6 + (double)((B + 2 * h->num_cu - 1) / (2 * h->num_cu)) * (double)((T + 63) / 64) * unit * 4.0 / (double)wk->NW;
+    const double t_sliced = 11e-6 + (double)((rps + 63) / 64) * unit;  // two graph-replayed launches: the pass, the record sums + H update
+    sliced = h->variant == 2 ? S >= 1 : (S >= 2 && t_sliced < 0.85 * t_pers);
   } else if (h->variant == 2) {
     return fail(HIPNMF_ERR_UNSUPPORTED, "the row-sliced wide path handles uniform Frobenius batches only");
   }
@@ -308,12 +309,12 @@ int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
       hipLaunchKernelGGL(kern, grid, block, smem, st, ra);
       WideSliceArgs<real> f = sa;
       f.it = it;
-      hipLaunchKernelGGL(wide_resid_finalize_kernel<real>, dim3(B), dim3(256), 0, st, f);
+      hipLaunchKernelGGL(wide_resid_finalize_kernel<real>, dim3(B), dim3(1024), 0, st, f);
     };
     auto enqueue = [&](int n, bool check) {
       for (int i = 0; i < n; ++i) {
         hipLaunchKernelGGL(kern, grid, block, smem, st, pa);
-        if (a.update_h) hipLaunchKernelGGL(wide_hupdate_kernel<real>, dim3(B), dim3(256), hsmem, st, sa);
+        if (a.update_h) hipLaunchKernelGGL(wide_hupdate_kernel<real>, dim3(B), dim3(1024), hsmem, st, sa);
       }
       if (check) residual(1);
     };

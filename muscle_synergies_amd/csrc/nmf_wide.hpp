@@ -811,8 +811,29 @@ struct WideSliceArgs {
 };
 
 // H *= (W^T X) / ((W^T W) H) from the slice records, summed in slice order (_nmf.py:638-640, 701-728).  One workgroup per matrix.
+// out[idx] = sum over the S slice records of in[slice][idx], idx < n, in slice order: a thread per sum, sixteen records in
+// flight per thread (a chain of S dependent loads cost 175 us per iteration at S = 157; a wave per sum with a butterfly
+// 55 us: six dependent cross-lane steps per sum; this form ~15 us)
 template <typename real>
-__global__ void __launch_bounds__(256) wide_hupdate_kernel(WideSliceArgs<real> a) {
+__device__ __forceinline__ void wide_sum_slices(const real* __restrict__ in, int n, int S, real* __restrict__ out) {
+  for (int idx = threadIdx.x; idx < n; idx += blockDim.x) {
+    const real* p = in + idx;
+    real s = (real)0;
+    int q = 0;
+    for (; q + 16 <= S; q += 16) {
+      real v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = p[(long long)(q + u) * n];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) s += v[u];
+    }
+    for (; q < S; ++q) s += p[(long long)q * n];
+    out[idx] = s;
+  }
+}
+
+template <typename real>
+__global__ void __launch_bounds__(1024) wide_hupdate_kernel(WideSliceArgs<real> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char wide_h_smem[];
   const int b = blockIdx.x, tid = threadIdx.x;
   if (a.state && a.state[(long long)b * 8 + 3] != (real)0) return;
@@ -821,15 +842,11 @@ __global__ void __launch_bounds__(256) wide_hupdate_kernel(WideSliceArgs<real> a
   real* sHo = sAB + rec;                               // [k][m] the old H
   real* Hb = a.H + (long long)b * a.k * a.m;
   const real* pb = a.part + (long long)b * a.S * rec;
-  for (int idx = tid; idx < rec; idx += 256) {
-    real s = pb[idx];
-    for (int q = 1; q < a.S; ++q) s += pb[(long long)q * rec + idx];
-    sAB[idx] = s;
-  }
-  for (int idx = tid; idx < a.k * a.m; idx += 256) sHo[idx] = Hb[idx];
+  wide_sum_slices<real>(pb, rec, a.S, sAB);
+  for (int idx = tid; idx < a.k * a.m; idx += blockDim.x) sHo[idx] = Hb[idx];
   __syncthreads();
   const real* sB = sAB + a.KP * a.MP;
-  for (int idx = tid; idx < a.k * a.m; idx += 256) {
+  for (int idx = tid; idx < a.k * a.m; idx += blockDim.x) {
     const int c = idx / a.m, jj = idx % a.m;
     real d = sB[c * a.KP] * sHo[jj];
     for (int c2 = 1; c2 < a.k; ++c2) d = fma_(sB[c * a.KP + c2], sHo[c2 * a.m + jj], d);
@@ -843,20 +860,13 @@ __global__ void __launch_bounds__(256) wide_hupdate_kernel(WideSliceArgs<real> a
 
 // per-column sums over the slices -> error, stop rule (_nmf.py:872-884), outputs.  One workgroup per matrix.
 template <typename real>
-__global__ void __launch_bounds__(256) wide_resid_finalize_kernel(WideSliceArgs<real> a) {
+__global__ void __launch_bounds__(1024) wide_resid_finalize_kernel(WideSliceArgs<real> a) {
   __shared__ real cols[2 * 128];
   const int b = blockIdx.x, tid = threadIdx.x;
   real* st = a.state + (long long)b * 8;
   const bool done = st[3] != (real)0;
   if (done && a.it != -1) return;
-  if (!done || a.it == -1) {
-    const real* cb = a.colpart + (long long)b * a.S * 2 * a.MP;
-    for (int idx = tid; idx < 2 * a.MP; idx += 256) {
-      real s = cb[idx];
-      for (int q = 1; q < a.S; ++q) s += cb[(long long)q * 2 * a.MP + idx];
-      cols[idx] = s;
-    }
-  }
+  wide_sum_slices<real>(a.colpart + (long long)b * a.S * 2 * a.MP, 2 * a.MP, a.S, cols);
   __syncthreads();
   if (tid == 0) {
     real tot = (real)0;
@@ -881,7 +891,7 @@ __global__ void __launch_bounds__(256) wide_resid_finalize_kernel(WideSliceArgs<
   if (a.it == -1) {
     // (a converged matrix's slices returned at once from the last residual pass: its sums are those of the check that
     //  stopped it -- W and H have not changed since)
-    for (int jj = tid; jj < a.m; jj += 256) {
+    for (int jj = tid; jj < a.m; jj += blockDim.x) {
       if (a.sse_col_out) a.sse_col_out[(long long)b * a.m + jj] = cols[jj];
       if (a.xsq_col_out) a.xsq_col_out[(long long)b * a.m + jj] = cols[a.MP + jj];
     }

