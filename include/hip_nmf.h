@@ -104,8 +104,12 @@ int hipnmf_set_async(hipnmf_handle* h, int enable);
  * solver path: 0 chosen by the library, 1 one persistent workgroup per matrix, 2 row-sliced launches,
  * 3 cooperative multi-workgroup kernel (few long matrices; HIPNMF_ERR_UNSUPPORTED when not applicable),
  * 4 / 5 = 1 with the kernel instance pinned: 4 fit_persistent_kernel (VALU contractions), 5 fit_rowlane_kernel
- * (X H^T and W H H^T on the f32 matrix pipe; fp32, 9..16 channels, Frobenius only, else HIPNMF_ERR_UNSUPPORTED),
- * 6 fit_small_kernel (one wave per matrix, n_samples <= 256; HIPNMF_ERR_UNSUPPORTED otherwise; picked automatically). */
+ * (X H^T and W H H^T on the f32 matrix pipe; fp32, 9..16 channels, else HIPNMF_ERR_UNSUPPORTED),
+ * 6 fit_small_kernel (one wave per matrix, n_samples <= 256; HIPNMF_ERR_UNSUPPORTED otherwise; picked automatically).
+ * Wide shapes (n_features > 32 or n_components > 8: fit_wide_kernel, every contraction on v_mfma_*_16x16x4; the library
+ * also routes float64 17..32 channels with k >= 6 there): variants 0, 1 (= 4) and 2 exist -- 2 = rows sliced over the chip,
+ * Frobenius loss and uniform batches only --, threads = 256 / 512 pins the instance (two workgroups per CU / one with
+ * the larger W cache); 3, 5, 6 answer HIPNMF_ERR_UNSUPPORTED. */
 int hipnmf_set_tuning(hipnmf_handle* h, int threads, int max_slices, int variant);
 
 /* ---- batched fit: replaces NMF(solver='mu').fit_transform / .transform for B matrices ------------- */
@@ -117,6 +121,12 @@ int hipnmf_set_tuning(hipnmf_handle* h, int threads, int max_slices, int variant
  * n_iter_out [B]  n_iter_ (_nmf.py:893), or NULL
  * sse_col_out [B][m]  per-column sum((X - W H)^2)  -> VAF numerators (analysis.py:660-662), or NULL
  * xsq_col_out [B][m]  per-column sum(X^2)          -> VAF denominators (analysis.py:654-656), or NULL
+ *
+ * Shapes: any 1 <= n_components <= 32, n_features <= 128 (the reference accepts any n <= m, analysis.py:829-846); float64
+ * with more than 16 components on more than 64 channels is HIPNMF_ERR_UNSUPPORTED.  Layouts used in place (anything
+ * else costs one conversion per fit): fp32 16-channel C-order X for the narrow row-per-lane instances, channel-major X
+ * for the other narrow ones; for the wide shapes a C-order X whose rows are a whole number of 16-byte pieces
+ * (n_features * sizeof % 16 == 0, ldx likewise) and a C-order W with n_components % 4 == 0.
  */
 int hipnmf_fit_batched_f32(hipnmf_handle* h, const hipnmf_problem* p, const float* X, float* W, float* H,
                            float* err_out, int32_t* n_iter_out, float* sse_col_out, float* xsq_col_out);
