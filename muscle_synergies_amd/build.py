@@ -101,14 +101,56 @@ def build(force: bool = False, jobs: int | None = None, extra_flags=(), verbose:
         with ThreadPoolExecutor(max_workers=jobs) as ex:
             list(ex.map(lambda s: _compile(s, list(extra_flags), objdir), todo))
     objs = [os.path.join(objdir, os.path.basename(s)[:-4] + ".o") for s in srcs]
+    linked = False
     if todo or _stale(lib, objs):
         cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", lib]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+        linked = True
         if verbose:
             print(f"[build] linked {lib}", flush=True)
+    if not variant:
+        _record(lib, srcs, todo, linked, verbose)
     return lib
+
+
+def _record(lib: str, srcs, todo, linked: bool, verbose: bool) -> None:
+    """What this call did -- compiled from source or found up to date -- next to the library and, for the record of the
+    round (the question "did build() recompile or reuse?"), in profiles/build_info.json."""
+    import hashlib
+    import json
+    import time
+
+    with open(lib, "rb") as f:
+        sha = hashlib.sha256(f.read()).hexdigest()
+    info = {
+        "library": os.path.relpath(lib, os.path.dirname(PKG)),
+        "sha256": sha,
+        "arch": ARCH,
+        "translation_units": len(srcs),
+        "compiled_in_this_call": sorted(os.path.basename(s) for s in todo),
+        "linked_in_this_call": linked,
+        "build_mode": ("compiled all from source" if len(todo) == len(srcs) else
+                       "compiled %d of %d translation units" % (len(todo), len(srcs)) if todo else "up to date: reused"),
+        "flags": CXXFLAGS,
+        "time_utc": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime()),
+    }
+    for path in (os.path.join(LIBDIR, "build_info.json"), os.path.join(os.path.dirname(PKG), "profiles", "build_info.json")):
+        try:
+            old = json.load(open(path)) if os.path.exists(path) else {}
+            if not todo and not linked and old.get("sha256") == sha:
+                if "profiles" in path:
+                    continue  # the tracked record keeps the build that produced this library; reuse is logged beside the .so
+                info_w = dict(old, last_checked_utc=info["time_utc"], last_check="up to date: reused")
+            else:
+                info_w = info
+            with open(path, "w") as f:
+                json.dump(info_w, f, indent=1)
+        except OSError:
+            pass
+    if verbose:
+        print(f"[build] {info['build_mode']}; sha256 {sha[:16]}", flush=True)
 
 
 if __name__ == "__main__":

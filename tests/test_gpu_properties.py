@@ -84,3 +84,27 @@ def test_stop_rule_in_a_batch_is_per_matrix(workload):
     assert (n % 10 == 0).all() and (n < 2000).all() and len(set(n.tolist())) > 1
     one = ms.fit_batched(X[5:6], W0[5:6], H0[5:6], max_iter=2000, tol=1e-3)
     assert int(one.n_iter[0]) == int(n[5])
+
+
+def test_bench_launch_is_deterministic_and_matches_oracle_row_major_4096():
+    """bench.py's exact headline launch -- 4096 matrices 16 x 10 000, k = 5, fp32, ROW-major X streamed in place -- twice:
+    bitwise equal; a handful of its matrices against the oracle (the full batch would take the CPU minutes)."""
+    import torch
+
+    import muscle_synergies_amd as ms
+    from muscle_synergies_amd import _lib
+    from muscle_synergies_amd.synth import emg_batch_torch
+    from oracle import nmf_mu_oracle as orc
+
+    X, W0, H0 = emg_batch_torch(4096, T=10_000, m=16, k=5, device="cuda:0", seed=0)
+    Xr = X.transpose(1, 2).contiguous()
+    a = ms.fit_batched(Xr, W0, H0, max_iter=20, tol=0.0)
+    assert _lib.get_handle(0).last_kernel() == "fit_persistent_kernel<float,1,16,5,0>"
+    b = ms.fit_batched(Xr, W0, H0, max_iter=20, tol=0.0)
+    assert torch.equal(a.W, b.W) and torch.equal(a.H, b.H) and torch.equal(a.reconstruction_err, b.reconstruction_err)
+    for i in (0, 1, 2047, 4095):
+        x = Xr[i].cpu().numpy()
+        ref = orc.nmf_mu_fit(x, W0[i].cpu().numpy(), H0[i].cpu().numpy(), max_iter=20, tol=0.0)
+        wh = a.W[i].double().cpu().numpy() @ a.H[i].double().cpu().numpy()
+        wr = ref["W"].astype(np.float64) @ ref["H"].astype(np.float64)
+        assert np.linalg.norm(wh - wr) / np.linalg.norm(x) <= 1e-5, i
