@@ -241,6 +241,21 @@ def flops_per_unit(T, m, k):
     return 4 * T * k * (m + k) + 2 * T * k + 4 * k * k * m + 2 * k * m
 
 
+def _matrix_pipe(kernel, tf, m, k):
+    """Useful vs issued rate of the matrix pipe for the wide-shape kernels: issued = useful x the padding of the tile shape."""
+    if kernel.startswith("fit_wide4_kernel"):  # nmf_wide4.hpp: v_mfma_f32_4x4x1, components padded to a multiple of 4
+        kp = (k + 3) // 4 * 4
+        mp = 48 if m <= 48 else 64 if m <= 64 else 96 if m <= 96 else 128
+        return {"achieved_tflops_useful": tf, "peak_tflops": FP32_PEAK_TFLOPS, "frac_useful": tf / FP32_PEAK_TFLOPS,
+                "issued_tflops": tf * (kp / k) * (mp + kp) / (m + k),
+                "note": "all four contractions on v_mfma_f32_4x4x1_16b_f32, components padded to a multiple of 4, channels to "
+                        "48 / 64 / 96 / 128 (issued = useful x padding); profiles/r03_pmc_fit_wide4_64_8.txt: matrix pipe busy 31 %"}
+    return {"achieved_tflops_useful": tf, "peak_tflops": FP32_PEAK_TFLOPS, "frac_useful": tf / FP32_PEAK_TFLOPS,
+            "issued_tflops": tf * (16.0 / k) * ((m + 15) // 16 * 16 + 16.0) / (m + k),
+            "note": "all four contractions on v_mfma_f32_16x16x4_f32 with components padded to 16 and "
+                    "channels to a multiple of 16 (issued = useful x padding)"}
+
+
 def compute_roofline(kernel, kernel_ms, units_per_launch, T, m, k, traffic=None, moved_bytes_per_unit=None):
     fl = flops_per_unit(T, m, k)
     by = 4 * T * (m + 2 * k)  # read X once, read + write W once (SURVEY 8d)
@@ -279,10 +294,7 @@ def compute_roofline(kernel, kernel_ms, units_per_launch, T, m, k, traffic=None,
         return {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                 "traffic": traffic, "kernel": kernel, "kernel_ms_avg": kernel_ms, "algorithmic_bytes_per_unit": by,
                 "units_per_launch": units_per_launch,
-                "matrix_pipe": {"achieved_tflops_useful": tf, "peak_tflops": FP32_PEAK_TFLOPS, "frac_useful": tf / FP32_PEAK_TFLOPS,
-                                "issued_tflops": tf * (16.0 / k) * ((m + 15) // 16 * 16 + 16.0) / (m + k),
-                                "note": "all four contractions on v_mfma_f32_16x16x4_f32 with components padded to 16 and "
-                                        "channels to a multiple of 16 (issued = useful x padding)"},
+                "matrix_pipe": _matrix_pipe(kernel, tf, m, k),
                 "memory": mem}
     return {
         "bound": "fp32_issue",

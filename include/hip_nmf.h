@@ -100,7 +100,7 @@ const char* hipnmf_last_kernel(hipnmf_handle* h);
  * stream) by the time-sharded solver so that kernels and RCCL collectives are ordered by the stream alone.
  * Only the shard entry points honour it; hipnmf_fit_batched_* always returns with results ready. */
 int hipnmf_set_async(hipnmf_handle* h, int enable);
-/* Tuning knobs (0 = library default): threads per workgroup (256/512/1024), max row slices per matrix, and the
+/* Tuning knobs (0 = library default): threads per workgroup (256/512/768/1024; 768 exists for fit_wide4_kernel only, elsewhere it means 512), max row slices per matrix, and the
  * solver path: 0 chosen by the library, 1 one persistent workgroup per matrix, 2 row-sliced launches,
  * 3 cooperative multi-workgroup kernel (few long matrices; HIPNMF_ERR_UNSUPPORTED when not applicable),
  * 4 / 5 = 1 with the kernel instance pinned: 4 fit_persistent_kernel (VALU contractions), 5 fit_rowlane_kernel

@@ -1242,8 +1242,8 @@ int hipnmf_set_async(hipnmf_handle* h, int enable) {
 
 int hipnmf_set_tuning(hipnmf_handle* h, int threads, int max_slices, int variant) {
   if (!h) return fail(HIPNMF_ERR_BAD_ARG, "handle is NULL");
-  if (threads != 0 && threads != 256 && threads != 512 && threads != 1024)
-    return fail(HIPNMF_ERR_BAD_ARG, "threads must be 0, 256, 512 or 1024");
+  if (threads != 0 && threads != 256 && threads != 512 && threads != 768 && threads != 1024)
+    return fail(HIPNMF_ERR_BAD_ARG, "threads must be 0, 256, 512, 768 or 1024");
   if (max_slices < 0 || variant < 0 || variant > 6) return fail(HIPNMF_ERR_BAD_ARG, "bad tuning value");
   h->threads = threads;
   h->max_slices = max_slices;

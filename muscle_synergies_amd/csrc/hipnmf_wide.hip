@@ -10,10 +10,12 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
 #include "hipnmf_internal.hpp"
+#include "nmf_wide4_inst.hpp"
 #include "nmf_wide_inst.hpp"
 
 using namespace hipnmf;
@@ -32,9 +34,25 @@ const WideKernel<double>* wide_kernel_f64(int m, int k, int nw) {
   if (k > 16) return nw == 4 ? wide_kernel_f64_k32(MP < 32 ? 32 : MP) : nullptr;
   return MP <= 48 ? wide_kernel_f64_lo(MP, 16, nw) : wide_kernel_f64_hi(MP, 16, nw);
 }
+// fp32, 33..128 channels, at most 8 components: the v_mfma_f32_4x4x1 formulation (nmf_wide4.hpp), which pads the components to
+// a multiple of 4 instead of 16
+const WideKernel<float>* wide4_kernel_f32(int m, int k, int nw) {
+  if (m <= 32 || m > 128 || k > 8) return nullptr;
+  const int MP = m <= 48 ? 48 : m <= 64 ? 64 : m <= 96 ? 96 : 128;
+  const int KQ = k <= 4 ? 1 : 2;
+  return MP <= 64 ? wide4_kernel_f32_lo(MP, KQ, nw) : wide4_kernel_f32_hi(MP, KQ, nw);
+}
 }  // namespace hipnmf
 
 namespace {
+template <typename real>
+const WideKernel<real>* pick4(int, int, int) {
+  return nullptr;
+}
+template <>
+const WideKernel<float>* pick4<float>(int m, int k, int nw) {
+  return wide4_kernel_f32(m, k, nw);
+}
 template <typename real>
 const WideKernel<real>* pick(int m, int k, int nw);
 template <>
@@ -146,6 +164,24 @@ int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
     return fail(HIPNMF_ERR_UNSUPPORTED, "the row-sliced wide path handles uniform Frobenius batches only");
   }
   if (sliced) wk = wk4;
+  // one workgroup per matrix, Frobenius, fp32, at most 8 components: the 4x4x1 formulation (HIPNMF_WIDE4=0: the 16x16x4 one)
+  if (!sliced && !kl) {
+    static const bool use4 = [] {
+      const char* e = getenv("HIPNMF_WIDE4");
+      return !(e && e[0] == '0');
+    }();
+    // waves per workgroup: 12 (three per SIMD: the instance stays within 168 registers up to 64 channels) where it exists,
+    // unless the caller asks for 4 / 8 (threads = 256 / 512).  tools/quick_bench.py, M matrix-it/s with 4 / 8 / 12 waves:
+    // 1024 x (64 x 10 000), k = 8: 1.80 / 1.84 / 1.93; 4096 x (64 x 2 500), k = 8: 7.89 / 8.69 / 9.29; 48 ch, k = 6: 9.25 / 10.15 / 10.68;
+    // k <= 4 (one component quad, at the X stream's rate with 8 waves already: 11.4 M at 64 x 2 500): 8
+    const WideKernel<real>* w4 = nullptr;
+    if (use4) {
+      const int want = h->threads == 256 ? 4 : h->threads == 512 ? 8 : (h->threads == 768 || k > 4) ? 12 : 8;
+      w4 = pick4<real>(m, k, want);
+      if (!w4 && want == 12) w4 = pick4<real>(m, k, 8);
+    }
+    if (w4 && w4->smem <= (size_t)h->lds_per_block) wk = w4;
+  }
 
   size_t off = 0;
   auto carve = [&](size_t bytes) {
@@ -248,7 +284,7 @@ int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
   // two workgroups stay resident); none in the sliced mode (a slice lives for one pass)
   size_t smem = wk->smem;
   if (!sliced) {
-    const size_t lds_cap = (h->lds_budget > 0 ? (size_t)h->lds_budget : (size_t)h->lds_per_block) / (wk->NW == 8 ? 1 : 2);
+    const size_t lds_cap = (h->lds_budget > 0 ? (size_t)h->lds_budget : (size_t)h->lds_per_block) / (wk->NW >= 8 ? 1 : 2);
     long long rows = 0;
     if (h->use_lds_w && lds_cap > smem + 1024) rows = (long long)((lds_cap - smem - 256) / (sizeof(real) * (size_t)ks)) / 16 * 16;
     rows = std::min<long long>(rows, round_up(T, 16));

@@ -351,7 +351,7 @@ fit_wide_kernel(WideArgs<real> a) {
     stage_x(t);
     real wold[NKB][4];
     get_w(t, i, wold);
-    issue(t, inext);  // the registers of this subtile are free again: request the one PF steps ahead
+    if (inext >= 0) issue(t, inext);  // the registers of this subtile are free again: request the one PF steps ahead
     if constexpr (LOSS == 1) {
       // numerator^T = H Q^T with Q = X / max(W H, eps): Q comes out of wh_block's D layout (lane (row j, g), register r <->
       // channel 16 cb + 4 g + r), which is the B operand of k-step (cb, r); A: lane (i, g) <-> H[16 kb + arow(i)][16 cb + 4 g + r]
@@ -671,8 +671,11 @@ fit_wide_kernel(WideArgs<real> a) {
   const bool upd = a.update_h != 0;
   int n_iter = 0;
   Tile ta, tb;
+  __builtin_amdgcn_sched_barrier(0);
   issue(ta, wave);
+  __builtin_amdgcn_sched_barrier(0);
   if constexpr (NSET > 1) issue(tb, wave + NW);
+  __builtin_amdgcn_sched_barrier(0);
   for (int it = 1; it <= a.max_iter; ++it) {
     n_iter = it;
 #pragma unroll
@@ -685,12 +688,20 @@ fit_wide_kernel(WideArgs<real> a) {
       for (int r = 0; r < 4; ++r) wsum[kb][r] = (real)0;
     }
     if constexpr (NSET > 1) {
-      for (int i = wave; i < ntiles; i += 2 * NW) {
+      // pairs of subtiles in a loop without inner exits, then the odd one (which requests nothing).  The compiler's s_waitcnt
+      // vmcnt is only exact -- "this set's loads are in, the other set's may still fly" -- when every path into the loop has the
+      // two sets' requests in the same order: a conditional second half, a tail that re-requests set a after set b, or a
+      // prologue whose two requests the scheduler swapped (hence the sched_barriers around them) made it wait for ALL loads
+      // in flight at the top of every round, i.e. a prefetch distance of half a round
+      int i = wave;
+      for (; i + NW < ntiles; i += 2 * NW) {
         update_subtile(ta, i, i + 2 * NW, upd);
         __builtin_amdgcn_sched_barrier(0);
-        if (i + NW < ntiles) update_subtile(tb, i + NW, i + 3 * NW, upd);
+        update_subtile(tb, i + NW, i + 3 * NW, upd);
         __builtin_amdgcn_sched_barrier(0);
       }
+      if (i < ntiles) update_subtile(ta, i, -1, upd);
+      __builtin_amdgcn_sched_barrier(0);
     } else {
       for (int i = wave; i < ntiles; i += NW) {
         update_subtile(ta, i, i + NW, upd);
@@ -699,8 +710,11 @@ fit_wide_kernel(WideArgs<real> a) {
     }
     // X does not depend on H, and this wave's first rows of W are final: request the next pass's first subtiles now
     if (it < a.max_iter) {
+      __builtin_amdgcn_sched_barrier(0);
       issue(ta, wave);
+      __builtin_amdgcn_sched_barrier(0);
       if constexpr (NSET > 1) issue(tb, wave + NW);
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (upd) {
       // per-wave record [W^T X | W^T W] over the wave's stages (idle between passes), fixed-order sum over the waves

@@ -44,7 +44,7 @@ def test_wide_shape_sweep_fp32(m, k, T):
     for layout in ("F", "C"):
         Xl = np.asfortranarray(X) if layout == "F" else np.ascontiguousarray(X)
         res = ms.fit_batched(Xl, W0, H0, max_iter=20, tol=0.0)
-        assert _last_kernel().startswith("fit_wide_kernel<float"), _last_kernel()
+        assert _last_kernel().startswith(("fit_wide_kernel<float", "fit_wide4_kernel<")), _last_kernel()
         assert int(res.n_iter[0]) == 20
         assert _rel(X, res.W[0], res.H[0], ref) <= TOL, (layout, m, k, T)
         assert abs(float(res.reconstruction_err[0]) - float(ref["reconstruction_err"])) / np.linalg.norm(X) <= TOL
@@ -120,7 +120,7 @@ def test_wide_ragged_batch(dtype):
         X, W0, H0 = _case(T, m, k, dtype, seed=70 + s)
         Xs.append(X), Ws.append(W0), Hs.append(H0)
     res = ms.fit_ragged(Xs, Ws, Hs, max_iter=25, tol=0.0)
-    assert _last_kernel().startswith("fit_wide_kernel")
+    assert _last_kernel().startswith(("fit_wide_kernel", "fit_wide4_kernel"))
     for b, T in enumerate(Ts):
         ref = orc.nmf_mu_fit(Xs[b], Ws[b], Hs[b], max_iter=25, tol=0.0)
         W = res.W[b].cpu().numpy()
@@ -289,7 +289,8 @@ def test_wide_row_sliced_path(dtype, m, k, T):
     rt = ms.fit_batched(X3, W3, out[1].H, max_iter=20, tol=0.0, update_H=False, handle=h)
     h.set_tuning(0, 0, 1)
     rt1 = ms.fit_batched(X3, W3, out[1].H, max_iter=20, tol=0.0, update_H=False, handle=h)
-    np.testing.assert_allclose(rt.W, rt1.W, rtol=1e-6 if dtype == np.float32 else 1e-12, atol=1e-9)
+    # (fp32, at most 8 components: the two paths are different formulations -- 16x16x4 slices vs fit_wide4_kernel -- equal to rounding)
+    np.testing.assert_allclose(rt.W, rt1.W, rtol=1e-4 if dtype == np.float32 else 1e-12, atol=1e-7 if dtype == np.float32 else 1e-9)
     # the library's own choice for one long matrix
     h.set_tuning(0, 0, 0)
     ms.fit_batched(X3[:1], W3[:1], H3[:1], max_iter=3, tol=0.0, handle=h)

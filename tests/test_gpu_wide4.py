@@ -1,0 +1,174 @@
+"""GPU parity of fit_wide4_kernel (nmf_wide4.hpp): fp32, 33..128 channels, at most 8 components, every contraction on
+v_mfma_f32_4x4x1 -- against the NumPy oracle through the host API, and against the 16x16x4 formulation it replaces
+(HIPNMF_WIDE4=0) on the same inputs."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from oracle import nmf_mu_oracle as orc
+from muscle_synergies_amd.synth import emg_matrix, random_init
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _rel(X, W, H, ref):
+    xn = np.linalg.norm(X.astype(np.float64))
+    wh = W.astype(np.float64) @ H.astype(np.float64)
+    wr = ref["W"].astype(np.float64) @ ref["H"].astype(np.float64)
+    return np.linalg.norm(wh - wr) / xn
+
+
+def _case(T, m, k, seed=0):
+    X = emg_matrix(seed, T=T, m=m, k_true=min(6, m), dtype=np.float32)
+    W0, H0 = random_init(X, k, seed)
+    return X, W0, H0
+
+
+def _handle(threads=0):
+    from muscle_synergies_amd import _lib
+
+    h = _lib.Handle(0)
+    h.set_tuning(threads, 0, 1)  # variant 1: one workgroup per matrix (a single long matrix would take the row-sliced path)
+    return h
+
+
+@pytest.mark.parametrize("m", [33, 48, 50, 64, 65, 96, 100, 128])
+@pytest.mark.parametrize("k", [1, 3, 4, 5, 8])
+def test_wide4_shape_sweep(m, k):
+    import muscle_synergies_amd as ms
+
+    for T, threads in ((1, 0), (15, 256), (16, 0), (17, 0), (250, 256), (1003, 0)):
+        h = _handle(threads)
+        X, W0, H0 = _case(T, m, k, seed=m * 100 + k + T)
+        ref = orc.nmf_mu_fit(X, W0, H0, max_iter=20, tol=0.0)
+        res = ms.fit_batched(np.ascontiguousarray(X), W0, H0, max_iter=20, tol=0.0, handle=h)
+        kern = h.last_kernel()
+        nw = 4 if threads == 256 else 12 if (k > 4 and m <= 64) else 8  # the library's own choice: three waves per SIMD where that instance exists
+        assert kern.startswith("fit_wide4_kernel<") and f",{nw}," in kern, kern
+        assert int(res.n_iter[0]) == 20
+        assert _rel(X, res.W[0], res.H[0], ref) <= TOL, (m, k, T)
+        assert abs(float(res.reconstruction_err[0]) - float(ref["reconstruction_err"])) / np.linalg.norm(X) <= TOL
+        np.testing.assert_allclose(res.W[0], ref["W"], rtol=5e-4, atol=1e-6)
+        np.testing.assert_allclose(res.H[0], ref["H"], rtol=5e-4, atol=1e-6)
+        assert (res.W[0] >= 0).all() and (res.H[0] >= 0).all()
+        va, vc = orc.vaf(X.astype(np.float64), ref["W"].astype(np.float64), ref["H"].astype(np.float64))
+        assert abs(res.vaf[0, 0] - va) <= TOL
+        np.testing.assert_allclose(res.vaf[0, 1:], vc, atol=5e-5)
+
+
+@pytest.mark.parametrize("m,k,T", [(64, 8, 9000), (128, 6, 6001), (48, 4, 20000), (96, 7, 5000)])
+@pytest.mark.parametrize("threads", [256, 512, 768])
+def test_wide4_rows_beyond_the_lds_cache(m, k, T, threads):
+    """Matrices longer than the W cache: the first rows live in LDS for the whole fit, the rest streams -- a batch, so that
+    both kinds of subtile run in every workgroup; and the same with the cache switched off."""
+    import muscle_synergies_amd as ms
+
+    X, W0, H0 = _case(T, m, k, seed=300)
+    ref = orc.nmf_mu_fit(X, W0, H0, max_iter=12, tol=0.0)
+    for lds in ("1", "0"):
+        env = dict(os.environ, HIPNMF_LDS_W=lds)
+        code = f"""
+import sys, numpy as np
+sys.path.insert(0, {ROOT!r})
+import muscle_synergies_amd as ms
+from muscle_synergies_amd import _lib
+from muscle_synergies_amd.synth import emg_matrix, random_init
+h = _lib.Handle(0); h.set_tuning({threads}, 0, 1)
+X = emg_matrix(300, T={T}, m={m}, k_true=min(6, {m}), dtype=np.float32); W0, H0 = random_init(X, {k}, 300)
+Xb = np.stack([X, X[::-1].copy(), X]); Wb = np.stack([W0, W0[::-1].copy(), W0]); Hb = np.stack([H0, H0, H0])
+r = ms.fit_batched(Xb, Wb, Hb, max_iter=12, tol=0.0, handle=h)
+assert h.last_kernel().startswith('fit_wide4_kernel<'), h.last_kernel()
+np.save(sys.argv[1], np.concatenate([r.W[0].ravel(), r.H[0].ravel(), r.W[2].ravel(), r.reconstruction_err[:1].astype(np.float32)]))
+"""
+        out = os.path.join(ROOT, "gpurun_out", f"w4_{m}_{k}_{threads}_{lds}.npy")
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        r = subprocess.run([sys.executable, "-c", code, out], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+        v = np.load(out)
+        W = v[: T * k].reshape(T, k)
+        H = v[T * k: T * k + k * m].reshape(k, m)
+        W2 = v[T * k + k * m: 2 * T * k + k * m].reshape(T, k)
+        assert _rel(X, W, H, ref) <= TOL, (lds,)
+        np.testing.assert_array_equal(W, W2)  # matrices 0 and 2 are the same problem: same bits, whatever ran beside them
+        assert abs(float(v[-1]) - float(ref["reconstruction_err"])) / np.linalg.norm(X) <= TOL
+
+
+@pytest.mark.parametrize("m,k", [(64, 8), (40, 3), (128, 5)])
+def test_wide4_stop_rule_regularisation_transform(m, k):
+    import muscle_synergies_amd as ms
+
+    h = _handle()
+    X, W0, H0 = _case(700, m, k, seed=41)
+    for tol in (1e-3, 3e-4):
+        ref = orc.nmf_mu_fit(X, W0, H0, max_iter=300, tol=tol)
+        res = ms.fit_batched(X, W0, H0, max_iter=300, tol=tol, handle=h)
+        assert h.last_kernel().startswith("fit_wide4_kernel<")
+        assert int(res.n_iter[0]) == ref["n_iter"], (int(res.n_iter[0]), ref["n_iter"])
+        assert _rel(X, res.W[0], res.H[0], ref) <= TOL
+    regs = dict(l1_reg_W=0.02, l1_reg_H=0.03, l2_reg_W=0.05, l2_reg_H=0.01)
+    Wr, Hr, _ = orc.fit_multiplicative_update(X, W0.copy(), H0.copy(), max_iter=30, tol=0.0, **regs)
+    res = ms.fit_batched(X, W0, H0, max_iter=30, tol=0.0, handle=h, **regs)
+    assert _rel(X, res.W[0], res.H[0], {"W": Wr, "H": Hr}) <= TOL
+    Wt = np.full_like(W0, np.sqrt(X.mean() / k))
+    Wt_ref, _, _ = orc.fit_multiplicative_update(X, Wt.copy(), Hr.copy(), max_iter=25, tol=0.0, update_H=False)
+    res_t = ms.fit_batched(X, Wt, Hr, max_iter=25, tol=0.0, update_H=False, handle=h)
+    np.testing.assert_array_equal(res_t.H[0], Hr)
+    np.testing.assert_allclose(res_t.W[0], Wt_ref, rtol=5e-4, atol=1e-7)
+
+
+def test_wide4_ragged_batch_and_padded_rows():
+    """Trials of unequal length (hipnmf_fit_ragged_*), and a row-major X whose rows are padded (ldx > n_features)."""
+    import torch
+
+    import muscle_synergies_amd as ms
+
+    m, k = 64, 7
+    h = _handle()
+    Ts = [17, 300, 64, 1025, 5]
+    cases = [_case(T, m, k, seed=70 + s) for s, T in enumerate(Ts)]
+    res = ms.fit_ragged([c[0] for c in cases], [c[1] for c in cases], [c[2] for c in cases], max_iter=25, tol=0.0, handle=h)
+    assert h.last_kernel().startswith("fit_wide4_kernel<"), h.last_kernel()
+    for s, (X, W0, H0) in enumerate(cases):
+        ref = orc.nmf_mu_fit(X, W0, H0, max_iter=25, tol=0.0)
+        assert _rel(X, res.W[s].cpu().numpy(), res.H[s].cpu().numpy(), ref) <= TOL, s
+    X, W0, H0 = _case(333, 40, 6, seed=5)
+    buf = torch.zeros((1, 333, 48), device="cuda")
+    buf[0, :, :40] = torch.from_numpy(X).cuda()
+    r = ms.fit_batched(buf[:, :, :40], torch.from_numpy(W0).cuda()[None], torch.from_numpy(H0).cuda()[None], max_iter=20, tol=0.0, handle=h)
+    assert h.last_kernel().startswith("fit_wide4_kernel<")
+    ref = orc.nmf_mu_fit(X, W0, H0, max_iter=20, tol=0.0)
+    assert _rel(X, r.W[0].cpu().numpy(), r.H[0].cpu().numpy(), ref) <= TOL
+
+
+def test_wide4_agrees_with_the_16x16x4_formulation_and_is_deterministic():
+    """Same batch through both formulations (separate processes: the choice is read once per process): W H equal to rounding;
+    two runs of the 4x4x1 kernel bitwise equal."""
+    code = f"""
+import sys, numpy as np, torch
+sys.path.insert(0, {ROOT!r})
+import muscle_synergies_amd as ms
+from muscle_synergies_amd import _lib
+from muscle_synergies_amd.synth import emg_batch_torch
+X, W0, H0 = emg_batch_torch(300, T=1500, m=64, k=8, k_true=6, device='cuda:0', seed=9)
+Xr = X.transpose(1, 2).contiguous()
+a = ms.fit_batched(Xr, W0, H0, max_iter=60, tol=0.0)
+b = ms.fit_batched(Xr, W0, H0, max_iter=60, tol=0.0)
+assert torch.equal(a.W, b.W) and torch.equal(a.H, b.H)
+print('KERNEL', _lib.get_handle(0).last_kernel())
+np.save(sys.argv[1], torch.bmm(a.W, a.H).cpu().numpy())
+"""
+    outs = []
+    for flag in ("1", "0"):
+        out = os.path.join(ROOT, "gpurun_out", f"w4_vs_w16_{flag}.npy")
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        r = subprocess.run([sys.executable, "-c", code, out], env=dict(os.environ, HIPNMF_WIDE4=flag), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+        assert ("KERNEL fit_wide4_kernel<" if flag == "1" else "KERNEL fit_wide_kernel<float,64,16") in r.stdout, r.stdout
+        outs.append(np.load(out))
+    scale = np.abs(outs[1]).max()
+    assert np.abs(outs[0] - outs[1]).max() <= 2e-5 * scale
