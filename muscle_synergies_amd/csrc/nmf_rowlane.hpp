@@ -699,6 +699,15 @@ __device__ __forceinline__ void buf_store4(rsrc_t r, unsigned voff, unsigned sof
   __builtin_amdgcn_raw_buffer_store_b128(u, r, voff, soff, 0);
 }
 
+// Cache policy of the time-shard pass (buf_load: 2 = non-temporal).  A shard (2.6 GB of X per 25M rows) is read once per
+// iteration and nothing of it survives in any cache until the next one.  tools/shard_bench.py, 2.5e7 rows, k = 5, per pass:
+// default policy 0.541 ms (4.81 TB/s algorithmic), X non-temporal 0.526 ms (4.94), X and W non-temporal 0.537 ms.
+#ifndef HIPNMF_SHARD_X_AUX
+#define HIPNMF_SHARD_X_AUX 2
+#endif
+#ifndef HIPNMF_SHARD_W_AUX
+#define HIPNMF_SHARD_W_AUX 0
+#endif
 template <int K>
 __global__ void __launch_bounds__(256) slice_pass_rowlane_kernel(SolveArgs<float> a) {
   using C = Cfg<float, 1, 16, K>;
@@ -745,14 +754,14 @@ __global__ void __launch_bounds__(256) slice_pass_rowlane_kernel(SolveArgs<float
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       if (j < m) {
-        buf_load<float, R>(xr, v, sb + (unsigned)j * ldx_b, x4[j]);
+        buf_load<float, R, (HIPNMF_SHARD_X_AUX)>(xr, v, sb + (unsigned)j * ldx_b, x4[j]);
       } else {
 #pragma unroll
         for (int r = 0; r < R; ++r) x4[j][r] = 0.f;
       }
     }
 #pragma unroll
-    for (int c = 0; c < K; ++c) buf_load<float, R>(wr, v, sb + (unsigned)c * ldw_b, w4[c]);
+    for (int c = 0; c < K; ++c) buf_load<float, R, (HIPNMF_SHARD_W_AUX)>(wr, v, sb + (unsigned)c * ldw_b, w4[c]);
     static_for<R>([&](auto RR) {
       constexpr int r = decltype(RR)::value;
       float x[16], w[K];

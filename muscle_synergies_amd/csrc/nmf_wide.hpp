@@ -440,10 +440,25 @@ fit_wide_kernel(WideArgs<real> a) {
     const real* xrow = xs + j * SX + g * VEC;
     const real* hrow = sH + ar * SX + g * VEC;
     if constexpr (!HREG) asm volatile("" : "+v"(hrow));  // keeps the H reads inside the subtile loop
+    // HOIST: request every LDS operand of a phase before its first product.  Left to itself the compiler reads one, waits for
+    // it, multiplies, reads the next ... and every wait exposes a full LDS round trip (8 per subtile); done where the extra
+    // live registers (16 per phase at 64 fp32 channels) fit the instance's budget
+    constexpr bool HOIST = MP * (int)(sizeof(real) / 4) <= 64;
+    real xball[HOIST ? NS1 : 1][VEC];
+    if constexpr (HOIST) {
+#pragma unroll
+      for (int s = 0; s < NS1; ++s) wide_lds_read<real, VEC>(xrow + s * 4 * VEC, xball[s]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int s = 0; s < NS1; ++s) {
       real xb[VEC];
-      wide_lds_read<real, VEC>(xrow + s * 4 * VEC, xb);
+      if constexpr (HOIST) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) xb[e] = xball[s][e];
+      } else {
+        wide_lds_read<real, VEC>(xrow + s * 4 * VEC, xb);
+      }
 #pragma unroll
       for (int kb = 0; kb < NKB; ++kb) {
         real ha[VEC];
@@ -517,11 +532,23 @@ fit_wide_kernel(WideArgs<real> a) {
         }
       // W^T X: B operand lane (channel j, g), k-step s <-> X[row 4 g + s][16 cb + j]
       const real* xcol = xs + 4 * g * SX + j;
+      real xcall[HOIST ? NCB : 1][4];
+      if constexpr (HOIST) {
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) xcall[cb][s] = xcol[s * SX + 16 * cb];
+        __builtin_amdgcn_sched_barrier(0);
+      }
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-          const real xb = xcol[s * SX + 16 * cb];
+          real xb;
+          if constexpr (HOIST)
+            xb = xcall[cb][s];
+          else
+            xb = xcol[s * SX + 16 * cb];
 #pragma unroll
           for (int kb = 0; kb < NKB; ++kb) accA[kb][cb] = M::mma(wa[kb][s], xb, accA[kb][cb]);
         }

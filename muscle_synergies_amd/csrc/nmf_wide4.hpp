@@ -280,14 +280,19 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
 #pragma unroll
       for (int cg = 0; cg < KQ; ++cg) wa[cg] = wst[blk * SW + 4 * cg + ii];
       // W^T X: lanes are channels, the row's W broadcast from block s
+      // (all sixteen rows are requested before the first product: left to itself the compiler reads two, waits, multiplies, reads
+      //  the next two ... and every wait exposes a full LDS round trip)
       const float* xcol = xs + lane;
 #pragma unroll
       for (int h = 0; h < NH; ++h) {
+        float xc[16];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) xc[s] = xcol[s * SX + 64 * h];
+        __builtin_amdgcn_sched_barrier(0);
         static_for<16>([&](auto S_) {
           constexpr int s = decltype(S_)::value;
-          const float xc = xcol[s * SX + 64 * h];
 #pragma unroll
-          for (int cg = 0; cg < KQ; ++cg) accA[h][cg] = w4_mfma<4, s>(wa[cg], xc, accA[h][cg]);
+          for (int cg = 0; cg < KQ; ++cg) accA[h][cg] = w4_mfma<4, s>(wa[cg], xc[s], accA[h][cg]);
         });
       }
 #pragma unroll
