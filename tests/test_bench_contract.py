@@ -39,6 +39,10 @@ def test_wide_shapes_report_against_the_hbm_line():
     assert r["algorithmic_bytes_per_unit"] == 4 * 10_000 * (64 + 16)
     assert abs(r["achieved"] - 3_200_000 * 40960 / 26.6e-3 / 1e9) < 1e-6 and 0 < r["frac"] < 1
     assert r["matrix_pipe"]["issued_tflops"] > r["matrix_pipe"]["achieved_tflops_useful"]
+    r4 = bench.compute_roofline("fit_wide4_kernel<64,2,12,2>", 26.6, 1024 * 40, 10_000, 64, 8)  # 4x4x1 tiles: no padding at 64 x 8
+    assert r4["bound"] == "hbm" and abs(r4["matrix_pipe"]["issued_tflops"] - r4["matrix_pipe"]["achieved_tflops_useful"]) < 1e-9
+    r5 = bench.compute_roofline("fit_wide4_kernel<48,2,12,2>", 26.6, 1024 * 40, 10_000, 40, 6)
+    assert r5["matrix_pipe"]["issued_tflops"] > r5["matrix_pipe"]["achieved_tflops_useful"]
 
 
 def test_committed_traffic_measurements_name_their_kernel_and_source():
@@ -51,7 +55,7 @@ def test_committed_traffic_measurements_name_their_kernel_and_source():
     for e in entries:
         for key in ("kernel", "batch", "iters", "T", "m", "k", "x_layout", "l2_fabric_bytes_per_launch", "source_commit", "method"):
             assert key in e, key
-        assert e["kernel"].startswith(("fit_persistent_kernel<", "fit_rowlane_kernel<", "fit_wide_kernel<"))
+        assert e["kernel"].startswith(("fit_persistent_kernel<", "fit_rowlane_kernel<", "fit_wide_kernel<", "fit_wide4_kernel<"))
     assert bench._traffic("no-such-kernel", batch=1) is None
 
 
