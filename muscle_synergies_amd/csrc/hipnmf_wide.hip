@@ -37,6 +37,8 @@ const WideKernel<double>* wide_kernel_f64(int m, int k, int nw) {
 // fp32, 33..128 channels, at most 8 components: the v_mfma_f32_4x4x1 formulation (nmf_wide4.hpp), which pads the components to
 // a multiple of 4 instead of 16
 const WideKernel<float>* wide4_kernel_f32(int m, int k, int nw) {
+  // (9..12 components as three component quads were built and measured too: 222..234 registers, two waves per SIMD, and no
+  //  faster than the 16x16x4 kernel -- 4096 x (64 x 2 500), k = 12: 6.71 vs 6.95 M matrix-it/s; 48 channels, k = 10: 7.64 vs 8.23)
   if (m <= 32 || m > 128 || k > 8) return nullptr;
   const int MP = m <= 48 ? 48 : m <= 64 ? 64 : m <= 96 ? 96 : 128;
   const int KQ = k <= 4 ? 1 : 2;
@@ -52,6 +54,12 @@ const WideKernel<real>* pick4(int, int, int) {
 template <>
 const WideKernel<float>* pick4<float>(int m, int k, int nw) {
   return wide4_kernel_f32(m, k, nw);
+}
+// float64, 33..64 channels, at most 8 components: v_mfma_f64_4x4x4 (nmf_wide4d.hpp); 4 or 8 waves
+template <>
+const WideKernel<double>* pick4<double>(int m, int k, int nw) {
+  if (m <= 32 || m > 64 || k > 8) return nullptr;
+  return wide4d_kernel_f64(m <= 48 ? 48 : 64, k <= 4 ? 1 : 2, nw == 4 ? 4 : 8);
 }
 template <typename real>
 const WideKernel<real>* pick(int m, int k, int nw);

@@ -172,8 +172,11 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void* base, unsigned bytes) {
 template <typename real, int N, int AUX = 0>
 __device__ __forceinline__ void buf_load(rsrc_t r, unsigned voff, unsigned soff, real (&out)[N]) {
   constexpr int BYTES = (int)sizeof(real) * N;
-  static_assert(BYTES == 4 || BYTES == 8 || BYTES == 16 || BYTES == 32, "unsupported vector width");
-  if constexpr (BYTES == 4) {
+  static_assert(BYTES == 4 || BYTES == 8 || BYTES == 12 || BYTES == 16 || BYTES == 32, "unsupported vector width");
+  if constexpr (BYTES == 12) {
+    const auto v = __builtin_amdgcn_raw_buffer_load_b96(r, voff, soff, AUX);
+    __builtin_memcpy(&out, &v, 12);
+  } else if constexpr (BYTES == 4) {
     const unsigned v = __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, AUX);
     __builtin_memcpy(&out, &v, 4);
   } else if constexpr (BYTES == 8) {

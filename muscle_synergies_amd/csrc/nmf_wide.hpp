@@ -112,13 +112,19 @@ struct WideCfg {
   __host__ __device__ static constexpr size_t smem_bytes(int nw) { return sizeof(real) * (size_t)(COMMON + nw * PERWAVE); }
 };
 
+// alignment the callers guarantee for an N-element piece: its size, capped at 16 bytes (12-byte pieces: 4)
+template <typename real, int N>
+constexpr size_t wide_piece_align() {
+  constexpr size_t bytes = N * sizeof(real);
+  return bytes >= 16 ? 16 : (bytes & (~bytes + 1));
+}
 template <typename real, int N>
 __device__ __forceinline__ void wide_lds_read(const real* p, real (&out)[N]) {
-  __builtin_memcpy(out, __builtin_assume_aligned(p, N * sizeof(real) >= 16 ? 16 : N * sizeof(real)), N * sizeof(real));
+  __builtin_memcpy(out, __builtin_assume_aligned(p, wide_piece_align<real, N>()), N * sizeof(real));
 }
 template <typename real, int N>
 __device__ __forceinline__ void wide_lds_write(real* p, const real (&in)[N]) {
-  __builtin_memcpy(__builtin_assume_aligned(p, N * sizeof(real) >= 16 ? 16 : N * sizeof(real)), in, N * sizeof(real));
+  __builtin_memcpy(__builtin_assume_aligned(p, wide_piece_align<real, N>()), in, N * sizeof(real));
 }
 // 16 / 32-byte buffer store of four consecutive elements
 template <typename real>

@@ -53,7 +53,7 @@ struct Wide4Cfg {
   static constexpr int REC = KP * MP + KP * KP;  // per-wave record of [W^T X | W^T W]
   static constexpr int PERWAVE = (XS + WS > REC ? XS + WS : REC);
   static constexpr int COMMON = KP * SH + KP * KP + KP * MP + KP * KP + 2 * MP + 8;
-  static_assert(MP % 16 == 0 && MP >= 16 && MP <= 128 && (KQ == 1 || KQ == 2 || KQ == 4), "unsupported wide4 shape");
+  static_assert(MP % 16 == 0 && MP >= 16 && MP <= 128 && KQ >= 1 && KQ <= 4, "unsupported wide4 shape");
   static_assert(SX >= 64 * NH, "the lanes-are-channels reads stay inside a stage row");
   __host__ __device__ static constexpr size_t smem_bytes(int nw) { return sizeof(float) * (size_t)(COMMON + nw * PERWAVE); }
 };
@@ -78,6 +78,11 @@ __device__ __forceinline__ void w4_store(rsrc_t r, unsigned voff, const float (&
     u32x2 u;
     __builtin_memcpy(&u, &v, 8);
     __builtin_amdgcn_raw_buffer_store_b64(u, r, voff, 0u, 0);
+  } else if constexpr (N == 3) {
+    using u32x3 = unsigned int __attribute__((ext_vector_type(3)));
+    u32x3 u;
+    __builtin_memcpy(&u, &v, 12);
+    __builtin_amdgcn_raw_buffer_store_b96(u, r, voff, 0u, 0);
   } else {
     using u32x4 = unsigned int __attribute__((ext_vector_type(4)));
     u32x4 u;

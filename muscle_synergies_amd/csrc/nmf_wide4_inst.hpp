@@ -4,6 +4,7 @@
 #include <cstdio>
 
 #include "nmf_wide4.hpp"
+#include "nmf_wide4d.hpp"
 #include "nmf_wide_decl.hpp"
 
 namespace hipnmf {
@@ -60,6 +61,35 @@ const WideKernel<float>* wide4_table_lookup(int MP, int KQ, int NW) {
   const WideKernel<float>* w = &t[q][KQ - 1][NW / 4 - 1];
   return w->fn ? w : nullptr;
 }
+// float64 (nmf_wide4d.hpp): 48 / 64 channels, KQ = 1, 2, {4, 8} waves
+#ifndef HIPNMF_WIDE4D_NSET
+#define HIPNMF_WIDE4D_NSET 1
+#endif
+template <int MP, int KQ, int NW, int NSET>
+const char* wide4d_kernel_name() {
+  static char buf[96];
+  static const bool once = [] {
+    snprintf(buf, sizeof(buf), "fit_wide4d_kernel<%d,%d,%d,%d>", MP, KQ, NW, NSET);
+    return true;
+  }();
+  (void)once;
+  return buf;
+}
+template <int MP, int KQ, int NW>
+WideKernel<double> make_wide4d_kernel() {
+  WideKernel<double> w;
+  constexpr int NSET = HIPNMF_WIDE4D_NSET;
+  w.fn = fit_wide4d_kernel<MP, KQ, NW, NSET>;
+  w.fn_kl = nullptr;
+  w.name_kl = "";
+  w.smem = Wide4dCfg<MP, KQ>::smem_bytes(NW);
+  w.MP = MP;
+  w.KP = 4 * KQ;
+  w.NW = NW;
+  w.name = wide4d_kernel_name<MP, KQ, NW, NSET>();
+  return w;
+}
+const WideKernel<double>* wide4d_kernel_f64(int MP, int KQ, int NW);   // MP = 48, 64
 const WideKernel<float>* wide4_kernel_f32_lo(int MP, int KQ, int NW);  // MP = 48, 64
 const WideKernel<float>* wide4_kernel_f32_hi(int MP, int KQ, int NW);  // MP = 96, 128
 }  // namespace hipnmf

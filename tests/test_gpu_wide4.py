@@ -4,6 +4,7 @@ v_mfma_f32_4x4x1 -- against the NumPy oracle through the host API, and against t
 import os
 import subprocess
 import sys
+import tempfile
 
 import numpy as np
 import pytest
@@ -48,7 +49,8 @@ def test_wide4_shape_sweep(m, k):
         ref = orc.nmf_mu_fit(X, W0, H0, max_iter=20, tol=0.0)
         res = ms.fit_batched(np.ascontiguousarray(X), W0, H0, max_iter=20, tol=0.0, handle=h)
         kern = h.last_kernel()
-        nw = 4 if threads == 256 else 12 if (k > 4 and m <= 64) else 8  # the library's own choice: three waves per SIMD where that instance exists
+        # the library's own choice of waves: three per SIMD where that instance exists (5..8 components up to 64 channels)
+        nw = 4 if threads == 256 else 12 if (4 < k <= 8 and m <= 64) else 8
         assert kern.startswith("fit_wide4_kernel<") and f",{nw}," in kern, kern
         assert int(res.n_iter[0]) == 20
         assert _rel(X, res.W[0], res.H[0], ref) <= TOL, (m, k, T)
@@ -85,11 +87,11 @@ r = ms.fit_batched(Xb, Wb, Hb, max_iter=12, tol=0.0, handle=h)
 assert h.last_kernel().startswith('fit_wide4_kernel<'), h.last_kernel()
 np.save(sys.argv[1], np.concatenate([r.W[0].ravel(), r.H[0].ravel(), r.W[2].ravel(), r.reconstruction_err[:1].astype(np.float32)]))
 """
-        out = os.path.join(ROOT, "gpurun_out", f"w4_{m}_{k}_{threads}_{lds}.npy")
-        os.makedirs(os.path.dirname(out), exist_ok=True)
+        out = os.path.join(tempfile.gettempdir(), f"w4_{os.getpid()}_{m}_{k}_{threads}_{lds}.npy")
         r = subprocess.run([sys.executable, "-c", code, out], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
         v = np.load(out)
+        os.remove(out)
         W = v[: T * k].reshape(T, k)
         H = v[T * k: T * k + k * m].reshape(k, m)
         W2 = v[T * k + k * m: 2 * T * k + k * m].reshape(T, k)
@@ -164,11 +166,99 @@ np.save(sys.argv[1], torch.bmm(a.W, a.H).cpu().numpy())
 """
     outs = []
     for flag in ("1", "0"):
-        out = os.path.join(ROOT, "gpurun_out", f"w4_vs_w16_{flag}.npy")
-        os.makedirs(os.path.dirname(out), exist_ok=True)
+        out = os.path.join(tempfile.gettempdir(), f"w4_vs_w16_{os.getpid()}_{flag}.npy")
         r = subprocess.run([sys.executable, "-c", code, out], env=dict(os.environ, HIPNMF_WIDE4=flag), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
         assert ("KERNEL fit_wide4_kernel<" if flag == "1" else "KERNEL fit_wide_kernel<float,64,16") in r.stdout, r.stdout
         outs.append(np.load(out))
+        os.remove(out)
     scale = np.abs(outs[1]).max()
     assert np.abs(outs[0] - outs[1]).max() <= 2e-5 * scale
+
+
+# ------------------------------------------------------------------------------------------------ float64: fit_wide4d_kernel
+def _case64(T, m, k, seed=0):
+    X = emg_matrix(seed, T=T, m=m, k_true=min(6, m), dtype=np.float64)
+    W0, H0 = random_init(X, k, seed)
+    return X, W0, H0
+
+
+@pytest.mark.parametrize("m", [33, 48, 50, 64])
+@pytest.mark.parametrize("k", [1, 3, 4, 5, 8])
+def test_wide4d_shape_sweep_fp64(m, k):
+    """float64 (what a DataFrame carries): 33..64 channels, at most 8 components on v_mfma_f64_4x4x4 (nmf_wide4d.hpp)."""
+    import muscle_synergies_amd as ms
+
+    for T, threads in ((1, 0), (15, 256), (16, 0), (17, 0), (250, 256), (1003, 0)):
+        h = _handle(threads)
+        X, W0, H0 = _case64(T, m, k, seed=m * 100 + k + T)
+        ref = orc.nmf_mu_fit(X, W0, H0, max_iter=40, tol=0.0)
+        for layout in ("C", "F"):
+            Xl = np.ascontiguousarray(X) if layout == "C" else np.asfortranarray(X)
+            res = ms.fit_batched(Xl, W0, H0, max_iter=40, tol=0.0, handle=h)
+            kern = h.last_kernel()
+            assert kern.startswith("fit_wide4d_kernel<") and f",{4 if threads == 256 else 8}," in kern, kern
+            np.testing.assert_allclose(res.W[0], ref["W"], rtol=1e-9, atol=1e-13)
+            np.testing.assert_allclose(res.H[0], ref["H"], rtol=1e-9, atol=1e-13)
+            np.testing.assert_allclose(res.reconstruction_err[0], ref["reconstruction_err"], rtol=1e-9, atol=1e-12 * np.linalg.norm(X))
+            va, vc = orc.vaf(X, ref["W"], ref["H"])
+            assert abs(res.vaf[0, 0] - va) <= 1e-10
+            np.testing.assert_allclose(res.vaf[0, 1:], vc, atol=1e-10)
+
+
+@pytest.mark.parametrize("m,k,T", [(64, 8, 5000), (48, 4, 9000), (40, 7, 3001)])
+@pytest.mark.parametrize("threads", [256, 512])
+def test_wide4d_rows_beyond_the_lds_cache_stop_rule_and_batch(m, k, T, threads):
+    import muscle_synergies_amd as ms
+
+    h = _handle(threads)
+    cases = [_case64(T - 37 * s, m, k, seed=500 + s) for s in range(3)]
+    Tm = min(c[0].shape[0] for c in cases)
+    Xb = np.stack([c[0][:Tm] for c in cases]); Wb = np.stack([c[1][:Tm] for c in cases]); Hb = np.stack([c[2] for c in cases])
+    res = ms.fit_batched(Xb, Wb, Hb, max_iter=25, tol=0.0, handle=h)
+    assert h.last_kernel().startswith("fit_wide4d_kernel<")
+    for s in range(3):
+        ref = orc.nmf_mu_fit(Xb[s], Wb[s], Hb[s], max_iter=25, tol=0.0)
+        np.testing.assert_allclose(res.W[s], ref["W"], rtol=1e-9, atol=1e-13)
+        np.testing.assert_allclose(res.H[s], ref["H"], rtol=1e-9, atol=1e-13)
+    X, W0, H0 = cases[0][0][:700], cases[0][1][:700], cases[0][2]
+    for tol in (1e-3, 2e-4):
+        ref = orc.nmf_mu_fit(X, W0, H0, max_iter=400, tol=tol)
+        r = ms.fit_batched(X, W0, H0, max_iter=400, tol=tol, handle=h)
+        assert int(r.n_iter[0]) == ref["n_iter"]
+        np.testing.assert_allclose(r.W[0], ref["W"], rtol=1e-9, atol=1e-13)
+    regs = dict(l1_reg_W=0.02, l1_reg_H=0.03, l2_reg_W=0.05, l2_reg_H=0.01)
+    Wr, Hr, _ = orc.fit_multiplicative_update(X, W0.copy(), H0.copy(), max_iter=30, tol=0.0, **regs)
+    r = ms.fit_batched(X, W0, H0, max_iter=30, tol=0.0, handle=h, **regs)
+    np.testing.assert_allclose(r.W[0], Wr, rtol=1e-9, atol=1e-13)
+    np.testing.assert_allclose(r.H[0], Hr, rtol=1e-9, atol=1e-13)
+    Wt = np.full_like(W0, np.sqrt(X.mean() / k))
+    Wt_ref, _, _ = orc.fit_multiplicative_update(X, Wt.copy(), Hr.copy(), max_iter=25, tol=0.0, update_H=False)
+    rt = ms.fit_batched(X, Wt, Hr, max_iter=25, tol=0.0, update_H=False, handle=h)
+    np.testing.assert_array_equal(rt.H[0], Hr)
+    np.testing.assert_allclose(rt.W[0], Wt_ref, rtol=1e-9, atol=1e-13)
+
+
+def test_wide4d_ragged_and_find_synergies_float64_frame():
+    """Trials of unequal length in float64, and the reference's own call on a 64-channel float64 DataFrame: no fallback."""
+    import warnings
+
+    import pandas as pd
+
+    import muscle_synergies_amd as ms
+
+    h = _handle()
+    m, k = 64, 6
+    Ts = [17, 300, 64, 1025, 5]
+    cases = [_case64(T, m, k, seed=90 + s) for s, T in enumerate(Ts)]
+    res = ms.fit_ragged([c[0] for c in cases], [c[1] for c in cases], [c[2] for c in cases], max_iter=25, tol=0.0, handle=h)
+    assert h.last_kernel().startswith("fit_wide4d_kernel<"), h.last_kernel()
+    for s, (X, W0, H0) in enumerate(cases):
+        ref = orc.nmf_mu_fit(X, W0, H0, max_iter=25, tol=0.0)
+        np.testing.assert_allclose(res.W[s].cpu().numpy(), ref["W"], rtol=1e-9, atol=1e-13)
+    X = emg_matrix(3, T=900, m=64, k_true=5, dtype=np.float64)
+    df = pd.DataFrame(X, columns=[f"ch{i}" for i in range(64)])
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", RuntimeWarning)
+        out = ms.find_synergies(df, 5, solver="mu", max_iter=60, tol=0.0, init="random", random_state=0)
+    assert out.model.components_.dtype == np.float64
