@@ -65,7 +65,7 @@ def test_wide_shape_sweep_fp64(m, k, T):
     for layout in ("F", "C"):
         Xl = np.asfortranarray(X) if layout == "F" else np.ascontiguousarray(X)
         res = ms.fit_batched(Xl, W0, H0, max_iter=40, tol=0.0)
-        assert _last_kernel().startswith("fit_wide_kernel<double"), _last_kernel()
+        assert _last_kernel().startswith(("fit_wide_kernel<double", "fit_wide4d_kernel<")), _last_kernel()
         np.testing.assert_allclose(res.W[0], ref["W"], rtol=1e-9, atol=1e-13)
         np.testing.assert_allclose(res.H[0], ref["H"], rtol=1e-9, atol=1e-13)
         np.testing.assert_allclose(res.reconstruction_err[0], ref["reconstruction_err"], rtol=1e-9)
@@ -164,7 +164,7 @@ def test_wide_find_synergies_does_not_fall_back():
         warnings.simplefilter("error", RuntimeWarning)  # the fallback announces itself with a RuntimeWarning
         res = ms.find_synergies(df, 10, solver="mu", max_iter=60, tol=0.0, init="nndsvda", random_state=0)
     assert isinstance(res.model, HipNMF)
-    assert _last_kernel().startswith("fit_wide_kernel<double")
+    assert _last_kernel().startswith(("fit_wide_kernel<double", "fit_wide4d_kernel<"))
     assert res.components.shape == (10, 64)
     from muscle_synergies_amd.init import initialize_nmf
 
