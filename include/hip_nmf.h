@@ -100,16 +100,18 @@ const char* hipnmf_last_kernel(hipnmf_handle* h);
  * stream) by the time-sharded solver so that kernels and RCCL collectives are ordered by the stream alone.
  * Only the shard entry points honour it; hipnmf_fit_batched_* always returns with results ready. */
 int hipnmf_set_async(hipnmf_handle* h, int enable);
-/* Tuning knobs (0 = library default): threads per workgroup (256/512/768/1024; 768 exists for fit_wide4_kernel only, elsewhere it means 512), max row slices per matrix, and the
+/* Tuning knobs (0 = library default): threads per workgroup (256 / 512 / 768 / 1024), max row slices per matrix, and the
  * solver path: 0 chosen by the library, 1 one persistent workgroup per matrix, 2 row-sliced launches,
  * 3 cooperative multi-workgroup kernel (few long matrices; HIPNMF_ERR_UNSUPPORTED when not applicable),
  * 4 / 5 = 1 with the kernel instance pinned: 4 fit_persistent_kernel (VALU contractions), 5 fit_rowlane_kernel
  * (X H^T and W H H^T on the f32 matrix pipe; fp32, 9..16 channels, else HIPNMF_ERR_UNSUPPORTED),
  * 6 fit_small_kernel (one wave per matrix, n_samples <= 256; HIPNMF_ERR_UNSUPPORTED otherwise; picked automatically).
- * Wide shapes (n_features > 32 or n_components > 8: fit_wide_kernel, every contraction on v_mfma_*_16x16x4; the library
- * also routes float64 17..32 channels with k >= 6 there): variants 0, 1 (= 4) and 2 exist -- 2 = rows sliced over the chip,
- * Frobenius loss and uniform batches only --, threads = 256 / 512 pins the instance (two workgroups per CU / one with
- * the larger W cache); 3, 5, 6 answer HIPNMF_ERR_UNSUPPORTED. */
+ * Wide shapes (n_features > 32 or n_components > 8: fit_wide_kernel, every contraction on v_mfma_*_16x16x4; at most 8
+ * components with the Frobenius loss: fit_wide4_kernel / fit_wide4d_kernel on v_mfma_f32_4x4x1 / v_mfma_f64_4x4x4; the
+ * library also routes float64 17..32 channels with k >= 6 there): variants 0, 1 (= 4) and 2 exist -- 2 = rows sliced over
+ * the chip, Frobenius loss and uniform batches only --, threads = 256 / 512 / 768 pins the instance (two workgroups per
+ * CU / one with the larger W cache / three waves per SIMD, fit_wide4_kernel up to 64 channels only); 3, 5, 6 answer
+ * HIPNMF_ERR_UNSUPPORTED. */
 int hipnmf_set_tuning(hipnmf_handle* h, int threads, int max_slices, int variant);
 
 /* ---- batched fit: replaces NMF(solver='mu').fit_transform / .transform for B matrices ------------- */

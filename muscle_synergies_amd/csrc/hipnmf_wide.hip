@@ -55,10 +55,11 @@ template <>
 const WideKernel<float>* pick4<float>(int m, int k, int nw) {
   return wide4_kernel_f32(m, k, nw);
 }
-// float64, 33..64 channels, at most 8 components: v_mfma_f64_4x4x4 (nmf_wide4d.hpp); 4 or 8 waves
+// float64, 33..128 channels, at most 8 components: v_mfma_f64_4x4x4 (nmf_wide4d.hpp); 4 or 8 waves up to 64 channels, 4 beyond
 template <>
 const WideKernel<double>* pick4<double>(int m, int k, int nw) {
-  if (m <= 32 || m > 64 || k > 8) return nullptr;
+  if (m <= 32 || m > 128 || k > 8) return nullptr;
+  if (m > 64) return wide4d_kernel_f64_hi(m <= 96 ? 96 : 128, k <= 4 ? 1 : 2, 4);  // one wave per SIMD, 256 threads
   return wide4d_kernel_f64(m <= 48 ? 48 : 64, k <= 4 ? 1 : 2, nw == 4 ? 4 : 8);
 }
 template <typename real>

@@ -65,11 +65,11 @@ const WideKernel<float>* wide4_table_lookup(int MP, int KQ, int NW) {
 #ifndef HIPNMF_WIDE4D_NSET
 #define HIPNMF_WIDE4D_NSET 1
 #endif
-template <int MP, int KQ, int NW, int NSET>
+template <int MP, int KQ, int NW, int NSET, int WPE>
 const char* wide4d_kernel_name() {
   static char buf[96];
   static const bool once = [] {
-    snprintf(buf, sizeof(buf), "fit_wide4d_kernel<%d,%d,%d,%d>", MP, KQ, NW, NSET);
+    snprintf(buf, sizeof(buf), "fit_wide4d_kernel<%d,%d,%d,%d,%d>", MP, KQ, NW, NSET, WPE);
     return true;
   }();
   (void)once;
@@ -79,17 +79,19 @@ template <int MP, int KQ, int NW>
 WideKernel<double> make_wide4d_kernel() {
   WideKernel<double> w;
   constexpr int NSET = HIPNMF_WIDE4D_NSET;
-  w.fn = fit_wide4d_kernel<MP, KQ, NW, NSET>;
+  constexpr int WPE = MP <= 64 ? 2 : 1;
+  w.fn = fit_wide4d_kernel<MP, KQ, NW, NSET, WPE>;
   w.fn_kl = nullptr;
   w.name_kl = "";
   w.smem = Wide4dCfg<MP, KQ>::smem_bytes(NW);
   w.MP = MP;
   w.KP = 4 * KQ;
   w.NW = NW;
-  w.name = wide4d_kernel_name<MP, KQ, NW, NSET>();
+  w.name = wide4d_kernel_name<MP, KQ, NW, NSET, WPE>();
   return w;
 }
-const WideKernel<double>* wide4d_kernel_f64(int MP, int KQ, int NW);   // MP = 48, 64
+const WideKernel<double>* wide4d_kernel_f64(int MP, int KQ, int NW);     // MP = 48, 64
+const WideKernel<double>* wide4d_kernel_f64_hi(int MP, int KQ, int NW);  // MP = 96, 128: one wave per SIMD, 256 threads
 const WideKernel<float>* wide4_kernel_f32_lo(int MP, int KQ, int NW);  // MP = 48, 64
 const WideKernel<float>* wide4_kernel_f32_hi(int MP, int KQ, int NW);  // MP = 96, 128
 }  // namespace hipnmf

@@ -1,4 +1,4 @@
-// nmf_wide4d.hpp -- float64 counterpart of fit_wide4_kernel (nmf_wide4.hpp): wide shapes (33..64 channels) with at most 8
+// nmf_wide4d.hpp -- float64 counterpart of fit_wide4_kernel (nmf_wide4.hpp): wide shapes (33..128 channels) with at most 8
 // components on v_mfma_f64_4x4x4_4b_f64 instead of v_mfma_f64_16x16x4_f64.  float64 is what the reference's own calls carry
 // (a DataFrame is float64 and scikit-learn keeps the dtype: src/muscle_synergies/analysis.py:862-863, sklearn/decomposition/
 // _nmf.py:1638-1734), and the 16x16x4 tile pads the components to 16: at k = 8 half of every fp64 MFMA -- 64 pipe cycles
@@ -47,7 +47,7 @@ struct Wide4dCfg {
   static constexpr int RREC = 8 * MP;  // residual record: 4 row slots x (sse | xsq) x MP
   static constexpr int PERWAVE = (XS + WS > REC ? (XS + WS > RREC ? XS + WS : RREC) : (REC > RREC ? REC : RREC));
   static constexpr int COMMON = KP * SH + KP * KP + KP * MP + KP * KP + 2 * MP + 8;
-  static_assert(MP % 16 == 0 && MP >= 16 && MP <= 64 && (KQ == 1 || KQ == 2), "unsupported wide4d shape");
+  static_assert(MP % 16 == 0 && MP >= 16 && MP <= 128 && (KQ == 1 || KQ == 2), "unsupported wide4d shape");
   static_assert(CPR <= 64, "a row must fit one load instruction");
   __host__ __device__ static constexpr size_t smem_bytes(int nw) { return sizeof(double) * (size_t)(COMMON + nw * PERWAVE); }
 };
@@ -61,8 +61,9 @@ struct Wide4dTile {
   double w[KQ];          // W[row 4 b + j][4 cg + i]
 };
 
-template <int MP, int KQ, int NW, int NSET>
-__global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 8))) fit_wide4d_kernel(WideArgs<double> a) {
+// WPE: waves per SIMD the instance is compiled for (2 = at most 256 registers: up to 64 channels; 1 beyond)
+template <int MP, int KQ, int NW, int NSET, int WPE = 2>
+__global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WPE > 1 ? 8 : 1))) fit_wide4d_kernel(WideArgs<double> a) {
   using C = Wide4dCfg<MP, KQ>;
   using Tile = Wide4dTile<MP, KQ>;
   constexpr int KP = C::KP, NQ = C::NQ, NU = C::NU, SX = C::SX, SW = C::SW, SH = C::SH, NLD = C::NLD, RPL = C::RPL, CPR = C::CPR,

@@ -183,7 +183,7 @@ def _case64(T, m, k, seed=0):
     return X, W0, H0
 
 
-@pytest.mark.parametrize("m", [33, 48, 50, 64])
+@pytest.mark.parametrize("m", [33, 48, 50, 64, 65, 96, 100, 128])
 @pytest.mark.parametrize("k", [1, 3, 4, 5, 8])
 def test_wide4d_shape_sweep_fp64(m, k):
     """float64 (what a DataFrame carries): 33..64 channels, at most 8 components on v_mfma_f64_4x4x4 (nmf_wide4d.hpp)."""
@@ -197,7 +197,7 @@ def test_wide4d_shape_sweep_fp64(m, k):
             Xl = np.ascontiguousarray(X) if layout == "C" else np.asfortranarray(X)
             res = ms.fit_batched(Xl, W0, H0, max_iter=40, tol=0.0, handle=h)
             kern = h.last_kernel()
-            assert kern.startswith("fit_wide4d_kernel<") and f",{4 if threads == 256 else 8}," in kern, kern
+            assert kern.startswith("fit_wide4d_kernel<") and f",{4 if (threads == 256 or m > 64) else 8}," in kern, kern
             np.testing.assert_allclose(res.W[0], ref["W"], rtol=1e-9, atol=1e-13)
             np.testing.assert_allclose(res.H[0], ref["H"], rtol=1e-9, atol=1e-13)
             np.testing.assert_allclose(res.reconstruction_err[0], ref["reconstruction_err"], rtol=1e-9, atol=1e-12 * np.linalg.norm(X))
@@ -206,7 +206,7 @@ def test_wide4d_shape_sweep_fp64(m, k):
             np.testing.assert_allclose(res.vaf[0, 1:], vc, atol=1e-10)
 
 
-@pytest.mark.parametrize("m,k,T", [(64, 8, 5000), (48, 4, 9000), (40, 7, 3001)])
+@pytest.mark.parametrize("m,k,T", [(64, 8, 5000), (48, 4, 9000), (40, 7, 3001), (128, 8, 2500), (96, 3, 4000)])
 @pytest.mark.parametrize("threads", [256, 512])
 def test_wide4d_rows_beyond_the_lds_cache_stop_rule_and_batch(m, k, T, threads):
     import muscle_synergies_amd as ms
