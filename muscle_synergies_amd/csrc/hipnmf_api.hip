@@ -187,12 +187,29 @@ SliceGeom slice_geometry(const hipnmf_handle* h, long long T, int B) {
 //   32 ch k = 7 0.51 -> 1.40, 24 ch k = 7 0.54 -> 1.52, 17 ch k = 8 0.44 -> 1.54; k = 6: 1.24 -> 1.42 (32 ch), 1.39 -> 1.53 (24 ch);
 //   k = 5: 1.53 -> 1.49 (32 ch), 1.86 -> 1.55 (24 ch): the lane mapping stays;
 //   float32, 17..32 channels: k = 8 2.23 -> 2.59 (32 ch), 2.46 -> 2.81 (20 ch); k = 7 2.83 -> 2.61, k = 6 3.24 -> 2.63: stays.
+// Since fit_wide4_kernel / fit_wide4d_kernel (4x4x1 / 4x4x4 tiles, at most 8 components; 17..32 channels: MP = 32, two rows per
+// W^T X instruction in fp32), same measurement, lane mapping -> 4x4 tiles:
+//   float32 2048 x (32 x 10 000): k = 8 2.31 -> 3.27 (16x16x4: 2.78), k = 7 3.12 -> 3.34, k = 6 3.58 -> 3.33; 24 ch k = 8 2.42 -> 3.87;
+//           8192 x (32 x 2 500):  k = 8 8.60 -> 14.9, k = 6 12.1 -> 15.3, k = 5 14.5 -> 15.7; 24 ch k = 7 10.8 -> 16.3
+//           => k >= 7 always, k = 5, 6 up to 5 000 rows (k <= 4: the lane mapping runs at 7.9 TB/s algorithmic already)
+//   float64 1024 x (32 x 10 000): k = 8 0.40 -> 1.87 (16x16x4: 1.42), k = 6 1.30 -> 1.69, k = 5 1.68 -> 1.87, k = 4 1.85 -> 2.18;
+//           4096 x (32 x 2 500):  k = 8 2.19 -> 8.22, k = 5 7.60 -> 7.78, k = 4 8.65 -> 11.2; 24 ch k = 6 6.67 -> 8.87   => every k
+// Short matrices -- the reference's own sizes: a few hundred to a few thousand samples -- favour the 4x4 kernels further: the
+// lane mappings walk 64-row tiles per wave and pay a heavier per-iteration epilogue.  16 384 matrices, M matrix-it/s:
+//   float32 32 ch k = 4: T = 300 49 -> 129, 600 42 -> 79, 1 200 30 -> 44, 2 400 19.2 -> 18.6; 24 ch k = 3: 49 -> 139, 43 -> 86, 27 -> 49, 18.7 -> 20.0
+//           (up to 16 channels the 32-channel instance pads too much: 16 ch k = 5 T = 600 49 -> 43: the lane mappings stay)
+//   float64 16 ch k = 5: T = 300 39 -> 66, 600 31 -> 40, 1 200 23.0 -> 23.9, 2 400 15.4 -> 12.4; k = 7: 25 -> 65, 20 -> 40, 14.6 -> 23.5, 9.3 -> 12.3,
+//           5 000: 5.2 -> 5.4; k = 8: 21 -> 65, ..., 10 000: 2.13 -> 2.67; 8 ch k = 4: 65 -> 161, 60 -> 97, 49 -> 55, 31 -> 20
 // Only where one workgroup per matrix is the path anyway (many matrices, or a ragged batch) and for the Frobenius loss.
 template <typename real>
 bool wide_preferred(int m, int k, const hipnmf_problem* p, const hipnmf_handle* h, bool ragged) {
-  if (m <= 16 || m > HIPNMF_NARROW_MAX_FEATURES || p->loss != HIPNMF_LOSS_FROBENIUS || h->variant != 0) return false;
+  if (m > HIPNMF_NARROW_MAX_FEATURES || p->loss != HIPNMF_LOSS_FROBENIUS || h->variant != 0) return false;
   if (!(ragged || p->batch >= h->num_cu / 2 || h->path_batch_hint >= h->num_cu / 2)) return false;
-  return sizeof(real) == 8 ? k >= 6 : k >= 8;
+  const long long T = p->n_samples;
+  if (m <= 16)  // float64 only, beyond the reach of fit_small_kernel (one wave per matrix, n_samples <= 256)
+    return sizeof(real) == 8 && T > 256 && (k >= 7 || T <= 1200);
+  if (sizeof(real) == 8) return true;
+  return k >= 7 || T <= (k >= 5 ? 5000 : 2400);
 }
 
 template <typename real>

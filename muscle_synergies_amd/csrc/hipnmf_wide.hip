@@ -39,9 +39,10 @@ const WideKernel<double>* wide_kernel_f64(int m, int k, int nw) {
 const WideKernel<float>* wide4_kernel_f32(int m, int k, int nw) {
   // (9..12 components as three component quads were built and measured too: 222..234 registers, two waves per SIMD, and no
   //  faster than the 16x16x4 kernel -- 4096 x (64 x 2 500), k = 12: 6.71 vs 6.95 M matrix-it/s; 48 channels, k = 10: 7.64 vs 8.23)
-  if (m <= 32 || m > 128 || k > 8) return nullptr;
-  const int MP = m <= 48 ? 48 : m <= 64 ? 64 : m <= 96 ? 96 : 128;
+  if (m > 128 || k > 8) return nullptr;
+  const int MP = m <= 32 ? 32 : m <= 48 ? 48 : m <= 64 ? 64 : m <= 96 ? 96 : 128;
   const int KQ = k <= 4 ? 1 : 2;
+  if (MP == 32) return wide4_kernel_f32_32(KQ, nw);
   return MP <= 64 ? wide4_kernel_f32_lo(MP, KQ, nw) : wide4_kernel_f32_hi(MP, KQ, nw);
 }
 }  // namespace hipnmf
@@ -58,9 +59,9 @@ const WideKernel<float>* pick4<float>(int m, int k, int nw) {
 // float64, 33..128 channels, at most 8 components: v_mfma_f64_4x4x4 (nmf_wide4d.hpp); 4 or 8 waves up to 64 channels, 4 beyond
 template <>
 const WideKernel<double>* pick4<double>(int m, int k, int nw) {
-  if (m <= 32 || m > 128 || k > 8) return nullptr;
+  if (m > 128 || k > 8) return nullptr;
   if (m > 64) return wide4d_kernel_f64_hi(m <= 96 ? 96 : 128, k <= 4 ? 1 : 2, 4);  // one wave per SIMD, 256 threads
-  return wide4d_kernel_f64(m <= 48 ? 48 : 64, k <= 4 ? 1 : 2, nw == 4 ? 4 : 8);
+  return wide4d_kernel_f64(m <= 16 ? 16 : m <= 32 ? 32 : m <= 48 ? 48 : 64, k <= 4 ? 1 : 2, nw == 4 ? 4 : 8);
 }
 template <typename real>
 const WideKernel<real>* pick(int m, int k, int nw);

@@ -1,11 +1,13 @@
-// fit_wide4d_kernel<MP, KQ, NW>, MP = 48, 64 (nmf_wide4d.hpp)
+// fit_wide4d_kernel<MP, KQ, NW>, MP = 16, 32, 48, 64 (nmf_wide4d.hpp)
 #include "nmf_wide4_inst.hpp"
 namespace hipnmf {
 const WideKernel<double>* wide4d_kernel_f64(int MP, int KQ, int NW) {
-  static const WideKernel<double> t[2][2][2] = {
+  static const WideKernel<double> t[4][2][2] = {
+      {{make_wide4d_kernel<16, 1, 4>(), make_wide4d_kernel<16, 1, 8>()}, {make_wide4d_kernel<16, 2, 4>(), make_wide4d_kernel<16, 2, 8>()}},
+      {{make_wide4d_kernel<32, 1, 4>(), make_wide4d_kernel<32, 1, 8>()}, {make_wide4d_kernel<32, 2, 4>(), make_wide4d_kernel<32, 2, 8>()}},
       {{make_wide4d_kernel<48, 1, 4>(), make_wide4d_kernel<48, 1, 8>()}, {make_wide4d_kernel<48, 2, 4>(), make_wide4d_kernel<48, 2, 8>()}},
       {{make_wide4d_kernel<64, 1, 4>(), make_wide4d_kernel<64, 1, 8>()}, {make_wide4d_kernel<64, 2, 4>(), make_wide4d_kernel<64, 2, 8>()}}};
-  if ((KQ != 1 && KQ != 2) || (NW != 4 && NW != 8) || (MP != 48 && MP != 64)) return nullptr;
-  return &t[MP == 64][KQ - 1][NW == 8];
+  if ((KQ != 1 && KQ != 2) || (NW != 4 && NW != 8) || (MP != 16 && MP != 32 && MP != 48 && MP != 64)) return nullptr;
+  return &t[MP == 16 ? 0 : MP == 32 ? 1 : MP == 48 ? 2 : 3][KQ - 1][NW == 8];
 }
 }  // namespace hipnmf

@@ -281,13 +281,28 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
     if (upd) {
       wide_lds_write<float, KQ>(wst + r * SW + KQ * p, wn);
       wide_wave_lds_fence();
-      float wa[KQ];  // lane 4 s + i <-> W'[row s][4 cg + i]
+      // block blk stands for row blk (64 channel lanes: one row per instruction, broadcast from block s) or, up to 32
+      // channels, for row 2 (blk mod 8) + blk / 8: two rows per instruction, lanes 0..31 the even one, CBSZ = 3 broadcasts
+      // block s of each half to its eight blocks
+      const int wrow = (MP <= 32) ? 2 * (blk & 7) + (blk >> 3) : blk;
+      float wa[KQ];  // lane 4 blk + i <-> W'[row of blk][4 cg + i]
 #pragma unroll
-      for (int cg = 0; cg < KQ; ++cg) wa[cg] = wst[blk * SW + 4 * cg + ii];
+      for (int cg = 0; cg < KQ; ++cg) wa[cg] = wst[wrow * SW + 4 * cg + ii];
       // W^T X: lanes are channels, the row's W broadcast from block s
       // (all sixteen rows are requested before the first product: left to itself the compiler reads two, waits, multiplies, reads
       //  the next two ... and every wait exposes a full LDS round trip)
       const float* xcol = xs + lane;
+      if constexpr (MP <= 32) {
+        float xc[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) xc[s] = xs[(2 * s + (lane >> 5)) * SX + (lane & 31)];
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<8>([&](auto S_) {
+          constexpr int s = decltype(S_)::value;
+#pragma unroll
+          for (int cg = 0; cg < KQ; ++cg) accA[0][cg] = w4_mfma<3, s>(wa[cg], xc[s], accA[0][cg]);
+        });
+      } else
 #pragma unroll
       for (int h = 0; h < NH; ++h) {
         float xc[16];
@@ -443,12 +458,21 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
       float* rec = xs;
 #pragma unroll
       for (int cg = 0; cg < KQ; ++cg) {
+        if constexpr (MP <= 32) {  // lanes l and l + 32 hold the sums over the even and the odd rows of the same channel
 #pragma unroll
-        for (int h = 0; h < NH; ++h)
-          if (64 * h + lane < MP) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) rec[(4 * cg + q) * MP + 64 * h + lane] = accA[h][cg][q];
+          for (int q = 0; q < 4; ++q) {
+            float v = accA[0][cg][q];
+            v += __shfl_xor(v, 32, WAVE);
+            if (lane < MP) rec[(4 * cg + q) * MP + lane] = v;
           }
+        } else {
+#pragma unroll
+          for (int h = 0; h < NH; ++h)
+            if (64 * h + lane < MP) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) rec[(4 * cg + q) * MP + 64 * h + lane] = accA[h][cg][q];
+            }
+        }
 #pragma unroll
         for (int cg2 = 0; cg2 < KQ; ++cg2)
 #pragma unroll

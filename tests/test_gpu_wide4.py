@@ -262,3 +262,34 @@ def test_wide4d_ragged_and_find_synergies_float64_frame():
         warnings.simplefilter("error", RuntimeWarning)
         out = ms.find_synergies(df, 5, solver="mu", max_iter=60, tol=0.0, init="random", random_state=0)
     assert out.model.components_.dtype == np.float64
+
+
+def test_wide4_17_to_32_channels_two_rows_per_instruction():
+    """fit_wide4_kernel<32, ..>: up to 32 channels the W^T X products take two rows per instruction (CBSZ = 3).  The library
+    sends these shapes there at k = 8 for batches; HIPNMF_FORCE_WIDE=1 (read once per process) sends every shape."""
+    code = f"""
+import sys, numpy as np
+sys.path.insert(0, {ROOT!r})
+sys.path.insert(0, {os.path.join(ROOT, "tests")!r})
+import muscle_synergies_amd as ms
+from muscle_synergies_amd import _lib
+from muscle_synergies_amd.synth import emg_matrix, random_init
+from oracle import nmf_mu_oracle as orc
+bad = 0
+for m in (17, 20, 24, 32):
+    for k in (1, 4, 5, 8):
+        for T, threads in ((1, 0), (16, 256), (33, 0), (700, 512), (4000, 0)):
+            h = _lib.Handle(0); h.set_tuning(threads, 0, 1)
+            X = emg_matrix(m * 10 + k, T=T, m=m, k_true=min(5, m), dtype=np.float32); W0, H0 = random_init(X, k, m + k)
+            r = ms.fit_batched(np.stack([X, X]), np.stack([W0, W0]), np.stack([H0, H0]), max_iter=25, tol=0.0, handle=h)
+            assert h.last_kernel().startswith('fit_wide4_kernel<32,'), h.last_kernel()
+            ref = orc.nmf_mu_fit(X, W0, H0, max_iter=25, tol=0.0)
+            xn = np.linalg.norm(X.astype(np.float64))
+            d = np.linalg.norm(r.W[1].astype(np.float64) @ r.H[1].astype(np.float64) - ref['W'].astype(np.float64) @ ref['H'].astype(np.float64)) / xn
+            e = abs(float(r.reconstruction_err[1]) - float(ref['reconstruction_err'])) / xn
+            if not (d <= 1e-5 and e <= 1e-5 and int(r.n_iter[0]) == 25 and np.array_equal(r.W[0], r.W[1])):
+                print('MISMATCH', m, k, T, threads, d, e); bad += 1
+print('problems', bad)
+"""
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, HIPNMF_FORCE_WIDE="1"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "problems 0" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
