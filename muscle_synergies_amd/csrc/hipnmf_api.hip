@@ -206,8 +206,15 @@ bool wide_preferred(int m, int k, const hipnmf_problem* p, const hipnmf_handle* 
   if (m > HIPNMF_NARROW_MAX_FEATURES || p->loss != HIPNMF_LOSS_FROBENIUS || h->variant != 0) return false;
   if (!(ragged || p->batch >= h->num_cu / 2 || h->path_batch_hint >= h->num_cu / 2)) return false;
   const long long T = p->n_samples;
-  if (m <= 16)  // float64 only, beyond the reach of fit_small_kernel (one wave per matrix, n_samples <= 256)
-    return sizeof(real) == 8 && T > 256 && (k >= 7 || T <= 1200);
+  if (m <= 16) {  // beyond the reach of fit_small_kernel (one wave per matrix: n_samples <= 256, and up to 1 024 for some shapes
+                  // when the batch gives every SIMD a wave -- then that kernel is the fastest of the three: inst_small_long.hpp)
+    if (T <= 256) return false;
+    int nt = 0;
+    if (!ragged && small_kernel_long<real>(m, k, T, &nt) && (p->batch >= 4 * h->num_cu || h->path_batch_hint >= 4 * h->num_cu)) return false;
+    // float32 (four rows per W^T X instruction): 16 ch k = 5: T = 300 55.8 -> 62.8, 600 49.4 -> 50.7, 1 200 42 -> 35; k = 8: 46 -> 61, 41 -> 49, 33.7 -> 34.1;
+    // 8 ch k = 4: 101 -> 177, 94 -> 124, 79 -> 75; 12 ch k = 3: 94 -> 179, 84 -> 118, 72 -> 71
+    return sizeof(real) == 8 ? (k >= 7 || T <= 1200) : T <= (k >= 7 ? 1200 : 600);
+  }
   if (sizeof(real) == 8) return true;
   return k >= 7 || T <= (k >= 5 ? 5000 : 2400);
 }
@@ -289,15 +296,31 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
   // in registers, no barrier and no memory traffic inside an iteration (nmf_small.hpp).  Chosen automatically when it
   // applies (HIPNMF_SMALL=0 disables it; hipnmf_set_tuning variant 6 insists on it).
   bool use_small = false;
+  SmallFn<real> small_fn = nullptr;
+  int small_nt = 0;
   {
     static const bool small_env = [] {
       const char* e = getenv("HIPNMF_SMALL");
       return !(e && atoi(e) == 0);
     }();
-    const bool small_ok = !kl && T <= 256 && small_kernel<real>(m, k) != nullptr && !(sizeof(real) == 8 && k > 6);
+    bool small_ok = !kl && T <= 256 && small_kernel<real>(m, k) != nullptr && !(sizeof(real) == 8 && k > 6);
+    if (small_ok) {
+      small_fn = small_kernel<real>(m, k);
+      small_nt = SMALL_NT;
+    } else if (!kl && T > 256) {
+      // up to 8 / 12 / 16 tiles in registers (n_samples <= 512 / 768 / 1 024): for batches that fill the chip with one wave per
+      // matrix (a lone long-ish matrix is better served by a workgroup), or on request (variant 6)
+      int nt = 0;
+      SmallFn<real> f = small_kernel_long<real>(m, k, T, &nt);
+      if (f && (h->variant == 6 || Bsel >= 4 * h->num_cu)) {
+        small_ok = true;
+        small_fn = f;
+        small_nt = nt;
+      }
+    }
     if (h->variant == 6 && !small_ok)
-      return fail(HIPNMF_ERR_UNSUPPORTED, "fit_small_kernel needs n_samples <= 256, the Frobenius loss and n_features <= %d "
-                  "(n_samples=%lld, n_features=%d, n_components=%d)", sizeof(real) == 8 ? 8 : 16, T, m, k);
+      return fail(HIPNMF_ERR_UNSUPPORTED, "fit_small_kernel needs n_samples <= 256 (<= 512 / 768 / 1 024 for some shapes), the Frobenius loss and "
+                  "n_features <= %d (n_samples=%lld, n_features=%d, n_components=%d)", sizeof(real) == 8 ? 8 : 16, T, m, k);
     use_small = small_ok && (h->variant == 6 || (h->variant == 0 && small_env));
     if (use_small) {
       persistent = true;
@@ -573,9 +596,13 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
     // nothing else to enqueue
   } else if (use_small) {
     h->last_path = 1;
-    snprintf(h->last_kernel, sizeof(h->last_kernel), "fit_small_kernel<%s,%d,%d>", sizeof(real) == 4 ? "float" : "double",
-             m <= 8 ? 8 : 16, k);
-    hipLaunchKernelGGL(small_kernel<real>(m, k), dim3(B), dim3(64), small_smem_bytes<real>(m, k), st, a);
+    if (small_nt == SMALL_NT)
+      snprintf(h->last_kernel, sizeof(h->last_kernel), "fit_small_kernel<%s,%d,%d>", sizeof(real) == 4 ? "float" : "double",
+               m <= 8 ? 8 : 16, k);
+    else
+      snprintf(h->last_kernel, sizeof(h->last_kernel), "fit_small_kernel<%s,%d,%d,%d>", sizeof(real) == 4 ? "float" : "double",
+               m <= 8 ? 8 : 16, k, small_nt);
+    hipLaunchKernelGGL(small_fn, dim3(B), dim3(64), small_smem_bytes<real>(m, k), st, a);
   } else if (persistent) {
     h->last_path = 1;
     int threads = h->threads > 0 ? h->threads : 512;

@@ -40,8 +40,9 @@ const WideKernel<float>* wide4_kernel_f32(int m, int k, int nw) {
   // (9..12 components as three component quads were built and measured too: 222..234 registers, two waves per SIMD, and no
   //  faster than the 16x16x4 kernel -- 4096 x (64 x 2 500), k = 12: 6.71 vs 6.95 M matrix-it/s; 48 channels, k = 10: 7.64 vs 8.23)
   if (m > 128 || k > 8) return nullptr;
-  const int MP = m <= 32 ? 32 : m <= 48 ? 48 : m <= 64 ? 64 : m <= 96 ? 96 : 128;
+  const int MP = m <= 16 ? 16 : m <= 32 ? 32 : m <= 48 ? 48 : m <= 64 ? 64 : m <= 96 ? 96 : 128;
   const int KQ = k <= 4 ? 1 : 2;
+  if (MP == 16) return wide4_kernel_f32_16(KQ, nw);
   if (MP == 32) return wide4_kernel_f32_32(KQ, nw);
   return MP <= 64 ? wide4_kernel_f32_lo(MP, KQ, nw) : wide4_kernel_f32_hi(MP, KQ, nw);
 }

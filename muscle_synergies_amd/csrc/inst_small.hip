@@ -1,5 +1,5 @@
 // fit_small_kernel<real, CH, K>: one wave per short matrix (nmf_small.hpp); fp32 with 8 / 16 channels, fp64 with 8
-#include "nmf_small.hpp"
+#include "inst_small_long.hpp"
 namespace hipnmf {
 #define SMALL_TABLE(REAL, CH)                                                                                        \
   {fit_small_kernel<REAL, CH, 1>, fit_small_kernel<REAL, CH, 2>, fit_small_kernel<REAL, CH, 3>,                     \
@@ -17,6 +17,24 @@ SmallFn<double> small_kernel<double>(int m, int K) {
   static const SmallFn<double> t8[8] = SMALL_TABLE(double, 8);
   if (K < 1 || K > 8 || m < 1 || m > 8) return nullptr;
   return t8[K - 1];
+}
+// the smallest NT in {8, 12, 16} that holds n_samples rows and is compiled for the shape (inst_small_long.hpp)
+template <>
+SmallFn<float> small_kernel_long<float>(int m, int K, long long T, int* nt_out) {
+  if (K < 1 || K > 8 || m < 1 || m > 16 || T > 1024) return nullptr;
+  const int CH = m <= 8 ? 8 : 16;
+  const int nt = T <= 512 ? 8 : T <= 768 ? 12 : 16;
+  SmallFn<float> f = nt == 8 ? small_f32_nt8(CH, K) : nt == 12 ? small_f32_nt12(CH, K) : small_f32_nt16(CH, K);
+  if (f) *nt_out = nt;
+  return f;
+}
+template <>
+SmallFn<double> small_kernel_long<double>(int m, int K, long long T, int* nt_out) {
+  if (K < 1 || K > 6 || m < 1 || m > 8 || T > 768) return nullptr;
+  const int nt = T <= 512 ? 8 : 12;
+  SmallFn<double> f = nt == 8 ? small_f64_nt8(K) : small_f64_nt12(K);
+  if (f) *nt_out = nt;
+  return f;
 }
 template <typename real>
 static size_t smem_of(int m, int K) {

@@ -20,13 +20,18 @@
 
 namespace hipnmf {
 
-constexpr int SMALL_NT = 4;               // 64-row tiles per matrix held in registers
+// NT: 64-row tiles per matrix held in registers.  4 (n_samples <= 256, ~130 registers: four waves per SIMD) is the reference's
+// own size; 8 / 12 / 16 (n_samples <= 512 / 768 / 1 024; up to 512 registers, one wave per SIMD) extend the same kernel to
+// the batches of a few hundred to a thousand samples in between, where a 512-thread workgroup per matrix spends most of
+// an iteration in its epilogue: 16 384 x (16 x 300), k = 5, fp32: 56 (workgroup per matrix) / 63 M (fit_wide4_kernel) matrix-it/s.
 constexpr int SMALL_MAX_T = SMALL_NT * WAVE;
 
-template <typename real, int CH, int K>
+template <typename real, int CH, int K, int NT = SMALL_NT>
 __global__ void __launch_bounds__(64) fit_small_kernel(SolveArgs<real> a) {
   using C = Cfg<real, 1, CH, K>;
-  constexpr int NT = SMALL_NT, NB = C::NB;
+  constexpr int NB = C::NB;
+  constexpr int TG = 4;  // tiles per group in the W update (the temporaries of a group live at once)
+  static_assert(NT % TG == 0, "whole groups of tiles");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   Smem<real, 1, CH, K> s(smem_raw, 1);
   const int b = blockIdx.x;
@@ -114,53 +119,56 @@ __global__ void __launch_bounds__(64) fit_small_kernel(SolveArgs<real> a) {
   int n_iter = 0;
   for (int it = 1; it <= a.max_iter; ++it) {
     n_iter = it;
-    // denominator W (H H^T): rows of H H^T broadcast from LDS
-    real den[NT][K];
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int tg = 0; tg < NT; tg += TG) {
+      // denominator W (H H^T): rows of H H^T broadcast from LDS
+      real den[TG][K];
 #pragma unroll
-      for (int c = 0; c < K; ++c) den[t][c] = (real)0;
+      for (int t = 0; t < TG; ++t)
 #pragma unroll
-    for (int c2 = 0; c2 < K; ++c2) {
-      real hrow[K];
+        for (int c = 0; c < K; ++c) den[t][c] = (real)0;
 #pragma unroll
-      for (int c = 0; c < K; ++c) hrow[c] = s.HHt[c2 * K + c];
+      for (int c2 = 0; c2 < K; ++c2) {
+        real hrow[K];
 #pragma unroll
-      for (int t = 0; t < NT; ++t)
+        for (int c = 0; c < K; ++c) hrow[c] = s.HHt[c2 * K + c];
 #pragma unroll
-        for (int c = 0; c < K; ++c) den[t][c] = fma_(w[t][c2], hrow[c], den[t][c]);
-    }
-    // numerator X H^T per component (row of H broadcast from LDS)
-    real num[NT][K];
+        for (int t = 0; t < TG; ++t)
 #pragma unroll
-    for (int c = 0; c < K; ++c) {
-      real hc[CH];
-#pragma unroll
-      for (int j = 0; j < CH; ++j) hc[j] = s.H[c * CH + j];
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        real acc = x[t][0] * hc[0];
-#pragma unroll
-        for (int j = 1; j < CH; ++j) acc = fma_(x[t][j], hc[j], acc);
-        num[t][c] = acc;
+          for (int c = 0; c < K; ++c) den[t][c] = fma_(w[tg + t][c2], hrow[c], den[t][c]);
       }
-    }
-    // regularisation (_nmf.py:616-619), zero guard (:620), quotient and update (:622-629)
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      real quo[K];
+      // numerator X H^T per component (row of H broadcast from LDS)
+      real num[TG][K];
 #pragma unroll
       for (int c = 0; c < K; ++c) {
-        real d = den[t][c];
-        if (reg) {
-          if (a.l1w > (real)0) d = d + a.l1w;
-          if (a.l2w > (real)0) d = d + a.l2w * w[t][c];
-        }
-        den[t][c] = (d == (real)0) ? eps_val<real>() : d;
-      }
-      quotients<K>(num[t], den[t], quo);
+        real hc[CH];
 #pragma unroll
-      for (int c = 0; c < K; ++c) w[t][c] = w[t][c] * quo[c];
+        for (int j = 0; j < CH; ++j) hc[j] = s.H[c * CH + j];
+#pragma unroll
+        for (int t = 0; t < TG; ++t) {
+          real acc = x[tg + t][0] * hc[0];
+#pragma unroll
+          for (int j = 1; j < CH; ++j) acc = fma_(x[tg + t][j], hc[j], acc);
+          num[t][c] = acc;
+        }
+      }
+      // regularisation (_nmf.py:616-619), zero guard (:620), quotient and update (:622-629)
+#pragma unroll
+      for (int t = 0; t < TG; ++t) {
+        real quo[K];
+#pragma unroll
+        for (int c = 0; c < K; ++c) {
+          real d = den[t][c];
+          if (reg) {
+            if (a.l1w > (real)0) d = d + a.l1w;
+            if (a.l2w > (real)0) d = d + a.l2w * w[tg + t][c];
+          }
+          den[t][c] = (d == (real)0) ? eps_val<real>() : d;
+        }
+        quotients<K>(num[t], den[t], quo);
+#pragma unroll
+        for (int c = 0; c < K; ++c) w[tg + t][c] = w[tg + t][c] * quo[c];
+      }
     }
     if (upd) {
       // W^T X and W^T W: partial sums over the lane's rows, one reduce-scatter over the wave, H update by the wave

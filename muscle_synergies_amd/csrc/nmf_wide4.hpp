@@ -40,6 +40,11 @@ template <int MP, int KQ>
 struct Wide4Cfg {
   static constexpr int KP = 4 * KQ;
   static constexpr int NH = (MP + 63) / 64;  // 64-lane groups of the lanes-are-channels layouts
+  // lanes-are-channels layouts below 64 channels: LP lanes per row, NG = 64 / LP rows per instruction (CBSZ = log2(LP / 4)
+  // broadcasts block ABID of each group of LP / 4 blocks)
+  static constexpr int LP = MP <= 16 ? 16 : MP <= 32 ? 32 : 64;
+  static constexpr int NG = 64 / LP;
+  static constexpr int CB = LP == 16 ? 2 : LP == 32 ? 3 : 4;
   static constexpr int NCB = MP / 16;
   static constexpr int CPR = MP / 4;  // 16-byte pieces per row
   static constexpr int RPL = wide_pow2_floor(64 / CPR) > 16 ? 16 : wide_pow2_floor(64 / CPR);
@@ -54,7 +59,7 @@ struct Wide4Cfg {
   static constexpr int PERWAVE = (XS + WS > REC ? XS + WS : REC);
   static constexpr int COMMON = KP * SH + KP * KP + KP * MP + KP * KP + 2 * MP + 8;
   static_assert(MP % 16 == 0 && MP >= 16 && MP <= 128 && KQ >= 1 && KQ <= 4, "unsupported wide4 shape");
-  static_assert(SX >= 64 * NH, "the lanes-are-channels reads stay inside a stage row");
+  static_assert(SX >= LP * NH, "the lanes-are-channels reads stay inside a stage row");
   __host__ __device__ static constexpr size_t smem_bytes(int nw) { return sizeof(float) * (size_t)(COMMON + nw * PERWAVE); }
 };
 
@@ -104,7 +109,7 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
   using C = Wide4Cfg<MP, KQ>;
   using Tile = Wide4Tile<MP, KQ>;
   constexpr int KP = C::KP, NH = C::NH, NCB = C::NCB, SX = C::SX, SW = C::SW, SH = C::SH, NLD = C::NLD, RPL = C::RPL,
-                CPR = C::CPR, NT = NW * 64;
+                CPR = C::CPR, NT = NW * 64, LP = C::LP, NG = C::NG, CB = C::CB;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* const sH = reinterpret_cast<float*>(smem_raw);  // [KP][SH]
   float* const sHHt = sH + KP * SH;                      // [KP][KP]
@@ -146,7 +151,6 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
     xvoff[n] = (xl_active && xl_chunk < a.xchunks) ? (unsigned)(n * RPL + xl_row) * ldx_b + (unsigned)xl_chunk * 16u : OOB;
   float* const xs_put = xs + xl_row * SX + xl_chunk * 4;
   const unsigned wvoff = (unsigned)((r * KP + KQ * p) * 4);         // this lane's KQ values of its row
-  const unsigned wrow_voff = (unsigned)(((lane & 15) * KP) * 4);    // residual pass: the whole row (lane & 15)
   float* const wc_lane = wcache + r * KP + KQ * p;
   const char* const xbase = reinterpret_cast<const char*>(Xb);
   char* const wbase = reinterpret_cast<char*>(Wb);
@@ -281,10 +285,10 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
     if (upd) {
       wide_lds_write<float, KQ>(wst + r * SW + KQ * p, wn);
       wide_wave_lds_fence();
-      // block blk stands for row blk (64 channel lanes: one row per instruction, broadcast from block s) or, up to 32
-      // channels, for row 2 (blk mod 8) + blk / 8: two rows per instruction, lanes 0..31 the even one, CBSZ = 3 broadcasts
-      // block s of each half to its eight blocks
-      const int wrow = (MP <= 32) ? 2 * (blk & 7) + (blk >> 3) : blk;
+      // block blk stands for row blk (64 channel lanes: one row per instruction, broadcast from block s) or, with LP < 64 lanes
+      // per row, for row NG (blk mod LP / 4) + blk / (LP / 4): NG rows per instruction, lanes [G LP, G LP + LP) row NG s + G,
+      // CBSZ broadcasts block s of each group to the group's LP / 4 blocks
+      const int wrow = NG * (blk % (LP / 4)) + blk / (LP / 4);
       float wa[KQ];  // lane 4 blk + i <-> W'[row of blk][4 cg + i]
 #pragma unroll
       for (int cg = 0; cg < KQ; ++cg) wa[cg] = wst[wrow * SW + 4 * cg + ii];
@@ -292,15 +296,15 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
       // (all sixteen rows are requested before the first product: left to itself the compiler reads two, waits, multiplies, reads
       //  the next two ... and every wait exposes a full LDS round trip)
       const float* xcol = xs + lane;
-      if constexpr (MP <= 32) {
-        float xc[8];
+      if constexpr (LP < 64) {
+        float xc[16 / NG];
 #pragma unroll
-        for (int s = 0; s < 8; ++s) xc[s] = xs[(2 * s + (lane >> 5)) * SX + (lane & 31)];
+        for (int s = 0; s < 16 / NG; ++s) xc[s] = xs[(NG * s + lane / LP) * SX + lane % LP];
         __builtin_amdgcn_sched_barrier(0);
-        static_for<8>([&](auto S_) {
+        static_for<16 / NG>([&](auto S_) {
           constexpr int s = decltype(S_)::value;
 #pragma unroll
-          for (int cg = 0; cg < KQ; ++cg) accA[0][cg] = w4_mfma<3, s>(wa[cg], xc[s], accA[0][cg]);
+          for (int cg = 0; cg < KQ; ++cg) accA[0][cg] = w4_mfma<CB, s>(wa[cg], xc[s], accA[0][cg]);
         });
       } else
 #pragma unroll
@@ -326,16 +330,20 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
   // ---- ||X - W H||_F^2 per column and sum X^2 per column of the whole matrix -> sPart[0 .. 2 MP); barriers inside ----
   auto block_resid = [&]() __attribute__((always_inline)) {
     float sse[NH], xsq[NH];
-    float hB[NH][KP];  // H[c][64 h + lane]
+    float hB[NH][KP];  // H[c][64 h + lane]  (LP < 64: H[c][lane mod LP], the same in every group of LP lanes)
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
       sse[h] = xsq[h] = 0.0f;
 #pragma unroll
-      for (int c = 0; c < KP; ++c) hB[h][c] = sH[c * SH + 64 * h + lane];
+      for (int c = 0; c < KP; ++c) hB[h][c] = sH[c * SH + 64 * h + lane % LP];
     }
+    // A operand: the lane's row of the subtile.  Instruction q covers the row quads NG q + G (G = lane / LP), broadcast from
+    // block q of each group: lane G LP + 4 q + i carries row 4 (NG q + G) + i  (LP = 64: lane l < 16 carries row l)
+    const int arow = (4 * (NG * ((lane % LP) >> 2) + lane / LP) + (lane & 3)) & 15;
+    const unsigned arow_voff = (unsigned)((arow * KP) * 4);
     for (int i = wave; i < ntiles; i += NW) {
       float xg[NLD][4];
-      float wrow[KP];  // W[row lane & 15][..]: lanes 0..15 are the A operand of every row quad
+      float wrow[KP];  // W[row arow][..]
       {
         const rsrc_t xr = x_rsrc(i);
         const rsrc_t wr = w_rsrc(i);
@@ -345,7 +353,7 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
 #pragma unroll
           for (int q = 0; q < KQ; ++q) {
             float t4[4];
-            wide_lds_read<float, 4>(wcache + i * 16 * KP + (lane & 15) * KP + 4 * q, t4);
+            wide_lds_read<float, 4>(wcache + i * 16 * KP + arow * KP + 4 * q, t4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) wrow[4 * q + e] = t4[e];
           }
@@ -353,7 +361,7 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
 #pragma unroll
           for (int q = 0; q < KQ; ++q) {
             float t4[4];
-            buf_load<float, 4>(wr, wrow_voff + 16u * q, 0u, t4);
+            buf_load<float, 4>(wr, arow_voff + 16u * q, 0u, t4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) wrow[4 * q + e] = t4[e];
           }
@@ -366,14 +374,14 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
       wide_wave_lds_fence();
 #pragma unroll
       for (int h = 0; h < NH; ++h) {
-        static_for<4>([&](auto Q_) {
-          constexpr int q = decltype(Q_)::value;  // rows 4 q .. 4 q + 3
+        static_for<4 / NG>([&](auto Q_) {
+          constexpr int q = decltype(Q_)::value;  // row quad NG q + G: rows 4 (NG q + G) .. + 3
           w4f4 rec = zero;
 #pragma unroll
-          for (int c = 0; c < KP; ++c) rec = w4_mfma<4, q>(wrow[c], hB[h][c], rec);
+          for (int c = 0; c < KP; ++c) rec = w4_mfma<CB, q>(wrow[c], hB[h][c], rec);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const float xv = xs[(4 * q + e) * SX + 64 * h + lane];
+            const float xv = xs[(4 * (NG * q + lane / LP) + e) * SX + 64 * h + lane % LP];
             const float d = xv - rec[e];
             sse[h] = fma_(d, d, sse[h]);
             xsq[h] = fma_(xv, xv, xsq[h]);
@@ -381,6 +389,14 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
         });
       }
       wide_wave_lds_fence();
+    }
+    if constexpr (LP < 64) {  // the groups of LP lanes hold the sums over their row quads for the same channels
+      if constexpr (LP == 16) {
+        sse[0] += __shfl_xor(sse[0], 16, WAVE);
+        xsq[0] += __shfl_xor(xsq[0], 16, WAVE);
+      }
+      sse[0] += __shfl_xor(sse[0], 32, WAVE);
+      xsq[0] += __shfl_xor(xsq[0], 32, WAVE);
     }
     float* rec = xs;  // [2][MP] record of this wave (the stage is idle now)
 #pragma unroll
@@ -458,10 +474,11 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
       float* rec = xs;
 #pragma unroll
       for (int cg = 0; cg < KQ; ++cg) {
-        if constexpr (MP <= 32) {  // lanes l and l + 32 hold the sums over the even and the odd rows of the same channel
+        if constexpr (LP < 64) {  // lanes l, l + LP, ... hold the sums over the rows of their group for the same channel
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             float v = accA[0][cg][q];
+            if constexpr (LP == 16) v += __shfl_xor(v, 16, WAVE);
             v += __shfl_xor(v, 32, WAVE);
             if (lane < MP) rec[(4 * cg + q) * MP + lane] = v;
           }

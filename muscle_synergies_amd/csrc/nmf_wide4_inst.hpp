@@ -94,5 +94,6 @@ const WideKernel<double>* wide4d_kernel_f64(int MP, int KQ, int NW);     // MP =
 const WideKernel<double>* wide4d_kernel_f64_hi(int MP, int KQ, int NW);  // MP = 96, 128: one wave per SIMD, 256 threads
 const WideKernel<float>* wide4_kernel_f32_lo(int MP, int KQ, int NW);  // MP = 48, 64
 const WideKernel<float>* wide4_kernel_f32_32(int KQ, int NW);          // MP = 32 (17..32 channels)
+const WideKernel<float>* wide4_kernel_f32_16(int KQ, int NW);          // MP = 16 (up to 16 channels)
 const WideKernel<float>* wide4_kernel_f32_hi(int MP, int KQ, int NW);  // MP = 96, 128
 }  // namespace hipnmf

@@ -192,7 +192,7 @@ def test_one_wave_per_matrix_kernel(dtype, m, k, T):
             ref = orc.nmf_mu_fit(np.ascontiguousarray(Xs[i][:Tr[i]]), W0[i][:Tr[i]], H0[i], max_iter=25, tol=0.0)
             assert _rel_wh(Xs[i][:Tr[i]], np.asarray(rr.W[i].cpu()), np.asarray(rr.H[i].cpu()), ref) <= lim
     with pytest.raises(_lib.HipNmfError, match="fit_small_kernel"):
-        big = emg_matrix(1, T=300, m=m, k_true=min(3, m), dtype=dtype)
+        big = emg_matrix(1, T=1100, m=m, k_true=min(3, m), dtype=dtype)  # (beyond the 16-tile instances too: tests/test_gpu_small_long.py)
         wb, hb = random_init(big, k, 1)
         ms.fit_batched(big, wb, hb, max_iter=2, tol=0.0, handle=h)
 

@@ -265,7 +265,7 @@ def test_wide4d_ragged_and_find_synergies_float64_frame():
 
 
 def test_wide4_17_to_32_channels_two_rows_per_instruction():
-    """fit_wide4_kernel<32, ..>: up to 32 channels the W^T X products take two rows per instruction (CBSZ = 3).  The library
+    """fit_wide4_kernel<32, ..> / <16, ..>: up to 32 / 16 channels the W^T X products take two / four rows per instruction (CBSZ = 3 / 2).  The library
     sends these shapes there at k = 8 for batches; HIPNMF_FORCE_WIDE=1 (read once per process) sends every shape."""
     code = f"""
 import sys, numpy as np
@@ -276,13 +276,14 @@ from muscle_synergies_amd import _lib
 from muscle_synergies_amd.synth import emg_matrix, random_init
 from oracle import nmf_mu_oracle as orc
 bad = 0
-for m in (17, 20, 24, 32):
+for m in (3, 8, 9, 16, 17, 20, 24, 32):
     for k in (1, 4, 5, 8):
+        if k > m: continue
         for T, threads in ((1, 0), (16, 256), (33, 0), (700, 512), (4000, 0)):
             h = _lib.Handle(0); h.set_tuning(threads, 0, 1)
             X = emg_matrix(m * 10 + k, T=T, m=m, k_true=min(5, m), dtype=np.float32); W0, H0 = random_init(X, k, m + k)
             r = ms.fit_batched(np.stack([X, X]), np.stack([W0, W0]), np.stack([H0, H0]), max_iter=25, tol=0.0, handle=h)
-            assert h.last_kernel().startswith('fit_wide4_kernel<32,'), h.last_kernel()
+            assert h.last_kernel().startswith('fit_wide4_kernel<16,' if m <= 16 else 'fit_wide4_kernel<32,'), h.last_kernel()
             ref = orc.nmf_mu_fit(X, W0, H0, max_iter=25, tol=0.0)
             xn = np.linalg.norm(X.astype(np.float64))
             d = np.linalg.norm(r.W[1].astype(np.float64) @ r.H[1].astype(np.float64) - ref['W'].astype(np.float64) @ ref['H'].astype(np.float64)) / xn
