@@ -245,11 +245,11 @@ def _matrix_pipe(kernel, tf, m, k):
     """Useful vs issued rate of the matrix pipe for the wide-shape kernels: issued = useful x the padding of the tile shape."""
     if kernel.startswith("fit_wide4_kernel"):  # nmf_wide4.hpp: v_mfma_f32_4x4x1, components padded to a multiple of 4
         kp = (k + 3) // 4 * 4
-        mp = 48 if m <= 48 else 64 if m <= 64 else 96 if m <= 96 else 128
+        mp = 16 if m <= 16 else 32 if m <= 32 else 48 if m <= 48 else 64 if m <= 64 else 96 if m <= 96 else 128
         return {"achieved_tflops_useful": tf, "peak_tflops": FP32_PEAK_TFLOPS, "frac_useful": tf / FP32_PEAK_TFLOPS,
                 "issued_tflops": tf * (kp / k) * (mp + kp) / (m + k),
                 "note": "all four contractions on v_mfma_f32_4x4x1_16b_f32, components padded to a multiple of 4, channels to "
-                        "48 / 64 / 96 / 128 (issued = useful x padding); profiles/r03_pmc_fit_wide4_64_8.txt: matrix pipe busy 31 %"}
+                        "16 / 32 / 48 / 64 / 96 / 128 (issued = useful x padding); profiles/r03_pmc_fit_wide4_64_8.txt: matrix pipe busy 31 %"}
     return {"achieved_tflops_useful": tf, "peak_tflops": FP32_PEAK_TFLOPS, "frac_useful": tf / FP32_PEAK_TFLOPS,
             "issued_tflops": tf * (16.0 / k) * ((m + 15) // 16 * 16 + 16.0) / (m + k),
             "note": "all four contractions on v_mfma_f32_16x16x4_f32 with components padded to 16 and "

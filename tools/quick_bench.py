@@ -36,4 +36,4 @@ for nt in a.threads:
         dt = time.perf_counter() - t0
         its = a.batch * a.iters / (r.kernel_ms * 1e-3)
         gbs = its * X.element_size() * a.T * (a.m + 2 * a.k) / 1e9
-        print(f"threads={nt} rep={rep} wall={dt*1e3:.1f} ms kernel={r.kernel_ms:.1f} ms  {its/1e6:.3f} M matrix-it/s  {gbs:.0f} GB/s algorithmic  err0={float(r.reconstruction_err[0]):.4f}", flush=True)
+        print(f"threads={nt} rep={rep} wall={dt*1e3:.1f} ms kernel={r.kernel_ms:.1f} ms  {its/1e6:.3f} M matrix-it/s  {gbs:.0f} GB/s algorithmic  err0={float(r.reconstruction_err[0]):.4f}  {h.last_kernel()}", flush=True)
