@@ -306,6 +306,9 @@ print('problems', bad)
     (np.float32, 32, 6, 2500, "fit_wide4_kernel<32,2"),
     (np.float32, 20, 7, 6000, "fit_wide4_kernel<32,2"),
     (np.float32, 32, 4, 6000, "fit_persistent_kernel<float"),
+    (np.float32, 16, 5, 400, "fit_wide4_kernel<16,2"),     # up to 16 channels in float32: 257..600 samples (four rows per W^T X instruction)
+    (np.float32, 7, 3, 500, "fit_wide4_kernel<16,1"),
+    (np.float32, 16, 5, 900, "fit_persistent_kernel<float"),
 ])
 def test_batches_of_narrow_shapes_routed_to_the_4x4_kernels(dtype, m, k, T, kernel):
     """hipnmf_api.hip::wide_preferred: batches (at least half as many matrices as CUs) of shapes the lane mappings also hold
