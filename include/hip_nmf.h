@@ -106,7 +106,7 @@ int hipnmf_set_async(hipnmf_handle* h, int enable);
  * 4 / 5 = 1 with the kernel instance pinned: 4 fit_persistent_kernel (VALU contractions), 5 fit_rowlane_kernel
  * (X H^T and W H H^T on the f32 matrix pipe; fp32, 9..16 channels, else HIPNMF_ERR_UNSUPPORTED),
  * 6 fit_small_kernel (one wave per matrix, n_samples <= 256 -- up to 512 / 768 / 1 024 for the shapes compiled with more tiles
- * in registers, which batches of at least four matrices per CU take by themselves --; HIPNMF_ERR_UNSUPPORTED otherwise).
+ * in registers, which batches of at least two (float64: three) matrices per CU take by themselves --; HIPNMF_ERR_UNSUPPORTED otherwise).
  * Wide shapes (n_features > 32 or n_components > 8: fit_wide_kernel, every contraction on v_mfma_*_16x16x4; at most 8
  * components with the Frobenius loss: fit_wide4_kernel / fit_wide4d_kernel on v_mfma_f32_4x4x1 / v_mfma_f64_4x4x4; the
  * library also routes float64 17..32 channels with k >= 6 there): variants 0, 1 (= 4) and 2 exist -- 2 = rows sliced over

@@ -201,6 +201,14 @@ SliceGeom slice_geometry(const hipnmf_handle* h, long long T, int B) {
 //   float64 16 ch k = 5: T = 300 39 -> 66, 600 31 -> 40, 1 200 23.0 -> 23.9, 2 400 15.4 -> 12.4; k = 7: 25 -> 65, 20 -> 40, 14.6 -> 23.5, 9.3 -> 12.3,
 //           5 000: 5.2 -> 5.4; k = 8: 21 -> 65, ..., 10 000: 2.13 -> 2.67; 8 ch k = 4: 65 -> 161, 60 -> 97, 49 -> 55, 31 -> 20
 // Only where one workgroup per matrix is the path anyway (many matrices, or a ragged batch) and for the Frobenius loss.
+// Smallest batch for which one WAVE per matrix (fit_small_kernel with 8 / 12 / 16 tiles, one wave per SIMD) beats a workgroup
+// per matrix.  tools/quick_bench.py --variant 0 / 6, M matrix-it/s (the other kernel / one wave per matrix): fp32 16 x 400, k = 5:
+// B = 256 55 / 41, 512 55 / 79, 768 57 / 117, 1 024 - / 152; 8 x 700, k = 4: 256 89 / 57, 512 91 / 106; fp64 8 x 400, k = 4: 512 129 / 100, 768 120 / 147
+template <typename real>
+int small_long_min_batch(const hipnmf_handle* h) {
+  return (sizeof(real) == 8 ? 3 : 2) * h->num_cu;
+}
+
 template <typename real>
 bool wide_preferred(int m, int k, const hipnmf_problem* p, const hipnmf_handle* h, bool ragged) {
   if (m > HIPNMF_NARROW_MAX_FEATURES || p->loss != HIPNMF_LOSS_FROBENIUS || h->variant != 0) return false;
@@ -210,7 +218,8 @@ bool wide_preferred(int m, int k, const hipnmf_problem* p, const hipnmf_handle* 
                   // when the batch gives every SIMD a wave -- then that kernel is the fastest of the three: inst_small_long.hpp)
     if (T <= 256) return false;
     int nt = 0;
-    if (!ragged && small_kernel_long<real>(m, k, T, &nt) && (p->batch >= 4 * h->num_cu || h->path_batch_hint >= 4 * h->num_cu)) return false;
+    const int small_min = small_long_min_batch<real>(h);
+    if (!ragged && small_kernel_long<real>(m, k, T, &nt) && (p->batch >= small_min || h->path_batch_hint >= small_min)) return false;
     // float32 (four rows per W^T X instruction): 16 ch k = 5: T = 300 55.8 -> 62.8, 600 49.4 -> 50.7, 1 200 42 -> 35; k = 8: 46 -> 61, 41 -> 49, 33.7 -> 34.1;
     // 8 ch k = 4: 101 -> 177, 94 -> 124, 79 -> 75; 12 ch k = 3: 94 -> 179, 84 -> 118, 72 -> 71
     return sizeof(real) == 8 ? (k >= 7 || T <= 1200) : T <= (k >= 7 ? 1200 : 600);
@@ -308,11 +317,11 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
       small_fn = small_kernel<real>(m, k);
       small_nt = SMALL_NT;
     } else if (!kl && T > 256) {
-      // up to 8 / 12 / 16 tiles in registers (n_samples <= 512 / 768 / 1 024): for batches that fill the chip with one wave per
-      // matrix (a lone long-ish matrix is better served by a workgroup), or on request (variant 6)
+      // up to 8 / 12 / 16 tiles in registers (n_samples <= 512 / 768 / 1 024): for batches that give most SIMDs a wave (a lone
+      // long-ish matrix is better served by a workgroup: small_long_min_batch), or on request (variant 6)
       int nt = 0;
       SmallFn<real> f = small_kernel_long<real>(m, k, T, &nt);
-      if (f && (h->variant == 6 || Bsel >= 4 * h->num_cu)) {
+      if (f && (h->variant == 6 || Bsel >= small_long_min_batch<real>(h))) {
         small_ok = true;
         small_fn = f;
         small_nt = nt;

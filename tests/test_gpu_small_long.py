@@ -71,7 +71,7 @@ def test_small_kernel_long_instances_match_oracle(dtype, m, k, T, tiles):
 
 
 def test_small_kernel_long_is_the_librarys_choice_for_big_batches_only():
-    """At least four matrices per CU (a wave for every SIMD): fit_small_kernel with 8 tiles for 16 x 400; a smaller batch of
+    """At least two matrices per CU (fp64: three): fit_small_kernel with 8 tiles for 16 x 400; a smaller batch of
     the same matrices keeps a workgroup per matrix (or the 4x4 kernel); shapes outside the compiled set are refused under variant 6."""
     import torch
 
@@ -81,7 +81,7 @@ def test_small_kernel_long_is_the_librarys_choice_for_big_batches_only():
     X = emg_matrix(9, T=400, m=16, k_true=4, dtype=np.float32)
     W0, H0 = random_init(X, 5, 9)
     h = _lib.Handle(0)
-    for B, small in ((1100, True), (300, False)):
+    for B, small in ((1100, True), (600, True), (300, False)):
         Xb = torch.from_numpy(np.stack([X] * 4)).cuda().repeat(B // 4, 1, 1)
         Wb = torch.from_numpy(np.stack([W0] * 4)).cuda().repeat(B // 4, 1, 1)
         Hb = torch.from_numpy(np.stack([H0] * 4)).cuda().repeat(B // 4, 1, 1)

@@ -296,21 +296,24 @@ print('problems', bad)
     assert r.returncode == 0 and "problems 0" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
-@pytest.mark.parametrize("dtype,m,k,T,kernel", [
-    (np.float64, 16, 5, 600, "fit_wide4d_kernel<16,2"),    # short float64 matrices, up to 16 channels
-    (np.float64, 8, 4, 900, "fit_wide4d_kernel<16,1"),
-    (np.float64, 12, 8, 3000, "fit_wide4d_kernel<16,2"),   # 7, 8 components: any length
-    (np.float64, 16, 5, 3000, "fit_persistent_kernel<double"),  # long: the lane mapping stays
-    (np.float64, 24, 3, 4000, "fit_wide4d_kernel<32,1"),   # 17..32 channels in float64: always
-    (np.float32, 24, 3, 300, "fit_wide4_kernel<32,1"),     # 17..32 channels in float32: short, or 7 / 8 components
-    (np.float32, 32, 6, 2500, "fit_wide4_kernel<32,2"),
-    (np.float32, 20, 7, 6000, "fit_wide4_kernel<32,2"),
-    (np.float32, 32, 4, 6000, "fit_persistent_kernel<float"),
-    (np.float32, 16, 5, 400, "fit_wide4_kernel<16,2"),     # up to 16 channels in float32: 257..600 samples (four rows per W^T X instruction)
-    (np.float32, 7, 3, 500, "fit_wide4_kernel<16,1"),
-    (np.float32, 16, 5, 900, "fit_persistent_kernel<float"),
+@pytest.mark.parametrize("dtype,m,k,T,B,kernel", [
+    (np.float64, 16, 5, 600, 640, "fit_wide4d_kernel<16,2"),    # short float64 matrices, up to 16 channels
+    (np.float64, 8, 4, 900, 640, "fit_wide4d_kernel<16,1"),
+    (np.float64, 12, 8, 3000, 640, "fit_wide4d_kernel<16,2"),   # 7, 8 components: any length
+    (np.float64, 16, 5, 3000, 640, "fit_persistent_kernel<double"),  # long: the lane mapping stays
+    (np.float64, 24, 3, 4000, 640, "fit_wide4d_kernel<32,1"),   # 17..32 channels in float64: always
+    (np.float32, 24, 3, 300, 640, "fit_wide4_kernel<32,1"),     # 17..32 channels in float32: short, or 7 / 8 components
+    (np.float32, 32, 6, 2500, 640, "fit_wide4_kernel<32,2"),
+    (np.float32, 20, 7, 6000, 640, "fit_wide4_kernel<32,2"),
+    (np.float32, 32, 4, 6000, 640, "fit_persistent_kernel<float"),
+    (np.float32, 16, 5, 400, 300, "fit_wide4_kernel<16,2"),     # up to 16 channels in float32: 257..600 samples (four rows per W^T X instruction)
+    (np.float32, 7, 3, 500, 300, "fit_wide4_kernel<16,1"),
+    (np.float32, 16, 5, 400, 640, "fit_small_kernel<float,16,5,8>"),  # ... unless the batch gives most SIMDs a wave: one wave per matrix
+    (np.float64, 8, 4, 400, 800, "fit_small_kernel<double,8,4,8>"),
+    (np.float64, 8, 4, 400, 640, "fit_wide4d_kernel<16,1"),
+    (np.float32, 16, 5, 900, 640, "fit_persistent_kernel<float"),
 ])
-def test_batches_of_narrow_shapes_routed_to_the_4x4_kernels(dtype, m, k, T, kernel):
+def test_batches_of_narrow_shapes_routed_to_the_4x4_kernels(dtype, m, k, T, B, kernel):
     """hipnmf_api.hip::wide_preferred: batches (at least half as many matrices as CUs) of shapes the lane mappings also hold
     run on fit_wide4_kernel / fit_wide4d_kernel where that measured faster.  Same answers either way (oracle)."""
     import torch
@@ -318,7 +321,7 @@ def test_batches_of_narrow_shapes_routed_to_the_4x4_kernels(dtype, m, k, T, kern
     import muscle_synergies_amd as ms
     from muscle_synergies_amd import _lib
 
-    B = 640  # (more than two matrices per CU: with fewer, long matrices may take the row-sliced path instead)
+    # (B = 640: more than two matrices per CU -- with fewer, long matrices may take the row-sliced path instead)
     X0 = emg_matrix(m + k, T=T, m=m, k_true=min(5, m), dtype=dtype)
     W00, H00 = random_init(X0, k, m)
     Xb = np.stack([X0 * (1.0 + 0.01 * b) for b in range(B)]).astype(dtype)
@@ -327,7 +330,7 @@ def test_batches_of_narrow_shapes_routed_to_the_4x4_kernels(dtype, m, k, T, kern
     h = _lib.Handle(0)
     res = ms.fit_batched(torch.from_numpy(Xb).cuda(), torch.from_numpy(Wb).cuda(), torch.from_numpy(Hb).cuda(), max_iter=30, tol=0.0, handle=h)
     assert h.last_kernel().startswith(kernel), h.last_kernel()
-    for b in (0, 77, 639):
+    for b in (0, 77, B - 1):
         ref = orc.nmf_mu_fit(Xb[b], Wb[b], Hb[b], max_iter=30, tol=0.0)
         W, H = res.W[b].cpu().numpy(), res.H[b].cpu().numpy()
         if dtype == np.float64:
