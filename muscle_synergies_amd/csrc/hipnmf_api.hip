@@ -216,7 +216,9 @@ bool wide_preferred(int m, int k, const hipnmf_problem* p, const hipnmf_handle* 
   const long long T = p->n_samples;
   if (m <= 16) {  // beyond the reach of fit_small_kernel (one wave per matrix: n_samples <= 256, and up to 1 024 for some shapes
                   // when the batch gives every SIMD a wave -- then that kernel is the fastest of the three: inst_small_long.hpp)
-    if (T <= 256) return false;
+    if (T <= 256)  // fit_small_kernel's own range -- where it exists: float64 beyond 8 channels / 6 components has no instance, and a
+                   // workgroup per such matrix is slow (16 384 x (16 x 200), k = 5: 40 -> 77 M matrix-it/s; 16 x 128, k = 8: 25 -> 102)
+      return sizeof(real) == 8 && (m > 8 || k > 6);
     int nt = 0;
     const int small_min = small_long_min_batch<real>(h);
     if (!ragged && small_kernel_long<real>(m, k, T, &nt) && (p->batch >= small_min || h->path_batch_hint >= small_min)) return false;

@@ -312,6 +312,9 @@ print('problems', bad)
     (np.float64, 8, 4, 400, 800, "fit_small_kernel<double,8,4,8>"),
     (np.float64, 8, 4, 400, 640, "fit_wide4d_kernel<16,1"),
     (np.float32, 16, 5, 900, 640, "fit_persistent_kernel<float"),
+    (np.float64, 16, 5, 200, 640, "fit_wide4d_kernel<16,2"),    # float64 beyond fit_small_kernel's shapes, however short
+    (np.float64, 8, 7, 128, 640, "fit_wide4d_kernel<16,2"),
+    (np.float64, 8, 4, 200, 640, "fit_small_kernel<double,8,4>"),
 ])
 def test_batches_of_narrow_shapes_routed_to_the_4x4_kernels(dtype, m, k, T, B, kernel):
     """hipnmf_api.hip::wide_preferred: batches (at least half as many matrices as CUs) of shapes the lane mappings also hold
