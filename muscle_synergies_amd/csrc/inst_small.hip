@@ -18,23 +18,36 @@ SmallFn<double> small_kernel<double>(int m, int K) {
   if (K < 1 || K > 8 || m < 1 || m > 8) return nullptr;
   return t8[K - 1];
 }
-// the smallest NT in {8, 12, 16} that holds n_samples rows and is compiled for the shape (inst_small_long.hpp)
+// the smallest NT in {6, 8, 10, 12, 16} that holds n_samples rows and is compiled for the shape (inst_small_long.hpp)
 template <>
 SmallFn<float> small_kernel_long<float>(int m, int K, long long T, int* nt_out) {
   if (K < 1 || K > 8 || m < 1 || m > 16 || T > 1024) return nullptr;
   const int CH = m <= 8 ? 8 : 16;
-  const int nt = T <= 512 ? 8 : T <= 768 ? 12 : 16;
-  SmallFn<float> f = nt == 8 ? small_f32_nt8(CH, K) : nt == 12 ? small_f32_nt12(CH, K) : small_f32_nt16(CH, K);
-  if (f) *nt_out = nt;
-  return f;
+  static const int nts[5] = {6, 8, 10, 12, 16};
+  for (int nt : nts) {
+    if (T > 64LL * nt) continue;
+    SmallFn<float> f = nt == 6 ? small_f32_nt6(CH, K) : nt == 8 ? small_f32_nt8(CH, K) : nt == 10 ? small_f32_nt10(CH, K)
+                     : nt == 12 ? small_f32_nt12(CH, K) : small_f32_nt16(CH, K);
+    if (f) {
+      *nt_out = nt;
+      return f;
+    }
+  }
+  return nullptr;
 }
 template <>
 SmallFn<double> small_kernel_long<double>(int m, int K, long long T, int* nt_out) {
   if (K < 1 || K > 6 || m < 1 || m > 8 || T > 768) return nullptr;
-  const int nt = T <= 512 ? 8 : 12;
-  SmallFn<double> f = nt == 8 ? small_f64_nt8(K) : small_f64_nt12(K);
-  if (f) *nt_out = nt;
-  return f;
+  static const int nts[3] = {6, 8, 12};
+  for (int nt : nts) {
+    if (T > 64LL * nt) continue;
+    SmallFn<double> f = nt == 6 ? small_f64_nt6(K) : nt == 8 ? small_f64_nt8(K) : small_f64_nt12(K);
+    if (f) {
+      *nt_out = nt;
+      return f;
+    }
+  }
+  return nullptr;
 }
 template <typename real>
 static size_t smem_of(int m, int K) {

@@ -21,7 +21,7 @@
 namespace hipnmf {
 
 // NT: 64-row tiles per matrix held in registers.  4 (n_samples <= 256, ~130 registers: four waves per SIMD) is the reference's
-// own size; 8 / 12 / 16 (n_samples <= 512 / 768 / 1 024; up to 512 registers, one wave per SIMD) extend the same kernel to
+// own size; 6 / 8 / 10 / 12 / 16 (n_samples <= 384 / 512 / 640 / 768 / 1 024; up to 512 registers, one wave per SIMD) extend the same kernel to
 // the batches of a few hundred to a thousand samples in between, where a 512-thread workgroup per matrix spends most of
 // an iteration in its epilogue: 16 384 x (16 x 300), k = 5, fp32: 56 (workgroup per matrix) / 63 M (fit_wide4_kernel) matrix-it/s.
 constexpr int SMALL_MAX_T = SMALL_NT * WAVE;
@@ -30,7 +30,7 @@ template <typename real, int CH, int K, int NT = SMALL_NT>
 __global__ void __launch_bounds__(64) fit_small_kernel(SolveArgs<real> a) {
   using C = Cfg<real, 1, CH, K>;
   constexpr int NB = C::NB;
-  constexpr int TG = 4;  // tiles per group in the W update (the temporaries of a group live at once)
+  constexpr int TG = (NT % 4 == 0) ? 4 : 2;  // tiles per group in the W update (the temporaries of a group live at once)
   static_assert(NT % TG == 0, "whole groups of tiles");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   Smem<real, 1, CH, K> s(smem_raw, 1);

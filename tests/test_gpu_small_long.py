@@ -1,4 +1,4 @@
-"""GPU parity of the fit_small_kernel instances with 8 / 12 / 16 tiles of 64 rows in registers (one WAVE per matrix, nothing
+"""GPU parity of the fit_small_kernel instances with 6 / 8 / 10 / 12 / 16 tiles of 64 rows in registers (one WAVE per matrix, nothing
 but registers and a little LDS inside an iteration; nmf_small.hpp, inst_small_long.hpp): matrices of 257..1024 samples, the
 sizes between the reference's time-normalised cycles and long recordings.  Variant 6 pins the kernel; batches that give every
 SIMD a wave get it by themselves."""
@@ -17,11 +17,13 @@ def _rel(X, W, H, ref):
     return np.linalg.norm(W.astype(np.float64) @ H.astype(np.float64) - ref["W"].astype(np.float64) @ ref["H"].astype(np.float64)) / xn
 
 
-CASES = [  # dtype, m, k, T, tiles
-    (np.float32, 16, 5, 257, 8), (np.float32, 16, 8, 512, 8), (np.float32, 9, 3, 300, 8), (np.float32, 8, 8, 400, 8), (np.float32, 3, 2, 511, 8),
-    (np.float32, 16, 6, 513, 12), (np.float32, 12, 5, 768, 12), (np.float32, 8, 6, 700, 12), (np.float32, 5, 1, 600, 12),
+CASES = [  # dtype, m, k, T, tiles: the smallest compiled tile count that holds T rows
+    (np.float32, 16, 5, 257, 6), (np.float32, 16, 8, 384, 6), (np.float32, 9, 3, 300, 6), (np.float32, 8, 8, 400, 8), (np.float32, 16, 8, 512, 8),
+    (np.float32, 3, 2, 511, 8), (np.float32, 16, 6, 513, 10), (np.float32, 16, 6, 640, 10), (np.float32, 5, 1, 600, 10), (np.float32, 16, 7, 520, None),
+    (np.float32, 12, 5, 768, 12), (np.float32, 8, 6, 700, 12),
     (np.float32, 16, 3, 769, 16), (np.float32, 16, 1, 1024, 16), (np.float32, 8, 5, 1000, 16), (np.float32, 7, 4, 900, 16),
-    (np.float64, 8, 6, 300, 8), (np.float64, 8, 4, 512, 8), (np.float64, 4, 2, 400, 8), (np.float64, 8, 3, 768, 12), (np.float64, 6, 1, 600, 12),
+    (np.float64, 8, 6, 300, 6), (np.float64, 8, 5, 384, 6), (np.float64, 8, 4, 512, 8), (np.float64, 4, 2, 400, 8), (np.float64, 8, 3, 768, 12),
+    (np.float64, 6, 1, 600, 12),
 ]
 
 
@@ -32,6 +34,12 @@ def test_small_kernel_long_instances_match_oracle(dtype, m, k, T, tiles):
 
     h = _lib.Handle(0)
     h.set_tuning(0, 0, 6)
+    if tiles is None:  # 7, 8 components beyond 512 samples: no instance (the registers run out) -- refused under variant 6
+        X = emg_matrix(1, T=T, m=m, k_true=3, dtype=dtype)
+        W0, H0 = random_init(X, k, 1)
+        with pytest.raises(_lib.HipNmfError, match="fit_small_kernel"):
+            ms.fit_batched(X, W0, H0, max_iter=2, tol=0.0, handle=h)
+        return
     lim = TOL if dtype == np.float32 else 1e-10
     Xs = [emg_matrix(50 + i, T=T, m=m, k_true=min(4, m), dtype=dtype) for i in range(3)]
     inits = [random_init(x, k, 60 + i) for i, x in enumerate(Xs)]
