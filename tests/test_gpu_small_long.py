@@ -48,7 +48,8 @@ def test_small_kernel_long_instances_match_oracle(dtype, m, k, T, tiles):
         Xb = np.stack(Xs) if order == "C" else np.ascontiguousarray(np.stack(Xs).transpose(0, 2, 1)).transpose(0, 2, 1)
         res = ms.fit_batched(Xb, W0, H0, max_iter=40, tol=0.0, handle=h)
         name = h.last_kernel()
-        assert name == "fit_small_kernel<%s,%d,%d,%d>" % ("float" if dtype == np.float32 else "double", 8 if m <= 8 else 16, k, tiles), name
+        want = "fit_small_kernel<%s,%d,%d" % ("float" if dtype == np.float32 else "double", 8 if m <= 8 else 16, k)
+        assert name == want + (">" if tiles == 4 else ",%d>" % tiles), name
         for i in range(3):
             ref = orc.nmf_mu_fit(Xs[i], W0[i], H0[i], max_iter=40, tol=0.0)
             assert _rel(Xs[i], res.W[i], res.H[i], ref) <= lim
