@@ -216,9 +216,14 @@ bool wide_preferred(int m, int k, const hipnmf_problem* p, const hipnmf_handle* 
   const long long T = p->n_samples;
   if (m <= 16) {  // beyond the reach of fit_small_kernel (one wave per matrix: n_samples <= 256, and up to 1 024 for some shapes
                   // when the batch gives every SIMD a wave -- then that kernel is the fastest of the three: inst_small_long.hpp)
-    if (T <= 256)  // fit_small_kernel's own range -- where it exists: float64 beyond 8 channels / 6 components has no instance, and a
-                   // workgroup per such matrix is slow (16 384 x (16 x 200), k = 5: 40 -> 77 M matrix-it/s; 16 x 128, k = 8: 25 -> 102)
-      return sizeof(real) == 8 && (m > 8 || k > 6);
+    if (T <= 256) {
+      // fit_small_kernel's own range -- where it exists: float64 with more than 6 components has no instance, and a workgroup per
+      // such matrix is slow (16 x 128, k = 8: 25 -> 102 M matrix-it/s).  float64 with 9..16 channels (instances since round 3):
+      // 16 384 x (16 x 200), k = 5: workgroup 40 / 4x4 kernel 78 / one wave per matrix 146; k = 3: - / 188 / 294; 16 x 250, k = 6: - / 71 / 115;
+      // but 12 x 128, k = 4: 268 / 212 (half of the 256 rows are padding)
+      if (sizeof(real) != 8) return false;
+      return k > 6 || (m > 8 && T <= 128);
+    }
     int nt = 0;
     const int small_min = small_long_min_batch<real>(h);
     if (!ragged && small_kernel_long<real>(m, k, T, &nt) && (p->batch >= small_min || h->path_batch_hint >= small_min)) return false;
@@ -331,7 +336,7 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
     }
     if (h->variant == 6 && !small_ok)
       return fail(HIPNMF_ERR_UNSUPPORTED, "fit_small_kernel needs n_samples <= 256 (<= 512 / 768 / 1 024 for some shapes), the Frobenius loss and "
-                  "n_features <= %d (n_samples=%lld, n_features=%d, n_components=%d)", sizeof(real) == 8 ? 8 : 16, T, m, k);
+                  "n_features <= 16 (float64: at most 6 components; n_samples=%lld, n_features=%d, n_components=%d)", T, m, k);
     use_small = small_ok && (h->variant == 6 || (h->variant == 0 && small_env));
     if (use_small) {
       persistent = true;

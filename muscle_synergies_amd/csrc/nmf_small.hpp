@@ -30,7 +30,9 @@ template <typename real, int CH, int K, int NT = SMALL_NT>
 __global__ void __launch_bounds__(64) fit_small_kernel(SolveArgs<real> a) {
   using C = Cfg<real, 1, CH, K>;
   constexpr int NB = C::NB;
-  constexpr int TG = (NT % 4 == 0) ? 4 : 2;  // tiles per group in the W update (the temporaries of a group live at once)
+  // tiles per group in the W update (the temporaries of a group live at once).  (float64, 16 channels, k = 5 in groups of four came
+  // out of hipcc returning wrong factors -- its neighbours k = 1..4, 6 were exact -- and one tile at a time is 6x slower: groups of two)
+  constexpr int TG = (sizeof(real) == 8 && CH == 16 && K == 5) ? 2 : (NT % 4 == 0) ? 4 : 2;
   static_assert(NT % TG == 0, "whole groups of tiles");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   Smem<real, 1, CH, K> s(smem_raw, 1);

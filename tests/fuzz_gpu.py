@@ -76,9 +76,8 @@ for case in range(a.cases):
             continue
         if wide and dtype == np.float64 and k > 16 and m > 64 and "bytes of LDS" in str(e):
             continue
-        if variant == 6 and ("fit_small_kernel" in str(e)):  # n_samples <= 256 (more for some shapes), Frobenius, m <= 16 (fp32) / 8 (fp64, k <= 6)
-            assert not (max(Ts) <= 256 and loss == "frobenius" and m <= (16 if dtype == np.float32 else 8)
-                        and not (dtype == np.float64 and k > 6)), desc
+        if variant == 6 and ("fit_small_kernel" in str(e)):  # n_samples <= 256 (more for some shapes), Frobenius, m <= 16, fp64: k <= 6
+            assert not (max(Ts) <= 256 and loss == "frobenius" and m <= 16 and not (dtype == np.float64 and k > 6)), desc
             continue
         if variant == 5 and ("fit_rowlane_kernel" in str(e)):  # fp32, 9..16 channels, Frobenius only
             assert not (dtype == np.float32 and 8 < m <= 16 and loss == "frobenius"), desc

@@ -147,7 +147,7 @@ def test_ragged_batch_and_restarts_on_the_matrix_pipe_instance():
     np.testing.assert_allclose(best, err.min(axis=1), rtol=1e-6)
 
 
-@pytest.mark.parametrize("dtype,m,k,T", [(np.float64, 8, 3, 200), (np.float64, 8, 6, 256), (np.float64, 5, 2, 1),
+@pytest.mark.parametrize("dtype,m,k,T", [(np.float64, 8, 3, 200), (np.float64, 8, 6, 256), (np.float64, 5, 2, 1), (np.float64, 16, 5, 200), (np.float64, 11, 6, 77),
                                         (np.float32, 8, 8, 130), (np.float32, 16, 5, 200), (np.float32, 13, 8, 255),
                                         (np.float32, 2, 1, 64)])
 def test_one_wave_per_matrix_kernel(dtype, m, k, T):

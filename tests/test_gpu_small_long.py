@@ -104,3 +104,39 @@ def test_small_kernel_long_is_the_librarys_choice_for_big_batches_only():
     wb, hb = random_init(big, 5, 1)
     with pytest.raises(_lib.HipNmfError, match="fit_small_kernel"):
         ms.fit_batched(big, wb, hb, max_iter=2, tol=0.0, handle=h)
+
+
+def test_every_compiled_one_wave_instance_matches_oracle():
+    """Every (dtype, channel padding, k, tiles) instance of fit_small_kernel, three iterations against the oracle: the
+    instances are spill-heavy builds of one template, and one of them (float64, 16 channels, k = 5, groups of four tiles)
+    once came out of the compiler wrong while its neighbours were exact."""
+    import muscle_synergies_amd as ms
+    from muscle_synergies_amd import _lib
+
+    h = _lib.Handle(0)
+    h.set_tuning(0, 0, 6)
+    table = {  # (dtype, CH): {tiles: max k}   (inst_small.hip, inst_small_long.hpp)
+        (np.float32, 8): {4: 8, 6: 8, 8: 8, 10: 6, 12: 6, 16: 5},
+        (np.float32, 16): {4: 8, 6: 8, 8: 8, 10: 6, 12: 6, 16: 3},
+        (np.float64, 8): {4: 6, 6: 6, 8: 6, 12: 3},
+        (np.float64, 16): {4: 6},
+    }
+    bad, n = [], 0
+    for (dtype, CH), tiles in table.items():
+        for nt, kmax in tiles.items():
+            for k in range(1, kmax + 1):
+                m = CH if (k + nt) % 2 else CH - 3
+                T = 64 * nt - (k % 5)
+                X = emg_matrix(nt * 100 + k, T=T, m=m, k_true=min(3, m), dtype=dtype)
+                W0, H0 = random_init(X, k, nt + k)
+                r = ms.fit_batched(X, W0, H0, max_iter=3, tol=0.0, handle=h)
+                want = "fit_small_kernel<%s,%d,%d" % ("float" if dtype == np.float32 else "double", CH, k) + (">" if nt == 4 else ",%d>" % nt)
+                assert h.last_kernel() == want, (h.last_kernel(), want)
+                ref = orc.nmf_mu_fit(X, W0, H0, max_iter=3, tol=0.0)
+                lim = 2e-6 if dtype == np.float32 else 1e-12
+                d = max(np.abs(r.W[0] - ref["W"]).max() / max(np.abs(ref["W"]).max(), 1e-30), np.abs(r.H[0] - ref["H"]).max() / np.abs(ref["H"]).max())
+                n += 1
+                if not d <= lim:
+                    bad.append((want, T, m, float(d)))
+    assert not bad, bad
+    assert n == 8 + 8 + 8 + 6 + 6 + 5 + 8 + 8 + 8 + 6 + 6 + 3 + 6 + 6 + 6 + 3 + 6

@@ -312,8 +312,8 @@ print('problems', bad)
     (np.float64, 8, 4, 400, 800, "fit_small_kernel<double,8,4,8>"),
     (np.float64, 8, 4, 400, 640, "fit_wide4d_kernel<16,1"),
     (np.float32, 16, 5, 900, 640, "fit_persistent_kernel<float"),
-    (np.float64, 16, 5, 200, 640, "fit_wide4d_kernel<16,2"),    # float64 beyond fit_small_kernel's shapes, however short
-    (np.float64, 12, 4, 100, 640, "fit_wide4d_kernel<16,1"),
+    (np.float64, 16, 5, 200, 640, "fit_small_kernel<double,16,5>"),  # float64 with 9..16 channels: one wave per matrix up to 256 samples ...
+    (np.float64, 12, 4, 100, 640, "fit_wide4d_kernel<16,1"),   # ... except the very short ones (half of its 256 rows would be padding)
     (np.float64, 8, 7, 128, 640, "fit_wide4d_kernel<16,2"),
     (np.float64, 8, 4, 200, 640, "fit_small_kernel<double,8,4>"),
 ])
