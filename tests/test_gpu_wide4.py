@@ -342,3 +342,40 @@ def test_batches_of_narrow_shapes_routed_to_the_4x4_kernels(dtype, m, k, T, B, k
             np.testing.assert_allclose(H, ref["H"], rtol=1e-9, atol=1e-13)
         else:
             assert _rel(Xb[b], W, H, ref) <= TOL
+
+
+def test_every_compiled_4x4_instance_matches_oracle():
+    """Every (channel padding, component quads, waves) instance of fit_wide4_kernel / fit_wide4d_kernel, three iterations on a
+    matrix with a ragged last subtile, against the oracle (see tests/test_gpu_small_long.py for why every instance)."""
+    code = f"""
+import sys, numpy as np
+sys.path.insert(0, {ROOT!r})
+sys.path.insert(0, {os.path.join(ROOT, "tests")!r})
+import muscle_synergies_amd as ms
+from muscle_synergies_amd import _lib
+from muscle_synergies_amd.synth import emg_matrix, random_init
+from oracle import nmf_mu_oracle as orc
+bad, seen = 0, set()
+for dtype, chans, waves in ((np.float32, (16, 32, 48, 64, 96, 128), (256, 512, 768)), (np.float64, (16, 32, 48, 64, 96, 128), (256, 512))):
+    for MP in chans:
+        for k in (3, 7):
+            for threads in waves:
+                m = MP - 1 if k == 3 else MP
+                h = _lib.Handle(0); h.set_tuning(threads, 0, 1)
+                X = emg_matrix(MP + k, T=203, m=m, k_true=min(5, m), dtype=dtype); W0, H0 = random_init(X, k, MP + k)
+                r = ms.fit_batched(np.stack([X, X]), np.stack([W0, W0]), np.stack([H0, H0]), max_iter=3, tol=0.0, handle=h)
+                name = h.last_kernel()
+                assert name.startswith('fit_wide4_kernel<%d,' % MP if dtype == np.float32 else 'fit_wide4d_kernel<%d,' % MP), name
+                seen.add(name)
+                ref = orc.nmf_mu_fit(X, W0, H0, max_iter=3, tol=0.0)
+                lim = 3e-6 if dtype == np.float32 else 1e-12
+                d = max(np.abs(r.W[1] - ref['W']).max() / np.abs(ref['W']).max(), np.abs(r.H[1] - ref['H']).max() / np.abs(ref['H']).max())
+                e = abs(float(r.reconstruction_err[1]) - float(ref['reconstruction_err'])) / np.linalg.norm(X)
+                if not (d <= lim and e <= max(lim, 1e-6 if dtype == np.float32 else 1e-12)):
+                    print('MISMATCH', name, m, k, d, e); bad += 1
+print('instances', len(seen), 'problems', bad)
+"""
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, HIPNMF_FORCE_WIDE="1"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "problems 0" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    # fp32: 4 paddings x 2 quads x 3 wave counts + 2 x 2 x 2 (96 / 128 channels: 4, 8 waves); fp64: 4 x 2 x 2 + 2 x 2 (256 threads only)
+    assert "instances %d " % (4 * 2 * 3 + 2 * 2 * 2 + 4 * 2 * 2 + 2 * 2) in r.stdout, r.stdout[-300:]
