@@ -1,3 +1,5 @@
+"""Probe that isolated the miscompiled one-wave instance: every float64 16-channel fit_small_kernel instance, one
+iteration against the oracle under variant 6; prints BAD where W or H differ.  Run on the GPU box: python tools/repro/dbg_small_f64_16.py"""
 import sys, os, numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import muscle_synergies_amd as ms
