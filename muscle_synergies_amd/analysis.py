@@ -89,6 +89,31 @@ def _check_component_range(df: pandas.DataFrame, n_components: int, max_componen
         raise ValueError(message)
 
 
+_RANK_POOL = None
+
+
+def _rank_pool():
+    """The worker threads of the rank ranges: created once and kept, so that each keeps its engine handle (stream, events,
+    workspace: ``_lib.get_handle`` caches per thread) from call to call."""
+    global _RANK_POOL
+    if _RANK_POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+
+        _RANK_POOL = ThreadPoolExecutor(max_workers=8, thread_name_prefix="hipnmf-rank")
+    return _RANK_POOL
+
+
+def _ranks_concurrently(n_ranks: int, nmf_kwargs) -> bool:
+    """Whether the solver calls of a rank range may run from concurrent host threads: GPU path only (scikit-learn's solvers
+    keep the reference's sequential loop).  The initialisations are still computed in rank order on the calling thread, so a
+    seeded global generator or a shared ``RandomState`` is consumed exactly as by the loop.  ``HIPNMF_RANK_THREADS=0`` keeps the loop."""
+    import os
+
+    if n_ranks < 2 or os.environ.get("HIPNMF_RANK_THREADS", "1") == "0":
+        return False
+    return nmf_kwargs.get("solver") == "mu" and HipNMF.supports(**nmf_kwargs)
+
+
 def _single_run(df: pandas.DataFrame, n_components: int, **nmf_kwargs) -> SynergyRunResult:
     """One factorisation + its VAF row (``analysis.py:866-882``)."""
     model = _make_model(n_components, n_features=len(df.columns), **nmf_kwargs)
@@ -120,9 +145,31 @@ def find_synergies(processed_emg_df: pandas.DataFrame, n_components: int, max_co
     if max_components is None:
         return _single_run(processed_emg_df, n_components, max_iter=max_iter, tol=tol, **sklearn_kwargs)
 
+    ranks = list(range(n_components, max_components + 1))
     runs = OrderedDict()
-    for rank in range(n_components, max_components + 1):
-        runs[rank] = _single_run(processed_emg_df, rank, max_iter=max_iter, tol=tol, **sklearn_kwargs)
+    if _ranks_concurrently(len(ranks), sklearn_kwargs):
+        # The fits of a rank range are independent.  Host preparation (validation, initialisation -- the only consumer of
+        # random_state / NumPy's global generator) runs here, rank by rank as in the loop below; then every rank's solver call
+        # goes to a worker thread, each with its own handle and stream (_lib.get_handle is per thread, the C call releases the
+        # GIL), so the ranks' kernels overlap instead of queueing: the call takes the time of its longest fit, not the sum.
+        models = [_make_model(rank, n_features=len(processed_emg_df.columns), max_iter=max_iter, tol=tol, **sklearn_kwargs) for rank in ranks]
+        if all(isinstance(mdl, HipNMF) for mdl in models):
+            prepared = [mdl._prepare(processed_emg_df) for mdl in models]
+
+            def fit(mdl, prep):
+                transformed = mdl._fit_prepared(*prep)
+                vaf_row = vaf(processed_emg_df, transformed_signal=transformed, components=mdl.components_)
+                return SynergyRunResult(vaf_row, pandas.DataFrame(mdl.components_, columns=processed_emg_df.columns), mdl)
+
+            futures = [_rank_pool().submit(fit, mdl, prep) for mdl, prep in zip(models, prepared)]
+            for rank, fut in zip(ranks, futures):
+                runs[rank] = fut.result()
+        else:
+            for rank in ranks:
+                runs[rank] = _single_run(processed_emg_df, rank, max_iter=max_iter, tol=tol, **sklearn_kwargs)
+    else:
+        for rank in ranks:
+            runs[rank] = _single_run(processed_emg_df, rank, max_iter=max_iter, tol=tol, **sklearn_kwargs)
 
     table = pandas.concat([run.vaf_values for run in runs.values()])
     table.set_index(np.array(tuple(runs.keys())), inplace=True)

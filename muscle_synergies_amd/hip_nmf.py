@@ -163,6 +163,12 @@ class HipNMF:
     # -- fitting -----------------------------------------------------------------------------------
     def fit_transform(self, X, y=None, W=None, H=None):
         """Learn the factorisation and return W (``_nmf.py:1594-1636``)."""
+        return self._fit_prepared(*self._prepare(X, W, H))
+
+    def _prepare(self, X, W=None, H=None):
+        """Everything of ``fit_transform`` that happens on the host before the solver runs: parameter and input validation
+        and the initialisation (the only consumer of ``random_state`` / NumPy's global generator).  ``find_synergies``
+        prepares the ranks of a range in order and then lets the fits run concurrently."""
         self._check_params()
         whom = "NMF (input X)" if self.init == "custom" else "NMF initialization"
         columns = getattr(X, "columns", None)
@@ -183,6 +189,12 @@ class HipNMF:
                 warnings.warn("When init!='custom', provided W or H are ignored. Set  init='custom' to use them as initialization.",
                               RuntimeWarning)
             W0, H0 = initialize_nmf(X, k, init=self.init, random_state=self.random_state)
+        return X, columns, W0, H0
+
+    def _fit_prepared(self, X, columns, W0, H0):
+        """The solver on a prepared problem (see ``_prepare``); sets the fitted attributes and returns W."""
+        T, m = X.shape
+        k = W0.shape[1]
         l1w, l1h, l2w, l2h = self._regularization(T, m)
         try:
             res = engine.fit_batched(X, W0, H0, max_iter=self.max_iter, tol=self.tol, l1_reg_W=l1w, l1_reg_H=l1h,

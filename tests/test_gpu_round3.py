@@ -176,3 +176,38 @@ def test_kullback_leibler_on_the_matrix_pipe(k):
     if k >= 6:  # the library's own choice
         ms.fit_batched(np.stack([X] * 3), np.stack([W0] * 3), np.stack([H0] * 3), max_iter=3, tol=0.0, beta_loss="kullback-leibler", handle=h)
         assert h.last_kernel().endswith("[kl]") and "rowlane" in h.last_kernel()
+
+
+def test_find_synergies_rank_range_concurrent_threads_equal_the_sequential_loop(monkeypatch):
+    """The ranks of find_synergies(df, n, max, solver='mu') run from concurrent host threads (one handle and stream each):
+    same VAF table, components and iteration counts as the sequential loop (HIPNMF_RANK_THREADS=0), bit for bit."""
+    import time
+
+    import pandas as pd
+
+    import muscle_synergies_amd as ms
+
+    X = emg_matrix(21, T=200, m=8, k_true=3, dtype=np.float64)
+    df = pd.DataFrame(X, columns=[f"m{i}" for i in range(8)])
+    kw = dict(solver="mu", init="random", random_state=4, max_iter=4000, tol=1e-7)
+    out = {}
+    for mode in ("0", "1", "1"):
+        monkeypatch.setenv("HIPNMF_RANK_THREADS", mode)
+        t0 = time.perf_counter()
+        out[mode] = (ms.find_synergies(df, 2, 6, **kw), time.perf_counter() - t0)
+    seq, par = out["0"][0], out["1"][0]
+    pd.testing.assert_frame_equal(seq.vaf_values, par.vaf_values, check_exact=True)
+    assert list(seq.components) == list(par.components) == [2, 3, 4, 5, 6]
+    for k in seq.components:
+        pd.testing.assert_frame_equal(seq.components[k], par.components[k], check_exact=True)
+        assert seq.model[k].n_iter_ == par.model[k].n_iter_
+    # the default initialisation draws from NumPy's global generator: seeded by the user, the concurrent call consumes it in rank
+    # order like the loop (the initialisations are computed on the calling thread), and a shared RandomState instance likewise
+    for make_rs in (lambda: None, lambda: np.random.RandomState(11)):
+        res = {}
+        for mode in ("0", "1"):
+            monkeypatch.setenv("HIPNMF_RANK_THREADS", mode)
+            np.random.seed(123)
+            res[mode] = ms.find_synergies(df, 2, 5, solver="mu", max_iter=300, tol=0.0, init="nndsvdar", random_state=make_rs())
+        for k in res["0"].components:
+            pd.testing.assert_frame_equal(res["0"].components[k], res["1"].components[k], check_exact=True)

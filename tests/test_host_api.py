@@ -179,3 +179,22 @@ def test_problem_struct_roundtrip():
     assert (p.batch, p.n_samples, p.n_features, p.n_components) == (7, 1000, 16, 5)
     assert (p.x_layout, p.update_h, p.w_layout, p.max_iter, p.check_every) == (1, 0, 0, 33, 10)
     assert (p.tol, p.l1_reg_W, p.l2_reg_H) == (1e-3, 0.5, 0.25)
+
+
+def test_rank_range_concurrency_rule(monkeypatch):
+    """find_synergies fits the ranks of a range from concurrent host threads only on the GPU path and only when that cannot
+    change what the reference's sequential loop would compute."""
+    import numpy as np
+
+    from muscle_synergies_amd.analysis import _ranks_concurrently
+
+    monkeypatch.delenv("HIPNMF_RANK_THREADS", raising=False)
+    assert _ranks_concurrently(3, dict(solver="mu"))
+    assert _ranks_concurrently(2, dict(solver="mu", random_state=7, init="random"))
+    assert not _ranks_concurrently(1, dict(solver="mu"))
+    assert not _ranks_concurrently(3, dict())                      # the reference's default solver: scikit-learn, sequential
+    assert not _ranks_concurrently(3, dict(solver="cd"))
+    assert not _ranks_concurrently(3, dict(solver="mu", beta_loss="itakura-saito"))
+    assert _ranks_concurrently(3, dict(solver="mu", random_state=np.random.RandomState(0)))  # (initialisations stay in rank order on the calling thread)
+    monkeypatch.setenv("HIPNMF_RANK_THREADS", "0")
+    assert not _ranks_concurrently(3, dict(solver="mu"))
