@@ -1,4 +1,5 @@
-// nmf_wide4.hpp -- the wide-shape solver for few components (fp32, 33..128 channels, n_components <= 8): the same
+// nmf_wide4.hpp -- the matrix-pipe solver for few components (fp32, n_components <= 8; 33..128 channels, and batches of narrower
+// matrices where hipnmf_api.hip::wide_preferred measured it faster than the lane mappings: MP = 16 / 32): the same
 // iteration as fit_wide_kernel (nmf_wide.hpp), with every contraction on v_mfma_f32_4x4x1_16b_f32 instead of
 // v_mfma_f32_16x16x4_f32.
 //

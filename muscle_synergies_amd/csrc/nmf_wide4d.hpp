@@ -1,4 +1,4 @@
-// nmf_wide4d.hpp -- float64 counterpart of fit_wide4_kernel (nmf_wide4.hpp): wide shapes (33..128 channels) with at most 8
+// nmf_wide4d.hpp -- float64 counterpart of fit_wide4_kernel (nmf_wide4.hpp): 1..128 channels (MP = 16 .. 128) with at most 8
 // components on v_mfma_f64_4x4x4_4b_f64 instead of v_mfma_f64_16x16x4_f64.  float64 is what the reference's own calls carry
 // (a DataFrame is float64 and scikit-learn keeps the dtype: src/muscle_synergies/analysis.py:862-863, sklearn/decomposition/
 // _nmf.py:1638-1734), and the 16x16x4 tile pads the components to 16: at k = 8 half of every fp64 MFMA -- 64 pipe cycles
