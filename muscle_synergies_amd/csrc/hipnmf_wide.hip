@@ -174,7 +174,18 @@ int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
   } else if (h->variant == 2) {
     return fail(HIPNMF_ERR_UNSUPPORTED, "the row-sliced wide path handles uniform Frobenius batches only");
   }
-  if (sliced) wk = wk4;
+  if (sliced) {
+    wk = wk4;
+    // the 256-thread instance of the 4x4 kernels where one exists (at most 8 components, Frobenius): same slice records
+    // (KP = 4 or 8 rows instead of 16), same phases (HIPNMF_WIDE4_SLICED=0: the 16x16x4 kernel)
+    static const bool sliced4 = [] {
+      const char* e = getenv("HIPNMF_WIDE4_SLICED");
+      const char* e4 = getenv("HIPNMF_WIDE4");
+      return !(e && e[0] == '0') && !(e4 && e4[0] == '0');
+    }();
+    const WideKernel<real>* w4s = (sliced4 && !kl && m > HIPNMF_NARROW_MAX_FEATURES) ? pick4<real>(m, k, 4) : nullptr;
+    if (w4s && w4s->NW == 4 && w4s->smem <= (size_t)h->lds_per_block) wk = w4s;
+  }
   // one workgroup per matrix, Frobenius, fp32, at most 8 components: the 4x4x1 formulation (HIPNMF_WIDE4=0: the 16x16x4 one)
   if (!sliced && !kl) {
     static const bool use4 = [] {

@@ -137,6 +137,17 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
     Wb = a.W + d[3];
   }
   const int m = a.m, k = a.k;  // (a.ks == KP: the host picks KQ = ks / 4)
+  const int slice = blockIdx.y;
+  if (a.mode != 0) {  // row-sliced mode (nmf_wide.hpp): a slice is a matrix of its own for everything row-local
+    if (a.state && a.state[(long long)b * 8 + 3] != 0.0f) return;
+    const int row_begin = slice * a.rows_per_slice;
+    int rows = T - row_begin;
+    if (rows > a.rows_per_slice) rows = a.rows_per_slice;
+    if (rows <= 0) rows = 0;
+    Xb += (long long)row_begin * a.ldx;
+    Wb += (long long)row_begin * KP;
+    T = rows;
+  }
   const int ntiles = (T + 15) / 16;
   float* const wcache = wv0 + NW * C::PERWAVE;  // [lds_rows][KP]
   const int ncached = (a.lds_rows / 16 < ntiles) ? a.lds_rows / 16 : ntiles;
@@ -420,6 +431,75 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
     return sqrt_(tot);
   };
 
+  // per-wave record [W^T X | W^T W] of a pass over the wave's stages (idle between passes); the waves' records are summed in fixed order
+  auto write_record = [&]() __attribute__((always_inline)) {
+    float* rec = xs;
+#pragma unroll
+    for (int cg = 0; cg < KQ; ++cg) {
+      if constexpr (LP < 64) {  // lanes l, l + LP, ... hold the sums over the rows of their group for the same channel
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float v = accA[0][cg][q];
+          if constexpr (LP == 16) v += __shfl_xor(v, 16, WAVE);
+          v += __shfl_xor(v, 32, WAVE);
+          if (lane < MP) rec[(4 * cg + q) * MP + lane] = v;
+        }
+      } else {
+#pragma unroll
+        for (int h = 0; h < NH; ++h)
+          if (64 * h + lane < MP) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) rec[(4 * cg + q) * MP + 64 * h + lane] = accA[h][cg][q];
+          }
+      }
+#pragma unroll
+      for (int cg2 = 0; cg2 < KQ; ++cg2)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          // sum over the 16 blocks (= rows of the subtiles): two row rotations, two cross-row exchanges
+          float v = accB[cg][cg2][q];
+          v += dpp_mov<0x124>(v);
+          v += dpp_mov<0x128>(v);
+          v += __shfl_xor(v, 16, WAVE);
+          v += __shfl_xor(v, 32, WAVE);
+          if (lane < 4) rec[KP * MP + (4 * cg + q) * KP + 4 * cg2 + lane] = v;
+        }
+    }
+  };
+
+  if (a.mode == 2) {  // residual of the slice: per-column sums to global memory, summed over the slices by wide_resid_finalize_kernel
+    block_resid();
+    float* out = a.colpart + ((long long)b * a.S + slice) * (2 * MP);
+    for (int idx = tid; idx < 2 * MP; idx += NT) out[idx] = sPart[idx];
+    return;
+  }
+  if (a.mode == 1) {  // one update pass over the slice, its record to global memory (wide_hupdate_kernel sums the slices)
+#pragma unroll
+    for (int cg = 0; cg < KQ; ++cg) {
+#pragma unroll
+      for (int h = 0; h < NH; ++h) accA[h][cg] = zero;
+#pragma unroll
+      for (int cg2 = 0; cg2 < KQ; ++cg2) accB[cg][cg2] = zero;
+    }
+    const bool upd1 = a.update_h != 0;
+    Tile t1;
+    issue(t1, wave);
+    for (int i = wave; i < ntiles; i += NW) {
+      update_subtile(t1, i, i + NW, upd1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (!upd1) return;
+    write_record();
+    __syncthreads();
+    float* out = a.part + ((long long)b * a.S + slice) * C::REC;
+    for (int idx = tid; idx < C::REC; idx += NT) {
+      float sacc = wv0[idx];
+      for (int w2 = 1; w2 < NW; ++w2) sacc += wv0[w2 * C::PERWAVE + idx];
+      out[idx] = sacc;
+    }
+    return;
+  }
+
   float err0 = 0.0f, prev = 0.0f;
   if (a.tol > 0.0f) {
     block_resid();
@@ -471,39 +551,7 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
       __builtin_amdgcn_sched_barrier(0);
     }
     if (upd) {
-      // per-wave record [W^T X | W^T W] over the wave's stages (idle between passes), fixed-order sum over the waves
-      float* rec = xs;
-#pragma unroll
-      for (int cg = 0; cg < KQ; ++cg) {
-        if constexpr (LP < 64) {  // lanes l, l + LP, ... hold the sums over the rows of their group for the same channel
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            float v = accA[0][cg][q];
-            if constexpr (LP == 16) v += __shfl_xor(v, 16, WAVE);
-            v += __shfl_xor(v, 32, WAVE);
-            if (lane < MP) rec[(4 * cg + q) * MP + lane] = v;
-          }
-        } else {
-#pragma unroll
-          for (int h = 0; h < NH; ++h)
-            if (64 * h + lane < MP) {
-#pragma unroll
-              for (int q = 0; q < 4; ++q) rec[(4 * cg + q) * MP + 64 * h + lane] = accA[h][cg][q];
-            }
-        }
-#pragma unroll
-        for (int cg2 = 0; cg2 < KQ; ++cg2)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            // sum over the 16 blocks (= rows of the subtiles): two row rotations, two cross-row exchanges
-            float v = accB[cg][cg2][q];
-            v += dpp_mov<0x124>(v);
-            v += dpp_mov<0x128>(v);
-            v += __shfl_xor(v, 16, WAVE);
-            v += __shfl_xor(v, 32, WAVE);
-            if (lane < 4) rec[KP * MP + (4 * cg + q) * KP + 4 * cg2 + lane] = v;
-          }
-      }
+      write_record();
       __syncthreads();
       for (int idx = tid; idx < C::REC; idx += NT) {
         float s = wv0[idx];

@@ -95,6 +95,17 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WP
     Wb = a.W + d[3];
   }
   const int m = a.m, k = a.k;  // (a.ks == KP: the host picks KQ = ks / 4)
+  const int slice = blockIdx.y;
+  if (a.mode != 0) {  // row-sliced mode (nmf_wide.hpp): a slice is a matrix of its own for everything row-local
+    if (a.state && a.state[(long long)b * 8 + 3] != 0.0) return;
+    const int row_begin = slice * a.rows_per_slice;
+    int rows = T - row_begin;
+    if (rows > a.rows_per_slice) rows = a.rows_per_slice;
+    if (rows <= 0) rows = 0;
+    Xb += (long long)row_begin * a.ldx;
+    Wb += (long long)row_begin * KP;
+    T = rows;
+  }
   const int ntiles = (T + 15) / 16;
   double* const wcache = wv0 + NW * C::PERWAVE;  // [lds_rows][KP]
   const int ncached = (a.lds_rows / 16 < ntiles) ? a.lds_rows / 16 : ntiles;
@@ -317,6 +328,57 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WP
     return sqrt_(tot);
   };
 
+  // per-wave record [W^T X | W^T W] of a pass over the wave's stages (idle between passes); the waves' records are summed in fixed order
+  auto write_record = [&]() __attribute__((always_inline)) {
+    double* rec = xs;
+#pragma unroll
+    for (int cg = 0; cg < KQ; ++cg) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) rec[(4 * cg + q2) * MP + 16 * q + 4 * q1 + q0] = accA[q][cg];
+#pragma unroll
+      for (int cg2 = 0; cg2 < KQ; ++cg2) {
+        // accB lane (j, b, i): partial over the rows of quad b of W^T W[4 cg + i][4 cg2 + j]: sum over b (lane bits 2, 3)
+        double v = accB[cg][cg2];
+        v += __shfl_xor(v, 4, WAVE);
+        v += __shfl_xor(v, 8, WAVE);
+        if (q1 == 0) rec[KP * MP + (4 * cg + q2) * KP + 4 * cg2 + q0] = v;
+      }
+    }
+  };
+
+  if (a.mode == 2) {  // residual of the slice: per-column sums to global memory, summed over the slices by wide_resid_finalize_kernel
+    block_resid();
+    double* out = a.colpart + ((long long)b * a.S + slice) * (2 * MP);
+    for (int idx = tid; idx < 2 * MP; idx += NT) out[idx] = sPart[idx];
+    return;
+  }
+  if (a.mode == 1) {  // one update pass over the slice, its record to global memory (wide_hupdate_kernel sums the slices)
+#pragma unroll
+    for (int cg = 0; cg < KQ; ++cg) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) accA[q][cg] = 0.0;
+#pragma unroll
+      for (int cg2 = 0; cg2 < KQ; ++cg2) accB[cg][cg2] = 0.0;
+    }
+    const bool upd1 = a.update_h != 0;
+    Tile t1;
+    issue(t1, wave);
+    for (int i = wave; i < ntiles; i += NW) {
+      update_subtile(t1, i, i + NW, upd1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (!upd1) return;
+    write_record();
+    __syncthreads();
+    double* out = a.part + ((long long)b * a.S + slice) * C::REC;
+    for (int idx = tid; idx < C::REC; idx += NT) {
+      double sacc = wv0[idx];
+      for (int w2 = 1; w2 < NW; ++w2) sacc += wv0[w2 * C::PERWAVE + idx];
+      out[idx] = sacc;
+    }
+    return;
+  }
+
   double err0 = 0.0, prev = 0.0;
   if (a.tol > 0.0) {
     block_resid();
@@ -364,21 +426,7 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WP
       __builtin_amdgcn_sched_barrier(0);
     }
     if (upd) {
-      // per-wave record [W^T X | W^T W] over the wave's stages (idle between passes), fixed-order sum over the waves
-      double* rec = xs;
-#pragma unroll
-      for (int cg = 0; cg < KQ; ++cg) {
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) rec[(4 * cg + q2) * MP + 16 * q + 4 * q1 + q0] = accA[q][cg];
-#pragma unroll
-        for (int cg2 = 0; cg2 < KQ; ++cg2) {
-          // accB lane (j, b, i): partial over the rows of quad b of W^T W[4 cg + i][4 cg2 + j]: sum over b (lane bits 2, 3)
-          double v = accB[cg][cg2];
-          v += __shfl_xor(v, 4, WAVE);
-          v += __shfl_xor(v, 8, WAVE);
-          if (q1 == 0) rec[KP * MP + (4 * cg + q2) * KP + 4 * cg2 + q0] = v;
-        }
-      }
+      write_record();
       __syncthreads();
       for (int idx = tid; idx < C::REC; idx += NT) {
         double s = wv0[idx];
