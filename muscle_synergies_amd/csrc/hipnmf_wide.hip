@@ -186,7 +186,7 @@ int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
     const WideKernel<real>* w4s = (sliced4 && !kl && m > HIPNMF_NARROW_MAX_FEATURES) ? pick4<real>(m, k, 4) : nullptr;
     if (w4s && w4s->NW == 4 && w4s->smem <= (size_t)h->lds_per_block) wk = w4s;
   }
-  // one workgroup per matrix, Frobenius, fp32, at most 8 components: the 4x4x1 formulation (HIPNMF_WIDE4=0: the 16x16x4 one)
+  // one workgroup per matrix, Frobenius, at most 8 components: the 4x4x1 / 4x4x4 formulation (HIPNMF_WIDE4=0: the 16x16x4 one)
   if (!sliced && !kl) {
     static const bool use4 = [] {
       const char* e = getenv("HIPNMF_WIDE4");
