@@ -103,13 +103,23 @@ def _rank_pool():
     return _RANK_POOL
 
 
-def _ranks_concurrently(n_ranks: int, nmf_kwargs) -> bool:
+# Concurrent ranks only for frames whose fits are single-workgroup launches (one wave or one workgroup per matrix).  Longer or
+# wider frames take the chip-filling paths -- row-sliced launches replayed as hipGraphs, the cooperative kernel -- which gain
+# nothing from overlapping and whose stream captures must not run side by side (tools/repro/rank_threads_long_matrix.py:
+# "operation failed due to a previous error during capture" with three threads capturing at once).
+_RANK_THREADS_MAX_SAMPLES = 2048
+_RANK_THREADS_MAX_FEATURES = 32
+
+
+def _ranks_concurrently(n_ranks: int, nmf_kwargs, shape=None) -> bool:
     """Whether the solver calls of a rank range may run from concurrent host threads: GPU path only (scikit-learn's solvers
-    keep the reference's sequential loop).  The initialisations are still computed in rank order on the calling thread, so a
+    keep the reference's sequential loop) and small frames only (see _RANK_THREADS_MAX_SAMPLES).  The initialisations are still computed in rank order on the calling thread, so a
     seeded global generator or a shared ``RandomState`` is consumed exactly as by the loop.  ``HIPNMF_RANK_THREADS=0`` keeps the loop."""
     import os
 
     if n_ranks < 2 or os.environ.get("HIPNMF_RANK_THREADS", "1") == "0":
+        return False
+    if shape is not None and (shape[0] > _RANK_THREADS_MAX_SAMPLES or shape[1] > _RANK_THREADS_MAX_FEATURES):
         return False
     return nmf_kwargs.get("solver") == "mu" and HipNMF.supports(**nmf_kwargs)
 
@@ -147,7 +157,7 @@ def find_synergies(processed_emg_df: pandas.DataFrame, n_components: int, max_co
 
     ranks = list(range(n_components, max_components + 1))
     runs = OrderedDict()
-    if _ranks_concurrently(len(ranks), sklearn_kwargs):
+    if _ranks_concurrently(len(ranks), sklearn_kwargs, processed_emg_df.shape):
         # The fits of a rank range are independent.  Host preparation (validation, initialisation -- the only consumer of
         # random_state / NumPy's global generator) runs here, rank by rank as in the loop below; then every rank's solver call
         # goes to a worker thread, each with its own handle and stream (_lib.get_handle is per thread, the C call releases the

@@ -196,5 +196,8 @@ def test_rank_range_concurrency_rule(monkeypatch):
     assert not _ranks_concurrently(3, dict(solver="cd"))
     assert not _ranks_concurrently(3, dict(solver="mu", beta_loss="itakura-saito"))
     assert _ranks_concurrently(3, dict(solver="mu", random_state=np.random.RandomState(0)))  # (initialisations stay in rank order on the calling thread)
+    assert _ranks_concurrently(3, dict(solver="mu"), (200, 8)) and _ranks_concurrently(3, dict(solver="mu"), (2048, 32))
+    assert not _ranks_concurrently(3, dict(solver="mu"), (10_000, 16))   # chip-filling paths (graphs, cooperative kernel): the loop
+    assert not _ranks_concurrently(3, dict(solver="mu"), (500, 64))
     monkeypatch.setenv("HIPNMF_RANK_THREADS", "0")
     assert not _ranks_concurrently(3, dict(solver="mu"))
