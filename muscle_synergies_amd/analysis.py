@@ -105,8 +105,8 @@ def _rank_pool():
 
 # Concurrent ranks only for frames whose fits are single-workgroup launches (one wave or one workgroup per matrix).  Longer or
 # wider frames take the chip-filling paths -- row-sliced launches replayed as hipGraphs, the cooperative kernel -- which gain
-# nothing from overlapping and whose stream captures must not run side by side (tools/repro/rank_threads_long_matrix.py:
-# "operation failed due to a previous error during capture" with three threads capturing at once).
+# little from overlapping, and the wide row-sliced path failed when three threads drove it at once ("operation failed due
+# to a previous error during capture": tools/repro/rank_threads_long_matrix.py with REPRO_UNLIMITED=1).
 _RANK_THREADS_MAX_SAMPLES = 2048
 _RANK_THREADS_MAX_FEATURES = 32
 

@@ -25,6 +25,11 @@
 
 using namespace hipnmf;
 
+std::mutex& hipnmf_capture_mutex() {
+  static std::mutex m;
+  return m;
+}
+
 thread_local std::string g_last_error;
 
 int hipnmf_fail(int code, const char* fmt, ...) {
@@ -708,12 +713,14 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
       // plain launch loop below takes over from wherever the replay stopped.
       hipGraph_t graph = nullptr;
       hipGraphExec_t exec = nullptr;
+      std::unique_lock<std::mutex> capture_lock(hipnmf_capture_mutex());
       hipError_t ge = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
       if (ge == hipSuccess) {
         enqueue(chunk, stop_rule);
         ge = hipStreamEndCapture(st, &graph);  // also leaves capture mode when an enqueued launch was invalid
       }
       if (ge == hipSuccess) ge = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+      capture_lock.unlock();
       int graph_rc = HIPNMF_OK;
       while (ge == hipSuccess && !converged && it_done + chunk <= p->max_iter) {
         ge = hipGraphLaunch(exec, st);

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstddef>
+#include <mutex>
 
 struct hipnmf_handle {
   int device = 0;
@@ -60,6 +61,12 @@ int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
 template <typename real>
 int hipnmf_random_init_indexed(hipnmf_handle* h, const hipnmf_problem* p, uint64_t seed, int first_matrix, const int* index,
                                const real* X, real* W, real* H);
+// Stream captures (the graph-replayed row-sliced paths) are serialised across the host threads of a process.  A precaution, not a
+// cure: three host threads driving the wide row-sliced path at once still ended with "operation failed due to a previous error
+// during capture" (tools/repro/rank_threads_long_matrix.py with REPRO_UNLIMITED=1; the cooperative kernel and the narrow sliced path
+// ran fine side by side), which is why the Python host fits the ranks of long or wide frames in a loop (analysis.py).
+std::mutex& hipnmf_capture_mutex();
+
 constexpr int HIPNMF_NARROW_MAX_FEATURES = 32, HIPNMF_NARROW_MAX_COMPONENTS = 8;  // nmf_kernels.hpp lane mappings
 constexpr int HIPNMF_MAX_FEATURES = 128, HIPNMF_MAX_COMPONENTS = 32;              // nmf_wide.hpp
 

@@ -391,12 +391,14 @@ int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
     if (h->use_graph && p->max_iter >= 2 * chunk) {
       hipGraph_t graph = nullptr;
       hipGraphExec_t exec = nullptr;
+      std::unique_lock<std::mutex> capture_lock(hipnmf_capture_mutex());
       hipError_t ge = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
       if (ge == hipSuccess) {
         enqueue(chunk, stop_rule);
         ge = hipStreamEndCapture(st, &graph);
       }
       if (ge == hipSuccess) ge = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+      capture_lock.unlock();
       int graph_rc = HIPNMF_OK;
       while (ge == hipSuccess && !converged && it_done + chunk <= p->max_iter) {
         ge = hipGraphLaunch(exec, st);

@@ -6,6 +6,9 @@ sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import muscle_synergies_amd as ms
 from muscle_synergies_amd import _lib
 from muscle_synergies_amd.synth import emg_matrix
+import muscle_synergies_amd.analysis as _an
+if os.environ.get("REPRO_UNLIMITED"):  # lift the frame-size limit of the concurrent ranks: the chip-filling paths from three threads at once
+    _an._RANK_THREADS_MAX_SAMPLES = 10**9; _an._RANK_THREADS_MAX_FEATURES = 10**9
 for dtype, T, m in ((np.float32, 10000, 16), (np.float64, 6000, 8), (np.float64, 20000, 64)):
     X = emg_matrix(5, T=T, m=m, k_true=4, dtype=dtype)
     df = pd.DataFrame(X, columns=[f"m{i}" for i in range(m)])
