@@ -64,6 +64,9 @@ def parse_args():
     ap.add_argument("--x-layout", choices=["row", "channel"], default="row",
                     help="config 3: memory order of the X batch handed to the engine: [B][T][m] (C order) or [B][m][T]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dry-orchestration", action="store_true",
+                    help="no GPU work: the rank plumbing only (spawn / rendezvous / barrier / max over ranks / one JSON line) "
+                         "over gloo on the CPU; the line is marked as such and is not a measurement")
     ap.add_argument("--cpu-sample", type=int, default=0, help="matrices in the CPU baseline sample (0 = auto)")
     return ap.parse_args()
 
@@ -170,14 +173,22 @@ class Ctx:
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
-        if self.world != a.gpus and self.world > 1:
-            raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={self.world}")
         self.distributed = self.world > 1 or "TORCHELASTIC_RUN_ID" in os.environ  # under torchrun: always a group
+        self.dry = bool(a.dry_orchestration)
 
     def init_gpu(self):
         import torch
 
         self.torch = torch
+        if self.dry:  # rank plumbing only: gloo on the CPU, nothing touches a GPU
+            self.dev = torch.device("cpu")
+            if self.distributed:
+                import torch.distributed as dist
+
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                dist.init_process_group(backend="gloo")
+                self.dist = dist
+            return
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs an MI355X: no ROCm GPU visible (the engine has no CPU fallback)")
         torch.cuda.set_device(self.local_rank)
@@ -189,10 +200,14 @@ class Ctx:
             dist.init_process_group(backend="nccl", device_id=self.dev)
             self.dist = dist
 
+    def sync(self):
+        if not self.dry:
+            self.torch.cuda.synchronize(self.dev)
+
     def barrier(self):
         if self.distributed:
             self.dist.barrier()
-        self.torch.cuda.synchronize(self.dev)
+        self.sync()
 
     def timed(self, step):
         """W untimed warm-up steps, then EXACTLY K steps between barrier + synchronize, max over ranks."""
@@ -202,7 +217,7 @@ class Ctx:
         self.barrier()
         t0 = time.perf_counter()
         outs = [step() for _ in range(a.steps)]
-        self.torch.cuda.synchronize(self.dev)
+        self.sync()
         elapsed = time.perf_counter() - t0
         self.barrier()
         if self.distributed:
@@ -532,14 +547,78 @@ def run_tsharded(cx):
 
 
 # ------------------------------------------------------------------------------------------------
+def run_dry(cx):
+    """--dry-orchestration: the units of config 3 with a sleep for a step -- checks the launcher, not the engine."""
+    a = cx.a
+    B = a.batch or 4096
+
+    def step():
+        time.sleep(0.01 * (1 + cx.rank))  # ranks differ: the reported time must be the slowest rank's
+        return None
+
+    elapsed, _ = cx.timed(step)
+    if cx.rank != 0:
+        return None
+    return {"units": cx.world * B * a.iters * a.steps, "elapsed": elapsed, "scaling": "weak",
+            "config": {"workload": "DRY ORCHESTRATION: no GPU work, a sleep per step (rank plumbing check only)",
+                       "global_batch": B * cx.world, "ranks_seen": cx.world}, "roofline": None}
+
+
+def _free_port():
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(a):
+    """``python bench.py --gpus N`` without a torchrun environment: start N fresh rank processes (one per GPU, rendezvous on
+    127.0.0.1) and relay rank 0's JSON line.  The parent never touches a GPU (``device_count`` does not initialise one) and
+    nothing is exec'ed from a process that has: the ranks are children, their exit codes are ours."""
+    import subprocess
+
+    if not a.dry_orchestration:
+        import torch
+
+        n = torch.cuda.device_count()
+        if n < a.gpus:
+            raise SystemExit(f"bench.py --gpus {a.gpus}: only {n} ROCm GPU(s) visible; refusing to report a {a.gpus}-GPU "
+                             f"number from fewer devices")
+    port = _free_port()
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HIPNMF_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    lines = [ln for ln in (out0 or "").splitlines() if ln.startswith("{")]
+    if any(codes) or len(lines) != 1:
+        sys.stdout.write(out0 or "")
+        raise SystemExit(f"bench.py --gpus {a.gpus}: rank exit codes {codes}, {len(lines)} JSON line(s) from rank 0")
+    print(lines[0], flush=True)
+
+
 def main():
     a = parse_args()
+    if a.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if a.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(a)  # invoked directly: be the launcher (under torchrun the environment is there already)
     cx = Ctx(a)
+    if cx.world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={cx.world}: start one rank per GPU (python bench.py --gpus N does "
+                         f"that by itself when no launcher environment is present)")
     cpu = None
-    if cx.rank == 0 and cx.world == 1 and not a.no_cpu_baseline:
+    if cx.rank == 0 and cx.world == 1 and not a.no_cpu_baseline and not a.dry_orchestration:
         cpu = cpu_baseline(a)  # before the GPU is initialised (spawns worker processes)
     cx.init_gpu()
-    if a.config == 3:
+    if a.dry_orchestration:
+        res = run_dry(cx)
+    elif a.config == 3:
         res = run_batch(cx, single=False)
     elif a.config == 2:
         res = run_batch(cx, single=True)
@@ -560,7 +639,7 @@ def main():
             "scaling": res["scaling"],
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "data": "none (dry orchestration)" if a.dry_orchestration else "synthetic",
             "config": res["config"],
             "roofline": res["roofline"],
             "cpu_baseline": cpu,

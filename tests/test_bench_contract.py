@@ -64,3 +64,55 @@ def test_command_line_contract():
     assert out.returncode == 0
     for flag in ("--gpus", "--steps", "--warmup", "--config"):
         assert flag in out.stdout
+
+
+def _json_lines(text):
+    import json
+
+    return [json.loads(ln) for ln in text.splitlines() if ln.startswith("{")]
+
+
+def test_gpus_n_invoked_directly_starts_n_ranks_over_gloo():
+    """`python bench.py --gpus 2` with no launcher environment must run TWO ranks (round 3: it silently ran one and printed
+    n_gpus 1).  --dry-orchestration swaps the GPU work for a sleep and RCCL for gloo; everything else is the real plumbing."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-orchestration", "--steps", "3",
+                          "--warmup", "1"], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    lines = _json_lines(out.stdout)
+    assert len(lines) == 1
+    r = lines[0]
+    assert r["n_gpus"] == 2 and r["config"]["ranks_seen"] == 2 and r["steps"] == 3 and r["warmup"] == 1
+    assert r["ms_per_step"] >= 19.0          # rank 1 sleeps 20 ms per step, rank 0 10 ms: the slowest rank's time is reported
+    assert r["data"].startswith("none") and r["cpu_baseline"] is None
+
+
+def test_gpus_n_under_torchrun_uses_the_launcher_environment():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", "29731", os.path.join(ROOT, "bench.py"), "--gpus", "2",
+                          "--dry-orchestration", "--steps", "2", "--warmup", "0"], capture_output=True, text=True, env=env,
+                         timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    lines = _json_lines(out.stdout)
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2
+
+
+def test_gpus_n_refuses_to_run_on_fewer_devices():
+    """Without a GPU (this container) --gpus 2 must fail loudly, never print a 1-GPU line."""
+    import torch
+
+    if torch.cuda.device_count() >= 2:
+        import pytest
+
+        pytest.skip("two GPUs visible")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode != 0 and not _json_lines(out.stdout)
+    assert "refusing" in (out.stderr + out.stdout)
+    # a launcher environment that disagrees with --gpus is an error too
+    env2 = dict(env, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-orchestration"],
+                         capture_output=True, text=True, env=env2, timeout=300)
+    assert out.returncode != 0 and "WORLD_SIZE=1" in (out.stderr + out.stdout)
