@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define HIPNMF_VERSION 100 /* 0.1.0 */
+#define HIPNMF_VERSION 200 /* 0.2.0: round 3 grew hipnmf_envelope_params and added hipnmf_rank_sweep_stop_*; round 4 added hipnmf_sosfilt_params.mode */
 
 #define HIPNMF_OK 0
 #define HIPNMF_ERR_BAD_ARG (-1)

@@ -90,36 +90,36 @@ def _check_component_range(df: pandas.DataFrame, n_components: int, max_componen
 
 
 _RANK_POOL = None
+_RANK_POOL_PID = None
 
 
 def _rank_pool():
-    """The worker threads of the rank ranges: created once and kept, so that each keeps its engine handle (stream, events,
-    workspace: ``_lib.get_handle`` caches per thread) from call to call."""
-    global _RANK_POOL
-    if _RANK_POOL is None:
+    """The worker threads of the rank ranges: created on first use in THIS process and kept, so that each keeps its engine
+    handle (stream, events, workspace: ``_lib.get_handle`` caches per thread) from call to call.  A forked child starts its
+    own (the parent's threads do not exist there; ``submit`` on the inherited object would wait for ever)."""
+    global _RANK_POOL, _RANK_POOL_PID
+    import os
+
+    if _RANK_POOL is None or _RANK_POOL_PID != os.getpid():
         from concurrent.futures import ThreadPoolExecutor
 
         _RANK_POOL = ThreadPoolExecutor(max_workers=8, thread_name_prefix="hipnmf-rank")
+        _RANK_POOL_PID = os.getpid()
     return _RANK_POOL
 
 
-# Concurrent ranks only for frames whose fits are single-workgroup launches (one wave or one workgroup per matrix).  Longer or
-# wider frames take the chip-filling paths -- row-sliced launches replayed as hipGraphs, the cooperative kernel -- which gain
-# little from overlapping, and the wide row-sliced path failed when three threads drove it at once ("operation failed due
-# to a previous error during capture": tools/repro/rank_threads_long_matrix.py with REPRO_UNLIMITED=1).
-_RANK_THREADS_MAX_SAMPLES = 2048
-_RANK_THREADS_MAX_FEATURES = 32
-
-
 def _ranks_concurrently(n_ranks: int, nmf_kwargs, shape=None) -> bool:
-    """Whether the solver calls of a rank range may run from concurrent host threads: GPU path only (scikit-learn's solvers
-    keep the reference's sequential loop) and small frames only (see _RANK_THREADS_MAX_SAMPLES).  The initialisations are still computed in rank order on the calling thread, so a
-    seeded global generator or a shared ``RandomState`` is consumed exactly as by the loop.  ``HIPNMF_RANK_THREADS=0`` keeps the loop."""
+    """Whether the solver calls of a rank range run from concurrent host threads, one engine handle each: whenever they run on
+    the GPU (scikit-learn's solvers keep the reference's sequential loop).  Any frame size: the C ABI's handles are independent
+    (include/hip_nmf.h; tests/test_gpu_abi_threads.py drives every solver path from 2, 3 and 8 threads).  Round 3 limited this to
+    frames of at most 2 048 x 32 because concurrent calls on long or wide frames failed with "operation failed due to a previous
+    error during capture"; the cause was stream capture itself (any legacy-stream call of another thread invalidates an open
+    capture on this HIP runtime, profiles/r04_threads_root_cause.md) and the library no longer captures.  The initialisations
+    are still computed in rank order on the calling thread, so a seeded global generator or a shared ``RandomState`` is consumed
+    exactly as by the loop.  ``HIPNMF_RANK_THREADS=0`` keeps the loop."""
     import os
 
     if n_ranks < 2 or os.environ.get("HIPNMF_RANK_THREADS", "1") == "0":
-        return False
-    if shape is not None and (shape[0] > _RANK_THREADS_MAX_SAMPLES or shape[1] > _RANK_THREADS_MAX_FEATURES):
         return False
     return nmf_kwargs.get("solver") == "mu" and HipNMF.supports(**nmf_kwargs)
 

@@ -63,7 +63,7 @@ def _compile(src: str, extra, objdir: str = OBJ) -> str:
 
 
 def build(force: bool = False, jobs: int | None = None, extra_flags=(), verbose: bool = False,
-          variant: str | None = None, only=()) -> str:
+          variant: str | None = None, only=(), record_profile: bool = False) -> str:
     """Build the library.  ``variant`` (development aid) builds ``libhip_nmf_<variant>.so`` with
     ``extra_flags`` in its own object directory; select it at run time with ``HIPNMF_LIBRARY``.
     ``only``: with a variant, the translation units (base names without ``.hip``) the flags apply to -- every
@@ -111,13 +111,14 @@ def build(force: bool = False, jobs: int | None = None, extra_flags=(), verbose:
         if verbose:
             print(f"[build] linked {lib}", flush=True)
     if not variant:
-        _record(lib, srcs, todo, linked, verbose)
+        _record(lib, srcs, todo, linked, verbose, record_profile)
     return lib
 
 
-def _record(lib: str, srcs, todo, linked: bool, verbose: bool) -> None:
-    """What this call did -- compiled from source or found up to date -- next to the library and, for the record of the
-    round (the question "did build() recompile or reuse?"), in profiles/build_info.json."""
+def _record(lib: str, srcs, todo, linked: bool, verbose: bool, record_profile: bool = False) -> None:
+    """What this call did -- compiled from source or found up to date -- next to the library (lib/build_info.json, untracked).
+    Only ``record_profile`` (``--record-profile``, used by tools/profile_round.sh) also updates the tracked
+    profiles/build_info.json: an ordinary rebuild must not dirty the work tree."""
     import hashlib
     import json
     import time
@@ -136,7 +137,10 @@ def _record(lib: str, srcs, todo, linked: bool, verbose: bool) -> None:
         "flags": CXXFLAGS,
         "time_utc": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime()),
     }
-    for path in (os.path.join(LIBDIR, "build_info.json"), os.path.join(os.path.dirname(PKG), "profiles", "build_info.json")):
+    paths = [os.path.join(LIBDIR, "build_info.json")]
+    if record_profile and os.path.isdir(os.path.join(os.path.dirname(PKG), "profiles")):
+        paths.append(os.path.join(os.path.dirname(PKG), "profiles", "build_info.json"))
+    for path in paths:
         try:
             old = json.load(open(path)) if os.path.exists(path) else {}
             if not todo and not linked and old.get("sha256") == sha:
@@ -161,5 +165,7 @@ if __name__ == "__main__":
     ap.add_argument("--variant", default=None, help="build lib/libhip_nmf_<variant>.so instead of the default library")
     ap.add_argument("--only", action="append", default=[],
                     help="with --variant: translation unit (base name) the flags apply to (repeatable); the rest is shared")
+    ap.add_argument("--record-profile", action="store_true", help="also update the tracked profiles/build_info.json")
     a = ap.parse_args()
-    print(build(force=a.force, jobs=a.jobs, extra_flags=a.flag, verbose=True, variant=a.variant, only=a.only))
+    print(build(force=a.force, jobs=a.jobs, extra_flags=a.flag, verbose=True, variant=a.variant, only=a.only,
+                record_profile=a.record_profile))

@@ -10,11 +10,14 @@
 
 #include <algorithm>
 #include <cmath>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <mutex>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -24,11 +27,6 @@
 #include "nmf_small_decl.hpp"
 
 using namespace hipnmf;
-
-std::mutex& hipnmf_capture_mutex() {
-  static std::mutex m;
-  return m;
-}
 
 thread_local std::string g_last_error;
 
@@ -100,7 +98,83 @@ int hipnmf_ensure_ws(hipnmf_handle* h, size_t bytes) {
   return HIPNMF_OK;
 }
 
+int hipnmf_ensure_aux(hipnmf_handle* h, size_t bytes) {
+  if (bytes <= h->aux_bytes) return HIPNMF_OK;
+  if (h->aux) {
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipFree(h->aux));
+    h->aux = nullptr;
+    h->aux_bytes = 0;
+  }
+  HIP_TRY(hipMalloc(&h->aux, bytes));
+  h->aux_bytes = bytes;
+  return HIPNMF_OK;
+}
+
+int hipnmf_copy(hipnmf_handle* h, void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
+  if (!bytes) return HIPNMF_OK;
+  HIP_TRY(hipMemcpyAsync(dst, src, bytes, kind, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return HIPNMF_OK;
+}
+
+int hipnmf_allow_full_lds(hipnmf_handle* h, const void* fn) {
+  static std::mutex mu;
+  static std::set<std::pair<const void*, int>> done;
+  std::lock_guard<std::mutex> lock(mu);
+  if (done.count({fn, h->device})) return HIPNMF_OK;
+  hipFuncAttributes fa;
+  HIP_TRY(hipFuncGetAttributes(&fa, fn));  // static + dynamic LDS must fit the CU: the runtime rejects more (invalid argument)
+  HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_per_block - (int)fa.sharedSizeBytes));
+  done.insert({fn, h->device});
+  return HIPNMF_OK;
+}
+
 namespace {
+
+// Cooperative grids need ALL their workgroups resident at once.  hipLaunchCooperativeKernel checks the grid against what the
+// device could hold, not against what other launches hold at that moment: two cooperative grids of this process (two host
+// threads, one handle each) that each got part of the chip would spin on each other until the exchange's time-out.  So every
+// cooperative launch reserves its workgroups out of the device's CUs (one workgroup per CU: each takes most of the CU's LDS)
+// until its stream has drained, and waits while there is no room.  Ordinary kernels of other threads only delay a
+// cooperative grid (they finish by themselves); other PROCESSES on the same GPU are beyond a mutex: the time-out and its
+// error code stay the last line of defence there.
+class CoopBudget {
+ public:
+  void acquire(int device, int need, int capacity) {
+    std::unique_lock<std::mutex> lock(mu_);
+    need = std::min(need, capacity);
+    cv_.wait(lock, [&] { return used_[slot(device)] + need <= capacity; });
+    used_[slot(device)] += need;
+  }
+  void release(int device, int need, int capacity) {
+    {
+      std::lock_guard<std::mutex> lock(mu_);
+      used_[slot(device)] -= std::min(need, capacity);
+    }
+    cv_.notify_all();
+  }
+
+ private:
+  static int slot(int device) { return device & 63; }
+  std::mutex mu_;
+  std::condition_variable cv_;
+  int used_[64] = {0};
+};
+CoopBudget g_coop_budget;
+struct CoopReservation {
+  int device = 0, need = 0, capacity = 0;
+  bool held = false;
+  void take(int dev, int n, int cap) {
+    g_coop_budget.acquire(dev, n, cap);
+    device = dev, need = n, capacity = cap, held = true;
+  }
+  void drop() {
+    if (held) g_coop_budget.release(device, need, capacity);
+    held = false;
+  }
+  ~CoopReservation() { drop(); }
+};
 
 int validate(const hipnmf_problem* p, bool shard, bool ragged = false) {
   if (!p) return fail(HIPNMF_ERR_BAD_ARG, "problem is NULL");
@@ -571,6 +645,7 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
 
   HIP_TRY(hipEventRecord(h->ev0, st));
   bool coop_done = false, coop_xcd_used = false;
+  CoopReservation coop_cus;  // held until the stream has drained (released on every return path)
   if (coop) {
     SolveArgs<real> c = a;
     c.S = coop_S;
@@ -593,12 +668,12 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
     }();
     c.gen_base = gen_base_env;
     const void* kern = reinterpret_cast<const void*>(c.coop_xcd ? ks->fit_coop_xcd : ks->fit_coop);
-    if (coop_smem > 48 * 1024)
-      HIP_TRY(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)coop_smem));
+    if (coop_smem > 48 * 1024 && (rc = hipnmf_allow_full_lds(h, kern))) return rc;
     HIP_TRY(hipMemsetAsync(c.sync, 0, sizeof(unsigned) * ((size_t)B + 2 + 10 * (size_t)B + 1024 * (size_t)B), st));
     // records travel as {value bits, generation} granules: those of a previous fit must not look fresh
     HIP_TRY(hipMemsetAsync(c.part, 0, 2 * sizeof(real) * (size_t)B * 2 * coop_S * ks->NACC, st));
     void* args[] = {&c};
+    coop_cus.take(h->device, (c.coop_xcd ? 8 * coop_S : coop_S) * B, h->num_cu);
     const hipError_t e = hipLaunchCooperativeKernel(kern, dim3(c.coop_xcd ? 8 * coop_S : coop_S, B), dim3(coop_threads), args,
                                                     (unsigned)coop_smem, st);
     coop_xcd_used = c.coop_xcd != 0;
@@ -608,6 +683,7 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
       snprintf(h->last_kernel, sizeof(h->last_kernel), "fit_coop_kernel<%s,%d,%d,%d%s>",
                sizeof(real) == 4 ? "float" : "double", ks->G, ks->CH, ks->K, c.coop_xcd ? ",xcd" : "");
     } else {
+      coop_cus.drop();
       (void)hipGetLastError();  // not launchable as a cooperative grid on this device: use the regular paths
       if (h->variant == 3)
         return fail(HIPNMF_ERR_HIP, "hipLaunchCooperativeKernel failed: %s", hipGetErrorString(e));
@@ -653,9 +729,7 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
         snprintf(h->last_kernel, sizeof(h->last_kernel), "%s%s", rowlane_kernel_name(k), kl ? "[kl]" : "");
       }
     }
-    if (smem > 48 * 1024)
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)smem));
+    if (smem > 48 * 1024 && (rc = hipnmf_allow_full_lds(h, reinterpret_cast<const void*>(kern)))) return rc;
     launch<real>(kern, dim3(B), dim3(threads), smem, st, a);
   } else {
     h->last_path = 2;
@@ -683,17 +757,21 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
       launch<real>(ks->resid_finalize, dim3(B), dim3(1024), 0, st, a);
       host_state.resize((size_t)B * 8);
     }
-    // `n` iterations, optionally followed by one stop-rule evaluation (sklearn: every check_every-th iteration)
-    auto enqueue = [&](int n, bool check) {
+    // `n` iterations, optionally followed by one stop-rule evaluation (sklearn: every check_every-th iteration), handed to
+    // `emit` launch by launch: straight onto the stream, or into the replayed chain
+    auto enqueue = [&](int n, bool check, auto&& emit) {
       for (int i = 0; i < n; ++i) {
-        launch<real>(ks->slice_pass, grid2, dim3(nt), smem, st, a);
-        if (a.update_h && !a.fuse_h) launch<real>(ks->hupdate, dim3(B), dim3(1024), smem1, st, a);  // sums the records
+        emit(ks->slice_pass, grid2, dim3(nt), smem, a);
+        if (a.update_h && !a.fuse_h) emit(ks->hupdate, dim3(B), dim3(1024), smem1, a);  // sums the records
       }
       if (check) {
         a.it = 1;
-        launch<real>(ks->slice_resid, grid2, dim3(nt), smem, st, a);
-        launch<real>(ks->resid_finalize, dim3(B), dim3(1024), 0, st, a);
+        emit(ks->slice_resid, grid2, dim3(nt), smem, a);
+        emit(ks->resid_finalize, dim3(B), dim3(1024), (size_t)0, a);
       }
+    };
+    auto direct = [&](typename KernelSet<real>::Fn fn, dim3 g, dim3 blk, size_t sm, const SolveArgs<real>& args) {
+      launch<real>(fn, g, blk, sm, st, args);
     };
     auto all_converged = [&](bool* done) -> int {
       HIP_TRY(hipMemcpyAsync(host_state.data(), a.state, sizeof(real) * (size_t)B * 8, hipMemcpyDeviceToHost, st));
@@ -702,28 +780,22 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
       for (int b = 0; b < B; ++b) *done = *done && host_state[(size_t)b * 8 + 3] != (real)0;
       return HIPNMF_OK;
     };
-    // The launches of one chunk are captured once into a hipGraph and replayed: this path is launch-bound
-    // (2 small kernels per iteration), and a replay costs ~1.5 us per kernel instead of ~4 us of host work.
+    // The launches of one chunk are built once into a hipGraph and replayed: this path is launch-bound (2 small kernels
+    // per iteration), and a replay costs ~1.5 us per kernel instead of ~4 us of host work.  An explicit kernel-node chain,
+    // not a stream capture (hipnmf_kernel_chain in hipnmf_internal.hpp says why).
     const int chunk = stop_rule ? p->check_every : std::min(p->max_iter, 64);
     int it_done = 0;
     bool converged = false;
     if (h->use_graph && p->max_iter >= 2 * chunk) {
-      // No early return between BeginCapture and the clean-up: a failure ends the capture (the stream may be the
-      // caller's own, e.g. torch's current stream after hipnmf_set_stream), destroys graph and executable, and the
-      // plain launch loop below takes over from wherever the replay stopped.
-      hipGraph_t graph = nullptr;
-      hipGraphExec_t exec = nullptr;
-      std::unique_lock<std::mutex> capture_lock(hipnmf_capture_mutex());
-      hipError_t ge = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
-      if (ge == hipSuccess) {
-        enqueue(chunk, stop_rule);
-        ge = hipStreamEndCapture(st, &graph);  // also leaves capture mode when an enqueued launch was invalid
-      }
-      if (ge == hipSuccess) ge = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-      capture_lock.unlock();
+      hipnmf_kernel_chain chain;
+      hipError_t ge = hipSuccess;
+      enqueue(chunk, stop_rule, [&](typename KernelSet<real>::Fn fn, dim3 g, dim3 blk, size_t sm, const SolveArgs<real>& args) {
+        if (ge == hipSuccess) ge = chain.add(reinterpret_cast<const void*>(fn), g, blk, sm, args);
+      });
+      if (ge == hipSuccess) ge = chain.instantiate();
       int graph_rc = HIPNMF_OK;
       while (ge == hipSuccess && !converged && it_done + chunk <= p->max_iter) {
-        ge = hipGraphLaunch(exec, st);
+        ge = chain.launch(st);
         if (ge != hipSuccess) break;
         it_done += chunk;
         if (stop_rule) {
@@ -731,9 +803,7 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
           if (graph_rc) break;
         }
       }
-      if (ge == hipSuccess && !graph_rc) ge = hipStreamSynchronize(st);
-      if (exec) (void)hipGraphExecDestroy(exec);
-      if (graph) (void)hipGraphDestroy(graph);
+      if (ge == hipSuccess && !graph_rc) ge = hipStreamSynchronize(st);  // the chain (and its argument copies) dies with this scope
       if (graph_rc) return graph_rc;
       if (ge != hipSuccess) {
         (void)hipGetLastError();
@@ -744,7 +814,7 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
     while (!converged && it_done < p->max_iter) {
       const int n = std::min(chunk, p->max_iter - it_done);
       const bool check = stop_rule && n == chunk;
-      enqueue(n, check);
+      enqueue(n, check, direct);
       it_done += n;
       if (check) {
         rc = all_converged(&converged);
@@ -767,15 +837,17 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
   }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(st));
+  coop_cus.drop();
   HIP_TRY(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
   if (coop_done) {  // a barrier that gave up (workgroups not co-resident after all) leaves the abort flag set
     unsigned flags2[2] = {0, 0};  // abort flag, 'updates began' word of the same-XCD mode
-    HIP_TRY(hipMemcpy(flags2, reinterpret_cast<unsigned*>(ws + o_sync) + B, sizeof(flags2), hipMemcpyDeviceToHost));
+    if ((rc = hipnmf_copy(h, flags2, reinterpret_cast<unsigned*>(ws + o_sync) + B, sizeof(flags2), hipMemcpyDeviceToHost))) return rc;
     if (flags2[0] && coop_xcd_used && !flags2[1]) {
       // same-XCD mode: fewer than S workgroups turned up on the chosen XCD, the head count timed out before anything was
       // updated (W, H and the layout round trip of W are value-preserving): run again with the device-scope exchange,
       // and do not try the same-XCD mode again on this handle
       h->coop_xcd_failed = true;
+      coop_cus.drop();
       return fit_batched_impl<real>(h, p, X, W, H, err_out, n_iter_out, sse_col_out, xsq_col_out, ragged);
     }
     if (flags2[0]) return fail(HIPNMF_ERR_HIP, "cooperative fit: a grid barrier timed out (results are invalid)");
@@ -954,8 +1026,9 @@ int tsharded_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, real
   const bool stop_rule = p->tol > 0;
   hipStream_t st = h->stream;
 
-  real* dbuf = nullptr;  // [sums | sse, xsq packed per matrix as the all-reduce wants them: one buffer, one call]
-  HIP_TRY(hipMalloc(&dbuf, sizeof(real) * (n_sums + 2 * n_res)));
+  // [sums | sse, xsq packed per matrix as the all-reduce wants them: one buffer, one call] in the handle's second scratch
+  if (int arc = hipnmf_ensure_aux(h, sizeof(real) * (n_sums + 2 * n_res))) return arc;
+  real* dbuf = static_cast<real*>(h->aux);
   real* sums = dbuf;
   real* packed = dbuf + n_sums;        // [B][2 m]: sse | xsq
   real* cols = dbuf + n_sums + n_res;  // scratch the residual kernels write: sse [B][m], xsq [B][m]
@@ -1034,7 +1107,6 @@ int tsharded_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, real
   } while (false);
   h->async_mode = saved_async;
   (void)hipStreamSynchronize(st);
-  (void)hipFree(dbuf);
   return rc;
 }
 
@@ -1072,16 +1144,37 @@ int rank_sweep_impl(hipnmf_handle* h, const hipnmf_problem* p, int k_min, int k_
   HIP_TRY(hipSetDevice(h->device));
   const int B = p->batch, m = p->n_features, nk = k_max - k_min + 1;
   const long long T = p->n_samples;
-  // one matrix of the caller's X as a flat span (gathered as it lies: same layout and leading dimension)
-  const long long span = (p->x_layout == HIPNMF_X_ROW_MAJOR ? T : (long long)m) * p->ldx;
+  // one matrix of the caller's X as a flat span (gathered as it lies: same layout and leading dimension; the last row ends after
+  // its own elements, not after a whole leading dimension -- a strided view's buffer may end there)
+  const long long rows = p->x_layout == HIPNMF_X_ROW_MAJOR ? T : (long long)m, row_len = p->x_layout == HIPNMF_X_ROW_MAJOR ? (long long)m : T;
+  const long long span = (rows - 1) * p->ldx + row_len;
   const long long cstride = round_up(span, 16 / (long long)sizeof(real));
-  real* cols = nullptr;  // [2][B][m] sse | xsq, [B] err, then n_iter
-  HIP_TRY(hipMalloc(&cols, sizeof(real) * ((size_t)2 * B * m + B) + sizeof(int32_t) * (size_t)B));
-  real* d_err = cols + (size_t)2 * B * m;
-  int32_t* d_it = reinterpret_cast<int32_t*>(d_err + B);
-  real* xc = nullptr;    // compacted X, compacted H and the index list (stop mode, allocated when first needed)
-  real* hc = nullptr;
+  // scratch (the handle's second buffer; `ws` belongs to the fits): [2][B][m] sse | xsq, [B] err, [B] n_iter, the index list and
+  // the compacted H; the compacted X is added when the first compaction happens, sized for the trials still active then
+  size_t aoff = 0;
+  auto acarve = [&](size_t bytes) {
+    size_t o = aoff;
+    aoff += (bytes + 255) / 256 * 256;
+    return o;
+  };
+  const size_t o_cols = acarve(sizeof(real) * ((size_t)2 * B * m + B)), o_it = acarve(sizeof(int32_t) * (size_t)B);
+  const size_t o_index = acarve(sizeof(int) * (size_t)B), o_hc = acarve(sizeof(real) * (size_t)B * k_max * m);
+  const size_t o_xc = aoff;
+  size_t xc_matrices = 0;
+  if (int arc = hipnmf_ensure_aux(h, aoff)) return arc;
+  real *cols = nullptr, *d_err = nullptr, *xc = nullptr, *hc = nullptr;
+  int32_t* d_it = nullptr;
   int* d_index = nullptr;
+  auto place = [&]() {  // (the buffer may have moved when it grew: nothing of a previous rank is live across that)
+    char* base = static_cast<char*>(h->aux);
+    cols = reinterpret_cast<real*>(base + o_cols);
+    d_err = cols + (size_t)2 * B * m;
+    d_it = reinterpret_cast<int32_t*>(base + o_it);
+    d_index = reinterpret_cast<int*>(base + o_index);
+    hc = reinterpret_cast<real*>(base + o_hc);
+    xc = reinterpret_cast<real*>(base + o_xc);
+  };
+  place();
   const real nan = std::numeric_limits<real>::quiet_NaN();
   std::vector<real> hs((size_t)2 * B * m), vaf((size_t)B * nk, nan), herr((size_t)B * nk, nan), e(B);
   std::vector<int32_t> hit((size_t)B * nk, 0), it(B), sel(B, -1);
@@ -1107,12 +1200,10 @@ int rank_sweep_impl(hipnmf_handle* h, const hipnmf_problem* p, int k_min, int k_
     const real* Xk = X;
     real* Hfit = Hk;
     if (compact) {
-      if (!xc) {
-        if (hipMalloc(&xc, sizeof(real) * (size_t)B * cstride) != hipSuccess ||
-            hipMalloc(&hc, sizeof(real) * (size_t)B * k_max * m) != hipSuccess || hipMalloc(&d_index, sizeof(int) * (size_t)B) != hipSuccess) {
-          rc = fail(HIPNMF_ERR_HIP, "hipMalloc of the compaction buffers failed");
-          break;
-        }
+      if (!xc_matrices) {
+        xc_matrices = (size_t)nA;  // the active set only shrinks
+        if ((rc = hipnmf_ensure_aux(h, o_xc + sizeof(real) * xc_matrices * (size_t)cstride))) break;
+        place();
       }
       if (hipMemcpyAsync(d_index, active.data(), sizeof(int) * (size_t)nA, hipMemcpyHostToDevice, h->stream) != hipSuccess) {
         rc = fail(HIPNMF_ERR_HIP, "copying the trial list failed");
@@ -1131,9 +1222,10 @@ int rank_sweep_impl(hipnmf_handle* h, const hipnmf_problem* p, int k_min, int k_
     if (rc) break;
     rc = fit_batched_impl<real>(h, &q, Xk, W_ws, Hfit, d_err, d_it, cols, cols + (size_t)nA * m);
     if (rc) break;
-    if (hipMemcpy(hs.data(), cols, sizeof(real) * (size_t)2 * nA * m, hipMemcpyDeviceToHost) != hipSuccess ||
-        hipMemcpy(e.data(), d_err, sizeof(real) * nA, hipMemcpyDeviceToHost) != hipSuccess ||
-        hipMemcpy(it.data(), d_it, sizeof(int32_t) * nA, hipMemcpyDeviceToHost) != hipSuccess) {
+    if (hipMemcpyAsync(hs.data(), cols, sizeof(real) * (size_t)2 * nA * m, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+        hipMemcpyAsync(e.data(), d_err, sizeof(real) * nA, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+        hipMemcpyAsync(it.data(), d_it, sizeof(int32_t) * nA, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+        hipStreamSynchronize(h->stream) != hipSuccess) {
       rc = fail(HIPNMF_ERR_HIP, "reading the results of rank %d back failed", k);
       break;
     }
@@ -1163,18 +1255,14 @@ int rank_sweep_impl(hipnmf_handle* h, const hipnmf_problem* p, int k_min, int k_
   }
   h->path_batch_hint = saved_hint;
   if (!rc) {
-    if (hipStreamSynchronize(h->stream) != hipSuccess ||
-        hipMemcpy(vaf_out, vaf.data(), sizeof(real) * vaf.size(), hipMemcpyHostToDevice) != hipSuccess ||
-        (selected_out && hipMemcpy(selected_out, sel.data(), sizeof(int32_t) * B, hipMemcpyHostToDevice) != hipSuccess) ||
-        (err_out && hipMemcpy(err_out, herr.data(), sizeof(real) * herr.size(), hipMemcpyHostToDevice) != hipSuccess) ||
-        (n_iter_out && hipMemcpy(n_iter_out, hit.data(), sizeof(int32_t) * hit.size(), hipMemcpyHostToDevice) != hipSuccess))
+    hipStream_t st = h->stream;
+    if (hipMemcpyAsync(vaf_out, vaf.data(), sizeof(real) * vaf.size(), hipMemcpyHostToDevice, st) != hipSuccess ||
+        (selected_out && hipMemcpyAsync(selected_out, sel.data(), sizeof(int32_t) * B, hipMemcpyHostToDevice, st) != hipSuccess) ||
+        (err_out && hipMemcpyAsync(err_out, herr.data(), sizeof(real) * herr.size(), hipMemcpyHostToDevice, st) != hipSuccess) ||
+        (n_iter_out && hipMemcpyAsync(n_iter_out, hit.data(), sizeof(int32_t) * hit.size(), hipMemcpyHostToDevice, st) != hipSuccess))
       rc = fail(HIPNMF_ERR_HIP, "writing the sweep results failed");
   }
-  (void)hipStreamSynchronize(h->stream);
-  (void)hipFree(cols);
-  if (xc) (void)hipFree(xc);
-  if (hc) (void)hipFree(hc);
-  if (d_index) (void)hipFree(d_index);
+  if (hipStreamSynchronize(h->stream) != hipSuccess && !rc) rc = fail(HIPNMF_ERR_HIP, "hipStreamSynchronize failed");  // (host vectors above are read until here)
   return rc;
 }
 
@@ -1268,6 +1356,7 @@ int hipnmf_destroy(hipnmf_handle* h) {
   (void)hipSetDevice(h->device);
   if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
   if (h->ws) (void)hipFree(h->ws);
+  if (h->aux) (void)hipFree(h->aux);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);

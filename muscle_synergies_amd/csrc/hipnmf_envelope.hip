@@ -136,7 +136,7 @@ int envelope_impl(hipnmf_handle* h, const hipnmf_envelope_params* p, const real*
   if (wg) {
     auto launch_wg = [&](auto kern) -> int {
       if (wg_lds > 48 * 1024)
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wg_lds));
+        if (int arc = hipnmf_allow_full_lds(h, reinterpret_cast<const void*>(kern))) return arc;
       hipLaunchKernelGGL(kern, dim3(m, B), dim3(64 * wg_nw), wg_lds, st, a, ring4);
       return HIPNMF_OK;
     };
@@ -154,8 +154,7 @@ int envelope_impl(hipnmf_handle* h, const hipnmf_envelope_params* p, const real*
       hipLaunchKernelGGL((emg_wave_kernel<real, 8>), dim3(m, B), dim3(64), lds, st, a, ring);
   } else if (fused) {
     if (fused_lds > 48 * 1024)
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(emg_fused_kernel<real>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds));
+      if (int arc = hipnmf_allow_full_lds(h, reinterpret_cast<const void*>(emg_fused_kernel<real>))) return arc;
     hipLaunchKernelGGL(emg_fused_kernel<real>, dim3(m, B), dim3(256), fused_lds, st, a);
   } else {
     hipLaunchKernelGGL(emg_prefix_kernel<real>, dim3(m, B), dim3(256), 0, st, a);

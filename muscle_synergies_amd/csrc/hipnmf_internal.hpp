@@ -5,7 +5,10 @@
 #include <hip/hip_runtime.h>
 
 #include <cstddef>
-#include <mutex>
+#include <cstring>
+#include <memory>
+#include <new>
+#include <vector>
 
 struct hipnmf_handle {
   int device = 0;
@@ -13,6 +16,8 @@ struct hipnmf_handle {
   hipStream_t stream = nullptr;
   void* ws = nullptr;
   size_t ws_bytes = 0;
+  void* aux = nullptr;  // second grow-only scratch: entry points that drive fit_batched_impl (which owns `ws`) keep theirs here
+  size_t aux_bytes = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   float last_ms = 0.f;
   int threads = 0;     // 0 = default
@@ -61,11 +66,77 @@ int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
 template <typename real>
 int hipnmf_random_init_indexed(hipnmf_handle* h, const hipnmf_problem* p, uint64_t seed, int first_matrix, const int* index,
                                const real* X, real* W, real* H);
-// Stream captures (the graph-replayed row-sliced paths) are serialised across the host threads of a process.  A precaution, not a
-// cure: three host threads driving the wide row-sliced path at once still ended with "operation failed due to a previous error
-// during capture" (tools/repro/rank_threads_long_matrix.py with REPRO_UNLIMITED=1; the cooperative kernel and the narrow sliced path
-// ran fine side by side), which is why the Python host fits the ranks of long or wide frames in a loop (analysis.py).
-std::mutex& hipnmf_capture_mutex();
+// grow-only second scratch buffer of the handle (rank sweep, time-sharded fit): no hipMalloc / hipFree per call -- hipFree waits for
+// every stream of the device, i.e. for the other host threads' work
+int hipnmf_ensure_aux(hipnmf_handle* h, size_t bytes);
+// Host <-> device copy ordered on the handle's stream and waited for.  Never the synchronous hipMemcpy: that is a legacy-(null-)stream
+// operation, serialises against every blocking stream of the process and -- see hipnmf_kernel_chain -- breaks other threads' captures.
+int hipnmf_copy(hipnmf_handle* h, void* dst, const void* src, size_t bytes, hipMemcpyKind kind);
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of the function, not of a launch: raised once per (function, device) to
+// the whole LDS of the CU instead of per call with the call's own size (round 3 did that from concurrent threads)
+int hipnmf_allow_full_lds(hipnmf_handle* h, const void* fn);
+
+// Replayed launch sequences (the row-sliced paths: two small kernels per iteration, launch-bound) are hipGraphs built EXPLICITLY
+// -- hipGraphCreate + hipGraphAddKernelNode, a linear chain -- and never by stream capture.  Root cause of round 3's "operation
+// failed due to a previous error during capture" (profiles/r04_threads_root_cause.md): on this runtime (ROCm 7.x CLR) ANY
+// legacy-stream call of ANY thread of the process -- a plain hipMemcpy of the host application, torch's null-stream traffic, this
+// library's own hipMemcpy in another handle's call -- returns hipErrorStreamCaptureImplicit while some stream is capturing AND
+// invalidates that capture, even a hipStreamCaptureModeThreadLocal capture on a hipStreamNonBlocking stream; hipStreamEndCapture
+// then returns hipErrorStreamCaptureInvalidated WITHOUT leaving capture mode, so every later call on that stream fails too.  A
+// library cannot know what the other threads of its host do, so it must not open captures at all.  Building the graph node by node
+// puts no stream into capture mode: nothing another thread does can invalidate it, and nothing it does can fail because of us.
+class hipnmf_kernel_chain {
+ public:
+  hipnmf_kernel_chain() = default;
+  hipnmf_kernel_chain(const hipnmf_kernel_chain&) = delete;
+  hipnmf_kernel_chain& operator=(const hipnmf_kernel_chain&) = delete;
+  ~hipnmf_kernel_chain() {
+    if (exec_) (void)hipGraphExecDestroy(exec_);
+    if (graph_) (void)hipGraphDestroy(graph_);
+  }
+  // appends kernel `fn`(args) after the previous node; the argument struct is copied (and kept until the chain dies)
+  template <typename Args>
+  hipError_t add(const void* fn, dim3 grid, dim3 block, size_t smem, const Args& args) {
+    hipError_t e = hipSuccess;
+    if (!graph_ && (e = hipGraphCreate(&graph_, 0)) != hipSuccess) return e;
+    slots_.emplace_back(new Slot);
+    Slot& s = *slots_.back();
+    s.bytes.reset(new (std::align_val_t(16)) unsigned char[sizeof(Args)]);
+    std::memcpy(s.bytes.get(), &args, sizeof(Args));
+    s.params[0] = s.bytes.get();
+    hipKernelNodeParams np;
+    std::memset(&np, 0, sizeof(np));
+    np.func = const_cast<void*>(fn);
+    np.gridDim = grid;
+    np.blockDim = block;
+    np.sharedMemBytes = (unsigned)smem;
+    np.kernelParams = s.params;
+    np.extra = nullptr;
+    hipGraphNode_t node = nullptr;
+    e = hipGraphAddKernelNode(&node, graph_, n_nodes_ ? &last_ : nullptr, n_nodes_ ? 1 : 0, &np);
+    if (e != hipSuccess) return e;
+    last_ = node;
+    ++n_nodes_;
+    return hipSuccess;
+  }
+  hipError_t instantiate() { return hipGraphInstantiate(&exec_, graph_, nullptr, nullptr, 0); }
+  hipError_t launch(hipStream_t st) { return hipGraphLaunch(exec_, st); }
+  int nodes() const { return n_nodes_; }
+
+ private:
+  struct AlignedDelete {
+    void operator()(unsigned char* p) const { ::operator delete[](p, std::align_val_t(16)); }
+  };
+  struct Slot {
+    std::unique_ptr<unsigned char[], AlignedDelete> bytes;
+    void* params[1] = {nullptr};
+  };
+  hipGraph_t graph_ = nullptr;
+  hipGraphExec_t exec_ = nullptr;
+  hipGraphNode_t last_ = nullptr;
+  int n_nodes_ = 0;
+  std::vector<std::unique_ptr<Slot>> slots_;
+};
 
 constexpr int HIPNMF_NARROW_MAX_FEATURES = 32, HIPNMF_NARROW_MAX_COMPONENTS = 8;  // nmf_kernels.hpp lane mappings
 constexpr int HIPNMF_MAX_FEATURES = 128, HIPNMF_MAX_COMPONENTS = 32;              // nmf_wide.hpp

@@ -52,28 +52,22 @@ hipError_t launch_ns(const SosArgs& a, const double* stat, hipStream_t st) {
 
 // round 2 kernel: LPS lanes per series (sections rounded up to a power of two), a second wave moves the data
 template <typename real, int LPS>
-hipError_t launch_v2(const SosArgs& a, const double* stat, int ns, hipStream_t st) {
+hipError_t launch_v2(hipnmf_handle* h, const SosArgs& a, const double* stat, int ns, hipStream_t st) {
   constexpr int S = sos2_series<LPS>();
   constexpr size_t smem = sos2_smem_bytes<LPS>();
   const void* kern = reinterpret_cast<const void*>(&sosfilt2_kernel<real, LPS>);
-  if (smem > 48 * 1024) {
-    const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e != hipSuccess) return e;
-  }
+  if (smem > 48 * 1024 && hipnmf_allow_full_lds(h, kern)) return hipErrorInvalidValue;
   hipLaunchKernelGGL((sosfilt2_kernel<real, LPS>), dim3((a.N + S - 1) / S), dim3(128), smem, st, a, stat, ns);
   return hipSuccess;
 }
 
 // round 3 kernel (zero-lag only): section states checkpointed per tile, forward output recomputed in the backward pass
 template <typename real, int LPS>
-hipError_t launch_v3(const SosArgs& a, const double* stat, int ns, hipStream_t st) {
+hipError_t launch_v3(hipnmf_handle* h, const SosArgs& a, const double* stat, int ns, hipStream_t st) {
   constexpr int S = sos2_series<LPS>();
   constexpr size_t smem = sos3_smem_bytes<LPS>();
   const void* kern = reinterpret_cast<const void*>(&sosfilt3_kernel<real, LPS>);
-  if (smem > 48 * 1024) {
-    const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e != hipSuccess) return e;
-  }
+  if (smem > 48 * 1024 && hipnmf_allow_full_lds(h, kern)) return hipErrorInvalidValue;
   hipLaunchKernelGGL((sosfilt3_kernel<real, LPS>), dim3((a.N + S - 1) / S), dim3(192), smem, st, a, stat, ns);
   return hipSuccess;
 }
@@ -196,23 +190,23 @@ int sosfilt_impl(hipnmf_handle* h, const hipnmf_sosfilt_params* p, const double*
   if (use_v3 && !sos_v1) {
     const int ns = p->n_sections;
     if (ns == 1)
-      HIP_TRY((launch_v3<real, 1>(a, stat, ns, st)));
+      HIP_TRY((launch_v3<real, 1>(h, a, stat, ns, st)));
     else if (ns == 2)
-      HIP_TRY((launch_v3<real, 2>(a, stat, ns, st)));
+      HIP_TRY((launch_v3<real, 2>(h, a, stat, ns, st)));
     else if (ns <= 4)
-      HIP_TRY((launch_v3<real, 4>(a, stat, ns, st)));
+      HIP_TRY((launch_v3<real, 4>(h, a, stat, ns, st)));
     else
-      HIP_TRY((launch_v3<real, 8>(a, stat, ns, st)));
+      HIP_TRY((launch_v3<real, 8>(h, a, stat, ns, st)));
   } else if (!sos_v1) {
     const int ns = p->n_sections;
     if (ns == 1)
-      HIP_TRY((launch_v2<real, 1>(a, stat, ns, st)));
+      HIP_TRY((launch_v2<real, 1>(h, a, stat, ns, st)));
     else if (ns == 2)
-      HIP_TRY((launch_v2<real, 2>(a, stat, ns, st)));
+      HIP_TRY((launch_v2<real, 2>(h, a, stat, ns, st)));
     else if (ns <= 4)
-      HIP_TRY((launch_v2<real, 4>(a, stat, ns, st)));
+      HIP_TRY((launch_v2<real, 4>(h, a, stat, ns, st)));
     else
-      HIP_TRY((launch_v2<real, 8>(a, stat, ns, st)));
+      HIP_TRY((launch_v2<real, 8>(h, a, stat, ns, st)));
   } else
   switch (p->n_sections) {
     case 1: HIP_TRY((launch_ns<real, 1>(a, stat, st))); break;

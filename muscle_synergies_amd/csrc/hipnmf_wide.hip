@@ -316,8 +316,7 @@ int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
   HIP_TRY(hipEventRecord(h->ev0, st));
   const auto kern = kl ? wk->fn_kl : wk->fn;
   if (!kern) return fail(HIPNMF_ERR_UNSUPPORTED, "no Kullback-Leibler instance of %s", wk->name);
-  if (smem > 48 * 1024)
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  if (smem > 48 * 1024 && (rc = hipnmf_allow_full_lds(h, reinterpret_cast<const void*>(kern)))) return rc;
   if (!sliced) {
     h->last_path = 1;
     snprintf(h->last_kernel, sizeof(h->last_kernel), "%s", kl ? wk->name_kl : wk->name);
@@ -360,21 +359,21 @@ int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
     sa.l2h = (real)p->l2_reg_H;
     const dim3 grid(B, S), block(wk->NW * 64);
     const size_t hsmem = sizeof(real) * (rec + (size_t)k * m);
-    if (hsmem > 48 * 1024)
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(wide_hupdate_kernel<real>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)hsmem));
-    auto residual = [&](int it) {
-      hipLaunchKernelGGL(kern, grid, block, smem, st, ra);
+    if (hsmem > 48 * 1024 && (rc = hipnmf_allow_full_lds(h, reinterpret_cast<const void*>(wide_hupdate_kernel<real>)))) return rc;
+    // every launch goes through an emitter: straight onto the stream, or into the replayed chain
+    auto direct = [&](auto fn, dim3 g, dim3 blk, size_t sm, const auto& args) { hipLaunchKernelGGL(fn, g, blk, sm, st, args); };
+    auto residual = [&](int it, auto&& emit) {
+      emit(kern, grid, block, smem, ra);
       WideSliceArgs<real> f = sa;
       f.it = it;
-      hipLaunchKernelGGL(wide_resid_finalize_kernel<real>, dim3(B), dim3(1024), 0, st, f);
+      emit(wide_resid_finalize_kernel<real>, dim3(B), dim3(1024), (size_t)0, f);
     };
-    auto enqueue = [&](int n, bool check) {
+    auto enqueue = [&](int n, bool check, auto&& emit) {
       for (int i = 0; i < n; ++i) {
-        hipLaunchKernelGGL(kern, grid, block, smem, st, pa);
-        if (a.update_h) hipLaunchKernelGGL(wide_hupdate_kernel<real>, dim3(B), dim3(1024), hsmem, st, sa);
+        emit(kern, grid, block, smem, pa);
+        if (a.update_h) emit(wide_hupdate_kernel<real>, dim3(B), dim3(1024), hsmem, sa);
       }
-      if (check) residual(1);
+      if (check) residual(1, emit);
     };
     std::vector<real> host_state((size_t)B * 8);
     auto all_converged = [&](bool* done) -> int {
@@ -384,24 +383,21 @@ int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
       for (int b = 0; b < B; ++b) *done = *done && host_state[(size_t)b * 8 + 3] != (real)0;
       return HIPNMF_OK;
     };
-    if (stop_rule) residual(0);
+    if (stop_rule) residual(0, direct);
     const int chunk = stop_rule ? p->check_every : std::min(p->max_iter, 64);
     int it_done = 0;
     bool converged = false;
     if (h->use_graph && p->max_iter >= 2 * chunk) {
-      hipGraph_t graph = nullptr;
-      hipGraphExec_t exec = nullptr;
-      std::unique_lock<std::mutex> capture_lock(hipnmf_capture_mutex());
-      hipError_t ge = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
-      if (ge == hipSuccess) {
-        enqueue(chunk, stop_rule);
-        ge = hipStreamEndCapture(st, &graph);
-      }
-      if (ge == hipSuccess) ge = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-      capture_lock.unlock();
+      // an explicit kernel-node chain, not a stream capture (hipnmf_kernel_chain in hipnmf_internal.hpp says why)
+      hipnmf_kernel_chain chain;
+      hipError_t ge = hipSuccess;
+      enqueue(chunk, stop_rule, [&](auto fn, dim3 g, dim3 blk, size_t sm, const auto& args) {
+        if (ge == hipSuccess) ge = chain.add(reinterpret_cast<const void*>(fn), g, blk, sm, args);
+      });
+      if (ge == hipSuccess) ge = chain.instantiate();
       int graph_rc = HIPNMF_OK;
       while (ge == hipSuccess && !converged && it_done + chunk <= p->max_iter) {
-        ge = hipGraphLaunch(exec, st);
+        ge = chain.launch(st);
         if (ge != hipSuccess) break;
         it_done += chunk;
         if (stop_rule) {
@@ -410,8 +406,6 @@ int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
         }
       }
       if (ge == hipSuccess && !graph_rc) ge = hipStreamSynchronize(st);
-      if (exec) (void)hipGraphExecDestroy(exec);
-      if (graph) (void)hipGraphDestroy(graph);
       if (graph_rc) return graph_rc;
       if (ge != hipSuccess) {
         (void)hipGetLastError();
@@ -422,14 +416,14 @@ int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
     while (!converged && it_done < p->max_iter) {
       const int n = std::min(chunk, p->max_iter - it_done);
       const bool check = stop_rule && n == chunk;
-      enqueue(n, check);
+      enqueue(n, check, direct);
       it_done += n;
       if (check) {
         rc = all_converged(&converged);
         if (rc) return rc;
       }
     }
-    residual(-1);
+    residual(-1, direct);
   }
   HIP_TRY(hipEventRecord(h->ev1, st));
   if (!w_inplace) convert_w(1);

@@ -1,14 +1,14 @@
-"""What happens when the ranks of find_synergies run from concurrent threads on frames that take the chip-filling paths (cooperative
-kernel, row-sliced hipGraph replay): set muscle_synergies_amd.analysis._RANK_THREADS_MAX_SAMPLES / _FEATURES high to reproduce
-"operation failed due to a previous error during capture"; with the shipped limits the long frames keep the sequential loop."""
+"""The ranks of find_synergies from concurrent threads on frames that take the chip-filling paths (cooperative kernel, row-sliced
+hipGraph replay), with torch in the process.  Round 3: "operation failed due to a previous error during capture" for the long /
+wide frames (an open stream capture is invalidated by any legacy-stream call of another thread -- here torch's null-stream
+copies; profiles/r04_threads_root_cause.md).  Round 4: the library builds its graphs node by node, no frame-size gate is left,
+and this prints identical=True for every frame."""
 import os, sys, time, numpy as np, pandas as pd
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import muscle_synergies_amd as ms
 from muscle_synergies_amd import _lib
 from muscle_synergies_amd.synth import emg_matrix
 import muscle_synergies_amd.analysis as _an
-if os.environ.get("REPRO_UNLIMITED"):  # lift the frame-size limit of the concurrent ranks: the chip-filling paths from three threads at once
-    _an._RANK_THREADS_MAX_SAMPLES = 10**9; _an._RANK_THREADS_MAX_FEATURES = 10**9
 for dtype, T, m in ((np.float32, 10000, 16), (np.float64, 6000, 8), (np.float64, 20000, 64)):
     X = emg_matrix(5, T=T, m=m, k_true=4, dtype=dtype)
     df = pd.DataFrame(X, columns=[f"m{i}" for i in range(m)])
