@@ -32,7 +32,10 @@ __global__ void __launch_bounds__(64) fit_small_kernel(SolveArgs<real> a) {
   constexpr int NB = C::NB;
   // tiles per group in the W update (the temporaries of a group live at once).  (float64, 16 channels, k = 5 in groups of four came
   // out of hipcc returning wrong factors -- its neighbours k = 1..4, 6 were exact -- and one tile at a time is 6x slower: groups of two)
-  constexpr int TG = (sizeof(real) == 8 && CH == 16 && K == 5) ? 2 : (NT % 4 == 0) ? 4 : 2;
+#ifndef HIPNMF_SMALL_F64_16_5_TG
+#define HIPNMF_SMALL_F64_16_5_TG 2
+#endif
+  constexpr int TG = (sizeof(real) == 8 && CH == 16 && K == 5) ? HIPNMF_SMALL_F64_16_5_TG : (NT % 4 == 0) ? 4 : 2;
   static_assert(NT % TG == 0, "whole groups of tiles");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   Smem<real, 1, CH, K> s(smem_raw, 1);
