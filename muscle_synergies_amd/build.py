@@ -53,13 +53,46 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _device_asm(src: str, objdir: str) -> str:
+    return os.path.join(objdir, os.path.basename(src)[:-4] + f"-hip-amdgcn-amd-amdhsa-{ARCH}.s")
+
+
 def _compile(src: str, extra, objdir: str = OBJ) -> str:
-    obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
-    cmd = [_hipcc(), *CXXFLAGS, *extra, "-I", CSRC, "-c", src, "-o", obj]
+    """One translation unit.  -save-temps=obj keeps the device assembly next to the object (same code generation, the
+    assembly is what the ISA lint below reads); the other intermediates are deleted again."""
+    base = os.path.basename(src)[:-4]
+    obj = os.path.join(objdir, base + ".o")
+    cmd = [_hipcc(), *CXXFLAGS, *extra, "-I", CSRC, "-save-temps=obj", "-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
+    keep = {obj, _device_asm(src, objdir)}
+    for f in os.listdir(objdir):
+        full = os.path.join(objdir, f)
+        if full not in keep and (f.startswith(base + "-hip-") or f.startswith(base + "-host-") or f.startswith(base + ".hip-")):
+            os.remove(full)
     return obj
+
+
+def lint_isa(srcs, objdir: str = OBJ, verbose: bool = False) -> None:
+    """Refuse a build whose device code shows the split-spill defect of hipcc that made one fp64 instance return wrong factors in
+    round 3 (tools/isa_split_spill_lint.py, profiles/r04_small_f64_miscompile.md).  Reads the assembly -save-temps left."""
+    tools = os.path.join(os.path.dirname(PKG), "tools")
+    if not os.path.exists(os.path.join(tools, "isa_split_spill_lint.py")):
+        return  # installed without the repo's tools/: nothing to run
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("isa_split_spill_lint", os.path.join(tools, "isa_split_spill_lint.py"))
+    lint = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(lint)
+    asm = [a for a in (_device_asm(s, objdir) for s in srcs) if os.path.exists(a)]
+    bad, n_kernels, n_split = lint.lint_files(asm)
+    if verbose:
+        print(f"[build] ISA lint: {n_kernels} kernels in {len(asm)} assembly file(s), {n_split} with a scratch/AGPR split value, "
+              f"{len(bad)} defective reload(s)", flush=True)
+    if bad:
+        raise RuntimeError("hipcc emitted the split-spill defect (a 64-bit value reloaded by halves from scratch and an AGPR, one half "
+                           "missing): refusing the library.\n" + "\n".join(f"{n}: {p}" for _, n, p in bad))
 
 
 def build(force: bool = False, jobs: int | None = None, extra_flags=(), verbose: bool = False,
@@ -111,6 +144,7 @@ def build(force: bool = False, jobs: int | None = None, extra_flags=(), verbose:
         if verbose:
             print(f"[build] linked {lib}", flush=True)
     if not variant:
+        lint_isa(srcs, objdir, verbose)
         _record(lib, srcs, todo, linked, verbose, record_profile)
     return lib
 

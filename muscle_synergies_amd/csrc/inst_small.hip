@@ -15,10 +15,10 @@ SmallFn<float> small_kernel<float>(int m, int K) {
 template <>
 SmallFn<double> small_kernel<double>(int m, int K) {
   static const SmallFn<double> t8[8] = SMALL_TABLE(double, 8);
-  // 9..16 channels in float64 (round 3), up to 6 components.  These instances walk the W update one tile at a time (TG = 1 in
-  // nmf_small.hpp): with groups of four tiles the k = 5 instance -- and only that one -- returned wrong factors (a spill-heavy
-  // build, 372 bytes of scratch per lane; k = 1..4 and 6 were exact), which is why tests/test_gpu_small_long.py checks EVERY
-  // compiled (dtype, channels, k, tiles) instance against the oracle.
+  // 9..16 channels in float64 (round 3), up to 6 components.  The k = 5 instance walks its W update in groups of two tiles
+  // instead of four (nmf_small.hpp: hipcc's split-spill defect, profiles/r04_small_f64_miscompile.md); the build lints every
+  // kernel's ISA for that defect and tests/test_gpu_small_long.py checks EVERY compiled (dtype, channels, k, tiles) instance
+  // against the oracle.
   static const SmallFn<double> t16[6] = {fit_small_kernel<double, 16, 1>, fit_small_kernel<double, 16, 2>, fit_small_kernel<double, 16, 3>,
                                          fit_small_kernel<double, 16, 4>, fit_small_kernel<double, 16, 5>, fit_small_kernel<double, 16, 6>};
   if (K < 1 || K > 8 || m < 1 || m > 16) return nullptr;

@@ -30,8 +30,11 @@ template <typename real, int CH, int K, int NT = SMALL_NT>
 __global__ void __launch_bounds__(64) fit_small_kernel(SolveArgs<real> a) {
   using C = Cfg<real, 1, CH, K>;
   constexpr int NB = C::NB;
-  // tiles per group in the W update (the temporaries of a group live at once).  (float64, 16 channels, k = 5 in groups of four came
-  // out of hipcc returning wrong factors -- its neighbours k = 1..4, 6 were exact -- and one tile at a time is 6x slower: groups of two)
+  // tiles per group in the W update (the temporaries of a group live at once).  float64, 16 channels, k = 5 walks groups of TWO:
+  // with groups of four hipcc (ROCm 7.2.0) spills w[0][1] by halves -- high dword to an AGPR, low dword to scratch -- and at the
+  // loop entry reloads only the scratch half, so the first W update of tile 0 reads an uninitialised register
+  // (profiles/r04_small_f64_miscompile.md has the ISA).  A register-allocator defect, not UB here; tools/isa_split_spill_lint.py
+  // looks for it in every kernel of every build (muscle_synergies_amd/build.py refuses the library if it fires).
 #ifndef HIPNMF_SMALL_F64_16_5_TG
 #define HIPNMF_SMALL_F64_16_5_TG 2
 #endif
