@@ -301,8 +301,17 @@ typedef struct hipnmf_sosfilt_params {
   int32_t padlen;         /* zero_lag: samples of extension at each end; -1 = scipy's default 3*ntaps  */
   int32_t zero_center;    /* 1: subtract the per-channel mean before filtering (linear_envelope)       */
   int32_t rectify;        /* 1: take |x| (after centring) before filtering (linear_envelope)           */
-  int32_t reserved0;      /* must be 0                                                                 */
+  int32_t mode;           /* HIPNMF_SOSFILT_*: EXACT (0, scipy's recurrence bit for bit) or SCAN (time-parallel) */
 } hipnmf_sosfilt_params;
+/* mode (round 4; the field was `reserved0`, must-be-zero, before: old callers get the exact mode):
+ *  HIPNMF_SOSFILT_EXACT  the sequential recurrence in scipy's operation order, no fused multiply-adds: the f64 entry point is
+ *                        bit-identical to scipy.  Bound by the dependent fp64 chain of the recursion (0.16 of HBM at 1024 x 16 x 20 000).
+ *  HIPNMF_SOSFILT_SCAN   every series cut into 256 chunks filtered at once, chunk-end states combined by a scan over the workgroup
+ *                        (csrc/sosfilt_scan.hpp); fp64 with fused multiply-adds, agrees with scipy to rounding times the filter's
+ *                        conditioning (1e-12 relative for the reference's 6 Hz low-pass at 2 kHz; tests bound 1e-10), not bit for
+ *                        bit.  Series of more than 20 480 extended samples (n_samples + 2 padlen) take the exact kernel. */
+#define HIPNMF_SOSFILT_EXACT 0
+#define HIPNMF_SOSFILT_SCAN 1
 
 int hipnmf_sosfilt_f32(hipnmf_handle* h, const hipnmf_sosfilt_params* p, const double* sos, const double* zi,
                        const float* x, float* y);

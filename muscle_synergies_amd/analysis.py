@@ -224,7 +224,7 @@ def find_synergies_batched(processed_emg_dfs, n_components: int, max_components:
                           alpha_H=alpha_H, l1_ratio=l1_ratio, beta_loss=beta_loss, device=device)
         template._check_params()
         equal_len = len({a.shape[0] for a in arrays}) == 1
-        if equal_len and init in (None, "nndsvd", "nndsvda") and rank <= min(arrays[0].shape) and rank <= 8:
+        if equal_len and init in (None, "nndsvd", "nndsvda") and rank <= min(arrays[0].shape):
             # one batched on-device NNDSVD (exact Gram-matrix SVD) instead of one randomized SVD per trial
             from .init import nndsvd_init_batched
 

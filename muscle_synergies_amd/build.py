@@ -53,6 +53,21 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _obj_stale(obj: str, src: str, hdrs) -> bool:
+    """An object is stale when its source or one of the project headers IT INCLUDES is newer (hipcc -MD writes the list next to
+    the object); without a dependency file every project header counts."""
+    dep = obj[:-2] + ".d"
+    if not os.path.exists(obj) or not os.path.exists(dep):
+        return _stale(obj, [src, *hdrs])
+    try:
+        words = open(dep).read().replace("\\\n", " ").split()
+    except OSError:
+        return True
+    root = os.path.dirname(PKG)
+    mine = [w for w in words[1:] if os.path.abspath(w).startswith(root) and os.path.exists(w)]
+    return _stale(obj, [src, *mine])
+
+
 def _device_asm(src: str, objdir: str) -> str:
     return os.path.join(objdir, os.path.basename(src)[:-4] + f"-hip-amdgcn-amd-amdhsa-{ARCH}.s")
 
@@ -62,7 +77,7 @@ def _compile(src: str, extra, objdir: str = OBJ) -> str:
     assembly is what the ISA lint below reads); the other intermediates are deleted again."""
     base = os.path.basename(src)[:-4]
     obj = os.path.join(objdir, base + ".o")
-    cmd = [_hipcc(), *CXXFLAGS, *extra, "-I", CSRC, "-save-temps=obj", "-c", src, "-o", obj]
+    cmd = [_hipcc(), *CXXFLAGS, *extra, "-I", CSRC, "-save-temps=obj", "-MD", "-MF", obj[:-2] + ".d", "-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
@@ -113,7 +128,7 @@ def build(force: bool = False, jobs: int | None = None, extra_flags=(), verbose:
         stamp = os.path.join(objdir, "flags.txt")  # same flags + objects newer than the sources: nothing to do
         same_flags = os.path.exists(stamp) and open(stamp).read() == " ".join(extra_flags)
         todo = [s for s in mine if force or not same_flags
-                or _stale(os.path.join(objdir, os.path.basename(s)[:-4] + ".o"), [s, *hdrs])]
+                or _obj_stale(os.path.join(objdir, os.path.basename(s)[:-4] + ".o"), s, hdrs)]
         with ThreadPoolExecutor(max_workers=jobs or min(8, os.cpu_count() or 1)) as ex:
             list(ex.map(lambda s: _compile(s, list(extra_flags), objdir), todo))
         with open(stamp, "w") as f:
@@ -126,7 +141,7 @@ def build(force: bool = False, jobs: int | None = None, extra_flags=(), verbose:
                 raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
         return lib
     todo = [s for s in srcs
-            if force or _stale(os.path.join(objdir, os.path.basename(s)[:-4] + ".o"), [s, *hdrs])]
+            if force or _obj_stale(os.path.join(objdir, os.path.basename(s)[:-4] + ".o"), s, hdrs)]
     jobs = jobs or min(8, os.cpu_count() or 1)
     if todo:
         if verbose:

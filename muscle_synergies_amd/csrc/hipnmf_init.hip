@@ -12,14 +12,15 @@ namespace {
 
 // validates the shape fields of *p and returns X in channel-major form (in place or converted into workspace)
 template <typename real>
-int canonical_x(hipnmf_handle* h, const hipnmf_problem* p, const real* X, InitArgs* a, bool any_shape = false) {
+int canonical_x(hipnmf_handle* h, const hipnmf_problem* p, const real* X, InitArgs* a) {
   if (!h) return fail(HIPNMF_ERR_BAD_ARG, "handle is NULL");
   if (!p || p->struct_size != (int32_t)sizeof(hipnmf_problem)) return fail(HIPNMF_ERR_BAD_ARG, "bad hipnmf_problem");
   if (!X) return fail(HIPNMF_ERR_BAD_ARG, "X is NULL");
   if (p->batch < 1 || p->n_samples < 1 || p->n_samples > 2000000000LL || p->n_features < 1 || p->n_components < 1)
     return fail(HIPNMF_ERR_BAD_ARG, "bad shape");
-  if (!any_shape && (p->n_features > GRAM_MAXM || p->n_components > 8))
-    return fail(HIPNMF_ERR_UNSUPPORTED, "init kernels support n_features <= %d and n_components <= 8", GRAM_MAXM);
+  if (p->n_features > HIPNMF_MAX_FEATURES || p->n_components > HIPNMF_MAX_COMPONENTS)
+    return fail(HIPNMF_ERR_UNSUPPORTED, "shape outside the compiled kernel set: n_features=%d (max %d), n_components=%d (max %d)",
+                p->n_features, HIPNMF_MAX_FEATURES, p->n_components, HIPNMF_MAX_COMPONENTS);
   if (p->x_layout != HIPNMF_X_ROW_MAJOR && p->x_layout != HIPNMF_X_CHANNEL_MAJOR)
     return fail(HIPNMF_ERR_BAD_ARG, "bad x_layout %d", p->x_layout);
   const long long min_ld = (p->x_layout == HIPNMF_X_ROW_MAJOR) ? p->n_features : p->n_samples;
@@ -52,6 +53,19 @@ int canonical_x(hipnmf_handle* h, const hipnmf_problem* p, const real* X, InitAr
   return HIPNMF_OK;
 }
 
+// the Gram matrix in GRAM_BLK x GRAM_BLK blocks, the batch on grid.y
+template <typename real>
+void launch_gram(hipnmf_handle* h, int B, const InitArgs& a) {
+  const int nblk = (a.m + GRAM_BLK - 1) / GRAM_BLK;
+  for (int b0 = 0; b0 < B; b0 += 65535) {
+    InitArgs ab = a;
+    ab.X = static_cast<const real*>(a.X) + (long long)b0 * a.bstride;
+    ab.gram = a.gram + (size_t)b0 * a.m * a.m;
+    ab.colsum = a.colsum + (size_t)b0 * a.m;
+    hipLaunchKernelGGL(gram_kernel<real>, dim3(nblk * nblk, std::min(65535, B - b0)), dim3(256), 0, h->stream, ab);
+  }
+}
+
 int finish(hipnmf_handle* h) {
   HIP_TRY(hipGetLastError());
   if (!h->async_mode) HIP_TRY(hipStreamSynchronize(h->stream));
@@ -66,7 +80,7 @@ int gram_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, double* 
   if (rc) return rc;
   a.gram = gram;
   a.colsum = colsum;
-  hipLaunchKernelGGL(gram_kernel<real>, dim3(p->batch), dim3(256), 0, h->stream, a);
+  launch_gram<real>(h, p->batch, a);
   return finish(h);
 }
 
@@ -80,7 +94,8 @@ int stats_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, const d
   a.V = V;
   a.inv_s = inv_s;
   a.stats = stats;
-  hipLaunchKernelGGL(nndsvd_stats_kernel<real>, dim3(p->batch), dim3(256), 0, h->stream, a);
+  hipLaunchKernelGGL(nndsvd_stats_kernel<real>, dim3(p->batch, (a.k + NNDSVD_KB - 1) / NNDSVD_KB), dim3(256),
+                     sizeof(double) * NNDSVD_KB * (size_t)a.m, h->stream, a);
   return finish(h);
 }
 
@@ -97,7 +112,8 @@ int write_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, const d
   a.fill = fill;
   a.eps = eps;
   a.W0 = W0;
-  hipLaunchKernelGGL(nndsvd_write_kernel<real>, dim3(p->batch), dim3(256), 0, h->stream, a);
+  hipLaunchKernelGGL(nndsvd_write_kernel<real>, dim3(p->batch, (a.k + NNDSVD_KB - 1) / NNDSVD_KB), dim3(256),
+                     sizeof(double) * NNDSVD_KB * (size_t)a.m, h->stream, a);
   return finish(h);
 }
 
@@ -123,13 +139,13 @@ int random_init_impl(hipnmf_handle* h, const hipnmf_problem* p, uint64_t seed, i
   if (p && (p->n_features > HIPNMF_MAX_FEATURES || p->n_components > HIPNMF_MAX_COMPONENTS))
     return fail(HIPNMF_ERR_UNSUPPORTED, "shape outside the compiled kernel set: n_features=%d (max %d), n_components=%d (max %d)",
                 p->n_features, HIPNMF_MAX_FEATURES, p->n_components, HIPNMF_MAX_COMPONENTS);
-  rc = canonical_x<real>(h, p, X, &a, true);  // validates everything (and reports what the shortcut above skipped)
+  rc = canonical_x<real>(h, p, X, &a);  // validates everything (and reports what the shortcut above skipped)
   if (rc) return rc;
   const int B = p->batch, m = p->n_features;
   a.gram = reinterpret_cast<double*>(static_cast<char*>(h->ws) + x_bytes);
   a.colsum = a.gram + (size_t)B * m * m;
-  if (m <= GRAM_MAXM)
-    hipLaunchKernelGGL(gram_kernel<real>, dim3(B), dim3(256), 0, h->stream, a);
+  if (m <= GRAM_BLK)
+    launch_gram<real>(h, B, a);  // (one block: the column sums of round 2's kernel, bit for bit)
   else  // only the column sums are needed here
     hipLaunchKernelGGL(colsum_kernel<real>, dim3(B), dim3(256), 0, h->stream, a);
   RandomInitArgs r{};

@@ -9,6 +9,7 @@
 #include "hipnmf_internal.hpp"
 #include "nmf_kernels.hpp"  // x_to_channel_major_kernel
 #include "sosfilt_kernels.hpp"
+#include "sosfilt_scan.hpp"
 
 using namespace hipnmf;
 
@@ -72,6 +73,21 @@ hipError_t launch_v3(hipnmf_handle* h, const SosArgs& a, const double* stat, int
   return hipSuccess;
 }
 
+// time-parallel mode (sosfilt_scan.hpp): tables for this filter and chunk length, then one workgroup per series
+template <typename real, int NSP>
+int launch_scan(hipnmf_handle* h, const SosArgs& a, int ns, int C_run, double* tab, hipStream_t st) {
+  constexpr int NST = 2 * NSP;
+  hipLaunchKernelGGL((sos_scan_tables_kernel<NSP>), dim3(1), dim3(256), 0, st, a, ns, C_run, tab);
+  const size_t smem = (size_t)SCAN_STAGE_BYTES + sizeof(double) * (SCAN_THREADS * NST + 8 + (size_t)C_run * NST);
+  auto go = [&](auto kern) -> int {
+    if (smem > 48 * 1024)
+      if (int rc = hipnmf_allow_full_lds(h, reinterpret_cast<const void*>(kern))) return rc;
+    hipLaunchKernelGGL(kern, dim3((unsigned)a.N), dim3(SCAN_THREADS), smem, st, a, (const double*)tab, ns, C_run);
+    return HIPNMF_OK;
+  };
+  return C_run <= 16 ? go(sosfilt_scan_kernel<real, NSP, 16>) : go(sosfilt_scan_kernel<real, NSP, SCAN_CMAX>);
+}
+
 template <typename real>
 int sosfilt_impl(hipnmf_handle* h, const hipnmf_sosfilt_params* p, const double* sos, const double* zi, const real* x,
                  real* y) {
@@ -85,7 +101,8 @@ int sosfilt_impl(hipnmf_handle* h, const hipnmf_sosfilt_params* p, const double*
     return fail(HIPNMF_ERR_BAD_ARG, "bad shape: batch=%d n_samples=%lld n_channels=%d", p->batch,
                 (long long)p->n_samples, p->n_channels);
   if ((long long)p->batch * p->n_channels > 2000000000LL) return fail(HIPNMF_ERR_BAD_ARG, "too many series");
-  if (p->reserved0 != 0) return fail(HIPNMF_ERR_BAD_ARG, "hipnmf_sosfilt_params.reserved0 must be 0 (got %d)", p->reserved0);
+  if (p->mode != HIPNMF_SOSFILT_EXACT && p->mode != HIPNMF_SOSFILT_SCAN)
+    return fail(HIPNMF_ERR_BAD_ARG, "hipnmf_sosfilt_params.mode must be HIPNMF_SOSFILT_EXACT (0) or HIPNMF_SOSFILT_SCAN (1) (got %d)", p->mode);
   if (p->n_sections < 1) return fail(HIPNMF_ERR_BAD_ARG, "n_sections must be >= 1 (got %d)", p->n_sections);
   if (p->n_sections > SOS_MAX_SECTIONS)
     return fail(HIPNMF_ERR_UNSUPPORTED, "n_sections=%d outside the compiled kernel set (max %d)", p->n_sections,
@@ -135,8 +152,21 @@ int sosfilt_impl(hipnmf_handle* h, const hipnmf_sosfilt_params* p, const double*
   // v3: section states per workgroup and tile only: [workgroups <= N / 8 + 1][tiles + 1][64 lanes][2]
   const size_t ws_v2 = sizeof(double) * (size_t)round_up(N, 64) * (size_t)round_up(L, 64);
   const size_t ws_v3 = sizeof(double) * (size_t)(N / 8 + 1) * (size_t)(round_up(L, 64) / 64 + 1) * 128;
-  const size_t o_ws = zero_lag ? carve(use_v3 ? ws_v3 : ws_v2) : 0;
+  // time-parallel mode: the whole extended series in the registers of one workgroup (256 chunks of at most SCAN_CMAX samples, whole
+  // groups of four), all staging traffic in 16-byte vectors: series and outputs 16-byte aligned, n_samples a multiple of the vector
+  constexpr int VS = 16 / (int)sizeof(real);
+  const int scan_delta = (VS - edge % VS) % VS;  // front padding that aligns the extended positions with the raw samples
+  const int scan_chunk = (int)round_up((L + scan_delta + SCAN_THREADS - 1) / SCAN_THREADS, 4);
+  const bool scan_aligned = (T % VS) == 0 && (reinterpret_cast<uintptr_t>(y) % 16) == 0 &&
+                            (!inplace || ((reinterpret_cast<uintptr_t>(x) % 16) == 0 && (p->ldx % VS) == 0 && (p->x_batch_stride % VS) == 0));
+  const bool scan_fits = p->mode == HIPNMF_SOSFILT_SCAN && scan_chunk <= SCAN_CMAX && scan_aligned;
+  const size_t o_ws = (zero_lag && !scan_fits) ? carve(use_v3 ? ws_v3 : ws_v2) : 0;
   const size_t o_stat = carve(sizeof(double) * (size_t)N * 3);
+  // time-parallel mode: the whole extended series in the registers of one workgroup (256 chunks of at most SCAN_CMAX samples);
+  // longer series take the sequential kernel
+  const int C_run = scan_fits ? scan_chunk : 0;
+  const bool use_scan = scan_fits;
+  const size_t o_tab = use_scan ? carve(sizeof(double) * SCAN_TAB_DOUBLES) : 0;
   int rc = hipnmf_ensure_ws(h, std::max<size_t>(off, 256));
   if (rc) return rc;
   char* ws = static_cast<char*>(h->ws);
@@ -182,6 +212,22 @@ int sosfilt_impl(hipnmf_handle* h, const hipnmf_sosfilt_params* p, const double*
   const bool async = h->async_mode != 0;
   if (!async) HIP_TRY(hipEventRecord(h->ev0, st));
   double* stat = reinterpret_cast<double*>(ws + o_stat);
+  if (use_scan) {
+    const int ns = p->n_sections;
+    double* tab = reinterpret_cast<double*>(ws + o_tab);
+    rc = ns == 1 ? launch_scan<real, 1>(h, a, ns, C_run, tab, st)
+         : ns == 2 ? launch_scan<real, 2>(h, a, ns, C_run, tab, st)
+         : ns <= 4 ? launch_scan<real, 4>(h, a, ns, C_run, tab, st)
+                   : launch_scan<real, 8>(h, a, ns, C_run, tab, st);
+    if (rc) return rc;
+    HIP_TRY(hipGetLastError());
+    if (!async) {
+      HIP_TRY(hipEventRecord(h->ev1, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      HIP_TRY(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
+    }
+    return HIPNMF_OK;
+  }
   hipLaunchKernelGGL(sos_stats_kernel<real>, dim3((unsigned)N), dim3(256), 0, st, a, stat);
   static const bool sos_v1 = [] {
     const char* e = getenv("HIPNMF_SOS_V1");

@@ -23,75 +23,87 @@ struct InitArgs {
   void* W0;  // [B][T][k]
 };
 
-constexpr int GRAM_TILE = 128;  // rows per LDS tile
-constexpr int GRAM_MAXM = 32;
+constexpr int GRAM_TILE = 64;  // rows per LDS tile
+constexpr int GRAM_BLK = 32;   // channels per block of the Gram matrix: one workgroup computes one GRAM_BLK x GRAM_BLK block
+constexpr int NNDSVD_KB = 8;   // components per workgroup of the two projection kernels
 
-// gram[b][j][j2] = sum_t X[t][j] X[t][j2];  colsum[b][j] = sum_t X[t][j]
+// gram[b][j][j2] = sum_t X[t][j] X[t][j2];  colsum[b][j] = sum_t X[t][j].  Any number of channels: grid = (nblk * nblk, B) with
+// nblk = ceil(m / GRAM_BLK); block (jb, j2b) of the matrix per workgroup, every entry accumulated by ONE thread in time order
+// (fixed summation order whatever the grid), the column sums by the blocks of the first block column.
 template <typename real>
 __global__ void __launch_bounds__(256) gram_kernel(InitArgs a) {
-  __shared__ double xs[GRAM_MAXM][GRAM_TILE + 1];
-  const int b = blockIdx.x, m = a.m;
+  __shared__ double xa[GRAM_BLK][GRAM_TILE + 1], xb[GRAM_BLK][GRAM_TILE + 1];
+  const int b = blockIdx.y, m = a.m;
+  const int nblk = (m + GRAM_BLK - 1) / GRAM_BLK;
+  const int jb = (int)blockIdx.x / nblk, j2b = (int)blockIdx.x % nblk;
+  const bool diag = jb == j2b;
   const real* __restrict__ Xb = static_cast<const real*>(a.X) + (long long)b * a.bstride;
-  const int npair = m * m;
-  double acc[4] = {0.0, 0.0, 0.0, 0.0};  // up to 4 (j, j2) pairs per thread (m <= 32)
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};  // 4 of the block's 1 024 (j, j2) pairs per thread
   double csum = 0.0;
   for (int t0 = 0; t0 < a.T; t0 += GRAM_TILE) {
     __syncthreads();
-    for (int i = threadIdx.x; i < m * GRAM_TILE; i += blockDim.x) {
-      const int j = i / GRAM_TILE, tt = i % GRAM_TILE, t = t0 + tt;
-      xs[j][tt] = (t < a.T) ? (double)Xb[(long long)j * a.ld + t] : 0.0;
+    for (int i = threadIdx.x; i < GRAM_BLK * GRAM_TILE; i += blockDim.x) {
+      const int jl = i / GRAM_TILE, tt = i % GRAM_TILE, t = t0 + tt;
+      const int j = jb * GRAM_BLK + jl, j2 = j2b * GRAM_BLK + jl;
+      xa[jl][tt] = (t < a.T && j < m) ? (double)Xb[(long long)j * a.ld + t] : 0.0;
+      if (!diag) xb[jl][tt] = (t < a.T && j2 < m) ? (double)Xb[(long long)j2 * a.ld + t] : 0.0;
     }
     __syncthreads();
+    const double(*xr)[GRAM_TILE + 1] = diag ? xa : xb;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int pidx = threadIdx.x + q * 256;
-      if (pidx < npair) {
-        const int j = pidx / m, j2 = pidx % m;
-        double s = acc[q];
-        for (int tt = 0; tt < GRAM_TILE; ++tt) s = fma(xs[j][tt], xs[j2][tt], s);
-        acc[q] = s;
-      }
+      const int jl = pidx / GRAM_BLK, j2l = pidx % GRAM_BLK;
+      double s = acc[q];
+      for (int tt = 0; tt < GRAM_TILE; ++tt) s = fma(xa[jl][tt], xr[j2l][tt], s);
+      acc[q] = s;
     }
-    if (threadIdx.x < m) {
+    if (j2b == 0 && threadIdx.x < GRAM_BLK) {
       double s = csum;
-      for (int tt = 0; tt < GRAM_TILE; ++tt) s += xs[threadIdx.x][tt];
+      for (int tt = 0; tt < GRAM_TILE; ++tt) s += xa[threadIdx.x][tt];
       csum = s;
     }
   }
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int pidx = threadIdx.x + q * 256;
-    if (pidx < npair) a.gram[(long long)b * npair + pidx] = acc[q];
+    const int j = jb * GRAM_BLK + pidx / GRAM_BLK, j2 = j2b * GRAM_BLK + pidx % GRAM_BLK;
+    if (j < m && j2 < m) a.gram[(long long)b * m * m + (long long)j * m + j2] = acc[q];
   }
-  if (threadIdx.x < m) a.colsum[(long long)b * m + threadIdx.x] = csum;
+  if (j2b == 0 && threadIdx.x < GRAM_BLK && jb * GRAM_BLK + (int)threadIdx.x < m)
+    a.colsum[(long long)b * m + jb * GRAM_BLK + threadIdx.x] = csum;
 }
 
-// u_j[t] = (sum_c X[t][c] V[j][c]) * inv_s[j]
+// u_j[t] = (sum_c X[t][c] V[j][c]) * inv_s[j] for the KMAX components of one block; Vs: [KMAX][m] in LDS
 template <typename real, int KMAX>
 __device__ __forceinline__ void project_row(const real* __restrict__ Xb, long long ld, int t, int m, int k,
-                                            const double (*Vs)[GRAM_MAXM], const double* is, double (&u)[KMAX]) {
+                                            const double* Vs, const double* is, double (&u)[KMAX]) {
 #pragma unroll
   for (int j = 0; j < KMAX; ++j) u[j] = 0.0;
   for (int c = 0; c < m; ++c) {
     const double x = (double)Xb[(long long)c * ld + t];
 #pragma unroll
     for (int j = 0; j < KMAX; ++j)
-      if (j < k) u[j] = fma(x, Vs[j][c], u[j]);
+      if (j < k) u[j] = fma(x, Vs[j * m + c], u[j]);
   }
 #pragma unroll
   for (int j = 0; j < KMAX; ++j) u[j] *= is[j < k ? j : 0];
 }
 
+// grid = (B, ceil(k / NNDSVD_KB)): workgroup (b, kb) handles components [kb * NNDSVD_KB, ...) of matrix b; dynamic LDS: the block's
+// rows of V, NNDSVD_KB * m doubles (any number of channels and components)
 template <typename real>
 __global__ void __launch_bounds__(256) nndsvd_stats_kernel(InitArgs a) {
-  constexpr int KMAX = 8;
-  __shared__ double Vs[KMAX][GRAM_MAXM];
+  constexpr int KMAX = NNDSVD_KB;
+  extern __shared__ __attribute__((aligned(16))) unsigned char init_smem[];
+  double* Vs = reinterpret_cast<double*>(init_smem);
   __shared__ double is[KMAX];
   __shared__ double red[4][KMAX][3];
-  const int b = blockIdx.x, m = a.m, k = a.k;
+  const int b = blockIdx.x, m = a.m, j0 = (int)blockIdx.y * KMAX;
+  const int k = a.k - j0 < KMAX ? a.k - j0 : KMAX;  // components of this block
   const real* __restrict__ Xb = static_cast<const real*>(a.X) + (long long)b * a.bstride;
-  for (int i = threadIdx.x; i < k * m; i += blockDim.x) Vs[i / m][i % m] = a.V[(long long)b * k * m + i];
-  if (threadIdx.x < k) is[threadIdx.x] = a.inv_s[(long long)b * k + threadIdx.x];
+  for (int i = threadIdx.x; i < k * m; i += blockDim.x) Vs[i] = a.V[((long long)b * a.k + j0) * m + i];
+  if ((int)threadIdx.x < k) is[threadIdx.x] = a.inv_s[(long long)b * a.k + j0 + threadIdx.x];
   __syncthreads();
   double sp[KMAX], sn[KMAX], piv[KMAX];
 #pragma unroll
@@ -125,7 +137,7 @@ __global__ void __launch_bounds__(256) nndsvd_stats_kernel(InitArgs a) {
     }
   }
   __syncthreads();
-  if (threadIdx.x < k) {
+  if ((int)threadIdx.x < k) {
     const int j = threadIdx.x;
     double p = 0.0, n = 0.0, pv = 0.0;
     for (int w = 0; w < 4; ++w) {
@@ -133,7 +145,7 @@ __global__ void __launch_bounds__(256) nndsvd_stats_kernel(InitArgs a) {
       n += red[w][j][1];
       if (fabs(red[w][j][2]) > fabs(pv)) pv = red[w][j][2];
     }
-    double* o = a.stats + ((long long)b * k + j) * 4;
+    double* o = a.stats + ((long long)b * a.k + j0 + j) * 4;
     o[0] = p;
     o[1] = n;
     o[2] = pv;
@@ -143,17 +155,19 @@ __global__ void __launch_bounds__(256) nndsvd_stats_kernel(InitArgs a) {
 
 template <typename real>
 __global__ void __launch_bounds__(256) nndsvd_write_kernel(InitArgs a) {
-  constexpr int KMAX = 8;
-  __shared__ double Vs[KMAX][GRAM_MAXM];
+  constexpr int KMAX = NNDSVD_KB;
+  extern __shared__ __attribute__((aligned(16))) unsigned char init_smem[];
+  double* Vs = reinterpret_cast<double*>(init_smem);
   __shared__ double is[KMAX], cf[KMAX][2];
-  const int b = blockIdx.x, m = a.m, k = a.k;
+  const int b = blockIdx.x, m = a.m, j0 = (int)blockIdx.y * KMAX;
+  const int k = a.k - j0 < KMAX ? a.k - j0 : KMAX;
   const real* __restrict__ Xb = static_cast<const real*>(a.X) + (long long)b * a.bstride;
-  real* __restrict__ Wb = static_cast<real*>(a.W0) + (long long)b * a.T * k;
-  for (int i = threadIdx.x; i < k * m; i += blockDim.x) Vs[i / m][i % m] = a.V[(long long)b * k * m + i];
-  if (threadIdx.x < k) {
-    is[threadIdx.x] = a.inv_s[(long long)b * k + threadIdx.x];
-    cf[threadIdx.x][0] = a.coef[((long long)b * k + threadIdx.x) * 2];
-    cf[threadIdx.x][1] = a.coef[((long long)b * k + threadIdx.x) * 2 + 1];
+  real* __restrict__ Wb = static_cast<real*>(a.W0) + (long long)b * a.T * a.k;
+  for (int i = threadIdx.x; i < k * m; i += blockDim.x) Vs[i] = a.V[((long long)b * a.k + j0) * m + i];
+  if ((int)threadIdx.x < k) {
+    is[threadIdx.x] = a.inv_s[(long long)b * a.k + j0 + threadIdx.x];
+    cf[threadIdx.x][0] = a.coef[((long long)b * a.k + j0 + threadIdx.x) * 2];
+    cf[threadIdx.x][1] = a.coef[((long long)b * a.k + j0 + threadIdx.x) * 2 + 1];
   }
   __syncthreads();
   const double fill = a.fill[b];
@@ -167,7 +181,7 @@ __global__ void __launch_bounds__(256) nndsvd_write_kernel(InitArgs a) {
         real w = (real)(cf[j][0] * part);
         if ((double)w < a.eps) w = (real)0;      // W[W < eps] = 0            (_nmf.py:355)
         if (w == (real)0) w = (real)fill;        // nndsvda: zeros -> X.mean() (_nmf.py:360-362); fill = 0 for nndsvd
-        Wb[(long long)t * k + j] = w;
+        Wb[(long long)t * a.k + j0 + j] = w;
       }
   }
 }
@@ -210,7 +224,7 @@ struct RandomInitArgs {
   const int* index;      // [B] or nullptr: matrix b of this (compacted) batch is matrix index[b] of the original one
 };
 
-// colsum[b][j] = sum_t X[t][j] for any number of channels (the Gram kernel above stops at GRAM_MAXM): one workgroup per
+// colsum[b][j] = sum_t X[t][j] for any number of channels (without the m x m products of the Gram kernel above): one workgroup per
 // matrix, channel-major X, fp64 sums in a fixed order
 template <typename real>
 __global__ void __launch_bounds__(256) colsum_kernel(InitArgs a) {

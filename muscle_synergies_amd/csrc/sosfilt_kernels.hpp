@@ -70,6 +70,51 @@ __device__ __forceinline__ double lane_bcast(double v, int r) {
   return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 
+// mean of one series in fp64 with a FIXED order of the sums (256 threads; the value every thread returns is bit-identical whichever
+// kernel calls this: the sequential and the time-parallel filter centre with the same number).  scratch: 4 doubles of LDS.
+template <typename real>
+__device__ __forceinline__ double series_mean(const real* __restrict__ xr, int T, double* scratch) {
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  constexpr int V = 16 / (int)sizeof(real);        // samples per 16-byte load
+  int i;
+  if ((reinterpret_cast<unsigned long long>(xr) & 15ull) == 0) {  // 16-byte loads, two in flight per thread
+    struct alignas(16) Vec { real v[V]; };
+    const Vec* __restrict__ xv = reinterpret_cast<const Vec*>(xr);
+    const int nv = T / V;
+    int q = threadIdx.x;
+    for (; q + 256 < nv; q += 512) {
+      const Vec a0 = xv[q], a1 = xv[q + 256];
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        s0 += (double)a0.v[e];
+        s1 += (double)a1.v[e];
+      }
+    }
+    for (; q < nv; q += 256) {
+      const Vec a0 = xv[q];
+#pragma unroll
+      for (int e = 0; e < V; ++e) s2 += (double)a0.v[e];
+    }
+    i = nv * V + threadIdx.x;
+  } else {
+    i = threadIdx.x;
+    for (; i + 768 < T; i += 1024) {
+      const real a0 = xr[i], a1 = xr[i + 256], a2 = xr[i + 512], a3 = xr[i + 768];
+      s0 += (double)a0;
+      s1 += (double)a1;
+      s2 += (double)a2;
+      s3 += (double)a3;
+    }
+  }
+  for (; i < T; i += 256) s3 += (double)xr[i];
+  double acc = (s0 + s1) + (s2 + s3);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  return (scratch[0] + scratch[1] + scratch[2] + scratch[3]) / (double)T;
+}
+
 // per-series statistics: stat[s] = {mean (0 unless zero_center), first, last pre-processed sample}
 template <typename real>
 __global__ void __launch_bounds__(256) sos_stats_kernel(SosArgs a, double* __restrict__ stat) {
@@ -78,47 +123,7 @@ __global__ void __launch_bounds__(256) sos_stats_kernel(SosArgs a, double* __res
   const real* __restrict__ xr =
       static_cast<const real*>(a.x) + (long long)(s / a.m) * a.bstride + (long long)(s % a.m) * a.ld;
   double mean = 0.0;
-  if (a.zero_center) {
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;  // fixed order of the sums (deterministic)
-    constexpr int V = 16 / (int)sizeof(real);        // samples per 16-byte load
-    int i;
-    if ((reinterpret_cast<unsigned long long>(xr) & 15ull) == 0) {  // 16-byte loads, two in flight per thread
-      struct alignas(16) Vec { real v[V]; };
-      const Vec* __restrict__ xv = reinterpret_cast<const Vec*>(xr);
-      const int nv = a.T / V;
-      int q = threadIdx.x;
-      for (; q + 256 < nv; q += 512) {
-        const Vec a0 = xv[q], a1 = xv[q + 256];
-#pragma unroll
-        for (int e = 0; e < V; ++e) {
-          s0 += (double)a0.v[e];
-          s1 += (double)a1.v[e];
-        }
-      }
-      for (; q < nv; q += 256) {
-        const Vec a0 = xv[q];
-#pragma unroll
-        for (int e = 0; e < V; ++e) s2 += (double)a0.v[e];
-      }
-      i = nv * V + threadIdx.x;
-    } else {
-      i = threadIdx.x;
-      for (; i + 768 < a.T; i += 1024) {
-        const real a0 = xr[i], a1 = xr[i + 256], a2 = xr[i + 512], a3 = xr[i + 768];
-        s0 += (double)a0;
-        s1 += (double)a1;
-        s2 += (double)a2;
-        s3 += (double)a3;
-      }
-    }
-    for (; i < a.T; i += 256) s3 += (double)xr[i];
-    double acc = (s0 + s1) + (s2 + s3);
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
-    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    mean = (scratch[0] + scratch[1] + scratch[2] + scratch[3]) / (double)a.T;
-  }
+  if (a.zero_center) mean = series_mean<real>(xr, a.T, scratch);
   if (threadIdx.x == 0) {
     const real mr = (real)mean;
     stat[3LL * s + 0] = (double)mr;

@@ -1,0 +1,474 @@
+// sosfilt_scan.hpp -- the time-parallel mode of the IIR filter stage (hipnmf_sosfilt_params.mode = HIPNMF_SOSFILT_SCAN).
+//
+// Same stage of the reference as sosfilt_kernels.hpp (digital_filter / linear_envelope, src/muscle_synergies/analysis.py:252-432 ->
+// scipy.signal.sosfiltfilt / sosfilt), other trade: sosfilt2_kernel reproduces scipy's sequential recurrence bit for bit and is
+// bound by its 41 200-step dependent fp64 chain per series (0.16 of HBM, round 3); this kernel cuts every series into 256 chunks,
+// one per thread of a workgroup, and runs them at once.  A cascade of second-order sections is a linear system
+//     s[n] = A s[n-1] + B x[n],   y[n] = c s[n-1] + d x[n]          (s: the 2 * n_sections direct-form-II-transposed states)
+// so for a chunk of C samples entered with state s0:  y = y0 + G s0  and  s_end = F + M s0, with y0 / F the chunk's response from
+// a ZERO state, G[n] (C x 2NS) the output's response to a unit state and M = A^C.  Per direction:
+//   1. every thread filters its chunk from a zero state (registers; the only dependent chain left is C = 79 samples long);
+//   2. the chunk-end states are combined by a scan over the 256 threads with the constant matrices M^(2^j): Kogge-Stone inside a
+//      wave (shuffles), the four waves' totals through LDS (scan_states);
+//   3. y += G s_start, 2NS independent FMAs per sample with G read through the scalar cache.
+// The whole (odd-extended) series lives in registers between the forward and the backward pass: HBM sees the samples once in and
+// once out.  sosfiltfilt's backward pass starts at the last extended sample with the state zi * y[L-1]; the chunks are aligned to
+// the front, so the tail of the last chunk is padded with that very constant and the backward recursion starts at the padded end
+// in the filter's steady state for it -- which it then keeps (zi is by definition the fixed point of a constant input).
+// Requirements (the host checks them and otherwise runs the sequential kernel): every series and its output 16-byte aligned with
+// n_samples a multiple of 4 (fp32) / 2 (fp64) -- all staging traffic is 16-byte vectors -- and at most 20 480 extended samples.
+// All arithmetic is fp64 with fused multiply-adds; the result agrees with scipy to rounding (1e-12 relative for the reference's
+// 6 Hz low-pass at 2 kHz; the conditioning of the filter sets the constant), not bit for bit: tests/test_filters.py, <= 1e-10.
+#pragma once
+#include "sosfilt_kernels.hpp"
+
+namespace hipnmf {
+
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_CMAX = 80;  // samples per thread of the large instance: series of up to 256 * 80 = 20 480 extended samples
+constexpr int SCAN_G_CAP = 128 * 2 * SOS_MAX_SECTIONS;            // doubles reserved for G in the table buffer
+constexpr int SCAN_TAB_DOUBLES = SCAN_G_CAP + 8 * 4 * SOS_MAX_SECTIONS * SOS_MAX_SECTIONS;  // + M^(2^j), j = 0..7
+constexpr int SCAN_STAGE_BYTES = 48 * 1024;
+constexpr int SCAN_LOADS = 12;  // 16-byte loads in flight per thread while staging (a 48 KiB piece in one round)
+
+// section coefficients {b0, b1, b2, a1, a2}; sections beyond `ns` pass their input through
+template <int NSP>
+__device__ __forceinline__ void scan_coeffs(const SosArgs& a, int ns, double (&c)[NSP][5]) {
+#pragma unroll
+  for (int s = 0; s < NSP; ++s) {
+    const bool on = s < ns;
+    c[s][0] = on ? a.sos[s][0] : 1.0;
+    c[s][1] = on ? a.sos[s][1] : 0.0;
+    c[s][2] = on ? a.sos[s][2] : 0.0;
+    c[s][3] = on ? a.sos[s][4] : 0.0;
+    c[s][4] = on ? a.sos[s][5] : 0.0;
+  }
+}
+
+// one sample through the cascade (fused multiply-adds; two dependent operations per section on the state's critical path)
+template <int NSP>
+__device__ __forceinline__ double scan_step(double xc, double (&z)[NSP][2], const double (&c)[NSP][5]) {
+#pragma unroll
+  for (int s = 0; s < NSP; ++s) {
+    const double u = __builtin_fma(c[s][1], xc, z[s][1]);  // off the critical path: does not wait for xn
+    const double xn = __builtin_fma(c[s][0], xc, z[s][0]);
+    z[s][0] = __builtin_fma(-c[s][3], xn, u);
+    z[s][1] = __builtin_fma(c[s][2], xc, -c[s][4] * xn);
+    xc = xn;
+  }
+  return xc;
+}
+
+// G[n][j] (n < C_run): output n steps after a unit state j, no input; M = A^C_run and its squarings M^2 .. M^128.
+// tab: [SCAN_G_CAP] G row-major [n][NST], then [8][NST][NST].  One workgroup of 256 threads.
+template <int NSP>
+__global__ void __launch_bounds__(256) sos_scan_tables_kernel(SosArgs a, int ns, int C_run, double* __restrict__ tab) {
+  constexpr int NST = 2 * NSP;
+  __shared__ double Ma[NST * NST], Mb[NST * NST];
+  const int j = threadIdx.x;
+  double c[NSP][5];
+  scan_coeffs<NSP>(a, ns, c);
+  if (j < NST) {
+    double z[NSP][2];
+#pragma unroll
+    for (int s = 0; s < NSP; ++s) {
+      z[s][0] = (j == 2 * s) ? 1.0 : 0.0;
+      z[s][1] = (j == 2 * s + 1) ? 1.0 : 0.0;
+    }
+    for (int n = 0; n < C_run; ++n) tab[n * NST + j] = scan_step<NSP>(0.0, z, c);
+#pragma unroll
+    for (int s = 0; s < NSP; ++s) {
+      Ma[(2 * s) * NST + j] = z[s][0];
+      Ma[(2 * s + 1) * NST + j] = z[s][1];
+    }
+  }
+  __syncthreads();
+  double* Mp = tab + SCAN_G_CAP;
+  for (int p = 0; p < 8; ++p) {
+    if (j < NST * NST) Mp[p * NST * NST + j] = Ma[j];
+    if (j < NST * NST) {
+      const int r = j / NST, q = j % NST;
+      double acc = 0.0;
+      for (int k = 0; k < NST; ++k) acc = __builtin_fma(Ma[r * NST + k], Ma[k * NST + q], acc);
+      Mb[j] = acc;
+    }
+    __syncthreads();
+    if (j < NST * NST) Ma[j] = Mb[j];
+    __syncthreads();
+  }
+}
+
+// E += Mat * o  (Mat: NST x NST row-major, uniform -> scalar loads)
+template <int NST>
+__device__ __forceinline__ void scan_matvec_acc(const double* __restrict__ Mat, const double (&o)[NST], double (&E)[NST]) {
+#pragma unroll
+  for (int i = 0; i < NST; ++i) {
+    double acc = E[i];
+#pragma unroll
+    for (int k = 0; k < NST; ++k) acc = __builtin_fma(Mat[i * NST + k], o[k], acc);
+    E[i] = acc;
+  }
+}
+
+// P = Mat * o  (Mat uniform)
+template <int NST>
+__device__ __forceinline__ void scan_matvec(const double* __restrict__ Mat, const double (&o)[NST], double (&P)[NST]) {
+#pragma unroll
+  for (int i = 0; i < NST; ++i) {
+    double acc = Mat[i * NST] * o[0];
+#pragma unroll
+    for (int k = 1; k < NST; ++k) acc = __builtin_fma(Mat[i * NST + k], o[k], acc);
+    P[i] = acc;
+  }
+}
+
+// Chunk-end states F of the 256 chunks -> the state every chunk is ENTERED with.  Logical chunk order q = t (forward) or 255 - t
+// (backward); chunk 0 is entered with s_init.  Three phases: (A) inclusive Kogge-Stone scan INSIDE each wave (64 chunks,
+// shuffles, constant matrices M^(2^j)); (B) the state each wave is entered with from the waves' totals (Horner with M^64, at most
+// three wave-uniform products); (C) lane l of a wave adds M^(l+1) times that state, the power built from the binary digits of
+// l + 1.  xch: LDS [256][NST].
+template <int NST>
+__device__ __forceinline__ void scan_states(double (&E)[NST], const double (&s_init)[NST], bool reverse, const double* __restrict__ Mp,
+                                            double* __restrict__ xch, double (&s_start)[NST]) {
+  const int t = threadIdx.x, lane = t & 63;
+  const int q = reverse ? SCAN_THREADS - 1 - t : t;
+  const int lq = q & 63, wq = q >> 6;
+  if (q == 0) scan_matvec_acc<NST>(Mp, s_init, E);  // E_0 = F_0 + M s_init
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {  // (A)
+    const int d = 1 << j;
+    const int src = reverse ? lane + d : lane - d;
+    double o[NST];
+#pragma unroll
+    for (int i = 0; i < NST; ++i) o[i] = __shfl(E[i], src & 63, 64);
+    if (lq >= d) scan_matvec_acc<NST>(Mp + j * NST * NST, o, E);
+  }
+  __syncthreads();
+  if (lq == 63) {
+#pragma unroll
+    for (int i = 0; i < NST; ++i) xch[wq * NST + i] = E[i];  // total of logical wave wq
+  }
+  __syncthreads();
+  if (wq > 0) {  // (B) + (C); wave-uniform
+    double K[NST];
+#pragma unroll
+    for (int i = 0; i < NST; ++i) K[i] = xch[i];
+    for (int u = 1; u < wq; ++u) {  // K <- W_u + M^64 K
+      double Wu[NST];
+#pragma unroll
+      for (int i = 0; i < NST; ++i) Wu[i] = xch[u * NST + i];
+      scan_matvec_acc<NST>(Mp + 6 * NST * NST, K, Wu);
+#pragma unroll
+      for (int i = 0; i < NST; ++i) K[i] = Wu[i];
+    }
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {  // K <- M^(lq + 1) K, digit by digit
+      double P[NST];
+      scan_matvec<NST>(Mp + j * NST * NST, K, P);
+      const bool on = ((lq + 1) >> j) & 1;
+#pragma unroll
+      for (int i = 0; i < NST; ++i) K[i] = on ? P[i] : K[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NST; ++i) E[i] += K[i];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NST; ++i) xch[q * NST + i] = E[i];
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NST; ++i) s_start[i] = q > 0 ? xch[(q - 1) * NST + i] : s_init[i];
+}
+
+// mean of one series in fp64, fixed order of the sums, sixteen 16-byte loads in flight per thread (series_mean of the sequential
+// kernels keeps two: its order is pinned by the bit-exact mode).  scratch: 4 doubles of LDS.
+template <typename real>
+__device__ __forceinline__ double scan_mean(const real* __restrict__ xr, int T, double* scratch) {
+  constexpr int V = 16 / (int)sizeof(real);
+  constexpr int NV = 16;  // 16-byte loads in flight per thread
+  double acc[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) acc[u] = 0.0;
+  int i;
+  if ((reinterpret_cast<unsigned long long>(xr) & 15ull) == 0) {
+    struct alignas(16) Vec { real v[V]; };
+    const Vec* __restrict__ xv = reinterpret_cast<const Vec*>(xr);
+    const int nv = T / V;
+    int q = threadIdx.x;
+    for (; q + (NV - 1) * SCAN_THREADS < nv; q += NV * SCAN_THREADS) {
+      Vec b[NV];
+#pragma unroll
+      for (int u = 0; u < NV; ++u) b[u] = xv[q + u * SCAN_THREADS];
+#pragma unroll
+      for (int u = 0; u < NV; ++u)
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[u & 7] += (double)b[u].v[e];
+    }
+    for (; q + 3 * SCAN_THREADS < nv; q += 4 * SCAN_THREADS) {
+      Vec b[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) b[u] = xv[q + u * SCAN_THREADS];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[u] += (double)b[u].v[e];
+    }
+    for (; q < nv; q += SCAN_THREADS) {
+      const Vec b0 = xv[q];
+#pragma unroll
+      for (int e = 0; e < V; ++e) acc[0] += (double)b0.v[e];
+    }
+    i = nv * V + threadIdx.x;
+  } else {
+    i = threadIdx.x;
+    for (; i + 7 * SCAN_THREADS < T; i += 8 * SCAN_THREADS) {
+      real b[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) b[u] = xr[i + u * SCAN_THREADS];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc[u] += (double)b[u];
+    }
+  }
+  for (; i < T; i += SCAN_THREADS) acc[1] += (double)xr[i];
+  double sum = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
+  if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = sum;
+  __syncthreads();
+  return ((scratch[0] + scratch[1]) + (scratch[2] + scratch[3])) / (double)T;
+}
+
+// One workgroup per series; thread t owns the extended samples [t * C_run, (t + 1) * C_run) in registers (C_run <= CMAX).
+// C_run is a multiple of 4 (the loops walk groups of four samples).  Dynamic LDS: the staging buffer (SCAN_STAGE_BYTES, coalesced
+// HBM <-> per-thread chunks) + [256][NST] + 8 + CMAX * NST doubles.
+template <typename real, int NSP, int CMAX>
+__global__ void __launch_bounds__(SCAN_THREADS, (CMAX > 32 ? (NSP > 4 ? 1 : 2) : (NSP > 4 ? 2 : 4)))
+sosfilt_scan_kernel(SosArgs a, const double* __restrict__ tab, int ns, int C_run) {
+  constexpr int NST = 2 * NSP;
+  extern __shared__ __attribute__((aligned(16))) unsigned char scan_smem[];
+  real* __restrict__ stage = reinterpret_cast<real*>(scan_smem);
+  double* __restrict__ xch = reinterpret_cast<double*>(scan_smem + SCAN_STAGE_BYTES);
+  double* __restrict__ misc = xch + SCAN_THREADS * NST;  // 8 doubles: mean scratch [0..3], broadcast value [4]
+  double* __restrict__ Gl = misc + 8;                    // G [C_run][NST]: read by every thread at the same address (LDS broadcast)
+  const int t = threadIdx.x;
+  const int series = blockIdx.x;
+  constexpr int V = 16 / (int)sizeof(real);  // samples per 16-byte vector
+  struct alignas(16) Vec {
+    real v[V];
+  };
+  // Positions p = delta + extended index: `delta` copies of the first extended sample in front make p and the raw index p - EO
+  // (EO = edge + delta) congruent modulo V, so 16-byte vectors of x, of the staging rows and of y line up.  (The recursion then
+  // starts `delta` samples early, in the steady state of that constant: the same argument as for the tail, see the header.)
+  const int T = a.T, edge = a.edge;
+  const int delta = (V - edge % V) % V, EO = edge + delta, L = T + 2 * edge + delta;
+  const real* __restrict__ xr =
+      static_cast<const real*>(a.x) + (long long)(series / a.m) * a.bstride + (long long)(series % a.m) * a.ld;
+  real* __restrict__ yr = static_cast<real*>(a.y) + (long long)series * T;
+  const double* __restrict__ G = tab;
+  const double* __restrict__ Mp = tab + SCAN_G_CAP;
+
+  double c[NSP][5];
+  scan_coeffs<NSP>(a, ns, c);
+  for (int i = t; i < C_run * NST; i += SCAN_THREADS) Gl[i] = G[i];  // (the first __syncthreads below orders it)
+
+  real mean = (real)0;
+  if (a.zero_center) mean = (real)scan_mean<real>(xr, T, misc);  // a first pass over the series; the second one hits the caches
+  const real first = sos_pre<real>(xr[0], mean, a.rectify), last = sos_pre<real>(xr[T - 1], mean, a.rectify);
+  // value at position p outside the recording: the odd extension about the end samples (in the samples' precision, as scipy
+  // builds it), its first value repeated in front, zeros past the end
+  auto outside = [&](int p) -> real {
+    int i = p - delta;
+    i = i < 0 ? 0 : i;
+    if (i >= T + 2 * edge) return (real)0;
+    const int j = i - edge;
+    const int jr = j < 0 ? -j : 2 * (T - 1) - j;
+    return (real)2 * (j < 0 ? first : last) - sos_pre<real>(xr[jr], mean, a.rectify);
+  };
+
+  // ---- HBM -> staging rows -> registers in 16-byte vectors, SCAN_LOADS of them in flight per thread; centring and rectification
+  // on the way in.  Row t = the chunk of thread t, SR samples apart with SR * sizeof / 16 odd: the 16-byte chunk reads of the 16
+  // lanes LDS serves at a time fall on distinct banks.  RP rows per piece.
+  const int CV = C_run / V;                                // vectors per row (C_run is a multiple of 4)
+  const int SR = C_run + ((CV & 1) ? 0 : V);
+  const int RP = min(SCAN_THREADS, (int)(SCAN_STAGE_BYTES / (SR * (int)sizeof(real))));
+  const unsigned inv = 0xFFFFFFFFu / (unsigned)CV + 1u;    // w / CV == umulhi(w, inv) for the w that occur (w < 2^15)
+  double v[CMAX];
+#pragma unroll
+  for (int n = 0; n < CMAX; ++n) v[n] = 0.0;
+  for (int r0 = 0; r0 < SCAN_THREADS; r0 += RP) {
+    const int rows = min(RP, SCAN_THREADS - r0);
+    const int NW = rows * CV;  // vectors of this piece
+    __syncthreads();
+    for (int w0 = t; w0 < NW; w0 += SCAN_LOADS * SCAN_THREADS) {
+      Vec raw[SCAN_LOADS];
+#pragma unroll
+      for (int u = 0; u < SCAN_LOADS; ++u) {  // all loads of the round go out before any of them is used
+        const int w = w0 + u * SCAN_THREADS;
+        const int row = CV == 1 ? w : (int)__umulhi((unsigned)w, inv);
+        int j = (r0 + row) * C_run + (w - row * CV) * V - EO;
+        j = (w < NW && j >= 0 && j < T) ? j : 0;  // outside the recording: any valid vector, replaced below
+        raw[u] = *reinterpret_cast<const Vec*>(xr + j);
+      }
+#pragma unroll
+      for (int u = 0; u < SCAN_LOADS; ++u) {
+        const int w = w0 + u * SCAN_THREADS;
+        if (w < NW) {
+          const int row = CV == 1 ? w : (int)__umulhi((unsigned)w, inv);
+          const int col = (w - row * CV) * V, p = (r0 + row) * C_run + col, j = p - EO;
+          Vec o;
+          if (j >= 0 && j < T) {  // (T is a multiple of V: a vector is inside the recording or outside, never astride)
+#pragma unroll
+            for (int q = 0; q < V; ++q) o.v[q] = sos_pre<real>(raw[u].v[q], mean, a.rectify);
+          } else {
+#pragma unroll
+            for (int q = 0; q < V; ++q) o.v[q] = outside(p + q);
+          }
+          *reinterpret_cast<Vec*>(stage + row * SR + col) = o;
+        }
+      }
+    }
+    __syncthreads();
+    if (t >= r0 && t < r0 + rows) {
+      const Vec* __restrict__ myrow = reinterpret_cast<const Vec*>(stage + (t - r0) * SR);
+#pragma unroll
+      for (int n0 = 0; n0 < CMAX; n0 += 4)
+        if (n0 < C_run) {
+#pragma unroll
+          for (int g = 0; g < 4 / V; ++g) {
+            const Vec x = myrow[n0 / V + g];
+#pragma unroll
+            for (int q = 0; q < V; ++q) v[n0 + g * V + q] = (double)x.v[q];
+          }
+        }
+    }
+  }
+
+  // ---- forward: zero-state response, scan, correction --------------------------------------------------------------------
+  double s_init[NST], s_start[NST], E[NST];
+  if (a.zero_lag) {  // zi * ext[0] (sosfiltfilt)
+    __syncthreads();
+    if (t == 0) misc[4] = v[0];
+    __syncthreads();
+    const double x0 = misc[4];
+#pragma unroll
+    for (int s = 0; s < NSP; ++s) {
+      s_init[2 * s] = s < ns ? a.zi[s][0] * x0 : 0.0;
+      s_init[2 * s + 1] = s < ns ? a.zi[s][1] * x0 : 0.0;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < NST; ++i) s_init[i] = 0.0;
+  }
+  {
+    double z[NSP][2];
+#pragma unroll
+    for (int s = 0; s < NSP; ++s) z[s][0] = z[s][1] = 0.0;
+#pragma unroll
+    for (int n0 = 0; n0 < CMAX; n0 += 4)
+      if (n0 < C_run) {
+#pragma unroll
+        for (int n = n0; n < n0 + 4; ++n) v[n] = scan_step<NSP>(v[n], z, c);
+      }
+#pragma unroll
+    for (int s = 0; s < NSP; ++s) {
+      E[2 * s] = z[s][0];
+      E[2 * s + 1] = z[s][1];
+    }
+  }
+  scan_states<NST>(E, s_init, false, Mp, xch, s_start);
+#pragma unroll
+  for (int n0 = 0; n0 < CMAX; n0 += 4)
+    if (n0 < C_run) {
+#pragma unroll
+      for (int n = n0; n < n0 + 4; ++n) {
+        double acc = v[n];
+#pragma unroll
+        for (int i = 0; i < NST; ++i) acc = __builtin_fma(Gl[n * NST + i], s_start[i], acc);
+        v[n] = acc;
+      }
+    }
+
+  if (a.zero_lag) {
+    // ---- backward over the forward output: start state zi * y[L-1]; the tail of the last chunk holds that constant ---------
+    const int tL = (L - 1) / C_run, nL = (L - 1) - tL * C_run;  // (wave-uniform: one scalar division)
+    __syncthreads();
+    if (t == tL) {  // the owner's chunk through LDS: a register array cannot be indexed with a run-time value
+      double* __restrict__ row = reinterpret_cast<double*>(stage);
+#pragma unroll
+      for (int n0 = 0; n0 < CMAX; n0 += 4)
+        if (n0 < C_run) {
+#pragma unroll
+          for (int n = n0; n < n0 + 4; ++n) row[n] = v[n];
+        }
+    }
+    __syncthreads();
+    const double ylast = reinterpret_cast<const double*>(stage)[nL];
+    if ((t + 1) * C_run > L) {
+#pragma unroll
+      for (int n = 0; n < CMAX; ++n) v[n] = (t * C_run + n >= L) ? ylast : v[n];  // (registers beyond C_run are never read)
+    }
+#pragma unroll
+    for (int s = 0; s < NSP; ++s) {
+      s_init[2 * s] = s < ns ? a.zi[s][0] * ylast : 0.0;
+      s_init[2 * s + 1] = s < ns ? a.zi[s][1] * ylast : 0.0;
+    }
+    {
+      double z[NSP][2];
+#pragma unroll
+      for (int s = 0; s < NSP; ++s) z[s][0] = z[s][1] = 0.0;
+#pragma unroll
+      for (int n0 = CMAX - 4; n0 >= 0; n0 -= 4)
+        if (n0 < C_run) {
+#pragma unroll
+          for (int n = n0 + 3; n >= n0; --n) v[n] = scan_step<NSP>(v[n], z, c);
+        }
+#pragma unroll
+      for (int s = 0; s < NSP; ++s) {
+        E[2 * s] = z[s][0];
+        E[2 * s + 1] = z[s][1];
+      }
+    }
+    scan_states<NST>(E, s_init, true, Mp, xch, s_start);
+    const double* __restrict__ Gr = Gl + (C_run - 1) * NST;  // sample n of a chunk is step C_run - 1 - n of the reversed walk
+#pragma unroll
+    for (int n0 = 0; n0 < CMAX; n0 += 4)
+      if (n0 < C_run) {
+#pragma unroll
+        for (int n = n0; n < n0 + 4; ++n) {
+          double acc = v[n];
+#pragma unroll
+          for (int i = 0; i < NST; ++i) acc = __builtin_fma(Gr[i - n * NST], s_start[i], acc);
+          v[n] = acc;
+        }
+      }
+  }
+
+  // ---- registers -> staging rows -> HBM (the T samples of the recording), 16-byte vectors ---------------------------------
+  for (int r0 = 0; r0 < SCAN_THREADS; r0 += RP) {
+    const int rows = min(RP, SCAN_THREADS - r0);
+    const int NW = rows * CV;
+    __syncthreads();
+    if (t >= r0 && t < r0 + rows) {
+      Vec* __restrict__ myrow = reinterpret_cast<Vec*>(stage + (t - r0) * SR);
+#pragma unroll
+      for (int n0 = 0; n0 < CMAX; n0 += 4)
+        if (n0 < C_run) {
+#pragma unroll
+          for (int g = 0; g < 4 / V; ++g) {
+            Vec x;
+#pragma unroll
+            for (int q = 0; q < V; ++q) x.v[q] = (real)v[n0 + g * V + q];
+            myrow[n0 / V + g] = x;
+          }
+        }
+    }
+    __syncthreads();
+    for (int w = t; w < NW; w += SCAN_THREADS) {
+      const int row = CV == 1 ? w : (int)__umulhi((unsigned)w, inv);
+      const int col = (w - row * CV) * V, j = (r0 + row) * C_run + col - EO;
+      if (j >= 0 && j < T) *reinterpret_cast<Vec*>(yr + j) = *reinterpret_cast<const Vec*>(stage + row * SR + col);
+    }
+  }
+}
+
+}  // namespace hipnmf

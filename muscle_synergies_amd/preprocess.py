@@ -68,7 +68,7 @@ class SosfiltParams(ctypes.Structure):
         ("padlen", ctypes.c_int32),
         ("zero_center", ctypes.c_int32),
         ("rectify", ctypes.c_int32),
-        ("reserved0", ctypes.c_int32),
+        ("mode", ctypes.c_int32),
     ]
 
 
@@ -202,14 +202,21 @@ def design_sos(filter_type: str, order: int, sampling_frequency, critical_freqs,
     return coeff_func(order, cheby_param, critical_freqs, btype=band_type, output="sos", fs=sampling_frequency)
 
 
+SOSFILT_MODES = {"exact": 0, "scan": 1}  # HIPNMF_SOSFILT_EXACT / HIPNMF_SOSFILT_SCAN (include/hip_nmf.h)
+
+
 def sosfilt_batched(x, sos, *, zero_lag: bool = True, zero_center: bool = False, rectify: bool = False,
-                    padlen: Optional[int] = None, device=None):
+                    padlen: Optional[int] = None, device=None, mode: str = "exact"):
     """``scipy.signal.sosfiltfilt(sos, x, axis=time)`` (``zero_lag``) or ``sosfilt`` for a batch of recordings.
 
     Args:
         x: ``[B, T, m]`` (or ``[T, m]``) float32/float64, NumPy or torch, any dense layout.
         sos: ``(n_sections, 6)`` second-order sections (``scipy.signal`` layout), at most 8 sections.
         zero_center, rectify: the two steps ``linear_envelope`` applies before its low-pass filter.
+        mode: ``"exact"`` -- scipy's sequential recurrence, bit-identical in float64 (what the reference-facing
+            ``digital_filter`` / ``linear_envelope`` use); ``"scan"`` -- the time-parallel kernel (every series cut into 256
+            chunks filtered at once; agrees with scipy to rounding, about 1e-12 relative for the reference's 6 Hz low-pass,
+            and runs about four times faster on a batch).
     Returns:
         tensor ``[B, T, m]`` on the device (transposed view of channel-major storage), dtype of ``x``; the
         arithmetic is fp64 either way.
@@ -242,7 +249,7 @@ def sosfilt_batched(x, sos, *, zero_lag: bool = True, zero_center: bool = False,
         zi = np.ascontiguousarray(signal.sosfilt_zi(sos), dtype=np.float64)
     layout, ldx, xbs, Xt = _x_layout(Xt)
     p = SosfiltParams(ctypes.sizeof(SosfiltParams), B, T, m, layout, ldx, xbs, sos.shape[0], int(bool(zero_lag)),
-                      -1 if padlen is None else int(padlen), int(bool(zero_center)), int(bool(rectify)), 0)
+                      -1 if padlen is None else int(padlen), int(bool(zero_center)), int(bool(rectify)), SOSFILT_MODES[mode])
     out = torch.empty((B, m, T), dtype=Xt.dtype, device=dev)
     h = _lib.get_handle(dev.index)
     lib = _lib.load()
@@ -281,12 +288,13 @@ def linear_envelope(signal_df: pandas.DataFrame, critical_freqs, sampling_freque
 
 def linear_envelope_batched(raw, critical_freqs, sampling_frequency, order: int = 4, *, filter_type: str = "butter",
                             zero_lag: bool = True, cheby_param: Optional[float] = None, zero_center: bool = True,
-                            reduce_to: Optional[int] = None, normalize: bool = True, device=None):
+                            reduce_to: Optional[int] = None, normalize: bool = True, device=None, mode: str = "scan"):
     """``linear_envelope -> time_normalize -> normalize`` for a batch of recordings ``[B, T, m]`` on one GPU
     (the filter-based alternative to :func:`emg_envelope_batched`).  Returns ``[B, T_out, m]`` on the device,
-    channel-major underneath, ready for ``fit_batched``."""
+    channel-major underneath, ready for ``fit_batched``.  ``mode``: see :func:`sosfilt_batched`; the batched producer of X defaults
+    to the time-parallel filter (the reference-facing single-frame functions keep scipy's bits)."""
     sos = design_sos(filter_type, order, sampling_frequency, critical_freqs, "lowpass", cheby_param)
-    env = sosfilt_batched(raw, sos, zero_lag=zero_lag, zero_center=zero_center, rectify=True, device=device)
+    env = sosfilt_batched(raw, sos, zero_lag=zero_lag, zero_center=zero_center, rectify=True, device=device, mode=mode)
     if reduce_to or normalize:
         env = emg_envelope_batched(env, 0, zero_center=False, reduce_to=reduce_to, normalize=normalize, device=device)
     return env

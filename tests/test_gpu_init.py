@@ -87,3 +87,62 @@ def test_rank_sweep_and_batched_synergies_with_device_nndsvda():
         ref = [ms.find_synergies(df, 3, solver="mu", max_iter=200, tol=0.0, random_state=0) for df in dfs]
     for g, r in zip(got, ref):  # same optimum up to sklearn's randomized-SVD error in the starting point
         np.testing.assert_allclose(g.vaf_values.to_numpy(), r.vaf_values.to_numpy(), atol=1e-4)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("T,m,k", [(1500, 64, 8), (900, 40, 12), (1200, 128, 16), (700, 100, 24), (300, 33, 9)])
+def test_device_nndsvd_wide_shapes_match_the_host_algorithm(dtype, T, m, k):
+    """Round 4: the Gram / projection kernels take any number of channels and components (blocks of 32 x 32 entries / 8
+    components); the default init of find_synergies (_nmf.py:296-300) for 33..128 channels no longer runs a randomized SVD per
+    matrix on the host."""
+    from muscle_synergies_amd.init import initialize_nmf, nndsvd_init_batched
+
+    Xs = np.stack([np.ascontiguousarray(emg_matrix(900 + b, T=T, m=m, k_true=min(k, 6), dtype=dtype)) for b in range(2)])
+    for init in ("nndsvd", "nndsvda"):
+        W0, H0 = nndsvd_init_batched(Xs, k, init=init)
+        W0, H0 = W0.cpu().numpy(), H0.cpu().numpy()
+        assert W0.dtype == dtype and W0.shape == (2, T, k) and H0.shape == (2, k, m)
+        assert (W0 >= 0).all() and (H0 >= 0).all() and np.isfinite(W0).all()
+        for b in range(2):
+            We, He = initialize_nmf(Xs[b], k, init=init, svd_solver="exact")
+            # the leading triplets (well separated) to the Gram route's accuracy; what matters downstream is the product
+            te = 1e-6 if dtype == np.float64 else 5e-3
+            scale = max(np.abs(We).max(), np.abs(He).max())
+            rel = np.linalg.norm(W0[b].astype(np.float64) @ H0[b] - We.astype(np.float64) @ He) / np.linalg.norm(We.astype(np.float64) @ He)
+            assert rel <= (1e-6 if dtype == np.float64 else 2e-3), (init, b, rel)
+            assert np.isclose(H0[b][:3], He[:3], rtol=te, atol=te * scale).all(), (init, b)
+
+
+def test_find_synergies_batched_on_wide_frames():
+    """analysis.py took the device-NNDSVD branch for equal-length trials without looking at the channel count and the init
+    kernels stopped at 32 channels (round 3: HipNmfError for 33..128 channels).  64 channels, ranks 6..9, equal and unequal lengths,
+    against per-trial find_synergies calls and -- for the device-made starting point -- the oracle."""
+    import warnings
+
+    import pandas as pd
+
+    import muscle_synergies_amd as ms
+    from muscle_synergies_amd.init import nndsvd_init_batched
+    from oracle import nmf_mu_oracle as orc
+
+    m = 64
+    cols = [f"ch{j}" for j in range(m)]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for lengths in ((800, 800, 800), (700, 950, 820)):
+            dfs = [pd.DataFrame(emg_matrix(40 + i, T=T, m=m, k_true=6, dtype=np.float64), columns=cols) for i, T in enumerate(lengths)]
+            got = ms.find_synergies_batched(dfs, 6, 9, max_iter=60, tol=0.0)
+            assert len(got) == 3
+            for df, res in zip(dfs, got):
+                assert sorted(res.components) == [6, 7, 8, 9] and res.components[9].shape == (9, m)
+                assert list(res.vaf_values.columns[:1]) == ["All signals"] and res.vaf_values.shape == (4, 1 + m)
+                assert np.isfinite(res.vaf_values.to_numpy()).all()
+                if len(set(lengths)) > 1:  # host initialisation per trial: the same numbers as the single-frame call
+                    one = ms.find_synergies(df, 6, 9, solver="mu", max_iter=60, tol=0.0)
+                    for r in (6, 9):
+                        np.testing.assert_allclose(res.components[r].to_numpy(), one.components[r].to_numpy(), rtol=1e-7, atol=1e-10)
+            if len(set(lengths)) == 1:  # device NNDSVDa: the fit from that starting point against the oracle
+                X = np.stack([df.to_numpy() for df in dfs])
+                W0, H0 = nndsvd_init_batched(X, 8, init="nndsvda")
+                ref = orc.nmf_mu_fit(X[1], W0[1].cpu().numpy(), H0[1].cpu().numpy(), max_iter=60, tol=0.0)
+                np.testing.assert_allclose(got[1].components[8].to_numpy(), ref["H"], rtol=1e-7, atol=1e-10)

@@ -384,7 +384,7 @@ def test_batch_larger_than_the_grid_y_limit():
 
 
 def test_ragged_entry_point_ignores_ldx_and_checks_reserved_fields():
-    """hip_nmf.h: ldx / x_batch_stride are ignored by hipnmf_fit_ragged_*; hipnmf_sosfilt_params.reserved0 must be 0."""
+    """hip_nmf.h: ldx / x_batch_stride are ignored by hipnmf_fit_ragged_*; hipnmf_sosfilt_params.mode must be a known mode (the field was the must-be-zero reserved0 before round 4)."""
     import ctypes
 
     import torch
@@ -420,11 +420,11 @@ def test_ragged_entry_point_ignores_ldx_and_checks_reserved_fields():
         W = Wp[wo[i]:wo[i] + k * lds[i]].view(k, lds[i])[:, :Ts[i]].t().cpu().numpy()
         np.testing.assert_allclose(W, ref["W"], rtol=1e-9, atol=1e-13)
         np.testing.assert_allclose(float(err[i]), ref["reconstruction_err"], rtol=1e-9)
-    sp = SosfiltParams(ctypes.sizeof(SosfiltParams), 1, 100, 4, 0, 4, 400, 1, 0, -1, 0, 0, 1)  # reserved0 = 1
+    sp = SosfiltParams(ctypes.sizeof(SosfiltParams), 1, 100, 4, 0, 4, 400, 1, 0, -1, 0, 0, 7)  # mode = 7: neither EXACT (0) nor SCAN (1)
     sos = (ctypes.c_double * 6)(1, 0, 0, 1, 0, 0)
     x = torch.zeros(400, dtype=torch.float32, device="cuda")
     rc = lib.hipnmf_sosfilt_f32(h.ptr, ctypes.byref(sp), sos, None, ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(x.data_ptr()))
-    assert rc == _lib.HIPNMF_ERR_BAD_ARG and b"reserved0" in lib.hipnmf_last_error()
+    assert rc == _lib.HIPNMF_ERR_BAD_ARG and b"mode" in lib.hipnmf_last_error()
 
 
 @pytest.mark.gpu

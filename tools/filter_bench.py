@@ -13,6 +13,7 @@ ap.add_argument("--T", type=int, default=20000)
 ap.add_argument("--m", type=int, default=16)
 ap.add_argument("--orders", type=int, nargs="*", default=[2, 4, 8])
 ap.add_argument("--dtypes", nargs="*", default=["float32", "float64"])
+ap.add_argument("--modes", nargs="*", default=["exact", "scan"])
 a = ap.parse_args()
 h = _lib.get_handle(0)
 for dtn in a.dtypes:
@@ -21,10 +22,11 @@ for dtn in a.dtypes:
     for order in a.orders:
         sos = design_sos("butter", order, 2000, 6)
         for zero_lag in (True, False):
-            for rep in range(3):
-                out = sosfilt_batched(raw, sos, zero_lag=zero_lag, zero_center=True, rectify=True)
-            ms = h.last_kernel_ms()
-            alg = 2 * raw.element_size() * a.batch * a.m * a.T
-            print(f"B={a.batch} T={a.T} m={a.m} {dtn} order={order} ({len(sos)} sections) zero_lag={zero_lag}: {ms:.3f} ms, "
-                  f"{a.batch*a.m*a.T/ms/1e6:.1f} G samples/s, {alg/ms/1e6:.0f} GB/s algorithmic", flush=True)
-            del out
+            for mode in a.modes:
+                for rep in range(3):
+                    out = sosfilt_batched(raw, sos, zero_lag=zero_lag, zero_center=True, rectify=True, mode=mode)
+                ms = h.last_kernel_ms()
+                alg = 2 * raw.element_size() * a.batch * a.m * a.T
+                print(f"B={a.batch} T={a.T} m={a.m} {dtn} order={order} ({len(sos)} sections) zero_lag={zero_lag} mode={mode}: {ms:.3f} ms, "
+                      f"{a.batch*a.m*a.T/ms/1e6:.1f} G samples/s, {alg/ms/1e6:.0f} GB/s algorithmic", flush=True)
+                del out
