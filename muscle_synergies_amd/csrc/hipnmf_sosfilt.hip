@@ -82,10 +82,11 @@ int launch_scan(hipnmf_handle* h, const SosArgs& a, int ns, int C_run, double* t
   auto go = [&](auto kern) -> int {
     if (smem > 48 * 1024)
       if (int rc = hipnmf_allow_full_lds(h, reinterpret_cast<const void*>(kern))) return rc;
-    hipLaunchKernelGGL(kern, dim3((unsigned)a.N), dim3(SCAN_THREADS), smem, st, a, (const double*)tab, ns, C_run);
+    hipLaunchKernelGGL(kern, dim3((unsigned)a.N), dim3(SCAN_THREADS), smem, st, a, (const double*)tab, ns);
     return HIPNMF_OK;
   };
-  return C_run <= 16 ? go(sosfilt_scan_kernel<real, NSP, 16>) : go(sosfilt_scan_kernel<real, NSP, SCAN_CMAX>);
+  return C_run == 16 ? go(sosfilt_scan_kernel<real, NSP, 16>) : C_run == 40 ? go(sosfilt_scan_kernel<real, NSP, 40>)
+                                                                             : go(sosfilt_scan_kernel<real, NSP, SCAN_CMAX>);
 }
 
 template <typename real>
@@ -156,7 +157,8 @@ int sosfilt_impl(hipnmf_handle* h, const hipnmf_sosfilt_params* p, const double*
   // groups of four), all staging traffic in 16-byte vectors: series and outputs 16-byte aligned, n_samples a multiple of the vector
   constexpr int VS = 16 / (int)sizeof(real);
   const int scan_delta = (VS - edge % VS) % VS;  // front padding that aligns the extended positions with the raw samples
-  const int scan_chunk = (int)round_up((L + scan_delta + SCAN_THREADS - 1) / SCAN_THREADS, 4);
+  const long long scan_need = (L + scan_delta + SCAN_THREADS - 1) / SCAN_THREADS;  // samples per thread; compiled: 16, 40, SCAN_CMAX
+  const int scan_chunk = scan_need <= 16 ? 16 : scan_need <= 40 ? 40 : scan_need <= SCAN_CMAX ? SCAN_CMAX : SCAN_CMAX + 1;
   const bool scan_aligned = (T % VS) == 0 && (reinterpret_cast<uintptr_t>(y) % 16) == 0 &&
                             (!inplace || ((reinterpret_cast<uintptr_t>(x) % 16) == 0 && (p->ldx % VS) == 0 && (p->x_batch_stride % VS) == 0));
   const bool scan_fits = p->mode == HIPNMF_SOSFILT_SCAN && scan_chunk <= SCAN_CMAX && scan_aligned;

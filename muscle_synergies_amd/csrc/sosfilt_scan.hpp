@@ -238,13 +238,13 @@ __device__ __forceinline__ double scan_mean(const real* __restrict__ xr, int T, 
   return ((scratch[0] + scratch[1]) + (scratch[2] + scratch[3])) / (double)T;
 }
 
-// One workgroup per series; thread t owns the extended samples [t * C_run, (t + 1) * C_run) in registers (C_run <= CMAX).
-// C_run is a multiple of 4 (the loops walk groups of four samples).  Dynamic LDS: the staging buffer (SCAN_STAGE_BYTES, coalesced
+// One workgroup per series; thread t owns the extended samples [t * CMAX, (t + 1) * CMAX) in registers (CMAX a multiple of 4).  Dynamic LDS: the staging buffer (SCAN_STAGE_BYTES, coalesced
 // HBM <-> per-thread chunks) + [256][NST] + 8 + CMAX * NST doubles.
 template <typename real, int NSP, int CMAX>
 __global__ void __launch_bounds__(SCAN_THREADS, (CMAX > 32 ? (NSP > 4 ? 1 : 2) : (NSP > 4 ? 2 : 4)))
-sosfilt_scan_kernel(SosArgs a, const double* __restrict__ tab, int ns, int C_run) {
+sosfilt_scan_kernel(SosArgs a, const double* __restrict__ tab, int ns) {
   constexpr int NST = 2 * NSP;
+  constexpr int C_run = CMAX;  // samples per thread: a compile-time constant (straight-line loops, no group branches)
   extern __shared__ __attribute__((aligned(16))) unsigned char scan_smem[];
   real* __restrict__ stage = reinterpret_cast<real*>(scan_smem);
   double* __restrict__ xch = reinterpret_cast<double*>(scan_smem + SCAN_STAGE_BYTES);
@@ -271,9 +271,15 @@ sosfilt_scan_kernel(SosArgs a, const double* __restrict__ tab, int ns, int C_run
   scan_coeffs<NSP>(a, ns, c);
   for (int i = t; i < C_run * NST; i += SCAN_THREADS) Gl[i] = G[i];  // (the first __syncthreads below orders it)
 
+  // ---- HBM -> registers -> staging rows -> registers, 16-byte vectors.  Row t of the staging buffer = the chunk of thread t, SR
+  // samples apart with SR * sizeof / 16 odd (the 16-byte chunk reads of the 16 lanes LDS serves at a time fall on distinct
+  // banks); RP rows per piece.  Centring and rectification are applied between the registers and the staging buffer.
+  constexpr int CV = C_run / V;  // vectors per row = vectors per thread (C_run is a multiple of 4)
+  constexpr int SR = C_run + ((CV & 1) ? 0 : V);
+  constexpr int RP = (SCAN_STAGE_BYTES / (SR * (int)sizeof(real))) < SCAN_THREADS ? (SCAN_STAGE_BYTES / (SR * (int)sizeof(real))) : SCAN_THREADS;
+  constexpr bool ONE_ROUND = CV <= 20;  // the whole series fits the registers that are free before the chunks are: ONE round trip
   real mean = (real)0;
-  if (a.zero_center) mean = (real)scan_mean<real>(xr, T, misc);  // a first pass over the series; the second one hits the caches
-  const real first = sos_pre<real>(xr[0], mean, a.rectify), last = sos_pre<real>(xr[T - 1], mean, a.rectify);
+  real first = (real)0, last = (real)0;
   // value at position p outside the recording: the odd extension about the end samples (in the samples' precision, as scipy
   // builds it), its first value repeated in front, zeros past the end
   auto outside = [&](int p) -> real {
@@ -284,62 +290,105 @@ sosfilt_scan_kernel(SosArgs a, const double* __restrict__ tab, int ns, int C_run
     const int jr = j < 0 ? -j : 2 * (T - 1) - j;
     return (real)2 * (j < 0 ? first : last) - sos_pre<real>(xr[jr], mean, a.rectify);
   };
-
-  // ---- HBM -> staging rows -> registers in 16-byte vectors, SCAN_LOADS of them in flight per thread; centring and rectification
-  // on the way in.  Row t = the chunk of thread t, SR samples apart with SR * sizeof / 16 odd: the 16-byte chunk reads of the 16
-  // lanes LDS serves at a time fall on distinct banks.  RP rows per piece.
-  const int CV = C_run / V;                                // vectors per row (C_run is a multiple of 4)
-  const int SR = C_run + ((CV & 1) ? 0 : V);
-  const int RP = min(SCAN_THREADS, (int)(SCAN_STAGE_BYTES / (SR * (int)sizeof(real))));
-  const unsigned inv = 0xFFFFFFFFu / (unsigned)CV + 1u;    // w / CV == umulhi(w, inv) for the w that occur (w < 2^15)
   double v[CMAX];
 #pragma unroll
   for (int n = 0; n < CMAX; ++n) v[n] = 0.0;
-  for (int r0 = 0; r0 < SCAN_THREADS; r0 += RP) {
-    const int rows = min(RP, SCAN_THREADS - r0);
-    const int NW = rows * CV;  // vectors of this piece
-    __syncthreads();
-    for (int w0 = t; w0 < NW; w0 += SCAN_LOADS * SCAN_THREADS) {
-      Vec raw[SCAN_LOADS];
+  auto read_chunk = [&](int r0) {
+    const Vec* __restrict__ myrow = reinterpret_cast<const Vec*>(stage + (t - r0) * SR);
 #pragma unroll
-      for (int u = 0; u < SCAN_LOADS; ++u) {  // all loads of the round go out before any of them is used
-        const int w = w0 + u * SCAN_THREADS;
-        const int row = CV == 1 ? w : (int)__umulhi((unsigned)w, inv);
-        int j = (r0 + row) * C_run + (w - row * CV) * V - EO;
-        j = (w < NW && j >= 0 && j < T) ? j : 0;  // outside the recording: any valid vector, replaced below
-        raw[u] = *reinterpret_cast<const Vec*>(xr + j);
+    for (int g = 0; g < CV; ++g) {
+      const Vec x = myrow[g];
+#pragma unroll
+      for (int q = 0; q < V; ++q) v[g * V + q] = (double)x.v[q];
+    }
+  };
+  if constexpr (ONE_ROUND) {
+    // thread t loads the vectors w = t + 256 u of the whole series at once (coalesced); the mean comes from these registers
+    Vec raw[CV];
+#pragma unroll
+    for (int u = 0; u < CV; ++u) {
+      const int w = t + u * SCAN_THREADS, row = w / CV;
+      const int j = row * C_run + (w - row * CV) * V - EO;
+      raw[u] = *reinterpret_cast<const Vec*>(xr + ((j >= 0 && j < T) ? j : 0));  // (T is a multiple of V: inside or outside, never astride)
+    }
+    if (a.zero_center) {  // fp64 sum in a fixed order: the thread's vectors in order, wave tree, four waves
+      double sum = 0.0;
+#pragma unroll
+      for (int u = 0; u < CV; ++u) {
+        const int w = t + u * SCAN_THREADS, row = w / CV;
+        const int j = row * C_run + (w - row * CV) * V - EO;
+        double part = 0.0;
+#pragma unroll
+        for (int q = 0; q < V; ++q) part += (double)raw[u].v[q];
+        sum += (j >= 0 && j < T) ? part : 0.0;
       }
 #pragma unroll
-      for (int u = 0; u < SCAN_LOADS; ++u) {
-        const int w = w0 + u * SCAN_THREADS;
-        if (w < NW) {
-          const int row = CV == 1 ? w : (int)__umulhi((unsigned)w, inv);
-          const int col = (w - row * CV) * V, p = (r0 + row) * C_run + col, j = p - EO;
+      for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
+      if ((t & 63) == 0) misc[t >> 6] = sum;
+      __syncthreads();
+      mean = (real)(((misc[0] + misc[1]) + (misc[2] + misc[3])) / (double)T);
+    }
+    first = sos_pre<real>(xr[0], mean, a.rectify), last = sos_pre<real>(xr[T - 1], mean, a.rectify);
+#pragma unroll
+    for (int r0 = 0; r0 < SCAN_THREADS; r0 += RP) {
+      const int rows = (RP < SCAN_THREADS - r0) ? RP : SCAN_THREADS - r0;
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < CV; ++u) {
+        const int w = t + u * SCAN_THREADS, row = w / CV;
+        if (row >= r0 && row < r0 + rows) {
+          const int col = (w - row * CV) * V, p = row * C_run + col, j = p - EO;
           Vec o;
-          if (j >= 0 && j < T) {  // (T is a multiple of V: a vector is inside the recording or outside, never astride)
+          if (j >= 0 && j < T) {
 #pragma unroll
             for (int q = 0; q < V; ++q) o.v[q] = sos_pre<real>(raw[u].v[q], mean, a.rectify);
           } else {
 #pragma unroll
             for (int q = 0; q < V; ++q) o.v[q] = outside(p + q);
           }
-          *reinterpret_cast<Vec*>(stage + row * SR + col) = o;
+          *reinterpret_cast<Vec*>(stage + (row - r0) * SR + col) = o;
         }
       }
+      __syncthreads();
+      if (t >= r0 && t < r0 + rows) read_chunk(r0);
     }
-    __syncthreads();
-    if (t >= r0 && t < r0 + rows) {
-      const Vec* __restrict__ myrow = reinterpret_cast<const Vec*>(stage + (t - r0) * SR);
+  } else {
+    if (a.zero_center) mean = (real)scan_mean<real>(xr, T, misc);  // a first pass over the series; the second one hits the caches
+    first = sos_pre<real>(xr[0], mean, a.rectify), last = sos_pre<real>(xr[T - 1], mean, a.rectify);
+    for (int r0 = 0; r0 < SCAN_THREADS; r0 += RP) {
+      const int rows = min(RP, SCAN_THREADS - r0);
+      const int NW = rows * CV;  // vectors of this piece
+      __syncthreads();
+      for (int w0 = t; w0 < NW; w0 += SCAN_LOADS * SCAN_THREADS) {
+        Vec raw[SCAN_LOADS];
 #pragma unroll
-      for (int n0 = 0; n0 < CMAX; n0 += 4)
-        if (n0 < C_run) {
+        for (int u = 0; u < SCAN_LOADS; ++u) {  // all loads of the round go out before any of them is used
+          const int w = w0 + u * SCAN_THREADS;
+          const int row = w / CV;
+          int j = (r0 + row) * C_run + (w - row * CV) * V - EO;
+          j = (w < NW && j >= 0 && j < T) ? j : 0;  // outside the recording: any valid vector, replaced below
+          raw[u] = *reinterpret_cast<const Vec*>(xr + j);
+        }
 #pragma unroll
-          for (int g = 0; g < 4 / V; ++g) {
-            const Vec x = myrow[n0 / V + g];
+        for (int u = 0; u < SCAN_LOADS; ++u) {
+          const int w = w0 + u * SCAN_THREADS;
+          if (w < NW) {
+            const int row = w / CV;
+            const int col = (w - row * CV) * V, p = (r0 + row) * C_run + col, j = p - EO;
+            Vec o;
+            if (j >= 0 && j < T) {
 #pragma unroll
-            for (int q = 0; q < V; ++q) v[n0 + g * V + q] = (double)x.v[q];
+              for (int q = 0; q < V; ++q) o.v[q] = sos_pre<real>(raw[u].v[q], mean, a.rectify);
+            } else {
+#pragma unroll
+              for (int q = 0; q < V; ++q) o.v[q] = outside(p + q);
+            }
+            *reinterpret_cast<Vec*>(stage + row * SR + col) = o;
           }
         }
+      }
+      __syncthreads();
+      if (t >= r0 && t < r0 + rows) read_chunk(r0);
     }
   }
 
@@ -365,7 +414,7 @@ sosfilt_scan_kernel(SosArgs a, const double* __restrict__ tab, int ns, int C_run
     for (int s = 0; s < NSP; ++s) z[s][0] = z[s][1] = 0.0;
 #pragma unroll
     for (int n0 = 0; n0 < CMAX; n0 += 4)
-      if (n0 < C_run) {
+      {
 #pragma unroll
         for (int n = n0; n < n0 + 4; ++n) v[n] = scan_step<NSP>(v[n], z, c);
       }
@@ -378,7 +427,7 @@ sosfilt_scan_kernel(SosArgs a, const double* __restrict__ tab, int ns, int C_run
   scan_states<NST>(E, s_init, false, Mp, xch, s_start);
 #pragma unroll
   for (int n0 = 0; n0 < CMAX; n0 += 4)
-    if (n0 < C_run) {
+    {
 #pragma unroll
       for (int n = n0; n < n0 + 4; ++n) {
         double acc = v[n];
@@ -396,7 +445,7 @@ sosfilt_scan_kernel(SosArgs a, const double* __restrict__ tab, int ns, int C_run
       double* __restrict__ row = reinterpret_cast<double*>(stage);
 #pragma unroll
       for (int n0 = 0; n0 < CMAX; n0 += 4)
-        if (n0 < C_run) {
+        {
 #pragma unroll
           for (int n = n0; n < n0 + 4; ++n) row[n] = v[n];
         }
@@ -418,7 +467,7 @@ sosfilt_scan_kernel(SosArgs a, const double* __restrict__ tab, int ns, int C_run
       for (int s = 0; s < NSP; ++s) z[s][0] = z[s][1] = 0.0;
 #pragma unroll
       for (int n0 = CMAX - 4; n0 >= 0; n0 -= 4)
-        if (n0 < C_run) {
+        {
 #pragma unroll
           for (int n = n0 + 3; n >= n0; --n) v[n] = scan_step<NSP>(v[n], z, c);
         }
@@ -432,7 +481,7 @@ sosfilt_scan_kernel(SosArgs a, const double* __restrict__ tab, int ns, int C_run
     const double* __restrict__ Gr = Gl + (C_run - 1) * NST;  // sample n of a chunk is step C_run - 1 - n of the reversed walk
 #pragma unroll
     for (int n0 = 0; n0 < CMAX; n0 += 4)
-      if (n0 < C_run) {
+      {
 #pragma unroll
         for (int n = n0; n < n0 + 4; ++n) {
           double acc = v[n];
@@ -452,7 +501,7 @@ sosfilt_scan_kernel(SosArgs a, const double* __restrict__ tab, int ns, int C_run
       Vec* __restrict__ myrow = reinterpret_cast<Vec*>(stage + (t - r0) * SR);
 #pragma unroll
       for (int n0 = 0; n0 < CMAX; n0 += 4)
-        if (n0 < C_run) {
+        {
 #pragma unroll
           for (int g = 0; g < 4 / V; ++g) {
             Vec x;
@@ -464,7 +513,7 @@ sosfilt_scan_kernel(SosArgs a, const double* __restrict__ tab, int ns, int C_run
     }
     __syncthreads();
     for (int w = t; w < NW; w += SCAN_THREADS) {
-      const int row = CV == 1 ? w : (int)__umulhi((unsigned)w, inv);
+      const int row = w / CV;  // (a compile-time divisor: multiply-high)
       const int col = (w - row * CV) * V, j = (r0 + row) * C_run + col - EO;
       if (j >= 0 && j < T) *reinterpret_cast<Vec*>(yr + j) = *reinterpret_cast<const Vec*>(stage + row * SR + col);
     }

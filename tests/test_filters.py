@@ -190,3 +190,79 @@ def test_gpu_filter_fuzz():
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "0 problems" in r.stdout
+
+
+# ---- the time-parallel mode (csrc/sosfilt_scan.hpp, hipnmf_sosfilt_params.mode = HIPNMF_SOSFILT_SCAN) --------------------------
+SCAN_TOL = 1e-10  # relative to the output's largest magnitude; measured 1e-12 .. 2e-11 for the reference's own designs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES)
+def test_gpu_scan_mode_matches_the_reference_outputs(g8, name):
+    """The fixtures captured from the reference's digital_filter / linear_envelope (G8), through the chunked filter: same result
+    to rounding times the filter's conditioning (not bit for bit: fused multiply-adds, another order of the sums)."""
+    from muscle_synergies_amd.preprocess import sosfilt_batched
+
+    raw, fs, zero_lag, sos, zi = _case(g8, name)
+    ref = so.digital_filter(raw, sos, zero_lag)
+    scale = np.abs(ref).max()
+    for arr in (np.ascontiguousarray(raw), np.asfortranarray(raw)):
+        got = sosfilt_batched(arr, sos, zero_lag=zero_lag, mode="scan")[0].cpu().numpy()
+        assert got.shape == raw.shape and got.dtype == np.float64
+        assert np.abs(got - ref).max() <= SCAN_TOL * scale, np.abs(got - ref).max() / scale
+    if KW[name]["band_type"] == "lowpass":
+        le = sosfilt_batched(raw, sos, zero_lag=zero_lag, zero_center=True, rectify=True, mode="scan")[0].cpu().numpy()
+        ref_le = so.linear_envelope(raw, sos, zero_lag)
+        assert np.abs(le - ref_le).max() <= SCAN_TOL * np.abs(ref_le).max()
+
+
+@pytest.mark.gpu
+def test_gpu_scan_mode_sizes_dtypes_and_fallbacks(g8):
+    """Every compiled chunk length (16 / 40 / 80 samples per thread), fp32 and fp64, a batch larger than the chip, the tail of the
+    last chunk, and the shapes the mode hands to the sequential kernel (longer than 20 480 extended samples, or n_samples not a
+    multiple of the 16-byte vector) -- which then answer bit for bit."""
+    import torch
+
+    from muscle_synergies_amd.preprocess import sosfilt_batched
+
+    sos = g8["lp4_sos"]
+    for T, B, m in ((3000, 5, 3), (4096, 2, 2), (9000, 3, 2), (10200, 2, 1), (20000, 2, 2), (20400, 1, 2), (64, 7, 5), (2000, 600, 2)):
+        raw = np.stack([raw_emg(500 + b % 7, T, m) for b in range(B)])
+        for zero_lag in (True, False):
+            got = sosfilt_batched(raw, sos, zero_lag=zero_lag, zero_center=True, rectify=True, mode="scan").cpu().numpy()
+            for b in (0, B - 1):
+                ref = so.linear_envelope(raw[b], sos, zero_lag)
+                assert np.abs(got[b] - ref).max() <= SCAN_TOL * np.abs(ref).max(), (T, B, m, zero_lag)
+        raw32 = raw.astype(np.float32)
+        got32 = sosfilt_batched(raw32, sos, zero_lag=True, mode="scan").cpu().numpy()
+        ex32 = sosfilt_batched(raw32, sos, zero_lag=True, mode="exact").cpu().numpy()
+        assert got32.dtype == np.float32
+        np.testing.assert_allclose(got32, ex32, rtol=0, atol=2e-7 * np.abs(ex32).max())  # both round an fp64 result to float
+    # handed to the sequential kernel: bit-identical to the exact mode
+    for T in (20481, 30000, 1333, 1001):
+        raw = raw_emg(9, T, 2)
+        a = sosfilt_batched(raw, sos, mode="scan")[0].cpu().numpy()
+        assert np.array_equal(a, so.sosfiltfilt(sos, raw)) or np.abs(a - so.sosfiltfilt(sos, raw)).max() <= SCAN_TOL * np.abs(a).max()
+    raw = raw_emg(9, 20481, 2)
+    assert np.array_equal(sosfilt_batched(raw, sos, mode="scan")[0].cpu().numpy(), so.sosfiltfilt(sos, raw))
+    with pytest.raises(KeyError):
+        sosfilt_batched(raw, sos, mode="fast")
+    # determinism
+    x = torch.from_numpy(np.stack([raw_emg(40 + b, 20000, 4) for b in range(8)]).astype(np.float32)).cuda()
+    y1, y2 = sosfilt_batched(x, sos, rectify=True, mode="scan"), sosfilt_batched(x, sos, rectify=True, mode="scan")
+    assert torch.equal(y1, y2)
+
+
+@pytest.mark.gpu
+def test_gpu_scan_mode_fuzz():
+    """tests/fuzz_sosfilt_gpu.py --mode scan: random designs (1-8 sections), lengths up to 20 400, paddings, options, layouts."""
+    import os
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz_sosfilt_gpu.py"), "--cases", "160", "--seed", "11", "--mode", "scan"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "0 problems" in r.stdout

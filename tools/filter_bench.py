@@ -14,6 +14,7 @@ ap.add_argument("--m", type=int, default=16)
 ap.add_argument("--orders", type=int, nargs="*", default=[2, 4, 8])
 ap.add_argument("--dtypes", nargs="*", default=["float32", "float64"])
 ap.add_argument("--modes", nargs="*", default=["exact", "scan"])
+ap.add_argument("--zero-lag", nargs="*", type=int, default=[1, 0], help="1: sosfiltfilt, 0: sosfilt")
 a = ap.parse_args()
 h = _lib.get_handle(0)
 for dtn in a.dtypes:
@@ -21,7 +22,7 @@ for dtn in a.dtypes:
     raw = torch.randn((a.batch, a.m, a.T), device="cuda:0", dtype=dt).transpose(1, 2)
     for order in a.orders:
         sos = design_sos("butter", order, 2000, 6)
-        for zero_lag in (True, False):
+        for zero_lag in [bool(z) for z in a.zero_lag]:
             for mode in a.modes:
                 for rep in range(3):
                     out = sosfilt_batched(raw, sos, zero_lag=zero_lag, zero_center=True, rectify=True, mode=mode)
