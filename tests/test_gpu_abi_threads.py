@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 
 PATHS = ("fit_persistent_kernel<", "fit_rowlane_kernel<", "fit_small_kernel<", "fit_coop_kernel<", "slice_pass_kernel<",
          "fit_wide_kernel<", "fit_wide4_kernel<", "fit_wide4d_kernel<", "[sliced]", "[ragged]", "[kl]", "rank_sweep,",
-         "rank_sweep_stop", "random_init", "emg_envelope", "sosfilt")
+         "rank_sweep_stop", "random_init", "emg_envelope", "sosfilt,", "sosfilt_scan")
 
 
 def _stress(*args, timeout=900):

@@ -238,7 +238,7 @@ _SOS = np.array([[2.91464945e-05, 5.82929890e-05, 2.91464945e-05, 1.0, -1.866892
                  [1.0, 2.0, 1.0, 1.0, -1.93296719, 0.94170979]])  # an order-4 low-pass as scipy.signal.butter(.., output="sos") lays it out
 
 
-def sosfilt_case(dtype, B, T, m, zero_lag):
+def sosfilt_case(dtype, B, T, m, zero_lag, mode=0):
     sfx = "f32" if dtype == np.float32 else "f64"
 
     def run(h):
@@ -246,9 +246,9 @@ def sosfilt_case(dtype, B, T, m, zero_lag):
         try:
             raw = np.stack([raw_emg(b, T, m) for b in range(B)]).astype(dtype)
             dR, dO = d.put(raw), d.put(np.zeros((B, m, T), dtype))
-            p = SosfiltParams(ctypes.sizeof(SosfiltParams), B, T, m, L.X_ROW_MAJOR, m, T * m, 2, zero_lag, -1, 1, 1, 0)
+            p = SosfiltParams(ctypes.sizeof(SosfiltParams), B, T, m, L.X_ROW_MAJOR, m, T * m, 2, zero_lag, -1, 1, 1, mode)
             ok(getattr(lib, "hipnmf_sosfilt_" + sfx)(h, ctypes.byref(p), _SOS.ctypes.data_as(vp), None, dR, dO), "sosfilt")
-            return "sosfilt", [d.get(dO, (B, m, T), dtype)]
+            return "sosfilt_scan" if mode else "sosfilt", [d.get(dO, (B, m, T), dtype)]
         finally:
             d.free()
 
@@ -289,6 +289,8 @@ CASES = {
     "envelope_tn": envelope_case(f64, 4, 5000, 8, 51, 200),
     "sosfilt": sosfilt_case(f32, 6, 6000, 16, 1),
     "sosfilt_causal": sosfilt_case(f64, 3, 4000, 8, 0),
+    "sosfilt_scan": sosfilt_case(f32, 6, 6000, 16, 1, mode=1),
+    "sosfilt_scan_f64": sosfilt_case(f64, 3, 12000, 4, 1, mode=1),
 }
 
 
