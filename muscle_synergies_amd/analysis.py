@@ -60,9 +60,10 @@ def vaf(original_df: pandas.DataFrame, transformed_signal=None, components=None,
 def _make_model(n_components: int, n_features: Optional[int] = None, **nmf_kwargs):
     """The seam: HIP engine for the mu path at the shapes it is compiled for, sklearn for everything else.
 
-    ``solver='mu'`` with more than 32 muscles (e.g. HD-EMG grids) or more than 8 synergies is outside the
-    compiled kernel set; such a call goes to scikit-learn like any other unsupported configuration (the
-    reference works for every shape, ``analysis.py:862-863``), with a warning saying so.
+    ``solver='mu'`` runs on the GPU for up to ``HipNMF.MAX_FEATURES`` (512) muscles and ``HipNMF.MAX_COMPONENTS`` (64) synergies
+    (lane mappings up to 32 x 8, matrix-pipe kernels up to 128 x 32, the general-shape kernels beyond); a call outside that goes
+    to scikit-learn like any other unsupported configuration (the reference works for every shape, ``analysis.py:862-863``), with
+    a warning saying so.
     """
     if HipNMF.supports(n_features=n_features, n_components=n_components, **nmf_kwargs):
         return HipNMF(n_components=n_components, **nmf_kwargs)

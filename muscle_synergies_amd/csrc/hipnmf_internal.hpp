@@ -139,6 +139,6 @@ class hipnmf_kernel_chain {
 };
 
 constexpr int HIPNMF_NARROW_MAX_FEATURES = 32, HIPNMF_NARROW_MAX_COMPONENTS = 8;  // nmf_kernels.hpp lane mappings
-constexpr int HIPNMF_MAX_FEATURES = 128, HIPNMF_MAX_COMPONENTS = 32;              // nmf_wide.hpp
+constexpr int HIPNMF_MAX_FEATURES = 512, HIPNMF_MAX_COMPONENTS = 64;              // nmf_big.hpp (nmf_wide.hpp: 128 / 32)
 
 // X layout canonicalisation kernel (nmf_kernels.hpp) reused by the envelope entry point

@@ -17,6 +17,7 @@
 #include "hipnmf_internal.hpp"
 #include "nmf_wide4_inst.hpp"
 #include "nmf_wide_inst.hpp"
+#include "nmf_big.hpp"
 
 using namespace hipnmf;
 
@@ -93,15 +94,26 @@ int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
   const bool want512 = !kl && (h->threads == 512 || (h->threads == 0 && ks_ >= 12 && m > 48));
   const WideKernel<real>* wk = want512 ? pick<real>(m, k, 8) : nullptr;
   if (!wk) wk = pick<real>(m, k, 4);
-  if (!wk) return fail(HIPNMF_ERR_UNSUPPORTED, "no kernel for n_features=%d (max 128) n_components=%d (max 32)", m, k);
-  if (wk->smem > (size_t)h->lds_per_block)  // float64 with more than 16 components and more than 64 channels
-    return fail(HIPNMF_ERR_UNSUPPORTED, "%s needs %zu bytes of LDS (the CU has %d): n_features=%d n_components=%d in this precision is outside "
-                "the compiled kernel set", wk->name, wk->smem, h->lds_per_block, m, k);
+  // beyond the instances of nmf_wide.hpp -- more than 128 channels or 32 components, or float64 with more than 16 components on
+  // more than 64 channels (its LDS footprint) -- the general-shape kernels of nmf_big.hpp take over (HIPNMF_FORCE_BIG=1: always)
+  static const bool force_big = [] {
+    const char* e = getenv("HIPNMF_FORCE_BIG");
+    return e && atoi(e) != 0;
+  }();
+  const bool big = !wk || wk->smem > (size_t)h->lds_per_block || (force_big && !kl && !ragged);
+  if (big) {
+    if (m > HIPNMF_MAX_FEATURES || k > HIPNMF_MAX_COMPONENTS)
+      return fail(HIPNMF_ERR_UNSUPPORTED, "no kernel for n_features=%d (max %d) n_components=%d (max %d)", m, HIPNMF_MAX_FEATURES, k,
+                  HIPNMF_MAX_COMPONENTS);
+    if (kl) return fail(HIPNMF_ERR_UNSUPPORTED, "beta_loss='kullback-leibler' beyond 128 channels / 32 components is not compiled");
+    if (ragged) return fail(HIPNMF_ERR_UNSUPPORTED, "ragged batches beyond 128 channels / 32 components are not compiled");
+  }
   if (h->variant == 3 || h->variant == 5 || h->variant == 6)
     return fail(HIPNMF_ERR_UNSUPPORTED, "tuning variant %d does not exist for wide shapes (n_features=%d, n_components=%d)",
                 h->variant, m, k);
   constexpr int VEC = 16 / (int)sizeof(real);
-  const int ks = (int)round_up(k, 4);
+  const int KPb = (int)round_up(k, 16), MPb = (int)round_up(m, 16);  // the general-shape kernels' padded sizes
+  const int ks = big ? KPb : (int)round_up(k, 4);                    // row length of the kernel-side W
   hipStream_t st = h->stream;
 
   if (ragged) {
@@ -154,11 +166,19 @@ int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
 
   // ---- path: one workgroup per matrix, or row slices over the whole chip (few long matrices: the reference's own
   // single-DataFrame call)
-  const WideKernel<real>* wk4 = pick<real>(m, k, 4);
+  const WideKernel<real>* wk4 = big ? nullptr : pick<real>(m, k, 4);
   int S = 1;
   long long rps = 0;
   bool sliced = false;
-  if (!ragged && !kl && wk4 && wk4->smem <= (size_t)h->lds_per_block && h->variant != 1 && h->variant != 4 && B <= 65535) {
+  if (big) {  // always row slices: enough of them to fill the chip, whole 64-row sweeps of a workgroup
+    const long long want = std::max<long long>(1, (2LL * h->num_cu + B - 1) / B);
+    long long s_try = std::min<long long>(want, (T + 63) / 64);
+    if (h->max_slices > 0) s_try = std::min<long long>(s_try, h->max_slices);
+    rps = round_up((T + s_try - 1) / s_try, 64);
+    S = (int)((T + rps - 1) / rps);
+    sliced = true;
+    if (B > 65535) return fail(HIPNMF_ERR_UNSUPPORTED, "batch=%d: the general-shape path takes at most 65535 matrices", B);
+  } else if (!ragged && !kl && wk4 && wk4->smem <= (size_t)h->lds_per_block && h->variant != 1 && h->variant != 4 && B <= 65535) {
     const long long target = std::min<long long>(128, std::max<long long>(1, 2LL * h->num_cu / B));  // (the H update sums S records per launch)
     long long s_try = std::min<long long>(target, (T + 127) / 128);  // at least two subtiles per wave and slice
     if (h->max_slices > 0) s_try = std::min<long long>(s_try, h->max_slices);
@@ -174,7 +194,7 @@ int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
   } else if (h->variant == 2) {
     return fail(HIPNMF_ERR_UNSUPPORTED, "the row-sliced wide path handles uniform Frobenius batches only");
   }
-  if (sliced) {
+  if (sliced && !big) {
     wk = wk4;
     // the 256-thread instance of the 4x4 kernels where one exists (at most 8 components, Frobenius): same slice records
     // (KP = 4 or 8 rows instead of 16), same phases (HIPNMF_WIDE4_SLICED=0: the 16x16x4 kernel)
@@ -216,10 +236,12 @@ int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
   const size_t o_w = w_inplace ? 0 : carve(sizeof(real) * (ragged ? (size_t)ragged_w_elems + 64 : (size_t)B * w_elems + 64));
   const size_t o_kdesc = ragged ? carve(sizeof(long long) * 4 * (size_t)B) : 0;
   const size_t o_cdesc = ragged ? carve(sizeof(long long) * 4 * (size_t)B) : 0;
-  const size_t rec = (size_t)wk->KP * wk->MP + (size_t)wk->KP * wk->KP;
+  const int recKP = big ? KPb : wk->KP, recMP = big ? MPb : wk->MP;  // (`wk` is not consulted on the general-shape path)
+  const size_t rec = (size_t)recKP * recMP + (size_t)recKP * recKP;
   const size_t o_part = sliced ? carve(sizeof(real) * (size_t)B * S * rec) : 0;
-  const size_t o_col = sliced ? carve(sizeof(real) * (size_t)B * S * 2 * wk->MP) : 0;
+  const size_t o_col = sliced ? carve(sizeof(real) * (size_t)B * S * 2 * recMP) : 0;
   const size_t o_state = sliced ? carve(sizeof(real) * (size_t)B * 8) : 0;
+  const size_t o_hht = big ? carve(sizeof(real) * (size_t)B * KPb * KPb) : 0;
   int rc = hipnmf_ensure_ws(h, std::max<size_t>(off, 256));
   if (rc) return rc;
   char* ws = static_cast<char*>(h->ws);
@@ -302,6 +324,174 @@ int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
   a.l1h = (real)p->l1_reg_H;
   a.l2h = (real)p->l2_reg_H;
 
+  // ---- driver of the row-sliced paths: `enqueue(n, check, emit)` queues n iterations (+ one stop-rule evaluation), `residual(it,
+  // emit)` one residual evaluation (it: 0 at init, 1 a check, -1 the final outputs); every launch goes through an emitter --
+  // straight onto the stream, or into the replayed chain of kernel nodes (hipnmf_kernel_chain in hipnmf_internal.hpp says why
+  // not a stream capture).  The done flags live on the device (state[b][3]).
+  const bool stop_rule = p->tol > 0;
+  real* d_state = sliced ? reinterpret_cast<real*>(ws + o_state) : nullptr;
+  auto direct = [&](auto fn, dim3 g, dim3 blk, size_t sm, const auto& args) { hipLaunchKernelGGL(fn, g, blk, sm, st, args); };
+  auto drive = [&](auto&& enqueue, auto&& residual) -> int {
+    std::vector<real> host_state((size_t)B * 8);
+    auto all_converged = [&](bool* done) -> int {
+      HIP_TRY(hipMemcpyAsync(host_state.data(), d_state, sizeof(real) * (size_t)B * 8, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      *done = true;
+      for (int b = 0; b < B; ++b) *done = *done && host_state[(size_t)b * 8 + 3] != (real)0;
+      return HIPNMF_OK;
+    };
+    if (stop_rule) residual(0, direct);
+    const int chunk = stop_rule ? p->check_every : std::min(p->max_iter, 64);
+    int it_done = 0;
+    bool converged = false;
+    if (h->use_graph && p->max_iter >= 2 * chunk) {
+      hipnmf_kernel_chain chain;
+      hipError_t ge = hipSuccess;
+      enqueue(chunk, stop_rule, [&](auto fn, dim3 g, dim3 blk, size_t sm, const auto& args) {
+        if (ge == hipSuccess) ge = chain.add(reinterpret_cast<const void*>(fn), g, blk, sm, args);
+      });
+      if (ge == hipSuccess) ge = chain.instantiate();
+      int graph_rc = HIPNMF_OK;
+      while (ge == hipSuccess && !converged && it_done + chunk <= p->max_iter) {
+        ge = chain.launch(st);
+        if (ge != hipSuccess) break;
+        it_done += chunk;
+        if (stop_rule) {
+          graph_rc = all_converged(&converged);
+          if (graph_rc) break;
+        }
+      }
+      if (ge == hipSuccess && !graph_rc) ge = hipStreamSynchronize(st);
+      if (graph_rc) return graph_rc;
+      if (ge != hipSuccess) {
+        (void)hipGetLastError();
+        if (it_done > 0)
+          return fail(HIPNMF_ERR_HIP, "hipGraph replay failed after %d iterations: %s", it_done, hipGetErrorString(ge));
+      }
+    }
+    while (!converged && it_done < p->max_iter) {
+      const int n = std::min(chunk, p->max_iter - it_done);
+      const bool check = stop_rule && n == chunk;
+      enqueue(n, check, direct);
+      it_done += n;
+      if (check) {
+        int crc = all_converged(&converged);
+        if (crc) return crc;
+      }
+    }
+    residual(-1, direct);
+    return HIPNMF_OK;
+  };
+  WideSliceArgs<real> sa;
+  std::memset(&sa, 0, sizeof(sa));
+  if (sliced) {
+    HIP_TRY(hipMemsetAsync(d_state, 0, sizeof(real) * (size_t)B * 8, st));  // zeroed: nothing is done yet (also read without a stop rule)
+    sa.H = H;
+    sa.part = reinterpret_cast<real*>(ws + o_part);
+    sa.colpart = reinterpret_cast<real*>(ws + o_col);
+    sa.state = d_state;
+    sa.err_out = err_out;
+    sa.n_iter_out = n_iter_out;
+    sa.sse_col_out = sse_col_out;
+    sa.xsq_col_out = xsq_col_out;
+    sa.m = m;
+    sa.k = k;
+    sa.MP = recMP;
+    sa.KP = recKP;
+    sa.S = S;
+    sa.max_iter = p->max_iter;
+    sa.check_every = p->check_every;
+    sa.tol = (real)p->tol;
+    sa.l1h = (real)p->l1_reg_H;
+    sa.l2h = (real)p->l2_reg_H;
+  }
+
+  if (big) {
+    // ---- general shapes (nmf_big.hpp): four launches per iteration over row slices, H staged in LDS in blocks of CBH channels
+    HIP_TRY(hipEventRecord(h->ev0, st));
+    h->last_path = 2;
+    snprintf(h->last_kernel, sizeof(h->last_kernel), "big_pass_w_kernel<%s,%d>[sliced]", sizeof(real) == 4 ? "float" : "double", KPb);
+    BigArgs<real> ba;
+    std::memset(&ba, 0, sizeof(ba));
+    ba.X = a.X;
+    ba.x_bstride = a.x_bstride;
+    ba.ldx = a.ldx;
+    ba.W = wc;
+    ba.w_bstride = (long long)w_elems;
+    ba.H = H;
+    ba.HHt = reinterpret_cast<real*>(ws + o_hht);
+    ba.part = reinterpret_cast<real*>(ws + o_part);
+    ba.colpart = reinterpret_cast<real*>(ws + o_col);
+    ba.state = d_state;
+    ba.T = (int)T;
+    ba.m = m;
+    ba.k = k;
+    ba.KP = KPb;
+    ba.MP = MPb;
+    ba.xchunks = a.xchunks;
+    ba.S = S;
+    ba.rows_per_slice = (int)rps;
+    ba.l1w = (real)p->l1_reg_W;
+    ba.l2w = (real)p->l2_reg_W;
+    // H in LDS: all of it when [KP][MP + 4] (+ H H^T, + the residual's column accumulators) fits 96 KiB, else blocks of channels
+    const size_t fixed = sizeof(real) * ((size_t)KPb * (KPb + 4) + 8 * (size_t)MPb);
+    const size_t cap = 96 * 1024;
+    int cbh = MPb;
+    while (cbh > 16 && fixed + sizeof(real) * (size_t)KPb * (cbh + 4) > cap) cbh = (int)round_up(cbh / 2, 16);
+    ba.CBH = cbh;
+    const size_t smem_w = sizeof(real) * ((size_t)KPb * (cbh + 4) + (size_t)KPb * (KPb + 4));
+    const size_t smem_r = sizeof(real) * ((size_t)KPb * (cbh + 4) + 8 * (size_t)MPb);
+    const size_t smem_rec = sizeof(real) * std::max<size_t>(4 * (16 * (size_t)(KPb + 4) + 16 * (size_t)(BIG_CB + 4)), 4 * (size_t)KPb * BIG_CB);
+    const size_t smem_h = sizeof(real) * ((size_t)k * k + 128 * (size_t)k);
+    BigHArgs<real> hb;
+    hb.H = H;
+    hb.part = ba.part;
+    hb.state = d_state;
+    hb.m = m;
+    hb.k = k;
+    hb.KP = KPb;
+    hb.MP = MPb;
+    hb.S = S;
+    hb.l1h = (real)p->l1_reg_H;
+    hb.l2h = (real)p->l2_reg_H;
+    const dim3 gslice(S, B), grec(S, B, (MPb + BIG_CB - 1) / BIG_CB + 1), ghup(B, (m + 63) / 64);
+    auto with_kp = [&](auto&& f) {  // the padded component count is a compile-time parameter of three of the kernels
+      switch (KPb) {
+        case 16: f(std::integral_constant<int, 16>{}); break;
+        case 32: f(std::integral_constant<int, 32>{}); break;
+        case 48: f(std::integral_constant<int, 48>{}); break;
+        default: f(std::integral_constant<int, 64>{}); break;
+      }
+    };
+    int arc = HIPNMF_OK;
+    with_kp([&](auto kp) {
+      constexpr int KP = decltype(kp)::value;
+      for (const void* fn : {reinterpret_cast<const void*>(big_pass_w_kernel<real, KP>), reinterpret_cast<const void*>(big_records_kernel<real, KP>),
+                             reinterpret_cast<const void*>(big_resid_kernel<real, KP>)})
+        if (!arc) arc = hipnmf_allow_full_lds(h, fn);
+    });
+    if (arc) return arc;
+    auto residual = [&](int it, auto&& emit) {
+      with_kp([&](auto kp) { emit(big_resid_kernel<real, decltype(kp)::value>, gslice, dim3(256), smem_r, ba); });
+      WideSliceArgs<real> f = sa;
+      f.it = it;
+      emit(big_resid_finalize_kernel<real>, dim3(B), dim3(1024), sizeof(real) * 2 * (size_t)MPb, f);
+    };
+    auto enqueue = [&](int n, bool check, auto&& emit) {
+      for (int i = 0; i < n; ++i) {
+        emit(big_hht_kernel<real>, dim3(B), dim3(256), (size_t)0, ba);
+        with_kp([&](auto kp) {
+          constexpr int KP = decltype(kp)::value;
+          emit(big_pass_w_kernel<real, KP>, gslice, dim3(256), smem_w, ba);
+          if (a.update_h) emit(big_records_kernel<real, KP>, grec, dim3(256), smem_rec, ba);
+        });
+        if (a.update_h) emit(big_hupdate_kernel<real>, ghup, dim3(256), smem_h, hb);
+      }
+      if (check) residual(1, emit);
+    };
+    rc = drive(enqueue, residual);
+    if (rc) return rc;
+  } else {
   // W cache: whole 16-row subtiles in what LDS is left (512 threads: of the whole CU; 256 threads: of half of it, so that
   // two workgroups stay resident); none in the sliced mode (a slice lives for one pass)
   size_t smem = wk->smem;
@@ -333,35 +523,10 @@ int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
     pa.rows_per_slice = ra.rows_per_slice = (int)rps;
     pa.part = reinterpret_cast<real*>(ws + o_part);
     ra.colpart = reinterpret_cast<real*>(ws + o_col);
-    const bool stop_rule = p->tol > 0;
-    real* d_state = reinterpret_cast<real*>(ws + o_state);
-    HIP_TRY(hipMemsetAsync(d_state, 0, sizeof(real) * (size_t)B * 8, st));
-    pa.state = ra.state = d_state;  // zeroed: nothing is done yet (also read without a stop rule)
-    WideSliceArgs<real> sa;
-    std::memset(&sa, 0, sizeof(sa));
-    sa.H = H;
-    sa.part = pa.part;
-    sa.colpart = ra.colpart;
-    sa.state = d_state;
-    sa.err_out = err_out;
-    sa.n_iter_out = n_iter_out;
-    sa.sse_col_out = sse_col_out;
-    sa.xsq_col_out = xsq_col_out;
-    sa.m = m;
-    sa.k = k;
-    sa.MP = wk->MP;
-    sa.KP = wk->KP;
-    sa.S = S;
-    sa.max_iter = p->max_iter;
-    sa.check_every = p->check_every;
-    sa.tol = (real)p->tol;
-    sa.l1h = (real)p->l1_reg_H;
-    sa.l2h = (real)p->l2_reg_H;
+    pa.state = ra.state = d_state;
     const dim3 grid(B, S), block(wk->NW * 64);
     const size_t hsmem = sizeof(real) * (rec + (size_t)k * m);
     if (hsmem > 48 * 1024 && (rc = hipnmf_allow_full_lds(h, reinterpret_cast<const void*>(wide_hupdate_kernel<real>)))) return rc;
-    // every launch goes through an emitter: straight onto the stream, or into the replayed chain
-    auto direct = [&](auto fn, dim3 g, dim3 blk, size_t sm, const auto& args) { hipLaunchKernelGGL(fn, g, blk, sm, st, args); };
     auto residual = [&](int it, auto&& emit) {
       emit(kern, grid, block, smem, ra);
       WideSliceArgs<real> f = sa;
@@ -375,55 +540,9 @@ int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
       }
       if (check) residual(1, emit);
     };
-    std::vector<real> host_state((size_t)B * 8);
-    auto all_converged = [&](bool* done) -> int {
-      HIP_TRY(hipMemcpyAsync(host_state.data(), d_state, sizeof(real) * (size_t)B * 8, hipMemcpyDeviceToHost, st));
-      HIP_TRY(hipStreamSynchronize(st));
-      *done = true;
-      for (int b = 0; b < B; ++b) *done = *done && host_state[(size_t)b * 8 + 3] != (real)0;
-      return HIPNMF_OK;
-    };
-    if (stop_rule) residual(0, direct);
-    const int chunk = stop_rule ? p->check_every : std::min(p->max_iter, 64);
-    int it_done = 0;
-    bool converged = false;
-    if (h->use_graph && p->max_iter >= 2 * chunk) {
-      // an explicit kernel-node chain, not a stream capture (hipnmf_kernel_chain in hipnmf_internal.hpp says why)
-      hipnmf_kernel_chain chain;
-      hipError_t ge = hipSuccess;
-      enqueue(chunk, stop_rule, [&](auto fn, dim3 g, dim3 blk, size_t sm, const auto& args) {
-        if (ge == hipSuccess) ge = chain.add(reinterpret_cast<const void*>(fn), g, blk, sm, args);
-      });
-      if (ge == hipSuccess) ge = chain.instantiate();
-      int graph_rc = HIPNMF_OK;
-      while (ge == hipSuccess && !converged && it_done + chunk <= p->max_iter) {
-        ge = chain.launch(st);
-        if (ge != hipSuccess) break;
-        it_done += chunk;
-        if (stop_rule) {
-          graph_rc = all_converged(&converged);
-          if (graph_rc) break;
-        }
-      }
-      if (ge == hipSuccess && !graph_rc) ge = hipStreamSynchronize(st);
-      if (graph_rc) return graph_rc;
-      if (ge != hipSuccess) {
-        (void)hipGetLastError();
-        if (it_done > 0)
-          return fail(HIPNMF_ERR_HIP, "hipGraph replay failed after %d iterations: %s", it_done, hipGetErrorString(ge));
-      }
-    }
-    while (!converged && it_done < p->max_iter) {
-      const int n = std::min(chunk, p->max_iter - it_done);
-      const bool check = stop_rule && n == chunk;
-      enqueue(n, check, direct);
-      it_done += n;
-      if (check) {
-        rc = all_converged(&converged);
-        if (rc) return rc;
-      }
-    }
-    residual(-1, direct);
+    rc = drive(enqueue, residual);
+    if (rc) return rc;
+  }
   }
   HIP_TRY(hipEventRecord(h->ev1, st));
   if (!w_inplace) convert_w(1);

@@ -1,0 +1,468 @@
+// nmf_big.hpp -- the general-shape path of the solver (round 4): every (n_features, n_components) beyond the instances of
+// nmf_wide.hpp -- up to 512 channels (HD-EMG grids of 256 electrodes are ordinary) and 64 components, fp32 and fp64, and float64
+// with more than 16 components on more than 64 channels -- so that no solver='mu' call of the reference leaves the GPU
+// (src/muscle_synergies/analysis.py:829-846 accepts any 1 <= n <= max <= n_muscles; :862-863 is the seam).
+//
+// Arithmetic replaced: sklearn/decomposition/_nmf.py (1.7.2) _multiplicative_update_w (:540-554, 615-631),
+// _multiplicative_update_h (:638-640, 701-728), _beta_divergence (:85-134), loop + stop rule (:731-893); beta_loss = 'frobenius'.
+//
+// Shapes are run-time values here except the padded component count KP (16 / 32 / 48 / 64: the accumulators live in registers).
+// One iteration is four launches over row slices of every matrix (grid.x = slice, grid.y = matrix), replayed as a hipGraph:
+//   big_hht_kernel      H H^T (KP x KP, zero padded)
+//   big_pass_w_kernel   per 16-row subtile of a wave: numerator^T = H X^T accumulated over 16-channel blocks (the channel-blocked
+//                       loop: X is streamed once, H staged in LDS in blocks of CBH channels), denominator^T = (H H^T) W^T,
+//                       W <- W * num / den in the accumulator layout, one 16-byte store per lane and component block
+//   big_records_kernel  W^T X (KP x CB channels per workgroup, grid.z over channel blocks) and W^T W (the last grid.z) of the slice:
+//                       the updated rows of W and the rows of X staged per wave in LDS and read back transposed (the contraction
+//                       runs over rows here); the four waves' accumulators summed in wave order -> the slice's record
+//   big_hupdate_kernel  records summed in slice order, H <- H * (W^T X) / ((W^T W) H), 64 channels per workgroup
+// and the residual (stop rule every check_every iterations, reconstruction_err_, per-column SSE for VAF) is
+//   big_resid_kernel    R = X - W H per 16-channel block on the pipe, per-column sums reduced over the rows of the subtile by
+//                       cross-lane adds, accumulated per wave in LDS, summed in wave order -> the slice's column record
+//   big_resid_finalize_kernel   (= wide_resid_finalize_kernel with the column buffer sized at run time)
+// All four contractions use v_mfma_f32_16x16x4_f32 / v_mfma_f64_16x16x4_f64 with the operand conventions of nmf_wide.hpp
+// (A: lane (i, g) <-> A[i][g], B: lane (j, g) <-> B[g][j], D: lane (j, g), register r <-> D[4 g + r][j] once the rows of A are
+// permuted by WideMma::arow).  X is read twice per iteration (update pass, record pass) and W written once and read twice:
+// (8 m + 12 k) sizeof bytes per row against the 4 m + 8 k of the one-pass kernels -- the price of accumulators that no longer
+// fit one wave; with k >= 16 the arithmetic intensity (~k flop / byte) keeps the pipe, not the stream, the bound.
+// Every sum has a fixed order (slices in order, waves in order, lanes by a fixed butterfly): results are bitwise reproducible.
+#pragma once
+#include "nmf_wide.hpp"
+
+namespace hipnmf {
+
+template <typename real>
+struct BigArgs {
+  const real* X;  // row-major [T][ldx], rows 16-byte aligned
+  long long x_bstride, ldx;
+  real* W;  // row-major [T][KP] (components >= k are zero and stay zero)
+  long long w_bstride;
+  real* H;            // [B][k][m]
+  real* HHt;          // [B][KP][KP]
+  real* part;         // [B][S][REC]  REC = KP MP + KP KP: [W^T X | W^T W] per slice
+  real* colpart;      // [B][S][2 MP] sse | xsq per slice
+  const real* state;  // [B][8]: entry 3 != 0 = matrix converged (its workgroups return at once), or nullptr
+  int T, m, k, KP, MP, xchunks;  // xchunks: 16-byte pieces of a row of X that hold data
+  int S, rows_per_slice;
+  int CBH;  // channels of H staged in LDS at a time (a multiple of 16; MP when all of H fits)
+  real l1w, l2w;
+};
+
+constexpr int BIG_CB = 64;  // channels per workgroup of the record kernel
+
+// 16 bytes = VEC consecutive elements of a row, or zeros
+template <typename real>
+__device__ __forceinline__ void big_load4(const real* __restrict__ row, int col, bool ok, real (&out)[4]) {
+  if (ok) {
+    __builtin_memcpy(out, __builtin_assume_aligned(row + col, 16), 4 * sizeof(real));
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[r] = (real)0;
+  }
+}
+
+// H H^T, zero padded to KP x KP.  One workgroup per matrix; every entry summed over the channels in order by one thread.
+template <typename real>
+__global__ void __launch_bounds__(256) big_hht_kernel(BigArgs<real> a) {
+  const int b = blockIdx.x;
+  if (a.state && a.state[(long long)b * 8 + 3] != (real)0) return;
+  const real* __restrict__ Hb = a.H + (long long)b * a.k * a.m;
+  real* __restrict__ out = a.HHt + (long long)b * a.KP * a.KP;
+  for (int idx = threadIdx.x; idx < a.KP * a.KP; idx += blockDim.x) {
+    const int c = idx / a.KP, c2 = idx % a.KP;
+    real s = (real)0;
+    if (c < a.k && c2 < a.k) {
+      const real* __restrict__ h1 = Hb + (long long)c * a.m;
+      const real* __restrict__ h2 = Hb + (long long)c2 * a.m;
+      for (int jj = 0; jj < a.m; ++jj) s = fma_(h1[jj], h2[jj], s);
+    }
+    out[idx] = s;
+  }
+}
+
+// rows [row_begin, row_end) of matrix b handled by slice blockIdx.x
+template <typename real>
+__device__ __forceinline__ void big_slice(const BigArgs<real>& a, int& row_begin, int& row_end) {
+  row_begin = (int)blockIdx.x * a.rows_per_slice;
+  row_end = row_begin + a.rows_per_slice;
+  if (row_end > a.T) row_end = a.T;
+}
+
+// stages H[:, cb0 .. cb0 + CBH) (zero beyond k x m) as sH[KP][CBH + 4]
+template <typename real>
+__device__ __forceinline__ void big_stage_h(const BigArgs<real>& a, const real* __restrict__ Hb, int cb0, real* __restrict__ sH) {
+  const int SH = a.CBH + 4;
+  for (int idx = threadIdx.x; idx < a.KP * a.CBH; idx += blockDim.x) {
+    const int c = idx / a.CBH, jj = idx % a.CBH;
+    sH[c * SH + jj] = (c < a.k && cb0 + jj < a.m) ? Hb[(long long)c * a.m + cb0 + jj] : (real)0;
+  }
+}
+
+// W <- W * (X H^T) / (W (H H^T))  (_nmf.py:540-554, 615-631) for the rows of one slice.  grid (S, B), 256 threads; dynamic LDS:
+// sH [KP][CBH + 4] + sHHt [KP][KP + 4].
+template <typename real, int KP>
+__global__ void __launch_bounds__(256) big_pass_w_kernel(BigArgs<real> a) {
+  using M = WideMma<real>;
+  using acc = typename M::acc;
+  constexpr int NKB = KP / 16, SK = KP + 4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char big_smem[];
+  const int b = blockIdx.y;
+  if (a.state && a.state[(long long)b * 8 + 3] != (real)0) return;
+  const int SH = a.CBH + 4;
+  real* const sH = reinterpret_cast<real*>(big_smem);
+  real* const sHHt = sH + KP * SH;
+  const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4, wave = tid >> 6;
+  const int ar = M::arow(j);
+  const real* __restrict__ Xb = a.X + (long long)b * a.x_bstride;
+  real* __restrict__ Wb = a.W + (long long)b * a.w_bstride;
+  const real* __restrict__ Hb = a.H + (long long)b * a.k * a.m;
+  int row_begin, row_end;
+  big_slice(a, row_begin, row_end);
+  for (int idx = tid; idx < KP * KP; idx += 256) sHHt[(idx / KP) * SK + idx % KP] = a.HHt[(long long)b * KP * KP + idx];
+  const bool h_resident = a.CBH >= a.MP;
+  if (h_resident) big_stage_h(a, Hb, 0, sH);
+  __syncthreads();
+  constexpr int V = 16 / (int)sizeof(real);  // elements per 16-byte piece
+  for (int t0 = row_begin + 16 * wave; t0 - 16 * wave < row_end; t0 += 64) {  // (all four waves make the same number of trips)
+    const int row = t0 + j;
+    const bool rok = row < row_end;
+    const real* __restrict__ xrow = Xb + (long long)row * a.ldx;
+    acc num[NKB];
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) num[kb] = acc{0, 0, 0, 0};
+    for (int cb0 = 0; cb0 < a.MP; cb0 += a.CBH) {
+      if (!h_resident) {
+        __syncthreads();
+        big_stage_h(a, Hb, cb0, sH);
+        __syncthreads();
+      }
+      const int cend = (cb0 + a.CBH < a.MP) ? cb0 + a.CBH : a.MP;
+      for (int ch = cb0; ch < cend; ch += 16) {
+        real x[4];
+        const int col = ch + 4 * g;
+        if constexpr (V == 4) {
+          big_load4<real>(xrow, col, rok && (col >> 2) < a.xchunks, x);
+        } else {  // fp64: two 16-byte pieces
+          real lo[4] = {0, 0, 0, 0};
+          if (rok && (col >> 1) < a.xchunks) __builtin_memcpy(lo, __builtin_assume_aligned(xrow + col, 16), 16);
+          if (rok && ((col + 2) >> 1) < a.xchunks) __builtin_memcpy(lo + 2, __builtin_assume_aligned(xrow + col + 2, 16), 16);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) x[r] = lo[r];
+        }
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+          real ha[4];
+          wide_lds_read<real, 4>(sH + (16 * kb + ar) * SH + (ch - cb0) + 4 * g, ha);
+#pragma unroll
+          for (int s = 0; s < 4; ++s) num[kb] = M::mma(ha[s], x[s], num[kb]);
+        }
+      }
+    }
+    // W fragment: lane (row j, g) <-> components 16 kb + 4 g .. + 3; register s is the B operand of k-step s
+    real w[NKB][4];
+    real* __restrict__ wrow = Wb + (long long)row * KP;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+      if (rok) {
+        __builtin_memcpy(w[kb], __builtin_assume_aligned(wrow + 16 * kb + 4 * g, 16), 4 * sizeof(real));
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) w[kb][r] = (real)0;
+      }
+    }
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+      acc den = acc{0, 0, 0, 0};
+#pragma unroll
+      for (int kb2 = 0; kb2 < NKB; ++kb2) {
+        real ha[4];
+        wide_lds_read<real, 4>(sHHt + (16 * kb + ar) * SK + 16 * kb2 + 4 * g, ha);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) den = M::mma(ha[s], w[kb2][s], den);
+      }
+      real wn[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        real d = den[r];
+        if (a.l1w > (real)0) d = d + a.l1w;
+        if (a.l2w > (real)0) d = d + a.l2w * w[kb][r];
+        d = (d == (real)0) ? eps_val<real>() : d;
+        wn[r] = w[kb][r] * (num[kb][r] / d);
+      }
+      if (rok) __builtin_memcpy(__builtin_assume_aligned(wrow + 16 * kb + 4 * g, 16), wn, 4 * sizeof(real));
+    }
+  }
+}
+
+// Record of a slice: W^T X for the CB channels [z CB, ...) (z < nz - 1) or W^T W (z = nz - 1).  grid (S, B, nz), 256 threads;
+// dynamic LDS: per wave a W stage [16][KP + 4] and a B-source stage [16][CB + 4], then (reused) the reduction buffer.
+template <typename real, int KP>
+__global__ void __launch_bounds__(256) big_records_kernel(BigArgs<real> a) {
+  using M = WideMma<real>;
+  using acc = typename M::acc;
+  constexpr int NKB = KP / 16, CB = BIG_CB, NCB = CB / 16, SWs = KP + 4, SXs = CB + 4;
+  constexpr int PERWAVE = 16 * SWs + 16 * SXs;
+  extern __shared__ __attribute__((aligned(16))) unsigned char big_smem[];
+  const int b = blockIdx.y;
+  if (a.state && a.state[(long long)b * 8 + 3] != (real)0) return;
+  real* const smem = reinterpret_cast<real*>(big_smem);
+  const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4, wave = tid >> 6;
+  const int ar = M::arow(j);
+  real* const wst = smem + wave * PERWAVE;
+  real* const xst = wst + 16 * SWs;
+  const bool is_wtw = (int)blockIdx.z == (int)gridDim.z - 1;
+  const real* __restrict__ Wb = a.W + (long long)b * a.w_bstride;
+  // the B operand's source: a block of CB channels of X, or W itself (W^T W)
+  const real* __restrict__ src = is_wtw ? Wb : a.X + (long long)b * a.x_bstride;
+  const long long src_ld = is_wtw ? (long long)KP : a.ldx;
+  const int src_col0 = is_wtw ? 0 : (int)blockIdx.z * CB;
+  const int src_pieces = is_wtw ? KP / (16 / (int)sizeof(real)) : a.xchunks;  // valid 16-byte pieces per source row
+  constexpr int V = 16 / (int)sizeof(real);
+  int row_begin, row_end;
+  big_slice(a, row_begin, row_end);
+  acc accu[NKB][NCB];
+#pragma unroll
+  for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) accu[kb][cb] = acc{0, 0, 0, 0};
+  for (int t0 = row_begin + 16 * wave; t0 < row_end; t0 += 64) {
+    const int row = t0 + j;
+    const bool rok = row < row_end;
+    // stage: lane (row j, g) brings 16-byte pieces of its row of W and of the source block
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+      real w4[4];
+      big_load4<real>(Wb + (long long)row * KP, 16 * kb + 4 * g, rok, w4);  // (fp64: 32 bytes, two aligned halves)
+      wide_lds_write<real, 4>(wst + j * SWs + 16 * kb + 4 * g, w4);
+    }
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+      const int col = src_col0 + 16 * cb + 4 * g;
+      real x4[4] = {0, 0, 0, 0};
+      if constexpr (V == 4) {
+        big_load4<real>(src + (long long)row * src_ld, col, rok && (col >> 2) < src_pieces, x4);
+      } else {
+        const real* p = src + (long long)row * src_ld + col;
+        if (rok && (col >> 1) < src_pieces) __builtin_memcpy(x4, __builtin_assume_aligned(p, 16), 16);
+        if (rok && ((col + 2) >> 1) < src_pieces) __builtin_memcpy(x4 + 2, __builtin_assume_aligned(p + 2, 16), 16);
+      }
+      wide_lds_write<real, 4>(xst + j * SXs + 16 * cb + 4 * g, x4);
+    }
+    wide_wave_lds_fence();
+    // contraction over the 16 rows: k-step s covers rows 4 s + g' (g' = the lane's g)
+    real av[NKB][4], bv[NCB][4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb) av[kb][s] = wst[(4 * s + g) * SWs + 16 * kb + ar];
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) bv[cb][s] = xst[(4 * s + g) * SXs + 16 * cb + j];
+    }
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) accu[kb][cb] = M::mma(av[kb][s], bv[cb][s], accu[kb][cb]);
+    wide_wave_lds_fence();
+  }
+  // the four waves' tiles summed in wave order; D: lane (j, g), register r <-> [component 16 kb + 4 g + r][channel 16 cb + j]
+  __syncthreads();
+  real* const red = smem;  // [4][KP][CB]
+#pragma unroll
+  for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[(wave * KP + 16 * kb + 4 * g + r) * CB + 16 * cb + j] = accu[kb][cb][r];
+  __syncthreads();
+  const int rec = KP * a.MP + KP * KP;
+  real* __restrict__ out = a.part + ((long long)b * a.S + blockIdx.x) * rec;
+  const int ncols = is_wtw ? KP : (a.MP - src_col0 < CB ? a.MP - src_col0 : CB);
+  for (int idx = tid; idx < KP * CB; idx += 256) {
+    const int c = idx / CB, jj = idx % CB;
+    if (jj < ncols) {
+      const real s = ((red[idx] + red[KP * CB + idx]) + red[2 * KP * CB + idx]) + red[3 * KP * CB + idx];
+      if (is_wtw)
+        out[KP * a.MP + c * KP + jj] = s;
+      else
+        out[c * a.MP + src_col0 + jj] = s;
+    }
+  }
+}
+
+// H <- H * (W^T X) / ((W^T W) H)  (_nmf.py:638-640, 701-728): records summed in slice order.  grid (B, ceil(m / 64)), 256 threads;
+// dynamic LDS: sB [k][k] + sNum [k][64] + sH [k][64].
+template <typename real>
+struct BigHArgs {
+  real* H;
+  const real* part;
+  const real* state;
+  int m, k, KP, MP, S;
+  real l1h, l2h;
+};
+template <typename real>
+__global__ void __launch_bounds__(256) big_hupdate_kernel(BigHArgs<real> a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char big_smem[];
+  const int b = blockIdx.x, tid = threadIdx.x, c0 = (int)blockIdx.y * 64;
+  if (a.state && a.state[(long long)b * 8 + 3] != (real)0) return;
+  const int k = a.k, ncol = (a.m - c0 < 64) ? a.m - c0 : 64;
+  real* const sB = reinterpret_cast<real*>(big_smem);  // [k][k]
+  real* const sNum = sB + k * k;                       // [k][64]
+  real* const sHo = sNum + k * 64;                     // [k][64] the old H
+  const int rec = a.KP * a.MP + a.KP * a.KP;
+  const real* __restrict__ pb = a.part + (long long)b * a.S * rec;
+  real* __restrict__ Hb = a.H + (long long)b * k * a.m;
+  for (int idx = tid; idx < k * k; idx += 256) {
+    const int off = a.KP * a.MP + (idx / k) * a.KP + idx % k;
+    real s = (real)0;
+    for (int q = 0; q < a.S; ++q) s += pb[(long long)q * rec + off];
+    sB[idx] = s;
+  }
+  for (int idx = tid; idx < k * ncol; idx += 256) {
+    const int c = idx / ncol, jj = idx % ncol;
+    const int off = c * a.MP + c0 + jj;
+    real s = (real)0;
+    for (int q = 0; q < a.S; ++q) s += pb[(long long)q * rec + off];
+    sNum[c * 64 + jj] = s;
+    sHo[c * 64 + jj] = Hb[(long long)c * a.m + c0 + jj];
+  }
+  __syncthreads();
+  for (int idx = tid; idx < k * ncol; idx += 256) {
+    const int c = idx / ncol, jj = idx % ncol;
+    real d = sB[c * k] * sHo[jj];
+    for (int c2 = 1; c2 < k; ++c2) d = fma_(sB[c * k + c2], sHo[c2 * 64 + jj], d);
+    const real hold = sHo[c * 64 + jj];
+    if (a.l1h > (real)0) d = d + a.l1h;
+    if (a.l2h > (real)0) d = d + a.l2h * hold;
+    d = (d == (real)0) ? eps_val<real>() : d;
+    Hb[(long long)c * a.m + c0 + jj] = hold * (sNum[c * 64 + jj] / d);
+  }
+}
+
+// per-column sum((X - W H)^2) | sum(X^2) of one slice.  grid (S, B), 256 threads; dynamic LDS: sH [KP][CBH + 4] + per-wave
+// column accumulators [4][2 MP].
+template <typename real, int KP>
+__global__ void __launch_bounds__(256) big_resid_kernel(BigArgs<real> a) {
+  using M = WideMma<real>;
+  using acc = typename M::acc;
+  constexpr int NKB = KP / 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char big_smem[];
+  const int b = blockIdx.y;
+  if (a.state && a.state[(long long)b * 8 + 3] != (real)0) return;
+  const int SH = a.CBH + 4;
+  real* const sH = reinterpret_cast<real*>(big_smem);
+  real* const cols = sH + KP * SH;  // [4][2 MP]
+  const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4, wave = tid >> 6;
+  const int ar = M::arow(j);
+  const real* __restrict__ Xb = a.X + (long long)b * a.x_bstride;
+  const real* __restrict__ Wb = a.W + (long long)b * a.w_bstride;
+  const real* __restrict__ Hb = a.H + (long long)b * a.k * a.m;
+  int row_begin, row_end;
+  big_slice(a, row_begin, row_end);
+  for (int idx = tid; idx < 4 * 2 * a.MP; idx += 256) cols[idx] = (real)0;
+  const bool h_resident = a.CBH >= a.MP;
+  if (h_resident) big_stage_h(a, Hb, 0, sH);
+  __syncthreads();
+  constexpr int V = 16 / (int)sizeof(real);
+  real* const mycols = cols + wave * 2 * a.MP;
+  for (int cb0 = 0; cb0 < a.MP; cb0 += a.CBH) {
+    if (!h_resident) {
+      __syncthreads();
+      big_stage_h(a, Hb, cb0, sH);
+      __syncthreads();
+    }
+    const int cend = (cb0 + a.CBH < a.MP) ? cb0 + a.CBH : a.MP;
+    for (int t0 = row_begin + 16 * wave; t0 < row_end; t0 += 64) {
+      const int row = t0 + j;
+      const bool rok = row < row_end;
+      real w[NKB][4];
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb) big_load4<real>(Wb + (long long)row * KP, 16 * kb + 4 * g, rok, w[kb]);
+      const real* __restrict__ xrow = Xb + (long long)row * a.ldx;
+      for (int ch = cb0; ch < cend; ch += 16) {
+        // R^T block: A = H^T (channel 16-block x components), B = the W fragment; D: lane (row j, g), register r <-> channel ch + 4 g + r
+        acc rec = acc{0, 0, 0, 0};
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) rec = M::mma(sH[(16 * kb + 4 * g + s) * SH + (ch - cb0) + ar], w[kb][s], rec);
+        real x[4] = {0, 0, 0, 0};
+        const int col = ch + 4 * g;
+        if constexpr (V == 4) {
+          big_load4<real>(xrow, col, rok && (col >> 2) < a.xchunks, x);
+        } else {
+          if (rok && (col >> 1) < a.xchunks) __builtin_memcpy(x, __builtin_assume_aligned(xrow + col, 16), 16);
+          if (rok && ((col + 2) >> 1) < a.xchunks) __builtin_memcpy(x + 2, __builtin_assume_aligned(xrow + col + 2, 16), 16);
+        }
+        real sse[4], xsq[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const real d = x[r] - rec[r];
+          sse[r] = d * d;
+          xsq[r] = x[r] * x[r];
+        }
+        // sum over the 16 rows of the subtile (lanes j = 0 .. 15 of the same g): a fixed butterfly
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            sse[r] += __shfl_xor(sse[r], off, 64);
+            xsq[r] += __shfl_xor(xsq[r], off, 64);
+          }
+        if (j == 0) {  // one lane per 4 channels adds the subtile's sums to the wave's column accumulators (program order)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            mycols[col + r] += sse[r];
+            mycols[a.MP + col + r] += xsq[r];
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  real* __restrict__ out = a.colpart + ((long long)b * a.S + blockIdx.x) * 2 * a.MP;
+  for (int idx = tid; idx < 2 * a.MP; idx += 256)
+    out[idx] = ((cols[idx] + cols[2 * a.MP + idx]) + cols[4 * a.MP + idx]) + cols[6 * a.MP + idx];
+}
+
+// wide_resid_finalize_kernel with the column buffer in dynamic LDS (2 MP values): error, stop rule (_nmf.py:872-884), outputs
+template <typename real>
+__global__ void __launch_bounds__(1024) big_resid_finalize_kernel(WideSliceArgs<real> a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char big_smem[];
+  real* const cols = reinterpret_cast<real*>(big_smem);
+  const int b = blockIdx.x, tid = threadIdx.x;
+  real* st = a.state + (long long)b * 8;
+  const bool done = st[3] != (real)0;
+  if (done && a.it != -1) return;
+  wide_sum_slices<real>(a.colpart + (long long)b * a.S * 2 * a.MP, 2 * a.MP, a.S, cols);
+  __syncthreads();
+  if (tid == 0) {
+    real tot = (real)0;
+    for (int jj = 0; jj < a.MP; ++jj) tot += cols[jj];
+    const real err = sqrt_(tot);
+    if (a.it == 0) {
+      st[0] = err;
+      st[1] = err;
+    } else if (a.it == 1) {
+      st[4] += (real)1;
+      if ((st[1] - err) / st[0] < a.tol) {
+        st[3] = (real)1;
+        st[5] = st[4] * (real)a.check_every;  // n_iter_ of this matrix
+      }
+      st[1] = err;
+    } else {
+      if (a.err_out) a.err_out[b] = err;
+      if (a.n_iter_out) a.n_iter_out[b] = done ? (int)st[5] : a.max_iter;
+    }
+    st[2] = err;
+  }
+  if (a.it == -1) {
+    for (int jj = tid; jj < a.m; jj += blockDim.x) {
+      if (a.sse_col_out) a.sse_col_out[(long long)b * a.m + jj] = cols[jj];
+      if (a.xsq_col_out) a.xsq_col_out[(long long)b * a.m + jj] = cols[a.MP + jj];
+    }
+  }
+}
+
+}  // namespace hipnmf

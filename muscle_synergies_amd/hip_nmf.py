@@ -96,8 +96,8 @@ class HipNMF:
         return f"HipNMF(n_components={self.n_components!r}, init={self.init!r}, tol={self.tol!r}, max_iter={self.max_iter!r})"
 
     # -- validation --------------------------------------------------------------------------------
-    MAX_FEATURES = 128   # widest instance compiled into libhip_nmf.so (nmf_wide.hpp; HIPNMF_ERR_UNSUPPORTED beyond)
-    MAX_COMPONENTS = 32  # (float64 beyond 16 components: up to 64 channels; the library says UNSUPPORTED otherwise)
+    MAX_FEATURES = 512   # widest shape compiled into libhip_nmf.so (nmf_big.hpp: the general-shape kernels beyond the 128 x 32 of
+    MAX_COMPONENTS = 64  # nmf_wide.hpp; HIPNMF_ERR_UNSUPPORTED beyond, and for the Kullback-Leibler loss beyond 128 x 32)
 
     @staticmethod
     def supports(solver="cd", beta_loss="frobenius", n_features=None, n_components=None, **_ignored) -> bool:

@@ -1,0 +1,133 @@
+"""GPU parity of the general-shape kernels (csrc/nmf_big.hpp): more than 128 channels or 32 components, and float64 with more
+than 16 components on more than 64 channels -- every shape the reference's validation accepts (analysis.py:829-846) up to
+512 x 64 -- against the NumPy restatement of sklearn's loop (_nmf.py:540-554, 638-640, 827-884), through the same host API."""
+import numpy as np
+import pytest
+
+from oracle import nmf_mu_oracle as orc
+from muscle_synergies_amd.synth import emg_matrix, random_init
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _rel(X, W, H, ref):
+    xn = np.linalg.norm(X.astype(np.float64))
+    return np.linalg.norm(W.astype(np.float64) @ H.astype(np.float64) - ref["W"].astype(np.float64) @ ref["H"].astype(np.float64)) / xn
+
+
+def _case(T, m, k, dtype, seed=0):
+    X = emg_matrix(seed, T=T, m=m, k_true=min(8, m), dtype=dtype)
+    W0, H0 = random_init(X, k, seed)
+    return X, W0, H0
+
+
+def _last_kernel():
+    from muscle_synergies_amd import _lib
+
+    return _lib.get_handle(0).last_kernel()
+
+
+SHAPES = [(200, 12), (256, 16), (129, 3), (512, 64), (300, 40), (40, 33), (130, 17), (384, 7), (144, 48), (500, 1)]
+
+
+@pytest.mark.parametrize("m,k", SHAPES)
+@pytest.mark.parametrize("T", [7, 64, 333, 1100])
+def test_big_shape_sweep_fp32(m, k, T):
+    import muscle_synergies_amd as ms
+
+    if k > min(T, m):
+        pytest.skip("n_components > min(n_samples, n_features)")
+    X, W0, H0 = _case(T, m, k, np.float32, seed=m + k)
+    ref = orc.nmf_mu_fit(X, W0, H0, max_iter=15, tol=0.0)
+    for layout in ("F", "C"):
+        Xl = np.asfortranarray(X) if layout == "F" else np.ascontiguousarray(X)
+        res = ms.fit_batched(Xl, W0, H0, max_iter=15, tol=0.0)
+        assert _last_kernel().startswith("big_pass_w_kernel<float"), _last_kernel()
+        assert int(res.n_iter[0]) == 15
+        assert _rel(X, res.W[0], res.H[0], ref) <= TOL, (layout, m, k, T)
+        assert abs(float(res.reconstruction_err[0]) - float(ref["reconstruction_err"])) / np.linalg.norm(X) <= TOL
+        np.testing.assert_allclose(res.W[0], ref["W"], rtol=1e-3, atol=1e-6)
+        np.testing.assert_allclose(res.H[0], ref["H"], rtol=1e-3, atol=1e-6)
+        assert (res.W[0] >= 0).all() and (res.H[0] >= 0).all()
+        va, vc = orc.vaf(X.astype(np.float64), ref["W"].astype(np.float64), ref["H"].astype(np.float64))
+        assert abs(res.vaf[0, 0] - va) <= TOL
+        np.testing.assert_allclose(res.vaf[0, 1:], vc, atol=5e-5)
+
+
+@pytest.mark.parametrize("m,k,T", [(200, 12, 700), (256, 16, 500), (128, 24, 900), (96, 24, 640), (512, 64, 300), (65, 17, 130), (130, 33, 257)])
+def test_big_shape_sweep_fp64(m, k, T):
+    """Includes float64 with more than 16 components on 65..128 channels: the shapes whose 16x16x4 instance does not fit LDS."""
+    import muscle_synergies_amd as ms
+
+    X, W0, H0 = _case(T, m, k, np.float64, seed=9)
+    ref = orc.nmf_mu_fit(X, W0, H0, max_iter=40, tol=0.0)
+    for layout in ("F", "C"):
+        Xl = np.asfortranarray(X) if layout == "F" else np.ascontiguousarray(X)
+        res = ms.fit_batched(Xl, W0, H0, max_iter=40, tol=0.0)
+        assert _last_kernel().startswith("big_pass_w_kernel<double"), _last_kernel()
+        np.testing.assert_allclose(res.W[0], ref["W"], rtol=1e-9, atol=1e-13)
+        np.testing.assert_allclose(res.H[0], ref["H"], rtol=1e-9, atol=1e-13)
+        np.testing.assert_allclose(res.reconstruction_err[0], ref["reconstruction_err"], rtol=1e-9)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_big_stop_rule_batch_regularisation_and_transform(dtype):
+    import muscle_synergies_amd as ms
+
+    m, k = 200, 12
+    Xs, Ws, Hs, refs = [], [], [], []
+    for s in range(4):
+        X, W0, H0 = _case(520, m, k, dtype, seed=60 + s)
+        Xs.append(X), Ws.append(W0), Hs.append(H0)
+        refs.append(orc.nmf_mu_fit(X, W0, H0, max_iter=300, tol=1e-3 if s % 2 else 3e-4))
+    for tol, sel in ((1e-3, [1, 3]), (3e-4, [0, 2])):  # sklearn's stop rule per matrix of a batch (_nmf.py:872-884)
+        res = ms.fit_batched(np.stack([Xs[i] for i in sel]), np.stack([Ws[i] for i in sel]), np.stack([Hs[i] for i in sel]),
+                             max_iter=300, tol=tol)
+        for q, i in enumerate(sel):
+            assert int(res.n_iter[q]) == refs[i]["n_iter"], (i, int(res.n_iter[q]), refs[i]["n_iter"])
+            assert _rel(Xs[i], res.W[q], res.H[q], refs[i]) <= (TOL if dtype == np.float32 else 1e-9)
+    X, W0, H0 = Xs[0], Ws[0], Hs[0]
+    regs = dict(l1_reg_W=0.02, l1_reg_H=0.03, l2_reg_W=0.05, l2_reg_H=0.01)
+    Wr, Hr, _ = orc.fit_multiplicative_update(X, W0.copy(), H0.copy(), max_iter=30, tol=0.0, **regs)
+    res = ms.fit_batched(X, W0, H0, max_iter=30, tol=0.0, **regs)
+    assert _rel(X, res.W[0], res.H[0], {"W": Wr, "H": Hr}) <= (TOL if dtype == np.float32 else 1e-9)
+    Wt = np.full_like(W0, np.sqrt(X.mean() / k))
+    Wt_ref, _, _ = orc.fit_multiplicative_update(X, Wt.copy(), Hr.copy(), max_iter=25, tol=0.0, update_H=False)
+    res_t = ms.fit_batched(X, Wt, Hr, max_iter=25, tol=0.0, update_H=False)
+    np.testing.assert_array_equal(res_t.H[0], Hr)
+    np.testing.assert_allclose(res_t.W[0], Wt_ref, rtol=1e-3 if dtype == np.float32 else 1e-9, atol=1e-7)
+
+
+def test_big_long_frame_is_sliced_over_the_chip_and_deterministic():
+    """One HD-EMG sized frame: 256 channels x 20 000 samples, 16 synergies, 200 iterations; twice, bitwise equal."""
+    import muscle_synergies_amd as ms
+
+    X, W0, H0 = _case(20_000, 256, 16, np.float32, seed=3)
+    r1 = ms.fit_batched(np.ascontiguousarray(X), W0, H0, max_iter=200, tol=0.0)
+    r2 = ms.fit_batched(np.ascontiguousarray(X), W0, H0, max_iter=200, tol=0.0)
+    assert np.array_equal(r1.W, r2.W) and np.array_equal(r1.H, r2.H)
+    ref = orc.nmf_mu_fit(X, W0, H0, max_iter=200, tol=0.0)
+    assert _rel(X, r1.W[0], r1.H[0], ref) <= TOL
+    assert abs(float(r1.reconstruction_err[0]) - float(ref["reconstruction_err"])) / np.linalg.norm(X) <= TOL
+
+
+def test_find_synergies_on_an_hd_emg_grid_stays_on_the_gpu():
+    """find_synergies(df, 4, 6, solver='mu') on 256 channels: HipNMF models, device NNDSVDa, no scikit-learn fallback warning."""
+    import warnings
+
+    import pandas as pd
+
+    import muscle_synergies_amd as ms
+
+    X = emg_matrix(12, T=1500, m=256, k_true=5, dtype=np.float64)
+    df = pd.DataFrame(X, columns=[f"e{j}" for j in range(256)])
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", category=RuntimeWarning)
+        res = ms.find_synergies(df, 4, 6, solver="mu", max_iter=80, tol=0.0, init="random", random_state=1)
+    assert all(isinstance(mdl, ms.HipNMF) for mdl in res.model.values())
+    assert res.components[6].shape == (6, 256) and res.vaf_values.shape == (3, 257)
+    W0, H0 = random_init(X, 5, 1)  # the same call by hand against the oracle (random_state=1 draws H then W per rank: use custom)
+    r = ms.fit_batched(X, W0, H0, max_iter=80, tol=0.0)
+    ref = orc.nmf_mu_fit(X, W0, H0, max_iter=80, tol=0.0)
+    np.testing.assert_allclose(r.H[0], ref["H"], rtol=1e-9, atol=1e-13)

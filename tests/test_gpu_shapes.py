@@ -243,8 +243,8 @@ def test_bad_arguments_are_reported():
         p = make_problem(1, 10, 8, 2, **kwargs)
         assert lib.hipnmf_fit_batched_f32(h.ptr, ctypes.byref(p), d.data_ptr(), d.data_ptr(), d.data_ptr(), None, None,
                                           None, None) == code
-    big = torch.zeros(10 * 129, device="cuda")
-    for m, k in ((129, 2), (40, 33)):  # beyond the widest instances (128 channels, 32 components)
+    big = torch.zeros(10 * 600, device="cuda")
+    for m, k in ((513, 2), (80, 65)):  # beyond the general-shape kernels (512 channels, 64 components)
         p = make_problem(1, 10, m, k, x_layout=_lib.X_ROW_MAJOR, ldx=m, x_batch_stride=10 * m)
         assert lib.hipnmf_fit_batched_f32(h.ptr, ctypes.byref(p), big.data_ptr(), big.data_ptr(), big.data_ptr(), None, None, None,
                                           None) == _lib.HIPNMF_ERR_UNSUPPORTED

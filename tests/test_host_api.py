@@ -60,31 +60,32 @@ def test_mu_without_gpu_fails_loudly(V):
 
 
 def test_mu_outside_the_compiled_shapes_falls_back_to_sklearn():
-    """The reference works for any shape (analysis.py:862-863); solver='mu' with more than 128 channels or more than
-    32 synergies is outside the compiled kernels (narrow lane mappings up to 32 x 8, matrix-pipe instances up to
-    128 x 32) and must reach scikit-learn, not an engine error."""
+    """The reference works for any shape (analysis.py:862-863); solver='mu' with more than 512 channels or more than
+    64 synergies is outside the compiled kernels (narrow lane mappings up to 32 x 8, matrix-pipe instances up to
+    128 x 32, the general-shape kernels up to 512 x 64) and must reach scikit-learn, not an engine error."""
     pytest.importorskip("sklearn")
     rng = np.random.default_rng(5)
-    wide = pd.DataFrame(rng.random((60, 129)), columns=[f"ch{j}" for j in range(129)])
+    wide = pd.DataFrame(rng.random((60, 513)), columns=[f"ch{j}" for j in range(513)])
     with pytest.warns(RuntimeWarning, match="outside the HIP engine's compiled shapes"):
         with warnings.catch_warnings():
             warnings.simplefilter("ignore", category=Warning)
             warnings.simplefilter("always", category=RuntimeWarning)
             res = ms.find_synergies(wide, 3, solver="mu", init="nndsvda", max_iter=20, tol=0)
     assert type(res.model).__module__.startswith("sklearn") and res.model.solver == "mu"
-    assert res.components.shape == (3, 129)
-    narrow = pd.DataFrame(rng.random((60, 40)), columns=[f"ch{j}" for j in range(40)])
+    assert res.components.shape == (3, 513)
+    narrow = pd.DataFrame(rng.random((90, 80)), columns=[f"ch{j}" for j in range(80)])
     with pytest.warns(RuntimeWarning):
         with warnings.catch_warnings():
             warnings.simplefilter("ignore", category=Warning)
             warnings.simplefilter("always", category=RuntimeWarning)
-            res = ms.find_synergies(narrow, 33, solver="mu", init="random", random_state=0, max_iter=20, tol=0)
+            res = ms.find_synergies(narrow, 65, solver="mu", init="random", random_state=0, max_iter=20, tol=0)
     assert type(res.model).__module__.startswith("sklearn")
     assert ms.HipNMF.supports(solver="mu", n_features=32, n_components=8)
     assert ms.HipNMF.supports(solver="mu", n_features=33, n_components=8)
     assert ms.HipNMF.supports(solver="mu", n_features=128, n_components=32)
-    assert not ms.HipNMF.supports(solver="mu", n_features=129, n_components=8)
-    assert not ms.HipNMF.supports(solver="mu", n_features=64, n_components=33)
+    assert ms.HipNMF.supports(solver="mu", n_features=512, n_components=64)
+    assert not ms.HipNMF.supports(solver="mu", n_features=513, n_components=8)
+    assert not ms.HipNMF.supports(solver="mu", n_features=80, n_components=65)
     assert not ms.HipNMF.supports(solver="cd", n_features=8, n_components=2)
 
 
