@@ -220,15 +220,20 @@ def test_wide_kl_through_the_estimator():
 @pytest.mark.parametrize("m,k,T", [(24, 20, 200), (40, 32, 333), (64, 17, 1001), (128, 32, 150), (48, 24, 64)])
 def test_wide_17_to_32_components(dtype, m, k, T):
     """17..32 components (two 16-component blocks on the matrix pipe), Frobenius and Kullback-Leibler, both layouts;
-    float64 beyond 64 channels does not fit LDS in this configuration and is refused (HIPNMF_ERR_UNSUPPORTED)."""
+    float64 beyond 64 channels does not fit LDS in this configuration: since round 4 the general-shape kernels (nmf_big.hpp)
+    take it (Frobenius; Kullback-Leibler there is refused, HIPNMF_ERR_UNSUPPORTED)."""
     import muscle_synergies_amd as ms
     from muscle_synergies_amd import _lib
 
     X, W0, H0 = _case(T, m, k, dtype, seed=3 * m + k)
     if dtype == np.float64 and m > 64:
+        ref = orc.nmf_mu_fit(X, W0, H0, max_iter=25, tol=0.0)
+        res = ms.fit_batched(X, W0, H0, max_iter=25, tol=0.0)
+        assert _last_kernel().startswith("big_pass_w_kernel<double,32>"), _last_kernel()
+        assert _rel(X, res.W[0], res.H[0], ref) <= 1e-9
         with pytest.raises(_lib.HipNmfError) as e:
-            ms.fit_batched(X, W0, H0, max_iter=5, tol=0.0)
-        assert e.value.code == _lib.HIPNMF_ERR_UNSUPPORTED and "LDS" in str(e.value)
+            ms.fit_batched(X, W0, H0, max_iter=5, tol=0.0, beta_loss="kullback-leibler")
+        assert e.value.code == _lib.HIPNMF_ERR_UNSUPPORTED and "not compiled" in str(e.value)
         return
     ref = orc.nmf_mu_fit(X, W0, H0, max_iter=25, tol=0.0)
     tol = TOL if dtype == np.float32 else 1e-9
