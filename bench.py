@@ -37,8 +37,8 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md:36); 6290 GB/s measured copy
 FP32_PEAK_TFLOPS = 157.3   # fp32 vector = fp32 matrix peak (MI355X_MICROARCH.md:41-42)
-STREAM_PEAK_GBS = 7800.0   # measured: 256 workgroups re-reading "their" 640 KB region (tools/ubench/mall_stream.hip,
-                           # profiles/README.md): 7.2 - 8.1 TB/s whatever the loads in flight -- the roof that binds
+STREAM_PEAK_GBS = 7800.0   # fallback only: the ceiling is MEASURED in the run (hipnmf_diag_stream_gbs: one workgroup per CU re-reading
+                           # "its" 640 KB region, no arithmetic; 7.2 - 8.1 TB/s in rounds 2-3, tools/ubench/mall_stream.hip)
 WIDE_STREAM_GBS = 5880.0   # measured: the wide-shape kernel's traffic (256 B of X non-temporal + 32 B of W read + 32 B of W written
                            # per row, 1024 matrices of 64 x 10 000) with no arithmetic: 5.85 - 5.89 TB/s; 4.97 with the default
                            # cache policy on X; X alone 6.3 (7.0 non-temporal) (tools/ubench/wide_stream.hip, profiles/r03_ubench_wide_stream.log)
@@ -271,8 +271,10 @@ def _matrix_pipe(kernel, tf, m, k):
                     "channels to a multiple of 16 (issued = useful x padding)"}
 
 
-def compute_roofline(kernel, kernel_ms, units_per_launch, T, m, k, traffic=None, moved_bytes_per_unit=None):
+def compute_roofline(kernel, kernel_ms, units_per_launch, T, m, k, traffic=None, moved_bytes_per_unit=None, stream_gbs=None):
+    """``stream_gbs``: the memory system's rate for the solver's access pattern measured in this run (None: the committed constant)."""
     fl = flops_per_unit(T, m, k)
+    peak_stream = stream_gbs if stream_gbs else STREAM_PEAK_GBS
     by = 4 * T * (m + 2 * k)  # read X once, read + write W once (SURVEY 8d)
     sec = kernel_ms * 1e-3
     tf = fl * units_per_launch / sec / 1e12
@@ -284,18 +286,21 @@ def compute_roofline(kernel, kernel_ms, units_per_launch, T, m, k, traffic=None,
         "note": ("the 256 matrices being worked on (~190 MB) sit in the 256 MiB Infinity Cache and most rows of W in "
                  "LDS, so algorithmic bytes / time may exceed the HBM line; what binds is the rate at which the XCDs "
                  "can re-read their matrices: stream_peak_gbs, measured by tools/ubench/mall_stream.hip"),
-        "stream_peak_gbs": STREAM_PEAK_GBS,
+        "stream_peak_gbs": peak_stream,
     }
     if "stream_peak_gbs" in mem:
-        mem["stream_peak_source"] = "tools/ubench/mall_stream.hip, profiles/r02_ubench_mall_stream.log (round 2, commit 6cd19eb); a constant, not re-measured in this run"
+        mem["stream_peak_source"] = ("measured in this run after the timed region: hipnmf_diag_stream_gbs (one workgroup per CU reading its "
+                                     "own region of one matrix's size, the batch's number of regions, 16-byte loads, no arithmetic)"
+                                     if stream_gbs else
+                                     "tools/ubench/mall_stream.hip, profiles/r02_ubench_mall_stream.log (round 2, commit 6cd19eb); a constant, not re-measured in this run")
     if traffic:
         mem["l2_fabric_source"] = _traffic.source  # a PMC measurement committed under profiles/, not taken in this run
         mem["l2_fabric_gbs"] = traffic / sec / 1e9
-        mem["frac_of_stream_peak"] = traffic / sec / 1e9 / STREAM_PEAK_GBS
+        mem["frac_of_stream_peak"] = traffic / sec / 1e9 / peak_stream
     elif moved_bytes_per_unit:
         mem["design_bytes_per_unit"] = moved_bytes_per_unit
         mem["design_gbs"] = moved_bytes_per_unit * units_per_launch / sec / 1e9
-        mem["frac_of_stream_peak"] = mem["design_gbs"] / STREAM_PEAK_GBS
+        mem["frac_of_stream_peak"] = mem["design_gbs"] / peak_stream
     if m > 32 or k > 8:
         # wide shapes (nmf_wide.hpp): the batch does not fit the Infinity Cache (2.56 MB of X per 64-channel matrix, one
         # matrix per workgroup, several hundred in flight) and W streams too: HBM-bound, reported against the 8 TB/s line
@@ -398,8 +403,15 @@ def run_batch(cx, single):
                                        if a.x_layout == "row" else "row-major [B][T][m]",
                                        "matrix_iterations_per_s_1gpu": other,
                                        "note": "one conversion kernel per fit inside the timed call"}
+    stream = None
+    if not single and not wide:  # the ceiling the headline kernel is priced against, measured now (after the timed region)
+        region = (4 * a.T * a.m + 1023) // 1024 * 1024
+        try:
+            stream = handle.stream_gbs(region, B, 20)
+        except Exception as e:  # noqa: BLE001 -- a diagnostic must not cost the benchmark line
+            cfg["stream_peak_error"] = str(e)
     return {"units": cx.world * B * a.iters * a.steps, "elapsed": elapsed, "scaling": "weak", "config": cfg,
-            "roofline": compute_roofline(kernel, avg_ms, units_per_launch, a.T, a.m, a.k, traffic, moved)}
+            "roofline": compute_roofline(kernel, avg_ms, units_per_launch, a.T, a.m, a.k, traffic, moved, stream)}
 
 
 # ------------------------------------------------------------------------------------------------ config 4

@@ -343,6 +343,16 @@ int hipnmf_nndsvd_write_f32(hipnmf_handle* h, const hipnmf_problem* p, const flo
 int hipnmf_nndsvd_write_f64(hipnmf_handle* h, const hipnmf_problem* p, const double* X, const double* V,
                             const double* inv_s, const double* coef, const double* fill, double eps, double* W0);
 
+/* ---- diagnostics ------------------------------------------------------------------------------------------- */
+/*
+ * Rate (GB/s) at which the memory system serves the batched solver's access pattern, measured on the spot: `regions`
+ * workgroups (one per matrix, one per CU at a time) each read their own `region_bytes` (a multiple of 1024; one matrix: 640 KB for
+ * 16 x 10 000 fp32) `passes` times with 16-byte loads, no arithmetic.  With regions >> the number of CUs the data lives in HBM
+ * and the 256 regions being read sit in the Infinity Cache -- the ceiling bench.py prices the headline kernel against
+ * (roofline.memory.stream_peak_gbs), taken in the run that quotes it.  Uses the handle's workspace (regions * region_bytes).
+ */
+int hipnmf_diag_stream_gbs(hipnmf_handle* h, int64_t region_bytes, int32_t regions, int32_t passes, double* gbs_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -44,7 +44,7 @@ EXPORTS = (
     "hipnmf_rank_sweep_stop_f32", "hipnmf_rank_sweep_stop_f64",
     "hipnmf_emg_envelope_f32", "hipnmf_emg_envelope_f64", "hipnmf_sosfilt_f32", "hipnmf_sosfilt_f64",
     "hipnmf_gram_f32", "hipnmf_gram_f64", "hipnmf_nndsvd_stats_f32", "hipnmf_nndsvd_stats_f64",
-    "hipnmf_nndsvd_write_f32", "hipnmf_nndsvd_write_f64",
+    "hipnmf_nndsvd_write_f32", "hipnmf_nndsvd_write_f64", "hipnmf_diag_stream_gbs",
 )
 
 
@@ -114,6 +114,8 @@ def _declare(lib):
     lib.hipnmf_set_async.argtypes = [vp, ip]
     lib.hipnmf_set_tuning.restype = ip
     lib.hipnmf_set_tuning.argtypes = [vp, ip, ip, ip]
+    lib.hipnmf_diag_stream_gbs.restype = ip
+    lib.hipnmf_diag_stream_gbs.argtypes = [vp, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_double)]
     for sfx in ("f32", "f64"):
         f = getattr(lib, f"hipnmf_fit_batched_{sfx}")
         f.restype = ip
@@ -208,6 +210,12 @@ class Handle:
         ms = ctypes.c_float()
         check(load().hipnmf_last_kernel_ms(self._h, ctypes.byref(ms)))
         return float(ms.value)
+
+    def stream_gbs(self, region_bytes: int, regions: int, passes: int = 20) -> float:
+        """``hipnmf_diag_stream_gbs``: the memory system's rate for the batched solver's access pattern, measured now."""
+        out = ctypes.c_double()
+        check(load().hipnmf_diag_stream_gbs(self._h, int(region_bytes), int(regions), int(passes), ctypes.byref(out)))
+        return float(out.value)
 
     def last_kernel(self) -> str:
         """Instance name of the solver kernel the last fit launched (``hipnmf_last_kernel``)."""
