@@ -38,7 +38,7 @@ extern "C" {
 #define HIPNMF_OK 0
 #define HIPNMF_ERR_BAD_ARG (-1)
 #define HIPNMF_ERR_HIP (-2)
-#define HIPNMF_ERR_UNSUPPORTED (-3) /* shape outside the compiled kernel set (m <= 128, k <= 32; shard entries m <= 32, k <= 8) */
+#define HIPNMF_ERR_UNSUPPORTED (-3) /* shape outside the compiled kernel set (m <= 512, k <= 64) or a combination it does not hold */
 #define HIPNMF_ERR_NO_DEVICE (-4)
 
 /* memory layout of one X matrix.  Either is accepted everywhere; which one the kernels stream WITHOUT a one-off
@@ -65,8 +65,8 @@ typedef struct hipnmf_problem {
   int32_t struct_size;    /* = sizeof(hipnmf_problem), ABI guard                                       */
   int32_t batch;          /* B  >= 1 independent factorisations                                        */
   int64_t n_samples;      /* T  rows of X (time samples)                                               */
-  int32_t n_features;     /* m  columns of X (muscles), 1..128 (time-shard entry points: 1..32)        */
-  int32_t n_components;   /* k  rank, 1..32 (time-shard entry points: 1..8)                            */
+  int32_t n_features;     /* m  columns of X (muscles), 1..512                                         */
+  int32_t n_components;   /* k  rank, 1..64                                                            */
   int32_t x_layout;       /* HIPNMF_X_*                                                                */
   int32_t update_h;       /* 1: fit (W and H updated, _nmf.py:854); 0: transform (H fixed, :1736-1763) */
   int32_t w_layout;       /* HIPNMF_W_*                                                                */
@@ -125,8 +125,9 @@ int hipnmf_set_tuning(hipnmf_handle* h, int threads, int max_slices, int variant
  * sse_col_out [B][m]  per-column sum((X - W H)^2)  -> VAF numerators (analysis.py:660-662), or NULL
  * xsq_col_out [B][m]  per-column sum(X^2)          -> VAF denominators (analysis.py:654-656), or NULL
  *
- * Shapes: any 1 <= n_components <= 32, n_features <= 128 (the reference accepts any n <= m, analysis.py:829-846); float64
- * with more than 16 components on more than 64 channels is HIPNMF_ERR_UNSUPPORTED.  Layouts used in place (anything
+ * Shapes: any 1 <= n_components <= 64, n_features <= 512 (the reference accepts any n <= m, analysis.py:829-846); beyond
+ * 128 channels / 32 components, and for float64 with more than 16 components on more than 64 channels, the general-shape kernels
+ * run (uniform batches, Frobenius loss; the Kullback-Leibler loss and ragged batches there: HIPNMF_ERR_UNSUPPORTED).  Layouts used in place (anything
  * else costs one conversion per fit): fp32 16-channel C-order X for the narrow row-per-lane instances, channel-major X
  * for the other narrow ones; for the wide shapes a C-order X whose rows are a whole number of 16-byte pieces
  * (n_features * sizeof % 16 == 0, ldx likewise) and a C-order W with n_components % 4 == 0.
@@ -158,8 +159,11 @@ int hipnmf_fit_ragged_f64(hipnmf_handle* h, const hipnmf_problem* p, const int64
  *     hipnmf_shard_hupdate: H <- H * (W^T X) / ((W^T W) H)
  * and hipnmf_shard_residual returns the shard's per-column SSE (and sum X^2) for the stop rule / VAF.
  * sums: [B][k*m + k*k] device buffer; sse_col/xsq_col: [B][m].  max_iter/tol in *p are ignored here.
- * The shard entry points require p->w_layout == HIPNMF_W_COMPONENT_MAJOR and channel-major X with
- * ldx % 4 == 0 (no per-call layout conversion on the per-iteration path).
+ * Up to 32 channels and 8 components the shard entry points require p->w_layout == HIPNMF_W_COMPONENT_MAJOR and channel-major X
+ * with ldx % 4 == 0 (no per-call layout conversion on the per-iteration path).  Beyond (round 4: up to 512 x 64, Frobenius) they
+ * run on the general-shape kernels and require p->x_layout == HIPNMF_X_ROW_MAJOR with 16-byte aligned rows (ldx * sizeof % 16
+ * == 0) and p->w_layout == HIPNMF_W_ROW_MAJOR with W stored as [n_samples][KP], KP = n_components rounded up to 16, the padding
+ * columns zero (they stay zero); sums keeps the [k*m + k*k] layout: W^T X (k x m) then W^T W (k x k).
  */
 int hipnmf_shard_pass_f32(hipnmf_handle* h, const hipnmf_problem* p, const float* X, float* W, const float* H,
                           float* sums);

@@ -186,13 +186,9 @@ int validate(const hipnmf_problem* p, bool shard, bool ragged = false) {
     return fail(HIPNMF_ERR_BAD_ARG, "n_samples must be in [1, 2e9] (got %lld)", (long long)p->n_samples);
   if (p->n_features < 1) return fail(HIPNMF_ERR_BAD_ARG, "n_features must be >= 1 (got %d)", p->n_features);
   if (p->n_components < 1) return fail(HIPNMF_ERR_BAD_ARG, "n_components must be >= 1 (got %d)", p->n_components);
-  {  // the time-shard building blocks exist for the narrow lane mappings only
-    const int max_m = shard ? HIPNMF_NARROW_MAX_FEATURES : HIPNMF_MAX_FEATURES;
-    const int max_k = shard ? HIPNMF_NARROW_MAX_COMPONENTS : HIPNMF_MAX_COMPONENTS;
-    if (p->n_features > max_m || p->n_components > max_k)
-      return fail(HIPNMF_ERR_UNSUPPORTED, "shape outside the compiled kernel set%s: n_features=%d (max %d), n_components=%d (max %d)",
-                  shard ? " of the time-shard entry points" : "", p->n_features, max_m, p->n_components, max_k);
-  }
+  if (p->n_features > HIPNMF_MAX_FEATURES || p->n_components > HIPNMF_MAX_COMPONENTS)
+    return fail(HIPNMF_ERR_UNSUPPORTED, "shape outside the compiled kernel set: n_features=%d (max %d), n_components=%d (max %d)",
+                p->n_features, HIPNMF_MAX_FEATURES, p->n_components, HIPNMF_MAX_COMPONENTS);
   if (p->x_layout != HIPNMF_X_ROW_MAJOR && p->x_layout != HIPNMF_X_CHANNEL_MAJOR)
     return fail(HIPNMF_ERR_BAD_ARG, "bad x_layout %d", p->x_layout);
   if (p->w_layout != HIPNMF_W_ROW_MAJOR && p->w_layout != HIPNMF_W_COMPONENT_MAJOR)
@@ -856,6 +852,11 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
 }
 
 // ---- shard building blocks ------------------------------------------------------------------------
+// beyond the narrow lane mappings (32 channels / 8 components) the building blocks run on the general-shape kernels (hipnmf_wide.hip)
+inline bool shard_is_wide(const hipnmf_problem* p) {
+  return p && p->struct_size == (int32_t)sizeof(hipnmf_problem) &&
+         (p->n_features > HIPNMF_NARROW_MAX_FEATURES || p->n_components > HIPNMF_NARROW_MAX_COMPONENTS);
+}
 template <typename real>
 int shard_common(hipnmf_handle* h, const hipnmf_problem* p, const KernelSet<real>** ks_out, SolveArgs<real>* a,
                  const real* X, const real* W, const real* H, SliceGeom* sg, bool need_part, bool need_col) {
@@ -919,6 +920,10 @@ template <typename real>
 int shard_pass_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, real* W, const real* H, real* sums) {
   if (!X || !W || !H) return fail(HIPNMF_ERR_BAD_ARG, "X, W and H must be non-NULL device pointers");
   if (p && p->update_h && !sums) return fail(HIPNMF_ERR_BAD_ARG, "sums must be non-NULL when update_h != 0");
+  if (h && shard_is_wide(p)) {
+    if (int vrc = validate(p, true)) return vrc;
+    return hipnmf_shard_wide<real>(h, p, 0, X, W, const_cast<real*>(H), sums, nullptr, nullptr);
+  }
   const KernelSet<real>* ks = nullptr;
   SolveArgs<real> a;
   SliceGeom sg;
@@ -959,6 +964,10 @@ int shard_pass_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
 template <typename real>
 int shard_hupdate_impl(hipnmf_handle* h, const hipnmf_problem* p, real* H, const real* sums) {
   if (!H || !sums) return fail(HIPNMF_ERR_BAD_ARG, "H and sums must be non-NULL device pointers");
+  if (h && shard_is_wide(p)) {
+    if (int vrc = validate(p, true)) return vrc;
+    return hipnmf_shard_wide<real>(h, p, 1, nullptr, nullptr, H, const_cast<real*>(sums), nullptr, nullptr);
+  }
   const KernelSet<real>* ks = nullptr;
   SolveArgs<real> a;
   SliceGeom sg;
@@ -982,6 +991,10 @@ template <typename real>
 int shard_residual_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, const real* W, const real* H,
                         real* sse_col, real* xsq_col) {
   if (!X || !W || !H || !sse_col) return fail(HIPNMF_ERR_BAD_ARG, "X, W, H and sse_col must be non-NULL");
+  if (h && shard_is_wide(p)) {
+    if (int vrc = validate(p, true)) return vrc;
+    return hipnmf_shard_wide<real>(h, p, 2, X, const_cast<real*>(W), const_cast<real*>(H), nullptr, sse_col, xsq_col);
+  }
   const KernelSet<real>* ks = nullptr;
   SolveArgs<real> a;
   SliceGeom sg;

@@ -62,6 +62,10 @@ inline long long round_up(long long v, long long q) { return (v + q - 1) / q * q
 template <typename real>
 int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, real* W, real* H, real* err_out,
                     int32_t* n_iter_out, real* sse_col_out, real* xsq_col_out, const int64_t* ragged);
+// hipnmf_shard_pass / _hupdate / _residual beyond the narrow lane mappings (hipnmf_wide.hip; op: 0 pass, 1 H update, 2 residual)
+template <typename real>
+int hipnmf_shard_wide(hipnmf_handle* h, const hipnmf_problem* p, int op, const real* X, real* W, real* H, real* sums,
+                      real* sse_col, real* xsq_col);
 // hipnmf_random_init_* for a compacted sub-batch: matrix b draws the numbers of matrix first_matrix + index[b] (hipnmf_init.hip)
 template <typename real>
 int hipnmf_random_init_indexed(hipnmf_handle* h, const hipnmf_problem* p, uint64_t seed, int first_matrix, const int* index,

@@ -449,9 +449,11 @@ int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
     hb.state = d_state;
     hb.m = m;
     hb.k = k;
-    hb.KP = KPb;
-    hb.MP = MPb;
     hb.S = S;
+    hb.rec = KPb * MPb + KPb * KPb;
+    hb.ldA = MPb;
+    hb.offB = KPb * MPb;
+    hb.ldB = KPb;
     hb.l1h = (real)p->l1_reg_H;
     hb.l2h = (real)p->l2_reg_H;
     const dim3 gslice(S, B), grec(S, B, (MPb + BIG_CB - 1) / BIG_CB + 1), ghup(B, (m + 63) / 64);
@@ -551,6 +553,134 @@ int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
   HIP_TRY(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
   return HIPNMF_OK;
 }
+
+// ---- time-shard building blocks for wide shapes (hipnmf_shard_pass / _hupdate / _residual beyond 32 channels / 8 components) on
+// the general-shape kernels.  Layout contract of these shapes (include/hip_nmf.h): X row-major [T][ldx] with 16-byte aligned rows,
+// W row-major [T][KP], KP = round_up(n_components, 16), columns >= n_components zero.  op: 0 pass, 1 H update, 2 residual.
+template <typename real>
+int hipnmf_shard_wide(hipnmf_handle* h, const hipnmf_problem* p, int op, const real* X, real* W, real* H, real* sums,
+                      real* sse_col, real* xsq_col) {
+  constexpr int VEC = 16 / (int)sizeof(real);
+  const int B = p->batch, m = p->n_features, k = p->n_components;
+  const long long T = p->n_samples;
+  const int KPb = (int)round_up(k, 16), MPb = (int)round_up(m, 16);
+  if (op != 1) {
+    if (p->x_layout != HIPNMF_X_ROW_MAJOR || p->w_layout != HIPNMF_W_ROW_MAJOR || (p->ldx % VEC) != 0 ||
+        (reinterpret_cast<uintptr_t>(X) % 16) != 0 || ((p->x_batch_stride * (long long)sizeof(real)) % 16) != 0 ||
+        (reinterpret_cast<uintptr_t>(W) % 16) != 0)
+      return fail(HIPNMF_ERR_UNSUPPORTED, "shard entry points beyond 32 channels / 8 components need row-major X with 16-byte aligned rows "
+                                          "(ldx %% %d == 0) and row-major W [n_samples][%d] (components padded to 16 with zeros)", VEC, KPb);
+    if (T >= (1LL << 31)) return fail(HIPNMF_ERR_UNSUPPORTED, "n_samples must be < 2^31 per shard");
+  }
+  if (B > 65535) return fail(HIPNMF_ERR_UNSUPPORTED, "batch=%d: at most 65535 matrices", B);
+  HIP_TRY(hipSetDevice(h->device));
+  hipStream_t st = h->stream;
+  const long long want = std::max<long long>(1, (2LL * h->num_cu + B - 1) / B);
+  long long s_try = std::min<long long>(want, (T + 63) / 64);
+  if (h->max_slices > 0) s_try = std::min<long long>(s_try, h->max_slices);
+  const long long rps = round_up((T + s_try - 1) / s_try, 64);
+  const int S = (int)((T + rps - 1) / rps);
+  const size_t rec = (size_t)KPb * MPb + (size_t)KPb * KPb;
+  size_t off = 0;
+  auto carve = [&](size_t bytes) {
+    size_t o = off;
+    off += (bytes + 255) / 256 * 256;
+    return o;
+  };
+  const size_t o_part = carve(sizeof(real) * (size_t)B * S * rec);
+  const size_t o_col = carve(sizeof(real) * (size_t)B * S * 2 * MPb);
+  const size_t o_hht = carve(sizeof(real) * (size_t)B * KPb * KPb);
+  int rc = hipnmf_ensure_ws(h, off);
+  if (rc) return rc;
+  char* ws = static_cast<char*>(h->ws);
+  BigArgs<real> ba;
+  std::memset(&ba, 0, sizeof(ba));
+  ba.X = X;
+  ba.x_bstride = p->x_batch_stride;
+  ba.ldx = p->ldx;
+  ba.W = W;
+  ba.w_bstride = T * (long long)KPb;
+  ba.H = H;
+  ba.HHt = reinterpret_cast<real*>(ws + o_hht);
+  ba.part = reinterpret_cast<real*>(ws + o_part);
+  ba.colpart = reinterpret_cast<real*>(ws + o_col);
+  ba.T = (int)T;
+  ba.m = m;
+  ba.k = k;
+  ba.KP = KPb;
+  ba.MP = MPb;
+  ba.xchunks = (m + VEC - 1) / VEC;
+  ba.S = S;
+  ba.rows_per_slice = (int)rps;
+  ba.l1w = (real)p->l1_reg_W;
+  ba.l2w = (real)p->l2_reg_W;
+  const size_t fixed = sizeof(real) * ((size_t)KPb * (KPb + 4) + 8 * (size_t)MPb);
+  int cbh = MPb;
+  while (cbh > 16 && fixed + sizeof(real) * (size_t)KPb * (cbh + 4) > 96 * 1024) cbh = (int)round_up(cbh / 2, 16);
+  ba.CBH = cbh;
+  const size_t smem_w = sizeof(real) * ((size_t)KPb * (cbh + 4) + (size_t)KPb * (KPb + 4));
+  const size_t smem_r = sizeof(real) * ((size_t)KPb * (cbh + 4) + 8 * (size_t)MPb);
+  const size_t smem_rec = sizeof(real) * std::max<size_t>(4 * (16 * (size_t)(KPb + 4) + 16 * (size_t)(BIG_CB + 4)), 4 * (size_t)KPb * BIG_CB);
+  const dim3 gslice(S, B), grec(S, B, (MPb + BIG_CB - 1) / BIG_CB + 1);
+  auto with_kp = [&](auto&& f) {
+    switch (KPb) {
+      case 16: f(std::integral_constant<int, 16>{}); break;
+      case 32: f(std::integral_constant<int, 32>{}); break;
+      case 48: f(std::integral_constant<int, 48>{}); break;
+      default: f(std::integral_constant<int, 64>{}); break;
+    }
+  };
+  const bool async = h->async_mode != 0;
+  if (!async) HIP_TRY(hipEventRecord(h->ev0, st));
+  int arc = HIPNMF_OK;
+  if (op == 0) {
+    hipLaunchKernelGGL(big_hht_kernel<real>, dim3(B), dim3(256), 0, st, ba);
+    with_kp([&](auto kp) {
+      constexpr int KP = decltype(kp)::value;
+      if (!arc) arc = hipnmf_allow_full_lds(h, reinterpret_cast<const void*>(big_pass_w_kernel<real, KP>));
+      if (!arc) arc = hipnmf_allow_full_lds(h, reinterpret_cast<const void*>(big_records_kernel<real, KP>));
+      if (arc) return;
+      hipLaunchKernelGGL((big_pass_w_kernel<real, KP>), gslice, dim3(256), smem_w, st, ba);
+      if (p->update_h) hipLaunchKernelGGL((big_records_kernel<real, KP>), grec, dim3(256), smem_rec, st, ba);
+    });
+    if (arc) return arc;
+    if (p->update_h) hipLaunchKernelGGL(big_pack_sums_kernel<real>, dim3(B), dim3(256), 0, st, ba, sums);
+  } else if (op == 1) {
+    BigHArgs<real> hb;
+    hb.H = H;
+    hb.part = sums;
+    hb.state = nullptr;
+    hb.m = m;
+    hb.k = k;
+    hb.S = 1;
+    hb.rec = k * m + k * k;
+    hb.ldA = m;
+    hb.offB = k * m;
+    hb.ldB = k;
+    hb.l1h = (real)p->l1_reg_H;
+    hb.l2h = (real)p->l2_reg_H;
+    hipLaunchKernelGGL(big_hupdate_kernel<real>, dim3(B, (m + 63) / 64), dim3(256), sizeof(real) * ((size_t)k * k + 128 * (size_t)k), st, hb);
+  } else {
+    with_kp([&](auto kp) {
+      constexpr int KP = decltype(kp)::value;
+      if (!arc) arc = hipnmf_allow_full_lds(h, reinterpret_cast<const void*>(big_resid_kernel<real, KP>));
+      if (arc) return;
+      hipLaunchKernelGGL((big_resid_kernel<real, KP>), gslice, dim3(256), smem_r, st, ba);
+    });
+    if (arc) return arc;
+    hipLaunchKernelGGL(big_colsum_kernel<real>, dim3(B), dim3(256), 0, st, ba, sse_col, xsq_col);
+  }
+  HIP_TRY(hipGetLastError());
+  if (!async) {
+    HIP_TRY(hipEventRecord(h->ev1, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
+  }
+  return HIPNMF_OK;
+}
+template int hipnmf_shard_wide<float>(hipnmf_handle*, const hipnmf_problem*, int, const float*, float*, float*, float*, float*, float*);
+template int hipnmf_shard_wide<double>(hipnmf_handle*, const hipnmf_problem*, int, const double*, double*, double*, double*, double*,
+                                       double*);
 
 template int hipnmf_fit_wide<float>(hipnmf_handle*, const hipnmf_problem*, const float*, float*, float*, float*, int32_t*,
                                     float*, float*, const int64_t*);

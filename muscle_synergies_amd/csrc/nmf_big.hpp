@@ -296,9 +296,10 @@ __global__ void __launch_bounds__(256) big_records_kernel(BigArgs<real> a) {
 template <typename real>
 struct BigHArgs {
   real* H;
-  const real* part;
+  const real* part;   // [B][S][rec]: per record W^T X as [k][ldA] at offset 0 and W^T W as [k][ldB] at offset offB
   const real* state;
-  int m, k, KP, MP, S;
+  int m, k, S;
+  int rec, ldA, offB, ldB;  // slice records of big_records_kernel: KP MP + KP KP, MP, KP MP, KP; packed sums: k m + k k, m, k m, k
   real l1h, l2h;
 };
 template <typename real>
@@ -310,18 +311,18 @@ __global__ void __launch_bounds__(256) big_hupdate_kernel(BigHArgs<real> a) {
   real* const sB = reinterpret_cast<real*>(big_smem);  // [k][k]
   real* const sNum = sB + k * k;                       // [k][64]
   real* const sHo = sNum + k * 64;                     // [k][64] the old H
-  const int rec = a.KP * a.MP + a.KP * a.KP;
+  const int rec = a.rec;
   const real* __restrict__ pb = a.part + (long long)b * a.S * rec;
   real* __restrict__ Hb = a.H + (long long)b * k * a.m;
   for (int idx = tid; idx < k * k; idx += 256) {
-    const int off = a.KP * a.MP + (idx / k) * a.KP + idx % k;
+    const int off = a.offB + (idx / k) * a.ldB + idx % k;
     real s = (real)0;
     for (int q = 0; q < a.S; ++q) s += pb[(long long)q * rec + off];
     sB[idx] = s;
   }
   for (int idx = tid; idx < k * ncol; idx += 256) {
     const int c = idx / ncol, jj = idx % ncol;
-    const int off = c * a.MP + c0 + jj;
+    const int off = c * a.ldA + c0 + jj;
     real s = (real)0;
     for (int q = 0; q < a.S; ++q) s += pb[(long long)q * rec + off];
     sNum[c * 64 + jj] = s;
@@ -337,6 +338,36 @@ __global__ void __launch_bounds__(256) big_hupdate_kernel(BigHArgs<real> a) {
     if (a.l2h > (real)0) d = d + a.l2h * hold;
     d = (d == (real)0) ? eps_val<real>() : d;
     Hb[(long long)c * a.m + c0 + jj] = hold * (sNum[c * 64 + jj] / d);
+  }
+}
+
+// Time-shard building blocks (hipnmf_shard_* for wide shapes): the slice records summed in slice order and packed as the
+// all-reduce wants them -- sums[b] = [W^T X (k x m) | W^T W (k x k)] -- and the slices' column records summed into sse | xsq.
+template <typename real>
+__global__ void __launch_bounds__(256) big_pack_sums_kernel(BigArgs<real> a, real* __restrict__ sums) {
+  const int b = blockIdx.x, k = a.k, m = a.m;
+  const int rec = a.KP * a.MP + a.KP * a.KP;
+  const real* __restrict__ pb = a.part + (long long)b * a.S * rec;
+  real* __restrict__ out = sums + (long long)b * (k * m + k * k);
+  for (int idx = threadIdx.x; idx < k * m + k * k; idx += blockDim.x) {
+    const int off = idx < k * m ? (idx / m) * a.MP + idx % m : a.KP * a.MP + ((idx - k * m) / k) * a.KP + (idx - k * m) % k;
+    real s = (real)0;
+    for (int q = 0; q < a.S; ++q) s += pb[(long long)q * rec + off];
+    out[idx] = s;
+  }
+}
+template <typename real>
+__global__ void __launch_bounds__(256) big_colsum_kernel(BigArgs<real> a, real* __restrict__ sse_col, real* __restrict__ xsq_col) {
+  const int b = blockIdx.x;
+  const real* __restrict__ cb = a.colpart + (long long)b * a.S * 2 * a.MP;
+  for (int jj = threadIdx.x; jj < a.m; jj += blockDim.x) {
+    real s0 = (real)0, s1 = (real)0;
+    for (int q = 0; q < a.S; ++q) {
+      s0 += cb[(long long)q * 2 * a.MP + jj];
+      s1 += cb[(long long)q * 2 * a.MP + a.MP + jj];
+    }
+    sse_col[(long long)b * a.m + jj] = s0;
+    if (xsq_col) xsq_col[(long long)b * a.m + jj] = s1;
   }
 }
 

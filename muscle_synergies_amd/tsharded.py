@@ -62,9 +62,15 @@ def plan_subshards(n_samples: int, world_size: int, rank: int, subshard: int):
     return out
 
 
+def _is_wide(m: int, k: int) -> bool:
+    """Beyond the narrow lane mappings the shard entry points run on the general-shape kernels, which take row-major X and W."""
+    return m > 32 or k > 8
+
+
 class HipShardOps:
-    """Shard-local compute on one GPU through the C ABI (native layouts: X ``[B, m, T_local]``
-    channel-major, W ``[B, k, T_local]`` component-major)."""
+    """Shard-local compute on one GPU through the C ABI.  Native layouts: up to 32 channels and 8 components X ``[B, m, T_local]``
+    channel-major and W ``[B, k, T_local]`` component-major; beyond (up to 512 x 64, round 4) X ``[B, T_local, ldx]`` row-major
+    with 16-byte aligned rows and W ``[B, T_local, KP]`` row-major, ``KP = round_up(k, 16)``, padding columns zero."""
 
     def __init__(self, X_local, W_local, H, *, l1_reg_W=0.0, l1_reg_H=0.0, l2_reg_W=0.0, l2_reg_H=0.0,
                  update_H=True, device=None):
@@ -77,15 +83,26 @@ class HipShardOps:
             X, W_local, H = X.unsqueeze(0), torch.as_tensor(W_local).unsqueeze(0), torch.as_tensor(H).unsqueeze(0)
         self.B, self.T, self.m = X.shape
         self.dtype = X.dtype
-        # native layouts; the shard is zero-padded to a multiple of 4 rows (zero rows of X with zero rows of
-        # W stay zero under the update and contribute nothing to any sum)
-        self.ld = (self.T + 3) // 4 * 4
-        self.Xc = torch.zeros((self.B, self.m, self.ld), dtype=self.dtype, device=self.dev)
-        self.Xc[:, :, : self.T] = X.transpose(1, 2)
         W = torch.as_tensor(W_local).to(self.dev, self.dtype)
         self.k = W.shape[2]
-        self.Wc = torch.zeros((self.B, self.k, self.ld), dtype=self.dtype, device=self.dev)
-        self.Wc[:, :, : self.T] = W.transpose(1, 2)
+        self.wide = _is_wide(self.m, self.k)
+        if self.wide:
+            vec = 4 if self.dtype == torch.float32 else 2
+            self.ld = self.T
+            self.ldx = (self.m + vec - 1) // vec * vec
+            self.kp = (self.k + 15) // 16 * 16
+            self.Xc = torch.zeros((self.B, self.T, self.ldx), dtype=self.dtype, device=self.dev)
+            self.Xc[:, :, : self.m] = X
+            self.Wc = torch.zeros((self.B, self.T, self.kp), dtype=self.dtype, device=self.dev)
+            self.Wc[:, :, : self.k] = W
+        else:
+            # native layouts; the shard is zero-padded to a multiple of 4 rows (zero rows of X with zero rows of
+            # W stay zero under the update and contribute nothing to any sum)
+            self.ld = (self.T + 3) // 4 * 4
+            self.Xc = torch.zeros((self.B, self.m, self.ld), dtype=self.dtype, device=self.dev)
+            self.Xc[:, :, : self.T] = X.transpose(1, 2)
+            self.Wc = torch.zeros((self.B, self.k, self.ld), dtype=self.dtype, device=self.dev)
+            self.Wc[:, :, : self.T] = W.transpose(1, 2)
         self.H = torch.as_tensor(H).to(self.dev, self.dtype).contiguous().clone()
         self.sums = torch.empty((self.B, self.k * self.m + self.k * self.k), dtype=self.dtype, device=self.dev)
         self.sse = torch.empty((self.B, self.m), dtype=self.dtype, device=self.dev)
@@ -95,10 +112,16 @@ class HipShardOps:
         self.handle = _lib.Handle(self.dev.index)
         self.handle.set_stream(torch.cuda.current_stream(self.dev).cuda_stream)
         self.handle.set_async(True)
-        self.p = make_problem(self.B, self.ld, self.m, self.k, x_layout=_lib.X_CHANNEL_MAJOR, ldx=self.ld,
-                              x_batch_stride=self.m * self.ld, w_layout=_lib.W_COMPONENT_MAJOR, update_H=update_H,
-                              max_iter=1, tol=0.0, l1_reg_W=l1_reg_W, l1_reg_H=l1_reg_H, l2_reg_W=l2_reg_W,
-                              l2_reg_H=l2_reg_H)
+        if self.wide:
+            self.p = make_problem(self.B, self.T, self.m, self.k, x_layout=_lib.X_ROW_MAJOR, ldx=self.ldx,
+                                  x_batch_stride=self.T * self.ldx, w_layout=_lib.W_ROW_MAJOR, update_H=update_H,
+                                  max_iter=1, tol=0.0, l1_reg_W=l1_reg_W, l1_reg_H=l1_reg_H, l2_reg_W=l2_reg_W,
+                                  l2_reg_H=l2_reg_H)
+        else:
+            self.p = make_problem(self.B, self.ld, self.m, self.k, x_layout=_lib.X_CHANNEL_MAJOR, ldx=self.ld,
+                                  x_batch_stride=self.m * self.ld, w_layout=_lib.W_COMPONENT_MAJOR, update_H=update_H,
+                                  max_iter=1, tol=0.0, l1_reg_W=l1_reg_W, l1_reg_H=l1_reg_H, l2_reg_W=l2_reg_W,
+                                  l2_reg_H=l2_reg_H)
         sfx = "f32" if self.dtype == torch.float32 else "f64"
         lib = _lib.load()
         self._pass = getattr(lib, f"hipnmf_shard_pass_{sfx}")
@@ -117,6 +140,7 @@ class HipShardOps:
 
         self = cls.__new__(cls)
         self.torch = torch
+        self.wide = False  # (the wide layouts go through the ordinary constructor)
         self.dev = Xc.device
         if not (Xc.is_cuda and Wc.is_cuda and H.is_cuda and Xc.is_contiguous() and Wc.is_contiguous()
                 and H.is_contiguous()):
@@ -208,6 +232,8 @@ class HipShardOps:
         return self.sse, self.xsq
 
     def result_W(self):
+        if self.wide:
+            return self.Wc[:, :, : self.k].contiguous()
         return self.Wc[:, :, : self.T].transpose(1, 2).contiguous()  # [B, T_local, k]
 
     def result_H(self):

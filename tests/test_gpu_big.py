@@ -131,3 +131,62 @@ def test_find_synergies_on_an_hd_emg_grid_stays_on_the_gpu():
     r = ms.fit_batched(X, W0, H0, max_iter=80, tol=0.0)
     ref = orc.nmf_mu_fit(X, W0, H0, max_iter=80, tol=0.0)
     np.testing.assert_allclose(r.H[0], ref["H"], rtol=1e-9, atol=1e-13)
+
+
+@pytest.mark.parametrize("dtype,m,k", [(np.float32, 64, 8), (np.float64, 64, 12), (np.float32, 200, 20)])
+def test_time_sharded_fit_of_a_wide_recording_is_shard_count_invariant(dtype, m, k):
+    """Row e-tshard for wide recordings (round 4: hipnmf_shard_* on the general-shape kernels): one 64-channel recording fitted
+    unsharded, as 1, 2 and 3 time shards (Python-driven loop, sums added across shards on the device) and through the library's own
+    hipnmf_fit_tsharded_* -- against the oracle and against each other."""
+    import torch
+
+    from muscle_synergies_amd.tsharded import HipShardOps, fit_tsharded
+
+    T = 6000
+    X = emg_matrix(31, T=T, m=m, k_true=6, dtype=dtype)
+    W0, H0 = random_init(X, k, 2)
+    ref = orc.nmf_mu_fit(X, W0, H0, max_iter=40, tol=0.0)
+    tol = TOL if dtype == np.float32 else 1e-9
+    results = []
+    for nshards in (1, 2, 3):
+        bounds = np.linspace(0, T, nshards + 1).astype(int)
+        shards = [HipShardOps(np.ascontiguousarray(X[lo:hi]), W0[lo:hi], H0) for lo, hi in zip(bounds[:-1], bounds[1:])]
+        assert all(sh.wide for sh in shards)
+
+        class Multi:  # the shards of ONE process standing in for ranks: sums added in shard order, H replicated by hand
+            def shard_pass(self):
+                tot = shards[0].shard_pass().clone()
+                for sh in shards[1:]:
+                    tot += sh.shard_pass()
+                return tot
+
+            def h_update(self, sums):
+                for sh in shards:
+                    sh.h_update(sums)
+
+            def residual(self):
+                sse, xsq = (t.clone() for t in shards[0].residual())
+                for sh in shards[1:]:
+                    a, b = sh.residual()
+                    sse += a
+                    xsq += b
+                return sse, xsq
+
+            def result_W(self):
+                return torch.cat([sh.result_W() for sh in shards], dim=1)
+
+            def result_H(self):
+                return shards[0].H
+
+        r = fit_tsharded(Multi(), max_iter=40, tol=0.0)
+        W, H = r.W_local[0].cpu().numpy(), r.H[0].cpu().numpy()
+        assert W.shape == (T, k) and _rel(X, W, H, ref) <= tol, nshards
+        assert abs(float(r.reconstruction_err[0]) - float(ref["reconstruction_err"])) / np.linalg.norm(X) <= TOL
+        results.append(W @ H)
+    assert np.linalg.norm(results[0] - results[2]) / np.linalg.norm(X) <= (2e-6 if dtype == np.float32 else 1e-12)
+    # the whole sharded fit as one library call, stop rule live
+    ref_s = orc.nmf_mu_fit(X, W0, H0, max_iter=200, tol=1e-3)
+    ops = HipShardOps(np.ascontiguousarray(X), W0, H0)
+    rn = ops.fit_native(max_iter=200, tol=1e-3)
+    assert rn.n_iter == ref_s["n_iter"]
+    assert _rel(X, rn.W_local[0].cpu().numpy(), rn.H[0].cpu().numpy(), ref_s) <= tol
