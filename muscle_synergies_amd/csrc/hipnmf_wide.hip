@@ -24,6 +24,13 @@ using namespace hipnmf;
 namespace hipnmf {
 static int wide_mp(int m) { return m <= 16 ? 16 : m <= 32 ? 32 : m <= 48 ? 48 : m <= 64 ? 64 : m <= 96 ? 96 : m <= 128 ? 128 : 0; }
 const WideKernel<float>* wide_kernel_f32(int m, int k, int nw) {
+  // 129..256 channels with at most 16 components (HD-EMG grids), fp32: the one-pass kernel still holds its accumulators in one
+  // wave (inst_wide_f32_xl.hip; one wave per SIMD).  HIPNMF_WIDE_XL=0: the two-pass general-shape kernels instead.
+  static const bool xl = [] {
+    const char* e = getenv("HIPNMF_WIDE_XL");
+    return !(e && atoi(e) == 0);
+  }();
+  if (xl && m > 128 && m <= 256 && k <= 16 && nw == 4) return wide_kernel_f32_xl(m <= 160 ? 160 : m <= 192 ? 192 : 256);
   const int MP = wide_mp(m);
   if (!MP || k > 32) return nullptr;
   if (k > 16) return nw == 4 ? wide_kernel_f32_k32(MP < 32 ? 32 : MP) : nullptr;

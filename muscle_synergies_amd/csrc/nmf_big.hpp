@@ -127,6 +127,19 @@ __global__ void __launch_bounds__(256) big_pass_w_kernel(BigArgs<real> a) {
     const int row = t0 + j;
     const bool rok = row < row_end;
     const real* __restrict__ xrow = Xb + (long long)row * a.ldx;
+    // W fragment: lane (row j, g) <-> components 16 kb + 4 g .. + 3; register s is the B operand of k-step s
+    // (requested first: in flight while the numerator runs)
+    real w[NKB][4];
+    real* __restrict__ wrow = Wb + (long long)row * KP;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+      if (rok) {
+        __builtin_memcpy(w[kb], __builtin_assume_aligned(wrow + 16 * kb + 4 * g, 16), 4 * sizeof(real));
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) w[kb][r] = (real)0;
+      }
+    }
     acc num[NKB];
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) num[kb] = acc{0, 0, 0, 0};
@@ -137,37 +150,34 @@ __global__ void __launch_bounds__(256) big_pass_w_kernel(BigArgs<real> a) {
         __syncthreads();
       }
       const int cend = (cb0 + a.CBH < a.MP) ? cb0 + a.CBH : a.MP;
-      for (int ch = cb0; ch < cend; ch += 16) {
-        real x[4];
-        const int col = ch + 4 * g;
-        if constexpr (V == 4) {
-          big_load4<real>(xrow, col, rok && (col >> 2) < a.xchunks, x);
-        } else {  // fp64: two 16-byte pieces
-          real lo[4] = {0, 0, 0, 0};
-          if (rok && (col >> 1) < a.xchunks) __builtin_memcpy(lo, __builtin_assume_aligned(xrow + col, 16), 16);
-          if (rok && ((col + 2) >> 1) < a.xchunks) __builtin_memcpy(lo + 2, __builtin_assume_aligned(xrow + col + 2, 16), 16);
+      for (int ch0 = cb0; ch0 < cend; ch0 += 64) {  // four 16-channel blocks per trip: their loads go out together
+        real x[4][4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) x[r] = lo[r];
+        for (int q = 0; q < 4; ++q) {
+          const int col = ch0 + 16 * q + 4 * g;
+          const bool cok = rok && ch0 + 16 * q < cend;
+          if constexpr (V == 4) {
+            big_load4<real>(xrow, col, cok && (col >> 2) < a.xchunks, x[q]);
+          } else {  // fp64: two 16-byte pieces
+            real lo[4] = {0, 0, 0, 0};
+            if (cok && (col >> 1) < a.xchunks) __builtin_memcpy(lo, __builtin_assume_aligned(xrow + col, 16), 16);
+            if (cok && ((col + 2) >> 1) < a.xchunks) __builtin_memcpy(lo + 2, __builtin_assume_aligned(xrow + col + 2, 16), 16);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[q][r] = lo[r];
+          }
         }
 #pragma unroll
-        for (int kb = 0; kb < NKB; ++kb) {
-          real ha[4];
-          wide_lds_read<real, 4>(sH + (16 * kb + ar) * SH + (ch - cb0) + 4 * g, ha);
+        for (int q = 0; q < 4; ++q) {
+          if (ch0 + 16 * q < cend) {
 #pragma unroll
-          for (int s = 0; s < 4; ++s) num[kb] = M::mma(ha[s], x[s], num[kb]);
+            for (int kb = 0; kb < NKB; ++kb) {
+              real ha[4];
+              wide_lds_read<real, 4>(sH + (16 * kb + ar) * SH + (ch0 + 16 * q - cb0) + 4 * g, ha);
+#pragma unroll
+              for (int s = 0; s < 4; ++s) num[kb] = M::mma(ha[s], x[q][s], num[kb]);
+            }
+          }
         }
-      }
-    }
-    // W fragment: lane (row j, g) <-> components 16 kb + 4 g .. + 3; register s is the B operand of k-step s
-    real w[NKB][4];
-    real* __restrict__ wrow = Wb + (long long)row * KP;
-#pragma unroll
-    for (int kb = 0; kb < NKB; ++kb) {
-      if (rok) {
-        __builtin_memcpy(w[kb], __builtin_assume_aligned(wrow + 16 * kb + 4 * g, 16), 4 * sizeof(real));
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) w[kb][r] = (real)0;
       }
     }
 #pragma unroll
@@ -411,41 +421,54 @@ __global__ void __launch_bounds__(256) big_resid_kernel(BigArgs<real> a) {
 #pragma unroll
       for (int kb = 0; kb < NKB; ++kb) big_load4<real>(Wb + (long long)row * KP, 16 * kb + 4 * g, rok, w[kb]);
       const real* __restrict__ xrow = Xb + (long long)row * a.ldx;
-      for (int ch = cb0; ch < cend; ch += 16) {
-        // R^T block: A = H^T (channel 16-block x components), B = the W fragment; D: lane (row j, g), register r <-> channel ch + 4 g + r
-        acc rec = acc{0, 0, 0, 0};
+      for (int ch0 = cb0; ch0 < cend; ch0 += 64) {  // four 16-channel blocks per trip: their loads go out together
+        real x[4][4];
 #pragma unroll
-        for (int kb = 0; kb < NKB; ++kb)
+        for (int q = 0; q < 4; ++q) {
+          const int col = ch0 + 16 * q + 4 * g;
+          const bool cok = rok && ch0 + 16 * q < cend;
 #pragma unroll
-          for (int s = 0; s < 4; ++s) rec = M::mma(sH[(16 * kb + 4 * g + s) * SH + (ch - cb0) + ar], w[kb][s], rec);
-        real x[4] = {0, 0, 0, 0};
-        const int col = ch + 4 * g;
-        if constexpr (V == 4) {
-          big_load4<real>(xrow, col, rok && (col >> 2) < a.xchunks, x);
-        } else {
-          if (rok && (col >> 1) < a.xchunks) __builtin_memcpy(x, __builtin_assume_aligned(xrow + col, 16), 16);
-          if (rok && ((col + 2) >> 1) < a.xchunks) __builtin_memcpy(x + 2, __builtin_assume_aligned(xrow + col + 2, 16), 16);
-        }
-        real sse[4], xsq[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const real d = x[r] - rec[r];
-          sse[r] = d * d;
-          xsq[r] = x[r] * x[r];
-        }
-        // sum over the 16 rows of the subtile (lanes j = 0 .. 15 of the same g): a fixed butterfly
-#pragma unroll
-        for (int off = 1; off < 16; off <<= 1)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            sse[r] += __shfl_xor(sse[r], off, 64);
-            xsq[r] += __shfl_xor(xsq[r], off, 64);
+          for (int r = 0; r < 4; ++r) x[q][r] = (real)0;
+          if constexpr (V == 4) {
+            big_load4<real>(xrow, col, cok && (col >> 2) < a.xchunks, x[q]);
+          } else {
+            if (cok && (col >> 1) < a.xchunks) __builtin_memcpy(x[q], __builtin_assume_aligned(xrow + col, 16), 16);
+            if (cok && ((col + 2) >> 1) < a.xchunks) __builtin_memcpy(x[q] + 2, __builtin_assume_aligned(xrow + col + 2, 16), 16);
           }
-        if (j == 0) {  // one lane per 4 channels adds the subtile's sums to the wave's column accumulators (program order)
+        }
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            mycols[col + r] += sse[r];
-            mycols[a.MP + col + r] += xsq[r];
+        for (int q = 0; q < 4; ++q) {
+          const int ch = ch0 + 16 * q;
+          if (ch < cend) {
+            // R^T block: A = H^T (channel 16-block x components), B = the W fragment; D: lane (row j, g), register r <-> channel ch + 4 g + r
+            acc rec = acc{0, 0, 0, 0};
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+              for (int s = 0; s < 4; ++s) rec = M::mma(sH[(16 * kb + 4 * g + s) * SH + (ch - cb0) + ar], w[kb][s], rec);
+            real sse[4], xsq[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const real d = x[q][r] - rec[r];
+              sse[r] = d * d;
+              xsq[r] = x[q][r] * x[q][r];
+            }
+            // sum over the 16 rows of the subtile (lanes j = 0 .. 15 of the same g): a fixed butterfly
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                sse[r] += __shfl_xor(sse[r], off, 64);
+                xsq[r] += __shfl_xor(xsq[r], off, 64);
+              }
+            if (j == 0) {  // one lane per 4 channels adds the subtile's sums to the wave's column accumulators (program order)
+              const int col = ch + 4 * g;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                mycols[col + r] += sse[r];
+                mycols[a.MP + col + r] += xsq[r];
+              }
+            }
           }
         }
       }

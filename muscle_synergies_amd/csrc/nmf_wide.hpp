@@ -107,7 +107,7 @@ struct WideCfg {
   static constexpr int REC = KP * MP + KP * KP;                         // per-wave record of [W^T X | W^T W]
   static constexpr int PERWAVE = (XS + WS > REC ? XS + WS : REC);
   static constexpr int COMMON = KP * SX + KP * KP + KP * MP + KP * KP + 2 * MP + 8;
-  static_assert(MP % 16 == 0 && MP >= 16 && MP <= 128 && (KP == 16 || KP == 32), "unsupported wide shape");
+  static_assert(MP % 16 == 0 && MP >= 16 && MP <= 256 && (KP == 16 || KP == 32), "unsupported wide shape");
   static_assert(CPR <= 64, "a row must fit one load instruction");
   __host__ __device__ static constexpr size_t smem_bytes(int nw) { return sizeof(real) * (size_t)(COMMON + nw * PERWAVE); }
 };
@@ -908,7 +908,7 @@ __global__ void __launch_bounds__(1024) wide_hupdate_kernel(WideSliceArgs<real> 
 // per-column sums over the slices -> error, stop rule (_nmf.py:872-884), outputs.  One workgroup per matrix.
 template <typename real>
 __global__ void __launch_bounds__(1024) wide_resid_finalize_kernel(WideSliceArgs<real> a) {
-  __shared__ real cols[2 * 128];
+  __shared__ real cols[2 * 256];  // (MP <= 256: inst_wide_f32_xl.hip)
   const int b = blockIdx.x, tid = threadIdx.x;
   real* st = a.state + (long long)b * 8;
   const bool done = st[3] != (real)0;

@@ -64,6 +64,8 @@ const WideKernel<double>* wide_kernel_f64_lo(int MP, int KP, int NW);
 const WideKernel<double>* wide_kernel_f64_hi(int MP, int KP, int NW);
 // 17..32 components (KP = 32): 256-thread instances for 32, 48, 64, 96, 128 channels
 const WideKernel<float>* wide_kernel_f32_k32(int MP);
+// 129..256 channels, at most 16 components, fp32 (MP = 160, 192, 256): inst_wide_f32_xl.hip
+const WideKernel<float>* wide_kernel_f32_xl(int MP);
 const WideKernel<double>* wide_kernel_f64_k32(int MP);
 // the 512-thread instance exists only where the kernel is compiled for two waves per SIMD (256 registers)
 template <typename real, int MP>

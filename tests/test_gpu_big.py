@@ -43,7 +43,10 @@ def test_big_shape_sweep_fp32(m, k, T):
     for layout in ("F", "C"):
         Xl = np.asfortranarray(X) if layout == "F" else np.ascontiguousarray(X)
         res = ms.fit_batched(Xl, W0, H0, max_iter=15, tol=0.0)
-        assert _last_kernel().startswith("big_pass_w_kernel<float"), _last_kernel()
+        # 129..256 channels with at most 16 components keep the one-pass kernel (inst_wide_f32_xl.hip), the rest is nmf_big.hpp
+        xl = 128 < m <= 256 and k <= 16
+        assert _last_kernel().startswith("fit_wide_kernel<float,%d,16,4" % (160 if m <= 160 else 192 if m <= 192 else 256) if xl
+                                         else "big_pass_w_kernel<float"), _last_kernel()
         assert int(res.n_iter[0]) == 15
         assert _rel(X, res.W[0], res.H[0], ref) <= TOL, (layout, m, k, T)
         assert abs(float(res.reconstruction_err[0]) - float(ref["reconstruction_err"])) / np.linalg.norm(X) <= TOL
@@ -100,16 +103,37 @@ def test_big_stop_rule_batch_regularisation_and_transform(dtype):
 
 
 def test_big_long_frame_is_sliced_over_the_chip_and_deterministic():
-    """One HD-EMG sized frame: 256 channels x 20 000 samples, 16 synergies, 200 iterations; twice, bitwise equal."""
+    """One HD-EMG sized frame: 320 channels x 20 000 samples, 20 synergies, 200 iterations; twice, bitwise equal."""
     import muscle_synergies_amd as ms
 
-    X, W0, H0 = _case(20_000, 256, 16, np.float32, seed=3)
+    X, W0, H0 = _case(20_000, 320, 20, np.float32, seed=3)
     r1 = ms.fit_batched(np.ascontiguousarray(X), W0, H0, max_iter=200, tol=0.0)
     r2 = ms.fit_batched(np.ascontiguousarray(X), W0, H0, max_iter=200, tol=0.0)
     assert np.array_equal(r1.W, r2.W) and np.array_equal(r1.H, r2.H)
     ref = orc.nmf_mu_fit(X, W0, H0, max_iter=200, tol=0.0)
     assert _rel(X, r1.W[0], r1.H[0], ref) <= TOL
     assert abs(float(r1.reconstruction_err[0]) - float(ref["reconstruction_err"])) / np.linalg.norm(X) <= TOL
+
+
+@pytest.mark.parametrize("m,k,T,B", [(256, 16, 5000, 1), (256, 8, 1200, 300), (192, 12, 900, 40), (140, 5, 3000, 2)])
+def test_hd_emg_grids_up_to_256_channels_on_the_one_pass_kernel(m, k, T, B):
+    """fp32, 129..256 channels, at most 16 components: fit_wide_kernel<float, 160 / 192 / 256, 16, 4> (one workgroup per matrix
+    for batches, rows sliced over the chip for few long frames), both losses, against the oracle at 60 iterations."""
+    import muscle_synergies_amd as ms
+
+    Xs, Ws, Hs = [], [], []
+    for b in range(B):
+        X, W0, H0 = _case(T, m, k, np.float32, seed=500 + b % 5)
+        Xs.append(np.ascontiguousarray(X)), Ws.append(W0), Hs.append(H0)
+    res = ms.fit_batched(np.stack(Xs), np.stack(Ws), np.stack(Hs), max_iter=60, tol=0.0)
+    assert _last_kernel().startswith("fit_wide_kernel<float,%d,16,4" % (160 if m <= 160 else 192 if m <= 192 else 256)), _last_kernel()
+    for b in (0, B - 1):
+        ref = orc.nmf_mu_fit(Xs[b], Ws[b], Hs[b], max_iter=60, tol=0.0)
+        assert _rel(Xs[b], res.W[b], res.H[b], ref) <= TOL
+        assert abs(float(res.reconstruction_err[b]) - float(ref["reconstruction_err"])) / np.linalg.norm(Xs[b]) <= TOL
+    Wr, Hr, _ = orc.fit_multiplicative_update_kl(Xs[0], Ws[0].copy(), Hs[0].copy(), 15, 0.0)
+    rk = ms.fit_batched(Xs[0], Ws[0], Hs[0], max_iter=15, tol=0.0, beta_loss="kullback-leibler")
+    assert _rel(Xs[0], rk.W[0], rk.H[0], {"W": Wr, "H": Hr}) <= 3e-5
 
 
 def test_find_synergies_on_an_hd_emg_grid_stays_on_the_gpu():
