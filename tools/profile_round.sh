@@ -1,6 +1,6 @@
 #!/bin/bash
-# rocprofv3 kernel statistics of the round's benchmarks (run on the GPU box: gpurun -- 'bash tools/profile_round.sh r03')
-tag=${1:-r03}
+# rocprofv3 kernel statistics of the round's benchmarks (run on the GPU box: gpurun -- 'bash tools/profile_round.sh r04')
+tag=${1:-r04}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_$tag
@@ -14,12 +14,29 @@ run() {  # name, program args...
 run bench_steps2 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline
 run bench_wide_m64_k8 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --m 64 --k 8
 run bench_wide_m128_k16 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --m 128 --k 16 --batch 512
+run bench_xl_m256_k16 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --m 256 --k 16 --batch 256 --iters 100
+run bench_big_m512_k32 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --m 512 --k 32 --batch 64 --iters 50
 run bench_config4 $R/bench.py --config 4 --steps 1 --warmup 1 --no-cpu-baseline
 run bench_config5 $R/bench.py --config 5 --steps 1 --warmup 1 --no-cpu-baseline
 run bench_config2 $R/bench.py --config 2 --steps 2 --warmup 1 --no-cpu-baseline
-run filter_bench $R/tools/filter_bench.py --orders 4 --dtypes float32
+run filter_bench $R/tools/filter_bench.py --orders 4 --dtypes float32 float64
 run envelope_bench $R/tools/envelope_bench.py
-for n in bench_steps2 bench_wide_m64_k8 bench_wide_m128_k16 bench_config4 bench_config5 bench_config2; do
+for n in bench_steps2 bench_wide_m64_k8 bench_wide_m128_k16 bench_xl_m256_k16 bench_big_m512_k32 bench_config4 bench_config5 bench_config2; do
   grep -h '^{' $O/$n.log > $O/${tag}_${n/bench_steps2/bench}.json
 done
-ls $O/*.csv $O/*.json
+cp $O/filter_bench.log $O/${tag}_filter_bench.log
+# bytes beyond L2 of the time-parallel filter kernel (separate PMC passes, program directly after `--`)
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_scan_$c -- python3 $R/tools/filter_bench.py --orders 4 --dtypes float32 --modes scan --zero-lag 1 > $O/pmc_scan_$c.log 2>&1
+done
+python3 - <<PY > $O/${tag}_pmc_scan_traffic.txt
+import csv, glob
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    vals = []
+    for f in glob.glob("$O/pmc_scan_%s/**/*_counter_collection.csv" % c, recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == c and "sosfilt_scan_kernel" in r["Kernel_Name"]:
+                vals.append(float(r["Counter_Value"]))
+    print(c, "KiB per launch of sosfilt_scan_kernel<float,2,80>:", vals, "(1024 x 16 x 20 000 fp32, zero-lag order 4; algorithmic 2 x 1 310 720 000 B)")
+PY
+ls $O/*.csv $O/*.json $O/*.txt $O/*_filter_bench.log
