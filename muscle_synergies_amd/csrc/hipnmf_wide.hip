@@ -213,8 +213,9 @@ int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
     const WideKernel<real>* w4s = (sliced4 && !kl && m > HIPNMF_NARROW_MAX_FEATURES) ? pick4<real>(m, k, 4) : nullptr;
     if (w4s && w4s->NW == 4 && w4s->smem <= (size_t)h->lds_per_block) wk = w4s;
   }
-  // one workgroup per matrix, Frobenius, at most 8 components: the 4x4x1 / 4x4x4 formulation (HIPNMF_WIDE4=0: the 16x16x4 one)
-  if (!sliced && !kl) {
+  // one workgroup per matrix, at most 8 components: the 4x4x1 / 4x4x4 formulation (HIPNMF_WIDE4=0: the 16x16x4 one); the
+  // Kullback-Leibler loss on its 256-thread fp32 instances of 33..128 channels (round 4), Frobenius on all of them
+  if (!sliced) {
     static const bool use4 = [] {
       const char* e = getenv("HIPNMF_WIDE4");
       return !(e && e[0] == '0');
@@ -225,13 +226,13 @@ int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
     // k <= 4 (one component quad, at the X stream's rate with 8 waves already: 11.4 M at 64 x 2 500): 8
     const WideKernel<real>* w4 = nullptr;
     if (use4) {
-      const int want = h->threads == 256 ? 4 : h->threads == 512 ? 8 : (h->threads == 768 || k > 4) ? 12 : 8;
+      const int want = kl ? 4 : h->threads == 256 ? 4 : h->threads == 512 ? 8 : (h->threads == 768 || k > 4) ? 12 : 8;
       w4 = pick4<real>(m, k, want);
       if (!w4 && want == 12) w4 = pick4<real>(m, k, 8);
+      if (kl && !(w4 && w4->fn_kl)) w4 = nullptr;
     }
     if (w4 && w4->smem <= (size_t)h->lds_per_block) wk = w4;
   }
-
   size_t off = 0;
   auto carve = [&](size_t bytes) {
     size_t o = off;

@@ -105,9 +105,16 @@ struct Wide4Tile {
 };
 
 // NSET: register sets of subtile loads a wave keeps in flight beyond the one being worked on (see fit_wide_kernel)
-template <int MP, int KQ, int NW, int NSET>
+// LOSS: 0 = Frobenius, 1 = Kullback-Leibler (beta_loss = 1; _nmf.py:556-591, 642-684; round 4): W *= ((X / WH) H^T) / rowsum(H),
+// H *= (W'^T (X / W'H)) / colsum(W') with W' the updated W.  Both reconstructions run on the pipe in the numerator's own layout:
+// lane (row r, part p) gathers its row's other component quads from the three lanes "below" (DPP row rotations) and multiplies
+// by H^T read from a transposed copy in LDS (sA, idle during a pass), D: lane (r, p), register e <-> W H [r][16 cb + 4 p + e] --
+// exactly where the lane's X values sit, so Q = X / max(W H, eps) IS the numerator's B operand; Q' goes over X in the stage and
+// W'^T Q' is the Frobenius W^T X.  (Instances with 64 lanes per row only: 33..128 channels.)
+template <int MP, int KQ, int NW, int NSET, int LOSS = 0>
 __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 8))) fit_wide4_kernel(WideArgs<float> a) {
   using C = Wide4Cfg<MP, KQ>;
+  static_assert(LOSS == 0 || C::LP == 64, "the Kullback-Leibler flavour exists for the 64-lanes-per-row instances");
   using Tile = Wide4Tile<MP, KQ>;
   constexpr int KP = C::KP, NH = C::NH, NCB = C::NCB, SX = C::SX, SW = C::SW, SH = C::SH, NLD = C::NLD, RPL = C::RPL,
                 CPR = C::CPR, NT = NW * 64, LP = C::LP, NG = C::NG, CB = C::CB;
@@ -197,6 +204,15 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
   }
   __syncthreads();
   auto compute_hht_lds = [&]() __attribute__((always_inline)) {  // call between barriers
+    if constexpr (LOSS == 1) {  // rowsum(H), the W update's denominator (_nmf.py:577-581), in sHHt[0 .. KP); H^T [MP][KP] in sA
+      for (int c = tid; c < KP; c += NT) {
+        float s = 0.0f;
+        for (int jj = 0; jj < MP; ++jj) s += sH[c * SH + jj];
+        sHHt[c] = s;
+      }
+      for (int idx = tid; idx < KP * MP; idx += NT) sA[idx] = sH[(idx % KP) * SH + idx / KP];
+      return;
+    }
     for (int idx = tid; idx < KP * KP; idx += NT) {
       const int c = idx / KP, c2 = idx % KP;
       float s = 0.0f;
@@ -215,6 +231,7 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
     const int f = 4 * cg + ii;
     comp_a[cg] = KQ * ((p + f / KQ) & 3) + f % KQ;
   }
+  float hsum[KQ];        // KL: rowsum(H) of this lane's components KQ p + e
   float hA[KQ][NCB][4];  // H[comp_a[cg]][16 cb + 4 p + e]
   float hhA[KQ][KQ];     // HHt[comp_a[cg]][KQ p + e]
   auto load_operands = [&]() __attribute__((always_inline)) {
@@ -222,11 +239,43 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
     for (int cg = 0; cg < KQ; ++cg) {
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb) wide_lds_read<float, 4>(sH + comp_a[cg] * SH + 16 * cb + 4 * p, hA[cg][cb]);
+      if constexpr (LOSS == 0) {
 #pragma unroll
-      for (int e = 0; e < KQ; ++e) hhA[cg][e] = sHHt[comp_a[cg] * KP + KQ * p + e];
+        for (int e = 0; e < KQ; ++e) hhA[cg][e] = sHHt[comp_a[cg] * KP + KQ * p + e];
+      }
+    }
+    if constexpr (LOSS == 1) {
+#pragma unroll
+      for (int e = 0; e < KQ; ++e) hsum[e] = sHHt[KQ * p + e];
     }
   };
   load_operands();
+  float csum[KQ];  // KL: this lane's share of colsum(W') (its row, its components)
+  // KL: W H for the lane's row and channels 16 cb + 4 p .. + 3 from a fragment (lane (r, p): components KQ p + e): the other quads'
+  // values come from the lanes D parts below (component KQ ((p - D) mod 4) + e), the matching H^T entries from sA
+  auto wh_block4 = [&](const float (&w)[KQ], int cb) __attribute__((always_inline)) -> w4f4 {
+    float wr[4][KQ];
+#pragma unroll
+    for (int e = 0; e < KQ; ++e) {
+      wr[0][e] = w[e];
+      wr[1][e] = w4_from_part_below<1>(w[e]);
+      wr[2][e] = w4_from_part_below<2>(w[e]);
+      wr[3][e] = w4_from_part_below<3>(w[e]);
+    }
+    w4f4 rec = {0.0f, 0.0f, 0.0f, 0.0f};
+    const float* ht = sA + (16 * cb + 4 * p + ii) * KP;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      float hv[KQ];
+      wide_lds_read<float, KQ>(ht + KQ * ((p - d) & 3), hv);
+#pragma unroll
+      for (int e = 0; e < KQ; ++e) rec = w4_mfma<0, 0>(hv[e], wr[d][e], rec);
+    }
+    return rec;
+  };
+  auto kl_quot4 = [&](float x, float wh) __attribute__((always_inline)) -> float {  // X / max(WH, EPSILON) (_nmf.py:574-575)
+    return fast_div(x, wh < eps_val<float>() ? eps_val<float>() : wh);
+  };
 
   w4f4 accA[NH][KQ], accB[KQ][KQ];
   const w4f4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -242,6 +291,82 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
       for (int e = 0; e < KQ; ++e) wold[e] = t.w[e];
     }
     if (inext >= 0) issue(t, inext);
+    if constexpr (LOSS == 1) {
+      w4f4 num[KQ];
+#pragma unroll
+      for (int cg = 0; cg < KQ; ++cg) num[cg] = zero;
+      const float* xrow = xs + r * SX + 4 * p;
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) {
+        const w4f4 wh = wh_block4(wold, cb);
+        float xb[4];
+        wide_lds_read<float, 4>(xrow + 16 * cb, xb);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float q = kl_quot4(xb[e], wh[e]);
+#pragma unroll
+          for (int cg = 0; cg < KQ; ++cg) num[cg] = w4_mfma<0, 0>(hA[cg][cb][e], q, num[cg]);
+        }
+      }
+      float nn[KQ], dd[KQ], qq[KQ], wn[KQ];
+      {
+        float nf[KP];
+#pragma unroll
+        for (int cg = 0; cg < KQ; ++cg)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) nf[4 * cg + q] = num[cg][q];
+#pragma unroll
+        for (int e = 0; e < KQ; ++e) {
+          nn[e] = ((nf[e] + w4_from_part_below<1>(nf[KQ + e])) + w4_from_part_below<2>(nf[2 * KQ + e])) + w4_from_part_below<3>(nf[3 * KQ + e]);
+          float d = hsum[e];
+          if (a.l1w > 0.0f) d = d + a.l1w;
+          if (a.l2w > 0.0f) d = d + a.l2w * wold[e];
+          dd[e] = (d == 0.0f) ? eps_val<float>() : d;
+        }
+      }
+      quotients<KQ>(nn, dd, qq);
+#pragma unroll
+      for (int e = 0; e < KQ; ++e) wn[e] = wold[e] * qq[e];
+      if (i < ncached) {
+        wide_lds_write<float, KQ>(wc_lane + i * 16 * KP, wn);
+      } else {
+        w4_store<KQ>(w_rsrc(i), wvoff, wn);
+      }
+      if (upd) {
+        wide_lds_write<float, KQ>(wst + r * SW + KQ * p, wn);
+#pragma unroll
+        for (int e = 0; e < KQ; ++e) csum[e] += wn[e];
+        // Q' = X / max(W' H, eps) with the updated rows, written over X in the stage (each lane replaces exactly what it read)
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+          const w4f4 wh = wh_block4(wn, cb);
+          float xb[4], qv[4];
+          wide_lds_read<float, 4>(xrow + 16 * cb, xb);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) qv[e] = kl_quot4(xb[e], wh[e]);
+          wide_lds_write<float, 4>(xs + r * SX + 4 * p + 16 * cb, qv);
+        }
+        wide_wave_lds_fence();
+        float wa[KQ];  // lane 4 blk + i <-> W'[row blk][4 cg + i]  (64 lanes per row: block blk stands for row blk)
+#pragma unroll
+        for (int cg = 0; cg < KQ; ++cg) wa[cg] = wst[blk * SW + 4 * cg + ii];
+        const float* xcol = xs + lane;
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+          float xc[16];
+#pragma unroll
+          for (int s = 0; s < 16; ++s) xc[s] = xcol[s * SX + 64 * h];
+          __builtin_amdgcn_sched_barrier(0);
+          static_for<16>([&](auto S_) {
+            constexpr int s = decltype(S_)::value;
+#pragma unroll
+            for (int cg = 0; cg < KQ; ++cg) accA[h][cg] = w4_mfma<4, s>(wa[cg], xc[s], accA[h][cg]);
+          });
+        }
+      }
+      wide_wave_lds_fence();
+      return;
+    }
     // numerator: partial sums over this lane's quarter of the channels, two chains per component quad
     w4f4 num[KQ], num2[KQ], den[KQ];
 #pragma unroll
@@ -342,6 +467,7 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
   // ---- ||X - W H||_F^2 per column and sum X^2 per column of the whole matrix -> sPart[0 .. 2 MP); barriers inside ----
   auto block_resid = [&]() __attribute__((always_inline)) {
     float sse[NH], xsq[NH];
+    float kl = 0.0f;  // LOSS == 1: generalised KL divergence, element by element as x log(x / wh) - x + wh (_nmf.py:138-161)
     float hB[NH][KP];  // H[c][64 h + lane]  (LP < 64: H[c][lane mod LP], the same in every group of LP lanes)
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
@@ -397,6 +523,15 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
             const float d = xv - rec[e];
             sse[h] = fma_(d, d, sse[h]);
             xsq[h] = fma_(xv, xv, xsq[h]);
+            if constexpr (LOSS == 1) {  // branch-free, as in nmf_wide.hpp
+              const float whv = rec[e];
+              const float whc = whv < eps_val<float>() ? eps_val<float>() : whv;
+              const float xs_ = xv > eps_val<float>() ? xv : eps_val<float>();
+              const float lg = fma_(xv, log_(xs_ / whc), whv - xv);
+              const float term = (xv > eps_val<float>()) ? lg : whv;
+              // MP = 48 / 96: the lanes past the padded width hold no channel (their sse / xsq are dropped below)
+              kl += (MP % 64 == 0 || 64 * h + lane < MP) ? term : 0.0f;
+            }
           }
         });
       }
@@ -410,7 +545,12 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
       sse[0] += __shfl_xor(sse[0], 32, WAVE);
       xsq[0] += __shfl_xor(xsq[0], 32, WAVE);
     }
-    float* rec = xs;  // [2][MP] record of this wave (the stage is idle now)
+    float* rec = xs;  // [2][MP] (+ 1) record of this wave (the stage is idle now)
+    if constexpr (LOSS == 1) {
+#pragma unroll
+      for (int off = 1; off < WAVE; off <<= 1) kl += __shfl_xor(kl, off, WAVE);
+      if (lane == 0) rec[2 * MP] = kl;
+    }
 #pragma unroll
     for (int h = 0; h < NH; ++h)
       if (64 * h + lane < MP) {
@@ -418,7 +558,7 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
         rec[MP + 64 * h + lane] = xsq[h];
       }
     __syncthreads();
-    for (int idx = tid; idx < 2 * MP; idx += NT) {
+    for (int idx = tid; idx < 2 * MP + (LOSS == 1 ? 1 : 0); idx += NT) {
       float s = wv0[idx];
       for (int w2 = 1; w2 < NW; ++w2) s += wv0[w2 * C::PERWAVE + idx];
       sPart[idx] = s;
@@ -426,6 +566,10 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
     __syncthreads();
   };
   auto error_from_part = [&]() __attribute__((always_inline)) -> float {
+    if constexpr (LOSS == 1) {  // sqrt(2 KL(X || WH)) (_nmf.py:185-189)
+      const float d = sPart[2 * MP];
+      return sqrt_(2.0f * (d > 0.0f ? d : 0.0f));
+    }
     float tot = 0.0f;
     for (int jj = 0; jj < m; ++jj) tot += sPart[jj];
     return sqrt_(tot);
@@ -452,6 +596,7 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
             for (int q = 0; q < 4; ++q) rec[(4 * cg + q) * MP + 64 * h + lane] = accA[h][cg][q];
           }
       }
+      if constexpr (LOSS == 1) continue;  // (colsum(W') below instead of W^T W)
 #pragma unroll
       for (int cg2 = 0; cg2 < KQ; ++cg2)
 #pragma unroll
@@ -464,6 +609,17 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
           v += __shfl_xor(v, 32, WAVE);
           if (lane < 4) rec[KP * MP + (4 * cg + q) * KP + 4 * cg2 + lane] = v;
         }
+    }
+    if constexpr (LOSS == 1) {  // colsum(W'): lanes (r, p) of one p hold the 16 rows: the quad (xor 1, 2), then the row quads (xor 16, 32)
+#pragma unroll
+      for (int e = 0; e < KQ; ++e) {
+        float v = csum[e];
+        v += __shfl_xor(v, 1, WAVE);
+        v += __shfl_xor(v, 2, WAVE);
+        v += __shfl_xor(v, 16, WAVE);
+        v += __shfl_xor(v, 32, WAVE);
+        if (ii == 0 && rq == 0) rec[KP * MP + KQ * p + e] = v;
+      }
     }
   };
 
@@ -522,6 +678,7 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
       for (int h = 0; h < NH; ++h) accA[h][cg] = zero;
 #pragma unroll
       for (int cg2 = 0; cg2 < KQ; ++cg2) accB[cg][cg2] = zero;
+      csum[cg] = 0.0f;
     }
     if constexpr (NSET > 1) {
       // pairs of subtiles in a loop without inner exits, then the odd one: with a conditional second half (or with the two
@@ -553,7 +710,7 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
     if (upd) {
       write_record();
       __syncthreads();
-      for (int idx = tid; idx < C::REC; idx += NT) {
+      for (int idx = tid; idx < (LOSS == 1 ? KP * MP + KP : C::REC); idx += NT) {
         float s = wv0[idx];
         for (int w2 = 1; w2 < NW; ++w2) s += wv0[w2 * C::PERWAVE + idx];
         sA[idx] = s;  // sB follows sA
@@ -568,13 +725,22 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
         const int c = idx / MP, jj = idx % MP;
         nh[q] = 0.0f;
         if (idx < KP * MP && c < k && jj < m) {
-          float d = sB[c * KP] * sH[jj];
-          for (int c2 = 1; c2 < k; ++c2) d = fma_(sB[c * KP + c2], sH[c2 * SH + jj], d);
+          float d;
+          if constexpr (LOSS == 1) {  // H *= (W'^T Q') / colsum(W')   (_nmf.py:663-684; colsum 0 -> 1)
+            d = sB[c];
+            if (d == 0.0f) d = 1.0f;
+          } else {
+            d = sB[c * KP] * sH[jj];
+            for (int c2 = 1; c2 < k; ++c2) d = fma_(sB[c * KP + c2], sH[c2 * SH + jj], d);
+          }
           const float hold = sH[c * SH + jj];
           if (a.l1h > 0.0f) d = d + a.l1h;
           if (a.l2h > 0.0f) d = d + a.l2h * hold;
           d = (d == 0.0f) ? eps_val<float>() : d;
           nh[q] = hold * (sA[idx] / d);
+          if constexpr (LOSS == 1) {
+            if (nh[q] < 2.220446049250313e-16f) nh[q] = 0.0f;  // H[H < float64 eps] = 0 (_nmf.py:866-868)
+          }
         }
       }
       __syncthreads();

@@ -379,3 +379,68 @@ print('instances', len(seen), 'problems', bad)
     assert r.returncode == 0 and "problems 0" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
     # fp32: 4 paddings x 2 quads x 3 wave counts + 2 x 2 x 2 (96 / 128 channels: 4, 8 waves); fp64: 4 x 2 x 2 + 2 x 2 (256 threads only)
     assert "instances %d " % (4 * 2 * 3 + 2 * 2 * 2 + 4 * 2 * 2 + 2 * 2) in r.stdout, r.stdout[-300:]
+
+
+# ---- Kullback-Leibler on the 4x4x1 kernel (round 4: fit_wide4_kernel<MP, KQ, 4, 1, LOSS = 1>, 33..128 channels, k <= 8, fp32) ----
+@pytest.mark.parametrize("m,k", [(33, 8), (48, 4), (64, 8), (64, 3), (65, 5), (96, 8), (100, 1), (128, 8), (128, 6)])
+@pytest.mark.parametrize("T", [16, 250, 1003])
+def test_wide4_kullback_leibler_shape_sweep(m, k, T):
+    import muscle_synergies_amd as ms
+    from muscle_synergies_amd import _lib
+
+    X = emg_matrix(m * 7 + k, T=T, m=m, k_true=min(6, m), dtype=np.float32)
+    W0, H0 = random_init(X, k, 3)
+    Wr, Hr, _ = orc.fit_multiplicative_update_kl(X, W0.copy(), H0.copy(), 25, 0.0)
+    for layout in ("F", "C"):
+        Xl = np.asfortranarray(X) if layout == "F" else np.ascontiguousarray(X)
+        res = ms.fit_batched(Xl, W0, H0, max_iter=25, tol=0.0, beta_loss="kullback-leibler")
+        name = _lib.get_handle(0).last_kernel()
+        assert name.startswith("fit_wide4_kernel<") and name.endswith(",4,1,1>"), name
+        xn = np.linalg.norm(X.astype(np.float64))
+        d = np.linalg.norm(res.W[0].astype(np.float64) @ res.H[0] - Wr.astype(np.float64) @ Hr) / xn
+        assert d <= 3e-5, (layout, d)
+        ref_err = np.sqrt(2 * max(orc.kl_divergence(X.astype(np.float64), Wr.astype(np.float64), Hr.astype(np.float64)), 0.0))
+        assert abs(float(res.reconstruction_err[0]) - ref_err) <= 1e-4 * max(ref_err, 1.0)
+        assert (res.W[0] >= 0).all() and (res.H[0] >= 0).all()
+
+
+def test_wide4_kullback_leibler_batch_stop_rule_regularisation_transform_ragged():
+    import muscle_synergies_amd as ms
+    from muscle_synergies_amd import _lib
+
+    m, k = 64, 8
+    Xs, Ws, Hs = [], [], []
+    for s in range(5):
+        X = emg_matrix(80 + s, T=500 + 37 * s if s else 500, m=m, k_true=6, dtype=np.float32)
+        W0, H0 = random_init(X, k, s)
+        Xs.append(X), Ws.append(W0), Hs.append(H0)
+    # stop rule per matrix of a uniform batch
+    Xu = [emg_matrix(90 + s, T=600, m=m, k_true=6, dtype=np.float32) for s in range(4)]
+    iu = [random_init(x, k, s) for s, x in enumerate(Xu)]
+    res = ms.fit_batched(np.stack(Xu), np.stack([w for w, _ in iu]), np.stack([h for _, h in iu]), max_iter=200, tol=2e-3,
+                         beta_loss="kullback-leibler")
+    assert _lib.get_handle(0).last_kernel().endswith(",4,1,1>")
+    for b in range(4):
+        Wr, Hr, n_it = orc.fit_multiplicative_update_kl(Xu[b], iu[b][0].copy(), iu[b][1].copy(), 200, 2e-3)
+        assert int(res.n_iter[b]) == n_it
+        xn = np.linalg.norm(Xu[b].astype(np.float64))
+        assert np.linalg.norm(res.W[b].astype(np.float64) @ res.H[b] - Wr.astype(np.float64) @ Hr) / xn <= 5e-5
+    # regularisation and transform
+    regs = dict(l1_reg_W=0.02, l1_reg_H=0.03, l2_reg_W=0.05, l2_reg_H=0.01)
+    Wr, Hr, _ = orc.fit_multiplicative_update_kl(Xu[0], iu[0][0].copy(), iu[0][1].copy(), 30, 0.0, *regs.values())
+    r = ms.fit_batched(Xu[0], iu[0][0], iu[0][1], max_iter=30, tol=0.0, beta_loss="kullback-leibler", **regs)
+    xn = np.linalg.norm(Xu[0].astype(np.float64))
+    assert np.linalg.norm(r.W[0].astype(np.float64) @ r.H[0] - Wr.astype(np.float64) @ Hr) / xn <= 3e-5
+    Wt = np.full_like(iu[0][0], np.sqrt(Xu[0].mean() / k))
+    Wt_ref, _, _ = orc.fit_multiplicative_update_kl(Xu[0], Wt.copy(), Hr.copy(), 20, 0.0, update_H=False)
+    rt = ms.fit_batched(Xu[0], Wt, Hr, max_iter=20, tol=0.0, beta_loss="kullback-leibler", update_H=False)
+    np.testing.assert_array_equal(rt.H[0], Hr)
+    np.testing.assert_allclose(rt.W[0], Wt_ref, rtol=2e-3, atol=1e-6)
+    # trials of unequal length
+    rr = ms.fit_ragged(Xs, Ws, Hs, max_iter=25, tol=0.0, beta_loss="kullback-leibler")
+    assert _lib.get_handle(0).last_kernel().endswith(",4,1,1>")
+    for b in range(5):
+        Wr, Hr, _ = orc.fit_multiplicative_update_kl(Xs[b], Ws[b].copy(), Hs[b].copy(), 25, 0.0)
+        xn = np.linalg.norm(Xs[b].astype(np.float64))
+        W, H = rr.W[b].cpu().numpy(), rr.H[b].cpu().numpy()
+        assert np.linalg.norm(W.astype(np.float64) @ H - Wr.astype(np.float64) @ Hr) / xn <= 3e-5
