@@ -1,13 +1,19 @@
 // hipnmf_envelope.hip -- C ABI of the EMG envelope preprocessing (include/hip_nmf.h, row f-1 of SURVEY.md section 8).
 #include <algorithm>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 
+#include "envelope_chunk.hpp"
 #include "envelope_kernels.hpp"
 #include "hipnmf_internal.hpp"
 #include "nmf_kernels.hpp"  // x_to_channel_major_kernel
 
 using namespace hipnmf;
+
+#ifndef HIPNMF_ENV_CHUNK_MIN_T_DEFAULT
+#define HIPNMF_ENV_CHUNK_MIN_T_DEFAULT 1280  // below: emg_wave_kernel (tools/envelope_chunk_sweep.sh)
+#endif
 
 namespace {
 
@@ -91,8 +97,35 @@ int envelope_impl(hipnmf_handle* h, const hipnmf_envelope_params* p, const real*
   const size_t wg_lds = sizeof(double) * ((size_t)wg_nw * (ring4 + ring4 / 8) + (size_t)wg_nw);
   const bool wg = wave && wg_ok && wg_nw > 0 && (p->n_out == 0 || p->n_out == T) && WG_TILE + p->window + 1 <= ring4 &&
                   ring4 <= 4096 && wg_lds <= (size_t)h->lds_per_block;
+  // a series that fits the LDS of one workgroup (emg_chunk_kernel: a thread owns C consecutive samples, one scan per series):
+  // C = 81 / 41 / 17 by length; HIPNMF_ENV_CHUNK=0 leaves those to the kernels above, HIPNMF_ENV_CHUNK_MIN_T moves the lower end
+  static const bool chunk_ok = [] {
+    const char* e = getenv("HIPNMF_ENV_CHUNK");
+    return !(e && atoi(e) == 0);
+  }();
+  static const long long chunk_min_t = [] {
+    const char* e = getenv("HIPNMF_ENV_CHUNK_MIN_T");
+    return e ? atoll(e) : (long long)HIPNMF_ENV_CHUNK_MIN_T_DEFAULT;
+  }();
+  const long long chunk_span = T + (p->window - 1) / 2;  // positions the window's leading edge visits
+  int chunk_c = 0;
+  if (chunk_ok && p->window >= 1 && T >= 2 && T >= chunk_min_t) {
+    // the shortest compiled chunk that covers the span (idle threads cost as much as busy ones); double: up to 41 (LDS)
+    constexpr int chunk_sizes[] = {9, 13, 17, 25, 33, 41, 49, 57, 65, 73, 81};
+    for (int c : chunk_sizes)
+      if (chunk_span <= 256LL * c && (sizeof(real) == 4 || c <= 41)) {
+        chunk_c = c;
+        break;
+      }
+  }
+  const int chunk_nact = chunk_c ? (int)((chunk_span + chunk_c - 1) / chunk_c) : 0;
+  const size_t chunk_lds = ((sizeof(real) * ((size_t)p->window + (size_t)chunk_nact * chunk_c) + 15) & ~(size_t)15) + 12 * sizeof(double);
+  // time-normalised output: only while two workgroups share a CU (measured: one alone loses to emg_wave_kernel, which overlaps
+  // its single read stream across 16 waves per CU; the full-length output wins either way, its write stream is what counts)
+  const bool chunk = chunk_c > 0 && chunk_lds <= (size_t)h->lds_per_block &&
+                     ((p->n_out == 0 || p->n_out == T) || 2 * chunk_lds <= (size_t)h->lds_per_block);
   const bool fused = wave || (fused_ok && fused_lds <= 96 * 1024);
-  const bool resample_tab = wave && p->n_out > 0 && p->n_out != T;
+  const bool resample_tab = (wave || chunk) && p->n_out > 0 && p->n_out != T;
   const size_t o_ti = resample_tab ? carve(sizeof(int) * (size_t)p->n_out) : 0;
   const size_t o_tw = resample_tab ? carve(sizeof(double) * (size_t)p->n_out) : 0;
   const size_t o_ps = fused ? 0 : carve(sizeof(double) * (size_t)B * m * (T + 1));
@@ -133,7 +166,34 @@ int envelope_impl(hipnmf_handle* h, const hipnmf_envelope_params* p, const real*
   if (resample_tab)
     hipLaunchKernelGGL(env_resample_table_kernel, dim3((unsigned)((p->n_out + 255) / 256)), dim3(256), 0, st, (int)T, (int)p->n_out, (int)p->resample_kind,
                        reinterpret_cast<int*>(ws + o_ti), reinterpret_cast<double*>(ws + o_tw));
-  if (wg) {
+  if (chunk) {
+    auto launch_chunk = [&](auto kern, const char* name) -> int {
+      if (chunk_lds > 48 * 1024)
+        if (int arc = hipnmf_allow_full_lds(h, reinterpret_cast<const void*>(kern))) return arc;
+      hipLaunchKernelGGL(kern, dim3(m, B), dim3(CHUNK_THREADS), chunk_lds, st, a, chunk_nact);
+      snprintf(h->last_kernel, sizeof(h->last_kernel), "%s", name);
+      return HIPNMF_OK;
+    };
+    int rcc = HIPNMF_ERR_UNSUPPORTED;
+    char name[64];
+    snprintf(name, sizeof(name), "emg_chunk_kernel<%s,%d>", sizeof(real) == 4 ? "float" : "double", chunk_c);
+    switch (chunk_c) {
+#define HIPNMF_CHUNK_CASE(C_) \
+  case C_:                    \
+    rcc = launch_chunk(emg_chunk_kernel<real, C_>, name); \
+    break;
+      HIPNMF_CHUNK_CASE(9) HIPNMF_CHUNK_CASE(13) HIPNMF_CHUNK_CASE(17) HIPNMF_CHUNK_CASE(25) HIPNMF_CHUNK_CASE(33) HIPNMF_CHUNK_CASE(41)
+      default:
+        if constexpr (sizeof(real) == 4) {
+          switch (chunk_c) {
+            HIPNMF_CHUNK_CASE(49) HIPNMF_CHUNK_CASE(57) HIPNMF_CHUNK_CASE(65) HIPNMF_CHUNK_CASE(73) HIPNMF_CHUNK_CASE(81)
+          }
+        }
+#undef HIPNMF_CHUNK_CASE
+    }
+    if (rcc) return rcc;
+  } else if (wg) {
+    snprintf(h->last_kernel, sizeof(h->last_kernel), "emg_wg_kernel");
     auto launch_wg = [&](auto kern) -> int {
       if (wg_lds > 48 * 1024)
         if (int arc = hipnmf_allow_full_lds(h, reinterpret_cast<const void*>(kern))) return arc;
@@ -147,16 +207,19 @@ int envelope_impl(hipnmf_handle* h, const hipnmf_envelope_params* p, const real*
       rcw = wg_nw == 8 ? launch_wg(emg_wg_kernel<real, 8, 6>) : launch_wg(emg_wg_kernel<real, 16, 7>);
     if (rcw) return rcw;
   } else if (wave) {
+    snprintf(h->last_kernel, sizeof(h->last_kernel), "emg_wave_kernel");
     const size_t lds = sizeof(double) * (size_t)(ring + ring / 8);
     if (wave_spl == 4)
       hipLaunchKernelGGL((emg_wave_kernel<real, 4>), dim3(m, B), dim3(64), lds, st, a, ring);
     else
       hipLaunchKernelGGL((emg_wave_kernel<real, 8>), dim3(m, B), dim3(64), lds, st, a, ring);
   } else if (fused) {
+    snprintf(h->last_kernel, sizeof(h->last_kernel), "emg_fused_kernel");
     if (fused_lds > 48 * 1024)
       if (int arc = hipnmf_allow_full_lds(h, reinterpret_cast<const void*>(emg_fused_kernel<real>))) return arc;
     hipLaunchKernelGGL(emg_fused_kernel<real>, dim3(m, B), dim3(256), fused_lds, st, a);
   } else {
+    snprintf(h->last_kernel, sizeof(h->last_kernel), "emg_prefix_kernel+emg_output_kernel");
     hipLaunchKernelGGL(emg_prefix_kernel<real>, dim3(m, B), dim3(256), 0, st, a);
     hipLaunchKernelGGL(emg_output_kernel<real>, dim3(m, B), dim3(256), 0, st, a);
   }

@@ -101,6 +101,8 @@ def test_gpu_batch_feeds_the_solver_without_a_copy():
     assert bool(torch.isfinite(r.reconstruction_err).all()) and float(r.vaf[:, 0].min()) > 0.5
 
 
+# Round 4: series of 1 280 .. 20 480 samples with a window go to emg_chunk_kernel (envelope_chunk.hpp); the kernels named in the
+# comments below are what HIPNMF_ENV_CHUNK=0 selects (test_gpu_envelope_kernels_without_the_chunk_kernel runs the list that way).
 # Shapes chosen to reach every envelope kernel (hipnmf_envelope.hip picks by shape): emg_wg_kernel (full-length
 # output of a series that fits in the registers of a workgroup), emg_wave_kernel (everything else with a window: ragged tiles, long windows,
 # up-sampling, the re-basing of the running prefix past 65 536 samples, unaligned channel rows) and
@@ -157,6 +159,89 @@ def test_gpu_envelope_kernels_match_oracle(case, layout):
             np.testing.assert_allclose(out[b], ref, rtol=3e-5, atol=3e-6 * np.abs(ref).max())
         else:
             np.testing.assert_allclose(out[b], ref, rtol=1e-9, atol=1e-12)
+
+
+_CHUNK_CASES = [
+    # T, m, W, reduce_to, normalize, zero_center, dtype, expected kernel
+    (20000, 2, 200, None, True, True, np.float32, "emg_chunk_kernel<float,81>"),   # the benchmark shape
+    (20000, 2, 200, 200, True, True, np.float32, "emg_chunk_kernel<float,81>"),    # ... time-normalised
+    (20000, 2, 279, None, True, False, np.float32, "emg_chunk_kernel<float,81>"),  # widest window with two workgroups per CU
+    (20480, 1, 256, None, False, True, np.float32, "emg_chunk_kernel<float,81>"),  # 20 480 + 127 positions of the 20 736
+    (20609, 2, 255, None, True, True, np.float32, "emg_chunk_kernel<float,81>"),   # the last position of the last thread
+    (20610, 2, 255, None, True, True, np.float32, "emg_wave_kernel"),              # one more: no instance
+    (20000, 2, 1400, 300, True, True, np.float32, "emg_wave_kernel"),              # time-normalised, LDS for one workgroup only
+    (20000, 2, 1400, None, True, True, np.float32, "emg_chunk_kernel<float,81>"),  # full length takes it all the same
+    (1280, 3, 37, None, True, True, np.float32, "emg_chunk_kernel<float,9>"),      # shortest series, smallest instance
+    (1279, 3, 37, None, True, True, np.float32, "emg_wave_kernel"),
+    (2304 - 18, 2, 37, 100, False, True, np.float32, "emg_chunk_kernel<float,9>"),   # all 256 threads own a chunk
+    (2304 - 17, 2, 37, 100, False, True, np.float32, "emg_chunk_kernel<float,13>"),
+    (5000, 2, 3000, None, True, True, np.float64, "emg_chunk_kernel<double,33>"),  # window longer than half the series
+    (5001, 3, 5001, None, True, True, np.float64, "emg_chunk_kernel<double,33>"),  # window = series
+    (4097, 2, 1, 4000, True, False, np.float64, "emg_chunk_kernel<double,17>"),    # window of one sample, dense time normalisation
+    (4097, 2, 2, None, True, True, np.float32, "emg_chunk_kernel<float,17>"),      # even window of two
+    (10000, 2, 200, None, True, True, np.float64, "emg_chunk_kernel<double,41>"),  # float64 at the top of its range (one workgroup per CU)
+    (10000, 2, 200, 500, True, True, np.float64, "emg_wave_kernel"),               # ... time-normalised: left to the wave kernel
+    (9000, 2, 200, 500, True, True, np.float64, "emg_chunk_kernel<double,41>"),
+    (10497, 2, 1, None, True, True, np.float64, "emg_wg_kernel"),                  # one position more than 256 x 41
+    (3000, 2, 100, 9001, True, True, np.float32, "emg_chunk_kernel<float,13>"),    # up-sampling
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", _CHUNK_CASES, ids=lambda c: f"T{c[0]}-m{c[1]}-W{c[2]}-r{c[3]}-n{int(c[4])}-z{int(c[5])}-{np.dtype(c[6]).name}")
+@pytest.mark.parametrize("layout", ["C", "F"])
+def test_gpu_envelope_chunk_kernel(case, layout):
+    """emg_chunk_kernel (round 4): every instance boundary, both outputs, and the shapes either side that must not take it."""
+    from muscle_synergies_amd import _lib
+    from muscle_synergies_amd.preprocess import emg_envelope_batched
+
+    T, m, W, reduce_to, norm, zc, dtype, kernel = case
+    B = 3
+    raw = np.stack([raw_emg(900 + 11 * b + T % 89, T, m) for b in range(B)]).astype(dtype)
+    raw[1] += 0.37
+    raw[2, :, 0] *= 1e-3  # a quiet channel next to loud ones
+    x = np.ascontiguousarray(raw) if layout == "C" else np.ascontiguousarray(raw.transpose(0, 2, 1)).transpose(0, 2, 1)
+    out = emg_envelope_batched(x, W, reduce_to=reduce_to, normalize=norm, zero_center=zc).cpu().numpy()
+    assert _lib.get_handle(0).last_kernel() == kernel
+    for b in range(B):
+        ref = eo.envelope(raw[b].astype(np.float64), W, reduce_to, do_zero_center=zc, do_normalize=norm)
+        for c in range(m):  # per channel: the quiet one is held to its own scale
+            top = float(np.abs(ref[:, c]).max())
+            if dtype == np.float32:
+                np.testing.assert_allclose(out[b][:, c], ref[:, c], rtol=3e-5, atol=3e-6 * top)
+            else:
+                np.testing.assert_allclose(out[b][:, c], ref[:, c], rtol=1e-9, atol=1e-6 * top if W <= 8 else 1e-12 * max(top, 1.0))
+
+
+@pytest.mark.gpu
+def test_gpu_envelope_kernels_without_the_chunk_kernel():
+    """HIPNMF_ENV_CHUNK=0: the round-2 kernels (emg_wg_kernel / emg_wave_kernel) still serve every shape of _KERNEL_CASES."""
+    import os
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    code = """
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from test_envelope import _KERNEL_CASES, raw_emg, eo
+from muscle_synergies_amd import _lib
+from muscle_synergies_amd.preprocess import emg_envelope_batched
+bad = 0; seen = set()
+for T, m, W, reduce_to, norm, zc, dtype in _KERNEL_CASES:
+    raw = np.stack([raw_emg(300 + 7 * b + T %% 97, T, m) for b in range(2)]).astype(dtype); raw[1] += 0.37
+    out = emg_envelope_batched(np.ascontiguousarray(raw), W, reduce_to=reduce_to, normalize=norm, zero_center=zc).cpu().numpy()
+    seen.add(_lib.get_handle(0).last_kernel())
+    for b in range(2):
+        ref = eo.envelope(raw[b].astype(np.float64), W, reduce_to, do_zero_center=zc, do_normalize=norm)
+        ok = np.allclose(out[b], ref, rtol=3e-5, atol=3e-6 * np.abs(ref).max()) if dtype == np.float32 else np.allclose(out[b], ref, rtol=1e-9, atol=1e-12)
+        if not ok: print('MISMATCH', T, m, W, reduce_to, norm, zc, dtype); bad += 1
+print('kernels', sorted(seen)); print('problems', bad)
+""" % (ROOT, os.path.join(ROOT, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, HIPNMF_ENV_CHUNK="0"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "problems 0" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "emg_wg_kernel" in r.stdout and "emg_wave_kernel" in r.stdout and "emg_fused_kernel" in r.stdout and "emg_chunk" not in r.stdout
 
 
 @pytest.mark.gpu
