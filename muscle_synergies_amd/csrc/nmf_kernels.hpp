@@ -60,6 +60,17 @@ __device__ __forceinline__ float fast_div(float n, float d) {
   const float e = __builtin_fmaf(-d, q, n);
   return __builtin_fmaf(e, r, q);
 }
+// x / wh of the Kullback-Leibler updates (_nmf.py:574-577, 660-663), 32 quotients per row of a 16-channel matrix and iteration:
+// the bare reciprocal (1 ulp) times x, without the correction step of fast_div -- the quotient feeds sums of 16 / of all rows
+// and the tolerance of the path is 1e-5 (north_star); wh >= EPSILON, so the reciprocal cannot overflow.  -DHIPNMF_KL_EXACT_Q
+// restores fast_div.
+__device__ __forceinline__ float kl_quot(float x, float wh) {
+#ifdef HIPNMF_KL_EXACT_Q
+  return fast_div(x, wh);
+#else
+  return x * __builtin_amdgcn_rcpf(wh);
+#endif
+}
 template <int K>
 __device__ __forceinline__ void quotients(const float (&n)[K], const float (&d)[K], float (&q)[K]) {
 #ifdef HIPNMF_EXACT_DIV
@@ -575,7 +586,7 @@ __device__ __forceinline__ void update_tile_kl(RowTile<real, G, CH, K>& t, const
       for (int c = 1; c < K; ++c) rec = fma_(wr[c], h[c][cc], rec);
       rec = rec < eps_val<real>() ? eps_val<real>() : rec;
       if constexpr (sizeof(real) == 4)
-        q[cc][r] = fast_div(t.x[cc][r], rec);
+        q[cc][r] = kl_quot(t.x[cc][r], rec);
       else
         q[cc][r] = t.x[cc][r] / rec;
     }
@@ -619,7 +630,7 @@ __device__ __forceinline__ void update_tile_kl(RowTile<real, G, CH, K>& t, const
         rec = rec < eps_val<real>() ? eps_val<real>() : rec;
         real qq;
         if constexpr (sizeof(real) == 4)
-          qq = fast_div(t.x[cc][r], rec);
+          qq = kl_quot(t.x[cc][r], rec);
         else
           qq = t.x[cc][r] / rec;
 #pragma unroll

@@ -347,7 +347,7 @@ fit_wide_kernel(WideArgs<real> a) {
   auto kl_quot = [&](real x, real wh) __attribute__((always_inline)) -> real {  // X / max(WH, EPSILON) (_nmf.py:574-575)
     const real d = wh < eps_val<real>() ? eps_val<real>() : wh;
     if constexpr (sizeof(real) == 4)
-      return fast_div(x, d);
+      return hipnmf::kl_quot(x, d);  // (nmf_kernels.hpp: the bare reciprocal)
     else
       return x / d;
   };

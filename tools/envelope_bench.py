@@ -15,11 +15,12 @@ ap.add_argument("--dtype", default="float32")
 ap.add_argument("--no-normalize", action="store_true", help="skip the division by the channel maximum (second sweep over the output)")
 ap.add_argument("--no-center", action="store_true", help="skip zero_center (the mean pass over the raw samples)")
 ap.add_argument("--reps", type=int, default=15)
+ap.add_argument("--reduce-to", nargs="*", default=["none", "200"], help="output lengths to time: 'none' (full length) or a number of points")
 a = ap.parse_args()
 dt = getattr(torch, a.dtype)
 raw = torch.randn((a.batch, a.m, a.T), device="cuda:0", dtype=dt).transpose(1, 2)
 h = _lib.get_handle(0)
-for reduce_to in (None, 200):
+for reduce_to in [None if r == "none" else int(r) for r in a.reduce_to]:
     times = []
     for rep in range(a.reps + 2):
         out = emg_envelope_batched(raw, a.window, reduce_to=reduce_to, normalize=not a.no_normalize,
