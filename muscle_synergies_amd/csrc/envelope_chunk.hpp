@@ -25,7 +25,7 @@
 
 namespace hipnmf {
 
-constexpr int CHUNK_THREADS = 256;
+constexpr int CHUNK_RED = 24;  // doubles of reduction scratch behind the samples (3 per wave, up to 8 waves)
 #ifndef HIPNMF_CHUNK_LD_AUX
 #define HIPNMF_CHUNK_LD_AUX 0
 #endif
@@ -52,9 +52,11 @@ __device__ __forceinline__ double chunk_centred(real x, double mean, bool inside
   return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | (unsigned)u);
 }
 
-template <typename real, int C>
-__global__ void __launch_bounds__(CHUNK_THREADS, 2) emg_chunk_kernel(EnvArgs a, int nact /* threads that own a chunk */) {
+template <typename real, int C, int NT>
+__global__ void __launch_bounds__(NT, NT / 128) emg_chunk_kernel(EnvArgs a, int nact /* threads that own a chunk */) {
   static_assert(C % 2 == 1, "odd chunk length: conflict-free LDS stride");
+  static_assert(NT == 256 || NT == 512, "four or eight waves");
+  constexpr int CHUNK_THREADS = NT, NW = NT / 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char env_smem[];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int ch = blockIdx.x, b = blockIdx.y;
@@ -66,7 +68,7 @@ __global__ void __launch_bounds__(CHUNK_THREADS, 2) emg_chunk_kernel(EnvArgs a, 
   real* __restrict__ o = static_cast<real*>(a.out) + cidx * (long long)n_out;
   const int NS = nact * C;                            // positions p in [0, NS): p < T samples, then zeros
   real* __restrict__ xs = reinterpret_cast<real*>(env_smem) + W;  // xs[p], p in [-W, NS)
-  double* __restrict__ red = reinterpret_cast<double*>(env_smem + (((size_t)(W + NS) * sizeof(real) + 15) & ~(size_t)15));  // [12]
+  double* __restrict__ red = reinterpret_cast<double*>(env_smem + (((size_t)(W + NS) * sizeof(real) + 15) & ~(size_t)15));  // [3 NW]
   const rsrc_t xr = make_rsrc(x, (unsigned)((long long)T * (long long)sizeof(real)));
   const rsrc_t orr = make_rsrc(o, (unsigned)((long long)n_out * (long long)sizeof(real)));
 
@@ -102,7 +104,11 @@ __global__ void __launch_bounds__(CHUNK_THREADS, 2) emg_chunk_kernel(EnvArgs a, 
       if (lane == 0) red[wave] = acc;
     }
     __syncthreads();
-    if (a.zero_center) mean = ((red[0] + red[1]) + (red[2] + red[3])) / (double)T;
+    if (a.zero_center) {
+      double tot = (red[0] + red[1]) + (red[2] + red[3]);
+      if constexpr (NW == 8) tot += (red[4] + red[5]) + (red[6] + red[7]);
+      mean = tot / (double)T;
+    }
   }
 
   // ---- 2. the window slides over the thread's chunk ------------------------------------------------------------------------
@@ -127,10 +133,10 @@ __global__ void __launch_bounds__(CHUNK_THREADS, 2) emg_chunk_kernel(EnvArgs a, 
 
   // ---- 3. R before the chunk: exclusive scan of the threads' totals ----------------------------------------------------------
   const double inc = env_wave_inclusive_scan(run);
-  if (lane == 63) red[4 + wave] = inc;
+  if (lane == 63) red[NW + wave] = inc;
   __syncthreads();  // (also: every read of the samples is done)
   double base = inc - run;
-  for (int w2 = 0; w2 < wave; ++w2) base += red[4 + w2];
+  for (int w2 = 0; w2 < wave; ++w2) base += red[NW + w2];
 
   // ---- 4. outputs over the dead samples: slot p holds output i = p - hi ------------------------------------------------------
   // (time normalisation: only the two neighbours of every output get their root, so the slots hold the window sums)
@@ -166,9 +172,11 @@ __global__ void __launch_bounds__(CHUNK_THREADS, 2) emg_chunk_kernel(EnvArgs a, 
     double vmax = (double)vmx;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) vmax = fmax(vmax, __shfl_xor(vmax, off, 64));
-    if (lane == 0) red[8 + wave] = vmax;
+    if (lane == 0) red[2 * NW + wave] = vmax;
     __syncthreads();
-    vmax = fmax(fmax(red[8], red[9]), fmax(red[10], red[11]));
+    vmax = red[2 * NW];
+#pragma unroll
+    for (int w2 = 1; w2 < NW; ++w2) vmax = fmax(vmax, red[2 * NW + w2]);
     const float vmf = (float)vmax;
     // y / vmax as the reference rounds it (env_scaled) costs ~10 instructions; with a reciprocal and one correction step
     // (q = y r, q += (y - q v) r) the quotient is the correctly rounded one up to rare off-by-an-ulp cases; that path is taken
@@ -216,9 +224,11 @@ __global__ void __launch_bounds__(CHUNK_THREADS, 2) emg_chunk_kernel(EnvArgs a, 
     if (norm) {
 #pragma unroll
       for (int off = 32; off >= 1; off >>= 1) vm = fmax(vm, __shfl_xor(vm, off, 64));
-      if (lane == 0) red[8 + wave] = vm;
+      if (lane == 0) red[2 * NW + wave] = vm;
       __syncthreads();
-      vm = fmax(fmax(red[8], red[9]), fmax(red[10], red[11]));
+      vm = red[2 * NW];
+#pragma unroll
+      for (int w2 = 1; w2 < NW; ++w2) vm = fmax(vm, red[2 * NW + w2]);
     }
     const float vmf = (float)vm;
     for (int q = t; q < n_out; q += CHUNK_THREADS) {

@@ -108,7 +108,11 @@ int envelope_impl(hipnmf_handle* h, const hipnmf_envelope_params* p, const real*
     return e ? atoll(e) : (long long)HIPNMF_ENV_CHUNK_MIN_T_DEFAULT;
   }();
   const long long chunk_span = T + (p->window - 1) / 2;  // positions the window's leading edge visits
-  int chunk_c = 0;
+  int chunk_c = 0, chunk_nt = 256;
+  static const bool chunk_wide_ok = [] {
+    const char* e = getenv("HIPNMF_ENV_CHUNK_512");
+    return !(e && atoi(e) == 0);
+  }();
   if (chunk_ok && p->window >= 1 && T >= 2 && T >= chunk_min_t) {
     // the shortest compiled chunk that covers the span (idle threads cost as much as busy ones); double: up to 41 (LDS)
     constexpr int chunk_sizes[] = {9, 13, 17, 25, 33, 41, 49, 57, 65, 73, 81};
@@ -117,9 +121,15 @@ int envelope_impl(hipnmf_handle* h, const hipnmf_envelope_params* p, const real*
         chunk_c = c;
         break;
       }
+    // float, the longest series: eight waves with half the chunk each (four waves per SIMD instead of two hide a little more
+    // of the slide's latencies: 0.59 -> 0.55 / 0.337 -> 0.326 ms at 20 000 samples; no gain or a loss below ~17 000)
+    if (sizeof(real) == 4 && chunk_c == 81 && chunk_wide_ok) {
+      chunk_nt = 512;
+      chunk_c = 41;
+    }
   }
-  const int chunk_nact = chunk_c ? (int)((chunk_span + chunk_c - 1) / chunk_c) : 0;
-  const size_t chunk_lds = ((sizeof(real) * ((size_t)p->window + (size_t)chunk_nact * chunk_c) + 15) & ~(size_t)15) + 12 * sizeof(double);
+  const int chunk_nact = chunk_c ? (int)((chunk_span + chunk_c - 1) / chunk_c) : 0;  // (<= chunk_nt)
+  const size_t chunk_lds = ((sizeof(real) * ((size_t)p->window + (size_t)chunk_nact * chunk_c) + 15) & ~(size_t)15) + CHUNK_RED * sizeof(double);
   // time-normalised output: only while two workgroups share a CU (measured: one alone loses to emg_wave_kernel, which overlaps
   // its single read stream across 16 waves per CU; the full-length output wins either way, its write stream is what counts)
   const bool chunk = chunk_c > 0 && chunk_lds <= (size_t)h->lds_per_block &&
@@ -170,27 +180,32 @@ int envelope_impl(hipnmf_handle* h, const hipnmf_envelope_params* p, const real*
     auto launch_chunk = [&](auto kern, const char* name) -> int {
       if (chunk_lds > 48 * 1024)
         if (int arc = hipnmf_allow_full_lds(h, reinterpret_cast<const void*>(kern))) return arc;
-      hipLaunchKernelGGL(kern, dim3(m, B), dim3(CHUNK_THREADS), chunk_lds, st, a, chunk_nact);
+      hipLaunchKernelGGL(kern, dim3(m, B), dim3(chunk_nt), chunk_lds, st, a, chunk_nact);
       snprintf(h->last_kernel, sizeof(h->last_kernel), "%s", name);
       return HIPNMF_OK;
     };
     int rcc = HIPNMF_ERR_UNSUPPORTED;
     char name[64];
-    snprintf(name, sizeof(name), "emg_chunk_kernel<%s,%d>", sizeof(real) == 4 ? "float" : "double", chunk_c);
-    switch (chunk_c) {
-#define HIPNMF_CHUNK_CASE(C_) \
-  case C_:                    \
-    rcc = launch_chunk(emg_chunk_kernel<real, C_>, name); \
+    snprintf(name, sizeof(name), "emg_chunk_kernel<%s,%d,%d>", sizeof(real) == 4 ? "float" : "double", chunk_c, chunk_nt);
+#define HIPNMF_CHUNK_CASE(C_, NT_) \
+  case C_:                         \
+    rcc = launch_chunk(emg_chunk_kernel<real, C_, NT_>, name); \
     break;
-      HIPNMF_CHUNK_CASE(9) HIPNMF_CHUNK_CASE(13) HIPNMF_CHUNK_CASE(17) HIPNMF_CHUNK_CASE(25) HIPNMF_CHUNK_CASE(33) HIPNMF_CHUNK_CASE(41)
-      default:
-        if constexpr (sizeof(real) == 4) {
-          switch (chunk_c) {
-            HIPNMF_CHUNK_CASE(49) HIPNMF_CHUNK_CASE(57) HIPNMF_CHUNK_CASE(65) HIPNMF_CHUNK_CASE(73) HIPNMF_CHUNK_CASE(81)
+    if (chunk_nt == 256) {
+      switch (chunk_c) {
+        HIPNMF_CHUNK_CASE(9, 256) HIPNMF_CHUNK_CASE(13, 256) HIPNMF_CHUNK_CASE(17, 256) HIPNMF_CHUNK_CASE(25, 256) HIPNMF_CHUNK_CASE(33, 256)
+        HIPNMF_CHUNK_CASE(41, 256)
+        default:
+          if constexpr (sizeof(real) == 4) {
+            switch (chunk_c) { HIPNMF_CHUNK_CASE(49, 256) HIPNMF_CHUNK_CASE(57, 256) HIPNMF_CHUNK_CASE(65, 256) HIPNMF_CHUNK_CASE(73, 256) HIPNMF_CHUNK_CASE(81, 256) }
           }
-        }
-#undef HIPNMF_CHUNK_CASE
+      }
+    } else {
+      if constexpr (sizeof(real) == 4) {
+        switch (chunk_c) { HIPNMF_CHUNK_CASE(41, 512) }
+      }
     }
+#undef HIPNMF_CHUNK_CASE
     if (rcc) return rcc;
   } else if (wg) {
     snprintf(h->last_kernel, sizeof(h->last_kernel), "emg_wg_kernel");

@@ -163,27 +163,29 @@ def test_gpu_envelope_kernels_match_oracle(case, layout):
 
 _CHUNK_CASES = [
     # T, m, W, reduce_to, normalize, zero_center, dtype, expected kernel
-    (20000, 2, 200, None, True, True, np.float32, "emg_chunk_kernel<float,81>"),   # the benchmark shape
-    (20000, 2, 200, 200, True, True, np.float32, "emg_chunk_kernel<float,81>"),    # ... time-normalised
-    (20000, 2, 279, None, True, False, np.float32, "emg_chunk_kernel<float,81>"),  # widest window with two workgroups per CU
-    (20480, 1, 256, None, False, True, np.float32, "emg_chunk_kernel<float,81>"),  # 20 480 + 127 positions of the 20 736
-    (20609, 2, 255, None, True, True, np.float32, "emg_chunk_kernel<float,81>"),   # the last position of the last thread
+    (20000, 2, 200, None, True, True, np.float32, "emg_chunk_kernel<float,41,512>"),   # the benchmark shape
+    (20000, 2, 200, 200, True, True, np.float32, "emg_chunk_kernel<float,41,512>"),    # ... time-normalised
+    (20000, 2, 279, None, True, False, np.float32, "emg_chunk_kernel<float,41,512>"),  # widest window with two workgroups per CU
+    (20480, 1, 256, None, False, True, np.float32, "emg_chunk_kernel<float,41,512>"),  # 20 480 + 127 positions of the 20 736
+    (20609, 2, 255, None, True, True, np.float32, "emg_chunk_kernel<float,41,512>"),   # the last position of the last thread
     (20610, 2, 255, None, True, True, np.float32, "emg_wave_kernel"),              # one more: no instance
     (20000, 2, 1400, 300, True, True, np.float32, "emg_wave_kernel"),              # time-normalised, LDS for one workgroup only
-    (20000, 2, 1400, None, True, True, np.float32, "emg_chunk_kernel<float,81>"),  # full length takes it all the same
-    (1280, 3, 37, None, True, True, np.float32, "emg_chunk_kernel<float,9>"),      # shortest series, smallest instance
+    (20000, 2, 1400, None, True, True, np.float32, "emg_chunk_kernel<float,41,512>"),  # full length takes it all the same
+    (1280, 3, 37, None, True, True, np.float32, "emg_chunk_kernel<float,9,256>"),      # shortest series, smallest instance
     (1279, 3, 37, None, True, True, np.float32, "emg_wave_kernel"),
-    (2304 - 18, 2, 37, 100, False, True, np.float32, "emg_chunk_kernel<float,9>"),   # all 256 threads own a chunk
-    (2304 - 17, 2, 37, 100, False, True, np.float32, "emg_chunk_kernel<float,13>"),
-    (5000, 2, 3000, None, True, True, np.float64, "emg_chunk_kernel<double,33>"),  # window longer than half the series
-    (5001, 3, 5001, None, True, True, np.float64, "emg_chunk_kernel<double,33>"),  # window = series
-    (4097, 2, 1, 4000, True, False, np.float64, "emg_chunk_kernel<double,17>"),    # window of one sample, dense time normalisation
-    (4097, 2, 2, None, True, True, np.float32, "emg_chunk_kernel<float,17>"),      # even window of two
-    (10000, 2, 200, None, True, True, np.float64, "emg_chunk_kernel<double,41>"),  # float64 at the top of its range (one workgroup per CU)
+    (2304 - 18, 2, 37, 100, False, True, np.float32, "emg_chunk_kernel<float,9,256>"),   # all 256 threads own a chunk
+    (2304 - 17, 2, 37, 100, False, True, np.float32, "emg_chunk_kernel<float,13,256>"),
+    (5000, 2, 3000, None, True, True, np.float64, "emg_chunk_kernel<double,33,256>"),  # window longer than half the series
+    (5001, 3, 5001, None, True, True, np.float64, "emg_chunk_kernel<double,33,256>"),  # window = series
+    (4097, 2, 1, 4000, True, False, np.float64, "emg_chunk_kernel<double,17,256>"),    # window of one sample, dense time normalisation
+    (4097, 2, 2, None, True, True, np.float32, "emg_chunk_kernel<float,17,256>"),      # even window of two
+    (10000, 2, 200, None, True, True, np.float64, "emg_chunk_kernel<double,41,256>"),  # float64 at the top of its range (one workgroup per CU)
     (10000, 2, 200, 500, True, True, np.float64, "emg_wave_kernel"),               # ... time-normalised: left to the wave kernel
-    (9000, 2, 200, 500, True, True, np.float64, "emg_chunk_kernel<double,41>"),
+    (9000, 2, 200, 500, True, True, np.float64, "emg_chunk_kernel<double,41,256>"),
     (10497, 2, 1, None, True, True, np.float64, "emg_wg_kernel"),                  # one position more than 256 x 41
-    (3000, 2, 100, 9001, True, True, np.float32, "emg_chunk_kernel<float,13>"),    # up-sampling
+    (3000, 2, 100, 9001, True, True, np.float32, "emg_chunk_kernel<float,13,256>"),    # up-sampling
+    (18560, 2, 257, None, True, True, np.float32, "emg_chunk_kernel<float,73,256>"),   # 18 688 positions: the longest four-wave series
+    (18561, 2, 257, 700, True, True, np.float32, "emg_chunk_kernel<float,41,512>"),    # one more: eight waves
 ]
 
 
