@@ -89,6 +89,28 @@ int launch_scan(hipnmf_handle* h, const SosArgs& a, int ns, int C_run, double* t
                                                                              : go(sosfilt_scan_kernel<real, NSP, SCAN_CMAX>);
 }
 
+// second version of the time-parallel mode (sosfilt_chunk_kernel): the whole extended series in LDS, chunk length C odd
+template <typename real, int NSP>
+int launch_chunk_scan(hipnmf_handle* h, const SosArgs& a, int ns, int C, size_t region, double* tab, hipStream_t st) {
+  hipLaunchKernelGGL((sos_scan_tables_kernel<NSP>), dim3(1), dim3(256), 0, st, a, ns, C, tab);
+  const size_t smem = region + 8 * sizeof(double);
+  auto go = [&](auto kern) -> int {
+    if (smem > 48 * 1024)
+      if (int rc = hipnmf_allow_full_lds(h, reinterpret_cast<const void*>(kern))) return rc;
+    hipLaunchKernelGGL(kern, dim3((unsigned)a.N), dim3(SCAN_THREADS), smem, st, a, (const double*)tab, ns, (int)region);
+    return HIPNMF_OK;
+  };
+  if (C == 17) return go(sosfilt_chunk_kernel<real, NSP, 17>);
+  if (C == 41) return go(sosfilt_chunk_kernel<real, NSP, 41>);
+  if constexpr (sizeof(real) == 4) return go(sosfilt_chunk_kernel<real, NSP, 79>);
+  return HIPNMF_ERR_UNSUPPORTED;
+}
+// LDS of sosfilt_chunk_kernel without the 8 doubles behind it: the series + a dump slot, or the overlay, whichever is larger
+inline size_t chunk_scan_region(size_t L, int C, int nsp, size_t sizeof_real) {
+  const size_t series = (L + 1) * sizeof_real, overlay = sizeof(double) * ((size_t)SCAN_THREADS * 2 * nsp + (size_t)C * 2 * nsp + (size_t)C);
+  return (std::max(series, overlay) + 15) & ~(size_t)15;
+}
+
 template <typename real>
 int sosfilt_impl(hipnmf_handle* h, const hipnmf_sosfilt_params* p, const double* sos, const double* zi, const real* x,
                  real* y) {
@@ -162,13 +184,25 @@ int sosfilt_impl(hipnmf_handle* h, const hipnmf_sosfilt_params* p, const double*
   const bool scan_aligned = (T % VS) == 0 && (reinterpret_cast<uintptr_t>(y) % 16) == 0 &&
                             (!inplace || ((reinterpret_cast<uintptr_t>(x) % 16) == 0 && (p->ldx % VS) == 0 && (p->x_batch_stride % VS) == 0));
   const bool scan_fits = p->mode == HIPNMF_SOSFILT_SCAN && scan_chunk <= SCAN_CMAX && scan_aligned;
-  const size_t o_ws = (zero_lag && !scan_fits) ? carve(use_v3 ? ws_v3 : ws_v2) : 0;
+  // second version (sosfilt_chunk_kernel): no alignment or length condition; float up to 256 x 79, double up to 256 x 41 extended
+  // samples; HIPNMF_SOS_CHUNK=0 leaves the mode to sosfilt_scan_kernel
+  static const bool chunk_scan_ok = [] {
+    const char* e = getenv("HIPNMF_SOS_CHUNK");
+    return !(e && atoi(e) == 0);
+  }();
+  const int nsp_c = p->n_sections == 1 ? 1 : p->n_sections == 2 ? 2 : p->n_sections <= 4 ? 4 : 8;
+  int chunk_c = 0;
+  if (p->mode == HIPNMF_SOSFILT_SCAN && chunk_scan_ok)
+    chunk_c = L <= 256 * 17 ? 17 : L <= 256 * 41 ? 41 : (sizeof(real) == 4 && L <= 256 * 79) ? 79 : 0;
+  const size_t chunk_region = chunk_c ? chunk_scan_region((size_t)L, chunk_c, nsp_c, sizeof(real)) : 0;
+  const bool use_chunk_scan = chunk_c > 0 && chunk_region + 64 <= (size_t)h->lds_per_block;
+  const size_t o_ws = (zero_lag && !scan_fits && !use_chunk_scan) ? carve(use_v3 ? ws_v3 : ws_v2) : 0;
   const size_t o_stat = carve(sizeof(double) * (size_t)N * 3);
   // time-parallel mode: the whole extended series in the registers of one workgroup (256 chunks of at most SCAN_CMAX samples);
   // longer series take the sequential kernel
   const int C_run = scan_fits ? scan_chunk : 0;
   const bool use_scan = scan_fits;
-  const size_t o_tab = use_scan ? carve(sizeof(double) * SCAN_TAB_DOUBLES) : 0;
+  const size_t o_tab = (use_scan || use_chunk_scan) ? carve(sizeof(double) * SCAN_TAB_DOUBLES) : 0;
   int rc = hipnmf_ensure_ws(h, std::max<size_t>(off, 256));
   if (rc) return rc;
   char* ws = static_cast<char*>(h->ws);
@@ -214,6 +248,22 @@ int sosfilt_impl(hipnmf_handle* h, const hipnmf_sosfilt_params* p, const double*
   const bool async = h->async_mode != 0;
   if (!async) HIP_TRY(hipEventRecord(h->ev0, st));
   double* stat = reinterpret_cast<double*>(ws + o_stat);
+  if (use_chunk_scan) {
+    const int ns = p->n_sections;
+    double* tab = reinterpret_cast<double*>(ws + o_tab);
+    rc = ns == 1 ? launch_chunk_scan<real, 1>(h, a, ns, chunk_c, chunk_region, tab, st)
+         : ns == 2 ? launch_chunk_scan<real, 2>(h, a, ns, chunk_c, chunk_region, tab, st)
+         : ns <= 4 ? launch_chunk_scan<real, 4>(h, a, ns, chunk_c, chunk_region, tab, st)
+                   : launch_chunk_scan<real, 8>(h, a, ns, chunk_c, chunk_region, tab, st);
+    if (rc) return rc;
+    HIP_TRY(hipGetLastError());
+    if (!async) {
+      HIP_TRY(hipEventRecord(h->ev1, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      HIP_TRY(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
+    }
+    return HIPNMF_OK;
+  }
   if (use_scan) {
     const int ns = p->n_sections;
     double* tab = reinterpret_cast<double*>(ws + o_tab);

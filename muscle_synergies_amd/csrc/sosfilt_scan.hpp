@@ -20,6 +20,7 @@
 // All arithmetic is fp64 with fused multiply-adds; the result agrees with scipy to rounding (1e-12 relative for the reference's
 // 6 Hz low-pass at 2 kHz; the conditioning of the filter sets the constant), not bit for bit: tests/test_filters.py, <= 1e-10.
 #pragma once
+#include "nmf_kernels.hpp"  // rsrc_t, make_rsrc, buf_load, buf_store (sosfilt_chunk_kernel)
 #include "sosfilt_kernels.hpp"
 
 namespace hipnmf {
@@ -517,6 +518,190 @@ sosfilt_scan_kernel(SosArgs a, const double* __restrict__ tab, int ns) {
       const int col = (w - row * CV) * V, j = (r0 + row) * C_run + col - EO;
       if (j >= 0 && j < T) *reinterpret_cast<Vec*>(yr + j) = *reinterpret_cast<const Vec*>(stage + row * SR + col);
     }
+  }
+}
+
+// =================================================================================================================================
+// sosfilt_chunk_kernel (round 4, second version of the time-parallel mode): the same mathematics, the memory side rebuilt like
+// emg_chunk_kernel (envelope_chunk.hpp).  sosfilt_scan_kernel moves the series HBM <-> registers through a 48 KiB staging buffer in
+// two pieces per direction (four barriers each way, half the threads idle per piece) with 16-byte vectors (alignment and length
+// conditions); alone on a CU a workgroup lives 24 us of which 7.4 us are arithmetic.  Here the WHOLE extended series sits in LDS in
+// natural order and a thread's chunk length C is ODD (17 / 41 / 79), so the coalesced accesses (thread t <-> position t + 256 k)
+// and the threads' own chunks (stride C) are both bank-conflict-free without padding; HBM is read and written with dword buffer
+// accesses (no alignment condition, range-checked).  While the chunks are in registers the series buffer is dead: the scan's
+// exchange area and the G table overlay it, so LDS = the series (80 120 B for 20 000 float samples of an order-4 zero-lag filter:
+// two workgroups per CU).  The odd extension is built in LDS from the centred samples by the first / last `edge` threads.
+// float and double up to 256 x 79 / 256 x 41 extended samples; anything else takes sosfilt_scan_kernel or the sequential kernels.
+template <typename real, int NSP, int C>
+__global__ void __launch_bounds__(SCAN_THREADS, (C > 32 ? (NSP > 4 ? 1 : 2) : (NSP > 4 ? 2 : 4)))
+sosfilt_chunk_kernel(SosArgs a, const double* __restrict__ tab, int ns, int region_bytes) {
+  static_assert(C % 2 == 1, "odd chunk length: conflict-free LDS stride");
+  constexpr int NST = 2 * NSP;
+  extern __shared__ __attribute__((aligned(16))) unsigned char scan_smem[];
+  real* __restrict__ xs = reinterpret_cast<real*>(scan_smem);               // [L] the extended series, later the output
+  double* __restrict__ xch = reinterpret_cast<double*>(scan_smem);          // overlay: [256][NST]
+  double* __restrict__ Gl = xch + SCAN_THREADS * NST;                        // overlay: G [C][NST]
+  double* __restrict__ row = Gl + C * NST;                                   // overlay: one chunk (ylast)
+  double* __restrict__ misc = reinterpret_cast<double*>(scan_smem + region_bytes);  // [8] behind both
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int series = blockIdx.x;
+  const int T = a.T, edge = a.edge, L = T + 2 * edge;
+  const real* __restrict__ xr =
+      static_cast<const real*>(a.x) + (long long)(series / a.m) * a.bstride + (long long)(series % a.m) * a.ld;
+  real* __restrict__ yr = static_cast<real*>(a.y) + (long long)series * T;
+  const rsrc_t xrs = make_rsrc(xr, (unsigned)((long long)T * (long long)sizeof(real)));
+  const rsrc_t yrs = make_rsrc(yr, (unsigned)((long long)T * (long long)sizeof(real)));
+  const double* __restrict__ G = tab;
+  const double* __restrict__ Mp = tab + SCAN_G_CAP;
+  const unsigned voff = (unsigned)t * (unsigned)sizeof(real);
+
+  double c[NSP][5];
+  scan_coeffs<NSP>(a, ns, c);
+  // this thread's entries of the G table: requested now, written to the overlay once the series buffer is dead
+  constexpr int GN = (C * NST + SCAN_THREADS - 1) / SCAN_THREADS;
+  double gpre[GN];
+#pragma unroll
+  for (int u = 0; u < GN; ++u) {
+    const int i = t + u * SCAN_THREADS;
+    gpre[u] = i < C * NST ? G[i] : 0.0;
+  }
+
+  // ---- HBM -> registers -> LDS (centred / rectified in the samples' precision, as the reference's array arithmetic) ------------
+  double v[C];
+  {
+    real raw[C];
+#pragma unroll
+    for (int k = 0; k < C; ++k) {
+      real r1[1];
+      buf_load<real, 1>(xrs, voff, (unsigned)(k * SCAN_THREADS) * (unsigned)sizeof(real), r1);
+      raw[k] = r1[0];
+    }
+    real mean = (real)0;
+    if (a.zero_center) {  // fp64 sum in a fixed order (zeros past the end of the series)
+      double sum = 0.0;
+#pragma unroll
+      for (int k = 0; k < C; ++k) sum += (double)raw[k];
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
+      if (lane == 0) misc[wave] = sum;
+      __syncthreads();
+      mean = (real)(((misc[0] + misc[1]) + (misc[2] + misc[3])) / (double)T);
+    }
+#pragma unroll
+    for (int k = 0; k < C; ++k) {
+      const int j = t + k * SCAN_THREADS;
+      const real pv = sos_pre<real>(raw[k], mean, a.rectify);
+      xs[j < T ? edge + j : L] = pv;  // (slot L: a dump slot behind the series -- a branch per store would serialise them)
+    }
+    __syncthreads();
+    for (int e = t; e < edge; e += SCAN_THREADS) {  // scipy's odd extension about the end samples, in the samples' precision
+      xs[e] = (real)2 * xs[edge] - xs[2 * edge - e];
+      xs[edge + T + e] = (real)2 * xs[edge + T - 1] - xs[edge + T - 2 - e];
+    }
+    __syncthreads();
+    const real* __restrict__ mine = xs + C * t;
+    const int nval = L - C * t;  // positions of this chunk inside the extended series (zeros behind it)
+#pragma unroll
+    for (int n = 0; n < C; ++n) {
+      const real xv = mine[n];  // (behind the series: whatever is there -- LDS reads cannot fault -- replaced by 0)
+      v[n] = n < nval ? (double)xv : 0.0;
+    }
+  }
+  const double x0 = (double)xs[0];
+  __syncthreads();  // the series buffer is dead from here: the overlay takes it
+#pragma unroll
+  for (int u = 0; u < GN; ++u) {
+    const int i = t + u * SCAN_THREADS;
+    if (i < C * NST) Gl[i] = gpre[u];
+  }
+
+  // ---- forward: zero-state response, scan, correction --------------------------------------------------------------------
+  double s_init[NST], s_start[NST], E[NST];
+#pragma unroll
+  for (int s = 0; s < NSP; ++s) {  // zi * ext[0] (sosfiltfilt); plain sosfilt starts at rest
+    s_init[2 * s] = (a.zero_lag && s < ns) ? a.zi[s][0] * x0 : 0.0;
+    s_init[2 * s + 1] = (a.zero_lag && s < ns) ? a.zi[s][1] * x0 : 0.0;
+  }
+  {
+    double z[NSP][2];
+#pragma unroll
+    for (int s = 0; s < NSP; ++s) z[s][0] = z[s][1] = 0.0;
+#pragma unroll
+    for (int n = 0; n < C; ++n) v[n] = scan_step<NSP>(v[n], z, c);
+#pragma unroll
+    for (int s = 0; s < NSP; ++s) {
+      E[2 * s] = z[s][0];
+      E[2 * s + 1] = z[s][1];
+    }
+  }
+  scan_states<NST>(E, s_init, false, Mp, xch, s_start);  // (its first barrier also publishes Gl)
+#pragma unroll
+  for (int n = 0; n < C; ++n) {
+    double acc = v[n];
+#pragma unroll
+    for (int i = 0; i < NST; ++i) acc = __builtin_fma(Gl[n * NST + i], s_start[i], acc);
+    v[n] = acc;
+  }
+
+  if (a.zero_lag) {
+    // ---- backward over the forward output: start state zi * y[L-1]; the tail of the last chunk holds that constant ---------
+    const int tL = (L - 1) / C, nL = (L - 1) - tL * C;  // (wave-uniform)
+    if (t == tL) {  // the owner's chunk through LDS: a register array cannot be indexed with a run-time value
+#pragma unroll
+      for (int n = 0; n < C; ++n) row[n] = v[n];
+    }
+    __syncthreads();
+    const double ylast = row[nL];
+    if ((t + 1) * C > L) {
+#pragma unroll
+      for (int n = 0; n < C; ++n) v[n] = (t * C + n >= L) ? ylast : v[n];
+    }
+#pragma unroll
+    for (int s = 0; s < NSP; ++s) {
+      s_init[2 * s] = s < ns ? a.zi[s][0] * ylast : 0.0;
+      s_init[2 * s + 1] = s < ns ? a.zi[s][1] * ylast : 0.0;
+    }
+    {
+      double z[NSP][2];
+#pragma unroll
+      for (int s = 0; s < NSP; ++s) z[s][0] = z[s][1] = 0.0;
+#pragma unroll
+      for (int n = C - 1; n >= 0; --n) v[n] = scan_step<NSP>(v[n], z, c);
+#pragma unroll
+      for (int s = 0; s < NSP; ++s) {
+        E[2 * s] = z[s][0];
+        E[2 * s + 1] = z[s][1];
+      }
+    }
+    scan_states<NST>(E, s_init, true, Mp, xch, s_start);
+    const double* __restrict__ Gr = Gl + (C - 1) * NST;  // sample n of a chunk is step C - 1 - n of the reversed walk
+#pragma unroll
+    for (int n = 0; n < C; ++n) {
+      double acc = v[n];
+#pragma unroll
+      for (int i = 0; i < NST; ++i) acc = __builtin_fma(Gr[i - n * NST], s_start[i], acc);
+      v[n] = acc;
+    }
+  }
+
+  // ---- registers -> LDS (natural order) -> HBM, the T samples of the recording -----------------------------------------------
+  __syncthreads();  // the overlay is dead
+  {
+    real* __restrict__ mine = xs + C * t;
+    const int nval = L - C * t;
+#pragma unroll
+    for (int n = 0; n < C; ++n) mine[n < nval ? n : L - C * t] = (real)v[n];  // (behind the series: the dump slot)
+  }
+  __syncthreads();
+  constexpr int CB = 8;
+  const int kmax = (T + SCAN_THREADS - 1) / SCAN_THREADS;
+  for (int k0 = 0; k0 < kmax; k0 += CB) {
+    real y[CB];
+    const real* __restrict__ src = xs + edge + t + k0 * SCAN_THREADS;  // (reads past the series cannot fault; the stores are dropped)
+#pragma unroll
+    for (int u = 0; u < CB; ++u) y[u] = src[u * SCAN_THREADS];
+#pragma unroll
+    for (int u = 0; u < CB; ++u) buf_store<real>(yrs, voff, (unsigned)((k0 + u) * SCAN_THREADS) * (unsigned)sizeof(real), y[u]);
   }
 }
 
