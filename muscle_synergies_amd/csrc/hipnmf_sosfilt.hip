@@ -3,6 +3,7 @@
 // (src/muscle_synergies/analysis.py:252-432).
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstdint>
 
@@ -256,6 +257,7 @@ int sosfilt_impl(hipnmf_handle* h, const hipnmf_sosfilt_params* p, const double*
          : ns <= 4 ? launch_chunk_scan<real, 4>(h, a, ns, chunk_c, chunk_region, tab, st)
                    : launch_chunk_scan<real, 8>(h, a, ns, chunk_c, chunk_region, tab, st);
     if (rc) return rc;
+    snprintf(h->last_kernel, sizeof(h->last_kernel), "sosfilt_chunk_kernel<%s,%d,%d>", sizeof(real) == 4 ? "float" : "double", nsp_c, chunk_c);
     HIP_TRY(hipGetLastError());
     if (!async) {
       HIP_TRY(hipEventRecord(h->ev1, st));
@@ -265,6 +267,7 @@ int sosfilt_impl(hipnmf_handle* h, const hipnmf_sosfilt_params* p, const double*
     return HIPNMF_OK;
   }
   if (use_scan) {
+    snprintf(h->last_kernel, sizeof(h->last_kernel), "sosfilt_scan_kernel<%s,%d,%d>", sizeof(real) == 4 ? "float" : "double", nsp_c, C_run);
     const int ns = p->n_sections;
     double* tab = reinterpret_cast<double*>(ws + o_tab);
     rc = ns == 1 ? launch_scan<real, 1>(h, a, ns, C_run, tab, st)
@@ -280,6 +283,7 @@ int sosfilt_impl(hipnmf_handle* h, const hipnmf_sosfilt_params* p, const double*
     }
     return HIPNMF_OK;
   }
+  snprintf(h->last_kernel, sizeof(h->last_kernel), "sosfilt (sequential)");
   hipLaunchKernelGGL(sos_stats_kernel<real>, dim3((unsigned)N), dim3(256), 0, st, a, stat);
   static const bool sos_v1 = [] {
     const char* e = getenv("HIPNMF_SOS_V1");

@@ -1,5 +1,7 @@
 """IIR filter stage (``digital_filter`` / ``linear_envelope`` = scipy sosfilt /
 sosfiltfilt): oracle vs the reference's recorded outputs (CPU) and the HIP kernel vs both (GPU)."""
+import json
+
 import numpy as np
 import pandas as pd
 import pytest
@@ -251,6 +253,62 @@ def test_gpu_scan_mode_sizes_dtypes_and_fallbacks(g8):
     x = torch.from_numpy(np.stack([raw_emg(40 + b, 20000, 4) for b in range(8)]).astype(np.float32)).cuda()
     y1, y2 = sosfilt_batched(x, sos, rectify=True, mode="scan"), sosfilt_batched(x, sos, rectify=True, mode="scan")
     assert torch.equal(y1, y2)
+
+
+@pytest.mark.gpu
+def test_gpu_scan_mode_kernel_choice_and_shapes_of_the_second_version(g8):
+    """sosfilt_chunk_kernel (round 4, the whole extended series in LDS): lengths that are no multiple of the 16-byte vector,
+    unaligned rows, a padding longer than the workgroup, both ends of every instance; what it does not hold goes to
+    sosfilt_scan_kernel (float64 beyond 256 x 41 extended samples) or to the sequential kernels; HIPNMF_SOS_CHUNK=0 restores
+    the first version."""
+    import os
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+    from muscle_synergies_amd import _lib
+    from muscle_synergies_amd.preprocess import sosfilt_batched
+
+    sos = g8["lp4_sos"]  # two sections: padlen 15
+    h = _lib.get_handle(0)
+    for T, dtype, padlen, want in ((1001, np.float64, None, "sosfilt_chunk_kernel<double,2,17>"),
+                                   (4352 - 30, np.float64, None, "sosfilt_chunk_kernel<double,2,17>"),
+                                   (4352 - 29, np.float64, None, "sosfilt_chunk_kernel<double,2,41>"),
+                                   (10496 - 30, np.float32, None, "sosfilt_chunk_kernel<float,2,41>"),
+                                   (10496 - 29, np.float32, None, "sosfilt_chunk_kernel<float,2,79>"),
+                                   (10496 - 28, np.float64, None, "sosfilt_scan_kernel<double,2,80>"),
+                                   (10496 - 29, np.float64, None, "sosfiltx"),   # odd length: the first version does not take it
+                                   (20224 - 30, np.float32, None, "sosfilt_chunk_kernel<float,2,79>"),
+                                   (20224 - 28, np.float32, None, "sosfilt_scan_kernel<float,2,80>"),
+                                   (3001, np.float32, 700, "sosfilt_chunk_kernel<float,2,41>"),
+                                   (333, np.float64, 300, "sosfilt_chunk_kernel<double,2,17>")):
+        raw = raw_emg(70 + T % 13, T, 3).astype(dtype)
+        x = np.ascontiguousarray(raw.T)[:, :T].T if T % 2 else raw  # channel-major rows of odd length: unaligned
+        got = sosfilt_batched(x, sos, zero_lag=True, zero_center=True, rectify=True, padlen=padlen, mode="scan")[0].cpu().numpy()
+        name = h.last_kernel()
+        assert name == want or (want == "sosfiltx" and name.startswith("sosfilt (sequential)")), (T, dtype, name)
+        import scipy.signal as ss
+
+        v = np.abs(raw - raw.mean(axis=0, dtype=np.float64).astype(dtype))  # centred and rectified in the samples' precision
+        ref = ss.sosfiltfilt(sos, v.astype(np.float64), axis=0, **({} if padlen is None else {"padlen": padlen}))
+        tol = SCAN_TOL if dtype == np.float64 else 3e-7
+        assert np.abs(got - ref).max() <= tol * np.abs(ref).max(), (T, dtype, np.abs(got - ref).max() / np.abs(ref).max())
+    code = """
+import sys, numpy as np
+sys.path.insert(0, %r)
+from muscle_synergies_amd import _lib
+from muscle_synergies_amd.preprocess import sosfilt_batched
+from muscle_synergies_amd.synth import raw_emg
+from oracle import sosfilt_oracle as so
+import json
+sos = np.array(json.loads(%r))
+raw = raw_emg(3, 20000, 2)
+got = sosfilt_batched(raw, sos, zero_lag=True, zero_center=True, rectify=True, mode='scan')[0].cpu().numpy()
+ref = so.linear_envelope(raw, sos, True)
+print(_lib.get_handle(0).last_kernel(), float(np.abs(got - ref).max() / np.abs(ref).max()) <= 1e-10)
+""" % (ROOT, json.dumps(np.asarray(sos).tolist()))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, HIPNMF_SOS_CHUNK="0"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "sosfilt_scan_kernel<double,2,80> True" in r.stdout, r.stdout[-1000:] + r.stderr[-1000:]
 
 
 @pytest.mark.gpu

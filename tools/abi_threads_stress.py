@@ -271,7 +271,8 @@ CASES = {
     "wide_a": fit_case(f32, 6, 700, 64, 12, variant=1, expect="fit_wide_kernel"),
     "wide_b": fit_case(f32, 3, 5000, 64, 12, variant=1, expect="fit_wide_kernel"),
     "wide_f64": fit_case(f64, 3, 900, 40, 10, variant=1, expect="fit_wide_kernel"),
-    "wide_kl": fit_case(f32, 3, 900, 64, 6, loss=1, expect="fit_wide_kernel"),
+    "wide_kl": fit_case(f32, 3, 900, 64, 12, loss=1, expect="fit_wide_kernel"),
+    "wide4_kl": fit_case(f32, 3, 900, 64, 6, loss=1, expect="fit_wide4_kernel"),
     "wide4_a": fit_case(f32, 6, 600, 64, 8, variant=1, expect="fit_wide4_kernel"),
     "wide4_b": fit_case(f32, 3, 4000, 64, 8, variant=1, expect="fit_wide4_kernel"),
     "wide4d": fit_case(f64, 4, 1200, 64, 6, variant=1, expect="fit_wide4d_kernel"),
