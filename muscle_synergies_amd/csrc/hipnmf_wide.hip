@@ -107,13 +107,39 @@ int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
     const char* e = getenv("HIPNMF_FORCE_BIG");
     return e && atoi(e) != 0;
   }();
-  const bool big = !wk || wk->smem > (size_t)h->lds_per_block || (force_big && !kl && !ragged);
+  const bool big = !wk || wk->smem > (size_t)h->lds_per_block || (force_big && !kl);
   if (big) {
     if (m > HIPNMF_MAX_FEATURES || k > HIPNMF_MAX_COMPONENTS)
       return fail(HIPNMF_ERR_UNSUPPORTED, "no kernel for n_features=%d (max %d) n_components=%d (max %d)", m, HIPNMF_MAX_FEATURES, k,
                   HIPNMF_MAX_COMPONENTS);
     if (kl) return fail(HIPNMF_ERR_UNSUPPORTED, "beta_loss='kullback-leibler' beyond 128 channels / 32 components is not compiled");
-    if (ragged) return fail(HIPNMF_ERR_UNSUPPORTED, "ragged batches beyond 128 channels / 32 components are not compiled");
+    if (ragged) {
+      // trials of unequal length on the general-shape kernels: one chip-filling row-sliced fit per trial (the slices of ONE
+      // matrix already fill the chip there, so nothing is lost against a common launch).  The padding rows of a packed matrix
+      // are zero by the entry point's contract and inert under the updates (0 * x / eps), so trial b is the uniform problem
+      // with n_samples = ld_b.
+      if (p->x_layout != HIPNMF_X_CHANNEL_MAJOR || p->w_layout != HIPNMF_W_COMPONENT_MAJOR)
+        return fail(HIPNMF_ERR_UNSUPPORTED, "ragged batches use the packed native layouts (channel-major X, component-major W)");
+      float total_ms = 0.0f;
+      for (int b = 0; b < B; ++b) {
+        const int64_t* d = ragged + 4 * (size_t)b;
+        if (d[0] < 1 || d[0] > p->n_samples || d[2] < d[0] || d[1] < 0 || d[3] < 0 || (d[2] % 4) != 0)
+          return fail(HIPNMF_ERR_BAD_ARG, "bad ragged descriptor for matrix %d (T=%lld, xoff=%lld, ld=%lld, woff=%lld)", b,
+                      (long long)d[0], (long long)d[1], (long long)d[2], (long long)d[3]);
+        hipnmf_problem q = *p;
+        q.batch = 1;
+        q.n_samples = d[2];
+        q.ldx = d[2];
+        q.x_batch_stride = (int64_t)m * d[2];
+        const int rc = hipnmf_fit_wide<real>(h, &q, X + d[1], W + d[3], H + (size_t)b * k * m, err_out ? err_out + b : nullptr,
+                                             n_iter_out ? n_iter_out + b : nullptr, sse_col_out ? sse_col_out + (size_t)b * m : nullptr,
+                                             xsq_col_out ? xsq_col_out + (size_t)b * m : nullptr, nullptr);
+        if (rc) return rc;
+        total_ms += h->last_ms;
+      }
+      h->last_ms = total_ms;
+      return HIPNMF_OK;
+    }
   }
   if (h->variant == 3 || h->variant == 5 || h->variant == 6)
     return fail(HIPNMF_ERR_UNSUPPORTED, "tuning variant %d does not exist for wide shapes (n_features=%d, n_components=%d)",

@@ -214,3 +214,48 @@ def test_time_sharded_fit_of_a_wide_recording_is_shard_count_invariant(dtype, m,
     rn = ops.fit_native(max_iter=200, tol=1e-3)
     assert rn.n_iter == ref_s["n_iter"]
     assert _rel(X, rn.W_local[0].cpu().numpy(), rn.H[0].cpu().numpy(), ref_s) <= tol
+
+
+@pytest.mark.parametrize("dtype,m,k", [(np.float64, 200, 12), (np.float32, 300, 20), (np.float64, 100, 24)])
+def test_ragged_batch_on_the_general_shape_kernels(dtype, m, k):
+    """Trials of unequal length beyond the one-pass instances (round 4: fitted trial by trial inside hipnmf_fit_ragged_*, each a
+    chip-filling row-sliced fit; the zero padding rows of the packed layout are inert): per-trial parity with the oracle, stop
+    rule per trial, and `find_synergies_batched` on a 200-channel float64 recording without leaving the GPU."""
+    import warnings
+
+    import pandas as pd
+
+    import muscle_synergies_amd as ms
+
+    Ts = [333, 1000, 77, 2049]
+    Xs, Ws, Hs = [], [], []
+    for s, T in enumerate(Ts):
+        X, W0, H0 = _case(T, m, k, dtype, seed=50 + s)
+        Xs.append(X), Ws.append(W0), Hs.append(H0)
+    res = ms.fit_ragged(Xs, Ws, Hs, max_iter=30, tol=0.0)
+    assert _last_kernel().startswith("big_pass_w_kernel"), _last_kernel()
+    tol = TOL if dtype == np.float32 else 1e-9
+    for b, T in enumerate(Ts):
+        ref = orc.nmf_mu_fit(Xs[b], Ws[b], Hs[b], max_iter=30, tol=0.0)
+        W, H = res.W[b].cpu().numpy(), res.H[b].cpu().numpy()
+        assert W.shape == (T, k) and _rel(Xs[b], W, H, ref) <= tol, b
+        assert abs(float(res.reconstruction_err[b]) - float(ref["reconstruction_err"])) / np.linalg.norm(Xs[b]) <= TOL
+    res = ms.fit_ragged(Xs, Ws, Hs, max_iter=300, tol=1e-3)
+    for b in range(len(Ts)):
+        ref = orc.nmf_mu_fit(Xs[b], Ws[b], Hs[b], max_iter=300, tol=1e-3)
+        assert abs(int(res.n_iter[b]) - ref["n_iter"]) <= (10 if dtype == np.float32 else 0), b
+    if dtype == np.float64 and m == 200:
+        cols = [f"ch{j}" for j in range(m)]
+        dfs = [pd.DataFrame(x, columns=cols) for x in Xs[:3]]
+        with warnings.catch_warnings():
+            warnings.simplefilter("error", RuntimeWarning)  # a fallback to scikit-learn warns
+            warnings.simplefilter("ignore", category=UserWarning)
+            try:
+                from sklearn.exceptions import ConvergenceWarning
+                warnings.simplefilter("ignore", category=ConvergenceWarning)
+            except ImportError:
+                pass
+            got = ms.find_synergies_batched(dfs, 3, 4, max_iter=60, tol=0.0, random_state=0)
+        assert _last_kernel().startswith("big_pass_w_kernel"), _last_kernel()
+        for g in got:
+            assert g.vaf_values.shape[0] == 2 and np.isfinite(g.vaf_values.to_numpy()).all()
