@@ -127,7 +127,7 @@ int hipnmf_set_tuning(hipnmf_handle* h, int threads, int max_slices, int variant
  *
  * Shapes: any 1 <= n_components <= 64, n_features <= 512 (the reference accepts any n <= m, analysis.py:829-846); beyond
  * 128 channels / 32 components, and for float64 with more than 16 components on more than 64 channels, the general-shape kernels
- * run (Frobenius loss; a ragged batch is fitted trial by trial there; the Kullback-Leibler loss: HIPNMF_ERR_UNSUPPORTED).  Layouts used in place (anything
+ * run (both losses; a ragged batch is fitted trial by trial there).  Layouts used in place (anything
  * else costs one conversion per fit): fp32 16-channel C-order X for the narrow row-per-lane instances, channel-major X
  * for the other narrow ones; for the wide shapes a C-order X whose rows are a whole number of 16-byte pieces
  * (n_features * sizeof % 16 == 0, ldx likewise) and a C-order W with n_components % 4 == 0.

@@ -112,7 +112,6 @@ int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
     if (m > HIPNMF_MAX_FEATURES || k > HIPNMF_MAX_COMPONENTS)
       return fail(HIPNMF_ERR_UNSUPPORTED, "no kernel for n_features=%d (max %d) n_components=%d (max %d)", m, HIPNMF_MAX_FEATURES, k,
                   HIPNMF_MAX_COMPONENTS);
-    if (kl) return fail(HIPNMF_ERR_UNSUPPORTED, "beta_loss='kullback-leibler' beyond 128 channels / 32 components is not compiled");
     if (ragged) {
       // trials of unequal length on the general-shape kernels: one chip-filling row-sliced fit per trial (the slices of ONE
       // matrix already fill the chip there, so nothing is lost against a common launch).  The padding rows of a packed matrix
@@ -273,7 +272,7 @@ int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
   const int recKP = big ? KPb : wk->KP, recMP = big ? MPb : wk->MP;  // (`wk` is not consulted on the general-shape path)
   const size_t rec = (size_t)recKP * recMP + (size_t)recKP * recKP;
   const size_t o_part = sliced ? carve(sizeof(real) * (size_t)B * S * rec) : 0;
-  const size_t o_col = sliced ? carve(sizeof(real) * (size_t)B * S * 2 * recMP) : 0;
+  const size_t o_col = sliced ? carve(sizeof(real) * (size_t)B * S * 3 * recMP) : 0;  // (3: sse | xsq | KL per column of the general-shape path)
   const size_t o_state = sliced ? carve(sizeof(real) * (size_t)B * 8) : 0;
   const size_t o_hht = big ? carve(sizeof(real) * (size_t)B * KPb * KPb) : 0;
   int rc = hipnmf_ensure_ws(h, std::max<size_t>(off, 256));
@@ -438,6 +437,7 @@ int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
     sa.tol = (real)p->tol;
     sa.l1h = (real)p->l1_reg_H;
     sa.l2h = (real)p->l2_reg_H;
+    sa.kl = (big && kl) ? 1 : 0;
   }
 
   if (big) {
@@ -467,15 +467,17 @@ int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
     ba.rows_per_slice = (int)rps;
     ba.l1w = (real)p->l1_reg_W;
     ba.l2w = (real)p->l2_reg_W;
+    ba.kl = kl ? 1 : 0;
     // H in LDS: all of it when [KP][MP + 4] (+ H H^T, + the residual's column accumulators) fits 96 KiB, else blocks of channels
-    const size_t fixed = sizeof(real) * ((size_t)KPb * (KPb + 4) + 8 * (size_t)MPb);
+    const size_t fixed = sizeof(real) * ((size_t)KPb * (KPb + 4) + 12 * (size_t)MPb);
     const size_t cap = 96 * 1024;
     int cbh = MPb;
     while (cbh > 16 && fixed + sizeof(real) * (size_t)KPb * (cbh + 4) > cap) cbh = (int)round_up(cbh / 2, 16);
     ba.CBH = cbh;
     const size_t smem_w = sizeof(real) * ((size_t)KPb * (cbh + 4) + (size_t)KPb * (KPb + 4));
-    const size_t smem_r = sizeof(real) * ((size_t)KPb * (cbh + 4) + 8 * (size_t)MPb);
-    const size_t smem_rec = sizeof(real) * std::max<size_t>(4 * (16 * (size_t)(KPb + 4) + 16 * (size_t)(BIG_CB + 4)), 4 * (size_t)KPb * BIG_CB);
+    const size_t smem_r = sizeof(real) * ((size_t)KPb * (cbh + 4) + 4 * (size_t)(kl ? 3 : 2) * MPb);
+    const size_t smem_rec = sizeof(real) * std::max<size_t>(4 * (16 * (size_t)(KPb + 4) + 16 * (size_t)(BIG_CB + 4)) + (kl ? (size_t)KPb * (BIG_CB + 4) : 0),
+                                                            4 * (size_t)KPb * BIG_CB);  // (stages [+ the block of H of the Kullback-Leibler quotient] | reduction buffer)
     const size_t smem_h = sizeof(real) * ((size_t)k * k + 128 * (size_t)k);
     BigHArgs<real> hb;
     hb.H = H;
@@ -490,6 +492,7 @@ int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
     hb.ldB = KPb;
     hb.l1h = (real)p->l1_reg_H;
     hb.l2h = (real)p->l2_reg_H;
+    hb.kl = kl ? 1 : 0;
     const dim3 gslice(S, B), grec(S, B, (MPb + BIG_CB - 1) / BIG_CB + 1), ghup(B, (m + 63) / 64);
     auto with_kp = [&](auto&& f) {  // the padded component count is a compile-time parameter of three of the kernels
       switch (KPb) {
@@ -511,7 +514,7 @@ int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
       with_kp([&](auto kp) { emit(big_resid_kernel<real, decltype(kp)::value>, gslice, dim3(256), smem_r, ba); });
       WideSliceArgs<real> f = sa;
       f.it = it;
-      emit(big_resid_finalize_kernel<real>, dim3(B), dim3(1024), sizeof(real) * 2 * (size_t)MPb, f);
+      emit(big_resid_finalize_kernel<real>, dim3(B), dim3(1024), sizeof(real) * 3 * (size_t)MPb, f);
     };
     auto enqueue = [&](int n, bool check, auto&& emit) {
       for (int i = 0; i < n; ++i) {
@@ -693,6 +696,7 @@ int hipnmf_shard_wide(hipnmf_handle* h, const hipnmf_problem* p, int op, const r
     hb.ldB = k;
     hb.l1h = (real)p->l1_reg_H;
     hb.l2h = (real)p->l2_reg_H;
+    hb.kl = 0;
     hipLaunchKernelGGL(big_hupdate_kernel<real>, dim3(B, (m + 63) / 64), dim3(256), sizeof(real) * ((size_t)k * k + 128 * (size_t)k), st, hb);
   } else {
     with_kp([&](auto kp) {

@@ -46,7 +46,14 @@ struct BigArgs {
   int S, rows_per_slice;
   int CBH;  // channels of H staged in LDS at a time (a multiple of 16; MP when all of H fits)
   real l1w, l2w;
+  int kl;   // 1: Kullback-Leibler updates (_nmf.py:556-591, 642-684) -- see the KL notes in every kernel; column records are 3 MP then
 };
+// values per slice of the column record: sse | xsq (| the Kullback-Leibler divergence per column)
+template <typename real>
+__device__ __forceinline__ int big_ncol(const BigArgs<real>& a) { return (a.kl ? 3 : 2) * a.MP; }
+// x / wh of the Kullback-Leibler updates, wh >= EPSILON (float: the bare reciprocal, as in the other KL kernels)
+__device__ __forceinline__ float big_quot(float x, float wh) { return kl_quot(x, wh); }
+__device__ __forceinline__ double big_quot(double x, double wh) { return x / wh; }
 
 constexpr int BIG_CB = 64;  // channels per workgroup of the record kernel
 
@@ -71,7 +78,10 @@ __global__ void __launch_bounds__(256) big_hht_kernel(BigArgs<real> a) {
   for (int idx = threadIdx.x; idx < a.KP * a.KP; idx += blockDim.x) {
     const int c = idx / a.KP, c2 = idx % a.KP;
     real s = (real)0;
-    if (c < a.k && c2 < a.k) {
+    if (a.kl) {  // column 0 holds rowsum(H), the W update's denominator (_nmf.py:577-581); the rest stays 0
+      if (c < a.k && c2 == 0)
+        for (int jj = 0; jj < a.m; ++jj) s += Hb[(long long)c * a.m + jj];
+    } else if (c < a.k && c2 < a.k) {
       const real* __restrict__ h1 = Hb + (long long)c * a.m;
       const real* __restrict__ h2 = Hb + (long long)c2 * a.m;
       for (int jj = 0; jj < a.m; ++jj) s = fma_(h1[jj], h2[jj], s);
@@ -169,6 +179,18 @@ __global__ void __launch_bounds__(256) big_pass_w_kernel(BigArgs<real> a) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           if (ch0 + 16 * q < cend) {
+            if (a.kl) {
+              // Kullback-Leibler: the block of (W H)^T on the pipe as in big_resid_kernel -- A = H^T (channels x components), B = the
+              // W fragment, D: lane (row j, g), register r <-> channel ch + 4 g + r: exactly where the lane's X values sit, so
+              // Q = X / max(W H, eps) replaces them and the numerator below is (X / WH) H^T
+              acc rec = acc{0, 0, 0, 0};
+#pragma unroll
+              for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) rec = M::mma(sH[(16 * kb + 4 * g + s) * SH + (ch0 + 16 * q - cb0) + ar], w[kb][s], rec);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) x[q][r] = big_quot(x[q][r], rec[r] < eps_val<real>() ? eps_val<real>() : rec[r]);
+            }
 #pragma unroll
             for (int kb = 0; kb < NKB; ++kb) {
               real ha[4];
@@ -183,12 +205,17 @@ __global__ void __launch_bounds__(256) big_pass_w_kernel(BigArgs<real> a) {
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
       acc den = acc{0, 0, 0, 0};
+      if (a.kl) {  // rowsum(H) of the lane's components (big_hht_kernel left it in column 0)
 #pragma unroll
-      for (int kb2 = 0; kb2 < NKB; ++kb2) {
-        real ha[4];
-        wide_lds_read<real, 4>(sHHt + (16 * kb + ar) * SK + 16 * kb2 + 4 * g, ha);
+        for (int r = 0; r < 4; ++r) den[r] = sHHt[(16 * kb + 4 * g + r) * SK];
+      } else {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) den = M::mma(ha[s], w[kb2][s], den);
+        for (int kb2 = 0; kb2 < NKB; ++kb2) {
+          real ha[4];
+          wide_lds_read<real, 4>(sHHt + (16 * kb + ar) * SK + 16 * kb2 + 4 * g, ha);
+#pragma unroll
+          for (int s = 0; s < 4; ++s) den = M::mma(ha[s], w[kb2][s], den);
+        }
       }
       real wn[4];
 #pragma unroll
@@ -221,6 +248,21 @@ __global__ void __launch_bounds__(256) big_records_kernel(BigArgs<real> a) {
   real* const wst = smem + wave * PERWAVE;
   real* const xst = wst + 16 * SWs;
   const bool is_wtw = (int)blockIdx.z == (int)gridDim.z - 1;
+  // Kullback-Leibler: the channel blocks accumulate W'^T Q' with Q' = X / max(W' H, eps) (_nmf.py:660-663) -- the block of H sits
+  // in LDS behind the stages, W' H comes from the pipe in the layout of the staged X values (the
+  // contraction's k-step s then covers rows 4 g + s instead of 4 s + g: the same 16 rows) -- and the last grid.z leaves
+  // colsum(W') in column 0 of the W^T W block (its B source is a column of ones).
+  const bool klq = a.kl != 0 && !is_wtw;
+  constexpr int SHB = CB + 4;
+  real* const sHb = smem + 4 * PERWAVE;  // [KP][CB + 4] behind the stages (the reduction buffer at the end may overlay it: dead by then)
+  if (klq) {
+    const real* __restrict__ Hb = a.H + (long long)b * a.k * a.m;
+    for (int idx = tid; idx < KP * CB; idx += 256) {
+      const int c = idx / CB, jj = idx % CB, ch = (int)blockIdx.z * CB + jj;
+      sHb[c * SHB + jj] = (c < a.k && ch < a.m) ? Hb[(long long)c * a.m + ch] : (real)0;
+    }
+    __syncthreads();
+  }
   const real* __restrict__ Wb = a.W + (long long)b * a.w_bstride;
   // the B operand's source: a block of CB channels of X, or W itself (W^T W)
   const real* __restrict__ src = is_wtw ? Wb : a.X + (long long)b * a.x_bstride;
@@ -249,7 +291,9 @@ __global__ void __launch_bounds__(256) big_records_kernel(BigArgs<real> a) {
     for (int cb = 0; cb < NCB; ++cb) {
       const int col = src_col0 + 16 * cb + 4 * g;
       real x4[4] = {0, 0, 0, 0};
-      if constexpr (V == 4) {
+      if (a.kl && is_wtw) {  // a column of ones: (W^T B)[c][0] = colsum(W)[c]
+        x4[0] = (rok && col == 0) ? (real)1 : (real)0;
+      } else if constexpr (V == 4) {
         big_load4<real>(src + (long long)row * src_ld, col, rok && (col >> 2) < src_pieces, x4);
       } else {
         const real* p = src + (long long)row * src_ld + col;
@@ -263,10 +307,28 @@ __global__ void __launch_bounds__(256) big_records_kernel(BigArgs<real> a) {
     real av[NKB][4], bv[NCB][4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
+      const int rs = klq ? 4 * g + s : 4 * s + g;  // the row k-step s covers
 #pragma unroll
-      for (int kb = 0; kb < NKB; ++kb) av[kb][s] = wst[(4 * s + g) * SWs + 16 * kb + ar];
+      for (int kb = 0; kb < NKB; ++kb) av[kb][s] = wst[rs * SWs + 16 * kb + ar];
 #pragma unroll
-      for (int cb = 0; cb < NCB; ++cb) bv[cb][s] = xst[(4 * s + g) * SXs + 16 * cb + j];
+      for (int cb = 0; cb < NCB; ++cb) bv[cb][s] = xst[rs * SXs + 16 * cb + j];
+    }
+    if (klq) {
+      // (W' H) block: A = W' (rows x components, row arow(j) of the stage), B = H (components x channels);
+      // D: lane (channel j, g), register r <-> row 4 g + r -- the rows of bv
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) {
+        acc rec = acc{0, 0, 0, 0};
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+          real wa[4];
+          wide_lds_read<real, 4>(wst + ar * SWs + 16 * kb + 4 * g, wa);
+#pragma unroll
+          for (int s = 0; s < 4; ++s) rec = M::mma(wa[s], sHb[(16 * kb + 4 * g + s) * SHB + 16 * cb + j], rec);
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) bv[cb][s] = big_quot(bv[cb][s], rec[s] < eps_val<real>() ? eps_val<real>() : rec[s]);
+      }
     }
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb)
@@ -311,6 +373,7 @@ struct BigHArgs {
   int m, k, S;
   int rec, ldA, offB, ldB;  // slice records of big_records_kernel: KP MP + KP KP, MP, KP MP, KP; packed sums: k m + k k, m, k m, k
   real l1h, l2h;
+  int kl;  // 1: H <- H * (W^T Q) / colsum(W)  (_nmf.py:663-684; colsum in column 0 of the second block), H[H < eps64] = 0 (:866-868)
 };
 template <typename real>
 __global__ void __launch_bounds__(256) big_hupdate_kernel(BigHArgs<real> a) {
@@ -341,13 +404,21 @@ __global__ void __launch_bounds__(256) big_hupdate_kernel(BigHArgs<real> a) {
   __syncthreads();
   for (int idx = tid; idx < k * ncol; idx += 256) {
     const int c = idx / ncol, jj = idx % ncol;
-    real d = sB[c * k] * sHo[jj];
-    for (int c2 = 1; c2 < k; ++c2) d = fma_(sB[c * k + c2], sHo[c2 * 64 + jj], d);
+    real d;
+    if (a.kl) {
+      d = sB[c * k];
+      if (d == (real)0) d = (real)1;
+    } else {
+      d = sB[c * k] * sHo[jj];
+      for (int c2 = 1; c2 < k; ++c2) d = fma_(sB[c * k + c2], sHo[c2 * 64 + jj], d);
+    }
     const real hold = sHo[c * 64 + jj];
     if (a.l1h > (real)0) d = d + a.l1h;
     if (a.l2h > (real)0) d = d + a.l2h * hold;
     d = (d == (real)0) ? eps_val<real>() : d;
-    Hb[(long long)c * a.m + c0 + jj] = hold * (sNum[c * 64 + jj] / d);
+    real hn = hold * (sNum[c * 64 + jj] / d);
+    if (a.kl && hn < (real)2.220446049250313e-16) hn = (real)0;
+    Hb[(long long)c * a.m + c0 + jj] = hn;
   }
 }
 
@@ -369,12 +440,13 @@ __global__ void __launch_bounds__(256) big_pack_sums_kernel(BigArgs<real> a, rea
 template <typename real>
 __global__ void __launch_bounds__(256) big_colsum_kernel(BigArgs<real> a, real* __restrict__ sse_col, real* __restrict__ xsq_col) {
   const int b = blockIdx.x;
-  const real* __restrict__ cb = a.colpart + (long long)b * a.S * 2 * a.MP;
+  const int nc = big_ncol(a);
+  const real* __restrict__ cb = a.colpart + (long long)b * a.S * nc;
   for (int jj = threadIdx.x; jj < a.m; jj += blockDim.x) {
     real s0 = (real)0, s1 = (real)0;
     for (int q = 0; q < a.S; ++q) {
-      s0 += cb[(long long)q * 2 * a.MP + jj];
-      s1 += cb[(long long)q * 2 * a.MP + a.MP + jj];
+      s0 += cb[(long long)q * nc + jj];
+      s1 += cb[(long long)q * nc + a.MP + jj];
     }
     sse_col[(long long)b * a.m + jj] = s0;
     if (xsq_col) xsq_col[(long long)b * a.m + jj] = s1;
@@ -393,7 +465,8 @@ __global__ void __launch_bounds__(256) big_resid_kernel(BigArgs<real> a) {
   if (a.state && a.state[(long long)b * 8 + 3] != (real)0) return;
   const int SH = a.CBH + 4;
   real* const sH = reinterpret_cast<real*>(big_smem);
-  real* const cols = sH + KP * SH;  // [4][2 MP]
+  real* const cols = sH + KP * SH;  // [4][NC], NC = 2 MP (sse | xsq) or 3 MP (| the Kullback-Leibler divergence per column)
+  const int NC = big_ncol(a);
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4, wave = tid >> 6;
   const int ar = M::arow(j);
   const real* __restrict__ Xb = a.X + (long long)b * a.x_bstride;
@@ -401,12 +474,12 @@ __global__ void __launch_bounds__(256) big_resid_kernel(BigArgs<real> a) {
   const real* __restrict__ Hb = a.H + (long long)b * a.k * a.m;
   int row_begin, row_end;
   big_slice(a, row_begin, row_end);
-  for (int idx = tid; idx < 4 * 2 * a.MP; idx += 256) cols[idx] = (real)0;
+  for (int idx = tid; idx < 4 * NC; idx += 256) cols[idx] = (real)0;
   const bool h_resident = a.CBH >= a.MP;
   if (h_resident) big_stage_h(a, Hb, 0, sH);
   __syncthreads();
   constexpr int V = 16 / (int)sizeof(real);
-  real* const mycols = cols + wave * 2 * a.MP;
+  real* const mycols = cols + wave * NC;
   for (int cb0 = 0; cb0 < a.MP; cb0 += a.CBH) {
     if (!h_resident) {
       __syncthreads();
@@ -446,12 +519,27 @@ __global__ void __launch_bounds__(256) big_resid_kernel(BigArgs<real> a) {
             for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
               for (int s = 0; s < 4; ++s) rec = M::mma(sH[(16 * kb + 4 * g + s) * SH + (ch - cb0) + ar], w[kb][s], rec);
-            real sse[4], xsq[4];
+            real sse[4], xsq[4], kld[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const real d = x[q][r] - rec[r];
               sse[r] = d * d;
               xsq[r] = x[q][r] * x[q][r];
+              kld[r] = (real)0;
+            }
+            if (a.kl) {  // element by element x log(x / wh) - x + wh, zeros of X skipped, wh clamped (_nmf.py:140-161), as nmf_wide.hpp
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const real xv = x[q][r], whv = rec[r];
+                const real whc = whv < eps_val<real>() ? eps_val<real>() : whv;
+                const real xs_ = xv > eps_val<real>() ? xv : eps_val<real>();
+                const real lg = fma_(xv, log_(xs_ / whc), whv - xv);
+                kld[r] = (xv > eps_val<real>()) ? lg : whv;
+              }
+#pragma unroll
+              for (int off = 1; off < 16; off <<= 1)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) kld[r] += __shfl_xor(kld[r], off, 64);
             }
             // sum over the 16 rows of the subtile (lanes j = 0 .. 15 of the same g): a fixed butterfly
 #pragma unroll
@@ -467,6 +555,7 @@ __global__ void __launch_bounds__(256) big_resid_kernel(BigArgs<real> a) {
               for (int r = 0; r < 4; ++r) {
                 mycols[col + r] += sse[r];
                 mycols[a.MP + col + r] += xsq[r];
+                if (a.kl) mycols[2 * a.MP + col + r] += kld[r];
               }
             }
           }
@@ -475,9 +564,8 @@ __global__ void __launch_bounds__(256) big_resid_kernel(BigArgs<real> a) {
     }
   }
   __syncthreads();
-  real* __restrict__ out = a.colpart + ((long long)b * a.S + blockIdx.x) * 2 * a.MP;
-  for (int idx = tid; idx < 2 * a.MP; idx += 256)
-    out[idx] = ((cols[idx] + cols[2 * a.MP + idx]) + cols[4 * a.MP + idx]) + cols[6 * a.MP + idx];
+  real* __restrict__ out = a.colpart + ((long long)b * a.S + blockIdx.x) * NC;
+  for (int idx = tid; idx < NC; idx += 256) out[idx] = ((cols[idx] + cols[NC + idx]) + cols[2 * NC + idx]) + cols[3 * NC + idx];
 }
 
 // wide_resid_finalize_kernel with the column buffer in dynamic LDS (2 MP values): error, stop rule (_nmf.py:872-884), outputs
@@ -489,12 +577,13 @@ __global__ void __launch_bounds__(1024) big_resid_finalize_kernel(WideSliceArgs<
   real* st = a.state + (long long)b * 8;
   const bool done = st[3] != (real)0;
   if (done && a.it != -1) return;
-  wide_sum_slices<real>(a.colpart + (long long)b * a.S * 2 * a.MP, 2 * a.MP, a.S, cols);
+  const int NC = (a.kl ? 3 : 2) * a.MP;
+  wide_sum_slices<real>(a.colpart + (long long)b * a.S * NC, NC, a.S, cols);
   __syncthreads();
   if (tid == 0) {
     real tot = (real)0;
-    for (int jj = 0; jj < a.MP; ++jj) tot += cols[jj];
-    const real err = sqrt_(tot);
+    for (int jj = 0; jj < a.MP; ++jj) tot += cols[(a.kl ? 2 * a.MP : 0) + jj];
+    const real err = a.kl ? sqrt_((real)2 * (tot > (real)0 ? tot : (real)0)) : sqrt_(tot);  // sqrt(2 KL) (_nmf.py:185-189)
     if (a.it == 0) {
       st[0] = err;
       st[1] = err;

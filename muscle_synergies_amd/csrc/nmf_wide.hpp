@@ -855,6 +855,7 @@ struct WideSliceArgs {
   real* xsq_col_out;
   int m, k, MP, KP, S, max_iter, check_every, it;  // it: 0 = error at init, 1 = stop-rule check, -1 = final outputs
   real tol, l1h, l2h;
+  int kl;  // big_resid_finalize_kernel only: column records of 3 MP values, error = sqrt(2 KL)
 };
 
 // H *= (W^T X) / ((W^T W) H) from the slice records, summed in slice order (_nmf.py:638-640, 701-728).  One workgroup per matrix.

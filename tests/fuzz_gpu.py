@@ -77,10 +77,6 @@ for case in range(a.cases):
             continue
         if wide and variant == 2 and (loss != "frobenius" or ragged) and "uniform Frobenius batches only" in str(e):
             continue
-        big = m > 128 or k > 32 or (dtype == np.float64 and k > 16 and m > 64)  # the general-shape kernels: Frobenius only (ragged: trial by trial)
-        big = big and not (dtype == np.float32 and 128 < m <= 256 and k <= 16)      # (fp32 up to 256 x 16: the one-pass kernel, everything goes)
-        if wide and big and (loss != "frobenius" or ragged) and "not compiled" in str(e):
-            continue
         if variant == 6 and ("fit_small_kernel" in str(e)):  # n_samples <= 256 (more for some shapes), Frobenius, m <= 16, fp64: k <= 6
             assert not (max(Ts) <= 256 and loss == "frobenius" and m <= 16 and not (dtype == np.float64 and k > 6)), desc
             continue

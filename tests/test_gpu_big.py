@@ -259,3 +259,52 @@ def test_ragged_batch_on_the_general_shape_kernels(dtype, m, k):
         assert _last_kernel().startswith("big_pass_w_kernel"), _last_kernel()
         for g in got:
             assert g.vaf_values.shape[0] == 2 and np.isfinite(g.vaf_values.to_numpy()).all()
+
+
+@pytest.mark.parametrize("dtype,m,k,T", [(np.float64, 200, 12, 700), (np.float32, 300, 20, 1000), (np.float64, 100, 24, 333),
+                                         (np.float32, 512, 64, 150), (np.float32, 129, 17, 2100), (np.float64, 136, 3, 4097)])
+def test_kullback_leibler_on_the_general_shape_kernels(dtype, m, k, T):
+    """beta_loss='kullback-leibler' beyond 128 channels / 32 components (round 4: Q = X / WH from the pipe inside
+    big_pass_w_kernel / big_records_kernel, colsum(W) through a column of ones, the divergence per column in the residual
+    kernel) against the oracle's restatement of _nmf.py:556-591, 642-684: fixed iterations, both layouts, the error, stop rule,
+    regularisation, transform; the estimator on a 200-channel frame stays on the GPU."""
+    import warnings
+
+    import muscle_synergies_amd as ms
+
+    X, W0, H0 = _case(T, m, k, dtype, seed=2 * m + k)
+    tol = 3e-5 if dtype == np.float32 else 1e-9
+    Wr, Hr, _ = orc.fit_multiplicative_update_kl(X, W0.copy(), H0.copy(), 20, 0.0)
+    for layout in ("F", "C"):
+        Xl = np.asfortranarray(X) if layout == "F" else np.ascontiguousarray(X)
+        res = ms.fit_batched(Xl, W0, H0, max_iter=20, tol=0.0, beta_loss="kullback-leibler")
+        assert _last_kernel().startswith("big_pass_w_kernel"), _last_kernel()
+        assert _rel(X, res.W[0], res.H[0], {"W": Wr, "H": Hr}) <= tol, layout
+        err = orc.kl_divergence(X, Wr, Hr, square_root=True)
+        assert abs(float(res.reconstruction_err[0]) - err) <= (5e-3 if dtype == np.float32 else 1e-9) * max(err, 1e-30)
+        assert (res.W[0] >= 0).all() and (res.H[0] >= 0).all()
+    Ws, Hs, n_it = orc.fit_multiplicative_update_kl(X, W0.copy(), H0.copy(), 150, 1e-3, 0.01, 0.02, 0.03, 0.01)
+    res = ms.fit_batched(X, W0, H0, max_iter=150, tol=1e-3, beta_loss="kullback-leibler", l1_reg_W=0.01, l1_reg_H=0.02,
+                         l2_reg_W=0.03, l2_reg_H=0.01)
+    if dtype == np.float64:
+        assert int(res.n_iter[0]) == n_it
+        assert _rel(X, res.W[0], res.H[0], {"W": Ws, "H": Hs}) <= 1e-9
+    else:
+        assert abs(int(res.n_iter[0]) - n_it) <= 10
+    Wt = np.full_like(W0, np.sqrt(X.mean() / k))
+    Wt_ref, _, _ = orc.fit_multiplicative_update_kl(X, Wt.copy(), Hr.copy(), 15, 0.0, update_H=False)
+    rt = ms.fit_batched(X, Wt, Hr, max_iter=15, tol=0.0, beta_loss="kullback-leibler", update_H=False)
+    np.testing.assert_array_equal(rt.H[0], Hr)
+    np.testing.assert_allclose(rt.W[0], Wt_ref, rtol=2e-3 if dtype == np.float32 else 1e-8, atol=1e-6 if dtype == np.float32 else 1e-12)
+    if m == 200:
+        with warnings.catch_warnings():
+            warnings.simplefilter("error", RuntimeWarning)  # a fallback to scikit-learn warns
+            try:
+                from sklearn.exceptions import ConvergenceWarning
+                warnings.simplefilter("ignore", category=ConvergenceWarning)
+            except ImportError:
+                pass
+            model = ms.HipNMF(n_components=k, init="custom", solver="mu", beta_loss="kullback-leibler", max_iter=20, tol=0.0)
+            Wm = model.fit_transform(X, W=W0.copy(), H=H0.copy())
+        assert _last_kernel().startswith("big_pass_w_kernel"), _last_kernel()
+        assert _rel(X, Wm, model.components_, {"W": Wr, "H": Hr}) <= tol

@@ -223,7 +223,7 @@ def test_wide_kl_through_the_estimator():
 def test_wide_17_to_32_components(dtype, m, k, T):
     """17..32 components (two 16-component blocks on the matrix pipe), Frobenius and Kullback-Leibler, both layouts;
     float64 beyond 64 channels does not fit LDS in this configuration: since round 4 the general-shape kernels (nmf_big.hpp)
-    take it (Frobenius; Kullback-Leibler there is refused, HIPNMF_ERR_UNSUPPORTED)."""
+    take it (both losses)."""
     import muscle_synergies_amd as ms
     from muscle_synergies_amd import _lib
 
@@ -233,9 +233,11 @@ def test_wide_17_to_32_components(dtype, m, k, T):
         res = ms.fit_batched(X, W0, H0, max_iter=25, tol=0.0)
         assert _last_kernel().startswith("big_pass_w_kernel<double,32>"), _last_kernel()
         assert _rel(X, res.W[0], res.H[0], ref) <= 1e-9
-        with pytest.raises(_lib.HipNmfError) as e:
-            ms.fit_batched(X, W0, H0, max_iter=5, tol=0.0, beta_loss="kullback-leibler")
-        assert e.value.code == _lib.HIPNMF_ERR_UNSUPPORTED and "not compiled" in str(e.value)
+        # (round 4, later: the Kullback-Leibler loss runs there too)
+        Wk, Hk, _ = orc.fit_multiplicative_update_kl(X, W0.copy(), H0.copy(), 5, 0.0)
+        rk = ms.fit_batched(X, W0, H0, max_iter=5, tol=0.0, beta_loss="kullback-leibler")
+        assert _last_kernel().startswith("big_pass_w_kernel<double,32>"), _last_kernel()
+        assert _rel(X, rk.W[0], rk.H[0], {"W": Wk, "H": Hk}) <= 1e-9
         return
     ref = orc.nmf_mu_fit(X, W0, H0, max_iter=25, tol=0.0)
     tol = TOL if dtype == np.float32 else 1e-9
