@@ -70,7 +70,7 @@ typedef struct hipnmf_problem {
   int32_t x_layout;       /* HIPNMF_X_*                                                                */
   int32_t update_h;       /* 1: fit (W and H updated, _nmf.py:854); 0: transform (H fixed, :1736-1763) */
   int32_t w_layout;       /* HIPNMF_W_*                                                                */
-  int32_t loss;           /* HIPNMF_LOSS_*; the shard entry points accept FROBENIUS only               */
+  int32_t loss;           /* HIPNMF_LOSS_*                                                             */
   int64_t ldx;            /* leading dimension of one X matrix, in elements                            */
   int64_t x_batch_stride; /* elements between consecutive X matrices                                   */
   int32_t max_iter;       /* >= 1 (NMF max_iter, _nmf.py:831)                                          */
@@ -164,6 +164,11 @@ int hipnmf_fit_ragged_f64(hipnmf_handle* h, const hipnmf_problem* p, const int64
  * run on the general-shape kernels and require p->x_layout == HIPNMF_X_ROW_MAJOR with 16-byte aligned rows (ldx * sizeof % 16
  * == 0) and p->w_layout == HIPNMF_W_ROW_MAJOR with W stored as [n_samples][KP], KP = n_components rounded up to 16, the padding
  * columns zero (they stay zero); sums keeps the [k*m + k*k] layout: W^T X (k x m) then W^T W (k x k).
+ * Those layouts select the general-shape kernels for narrow shapes too.
+ * HIPNMF_LOSS_KL (round 4): always the general-shape kernels and their layouts, whatever the shape; sums = [W^T (X / WH) (k x m) |
+ * colsum(W) in column 0 of the k x k block]; hipnmf_shard_residual returns the generalised Kullback-Leibler divergence per
+ * column in sse_col (reconstruction_err_ = sqrt(2 * the sum over shards and columns)) -- call it with loss = FROBENIUS for the
+ * squared-error columns of VAF; hipnmf_fit_tsharded_* does both.
  */
 int hipnmf_shard_pass_f32(hipnmf_handle* h, const hipnmf_problem* p, const float* X, float* W, const float* H,
                           float* sums);

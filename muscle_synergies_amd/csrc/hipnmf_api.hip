@@ -195,8 +195,6 @@ int validate(const hipnmf_problem* p, bool shard, bool ragged = false) {
     return fail(HIPNMF_ERR_BAD_ARG, "bad w_layout %d", p->w_layout);
   if (p->loss != HIPNMF_LOSS_FROBENIUS && p->loss != HIPNMF_LOSS_KL)
     return fail(HIPNMF_ERR_BAD_ARG, "bad loss %d", p->loss);
-  if (shard && p->loss != HIPNMF_LOSS_FROBENIUS)
-    return fail(HIPNMF_ERR_UNSUPPORTED, "the time-shard entry points implement the Frobenius loss only");
   if (!ragged) {  // the ragged entry points take leading dimension and offsets per matrix from the descriptors
     const long long min_ld = (p->x_layout == HIPNMF_X_ROW_MAJOR) ? p->n_features : p->n_samples;
     if (p->ldx < min_ld) return fail(HIPNMF_ERR_BAD_ARG, "ldx=%lld smaller than %lld", (long long)p->ldx, min_ld);
@@ -852,10 +850,13 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
 }
 
 // ---- shard building blocks ------------------------------------------------------------------------
-// beyond the narrow lane mappings (32 channels / 8 components) the building blocks run on the general-shape kernels (hipnmf_wide.hip)
+// beyond the narrow lane mappings (32 channels / 8 components), for the Kullback-Leibler loss whatever the shape, and for any
+// caller that hands over the general-shape kernels' layouts (row-major X and W: e.g. the squared-error residual of a
+// Kullback-Leibler fit of a narrow recording), the building blocks run on the general-shape kernels (hipnmf_wide.hip)
 inline bool shard_is_wide(const hipnmf_problem* p) {
   return p && p->struct_size == (int32_t)sizeof(hipnmf_problem) &&
-         (p->n_features > HIPNMF_NARROW_MAX_FEATURES || p->n_components > HIPNMF_NARROW_MAX_COMPONENTS);
+         (p->n_features > HIPNMF_NARROW_MAX_FEATURES || p->n_components > HIPNMF_NARROW_MAX_COMPONENTS || p->loss == HIPNMF_LOSS_KL ||
+          (p->x_layout == HIPNMF_X_ROW_MAJOR && p->w_layout == HIPNMF_W_ROW_MAJOR));
 }
 template <typename real>
 int shard_common(hipnmf_handle* h, const hipnmf_problem* p, const KernelSet<real>** ks_out, SolveArgs<real>* a,
@@ -1056,8 +1057,12 @@ int tsharded_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, real
     return e == 0 ? HIPNMF_OK : fail(HIPNMF_ERR_HIP, "the all-reduce callback returned %d", e);
   };
   // global ||X - W H||_F per matrix (and the per-column sums for VAF), in the arithmetic type like the other paths
-  auto global_error = [&]() -> int {
-    int r = shard_residual_impl<real>(h, p, X, W, H, cols, cols + (size_t)B * m);
+  // (Kullback-Leibler: the residual returns the divergence per column, err = sqrt(2 KL) (_nmf.py:185-189); `pp` with the loss
+  // switched to Frobenius gives the squared-error columns of VAF once at the end)
+  const bool kl = p->loss == HIPNMF_LOSS_KL;
+  auto global_error = [&](const hipnmf_problem* pp = nullptr) -> int {
+    if (!pp) pp = p;
+    int r = shard_residual_impl<real>(h, pp, X, W, H, cols, cols + (size_t)B * m);
     if (r) return r;
     for (int b = 0; b < B && !r; ++b) {  // pack [sse_b | xsq_b]
       if (hipMemcpyAsync(packed + (size_t)b * 2 * m, cols + (size_t)b * m, sizeof(real) * m, hipMemcpyDeviceToDevice, st) != hipSuccess ||
@@ -1070,10 +1075,11 @@ int tsharded_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, real
     if (hipMemcpyAsync(host.data(), packed, sizeof(real) * n_res, hipMemcpyDeviceToHost, st) != hipSuccess ||
         hipStreamSynchronize(st) != hipSuccess)
       return fail(HIPNMF_ERR_HIP, "reading the residual back failed: %s", hipGetErrorString(hipGetLastError()));
+    if (pp != p) return HIPNMF_OK;  // (the extra pass for VAF: the error stays the divergence's)
     for (int b = 0; b < B; ++b) {
       real tot = (real)0;
       for (int j = 0; j < m; ++j) tot += host[(size_t)b * 2 * m + j];
-      err[b] = (double)(real)std::sqrt((double)tot);
+      err[b] = kl ? (double)(real)std::sqrt(2.0 * std::max((double)tot, 0.0)) : (double)(real)std::sqrt((double)tot);
     }
     return HIPNMF_OK;
   };
@@ -1116,6 +1122,11 @@ int tsharded_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, real
     if (rc) break;
     if (n_iter > p->max_iter) n_iter = p->max_iter;
     if ((rc = global_error())) break;
+    if (kl && (sse_col_out || xsq_col_out)) {
+      hipnmf_problem q = *p;
+      q.loss = HIPNMF_LOSS_FROBENIUS;
+      if ((rc = global_error(&q))) break;
+    }
     rc = write_outputs();
   } while (false);
   h->async_mode = saved_async;

@@ -625,7 +625,8 @@ int hipnmf_shard_wide(hipnmf_handle* h, const hipnmf_problem* p, int op, const r
     return o;
   };
   const size_t o_part = carve(sizeof(real) * (size_t)B * S * rec);
-  const size_t o_col = carve(sizeof(real) * (size_t)B * S * 2 * MPb);
+  const bool kl = p->loss == HIPNMF_LOSS_KL;
+  const size_t o_col = carve(sizeof(real) * (size_t)B * S * 3 * MPb);
   const size_t o_hht = carve(sizeof(real) * (size_t)B * KPb * KPb);
   int rc = hipnmf_ensure_ws(h, off);
   if (rc) return rc;
@@ -651,13 +652,15 @@ int hipnmf_shard_wide(hipnmf_handle* h, const hipnmf_problem* p, int op, const r
   ba.rows_per_slice = (int)rps;
   ba.l1w = (real)p->l1_reg_W;
   ba.l2w = (real)p->l2_reg_W;
-  const size_t fixed = sizeof(real) * ((size_t)KPb * (KPb + 4) + 8 * (size_t)MPb);
+  ba.kl = kl ? 1 : 0;
+  const size_t fixed = sizeof(real) * ((size_t)KPb * (KPb + 4) + 12 * (size_t)MPb);
   int cbh = MPb;
   while (cbh > 16 && fixed + sizeof(real) * (size_t)KPb * (cbh + 4) > 96 * 1024) cbh = (int)round_up(cbh / 2, 16);
   ba.CBH = cbh;
   const size_t smem_w = sizeof(real) * ((size_t)KPb * (cbh + 4) + (size_t)KPb * (KPb + 4));
-  const size_t smem_r = sizeof(real) * ((size_t)KPb * (cbh + 4) + 8 * (size_t)MPb);
-  const size_t smem_rec = sizeof(real) * std::max<size_t>(4 * (16 * (size_t)(KPb + 4) + 16 * (size_t)(BIG_CB + 4)), 4 * (size_t)KPb * BIG_CB);
+  const size_t smem_r = sizeof(real) * ((size_t)KPb * (cbh + 4) + 4 * (size_t)(kl ? 3 : 2) * MPb);
+  const size_t smem_rec = sizeof(real) * std::max<size_t>(4 * (16 * (size_t)(KPb + 4) + 16 * (size_t)(BIG_CB + 4)) + (kl ? (size_t)KPb * (BIG_CB + 4) : 0),
+                                                          4 * (size_t)KPb * BIG_CB);
   const dim3 gslice(S, B), grec(S, B, (MPb + BIG_CB - 1) / BIG_CB + 1);
   auto with_kp = [&](auto&& f) {
     switch (KPb) {
@@ -696,7 +699,7 @@ int hipnmf_shard_wide(hipnmf_handle* h, const hipnmf_problem* p, int op, const r
     hb.ldB = k;
     hb.l1h = (real)p->l1_reg_H;
     hb.l2h = (real)p->l2_reg_H;
-    hb.kl = 0;
+    hb.kl = kl ? 1 : 0;
     hipLaunchKernelGGL(big_hupdate_kernel<real>, dim3(B, (m + 63) / 64), dim3(256), sizeof(real) * ((size_t)k * k + 128 * (size_t)k), st, hb);
   } else {
     with_kp([&](auto kp) {

@@ -448,6 +448,10 @@ __global__ void __launch_bounds__(256) big_colsum_kernel(BigArgs<real> a, real* 
       s0 += cb[(long long)q * nc + jj];
       s1 += cb[(long long)q * nc + a.MP + jj];
     }
+    if (a.kl) {  // Kullback-Leibler: the divergence per column takes the place of the squared error
+      s0 = (real)0;
+      for (int q = 0; q < a.S; ++q) s0 += cb[(long long)q * nc + 2 * a.MP + jj];
+    }
     sse_col[(long long)b * a.m + jj] = s0;
     if (xsq_col) xsq_col[(long long)b * a.m + jj] = s1;
   }

@@ -62,9 +62,10 @@ def plan_subshards(n_samples: int, world_size: int, rank: int, subshard: int):
     return out
 
 
-def _is_wide(m: int, k: int) -> bool:
-    """Beyond the narrow lane mappings the shard entry points run on the general-shape kernels, which take row-major X and W."""
-    return m > 32 or k > 8
+def _is_wide(m: int, k: int, kl: bool = False) -> bool:
+    """Beyond the narrow lane mappings -- and for the Kullback-Leibler loss whatever the shape -- the shard entry points run on
+    the general-shape kernels, which take row-major X and W."""
+    return m > 32 or k > 8 or kl
 
 
 class HipShardOps:
@@ -73,10 +74,13 @@ class HipShardOps:
     with 16-byte aligned rows and W ``[B, T_local, KP]`` row-major, ``KP = round_up(k, 16)``, padding columns zero."""
 
     def __init__(self, X_local, W_local, H, *, l1_reg_W=0.0, l1_reg_H=0.0, l2_reg_W=0.0, l2_reg_H=0.0,
-                 update_H=True, device=None):
+                 update_H=True, device=None, beta_loss="frobenius"):
         import torch
 
+        from .engine import beta_loss_code
+
         self.torch = torch
+        self.kl = beta_loss_code(beta_loss) == _lib.LOSS_KL  # residual() then returns the divergence per column
         self.dev = resolve_device(device)
         X = torch.as_tensor(X_local).to(self.dev)
         if X.dim() == 2:
@@ -85,7 +89,7 @@ class HipShardOps:
         self.dtype = X.dtype
         W = torch.as_tensor(W_local).to(self.dev, self.dtype)
         self.k = W.shape[2]
-        self.wide = _is_wide(self.m, self.k)
+        self.wide = _is_wide(self.m, self.k, self.kl)
         if self.wide:
             vec = 4 if self.dtype == torch.float32 else 2
             self.ld = self.T
@@ -116,7 +120,7 @@ class HipShardOps:
             self.p = make_problem(self.B, self.T, self.m, self.k, x_layout=_lib.X_ROW_MAJOR, ldx=self.ldx,
                                   x_batch_stride=self.T * self.ldx, w_layout=_lib.W_ROW_MAJOR, update_H=update_H,
                                   max_iter=1, tol=0.0, l1_reg_W=l1_reg_W, l1_reg_H=l1_reg_H, l2_reg_W=l2_reg_W,
-                                  l2_reg_H=l2_reg_H)
+                                  l2_reg_H=l2_reg_H, loss=_lib.LOSS_KL if self.kl else _lib.LOSS_FROBENIUS)
         else:
             self.p = make_problem(self.B, self.ld, self.m, self.k, x_layout=_lib.X_CHANNEL_MAJOR, ldx=self.ld,
                                   x_batch_stride=self.m * self.ld, w_layout=_lib.W_COMPONENT_MAJOR, update_H=update_H,
@@ -141,6 +145,7 @@ class HipShardOps:
         self = cls.__new__(cls)
         self.torch = torch
         self.wide = False  # (the wide layouts go through the ordinary constructor)
+        self.kl = False
         self.dev = Xc.device
         if not (Xc.is_cuda and Wc.is_cuda and H.is_cuda and Xc.is_contiguous() and Wc.is_contiguous()
                 and H.is_contiguous()):
@@ -227,7 +232,19 @@ class HipShardOps:
         _lib.check(self._hupd(self.handle.ptr, ctypes.byref(self.p), self.H.data_ptr(), sums.data_ptr()))
 
     def residual(self):
+        """Per-column sums of this shard: ``(sse, xsq)``; with the Kullback-Leibler loss the first is the generalised
+        divergence per column (``reconstruction_err = sqrt(2 * sum)``), :meth:`residual_squared` the squared error."""
         _lib.check(self._res(self.handle.ptr, ctypes.byref(self.p), self.Xc.data_ptr(), self.Wc.data_ptr(),
+                             self.H.data_ptr(), self.sse.data_ptr(), self.xsq.data_ptr()))
+        return self.sse, self.xsq
+
+    def residual_squared(self):
+        """``(sse, xsq)`` of the squared error whatever the loss (the columns VAF is made of)."""
+        if not self.kl:
+            return self.residual()
+        q = _lib.Problem.from_buffer_copy(self.p)
+        q.loss = _lib.LOSS_FROBENIUS
+        _lib.check(self._res(self.handle.ptr, ctypes.byref(q), self.Xc.data_ptr(), self.Wc.data_ptr(),
                              self.H.data_ptr(), self.sse.data_ptr(), self.xsq.data_ptr()))
         return self.sse, self.xsq
 
@@ -276,6 +293,19 @@ class MultiShardOps:
             xsq += b
         return sse, xsq
 
+    @property
+    def kl(self):
+        return bool(getattr(self.shards[0], "kl", False))
+
+    def residual_squared(self):
+        sse, xsq = self.shards[0].residual_squared()
+        sse, xsq = sse.clone(), xsq.clone()
+        for sh in self.shards[1:]:
+            a, b = sh.residual_squared()
+            sse += a
+            xsq += b
+        return sse, xsq
+
     def result_W(self):
         return [sh.Wc for sh in self.shards]  # native layout, no concatenation (may be tens of GB)
 
@@ -302,17 +332,23 @@ def fit_tsharded(ops, *, max_iter: int = 200, tol: float = 1e-4, check_every: in
             def all_reduce(t):  # single rank
                 return t
 
-    def global_error():
-        sse, xsq = ops.residual()
+    kl = bool(getattr(ops, "kl", False))  # the residual's first output is then the divergence per column (_nmf.py:185-189)
+
+    def global_error(squared=False):
+        sse, xsq = ops.residual_squared() if squared else ops.residual()
         packed = torch.cat([sse, xsq], dim=1).clone()
         packed = all_reduce(packed)
         m = sse.shape[1]
         return packed[:, :m], packed[:, m:]
 
+    def to_err(cols):
+        tot = cols.sum(dim=1)
+        return torch.sqrt(2 * torch.clamp(tot, min=0)) if kl else torch.sqrt(tot)
+
     err_init = prev = None
     if tol > 0:
         sse, _ = global_error()
-        err_init = torch.sqrt(sse.sum(dim=1))
+        err_init = to_err(sse)
         prev = err_init.clone()
     n_iter = 0
     for n_iter in range(1, max_iter + 1):
@@ -322,19 +358,22 @@ def fit_tsharded(ops, *, max_iter: int = 200, tol: float = 1e-4, check_every: in
             ops.h_update(sums)
         if tol > 0 and n_iter % check_every == 0:
             sse, _ = global_error()
-            err = torch.sqrt(sse.sum(dim=1))
+            err = to_err(sse)
             # every matrix of the (small) batch must have converged; with B == 1 this is sklearn's rule
             if bool((((prev - err) / err_init) < tol).all()):
                 break
             prev = err
     sse, xsq = global_error()
-    err = torch.sqrt(sse.sum(dim=1))
+    err = to_err(sse)
+    if kl:  # VAF is made of the squared-error columns: one more residual pass
+        sse, xsq = global_error(squared=True)
     vaf = torch.cat([(1 - sse.sum(dim=1) / xsq.sum(dim=1)).unsqueeze(1), 1 - sse / xsq], dim=1)
     return ShardedResult(ops.result_W(), ops.result_H(), n_iter, err, vaf)
 
 
 def fit_tsharded_hip(X_local, W_local, H, *, max_iter=200, tol=1e-4, check_every=10, update_H=True, group=None,
                      device=None, **reg) -> ShardedResult:
-    """Convenience wrapper: build :class:`HipShardOps` for this rank's rows and run :func:`fit_tsharded`."""
+    """Convenience wrapper: build :class:`HipShardOps` for this rank's rows and run :func:`fit_tsharded`
+    (``beta_loss='kullback-leibler'`` among the keyword arguments selects that loss)."""
     ops = HipShardOps(X_local, W_local, H, update_H=update_H, device=device, **reg)
     return fit_tsharded(ops, max_iter=max_iter, tol=tol, check_every=check_every, update_H=update_H, group=group)

@@ -325,3 +325,42 @@ def h_update_from_sums(WtX, WtW, H, l1_reg_H=0.0, l2_reg_H=0.0):
     denominator[denominator == 0] = EPSILON
     H *= WtX / denominator
     return H
+
+
+def kl_shard_pass(X_s, W_s, H, l1_reg_W=0.0, l2_reg_W=0.0):
+    """Kullback-Leibler flavour of :func:`shard_pass`: update the shard's rows of W (row-local: the denominator is
+    ``rowsum(H)``), return ``W_s^T (X_s / W_s H)`` (k x m) and ``colsum(W_s)`` in column 0 of a k x k block."""
+    kl_update_w(X_s, W_s, H, l1_reg_W, l2_reg_W)
+    WH = np.dot(W_s, H)
+    WH[WH < EPSILON] = EPSILON
+    k = H.shape[0]
+    second = np.zeros((k, k), dtype=W_s.dtype)
+    second[:, 0] = W_s.sum(axis=0)
+    return W_s.T @ (X_s / WH), second
+
+
+def kl_h_update_from_sums(WtQ, second, H, l1_reg_H=0.0, l2_reg_H=0.0):
+    """H update of the Kullback-Leibler loss from the summed-over-shards ``W^T (X / WH)`` and ``colsum(W)``
+    (_nmf.py:663-684, 866-868)."""
+    W_sum = second[:, 0].copy()
+    W_sum[W_sum == 0] = 1.0
+    denominator = W_sum[:, np.newaxis]
+    if l1_reg_H > 0:
+        denominator = denominator + l1_reg_H
+    if l2_reg_H > 0:
+        denominator = denominator + l2_reg_H * H
+    denominator = np.array(np.broadcast_to(denominator, WtQ.shape))
+    denominator[denominator == 0] = EPSILON
+    H *= WtQ / denominator
+    H[H < EPS64] = 0.0
+    return H
+
+
+def kl_divergence_columns(X, W, H):
+    """The generalised Kullback-Leibler divergence split by column (element by element ``x log(x / wh) - x + wh`` with zeros of
+    X skipped and WH clamped): sums to :func:`kl_divergence`."""
+    WH = np.dot(W, H)
+    WHc = np.where(WH < EPSILON, EPSILON, WH)
+    pos = X > EPSILON
+    term = np.where(pos, X * np.log(np.where(pos, X, 1.0) / WHc) - X + WH, WH)
+    return term.sum(axis=0)

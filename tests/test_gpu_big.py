@@ -308,3 +308,72 @@ def test_kullback_leibler_on_the_general_shape_kernels(dtype, m, k, T):
             Wm = model.fit_transform(X, W=W0.copy(), H=H0.copy())
         assert _last_kernel().startswith("big_pass_w_kernel"), _last_kernel()
         assert _rel(X, Wm, model.components_, {"W": Wr, "H": Hr}) <= tol
+
+
+@pytest.mark.parametrize("dtype,m,k", [(np.float64, 16, 5), (np.float32, 64, 8), (np.float64, 200, 12)])
+def test_time_sharded_kullback_leibler_fit(dtype, m, k):
+    """hipnmf_shard_* / hipnmf_fit_tsharded_* with HIPNMF_LOSS_KL (round 4: always on the general-shape kernels, whatever the
+    shape): one recording as 1 and 3 time shards -- the Python-driven loop with the sums added across shards on the device,
+    and the library's own loop -- against the oracle: factors, sqrt(2 KL), the squared-error VAF, the stop rule."""
+    import torch
+
+    from muscle_synergies_amd.tsharded import HipShardOps, fit_tsharded
+
+    T = 3000
+    X = emg_matrix(41, T=T, m=m, k_true=min(6, m), dtype=dtype)
+    W0, H0 = random_init(X, k, 4)
+    ref = orc.nmf_mu_fit_kl(X, W0, H0, max_iter=30, tol=0.0)
+    tol = 3e-5 if dtype == np.float32 else 1e-9
+    va, vc = orc.vaf(X.astype(np.float64), ref["W"].astype(np.float64), ref["H"].astype(np.float64))
+    for nshards in (1, 3):
+        bounds = np.linspace(0, T, nshards + 1).astype(int)
+        shards = [HipShardOps(X[a:b], W0[a:b], H0, beta_loss="kullback-leibler") for a, b in zip(bounds[:-1], bounds[1:])]
+
+        class Multi:
+            kl = True
+
+            def shard_pass(self):
+                tot = shards[0].shard_pass().clone()
+                for sh in shards[1:]:
+                    tot += sh.shard_pass()
+                return tot
+
+            def h_update(self, sums):
+                for sh in shards:
+                    sh.h_update(sums)
+
+            def _sum(self, which):
+                sse, xsq = (t.clone() for t in getattr(shards[0], which)())
+                for sh in shards[1:]:
+                    a, b = getattr(sh, which)()
+                    sse += a
+                    xsq += b
+                return sse, xsq
+
+            def residual(self):
+                return self._sum("residual")
+
+            def residual_squared(self):
+                return self._sum("residual_squared")
+
+            def result_W(self):
+                return torch.cat([sh.result_W() for sh in shards], dim=1)
+
+            def result_H(self):
+                return shards[0].H
+
+        r = fit_tsharded(Multi(), max_iter=30, tol=0.0)
+        W, H = r.W_local[0].cpu().numpy(), r.H[0].cpu().numpy()
+        assert W.shape == (T, k) and _rel(X, W, H, ref) <= tol, nshards
+        assert abs(float(r.reconstruction_err[0]) - float(ref["reconstruction_err"])) <= (5e-3 if dtype == np.float32 else 1e-9) * float(ref["reconstruction_err"])
+        np.testing.assert_allclose(r.vaf[0].cpu().numpy(), np.r_[va, vc], atol=5e-5 if dtype == np.float32 else 1e-9)
+    # the whole sharded fit as one library call, stop rule live
+    ref_s = orc.nmf_mu_fit_kl(X, W0, H0, max_iter=200, tol=1e-3)
+    ops = HipShardOps(np.ascontiguousarray(X), W0, H0, beta_loss="kullback-leibler")
+    rn = ops.fit_native(max_iter=200, tol=1e-3)
+    assert abs(rn.n_iter - ref_s["n_iter"]) <= (10 if dtype == np.float32 else 0)
+    if dtype == np.float64:
+        assert _rel(X, rn.W_local[0].cpu().numpy(), rn.H[0].cpu().numpy(), ref_s) <= 1e-9
+        np.testing.assert_allclose(float(rn.reconstruction_err[0]), float(ref_s["reconstruction_err"]), rtol=1e-9)
+        va_s, vc_s = orc.vaf(X, ref_s["W"], ref_s["H"])
+        np.testing.assert_allclose(rn.vaf[0].cpu().numpy(), np.r_[va_s, vc_s], atol=1e-9)

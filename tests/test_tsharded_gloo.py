@@ -46,6 +46,29 @@ class OracleShardOps:
         return torch.from_numpy(self.H)[None]
 
 
+class OracleKLShardOps(OracleShardOps):
+    """The same stand-in for beta_loss='kullback-leibler': sums = [W^T (X / WH) | colsum(W) in column 0], the residual's first
+    output is the divergence per column, residual_squared() the squared error (what HipShardOps(beta_loss=...) does)."""
+
+    kl = True
+
+    def shard_pass(self):
+        a, b = orc.kl_shard_pass(self.X, self.W, self.H)
+        return torch.from_numpy(np.concatenate([a.ravel(), b.ravel()])[None, :].copy())
+
+    def h_update(self, sums):
+        s = sums.numpy()[0]
+        km = self.k * self.m
+        orc.kl_h_update_from_sums(s[:km].reshape(self.k, self.m), s[km:].reshape(self.k, self.k), self.H)
+
+    def residual(self):
+        return (torch.from_numpy(orc.kl_divergence_columns(self.X, self.W, self.H)[None, :]),
+                torch.from_numpy((self.X ** 2).sum(axis=0)[None, :]))
+
+    def residual_squared(self):
+        return OracleShardOps.residual(self)
+
+
 class SharedHOracleShardOps(OracleShardOps):
     """Sub-shard flavour for MultiShardOps: ``H`` is a torch tensor shared by all sub-shards of a rank."""
 
@@ -70,7 +93,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, T, tol, max_iter, out_dir):
+def _worker(rank, world, port, T, tol, max_iter, out_dir, kl=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -78,7 +101,7 @@ def _worker(rank, world, port, T, tol, max_iter, out_dir):
         X = emg_matrix(21, T=T, m=16, dtype=np.float64)
         W0, H0 = random_init(X, 5, 21)
         lo, hi = shard_bounds(T, world)[rank]
-        ops = OracleShardOps(X[lo:hi], W0[lo:hi], H0)
+        ops = (OracleKLShardOps if kl else OracleShardOps)(X[lo:hi], W0[lo:hi], H0)
         res = fit_tsharded(ops, max_iter=max_iter, tol=tol)
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), W=res.W_local.numpy()[0], H=res.H.numpy()[0],
                  n_iter=res.n_iter, err=res.reconstruction_err.numpy(), vaf=res.vaf.numpy(), lo=lo, hi=hi)
@@ -106,6 +129,26 @@ def test_two_rank_sharded_equals_unsharded(tmp_path, tol, max_iter):
     np.testing.assert_allclose(W, ref["W"], rtol=1e-9)
     if tol > 0:
         assert ref["n_iter"] % 10 == 0 and ref["n_iter"] < max_iter
+
+
+@pytest.mark.parametrize("tol,max_iter", [(0.0, 25), (1e-3, 200)])
+def test_two_rank_sharded_kullback_leibler_equals_unsharded(tmp_path, tol, max_iter):
+    """The Kullback-Leibler flavour of the orchestration (round 4): sums = [W^T (X / WH) | colsum(W)], the stop rule on
+    sqrt(2 KL) all-reduced per column, VAF from one extra squared-error pass."""
+    T, world = 1002, 2
+    mp.spawn(_worker, args=(world, _free_port(), T, tol, max_iter, str(tmp_path), True), nprocs=world, join=True)
+    X = emg_matrix(21, T=T, m=16, dtype=np.float64)
+    W0, H0 = random_init(X, 5, 21)
+    ref = orc.nmf_mu_fit_kl(X, W0, H0, max_iter=max_iter, tol=tol)
+    parts = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    W = np.concatenate([p["W"] for p in parts], axis=0)
+    for p in parts:
+        assert int(p["n_iter"]) == ref["n_iter"]
+        np.testing.assert_allclose(p["H"], ref["H"], rtol=1e-9, atol=1e-300)
+        np.testing.assert_allclose(p["err"][0], ref["reconstruction_err"], rtol=1e-9)
+        va, vc = orc.vaf(X, ref["W"], ref["H"])
+        np.testing.assert_allclose(p["vaf"][0], np.r_[va, vc], rtol=1e-9)
+    np.testing.assert_allclose(W, ref["W"], rtol=1e-9, atol=1e-300)
 
 
 def _multi_worker(rank, world, port, T, out_dir):
