@@ -404,10 +404,11 @@ struct SosLane {
 // one ds_write2_b64, which performs the lower-address element of every lane first: in this ASCENDING pass that is step
 // order, so the last section's value stays -- exact against scipy in every test and ~10 000 fuzz cases -- but it is the
 // compiler's pairing, not the source, that decides (sosfilt3_kernel's descending pass came out reversed and needs the
-// barrier).  -DHIPNMF_SOS_STORE_ORDER pins the order here too with a compiler barrier after every store; measured cost
-// 2.08 -> 2.35 ms (order 4 zero-lag, 1024 x 16 x 20 000 fp32), so it is off and tests/test_filters.py + the fuzz (bit
-// equality with scipy) stand guard over a toolchain change.
-#ifdef HIPNMF_SOS_STORE_ORDER
+// barrier).  A compiler barrier after every store pins the order in the source; measured cost 2.08 -> 2.35 ms (order 4
+// zero-lag, 1024 x 16 x 20 000 fp32).  Round 4: ON by default -- the exact mode exists to be bit-identical to scipy, the
+// time-parallel mode (sosfilt_scan.hpp) is the fast one, and a result that depends on an instruction pairing is not exact
+// (ADVICE r03).  -DHIPNMF_SOS_FAST_STORES restores the unordered stores.
+#ifndef HIPNMF_SOS_FAST_STORES
 #define SOS_STORE_ORDER() asm volatile("" ::: "memory")
 #else
 #define SOS_STORE_ORDER()
