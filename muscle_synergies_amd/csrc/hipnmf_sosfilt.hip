@@ -184,7 +184,10 @@ int sosfilt_impl(hipnmf_handle* h, const hipnmf_sosfilt_params* p, const double*
   const int scan_chunk = scan_need <= 16 ? 16 : scan_need <= 40 ? 40 : scan_need <= SCAN_CMAX ? SCAN_CMAX : SCAN_CMAX + 1;
   const bool scan_aligned = (T % VS) == 0 && (reinterpret_cast<uintptr_t>(y) % 16) == 0 &&
                             (!inplace || ((reinterpret_cast<uintptr_t>(x) % 16) == 0 && (p->ldx % VS) == 0 && (p->x_batch_stride % VS) == 0));
-  const bool scan_fits = p->mode == HIPNMF_SOSFILT_SCAN && scan_chunk <= SCAN_CMAX && scan_aligned;
+  // (the first version loads a float64 series in two passes; without the backward pass that loses to the sequential kernel --
+  // 1.60 vs 1.49 ms at 1024 x 16 x 20 000 -- so causal float64 filters beyond the second version's range stay sequential)
+  const bool scan_fits = p->mode == HIPNMF_SOSFILT_SCAN && scan_chunk <= SCAN_CMAX && scan_aligned &&
+                         !(sizeof(real) == 8 && !zero_lag && scan_chunk > 40);
   // second version (sosfilt_chunk_kernel): no alignment or length condition; float up to 256 x 79, double up to 256 x 41 extended
   // samples; HIPNMF_SOS_CHUNK=0 leaves the mode to sosfilt_scan_kernel
   static const bool chunk_scan_ok = [] {

@@ -20,7 +20,6 @@ run bench_config4 $R/bench.py --config 4 --steps 1 --warmup 1 --no-cpu-baseline
 run bench_config5 $R/bench.py --config 5 --steps 1 --warmup 1 --no-cpu-baseline
 run bench_config2 $R/bench.py --config 2 --steps 2 --warmup 1 --no-cpu-baseline
 run filter_bench $R/tools/filter_bench.py --orders 4 --dtypes float32 float64
-run envelope_bench $R/tools/envelope_bench.py
 for n in bench_steps2 bench_wide_m64_k8 bench_wide_m128_k16 bench_xl_m256_k16 bench_big_m512_k32 bench_config4 bench_config5 bench_config2; do
   grep -h '^{' $O/$n.log > $O/${tag}_${n/bench_steps2/bench}.json
 done
@@ -35,8 +34,12 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     vals = []
     for f in glob.glob("$O/pmc_scan_%s/**/*_counter_collection.csv" % c, recursive=True):
         for r in csv.DictReader(open(f)):
-            if r["Counter_Name"] == c and "sosfilt_scan_kernel" in r["Kernel_Name"]:
+            if r["Counter_Name"] == c and ("sosfilt_chunk_kernel" in r["Kernel_Name"] or "sosfilt_scan_kernel" in r["Kernel_Name"]):
                 vals.append(float(r["Counter_Value"]))
-    print(c, "KiB per launch of sosfilt_scan_kernel<float,2,80>:", vals, "(1024 x 16 x 20 000 fp32, zero-lag order 4; algorithmic 2 x 1 310 720 000 B)")
+    print(c, "KiB per launch of sosfilt_chunk_kernel<float,2,79>:", vals, "(1024 x 16 x 20 000 fp32, zero-lag order 4; algorithmic 2 x 1 310 720 000 B; FETCH_SIZE counts 64 B per 128-B request on gfx950: double it)")
 PY
+bash $R/tools/profile_envelope.sh $tag > $O/profile_envelope.log 2>&1
+cd /tmp
+run kl_narrow $R/tools/quick_bench.py --batch 2048 --iters 200 --threads 512 --loss kullback-leibler --rowmajor --reps 3
+run kl_wide4_64x8 $R/tools/quick_bench.py --batch 2048 --T 1000 --m 64 --k 8 --iters 200 --loss kullback-leibler --reps 3
 ls $O/*.csv $O/*.json $O/*.txt $O/*_filter_bench.log
