@@ -518,7 +518,7 @@ int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
     };
     auto enqueue = [&](int n, bool check, auto&& emit) {
       for (int i = 0; i < n; ++i) {
-        emit(big_hht_kernel<real>, dim3(B), dim3(256), (size_t)0, ba);
+        emit(big_hht_kernel<real>, dim3(B, KPb), dim3(256), (size_t)0, ba);
         with_kp([&](auto kp) {
           constexpr int KP = decltype(kp)::value;
           emit(big_pass_w_kernel<real, KP>, gslice, dim3(256), smem_w, ba);
@@ -674,7 +674,7 @@ int hipnmf_shard_wide(hipnmf_handle* h, const hipnmf_problem* p, int op, const r
   if (!async) HIP_TRY(hipEventRecord(h->ev0, st));
   int arc = HIPNMF_OK;
   if (op == 0) {
-    hipLaunchKernelGGL(big_hht_kernel<real>, dim3(B), dim3(256), 0, st, ba);
+    hipLaunchKernelGGL(big_hht_kernel<real>, dim3(B, KPb), dim3(256), 0, st, ba);
     with_kp([&](auto kp) {
       constexpr int KP = decltype(kp)::value;
       if (!arc) arc = hipnmf_allow_full_lds(h, reinterpret_cast<const void*>(big_pass_w_kernel<real, KP>));

@@ -68,25 +68,37 @@ __device__ __forceinline__ void big_load4(const real* __restrict__ row, int col,
   }
 }
 
-// H H^T, zero padded to KP x KP.  One workgroup per matrix; every entry summed over the channels in order by one thread.
+// H H^T, zero padded to KP x KP.  grid (B, KP): one workgroup per ROW of the result; the 256 threads split the channels into
+// 256 / KP contiguous segments per entry, each summed in order, the segments added in a fixed tree (the first version -- one
+// workgroup per matrix, a thread per entry over all channels -- took 0.24 ms of the 1.13 ms iteration at 512 x 32).
+// Kullback-Leibler: column 0 holds rowsum(H), the W update's denominator (_nmf.py:577-581); the rest stays 0.
 template <typename real>
 __global__ void __launch_bounds__(256) big_hht_kernel(BigArgs<real> a) {
-  const int b = blockIdx.x;
+  __shared__ real partial[256];
+  const int b = blockIdx.x, c = blockIdx.y, KP = a.KP;
   if (a.state && a.state[(long long)b * 8 + 3] != (real)0) return;
   const real* __restrict__ Hb = a.H + (long long)b * a.k * a.m;
-  real* __restrict__ out = a.HHt + (long long)b * a.KP * a.KP;
-  for (int idx = threadIdx.x; idx < a.KP * a.KP; idx += blockDim.x) {
-    const int c = idx / a.KP, c2 = idx % a.KP;
-    real s = (real)0;
-    if (a.kl) {  // column 0 holds rowsum(H), the W update's denominator (_nmf.py:577-581); the rest stays 0
-      if (c < a.k && c2 == 0)
-        for (int jj = 0; jj < a.m; ++jj) s += Hb[(long long)c * a.m + jj];
-    } else if (c < a.k && c2 < a.k) {
-      const real* __restrict__ h1 = Hb + (long long)c * a.m;
+  real* __restrict__ out = a.HHt + (long long)b * KP * KP + (long long)c * KP;
+  const int nseg = 256 / KP;  // 16 / 8 / 5 / 4 segments for KP = 16 / 32 / 48 / 64
+  const int c2 = threadIdx.x % KP, seg = threadIdx.x / KP;
+  real s = (real)0;
+  if (seg < nseg && c < a.k) {
+    const int len = (a.m + nseg - 1) / nseg, j0 = seg * len, j1 = (j0 + len < a.m) ? j0 + len : a.m;
+    const real* __restrict__ h1 = Hb + (long long)c * a.m;
+    if (a.kl) {
+      if (c2 == 0)
+        for (int jj = j0; jj < j1; ++jj) s += h1[jj];
+    } else if (c2 < a.k) {
       const real* __restrict__ h2 = Hb + (long long)c2 * a.m;
-      for (int jj = 0; jj < a.m; ++jj) s = fma_(h1[jj], h2[jj], s);
+      for (int jj = j0; jj < j1; ++jj) s = fma_(h1[jj], h2[jj], s);
     }
-    out[idx] = s;
+  }
+  partial[threadIdx.x] = s;
+  __syncthreads();
+  if ((int)threadIdx.x < KP) {
+    real tot = partial[threadIdx.x];
+    for (int g = 1; g < nseg; ++g) tot += partial[g * KP + threadIdx.x];  // (segments in order)
+    out[threadIdx.x] = tot;
   }
 }
 
