@@ -311,6 +311,14 @@ def compute_roofline(kernel, kernel_ms, units_per_launch, T, m, k, traffic=None,
         mem["measured_stream_ceiling_source"] = ("tools/ubench/wide_stream.hip, profiles/r03_ubench_wide_stream.log: the same bytes "
                                                  "per row (X read non-temporal, W read and written back) with no arithmetic, at the "
                                                  "64-channel k = 8 mix; a constant, not re-measured in this run")
+        if fl / (FP32_PEAK_TFLOPS * 1e12) > by / (HBM_PEAK_GBS * 1e9):
+            # beyond the ridge (157.3 TFLOP/s / 8 TB/s = 19.7 flop per algorithmic byte; e.g. 512 channels x 32 components: 30):
+            # the dense fp32 matrix peak is the roof, the stream is reported beside it
+            mem["frac_of_hbm_peak"] = gbs / HBM_PEAK_GBS
+            return {"bound": "mfma", "achieved": tf, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_PEAK_TFLOPS,
+                    "traffic": traffic, "kernel": kernel, "kernel_ms_avg": kernel_ms, "flops_per_unit": fl,
+                    "algorithmic_bytes_per_unit": by, "units_per_launch": units_per_launch,
+                    "matrix_pipe": _matrix_pipe(kernel, tf, m, k), "memory": mem}
         return {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                 "traffic": traffic, "kernel": kernel, "kernel_ms_avg": kernel_ms, "algorithmic_bytes_per_unit": by,
                 "units_per_launch": units_per_launch,
