@@ -127,6 +127,12 @@ int envelope_impl(hipnmf_handle* h, const hipnmf_envelope_params* p, const real*
       chunk_nt = 512;
       chunk_c = 41;
     }
+    // double, 10 497 .. 20 992 positions: the same eight-wave instance with the whole CU's LDS for one series (20 000 doubles +
+    // a window of up to ~280 samples fit 160 KB; anything more falls through to emg_wg_kernel by the LDS check below)
+    if (sizeof(real) == 8 && chunk_c == 0 && chunk_wide_ok && chunk_span <= 512LL * 41) {
+      chunk_nt = 512;
+      chunk_c = 41;
+    }
   }
   const int chunk_nact = chunk_c ? (int)((chunk_span + chunk_c - 1) / chunk_c) : 0;  // (<= chunk_nt)
   const size_t chunk_lds = ((sizeof(real) * ((size_t)p->window + (size_t)chunk_nact * chunk_c) + 15) & ~(size_t)15) + CHUNK_RED * sizeof(double);
@@ -201,9 +207,7 @@ int envelope_impl(hipnmf_handle* h, const hipnmf_envelope_params* p, const real*
           }
       }
     } else {
-      if constexpr (sizeof(real) == 4) {
-        switch (chunk_c) { HIPNMF_CHUNK_CASE(41, 512) }
-      }
+      switch (chunk_c) { HIPNMF_CHUNK_CASE(41, 512) }
     }
 #undef HIPNMF_CHUNK_CASE
     if (rcc) return rcc;

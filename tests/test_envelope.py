@@ -182,7 +182,10 @@ _CHUNK_CASES = [
     (10000, 2, 200, None, True, True, np.float64, "emg_chunk_kernel<double,41,256>"),  # float64 at the top of its range (one workgroup per CU)
     (10000, 2, 200, 500, True, True, np.float64, "emg_wave_kernel"),               # ... time-normalised: left to the wave kernel
     (9000, 2, 200, 500, True, True, np.float64, "emg_chunk_kernel<double,41,256>"),
-    (10497, 2, 1, None, True, True, np.float64, "emg_wg_kernel"),                  # one position more than 256 x 41
+    (10497, 2, 1, None, True, True, np.float64, "emg_chunk_kernel<double,41,512>"),  # one position more than 256 x 41: eight waves
+    (20000, 2, 200, None, True, True, np.float64, "emg_chunk_kernel<double,41,512>"),  # the benchmark shape in float64: the CU's whole LDS
+    (20000, 2, 200, 300, True, True, np.float64, "emg_wave_kernel"),               # ... time-normalised: one workgroup per CU does not pay
+    (20480, 1, 255, None, True, False, np.float64, "emg_wg_kernel"),               # 167 KB: does not fit
     (3000, 2, 100, 9001, True, True, np.float32, "emg_chunk_kernel<float,13,256>"),    # up-sampling
     (18560, 2, 257, None, True, True, np.float32, "emg_chunk_kernel<float,73,256>"),   # 18 688 positions: the longest four-wave series
     (18561, 2, 257, 700, True, True, np.float32, "emg_chunk_kernel<float,41,512>"),    # one more: eight waves

@@ -1,8 +1,15 @@
 #!/bin/bash
-# Long randomised soak of all four cross-checks (run on the GPU box: gpurun -- bash tools/fuzz_soak.sh); every driver under a timeout.
-cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/soak
-for s in $(seq 500 517); do timeout 280 python -u tests/fuzz_gpu.py --cases 400 --seed $s --wide-frac 0.4 --verbose > gpurun_out/soak/nmf$s.log 2>&1; echo "nmf $s rc=$? $(grep -v '^RUN' gpurun_out/soak/nmf$s.log | grep 'fuzz:\|MISMATCH\|ERROR' | tail -2)"; done
-for s in $(seq 500 509); do timeout 280 python -u tests/fuzz_envelope_gpu.py --cases 300 --seed $s > gpurun_out/soak/env$s.log 2>&1; echo "env $s rc=$? $(grep 'cases\|MISMATCH\|ERROR' gpurun_out/soak/env$s.log | tail -2)"; done
-for s in $(seq 500 505); do timeout 280 python -u tests/fuzz_sosfilt_gpu.py --cases 250 --seed $s > gpurun_out/soak/sos$s.log 2>&1; echo "sos $s rc=$? $(grep 'cases\|MISMATCH\|ERROR' gpurun_out/soak/sos$s.log | tail -2)"; done
-for s in $(seq 500 505); do timeout 280 python -u tests/fuzz_shard_gpu.py --cases 150 --seed $s > gpurun_out/soak/shard$s.log 2>&1; echo "shard $s rc=$? $(grep 'cases\|MISMATCH\|ERROR' gpurun_out/soak/shard$s.log | tail -2)"; done
+# the four randomised cross-checks against the oracle at soak sizes (gpurun -- 'bash tools/fuzz_soak.sh r04')
+tag=${1:-r04}
+R=${GRAFT_REPO_ROOT:-.}
+O=$R/gpurun_out/fuzz_$tag
+mkdir -p $O
+cd $R
+{
+  echo "library: $(sha256sum muscle_synergies_amd/lib/libhip_nmf.so | cut -c1-16)"
+  for seed in 101 102 103 104; do echo -n "fuzz_gpu seed $seed: "; python3 tests/fuzz_gpu.py --cases 500 --seed $seed 2>&1 | tail -1; done
+  for seed in 201 202 203; do echo -n "fuzz_envelope_gpu seed $seed: "; python3 tests/fuzz_envelope_gpu.py --cases 600 --seed $seed 2>&1 | tail -1; done
+  for seed in 301 302 303; do echo -n "fuzz_sosfilt_gpu scan seed $seed: "; python3 tests/fuzz_sosfilt_gpu.py --cases 500 --seed $seed --mode scan 2>&1 | tail -1; done
+  for seed in 501 502; do echo -n "fuzz_shard_gpu seed $seed: "; python3 tests/fuzz_shard_gpu.py --cases 200 --seed $seed 2>&1 | tail -1; done
+  for seed in 401 402; do echo -n "fuzz_sosfilt_gpu exact seed $seed: "; python3 tests/fuzz_sosfilt_gpu.py --cases 400 --seed $seed 2>&1 | tail -1; done
+} | tee $O/${tag}_fuzz_soak_summary.log
