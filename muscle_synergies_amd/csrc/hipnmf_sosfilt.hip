@@ -103,7 +103,18 @@ int launch_chunk_scan(hipnmf_handle* h, const SosArgs& a, int ns, int C, size_t 
   };
   if (C == 17) return go(sosfilt_chunk_kernel<real, NSP, 17>);
   if (C == 41) return go(sosfilt_chunk_kernel<real, NSP, 41>);
-  if constexpr (sizeof(real) == 4) return go(sosfilt_chunk_kernel<real, NSP, 79>);
+  if constexpr (NSP <= 4) {  // intermediate lengths (idle threads cost as much as busy ones); filters of more than four sections keep three
+    if (C == 25) return go(sosfilt_chunk_kernel<real, NSP, 25>);
+    if (C == 33) return go(sosfilt_chunk_kernel<real, NSP, 33>);
+    if constexpr (sizeof(real) == 4) {
+      if (C == 49) return go(sosfilt_chunk_kernel<real, NSP, 49>);
+      if (C == 57) return go(sosfilt_chunk_kernel<real, NSP, 57>);
+      if (C == 65) return go(sosfilt_chunk_kernel<real, NSP, 65>);
+    }
+  }
+  if constexpr (sizeof(real) == 4) {
+    if (C == 79) return go(sosfilt_chunk_kernel<real, NSP, 79>);
+  }
   return HIPNMF_ERR_UNSUPPORTED;
 }
 // LDS of sosfilt_chunk_kernel without the 8 doubles behind it: the series + a dump slot, or the overlay, whichever is larger
@@ -197,7 +208,18 @@ int sosfilt_impl(hipnmf_handle* h, const hipnmf_sosfilt_params* p, const double*
   const int nsp_c = p->n_sections == 1 ? 1 : p->n_sections == 2 ? 2 : p->n_sections <= 4 ? 4 : 8;
   int chunk_c = 0;
   if (p->mode == HIPNMF_SOSFILT_SCAN && chunk_scan_ok)
-    chunk_c = L <= 256 * 17 ? 17 : L <= 256 * 41 ? 41 : (sizeof(real) == 4 && L <= 256 * 79) ? 79 : 0;
+  {
+    const bool fine = nsp_c <= 4;  // (the intermediate lengths are compiled for up to four sections)
+    const int sizes[] = {17, 25, 33, 41, 49, 57, 65, 79};
+    for (int c : sizes) {
+      if (!fine && c != 17 && c != 41 && c != 79) continue;
+      if (sizeof(real) == 8 && c > 41) break;
+      if (L <= 256LL * c) {
+        chunk_c = c;
+        break;
+      }
+    }
+  }
   const size_t chunk_region = chunk_c ? chunk_scan_region((size_t)L, chunk_c, nsp_c, sizeof(real)) : 0;
   const bool use_chunk_scan = chunk_c > 0 && chunk_region + 64 <= (size_t)h->lds_per_block;
   const size_t o_ws = (zero_lag && !scan_fits && !use_chunk_scan) ? carve(use_v3 ? ws_v3 : ws_v2) : 0;

@@ -273,14 +273,16 @@ def test_gpu_scan_mode_kernel_choice_and_shapes_of_the_second_version(g8):
     h = _lib.get_handle(0)
     for T, dtype, padlen, want in ((1001, np.float64, None, "sosfilt_chunk_kernel<double,2,17>"),
                                    (4352 - 30, np.float64, None, "sosfilt_chunk_kernel<double,2,17>"),
-                                   (4352 - 29, np.float64, None, "sosfilt_chunk_kernel<double,2,41>"),
+                                   (4352 - 29, np.float64, None, "sosfilt_chunk_kernel<double,2,25>"),
                                    (10496 - 30, np.float32, None, "sosfilt_chunk_kernel<float,2,41>"),
-                                   (10496 - 29, np.float32, None, "sosfilt_chunk_kernel<float,2,79>"),
+                                   (10496 - 29, np.float32, None, "sosfilt_chunk_kernel<float,2,49>"),
                                    (10496 - 28, np.float64, None, "sosfilt_scan_kernel<double,2,80>"),
                                    (10496 - 29, np.float64, None, "sosfiltx"),   # odd length: the first version does not take it
                                    (20224 - 30, np.float32, None, "sosfilt_chunk_kernel<float,2,79>"),
                                    (20224 - 28, np.float32, None, "sosfilt_scan_kernel<float,2,80>"),
-                                   (3001, np.float32, 700, "sosfilt_chunk_kernel<float,2,41>"),
+                                   (3001, np.float32, 700, "sosfilt_chunk_kernel<float,2,25>"),
+                                   (16640 - 30, np.float32, None, "sosfilt_chunk_kernel<float,2,65>"),
+                                   (8448 - 29, np.float64, None, "sosfilt_chunk_kernel<double,2,41>"),
                                    (333, np.float64, 300, "sosfilt_chunk_kernel<double,2,17>")):
         raw = raw_emg(70 + T % 13, T, 3).astype(dtype)
         x = np.ascontiguousarray(raw.T)[:, :T].T if T % 2 else raw  # channel-major rows of odd length: unaligned
