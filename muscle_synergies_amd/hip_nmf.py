@@ -97,7 +97,7 @@ class HipNMF:
 
     # -- validation --------------------------------------------------------------------------------
     MAX_FEATURES = 512   # widest shape compiled into libhip_nmf.so (nmf_big.hpp: the general-shape kernels beyond the 128 x 32 of
-    MAX_COMPONENTS = 64  # nmf_wide.hpp; HIPNMF_ERR_UNSUPPORTED beyond, and for the Kullback-Leibler loss beyond 128 x 32)
+    MAX_COMPONENTS = 64  # nmf_wide.hpp, both losses); HIPNMF_ERR_UNSUPPORTED beyond
 
     @staticmethod
     def supports(solver="cd", beta_loss="frobenius", n_features=None, n_components=None, **_ignored) -> bool:
