@@ -21,7 +21,7 @@
 // differs from the other kernels', results agree to ~1e-13 relative (fp64) / an ulp of float (fp32).
 #pragma once
 #include "envelope_kernels.hpp"
-#include "nmf_kernels.hpp"  // rsrc_t, make_rsrc, buf_load, buf_store
+#include "nmf_wide.hpp"  // rsrc_t, make_rsrc, buf_load, buf_store (nmf_kernels.hpp), wide_lds_write
 
 namespace hipnmf {
 
@@ -52,7 +52,18 @@ __device__ __forceinline__ double chunk_centred(real x, double mean, bool inside
   return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | (unsigned)u);
 }
 
-template <typename real, int C, int NT>
+// 16 bytes to / from a buffer resource (VEC instances: rows and lengths that are whole 16-byte pieces)
+template <typename real>
+__device__ __forceinline__ void chunk_store_vec(rsrc_t r, unsigned voff, unsigned soff, const real (&v)[16 / sizeof(real)]) {
+  using u32x4 = unsigned int __attribute__((ext_vector_type(4)));
+  u32x4 u;
+  __builtin_memcpy(&u, &v, 16);
+  __builtin_amdgcn_raw_buffer_store_b128(u, r, voff, soff, (HIPNMF_CHUNK_ST_AUX));
+}
+
+// VEC: the series (and, full length, the output) are moved in 16-byte pieces -- a quarter of the memory instructions; the host
+// selects it when every row is 16-byte aligned and the lengths are whole pieces (the front pad is rounded up to a piece then).
+template <typename real, int C, int NT, bool VEC = false>
 __global__ void __launch_bounds__(NT, NT / 128) emg_chunk_kernel(EnvArgs a, int nact /* threads that own a chunk */) {
   static_assert(C % 2 == 1, "odd chunk length: conflict-free LDS stride");
   static_assert(NT == 256 || NT == 512, "four or eight waves");
@@ -66,9 +77,12 @@ __global__ void __launch_bounds__(NT, NT / 128) emg_chunk_kernel(EnvArgs a, int 
   const int n_out = a.n_out > 0 ? a.n_out : T;
   const bool resample = a.n_out > 0 && a.n_out != T;
   real* __restrict__ o = static_cast<real*>(a.out) + cidx * (long long)n_out;
+  constexpr int V = 16 / (int)sizeof(real);
   const int NS = nact * C;                            // positions p in [0, NS): p < T samples, then zeros
-  real* __restrict__ xs = reinterpret_cast<real*>(env_smem) + W;  // xs[p], p in [-W, NS)
-  double* __restrict__ red = reinterpret_cast<double*>(env_smem + (((size_t)(W + NS) * sizeof(real) + 15) & ~(size_t)15));  // [3 NW]
+  const int WP = VEC ? (W + V - 1) / V * V : W;       // front pad (VEC: whole pieces, so that position 0 is 16-byte aligned)
+  const int NSA = VEC ? (NS + V - 1) / V * V : NS;
+  real* __restrict__ xs = reinterpret_cast<real*>(env_smem) + WP;  // xs[p], p in [-WP, NSA)
+  double* __restrict__ red = reinterpret_cast<double*>(env_smem + (((size_t)(WP + NSA) * sizeof(real) + 15) & ~(size_t)15));  // [3 NW]
   const rsrc_t xr = make_rsrc(x, (unsigned)((long long)T * (long long)sizeof(real)));
   const rsrc_t orr = make_rsrc(o, (unsigned)((long long)n_out * (long long)sizeof(real)));
 
@@ -83,20 +97,35 @@ __global__ void __launch_bounds__(NT, NT / 128) emg_chunk_kernel(EnvArgs a, int 
   // ---- 1. HBM -> registers -> LDS; mean --------------------------------------------------------------------------------------
   double mean = 0.0;
   {
-    real v[C];
-    const unsigned voff = (unsigned)t * (unsigned)sizeof(real);
-#pragma unroll
-    for (int k = 0; k < C; ++k) {
-      real r1[1];
-      buf_load<real, 1, (HIPNMF_CHUNK_LD_AUX)>(xr, voff, (unsigned)(k * CHUNK_THREADS) * (unsigned)sizeof(real), r1);
-      v[k] = r1[0];
-    }
     double acc = 0.0;
+    if constexpr (VEC) {
+      constexpr int CV = (C + V - 1) / V;  // pieces per thread: piece t + NT k4 holds positions V (t + NT k4) .. + V - 1
+      real v[CV][V];
 #pragma unroll
-    for (int k = 0; k < C; ++k) {
-      const int p = t + k * CHUNK_THREADS;
-      xs[p < NS ? p : -1] = v[k];  // (xs[-1]: the front pad, W >= 1 -- a branch per store would serialise them)
-      acc += (double)v[k];         // (zeros past the end of the series)
+      for (int k4 = 0; k4 < CV; ++k4)
+        buf_load<real, V, (HIPNMF_CHUNK_LD_AUX)>(xr, (unsigned)t * 16u, (unsigned)(k4 * CHUNK_THREADS) * 16u, v[k4]);
+#pragma unroll
+      for (int k4 = 0; k4 < CV; ++k4) {
+        const int p = (t + k4 * CHUNK_THREADS) * V;
+        wide_lds_write<real, V>(xs + (p < NSA ? p : -V), v[k4]);  // (the front pad takes what lies behind the chunks)
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc += (double)v[k4][e];  // (zeros past the end of the series)
+      }
+    } else {
+      real v[C];
+      const unsigned voff = (unsigned)t * (unsigned)sizeof(real);
+#pragma unroll
+      for (int k = 0; k < C; ++k) {
+        real r1[1];
+        buf_load<real, 1, (HIPNMF_CHUNK_LD_AUX)>(xr, voff, (unsigned)(k * CHUNK_THREADS) * (unsigned)sizeof(real), r1);
+        v[k] = r1[0];
+      }
+#pragma unroll
+      for (int k = 0; k < C; ++k) {
+        const int p = t + k * CHUNK_THREADS;
+        xs[p < NS ? p : -1] = v[k];  // (xs[-1]: the front pad, W >= 1 -- a branch per store would serialise them)
+        acc += (double)v[k];         // (zeros past the end of the series)
+      }
     }
     if (a.zero_center) {
 #pragma unroll
@@ -186,14 +215,33 @@ __global__ void __launch_bounds__(NT, NT / 128) emg_chunk_kernel(EnvArgs a, int 
     const int kmax = (T + CHUNK_THREADS - 1) / CHUNK_THREADS;
     const unsigned voff = (unsigned)t * (unsigned)sizeof(real);
     auto copy_out = [&](auto scale) __attribute__((always_inline)) {
-      for (int k0 = 0; k0 < kmax; k0 += CB) {
-        real y[CB];
-        const real* __restrict__ src = yo + t + k0 * CHUNK_THREADS;  // (reads past NS: LDS reads cannot fault, the stores are dropped)
+      if constexpr (VEC) {
+        const int kmax4 = (T / V + CHUNK_THREADS - 1) / CHUNK_THREADS;
+        constexpr int CB4 = CB / V > 0 ? CB / V : 1;
+        for (int k0 = 0; k0 < kmax4; k0 += CB4) {
+          real y[CB4][V];
+          const real* __restrict__ src = yo + (t + k0 * CHUNK_THREADS) * V;
 #pragma unroll
-        for (int u = 0; u < CB; ++u) y[u] = src[u * CHUNK_THREADS];
+          for (int u = 0; u < CB4; ++u)
 #pragma unroll
-        for (int u = 0; u < CB; ++u)
-          chunk_store<real>(orr, voff, (unsigned)((k0 + u) * CHUNK_THREADS) * (unsigned)sizeof(real), scale(y[u]));
+            for (int e = 0; e < V; ++e) y[u][e] = src[u * CHUNK_THREADS * V + e];
+#pragma unroll
+          for (int u = 0; u < CB4; ++u) {
+#pragma unroll
+            for (int e = 0; e < V; ++e) y[u][e] = scale(y[u][e]);
+            chunk_store_vec<real>(orr, (unsigned)t * 16u, (unsigned)((k0 + u) * CHUNK_THREADS) * 16u, y[u]);
+          }
+        }
+      } else {
+        for (int k0 = 0; k0 < kmax; k0 += CB) {
+          real y[CB];
+          const real* __restrict__ src = yo + t + k0 * CHUNK_THREADS;  // (reads past NS: LDS reads cannot fault, the stores are dropped)
+#pragma unroll
+          for (int u = 0; u < CB; ++u) y[u] = src[u * CHUNK_THREADS];
+#pragma unroll
+          for (int u = 0; u < CB; ++u)
+            chunk_store<real>(orr, voff, (unsigned)((k0 + u) * CHUNK_THREADS) * (unsigned)sizeof(real), scale(y[u]));
+        }
       }
     };
     bool done = false;

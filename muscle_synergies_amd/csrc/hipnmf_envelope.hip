@@ -135,7 +135,19 @@ int envelope_impl(hipnmf_handle* h, const hipnmf_envelope_params* p, const real*
     }
   }
   const int chunk_nact = chunk_c ? (int)((chunk_span + chunk_c - 1) / chunk_c) : 0;  // (<= chunk_nt)
-  const size_t chunk_lds = ((sizeof(real) * ((size_t)p->window + (size_t)chunk_nact * chunk_c) + 15) & ~(size_t)15) + CHUNK_RED * sizeof(double);
+  // 16-byte pieces (a quarter of the memory instructions) when every row of the canonical layout and of the output is aligned and
+  // a whole number of pieces; HIPNMF_ENV_CHUNK_VEC=0 keeps the dword form
+  static const bool chunk_vec_ok = [] {
+    const char* e = getenv("HIPNMF_ENV_CHUNK_VEC");
+    return !(e && atoi(e) == 0);
+  }();
+  constexpr int CV_ = 16 / (int)sizeof(real);
+  const bool chunk_full = p->n_out == 0 || p->n_out == T;
+  const bool chunk_vec = chunk_vec_ok && chunk_c > 0 && T % CV_ == 0 && (reinterpret_cast<uintptr_t>(out) % 16) == 0 &&
+                         (!inplace || ((reinterpret_cast<uintptr_t>(raw) % 16) == 0 && p->ldx % CV_ == 0 && p->x_batch_stride % CV_ == 0));
+  const size_t chunk_pad = chunk_vec ? ((size_t)p->window + CV_ - 1) / CV_ * CV_ : (size_t)p->window;
+  const size_t chunk_ns = chunk_vec ? ((size_t)chunk_nact * chunk_c + CV_ - 1) / CV_ * CV_ : (size_t)chunk_nact * chunk_c;
+  const size_t chunk_lds = ((sizeof(real) * (chunk_pad + chunk_ns) + 15) & ~(size_t)15) + CHUNK_RED * sizeof(double);
   // time-normalised output: only while two workgroups share a CU (measured: one alone loses to emg_wave_kernel, which overlaps
   // its single read stream across 16 waves per CU; the full-length output wins either way, its write stream is what counts)
   const bool chunk = chunk_c > 0 && chunk_lds <= (size_t)h->lds_per_block &&
@@ -192,10 +204,10 @@ int envelope_impl(hipnmf_handle* h, const hipnmf_envelope_params* p, const real*
     };
     int rcc = HIPNMF_ERR_UNSUPPORTED;
     char name[64];
-    snprintf(name, sizeof(name), "emg_chunk_kernel<%s,%d,%d>", sizeof(real) == 4 ? "float" : "double", chunk_c, chunk_nt);
+    snprintf(name, sizeof(name), "emg_chunk_kernel<%s,%d,%d>%s", sizeof(real) == 4 ? "float" : "double", chunk_c, chunk_nt, chunk_vec ? "[vec]" : "");
 #define HIPNMF_CHUNK_CASE(C_, NT_) \
   case C_:                         \
-    rcc = launch_chunk(emg_chunk_kernel<real, C_, NT_>, name); \
+    rcc = chunk_vec ? launch_chunk(emg_chunk_kernel<real, C_, NT_, true>, name) : launch_chunk(emg_chunk_kernel<real, C_, NT_, false>, name); \
     break;
     if (chunk_nt == 256) {
       switch (chunk_c) {
