@@ -201,7 +201,7 @@ __global__ void __launch_bounds__(256) big_pass_w_kernel(BigArgs<real> a) {
 #pragma unroll
                 for (int s = 0; s < 4; ++s) rec = M::mma(sH[(16 * kb + 4 * g + s) * SH + (ch0 + 16 * q - cb0) + ar], w[kb][s], rec);
 #pragma unroll
-              for (int r = 0; r < 4; ++r) x[q][r] = big_quot(x[q][r], rec[r] < eps_val<real>() ? eps_val<real>() : rec[r]);
+              for (int r = 0; r < 4; ++r) x[q][r] = big_quot(x[q][r], kl_floor(rec[r]));
             }
 #pragma unroll
             for (int kb = 0; kb < NKB; ++kb) {
@@ -339,7 +339,7 @@ __global__ void __launch_bounds__(256) big_records_kernel(BigArgs<real> a) {
           for (int s = 0; s < 4; ++s) rec = M::mma(wa[s], sHb[(16 * kb + 4 * g + s) * SHB + 16 * cb + j], rec);
         }
 #pragma unroll
-        for (int s = 0; s < 4; ++s) bv[cb][s] = big_quot(bv[cb][s], rec[s] < eps_val<real>() ? eps_val<real>() : rec[s]);
+        for (int s = 0; s < 4; ++s) bv[cb][s] = big_quot(bv[cb][s], kl_floor(rec[s]));
       }
     }
 #pragma unroll

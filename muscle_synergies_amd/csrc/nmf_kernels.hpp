@@ -64,6 +64,11 @@ __device__ __forceinline__ float fast_div(float n, float d) {
 // the bare reciprocal (1 ulp) times x, without the correction step of fast_div -- the quotient feeds sums of 16 / of all rows
 // and the tolerance of the path is 1e-5 (north_star); wh >= EPSILON, so the reciprocal cannot overflow.  -DHIPNMF_KL_EXACT_Q
 // restores fast_div.
+// max(wh, EPSILON) of the Kullback-Leibler quotients (_nmf.py:574-575: WH_safe_X[WH_safe_X < EPSILON] = EPSILON) as ONE v_max
+// (the comparison + select the ternary compiles to is two instructions, 32 times per row).  A NaN in wh would come out as
+// EPSILON here instead of NaN -- it still reaches the factors through W and H themselves, which the update multiplies.
+__device__ __forceinline__ float kl_floor(float wh) { return __builtin_fmaxf(wh, eps_val<float>()); }
+__device__ __forceinline__ double kl_floor(double wh) { return __builtin_fmax(wh, eps_val<double>()); }
 __device__ __forceinline__ float kl_quot(float x, float wh) {
 #ifdef HIPNMF_KL_EXACT_Q
   return fast_div(x, wh);
@@ -584,7 +589,7 @@ __device__ __forceinline__ void update_tile_kl(RowTile<real, G, CH, K>& t, const
       real rec = wr[0] * h[0][cc];
 #pragma unroll
       for (int c = 1; c < K; ++c) rec = fma_(wr[c], h[c][cc], rec);
-      rec = rec < eps_val<real>() ? eps_val<real>() : rec;
+      rec = kl_floor(rec);
       if constexpr (sizeof(real) == 4)
         q[cc][r] = kl_quot(t.x[cc][r], rec);
       else
@@ -627,7 +632,7 @@ __device__ __forceinline__ void update_tile_kl(RowTile<real, G, CH, K>& t, const
         real rec = wr[0] * h[0][cc];
 #pragma unroll
         for (int c = 1; c < K; ++c) rec = fma_(wr[c], h[c][cc], rec);
-        rec = rec < eps_val<real>() ? eps_val<real>() : rec;
+        rec = kl_floor(rec);
         real qq;
         if constexpr (sizeof(real) == 4)
           qq = kl_quot(t.x[cc][r], rec);

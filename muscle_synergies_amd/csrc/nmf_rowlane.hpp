@@ -264,7 +264,7 @@ __device__ __forceinline__ void rl_update_kl(const float (&x)[16], float (&w)[K]
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
     const float r = wh[j >> 2][j & 3];
-    q[j] = kl_quot(x[j], r < eps_val<float>() ? eps_val<float>() : r);
+    q[j] = kl_quot(x[j], kl_floor(r));
   }
   // numerator Q H^T: the X H^T form of rl_update with Q in the place of X
   f4 n0a = {0.f, 0.f, 0.f, 0.f}, n0b = n0a, n1a = n0a, n1b = n0a;
@@ -296,7 +296,7 @@ __device__ __forceinline__ void rl_update_kl(const float (&x)[16], float (&w)[K]
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       const float r = wh[j >> 2][j & 3];
-      q[j] = kl_quot(x[j], r < eps_val<float>() ? eps_val<float>() : r);
+      q[j] = kl_quot(x[j], kl_floor(r));
     }
 #pragma unroll
     for (int c = 0; c < K; ++c) {

@@ -345,7 +345,7 @@ fit_wide_kernel(WideArgs<real> a) {
     return rec;
   };
   auto kl_quot = [&](real x, real wh) __attribute__((always_inline)) -> real {  // X / max(WH, EPSILON) (_nmf.py:574-575)
-    const real d = wh < eps_val<real>() ? eps_val<real>() : wh;
+    const real d = kl_floor(wh);
     if constexpr (sizeof(real) == 4)
       return hipnmf::kl_quot(x, d);  // (nmf_kernels.hpp: the bare reciprocal)
     else

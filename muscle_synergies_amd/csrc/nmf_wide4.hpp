@@ -274,7 +274,7 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
     return rec;
   };
   auto kl_quot4 = [&](float x, float wh) __attribute__((always_inline)) -> float {  // X / max(WH, EPSILON) (_nmf.py:574-575)
-    return kl_quot(x, wh < eps_val<float>() ? eps_val<float>() : wh);  // (nmf_kernels.hpp: the bare reciprocal)
+    return kl_quot(x, kl_floor(wh));  // (nmf_kernels.hpp: one v_max, the bare reciprocal)
   };
 
   w4f4 accA[NH][KQ], accB[KQ][KQ];
