@@ -511,8 +511,10 @@ __device__ __forceinline__ void update_tile(RowTile<real, G, CH, K>& t, const Ma
     real d = t.w[0] * hht[0][c];
 #pragma unroll
     for (int c2 = 1; c2 < K; ++c2) d = fma_(t.w[c2], hht[c2][c], d);
-    if (l1w > (real)0) d = d + l1w;
-    if (l2w > (real)0) d = d + l2w * t.w[c];
+    // regularisation (_nmf.py:616-619 adds the terms only when positive): added unconditionally -- the coefficients are >= 0
+    // (validated by the host) and d + 0, d + 0 * w leave d as it is, while the conditional form costs a select per term and row
+    d = d + l1w;
+    d = d + l2w * t.w[c];
     den[c] = (d == (real)0) ? eps_val<real>() : d;
     num[c] = pn[0][c];
   }
@@ -611,8 +613,10 @@ __device__ __forceinline__ void update_tile_kl(RowTile<real, G, CH, K>& t, const
 #pragma unroll
   for (int c = 0; c < K; ++c) {
     real d = hht[0][c];
-    if (l1w > (real)0) d = d + l1w;
-    if (l2w > (real)0) d = d + l2w * t.w[c];
+    // regularisation (_nmf.py:616-619 adds the terms only when positive): added unconditionally -- the coefficients are >= 0
+    // (validated by the host) and d + 0, d + 0 * w leave d as it is, while the conditional form costs a select per term and row
+    d = d + l1w;
+    d = d + l2w * t.w[c];
     den[c] = (d == (real)0) ? eps_val<real>() : d;
     num[c] = pn[0][c];
   }
