@@ -88,6 +88,8 @@ int hipnmf_create(int device, hipnmf_handle** out);       /* own stream + worksp
 int hipnmf_destroy(hipnmf_handle* h);
 #define HIPNMF_STREAM_NULL ((void*)1)                    /* the device's default (null) HIP stream    */
 int hipnmf_set_stream(hipnmf_handle* h, void* hip_stream);/* NULL restores the handle's own stream     */
+/* upper-bound estimate of the device workspace a fit of *p makes the handle allocate (informational: the library sizes and
+ * grows its workspace itself) */
 size_t hipnmf_workspace_bytes(const hipnmf_problem* p, int elem_size /* 4 or 8 */);
 /* Device time (HIP events on the handle's stream) of the solver kernels of the last compute call. */
 int hipnmf_last_kernel_ms(hipnmf_handle* h, float* ms);

@@ -1403,6 +1403,13 @@ size_t hipnmf_workspace_bytes(const hipnmf_problem* p, int elem_size) {
   const int m_pad = p->n_features <= 8 ? 8 : (p->n_features <= 16 ? 16 : p->n_features);  // row-major copies pad the rows
   size_t bytes = (size_t)elem_size * (size_t)p->batch * (size_t)(m_pad + p->n_components) * (size_t)ld;
   bytes += (size_t)elem_size * (size_t)p->batch * 4096 * 2;  // slice partials upper bound
+  if (p->n_features > HIPNMF_NARROW_MAX_FEATURES || p->n_components > HIPNMF_NARROW_MAX_COMPONENTS) {
+    // wide / general shapes: row-major copies with the components padded to 16, and when the fit is row-sliced (at most
+    // max(batch, 2 x 256 CUs) slices in all) one [W^T X | W^T W] record and three column sums per slice, H H^T per matrix
+    const size_t KP = (size_t)round_up(p->n_components, 16), MP = (size_t)round_up(p->n_features, 16);
+    const size_t slices = std::max<size_t>((size_t)p->batch, 512);
+    bytes = (size_t)elem_size * ((size_t)p->batch * (MP + KP) * (size_t)ld + slices * (KP * MP + KP * KP + 3 * MP) + (size_t)p->batch * KP * KP + 4096);
+  }
   return bytes;
 }
 
