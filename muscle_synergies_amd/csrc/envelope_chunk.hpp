@@ -64,9 +64,9 @@ __device__ __forceinline__ void chunk_store_vec(rsrc_t r, unsigned voff, unsigne
 // VEC: the series (and, full length, the output) are moved in 16-byte pieces -- a quarter of the memory instructions; the host
 // selects it when every row is 16-byte aligned and the lengths are whole pieces (the front pad is rounded up to a piece then).
 template <typename real, int C, int NT, bool VEC = false>
-__global__ void __launch_bounds__(NT, NT / 128) emg_chunk_kernel(EnvArgs a, int nact /* threads that own a chunk */) {
+__global__ void __launch_bounds__(NT, (NT >= 256 ? NT / 128 : 4)) emg_chunk_kernel(EnvArgs a, int nact /* threads that own a chunk */) {
   static_assert(C % 2 == 1, "odd chunk length: conflict-free LDS stride");
-  static_assert(NT == 256 || NT == 512, "four or eight waves");
+  static_assert(NT == 64 || NT == 256 || NT == 512, "one (short series: no workgroup-wide step is left), four or eight waves");
   constexpr int CHUNK_THREADS = NT, NW = NT / 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char env_smem[];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -134,7 +134,8 @@ __global__ void __launch_bounds__(NT, NT / 128) emg_chunk_kernel(EnvArgs a, int 
     }
     __syncthreads();
     if (a.zero_center) {
-      double tot = (red[0] + red[1]) + (red[2] + red[3]);
+      double tot = red[0];
+      if constexpr (NW >= 4) tot = (red[0] + red[1]) + (red[2] + red[3]);
       if constexpr (NW == 8) tot += (red[4] + red[5]) + (red[6] + red[7]);
       mean = tot / (double)T;
     }

@@ -107,13 +107,17 @@ int envelope_impl(hipnmf_handle* h, const hipnmf_envelope_params* p, const real*
     const char* e = getenv("HIPNMF_ENV_CHUNK_MIN_T");
     return e ? atoll(e) : (long long)HIPNMF_ENV_CHUNK_MIN_T_DEFAULT;
   }();
+  static const long long chunk_min_t_one = [] {
+    const char* e = getenv("HIPNMF_ENV_CHUNK_MIN_T_ONE");
+    return e ? atoll(e) : 64LL;
+  }();
   const long long chunk_span = T + (p->window - 1) / 2;  // positions the window's leading edge visits
   int chunk_c = 0, chunk_nt = 256;
   static const bool chunk_wide_ok = [] {
     const char* e = getenv("HIPNMF_ENV_CHUNK_512");
     return !(e && atoi(e) == 0);
   }();
-  if (chunk_ok && p->window >= 1 && T >= 2 && T >= chunk_min_t) {
+  if (chunk_ok && p->window >= 1 && T >= 2 && (T >= chunk_min_t || (T + (p->window - 1) / 2 <= 64LL * 33 && T >= chunk_min_t_one))) {
     // the shortest compiled chunk that covers the span (idle threads cost as much as busy ones); double: up to 41 (LDS)
     constexpr int chunk_sizes[] = {9, 13, 17, 25, 33, 41, 49, 57, 65, 73, 81};
     for (int c : chunk_sizes)
@@ -127,6 +131,22 @@ int envelope_impl(hipnmf_handle* h, const hipnmf_envelope_params* p, const real*
       chunk_nt = 512;
       chunk_c = 41;
     }
+    // short series: ONE wave per series (no workgroup-wide step is left, 4 KB of LDS: many series per CU) with the shortest chunk
+    // that covers 64 of them; HIPNMF_ENV_CHUNK_64=0 keeps the four-wave instances / emg_wave_kernel
+    static const bool chunk_one_ok = [] {
+      const char* e = getenv("HIPNMF_ENV_CHUNK_64");
+      return !(e && atoi(e) == 0);
+    }();
+    if (chunk_one_ok && chunk_span <= 64LL * 33) {
+      constexpr int one_sizes[] = {9, 13, 17, 25, 33};
+      for (int c : one_sizes)
+        if (chunk_span <= 64LL * c) {
+          chunk_c = c;
+          chunk_nt = 64;
+          break;
+        }
+    }
+    if (chunk_nt != 64 && T < chunk_min_t) chunk_c = 0;  // (below the four-wave instances' range only the one-wave ones apply)
     // double, 10 497 .. 20 992 positions: the same eight-wave instance with the whole CU's LDS for one series (20 000 doubles +
     // a window of up to ~280 samples fit 160 KB; anything more falls through to emg_wg_kernel by the LDS check below)
     if (sizeof(real) == 8 && chunk_c == 0 && chunk_wide_ok && chunk_span <= 512LL * 41) {
@@ -217,6 +237,10 @@ int envelope_impl(hipnmf_handle* h, const hipnmf_envelope_params* p, const real*
           if constexpr (sizeof(real) == 4) {
             switch (chunk_c) { HIPNMF_CHUNK_CASE(49, 256) HIPNMF_CHUNK_CASE(57, 256) HIPNMF_CHUNK_CASE(65, 256) HIPNMF_CHUNK_CASE(73, 256) HIPNMF_CHUNK_CASE(81, 256) }
           }
+      }
+    } else if (chunk_nt == 64) {
+      switch (chunk_c) {
+        HIPNMF_CHUNK_CASE(9, 64) HIPNMF_CHUNK_CASE(13, 64) HIPNMF_CHUNK_CASE(17, 64) HIPNMF_CHUNK_CASE(25, 64) HIPNMF_CHUNK_CASE(33, 64)
       }
     } else {
       switch (chunk_c) { HIPNMF_CHUNK_CASE(41, 512) }

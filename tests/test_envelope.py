@@ -171,8 +171,13 @@ _CHUNK_CASES = [
     (20610, 2, 255, None, True, True, np.float32, "emg_wave_kernel"),              # one more: no instance
     (20000, 2, 1400, 300, True, True, np.float32, "emg_wave_kernel"),              # time-normalised, LDS for one workgroup only
     (20000, 2, 1400, None, True, True, np.float32, "emg_chunk_kernel<float,41,512>"),  # full length takes it all the same
-    (1280, 3, 37, None, True, True, np.float32, "emg_chunk_kernel<float,9,256>"),      # shortest series, smallest instance
-    (1279, 3, 37, None, True, True, np.float32, "emg_wave_kernel"),
+    (1280, 3, 37, None, True, True, np.float32, "emg_chunk_kernel<float,25,64>"),      # up to 64 x 33 positions: one wave per series
+    (2112 - 18, 3, 37, None, True, True, np.float32, "emg_chunk_kernel<float,33,64>"),  # the longest one-wave series
+    (2112 - 17, 3, 37, None, True, True, np.float32, "emg_chunk_kernel<float,9,256>"),  # one more: four waves, smallest instance
+    (64, 2, 5, None, True, True, np.float32, "emg_chunk_kernel<float,9,64>"),          # shortest series the kernel takes
+    (63, 2, 5, None, True, True, np.float32, "emg_wave_kernel"),
+    (300, 2, 1, 50, False, False, np.float64, "emg_chunk_kernel<double,9,64>"),        # window of one sample, time-normalised
+    (577, 3, 577, 1200, True, True, np.float64, "emg_chunk_kernel<double,17,64>"),     # window = series, up-sampling, one wave
     (2304 - 18, 2, 37, 100, False, True, np.float32, "emg_chunk_kernel<float,9,256>"),   # all 256 threads own a chunk
     (2304 - 17, 2, 37, 100, False, True, np.float32, "emg_chunk_kernel<float,13,256>"),
     (5000, 2, 3000, None, True, True, np.float64, "emg_chunk_kernel<double,33,256>"),  # window longer than half the series
