@@ -90,36 +90,48 @@ int launch_scan(hipnmf_handle* h, const SosArgs& a, int ns, int C_run, double* t
                                                                              : go(sosfilt_scan_kernel<real, NSP, SCAN_CMAX>);
 }
 
-// second version of the time-parallel mode (sosfilt_chunk_kernel): the whole extended series in LDS, chunk length C odd
+// second version of the time-parallel mode (sosfilt_chunk_kernel): the whole extended series in LDS, chunk length C odd; NT = 64:
+// one wave per series (short series)
 template <typename real, int NSP>
-int launch_chunk_scan(hipnmf_handle* h, const SosArgs& a, int ns, int C, size_t region, double* tab, hipStream_t st) {
+int launch_chunk_scan(hipnmf_handle* h, const SosArgs& a, int ns, int C, int NT, size_t region, double* tab, hipStream_t st) {
   hipLaunchKernelGGL((sos_scan_tables_kernel<NSP>), dim3(1), dim3(256), 0, st, a, ns, C, tab);
   const size_t smem = region + 8 * sizeof(double);
   auto go = [&](auto kern) -> int {
     if (smem > 48 * 1024)
       if (int rc = hipnmf_allow_full_lds(h, reinterpret_cast<const void*>(kern))) return rc;
-    hipLaunchKernelGGL(kern, dim3((unsigned)a.N), dim3(SCAN_THREADS), smem, st, a, (const double*)tab, ns, (int)region);
+    hipLaunchKernelGGL(kern, dim3((unsigned)a.N), dim3(NT), smem, st, a, (const double*)tab, ns, (int)region);
     return HIPNMF_OK;
   };
-  if (C == 17) return go(sosfilt_chunk_kernel<real, NSP, 17>);
-  if (C == 41) return go(sosfilt_chunk_kernel<real, NSP, 41>);
+  if (NT == 64) {
+    if constexpr (NSP <= 4) {
+      if (C == 5) return go(sosfilt_chunk_kernel<real, NSP, 5, 64>);
+      if (C == 9) return go(sosfilt_chunk_kernel<real, NSP, 9, 64>);
+      if (C == 17) return go(sosfilt_chunk_kernel<real, NSP, 17, 64>);
+      if (C == 25) return go(sosfilt_chunk_kernel<real, NSP, 25, 64>);
+      if (C == 33) return go(sosfilt_chunk_kernel<real, NSP, 33, 64>);
+      if (C == 41) return go(sosfilt_chunk_kernel<real, NSP, 41, 64>);
+    }
+    return HIPNMF_ERR_UNSUPPORTED;
+  }
+  if (C == 17) return go(sosfilt_chunk_kernel<real, NSP, 17, SCAN_THREADS>);
+  if (C == 41) return go(sosfilt_chunk_kernel<real, NSP, 41, SCAN_THREADS>);
   if constexpr (NSP <= 4) {  // intermediate lengths (idle threads cost as much as busy ones); filters of more than four sections keep three
-    if (C == 25) return go(sosfilt_chunk_kernel<real, NSP, 25>);
-    if (C == 33) return go(sosfilt_chunk_kernel<real, NSP, 33>);
+    if (C == 25) return go(sosfilt_chunk_kernel<real, NSP, 25, SCAN_THREADS>);
+    if (C == 33) return go(sosfilt_chunk_kernel<real, NSP, 33, SCAN_THREADS>);
     if constexpr (sizeof(real) == 4) {
-      if (C == 49) return go(sosfilt_chunk_kernel<real, NSP, 49>);
-      if (C == 57) return go(sosfilt_chunk_kernel<real, NSP, 57>);
-      if (C == 65) return go(sosfilt_chunk_kernel<real, NSP, 65>);
+      if (C == 49) return go(sosfilt_chunk_kernel<real, NSP, 49, SCAN_THREADS>);
+      if (C == 57) return go(sosfilt_chunk_kernel<real, NSP, 57, SCAN_THREADS>);
+      if (C == 65) return go(sosfilt_chunk_kernel<real, NSP, 65, SCAN_THREADS>);
     }
   }
   if constexpr (sizeof(real) == 4) {
-    if (C == 79) return go(sosfilt_chunk_kernel<real, NSP, 79>);
+    if (C == 79) return go(sosfilt_chunk_kernel<real, NSP, 79, SCAN_THREADS>);
   }
   return HIPNMF_ERR_UNSUPPORTED;
 }
 // LDS of sosfilt_chunk_kernel without the 8 doubles behind it: the series + a dump slot, or the overlay, whichever is larger
-inline size_t chunk_scan_region(size_t L, int C, int nsp, size_t sizeof_real) {
-  const size_t series = (L + 1) * sizeof_real, overlay = sizeof(double) * ((size_t)SCAN_THREADS * 2 * nsp + (size_t)C * 2 * nsp + (size_t)C);
+inline size_t chunk_scan_region(size_t L, int C, int nt, int nsp, size_t sizeof_real) {
+  const size_t series = (L + 1) * sizeof_real, overlay = sizeof(double) * ((size_t)nt * 2 * nsp + (size_t)C * 2 * nsp + (size_t)C);
   return (std::max(series, overlay) + 15) & ~(size_t)15;
 }
 
@@ -206,8 +218,15 @@ int sosfilt_impl(hipnmf_handle* h, const hipnmf_sosfilt_params* p, const double*
     return !(e && atoi(e) == 0);
   }();
   const int nsp_c = p->n_sections == 1 ? 1 : p->n_sections == 2 ? 2 : p->n_sections <= 4 ? 4 : 8;
-  int chunk_c = 0;
-  if (p->mode == HIPNMF_SOSFILT_SCAN && chunk_scan_ok)
+  int chunk_c = 0, chunk_nt = SCAN_THREADS;
+  static const bool chunk_one_ok = [] {
+    const char* e = getenv("HIPNMF_SOS_CHUNK_64");
+    return !(e && atoi(e) == 0);
+  }();
+  if (p->mode == HIPNMF_SOSFILT_SCAN && chunk_scan_ok && chunk_one_ok && nsp_c <= 4 && L <= 64LL * 41) {
+    chunk_nt = 64;  // one wave per series
+    chunk_c = L <= 64 * 5 ? 5 : L <= 64 * 9 ? 9 : L <= 64 * 17 ? 17 : L <= 64 * 25 ? 25 : L <= 64 * 33 ? 33 : 41;
+  } else if (p->mode == HIPNMF_SOSFILT_SCAN && chunk_scan_ok)
   {
     const bool fine = nsp_c <= 4;  // (the intermediate lengths are compiled for up to four sections)
     const int sizes[] = {17, 25, 33, 41, 49, 57, 65, 79};
@@ -220,7 +239,7 @@ int sosfilt_impl(hipnmf_handle* h, const hipnmf_sosfilt_params* p, const double*
       }
     }
   }
-  const size_t chunk_region = chunk_c ? chunk_scan_region((size_t)L, chunk_c, nsp_c, sizeof(real)) : 0;
+  const size_t chunk_region = chunk_c ? chunk_scan_region((size_t)L, chunk_c, chunk_nt, nsp_c, sizeof(real)) : 0;
   const bool use_chunk_scan = chunk_c > 0 && chunk_region + 64 <= (size_t)h->lds_per_block;
   const size_t o_ws = (zero_lag && !scan_fits && !use_chunk_scan) ? carve(use_v3 ? ws_v3 : ws_v2) : 0;
   const size_t o_stat = carve(sizeof(double) * (size_t)N * 3);
@@ -277,12 +296,15 @@ int sosfilt_impl(hipnmf_handle* h, const hipnmf_sosfilt_params* p, const double*
   if (use_chunk_scan) {
     const int ns = p->n_sections;
     double* tab = reinterpret_cast<double*>(ws + o_tab);
-    rc = ns == 1 ? launch_chunk_scan<real, 1>(h, a, ns, chunk_c, chunk_region, tab, st)
-         : ns == 2 ? launch_chunk_scan<real, 2>(h, a, ns, chunk_c, chunk_region, tab, st)
-         : ns <= 4 ? launch_chunk_scan<real, 4>(h, a, ns, chunk_c, chunk_region, tab, st)
-                   : launch_chunk_scan<real, 8>(h, a, ns, chunk_c, chunk_region, tab, st);
+    rc = ns == 1 ? launch_chunk_scan<real, 1>(h, a, ns, chunk_c, chunk_nt, chunk_region, tab, st)
+         : ns == 2 ? launch_chunk_scan<real, 2>(h, a, ns, chunk_c, chunk_nt, chunk_region, tab, st)
+         : ns <= 4 ? launch_chunk_scan<real, 4>(h, a, ns, chunk_c, chunk_nt, chunk_region, tab, st)
+                   : launch_chunk_scan<real, 8>(h, a, ns, chunk_c, chunk_nt, chunk_region, tab, st);
     if (rc) return rc;
-    snprintf(h->last_kernel, sizeof(h->last_kernel), "sosfilt_chunk_kernel<%s,%d,%d>", sizeof(real) == 4 ? "float" : "double", nsp_c, chunk_c);
+    if (chunk_nt == 64)
+      snprintf(h->last_kernel, sizeof(h->last_kernel), "sosfilt_chunk_kernel<%s,%d,%d,64>", sizeof(real) == 4 ? "float" : "double", nsp_c, chunk_c);
+    else
+      snprintf(h->last_kernel, sizeof(h->last_kernel), "sosfilt_chunk_kernel<%s,%d,%d>", sizeof(real) == 4 ? "float" : "double", nsp_c, chunk_c);
     HIP_TRY(hipGetLastError());
     if (!async) {
       HIP_TRY(hipEventRecord(h->ev1, st));

@@ -128,11 +128,11 @@ __device__ __forceinline__ void scan_matvec(const double* __restrict__ Mat, cons
 // shuffles, constant matrices M^(2^j)); (B) the state each wave is entered with from the waves' totals (Horner with M^64, at most
 // three wave-uniform products); (C) lane l of a wave adds M^(l+1) times that state, the power built from the binary digits of
 // l + 1.  xch: LDS [256][NST].
-template <int NST>
+template <int NST, int NT = SCAN_THREADS>
 __device__ __forceinline__ void scan_states(double (&E)[NST], const double (&s_init)[NST], bool reverse, const double* __restrict__ Mp,
                                             double* __restrict__ xch, double (&s_start)[NST]) {
   const int t = threadIdx.x, lane = t & 63;
-  const int q = reverse ? SCAN_THREADS - 1 - t : t;
+  const int q = reverse ? NT - 1 - t : t;
   const int lq = q & 63, wq = q >> 6;
   if (q == 0) scan_matvec_acc<NST>(Mp, s_init, E);  // E_0 = F_0 + M s_init
 #pragma unroll
@@ -532,15 +532,17 @@ sosfilt_scan_kernel(SosArgs a, const double* __restrict__ tab, int ns) {
 // exchange area and the G table overlay it, so LDS = the series (80 120 B for 20 000 float samples of an order-4 zero-lag filter:
 // two workgroups per CU).  The odd extension is built in LDS from the centred samples by the first / last `edge` threads.
 // float and double up to 256 x 79 / 256 x 41 extended samples; anything else takes sosfilt_scan_kernel or the sequential kernels.
-template <typename real, int NSP, int C>
-__global__ void __launch_bounds__(SCAN_THREADS, (C > 32 ? (NSP > 4 ? 1 : 2) : (NSP > 4 ? 2 : 4)))
+// NT = 64: one wave per series (short series: up to 64 x 41 extended samples; with 256 threads a 1 000-sample series kept 61 of
+// them busy) -- the scan's cross-wave phases and the workgroup-wide steps fall away.
+template <typename real, int NSP, int C, int NT = SCAN_THREADS>
+__global__ void __launch_bounds__(NT, (C > 32 ? (NSP > 4 ? 1 : 2) : (NSP > 4 ? 2 : 4)))
 sosfilt_chunk_kernel(SosArgs a, const double* __restrict__ tab, int ns, int region_bytes) {
   static_assert(C % 2 == 1, "odd chunk length: conflict-free LDS stride");
   constexpr int NST = 2 * NSP;
   extern __shared__ __attribute__((aligned(16))) unsigned char scan_smem[];
   real* __restrict__ xs = reinterpret_cast<real*>(scan_smem);               // [L] the extended series, later the output
   double* __restrict__ xch = reinterpret_cast<double*>(scan_smem);          // overlay: [256][NST]
-  double* __restrict__ Gl = xch + SCAN_THREADS * NST;                        // overlay: G [C][NST]
+  double* __restrict__ Gl = xch + NT * NST;                        // overlay: G [C][NST]
   double* __restrict__ row = Gl + C * NST;                                   // overlay: one chunk (ylast)
   double* __restrict__ misc = reinterpret_cast<double*>(scan_smem + region_bytes);  // [8] behind both
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -558,11 +560,11 @@ sosfilt_chunk_kernel(SosArgs a, const double* __restrict__ tab, int ns, int regi
   double c[NSP][5];
   scan_coeffs<NSP>(a, ns, c);
   // this thread's entries of the G table: requested now, written to the overlay once the series buffer is dead
-  constexpr int GN = (C * NST + SCAN_THREADS - 1) / SCAN_THREADS;
+  constexpr int GN = (C * NST + NT - 1) / NT;
   double gpre[GN];
 #pragma unroll
   for (int u = 0; u < GN; ++u) {
-    const int i = t + u * SCAN_THREADS;
+    const int i = t + u * NT;
     gpre[u] = i < C * NST ? G[i] : 0.0;
   }
 
@@ -573,7 +575,7 @@ sosfilt_chunk_kernel(SosArgs a, const double* __restrict__ tab, int ns, int regi
 #pragma unroll
     for (int k = 0; k < C; ++k) {
       real r1[1];
-      buf_load<real, 1>(xrs, voff, (unsigned)(k * SCAN_THREADS) * (unsigned)sizeof(real), r1);
+      buf_load<real, 1>(xrs, voff, (unsigned)(k * NT) * (unsigned)sizeof(real), r1);
       raw[k] = r1[0];
     }
     real mean = (real)0;
@@ -585,16 +587,16 @@ sosfilt_chunk_kernel(SosArgs a, const double* __restrict__ tab, int ns, int regi
       for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
       if (lane == 0) misc[wave] = sum;
       __syncthreads();
-      mean = (real)(((misc[0] + misc[1]) + (misc[2] + misc[3])) / (double)T);
+      mean = (real)((NT == 64 ? misc[0] : ((misc[0] + misc[1]) + (misc[2] + misc[3]))) / (double)T);
     }
 #pragma unroll
     for (int k = 0; k < C; ++k) {
-      const int j = t + k * SCAN_THREADS;
+      const int j = t + k * NT;
       const real pv = sos_pre<real>(raw[k], mean, a.rectify);
       xs[j < T ? edge + j : L] = pv;  // (slot L: a dump slot behind the series -- a branch per store would serialise them)
     }
     __syncthreads();
-    for (int e = t; e < edge; e += SCAN_THREADS) {  // scipy's odd extension about the end samples, in the samples' precision
+    for (int e = t; e < edge; e += NT) {  // scipy's odd extension about the end samples, in the samples' precision
       xs[e] = (real)2 * xs[edge] - xs[2 * edge - e];
       xs[edge + T + e] = (real)2 * xs[edge + T - 1] - xs[edge + T - 2 - e];
     }
@@ -611,7 +613,7 @@ sosfilt_chunk_kernel(SosArgs a, const double* __restrict__ tab, int ns, int regi
   __syncthreads();  // the series buffer is dead from here: the overlay takes it
 #pragma unroll
   for (int u = 0; u < GN; ++u) {
-    const int i = t + u * SCAN_THREADS;
+    const int i = t + u * NT;
     if (i < C * NST) Gl[i] = gpre[u];
   }
 
@@ -634,7 +636,7 @@ sosfilt_chunk_kernel(SosArgs a, const double* __restrict__ tab, int ns, int regi
       E[2 * s + 1] = z[s][1];
     }
   }
-  scan_states<NST>(E, s_init, false, Mp, xch, s_start);  // (its first barrier also publishes Gl)
+  scan_states<NST, NT>(E, s_init, false, Mp, xch, s_start);  // (its first barrier also publishes Gl)
 #pragma unroll
   for (int n = 0; n < C; ++n) {
     double acc = v[n];
@@ -673,7 +675,7 @@ sosfilt_chunk_kernel(SosArgs a, const double* __restrict__ tab, int ns, int regi
         E[2 * s + 1] = z[s][1];
       }
     }
-    scan_states<NST>(E, s_init, true, Mp, xch, s_start);
+    scan_states<NST, NT>(E, s_init, true, Mp, xch, s_start);
     const double* __restrict__ Gr = Gl + (C - 1) * NST;  // sample n of a chunk is step C - 1 - n of the reversed walk
 #pragma unroll
     for (int n = 0; n < C; ++n) {
@@ -694,14 +696,14 @@ sosfilt_chunk_kernel(SosArgs a, const double* __restrict__ tab, int ns, int regi
   }
   __syncthreads();
   constexpr int CB = 8;
-  const int kmax = (T + SCAN_THREADS - 1) / SCAN_THREADS;
+  const int kmax = (T + NT - 1) / NT;
   for (int k0 = 0; k0 < kmax; k0 += CB) {
     real y[CB];
-    const real* __restrict__ src = xs + edge + t + k0 * SCAN_THREADS;  // (reads past the series cannot fault; the stores are dropped)
+    const real* __restrict__ src = xs + edge + t + k0 * NT;  // (reads past the series cannot fault; the stores are dropped)
 #pragma unroll
-    for (int u = 0; u < CB; ++u) y[u] = src[u * SCAN_THREADS];
+    for (int u = 0; u < CB; ++u) y[u] = src[u * NT];
 #pragma unroll
-    for (int u = 0; u < CB; ++u) buf_store<real>(yrs, voff, (unsigned)((k0 + u) * SCAN_THREADS) * (unsigned)sizeof(real), y[u]);
+    for (int u = 0; u < CB; ++u) buf_store<real>(yrs, voff, (unsigned)((k0 + u) * NT) * (unsigned)sizeof(real), y[u]);
   }
 }
 

@@ -271,7 +271,12 @@ def test_gpu_scan_mode_kernel_choice_and_shapes_of_the_second_version(g8):
 
     sos = g8["lp4_sos"]  # two sections: padlen 15
     h = _lib.get_handle(0)
-    for T, dtype, padlen, want in ((1001, np.float64, None, "sosfilt_chunk_kernel<double,2,17>"),
+    for T, dtype, padlen, want in ((1001, np.float64, None, "sosfilt_chunk_kernel<double,2,17,64>"),
+                                   (2624 - 30, np.float32, None, "sosfilt_chunk_kernel<float,2,41,64>"),
+                                   (2624 - 29, np.float32, None, "sosfilt_chunk_kernel<float,2,17>"),
+                                   (100, np.float64, None, "sosfilt_chunk_kernel<double,2,5,64>"),
+                                   (290, np.float32, None, "sosfilt_chunk_kernel<float,2,5,64>"),
+                                   (291, np.float32, None, "sosfilt_chunk_kernel<float,2,9,64>"),
                                    (4352 - 30, np.float64, None, "sosfilt_chunk_kernel<double,2,17>"),
                                    (4352 - 29, np.float64, None, "sosfilt_chunk_kernel<double,2,25>"),
                                    (10496 - 30, np.float32, None, "sosfilt_chunk_kernel<float,2,41>"),
@@ -283,7 +288,7 @@ def test_gpu_scan_mode_kernel_choice_and_shapes_of_the_second_version(g8):
                                    (3001, np.float32, 700, "sosfilt_chunk_kernel<float,2,25>"),
                                    (16640 - 30, np.float32, None, "sosfilt_chunk_kernel<float,2,65>"),
                                    (8448 - 29, np.float64, None, "sosfilt_chunk_kernel<double,2,41>"),
-                                   (333, np.float64, 300, "sosfilt_chunk_kernel<double,2,17>")):
+                                   (333, np.float64, 300, "sosfilt_chunk_kernel<double,2,17,64>")):
         raw = raw_emg(70 + T % 13, T, 3).astype(dtype)
         x = np.ascontiguousarray(raw.T)[:, :T].T if T % 2 else raw  # channel-major rows of odd length: unaligned
         got = sosfilt_batched(x, sos, zero_lag=True, zero_center=True, rectify=True, padlen=padlen, mode="scan")[0].cpu().numpy()
