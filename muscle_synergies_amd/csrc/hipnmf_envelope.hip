@@ -138,7 +138,7 @@ int envelope_impl(hipnmf_handle* h, const hipnmf_envelope_params* p, const real*
       return !(e && atoi(e) == 0);
     }();
     if (chunk_one_ok && chunk_span <= 64LL * 33) {
-      constexpr int one_sizes[] = {9, 13, 17, 25, 33};
+      constexpr int one_sizes[] = {5, 9, 13, 17, 25, 33};
       for (int c : one_sizes)
         if (chunk_span <= 64LL * c) {
           chunk_c = c;
@@ -240,7 +240,7 @@ int envelope_impl(hipnmf_handle* h, const hipnmf_envelope_params* p, const real*
       }
     } else if (chunk_nt == 64) {
       switch (chunk_c) {
-        HIPNMF_CHUNK_CASE(9, 64) HIPNMF_CHUNK_CASE(13, 64) HIPNMF_CHUNK_CASE(17, 64) HIPNMF_CHUNK_CASE(25, 64) HIPNMF_CHUNK_CASE(33, 64)
+        HIPNMF_CHUNK_CASE(5, 64) HIPNMF_CHUNK_CASE(9, 64) HIPNMF_CHUNK_CASE(13, 64) HIPNMF_CHUNK_CASE(17, 64) HIPNMF_CHUNK_CASE(25, 64) HIPNMF_CHUNK_CASE(33, 64)
       }
     } else {
       switch (chunk_c) { HIPNMF_CHUNK_CASE(41, 512) }

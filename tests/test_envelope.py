@@ -174,9 +174,11 @@ _CHUNK_CASES = [
     (1280, 3, 37, None, True, True, np.float32, "emg_chunk_kernel<float,25,64>"),      # up to 64 x 33 positions: one wave per series
     (2112 - 18, 3, 37, None, True, True, np.float32, "emg_chunk_kernel<float,33,64>"),  # the longest one-wave series
     (2112 - 17, 3, 37, None, True, True, np.float32, "emg_chunk_kernel<float,9,256>"),  # one more: four waves, smallest instance
-    (64, 2, 5, None, True, True, np.float32, "emg_chunk_kernel<float,9,64>"),          # shortest series the kernel takes
+    (64, 2, 5, None, True, True, np.float32, "emg_chunk_kernel<float,5,64>"),          # shortest series the kernel takes
+    (318, 2, 5, 40, True, True, np.float32, "emg_chunk_kernel<float,5,64>"),           # 320 positions
+    (319, 2, 5, 40, True, True, np.float32, "emg_chunk_kernel<float,9,64>"),
     (63, 2, 5, None, True, True, np.float32, "emg_wave_kernel"),
-    (300, 2, 1, 50, False, False, np.float64, "emg_chunk_kernel<double,9,64>"),        # window of one sample, time-normalised
+    (300, 2, 1, 50, False, False, np.float64, "emg_chunk_kernel<double,5,64>"),        # window of one sample, time-normalised
     (577, 3, 577, 1200, True, True, np.float64, "emg_chunk_kernel<double,17,64>"),     # window = series, up-sampling, one wave
     (2304 - 18, 2, 37, 100, False, True, np.float32, "emg_chunk_kernel<float,9,256>"),   # all 256 threads own a chunk
     (2304 - 17, 2, 37, 100, False, True, np.float32, "emg_chunk_kernel<float,13,256>"),
