@@ -15,7 +15,7 @@ from .analysis import SynergyRunResult, find_synergies, find_synergies_batched, 
 from .engine import (BatchedResult, RankSweepResult, RestartResult, fit_batched, fit_batched_multi_gpu, fit_ragged,
                      fit_restarts, random_init_batched, random_init_device, rank_sweep_batched, rank_sweep_native)
 from .hip_nmf import HipNMF
-from .preprocess import (digital_filter, emg_envelope_batched, linear_envelope, linear_envelope_batched, normalize,
+from .preprocess import (digital_filter, emg_envelope_batched, linear_envelope, linear_envelope_batched, normalize, set_filter_mode,
                          rms, sosfilt_batched, time_normalize, zero_center)
 from .segments import find_synergies_segments, segment_frames
 from ._lib import HipNmfError
@@ -51,5 +51,6 @@ __all__ = [
     "time_normalize",
     "emg_envelope_batched",
     "linear_envelope_batched",
+    "set_filter_mode",
     "sosfilt_batched",
 ]

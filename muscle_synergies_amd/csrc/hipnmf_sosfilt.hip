@@ -135,6 +135,41 @@ inline size_t chunk_scan_region(size_t L, int C, int nt, int nsp, size_t sizeof_
   return (std::max(series, overlay) + 15) & ~(size_t)15;
 }
 
+// long series (sosfilt_block_kernel): state pass, block scan, full pass per direction
+template <typename real, int NSP>
+int launch_block_scan(hipnmf_handle* h, const SosArgs& a, int ns, long long L, int NB, size_t region, double* tab, const double* stat,
+                      real* fwd, double* bend, double* bstart, real* y, hipStream_t st) {
+  constexpr int C = sizeof(real) == 4 ? 79 : 41;
+  hipLaunchKernelGGL((sos_scan_tables_kernel<NSP>), dim3(1), dim3(256), 0, st, a, ns, C, tab);
+  const size_t smem = region + 8 * sizeof(double);
+  auto kern = sosfilt_block_kernel<real, NSP, C>;
+  if (smem > 48 * 1024)
+    if (int rc = hipnmf_allow_full_lds(h, reinterpret_cast<const void*>(kern))) return rc;
+  const dim3 grid((unsigned)((long long)a.N * NB)), gscan((unsigned)((a.N + 63) / 64));
+  SosBlockArgs<real> k;
+  k.stat = stat;
+  k.L = (int)L;
+  k.NB = NB;
+  for (int dir = 0; dir < (a.zero_lag ? 2 : 1); ++dir) {
+    k.backward = dir;
+    k.src = dir ? fwd : nullptr;
+    k.block_end = bend;
+    k.block_start = nullptr;
+    k.full = 0;
+    k.dst = nullptr;
+    k.dst_is_y = 0;
+    hipLaunchKernelGGL(kern, grid, dim3(SCAN_THREADS), smem, st, a, k, (const double*)tab, ns, (int)region);
+    hipLaunchKernelGGL((sos_block_scan_kernel<real, NSP>), gscan, dim3(64), 0, st, a, k, (const double*)tab, ns, bstart);
+    k.block_start = bstart;
+    k.full = 1;
+    const bool last = dir == (a.zero_lag ? 1 : 0);
+    k.dst = last ? y : fwd;
+    k.dst_is_y = last ? 1 : 0;
+    hipLaunchKernelGGL(kern, grid, dim3(SCAN_THREADS), smem, st, a, k, (const double*)tab, ns, (int)region);
+  }
+  return HIPNMF_OK;
+}
+
 template <typename real>
 int sosfilt_impl(hipnmf_handle* h, const hipnmf_sosfilt_params* p, const double* sos, const double* zi, const real* x,
                  real* y) {
@@ -241,13 +276,29 @@ int sosfilt_impl(hipnmf_handle* h, const hipnmf_sosfilt_params* p, const double*
   }
   const size_t chunk_region = chunk_c ? chunk_scan_region((size_t)L, chunk_c, chunk_nt, nsp_c, sizeof(real)) : 0;
   const bool use_chunk_scan = chunk_c > 0 && chunk_region + 64 <= (size_t)h->lds_per_block;
-  const size_t o_ws = (zero_lag && !scan_fits && !use_chunk_scan) ? carve(use_v3 ? ws_v3 : ws_v2) : 0;
+  // long series: blocks of 256 chunks per workgroup, a scan over the blocks (sosfilt_block_kernel); HIPNMF_SOS_BLOCK=0: the
+  // sequential kernels
+  static const bool block_scan_ok = [] {
+    const char* e = getenv("HIPNMF_SOS_BLOCK");
+    return !(e && atoi(e) == 0);
+  }();
+  constexpr int BLK_C = sizeof(real) == 4 ? 79 : 41;
+  const long long blk_len = 256LL * BLK_C;
+  const long long blk_nb = (L + blk_len - 1) / blk_len;
+  const size_t blk_region = chunk_scan_region((size_t)blk_len, BLK_C, SCAN_THREADS, nsp_c, sizeof(real));
+  const bool use_block_scan = p->mode == HIPNMF_SOSFILT_SCAN && block_scan_ok && !use_chunk_scan && !scan_fits && blk_nb > 1 &&
+                              (long long)T * (long long)sizeof(real) < (1LL << 31) && L * (long long)sizeof(real) < (1LL << 31) &&
+                              N * blk_nb < (1LL << 31) && blk_region + 64 <= (size_t)h->lds_per_block;
+  const size_t o_fwd = (use_block_scan && zero_lag) ? carve(sizeof(real) * (size_t)N * (size_t)L) : 0;
+  const size_t o_bend = use_block_scan ? carve(sizeof(double) * (size_t)N * (size_t)blk_nb * 2 * nsp_c) : 0;
+  const size_t o_bstart = use_block_scan ? carve(sizeof(double) * (size_t)N * (size_t)blk_nb * 2 * nsp_c) : 0;
+  const size_t o_ws = (zero_lag && !scan_fits && !use_chunk_scan && !use_block_scan) ? carve(use_v3 ? ws_v3 : ws_v2) : 0;
   const size_t o_stat = carve(sizeof(double) * (size_t)N * 3);
   // time-parallel mode: the whole extended series in the registers of one workgroup (256 chunks of at most SCAN_CMAX samples);
   // longer series take the sequential kernel
   const int C_run = scan_fits ? scan_chunk : 0;
   const bool use_scan = scan_fits;
-  const size_t o_tab = (use_scan || use_chunk_scan) ? carve(sizeof(double) * SCAN_TAB_DOUBLES) : 0;
+  const size_t o_tab = (use_scan || use_chunk_scan || use_block_scan) ? carve(sizeof(double) * SCAN_TAB_DOUBLES) : 0;
   int rc = hipnmf_ensure_ws(h, std::max<size_t>(off, 256));
   if (rc) return rc;
   char* ws = static_cast<char*>(h->ws);
@@ -305,6 +356,27 @@ int sosfilt_impl(hipnmf_handle* h, const hipnmf_sosfilt_params* p, const double*
       snprintf(h->last_kernel, sizeof(h->last_kernel), "sosfilt_chunk_kernel<%s,%d,%d,64>", sizeof(real) == 4 ? "float" : "double", nsp_c, chunk_c);
     else
       snprintf(h->last_kernel, sizeof(h->last_kernel), "sosfilt_chunk_kernel<%s,%d,%d>", sizeof(real) == 4 ? "float" : "double", nsp_c, chunk_c);
+    HIP_TRY(hipGetLastError());
+    if (!async) {
+      HIP_TRY(hipEventRecord(h->ev1, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      HIP_TRY(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
+    }
+    return HIPNMF_OK;
+  }
+  if (use_block_scan) {
+    const int ns = p->n_sections;
+    double* tab = reinterpret_cast<double*>(ws + o_tab);
+    hipLaunchKernelGGL(sos_stats_kernel<real>, dim3((unsigned)N), dim3(256), 0, st, a, stat);
+    real* fwd = reinterpret_cast<real*>(ws + o_fwd);
+    double* bend = reinterpret_cast<double*>(ws + o_bend);
+    double* bstart = reinterpret_cast<double*>(ws + o_bstart);
+    rc = ns == 1 ? launch_block_scan<real, 1>(h, a, ns, L, (int)blk_nb, blk_region, tab, stat, fwd, bend, bstart, y, st)
+         : ns == 2 ? launch_block_scan<real, 2>(h, a, ns, L, (int)blk_nb, blk_region, tab, stat, fwd, bend, bstart, y, st)
+         : ns <= 4 ? launch_block_scan<real, 4>(h, a, ns, L, (int)blk_nb, blk_region, tab, stat, fwd, bend, bstart, y, st)
+                   : launch_block_scan<real, 8>(h, a, ns, L, (int)blk_nb, blk_region, tab, stat, fwd, bend, bstart, y, st);
+    if (rc) return rc;
+    snprintf(h->last_kernel, sizeof(h->last_kernel), "sosfilt_block_kernel<%s,%d,%d>", sizeof(real) == 4 ? "float" : "double", nsp_c, (int)BLK_C);
     HIP_TRY(hipGetLastError());
     if (!async) {
       HIP_TRY(hipEventRecord(h->ev1, st));

@@ -28,7 +28,7 @@ namespace hipnmf {
 constexpr int SCAN_THREADS = 256;
 constexpr int SCAN_CMAX = 80;  // samples per thread of the large instance: series of up to 256 * 80 = 20 480 extended samples
 constexpr int SCAN_G_CAP = 128 * 2 * SOS_MAX_SECTIONS;            // doubles reserved for G in the table buffer
-constexpr int SCAN_TAB_DOUBLES = SCAN_G_CAP + 8 * 4 * SOS_MAX_SECTIONS * SOS_MAX_SECTIONS;  // + M^(2^j), j = 0..7
+constexpr int SCAN_TAB_DOUBLES = SCAN_G_CAP + 9 * 4 * SOS_MAX_SECTIONS * SOS_MAX_SECTIONS;  // + M^(2^j), j = 0..8 (M^256: a whole block of 256 chunks)
 constexpr int SCAN_STAGE_BYTES = 48 * 1024;
 constexpr int SCAN_LOADS = 12;  // 16-byte loads in flight per thread while staging (a 48 KiB piece in one round)
 
@@ -61,7 +61,7 @@ __device__ __forceinline__ double scan_step(double xc, double (&z)[NSP][2], cons
 }
 
 // G[n][j] (n < C_run): output n steps after a unit state j, no input; M = A^C_run and its squarings M^2 .. M^128.
-// tab: [SCAN_G_CAP] G row-major [n][NST], then [8][NST][NST].  One workgroup of 256 threads.
+// tab: [SCAN_G_CAP] G row-major [n][NST], then [9][NST][NST] (M^(2^j), j = 0..8).  One workgroup of 256 threads.
 template <int NSP>
 __global__ void __launch_bounds__(256) sos_scan_tables_kernel(SosArgs a, int ns, int C_run, double* __restrict__ tab) {
   constexpr int NST = 2 * NSP;
@@ -85,7 +85,7 @@ __global__ void __launch_bounds__(256) sos_scan_tables_kernel(SosArgs a, int ns,
   }
   __syncthreads();
   double* Mp = tab + SCAN_G_CAP;
-  for (int p = 0; p < 8; ++p) {
+  for (int p = 0; p < 9; ++p) {
     if (j < NST * NST) Mp[p * NST * NST + j] = Ma[j];
     if (j < NST * NST) {
       const int r = j / NST, q = j % NST;
@@ -704,6 +704,230 @@ sosfilt_chunk_kernel(SosArgs a, const double* __restrict__ tab, int ns, int regi
     for (int u = 0; u < CB; ++u) y[u] = src[u * NT];
 #pragma unroll
     for (int u = 0; u < CB; ++u) buf_store<real>(yrs, voff, (unsigned)((k0 + u) * NT) * (unsigned)sizeof(real), y[u]);
+  }
+}
+
+// =================================================================================================================================
+// Long series (round 4): more than one workgroup's worth of samples -- a whole recording of minutes at 2 kHz is 10^5 .. 10^6
+// samples, and the sequential kernels need 20 ms for ONE 16 x 200 000 frame (a dependent chain of 400 000 steps).  The chunk
+// algebra nests: a block of 256 chunks entered with state s0 leaves the state F_blk + M^256 s0 behind, so per direction
+//   state pass   every (series, block) workgroup filters its block from rest and stores F_blk          (sosfilt_block_kernel, full = 0)
+//   block scan   one thread per series walks its blocks: start_b = s,  s <- F_b + M^256 s                (sos_block_scan_kernel)
+//   full pass    every workgroup filters its block again, entered with start_b, and writes it out       (full = 1)
+// forward over x (centred / rectified, odd extension at the recording's ends) into a workspace, backward over the workspace into y.
+// Each pass is one chip-filling launch with a dependent chain of one block; the data are read four times and written twice
+// instead of once each -- bandwidth that a single long frame does not miss and a batch of them trades for the chain.
+template <typename real>
+struct SosBlockArgs {
+  const real* src;            // nullptr: the recording a.x (centred / rectified / extended); else the forward output [N][L]
+  real* dst;                  // full pass: the forward output [N][L] (forward) or y [N][T] (backward, or forward of a causal filter)
+  const double* stat;         // [N][3]: mean, first, last pre-processed sample (sos_stats_kernel)
+  double* block_end;          // state pass: [N][NB][NST] state a block leaves behind when entered at rest
+  const double* block_start;  // full pass: [N][NB][NST] state every block is entered with
+  int L, NB, backward, full, dst_is_y;
+};
+
+template <typename real, int NSP>
+__global__ void __launch_bounds__(64) sos_block_scan_kernel(SosArgs a, SosBlockArgs<real> k, const double* __restrict__ tab, int ns,
+                                                            double* __restrict__ block_start) {
+  constexpr int NST = 2 * NSP;
+  const int s = blockIdx.x * 64 + threadIdx.x;
+  if (s >= a.N) return;
+  const double* __restrict__ M256 = tab + SCAN_G_CAP + 8 * NST * NST;
+  double st[NST];
+  double x0 = 0.0;
+  if (a.zero_lag) {
+    if (k.backward) {
+      x0 = (double)k.src[(long long)s * k.L + k.L - 1];  // y_fwd[L - 1]
+    } else {
+      const real* __restrict__ xr = static_cast<const real*>(a.x) + (long long)(s / a.m) * a.bstride + (long long)(s % a.m) * a.ld;
+      const real mean = (real)k.stat[3LL * s], first = (real)k.stat[3LL * s + 1];
+      x0 = (double)(a.edge > 0 ? (real)2 * first - sos_pre<real>(xr[a.edge], mean, a.rectify) : first);  // ext[0]
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < NSP; ++q) {
+    st[2 * q] = (a.zero_lag && q < ns) ? a.zi[q][0] * x0 : 0.0;
+    st[2 * q + 1] = (a.zero_lag && q < ns) ? a.zi[q][1] * x0 : 0.0;
+  }
+  for (int i = 0; i < k.NB; ++i) {
+    const int b = k.backward ? k.NB - 1 - i : i;
+    double* __restrict__ o = block_start + ((long long)s * k.NB + b) * NST;
+    const double* __restrict__ e = k.block_end + ((long long)s * k.NB + b) * NST;
+    double nx[NST];
+#pragma unroll
+    for (int r = 0; r < NST; ++r) {
+      o[r] = st[r];
+      double acc = e[r];
+#pragma unroll
+      for (int c2 = 0; c2 < NST; ++c2) acc = __builtin_fma(M256[r * NST + c2], st[c2], acc);
+      nx[r] = acc;
+    }
+#pragma unroll
+    for (int r = 0; r < NST; ++r) st[r] = nx[r];
+  }
+}
+
+// One workgroup per (series, block): grid.x = N * NB.  Dynamic LDS as sosfilt_chunk_kernel (the block in natural order, the
+// overlay, 8 doubles behind).
+template <typename real, int NSP, int C>
+__global__ void __launch_bounds__(SCAN_THREADS, (C > 32 ? (NSP > 4 ? 1 : 2) : (NSP > 4 ? 2 : 4)))
+sosfilt_block_kernel(SosArgs a, SosBlockArgs<real> k, const double* __restrict__ tab, int ns, int region_bytes) {
+  static_assert(C % 2 == 1, "odd chunk length: conflict-free LDS stride");
+  constexpr int NST = 2 * NSP, NT = SCAN_THREADS, LB = NT * C;
+  extern __shared__ __attribute__((aligned(16))) unsigned char scan_smem[];
+  real* __restrict__ xs = reinterpret_cast<real*>(scan_smem);
+  double* __restrict__ xch = reinterpret_cast<double*>(scan_smem);
+  double* __restrict__ Gl = xch + NT * NST;
+  const int t = threadIdx.x;
+  const int series = (int)(blockIdx.x / (unsigned)k.NB), b = (int)(blockIdx.x % (unsigned)k.NB);
+  const int T = a.T, edge = a.edge, L = k.L;
+  const int p0 = b * LB;
+  const int nblk = (L - p0 < LB) ? L - p0 : LB;  // positions of the (extended) series in this block
+  const double* __restrict__ G = tab;
+  const double* __restrict__ Mp = tab + SCAN_G_CAP;
+  const unsigned voff = (unsigned)t * (unsigned)sizeof(real);
+
+  double c[NSP][5];
+  scan_coeffs<NSP>(a, ns, c);
+  constexpr int GN = (C * NST + NT - 1) / NT;
+  double gpre[GN];
+#pragma unroll
+  for (int u = 0; u < GN; ++u) {
+    const int i = t + u * NT;
+    gpre[u] = (k.full && i < C * NST) ? G[i] : 0.0;
+  }
+
+  // ---- the block -> LDS ------------------------------------------------------------------------------------------------------
+  double tailv = 0.0;  // value of the positions behind the series: 0 (forward), y_fwd[L - 1] (backward: the recursion then starts in its steady state)
+  if (k.src) {
+    const real* __restrict__ sr = k.src + (long long)series * L;
+    const rsrc_t rs = make_rsrc(sr + p0, (unsigned)((long long)nblk * (long long)sizeof(real)));
+    real raw[C];
+#pragma unroll
+    for (int q = 0; q < C; ++q) {
+      real r1[1];
+      buf_load<real, 1>(rs, voff, (unsigned)(q * NT) * (unsigned)sizeof(real), r1);
+      raw[q] = r1[0];
+    }
+    if (k.backward) tailv = (double)sr[L - 1];
+#pragma unroll
+    for (int q = 0; q < C; ++q) {
+      const int i = t + q * NT;
+      xs[i < nblk ? i : LB] = raw[q];  // (slot LB: a dump slot behind the block)
+    }
+  } else {
+    const real* __restrict__ xr = static_cast<const real*>(a.x) + (long long)(series / a.m) * a.bstride + (long long)(series % a.m) * a.ld;
+    const rsrc_t rs = make_rsrc(xr, (unsigned)((long long)T * (long long)sizeof(real)));
+    const real mean = (real)k.stat[3LL * series], first = (real)k.stat[3LL * series + 1], last = (real)k.stat[3LL * series + 2];
+    real raw[C];
+#pragma unroll
+    for (int q = 0; q < C; ++q) {  // extended position p0 + i <-> sample p0 + i - edge (outside the recording: an offset the range check refuses)
+      const long long j = (long long)p0 - edge + t + q * NT;
+      real r1[1];
+      buf_load<real, 1>(rs, (j >= 0 && j < T) ? (unsigned)((unsigned long long)j * sizeof(real)) : OOB, 0u, r1);
+      raw[q] = r1[0];
+    }
+#pragma unroll
+    for (int q = 0; q < C; ++q) {
+      const int i = t + q * NT;
+      xs[i < nblk ? i : LB] = sos_pre<real>(raw[q], mean, a.rectify);
+    }
+    __syncthreads();
+    // scipy's odd extension about the recording's end samples, where this block holds a piece of it (straight from memory: the
+    // reflected samples may belong to a neighbouring block)
+    for (int e = t; e < edge; e += NT) {
+      const int pf = e - p0, pt = edge + T + e - p0;
+      if (pf >= 0 && pf < nblk) xs[pf] = (real)2 * first - sos_pre<real>(xr[edge - e], mean, a.rectify);
+      if (pt >= 0 && pt < nblk) xs[pt] = (real)2 * last - sos_pre<real>(xr[T - 2 - e], mean, a.rectify);
+    }
+  }
+  __syncthreads();
+  double v[C];
+  {
+    const real* __restrict__ mine = xs + C * t;
+    const int nval = nblk - C * t;
+#pragma unroll
+    for (int n = 0; n < C; ++n) {
+      const real xv = mine[n];
+      v[n] = n < nval ? (double)xv : tailv;
+    }
+  }
+  __syncthreads();  // the block buffer is dead from here: the overlay takes it
+  if (k.full) {
+#pragma unroll
+    for (int u = 0; u < GN; ++u) {
+      const int i = t + u * NT;
+      if (i < C * NST) Gl[i] = gpre[u];
+    }
+  }
+  double s_init[NST], s_start[NST], E[NST];
+#pragma unroll
+  for (int i = 0; i < NST; ++i) s_init[i] = k.block_start ? k.block_start[((long long)series * k.NB + b) * NST + i] : 0.0;
+  {
+    double z[NSP][2];
+#pragma unroll
+    for (int q = 0; q < NSP; ++q) z[q][0] = z[q][1] = 0.0;
+    if (k.backward) {
+#pragma unroll
+      for (int n = C - 1; n >= 0; --n) v[n] = scan_step<NSP>(v[n], z, c);
+    } else {
+#pragma unroll
+      for (int n = 0; n < C; ++n) v[n] = scan_step<NSP>(v[n], z, c);
+    }
+#pragma unroll
+    for (int q = 0; q < NSP; ++q) {
+      E[2 * q] = z[q][0];
+      E[2 * q + 1] = z[q][1];
+    }
+  }
+  scan_states<NST, NT>(E, s_init, k.backward != 0, Mp, xch, s_start);
+  if (!k.full) {  // the state the whole block leaves behind: the inclusive value of the last chunk of the walk
+    if (t < NST) k.block_end[((long long)series * k.NB + b) * NST + t] = xch[(NT - 1) * NST + t];
+    return;
+  }
+  if (k.backward) {
+    const double* __restrict__ Gr = Gl + (C - 1) * NST;
+#pragma unroll
+    for (int n = 0; n < C; ++n) {
+      double acc = v[n];
+#pragma unroll
+      for (int i = 0; i < NST; ++i) acc = __builtin_fma(Gr[i - n * NST], s_start[i], acc);
+      v[n] = acc;
+    }
+  } else {
+#pragma unroll
+    for (int n = 0; n < C; ++n) {
+      double acc = v[n];
+#pragma unroll
+      for (int i = 0; i < NST; ++i) acc = __builtin_fma(Gl[n * NST + i], s_start[i], acc);
+      v[n] = acc;
+    }
+  }
+  __syncthreads();  // the overlay is dead
+  {
+    real* __restrict__ mine = xs + C * t;
+    const int nval = nblk - C * t;
+#pragma unroll
+    for (int n = 0; n < C; ++n) mine[n < nval ? n : LB - C * t] = (real)v[n];
+  }
+  __syncthreads();
+  // block position i <-> extended position p0 + i; y keeps the positions [edge, edge + T)
+  const int shift = k.dst_is_y ? edge : 0, len = k.dst_is_y ? T : L;
+  real* __restrict__ dr = k.dst + (long long)series * len;
+  const rsrc_t ds = make_rsrc(dr, (unsigned)((long long)len * (long long)sizeof(real)));
+  constexpr int CB = 8;
+  for (int k0 = 0; k0 < C; k0 += CB) {
+    real y[CB];
+#pragma unroll
+    for (int u = 0; u < CB; ++u) y[u] = xs[(t + (k0 + u) * NT) < LB ? t + (k0 + u) * NT : LB];
+#pragma unroll
+    for (int u = 0; u < CB; ++u) {
+      const int i = t + (k0 + u) * NT;
+      const long long j = (long long)p0 + i - shift;  // (outside [0, len): an offset the range check refuses -- no branch around the store)
+      const bool ok = k0 + u < C && i < nblk && j >= 0 && j < len;
+      buf_store<real>(ds, ok ? (unsigned)((unsigned long long)j * sizeof(real)) : OOB, 0u, y[u]);
+    }
   }
 }
 

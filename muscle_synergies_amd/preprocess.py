@@ -14,6 +14,8 @@ where the reference does it (``analysis.py:381-403``).  ``subsample`` and plotti
 
 from __future__ import annotations
 
+import os
+
 import ctypes
 from typing import Optional, Union
 
@@ -261,29 +263,45 @@ def sosfilt_batched(x, sos, *, zero_lag: bool = True, zero_center: bool = False,
     return out.transpose(1, 2)
 
 
-def _filter_frame(signal_df: pandas.DataFrame, sos, zero_lag: bool, inplace: bool, **pre) -> pandas.DataFrame:
+# Filter mode of the reference-facing single-frame functions (digital_filter / linear_envelope): "exact" reproduces scipy's
+# sequential recurrence bit for bit; "scan" is the time-parallel kernel (equal to scipy to ~1e-12 relative, far inside the 1e-5
+# the path is held to) -- one 20 000-sample frame: 2.5 ms -> 0.15 ms.  Set per call (``mode=``), per process
+# (:func:`set_filter_mode`) or with HIPNMF_FILTER_MODE.
+_FILTER_MODE = os.environ.get("HIPNMF_FILTER_MODE", "exact")
+
+
+def set_filter_mode(mode: str) -> None:
+    """Default filter mode of :func:`digital_filter` / :func:`linear_envelope`: ``"exact"`` (scipy's bits) or ``"scan"``."""
+    global _FILTER_MODE
+    if mode not in SOSFILT_MODES:
+        raise KeyError(mode)
+    _FILTER_MODE = mode
+
+
+def _filter_frame(signal_df: pandas.DataFrame, sos, zero_lag: bool, inplace: bool, mode: Optional[str] = None, **pre) -> pandas.DataFrame:
     # scipy filters in float64 whatever the input dtype and the reference returns that (analysis.py:414-416)
     arr = signal_df.to_numpy().astype(np.float64, copy=False)
-    vals = sosfilt_batched(arr, sos, zero_lag=zero_lag, **pre)[0].cpu().numpy()
+    vals = sosfilt_batched(arr, sos, zero_lag=zero_lag, mode=mode or _FILTER_MODE, **pre)[0].cpu().numpy()
     return _recreate(signal_df, inplace, vals)
 
 
 def digital_filter(signal_df: pandas.DataFrame, critical_freqs, sampling_frequency: int, order: int,
                    filter_type: str = "butter", band_type: str = "lowpass", zero_lag: bool = True,
-                   cheby_param: Optional[float] = None, inplace: bool = False) -> pandas.DataFrame:
+                   cheby_param: Optional[float] = None, inplace: bool = False, *, mode: Optional[str] = None) -> pandas.DataFrame:
     """Butterworth / Chebyshev I / II filter of any band type, forward-backward when ``zero_lag``
-    (``analysis.py:314-432``); every column is filtered on the GPU."""
+    (``analysis.py:314-432``); every column is filtered on the GPU.  ``mode`` (not in the reference): ``"exact"`` /
+    ``"scan"``, default :func:`set_filter_mode`'s."""
     sos = design_sos(filter_type, order, sampling_frequency, critical_freqs, band_type, cheby_param)
-    return _filter_frame(signal_df, sos, zero_lag, inplace)
+    return _filter_frame(signal_df, sos, zero_lag, inplace, mode)
 
 
 def linear_envelope(signal_df: pandas.DataFrame, critical_freqs, sampling_frequency: int, order: int,
                     filter_type: str = "butter", zero_lag: bool = True, cheby_param: Optional[float] = None,
-                    zero_center_: bool = True, inplace: bool = False) -> pandas.DataFrame:
+                    zero_center_: bool = True, inplace: bool = False, *, mode: Optional[str] = None) -> pandas.DataFrame:
     """Linear envelope of raw EMG: (optional) zero-centring, rectification, low-pass filter
-    (``analysis.py:252-311``) -- one fused GPU pass."""
+    (``analysis.py:252-311``) -- one fused GPU pass.  ``mode`` (not in the reference): ``"exact"`` / ``"scan"``."""
     sos = design_sos(filter_type, order, sampling_frequency, critical_freqs, "lowpass", cheby_param)
-    return _filter_frame(signal_df, sos, zero_lag, inplace, zero_center=zero_center_, rectify=True)
+    return _filter_frame(signal_df, sos, zero_lag, inplace, mode, zero_center=zero_center_, rectify=True)
 
 
 def linear_envelope_batched(raw, critical_freqs, sampling_frequency, order: int = 4, *, filter_type: str = "butter",

@@ -41,7 +41,7 @@ for case in range(a.cases):
         continue
     dtype = np.float64 if rng.random() < 0.65 else np.float32
     T = int(rng.choice([40, 63, 64, 65, 100, 127, 128, 129, 191, 192, 193, 500, 1000, 1333, 2048, 2500, 4097] +
-                       ([4000, 4096, 8191, 12000, 20000, 20400] if a.mode == "scan" else [])))
+                       ([4000, 4096, 8191, 12000, 20000, 20400, 20481, 33000, 40449, 61000] if a.mode == "scan" else [])))
     B = int(rng.choice([1, 2, 3, 7, 11, 17, 33]))
     m = int(rng.choice([1, 2, 3, 4, 5]))
     zero_lag = bool(rng.random() < 0.7)
