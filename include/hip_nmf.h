@@ -320,7 +320,8 @@ typedef struct hipnmf_sosfilt_params {
  *  HIPNMF_SOSFILT_SCAN   every series cut into 256 chunks filtered at once, chunk-end states combined by a scan over the workgroup
  *                        (csrc/sosfilt_scan.hpp); fp64 with fused multiply-adds, agrees with scipy to rounding times the filter's
  *                        conditioning (1e-12 relative for the reference's 6 Hz low-pass at 2 kHz; tests bound 1e-10), not bit for
- *                        bit.  Series of more than 20 480 extended samples (n_samples + 2 padlen) take the exact kernel. */
+ *                        bit.  Series longer than one workgroup holds (20 224 extended samples in float, 10 496 in double) are cut
+ *                        into blocks with a scan over the blocks' end states (any length up to 2^31 bytes per series). */
 #define HIPNMF_SOSFILT_EXACT 0
 #define HIPNMF_SOSFILT_SCAN 1
 
