@@ -293,6 +293,7 @@ CASES = {
     "sosfilt_scan": sosfilt_case(f32, 6, 6000, 16, 1, mode=1),
     "sosfilt_scan_f64": sosfilt_case(f64, 3, 12000, 4, 1, mode=1),
     "sosfilt_scan_short": sosfilt_case(f32, 40, 700, 8, 1, mode=1),      # one wave per series
+    "sosfilt_scan_long": sosfilt_case(f64, 2, 50000, 4, 1, mode=1),       # scan over blocks (five launches, workspace)
     "envelope_short": envelope_case(f32, 40, 900, 8, 41, 0),              # one wave per series
     "envelope_long_f64": envelope_case(f64, 2, 20000, 4, 200, 0),         # eight waves, the CU's whole LDS
 }
