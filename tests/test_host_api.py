@@ -202,3 +202,29 @@ def test_rank_range_concurrency_rule(monkeypatch):
     assert _ranks_concurrently(3, dict(solver="mu"), (10_000, 16)) and _ranks_concurrently(3, dict(solver="mu"), (500, 64))
     monkeypatch.setenv("HIPNMF_RANK_THREADS", "0")
     assert not _ranks_concurrently(3, dict(solver="mu"))
+
+
+def test_filter_mode_switch_of_the_single_frame_functions():
+    """digital_filter / linear_envelope keep the reference's signature and take one extra keyword, mode; the process-wide default is
+    "exact" (scipy's bits) and set_filter_mode validates its argument."""
+    import inspect
+
+    import muscle_synergies_amd as ms
+    from muscle_synergies_amd import preprocess
+
+    assert preprocess._FILTER_MODE in ("exact", "scan")
+    before = preprocess._FILTER_MODE
+    try:
+        ms.set_filter_mode("scan")
+        assert preprocess._FILTER_MODE == "scan"
+        with pytest.raises(KeyError):
+            ms.set_filter_mode("fast")
+    finally:
+        ms.set_filter_mode(before)
+    for fn, ref_names in ((ms.digital_filter, ["signal_df", "critical_freqs", "sampling_frequency", "order", "filter_type", "band_type",
+                                               "zero_lag", "cheby_param", "inplace"]),
+                          (ms.linear_envelope, ["signal_df", "critical_freqs", "sampling_frequency", "order", "filter_type", "zero_lag",
+                                                "cheby_param"])):
+        params = inspect.signature(fn).parameters
+        assert list(params)[: len(ref_names)] == ref_names  # the reference's positional order (analysis.py:252-432)
+        assert params["mode"].kind is inspect.Parameter.KEYWORD_ONLY and params["mode"].default is None
