@@ -286,7 +286,16 @@ int sosfilt_impl(hipnmf_handle* h, const hipnmf_sosfilt_params* p, const double*
   const long long blk_len = 256LL * BLK_C;
   const long long blk_nb = (L + blk_len - 1) / blk_len;
   const size_t blk_region = chunk_scan_region((size_t)blk_len, BLK_C, SCAN_THREADS, nsp_c, sizeof(real));
+  // the sequential kernels cost a dependent chain (measured ~130 / ~70 ns per sample and series, zero-lag / causal, whatever the
+  // batch up to a chip-full of 16 384 series); the block scan moves the data six / three times at ~2.2 TB/s: whichever is less
+  const double blk_exact_ms = (double)T * (zero_lag ? 130e-6 : 70e-6) * std::max(1.0, (double)N / 16384.0);
+  const double blk_scan_ms = 0.06 + (zero_lag ? 6.0 : 3.0) * (double)N * (double)T * (double)sizeof(real) / 2.2e9;
+  static const bool block_scan_force = [] {
+    const char* e = getenv("HIPNMF_SOS_BLOCK");
+    return e && atoi(e) == 2;
+  }();
   const bool use_block_scan = p->mode == HIPNMF_SOSFILT_SCAN && block_scan_ok && !use_chunk_scan && !scan_fits && blk_nb > 1 &&
+                              (blk_scan_ms < blk_exact_ms || block_scan_force) &&
                               (long long)T * (long long)sizeof(real) < (1LL << 31) && L * (long long)sizeof(real) < (1LL << 31) &&
                               N * blk_nb < (1LL << 31) && blk_region + 64 <= (size_t)h->lds_per_block;
   const size_t o_fwd = (use_block_scan && zero_lag) ? carve(sizeof(real) * (size_t)N * (size_t)L) : 0;
