@@ -102,6 +102,12 @@ int launch_chunk_scan(hipnmf_handle* h, const SosArgs& a, int ns, int C, int NT,
     hipLaunchKernelGGL(kern, dim3((unsigned)a.N), dim3(NT), smem, st, a, (const double*)tab, ns, (int)region);
     return HIPNMF_OK;
   };
+  if (NT == 512) {
+    if constexpr (sizeof(real) == 8 && NSP <= 4) {
+      if (C == 41) return go(sosfilt_chunk_kernel<real, NSP, 41, 512>);
+    }
+    return HIPNMF_ERR_UNSUPPORTED;
+  }
   if (NT == 64) {
     if constexpr (NSP <= 4) {
       if (C == 5) return go(sosfilt_chunk_kernel<real, NSP, 5, 64>);
@@ -274,6 +280,17 @@ int sosfilt_impl(hipnmf_handle* h, const hipnmf_sosfilt_params* p, const double*
       }
     }
   }
+  // float64 beyond 256 x 41 extended samples: eight waves and the CU's whole LDS for one series (HIPNMF_SOS_CHUNK_512=0: the first
+  // version's two-pass loading)
+  static const bool chunk_512_ok = [] {
+    const char* e = getenv("HIPNMF_SOS_CHUNK_512");
+    return !(e && atoi(e) == 0);
+  }();
+  if (sizeof(real) == 8 && chunk_c == 0 && p->mode == HIPNMF_SOSFILT_SCAN && chunk_scan_ok && chunk_512_ok && nsp_c <= 4 && L <= 512LL * 41 &&
+      L > 16800) {  // (below ~80 % of the 20 992 positions the idle threads cost more than the two-pass loading: 14 000 samples 2.29 vs 2.21 ms)
+    chunk_c = 41;
+    chunk_nt = 512;
+  }
   const size_t chunk_region = chunk_c ? chunk_scan_region((size_t)L, chunk_c, chunk_nt, nsp_c, sizeof(real)) : 0;
   const bool use_chunk_scan = chunk_c > 0 && chunk_region + 64 <= (size_t)h->lds_per_block;
   // long series: blocks of 256 chunks per workgroup, a scan over the blocks (sosfilt_block_kernel); HIPNMF_SOS_BLOCK=0: the
@@ -361,8 +378,8 @@ int sosfilt_impl(hipnmf_handle* h, const hipnmf_sosfilt_params* p, const double*
          : ns <= 4 ? launch_chunk_scan<real, 4>(h, a, ns, chunk_c, chunk_nt, chunk_region, tab, st)
                    : launch_chunk_scan<real, 8>(h, a, ns, chunk_c, chunk_nt, chunk_region, tab, st);
     if (rc) return rc;
-    if (chunk_nt == 64)
-      snprintf(h->last_kernel, sizeof(h->last_kernel), "sosfilt_chunk_kernel<%s,%d,%d,64>", sizeof(real) == 4 ? "float" : "double", nsp_c, chunk_c);
+    if (chunk_nt != SCAN_THREADS)
+      snprintf(h->last_kernel, sizeof(h->last_kernel), "sosfilt_chunk_kernel<%s,%d,%d,%d>", sizeof(real) == 4 ? "float" : "double", nsp_c, chunk_c, chunk_nt);
     else
       snprintf(h->last_kernel, sizeof(h->last_kernel), "sosfilt_chunk_kernel<%s,%d,%d>", sizeof(real) == 4 ? "float" : "double", nsp_c, chunk_c);
     HIP_TRY(hipGetLastError());

@@ -533,7 +533,8 @@ sosfilt_scan_kernel(SosArgs a, const double* __restrict__ tab, int ns) {
 // two workgroups per CU).  The odd extension is built in LDS from the centred samples by the first / last `edge` threads.
 // float and double up to 256 x 79 / 256 x 41 extended samples; anything else takes sosfilt_scan_kernel or the sequential kernels.
 // NT = 64: one wave per series (short series: up to 64 x 41 extended samples; with 256 threads a 1 000-sample series kept 61 of
-// them busy) -- the scan's cross-wave phases and the workgroup-wide steps fall away.
+// them busy) -- the scan's cross-wave phases and the workgroup-wide steps fall away.  NT = 512: float64 series of up to 512 x 41
+// extended samples with the CU's whole LDS for one series (20 000 doubles fit the 160 KB).
 template <typename real, int NSP, int C, int NT = SCAN_THREADS>
 __global__ void __launch_bounds__(NT, (C > 32 ? (NSP > 4 ? 1 : 2) : (NSP > 4 ? 2 : 4)))
 sosfilt_chunk_kernel(SosArgs a, const double* __restrict__ tab, int ns, int region_bytes) {
@@ -587,7 +588,10 @@ sosfilt_chunk_kernel(SosArgs a, const double* __restrict__ tab, int ns, int regi
       for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
       if (lane == 0) misc[wave] = sum;
       __syncthreads();
-      mean = (real)((NT == 64 ? misc[0] : ((misc[0] + misc[1]) + (misc[2] + misc[3]))) / (double)T);
+      double tot = misc[0];
+      if constexpr (NT >= 256) tot = (misc[0] + misc[1]) + (misc[2] + misc[3]);
+      if constexpr (NT == 512) tot += (misc[4] + misc[5]) + (misc[6] + misc[7]);
+      mean = (real)(tot / (double)T);
     }
 #pragma unroll
     for (int k = 0; k < C; ++k) {

@@ -285,6 +285,8 @@ def test_gpu_scan_mode_kernel_choice_and_shapes_of_the_second_version(g8):
                                    (10496 - 29, np.float64, None, "sosfilt_block_kernel<double,2,41>"),  # odd length: the first version does not take it, two blocks do
                                    (20224 - 30, np.float32, None, "sosfilt_chunk_kernel<float,2,79>"),
                                    (20224 - 28, np.float32, None, "sosfilt_scan_kernel<float,2,80>"),
+                                   (20000, np.float64, None, "sosfilt_chunk_kernel<double,2,41,512>"),  # eight waves, the CU's whole LDS
+                                   (16000, np.float64, None, "sosfilt_scan_kernel<double,2,80>"),         # below 80 % of its positions: the first version
                                    (20224 - 27, np.float32, None, "sosfilt_block_kernel<float,2,79>"),
                                    (3001, np.float32, 700, "sosfilt_chunk_kernel<float,2,25>"),
                                    (16640 - 30, np.float32, None, "sosfilt_chunk_kernel<float,2,65>"),
