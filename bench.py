@@ -68,6 +68,9 @@ def parse_args():
                     help="no GPU work: the rank plumbing only (spawn / rendezvous / barrier / max over ranks / one JSON line) "
                          "over gloo on the CPU; the line is marked as such and is not a measurement")
     ap.add_argument("--cpu-sample", type=int, default=0, help="matrices in the CPU baseline sample (0 = auto)")
+    ap.add_argument("--dry-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)  # tests: this rank dies before the rendezvous
+    ap.add_argument("--no-parity", action="store_true", help="skip the in-run parity check of the last timed step's output")
+    ap.add_argument("--launch-timeout", type=float, default=3600.0, help="--gpus N launcher: seconds before the ranks are ended")
     return ap.parse_args()
 
 
@@ -165,6 +168,80 @@ def cpu_baseline(a):
 
 
 # ------------------------------------------------------------------------------------------------
+# In-run parity: a few matrices of the LAST timed step's output against scikit-learn (the dependency that holds the
+# reference's arithmetic, sklearn/decomposition/_nmf.py:731-893) from the same W0/H0, in CPU worker processes that
+# were started before this process touched the GPU.  Checker leg only: nothing here is timed or shipped.
+PARITY_TOL = 1e-5  # BASELINE.json north_star: 1e-5 relative Frobenius error; SURVEY.md 8c: |d(WH)|_F / |X|_F and |d err| / |X|_F
+
+
+def _parity_noop(_):
+    try:
+        import sklearn.decomposition  # noqa: F401 -- page the import in while the GPU works
+    except Exception:  # noqa: BLE001
+        pass
+    return 0
+
+
+def _parity_worker(job):
+    X, W0, H0, iters, loss = job
+    import warnings
+
+    import numpy as np
+
+    warnings.simplefilter("ignore")
+    try:
+        from sklearn.decomposition import NMF
+
+        mdl = NMF(H0.shape[0], solver="mu", init="custom", tol=0, max_iter=iters, beta_loss=loss)
+        W = mdl.fit_transform(X, W=W0.copy(), H=H0.copy())
+        return "scikit-learn", W, mdl.components_, float(mdl.reconstruction_err_)
+    except ImportError:
+        from oracle import nmf_mu_oracle as orc  # the checker may stand in for the absent dependency
+
+        r = orc.nmf_mu_fit(X, W0, H0, max_iter=iters, tol=0.0)
+        return "oracle", np.asarray(r["W"]), np.asarray(r["H"]), float(r["reconstruction_err"])
+
+
+class ParityChecker:
+    def __init__(self, enabled):
+        self.pool = None
+        if enabled:
+            import multiprocessing as mp
+
+            self.pool = mp.get_context("spawn").Pool(4)
+            self._warm = self.pool.map_async(_parity_noop, range(4))
+
+    def check(self, jobs, ours):
+        """jobs: [(X [T, m], W0, H0, iters, loss)] NumPy; ours: [(W or None, H, err)].  Returns the ``parity`` object."""
+        import numpy as np
+
+        if self.pool is None:
+            return None
+        ref = self.pool.map(_parity_worker, jobs)
+        d_wh, d_err, d_h, checker = 0.0, 0.0, 0.0, None
+        for (X, _w0, _h0, _it, _loss), (W, H, err), (who, Wr, Hr, err_r) in zip(jobs, ours, ref):
+            checker = who
+            xn = float(np.linalg.norm(X.astype(np.float64)))
+            Hd = H.astype(np.float64)
+            if W is not None:
+                d_wh = max(d_wh, float(np.linalg.norm(W.astype(np.float64) @ Hd - Wr.astype(np.float64) @ Hr.astype(np.float64))) / xn)
+            d_h = max(d_h, float(np.linalg.norm(Hd - Hr) / max(np.linalg.norm(Hr), 1e-300)))
+            d_err = max(d_err, abs(float(err) - err_r) / xn)
+        ok = bool(d_wh <= PARITY_TOL and d_err <= PARITY_TOL and np.isfinite(d_wh) and np.isfinite(d_err))
+        return {"n_checked": len(jobs), "max_rel_dWH": d_wh, "max_rel_derr": d_err, "max_rel_dH": d_h, "tol": PARITY_TOL,
+                "ok": ok, "checker": checker,
+                "what": "matrices of the last timed step's output vs the checker's fit from the same W0/H0 at the same iteration "
+                        "count: |W H - W_ref H_ref|_F / |X|_F and |err - err_ref| / |X|_F (max_rel_dH is informational: the "
+                        "factors themselves drift ~1e-3 at 500 fp32 iterations under ANY change of summation order, SURVEY.md 8c)"}
+
+    def close(self):
+        if self.pool is not None:
+            self.pool.terminate()
+            self.pool.join()
+            self.pool = None
+
+
+# ------------------------------------------------------------------------------------------------
 class Ctx:
     """Rank / device / process-group plumbing shared by the configurations."""
 
@@ -180,34 +257,52 @@ class Ctx:
         import torch
 
         self.torch = torch
+        self.backend = None
         if self.dry:  # rank plumbing only: gloo on the CPU, nothing touches a GPU
             self.dev = torch.device("cpu")
-            if self.distributed:
-                import torch.distributed as dist
-
-                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-                dist.init_process_group(backend="gloo")
-                self.dist = dist
-            return
-        if not torch.cuda.is_available():
-            raise SystemExit("bench.py needs an MI355X: no ROCm GPU visible (the engine has no CPU fallback)")
-        torch.cuda.set_device(self.local_rank)
-        self.dev = torch.device("cuda", self.local_rank)
+        else:
+            # every rank checks ITS device (the launcher parent stays free of GPU libraries) and exits non-zero without one
+            n = torch.cuda.device_count()
+            if n <= self.local_rank or not torch.cuda.is_available():
+                raise SystemExit(f"bench.py rank {self.rank}: needs ROCm GPU index {self.local_rank}, {n} visible (the engine has "
+                                 f"no CPU fallback; a {self.world}-GPU number is never reported from fewer devices)")
+            torch.cuda.set_device(self.local_rank)
+            self.dev = torch.device("cuda", self.local_rank)
         if self.distributed:
             import torch.distributed as dist
 
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            dist.init_process_group(backend="nccl", device_id=self.dev)
+            # RCCL only where the data path has a collective (config 5: one all-reduce per iteration).  Configs 2/3/4 share
+            # nothing between ranks: their timing barrier and the max over ranks of one float64 go over gloo on the CPU,
+            # so the scaling record of the embarrassingly parallel configurations does not depend on RCCL coming up.
+            self.backend = "nccl" if (self.a.config == 5 and not self.dry) else "gloo"
+            if self.backend == "nccl":
+                dist.init_process_group(backend="nccl", device_id=self.dev)
+            else:
+                dist.init_process_group(backend="gloo")
             self.dist = dist
 
     def sync(self):
         if not self.dry:
             self.torch.cuda.synchronize(self.dev)
 
+    def _coll_dev(self):
+        return self.dev if self.backend == "nccl" else self.torch.device("cpu")
+
     def barrier(self):
+        """Device work of every rank finished, then all ranks met, then (nccl: the barrier's own kernel) drained."""
+        self.sync()
         if self.distributed:
             self.dist.barrier()
         self.sync()
+
+    def ranks_seen(self):
+        """Number of ranks that took part (sum of ones over the group): in the JSON line as evidence of the launch."""
+        if not self.distributed:
+            return 1
+        t = self.torch.ones(1, dtype=self.torch.int64, device=self._coll_dev())
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return int(t.item())
 
     def timed(self, step):
         """W untimed warm-up steps, then EXACTLY K steps between barrier + synchronize, max over ranks."""
@@ -221,7 +316,7 @@ class Ctx:
         elapsed = time.perf_counter() - t0
         self.barrier()
         if self.distributed:
-            t = self.torch.tensor([elapsed], dtype=self.torch.float64, device=self.dev)
+            t = self.torch.tensor([elapsed], dtype=self.torch.float64, device=self._coll_dev())
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
             elapsed = float(t.item())
         return elapsed, outs
@@ -269,6 +364,18 @@ def _matrix_pipe(kernel, tf, m, k):
             "issued_tflops": tf * (16.0 / k) * ((m + 15) // 16 * 16 + 16.0) / (m + k),
             "note": "all four contractions on v_mfma_f32_16x16x4_f32 with components padded to 16 and "
                     "channels to a multiple of 16 (issued = useful x padding)"}
+
+
+def _bound_detail(kernel):
+    """Which pipe does the fp32 work of this kernel family (f32 VALU peak = f32 MFMA peak = 157.3 TFLOP/s on gfx950)."""
+    if kernel.startswith("fit_rowlane") or "rowlane" in kernel:
+        return ("fp32 issue: nmf_rowlane.hpp puts the two T-long contractions on v_mfma_f32_4x4x1_16b_f32 and keeps the row-local "
+                "products on the VALU; both pipes peak at 157.3 TFLOP/s fp32")
+    if kernel.startswith(("fit_persistent", "fit_small", "fit_coop", "slice_pass_kernel")):
+        return ("fp32 issue, VALU only: nmf_kernels.hpp / nmf_small.hpp use v_fma_f32 / v_pk_fma_f32 with DPP reductions and no "
+                "MFMA (k <= 5 x 16 channels lost the round-2 shoot-out on the matrix pipe); f32 VALU peak = f32 MFMA peak = "
+                "157.3 TFLOP/s on gfx950")
+    return "fp32 issue (f32 MFMA = f32 VALU = 157.3 TFLOP/s on gfx950)"
 
 
 def compute_roofline(kernel, kernel_ms, units_per_launch, T, m, k, traffic=None, moved_bytes_per_unit=None, stream_gbs=None):
@@ -326,7 +433,7 @@ def compute_roofline(kernel, kernel_ms, units_per_launch, T, m, k, traffic=None,
                 "memory": mem}
     return {
         "bound": "fp32_issue",
-        "bound_detail": "fp32 issue: f32 MFMA = f32 VALU = 157.3 TFLOP/s on gfx950 (the kernels use both)",
+        "bound_detail": _bound_detail(kernel),
         "achieved": tf,
         "peak": FP32_PEAK_TFLOPS,
         "unit": "TFLOP/s",
@@ -390,6 +497,14 @@ def run_batch(cx, single):
     if cx.rank != 0:
         return None
     r = outs[-1]
+    parity = None
+    if cx.parity is not None:  # matrices spread over the batch, from the LAST timed step's output
+        idx = sorted({int(round(i * (B - 1) / 3)) for i in range(4)})
+        host = lambda t: t.detach().cpu().numpy()  # noqa: E731
+        jobs = [(host(Xr[i]), host(W0[i]), host(H0[i]), a.iters, "frobenius") for i in idx]
+        ours = [(host(r.W[i]), host(r.H[i]), float(r.reconstruction_err[i])) for i in idx]
+        parity = cx.parity.check(jobs, ours)
+        parity["matrices"] = idx
     units_per_launch = B * a.iters
     avg_ms = sum(kernel_ms) / len(kernel_ms)
     layout = "row-major [B][T][m] (C order)" if a.x_layout == "row" else "channel-major [B][m][T] (F order)"
@@ -418,7 +533,7 @@ def run_batch(cx, single):
             stream = handle.stream_gbs(region, B, 20)
         except Exception as e:  # noqa: BLE001 -- a diagnostic must not cost the benchmark line
             cfg["stream_peak_error"] = str(e)
-    return {"units": cx.world * B * a.iters * a.steps, "elapsed": elapsed, "scaling": "weak", "config": cfg,
+    return {"units": cx.world * B * a.iters * a.steps, "elapsed": elapsed, "scaling": "weak", "config": cfg, "parity": parity,
             "roofline": compute_roofline(kernel, avg_ms, units_per_launch, a.T, a.m, a.k, traffic, moved, stream)}
 
 
@@ -461,6 +576,27 @@ def run_rank_sweep(cx):
     if cx.rank != 0:
         return None
     r = outs[-1]
+    parity = None
+    if cx.parity is not None:
+        # the timed sweep draws W0/H0 with random_init_batched(X, k, seed + k): the same call gives the same factors again
+        from muscle_synergies_amd.engine import random_init_batched
+
+        rw = ms.rank_sweep_batched(Xv, kmin, kmax, vaf_threshold=0.90, max_iter=a.iters, tol=0.0, seed=1, device=cx.dev, keep_W=True)
+        host = lambda t: t.detach().cpu().numpy()  # noqa: E731
+        jobs, ours, what = [], [], []
+        for k in sorted({kmin, (kmin + kmax) // 2, kmax}):
+            W0k, H0k = random_init_batched(Xv, k, seed=1 + k)
+            for i in sorted({0, B - 1}):
+                jobs.append((host(Xv[i]), host(W0k[i]), host(H0k[i]), a.iters, "frobenius"))
+                ours.append((host(rw.W[k][i]), host(rw.components[k][i]), float(rw.reconstruction_err[k][i])))
+                what.append([i, k])
+            del W0k, H0k
+        same = all(bool(torch.equal(rw.reconstruction_err[k], r.reconstruction_err[k])) for k in r.ranks)
+        del rw
+        parity = cx.parity.check(jobs, ours)
+        parity["trial_rank_pairs"] = what
+        parity["untimed_rerun_bitwise_equal_to_last_timed_step"] = same
+        parity["ok"] = bool(parity["ok"] and same)
     nk = kmax - kmin + 1
     r_all, t_all = native[False]
     r_stop, t_stop = native[True]
@@ -470,7 +606,7 @@ def run_rank_sweep(cx):
     fl = sum(flops_per_unit(a.T, a.m, k) for k in range(kmin, kmax + 1)) * B * a.iters
     tf = fl / (avg_ms * 1e-3) / 1e12
     hist = torch.bincount(r.selected.clamp(min=0), minlength=kmax + 1).tolist()
-    return {"units": total * nk * a.iters * a.steps, "elapsed": elapsed, "scaling": "strong",
+    return {"units": total * nk * a.iters * a.steps, "elapsed": elapsed, "scaling": "strong", "parity": parity,
             "config": {"workload": (f"rank sweep k={kmin}..{kmax} ({a.iters} mu iterations each, random init drawn on the "
                                     f"device, smallest k with VAF >= 0.90 selected) over {total} synthetic EMG trials "
                                     f"{a.m} ch x {a.T} samples in total, fp32 (BASELINE.json configs[3])"),
@@ -512,11 +648,20 @@ def run_tsharded(cx):
     torch.cuda.synchronize(cx.dev)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     pass_ms = []
+    coll = {"calls": 0, "elements": 0, "max_elements": 0}
+
+    def counted_all_reduce(t):
+        coll["calls"] += 1
+        coll["elements"] += t.numel()
+        coll["max_elements"] = max(coll["max_elements"], t.numel())
+        if cx.distributed:
+            cx.dist.all_reduce(t, op=cx.dist.ReduceOp.SUM)
+        return t
 
     def step():
         # the solver runs on torch's current stream (handles are bound to it), so torch events see its kernels
         ev[0].record()
-        r = fit_tsharded(ops, max_iter=a.iters5, tol=0.0)
+        r = fit_tsharded(ops, max_iter=a.iters5, tol=0.0, all_reduce=counted_all_reduce)
         ev[1].record()
         torch.cuda.synchronize(cx.dev)
         pass_ms.append(ev[0].elapsed_time(ev[1]))
@@ -526,6 +671,19 @@ def run_tsharded(cx):
     if cx.rank != 0:
         return None
     r = outs[-1]
+    parity = None
+    if cx.parity is not None:
+        # a 2e8-row matrix cannot go through scikit-learn: the same entry points, kernels and loop on a 200 000-row
+        # replica of the recording (sub-shard 0's generator), rank 0 alone, against the checker at the same iteration count
+        Tp = 200_000
+        Xp, Wp, Hp = emg_shard_torch(5, 0, Tp, m=m, k=k, device=cx.dev)
+        host = lambda t: t.detach().cpu().numpy()  # noqa: E731
+        job = (host(Xp[0].t().contiguous()), host(Wp[0].t().contiguous()), host(Hp[0]), a.iters5, "frobenius")
+        rp = fit_tsharded(HipShardOps.from_native(Xp, Wp, Hp.clone()), max_iter=a.iters5, tol=0.0, all_reduce=lambda t: t)
+        parity = cx.parity.check([job], [(host(rp.W_local[0]), host(rp.H[0]), float(rp.reconstruction_err[0]))])
+        parity["what"] = (f"a {Tp}-row replica (sub-shard 0's generator) through the same shard entry points on rank 0 alone, "
+                          f"{a.iters5} iterations, " + parity["what"])
+        del Xp, Wp, Hp, rp
     pass_ms = pass_ms[a.warmup:]
     by = 4 * T * (m + 2 * k)  # per iteration of the whole matrix
     rows_rank0 = hi - lo
@@ -544,7 +702,14 @@ def run_tsharded(cx):
     it_ms = ev[0].elapsed_time(ev[1]) / 10
     step_it_ms = (sum(pass_ms) / len(pass_ms)) / a.iters5  # includes 1 / iters5 of the final residual pass
     achieved = by_rank / (it_ms * 1e-3) / 1e9
-    return {"units": a.iters5 * a.steps, "elapsed": elapsed, "scaling": "strong",
+    n_fit = a.steps + a.warmup
+    return {"units": a.iters5 * a.steps, "elapsed": elapsed, "scaling": "strong", "parity": parity,
+            "collective": {"backend": (cx.backend + (" (RCCL over xGMI)" if cx.backend == "nccl" else "")) if cx.distributed else "none (single rank)",
+                           "all_reduce_calls_per_fit": coll["calls"] // n_fit,
+                           "all_reduce_elements_per_iteration": k * m + k * k,
+                           "all_reduce_elements_issued_per_fit": coll["elements"] // n_fit,
+                           "largest_all_reduce_elements": coll["max_elements"],
+                           "note": f"per fit: {a.iters5} x ({k * m} + {k * k}) floats for the H update + one 2 x {m} residual/VAF reduction at the end"},
             "config": {"workload": (f"ONE synthetic EMG matrix {m} ch x {T} samples, k={k}, fp32, rows sharded over "
                                     f"{cx.world} GPU(s) ({rows_rank0} rows on rank 0 in {len(shards)} sub-shard(s)), "
                                     f"{a.iters5} mu iterations per step, tol=0 (BASELINE.json configs[4])"),
@@ -581,7 +746,7 @@ def run_dry(cx):
         return None
     return {"units": cx.world * B * a.iters * a.steps, "elapsed": elapsed, "scaling": "weak",
             "config": {"workload": "DRY ORCHESTRATION: no GPU work, a sleep per step (rank plumbing check only)",
-                       "global_batch": B * cx.world, "ranks_seen": cx.world}, "roofline": None}
+                       "global_batch": B * cx.world}, "roofline": None}
 
 
 def _free_port():
@@ -594,31 +759,48 @@ def _free_port():
 
 def launch_ranks(a):
     """``python bench.py --gpus N`` without a torchrun environment: start N fresh rank processes (one per GPU, rendezvous on
-    127.0.0.1) and relay rank 0's JSON line.  The parent never touches a GPU (``device_count`` does not initialise one) and
-    nothing is exec'ed from a process that has: the ranks are children, their exit codes are ours."""
+    127.0.0.1) and relay rank 0's JSON line.  The parent imports no GPU library at all (every rank checks its own device and
+    exits non-zero without one) and nothing is exec'ed from a process that has touched a GPU: the ranks are children, their
+    exit codes are ours.  All ranks are polled: the first non-zero exit (or the deadline) ends the others."""
     import subprocess
+    import tempfile
 
-    if not a.dry_orchestration:
-        import torch
-
-        n = torch.cuda.device_count()
-        if n < a.gpus:
-            raise SystemExit(f"bench.py --gpus {a.gpus}: only {n} ROCm GPU(s) visible; refusing to report a {a.gpus}-GPU "
-                             f"number from fewer devices")
     port = _free_port()
     procs = []
+    out0 = tempfile.TemporaryFile(mode="w+")
     for r in range(a.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HIPNMF_BENCH_CHILD="1")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    lines = [ln for ln in (out0 or "").splitlines() if ln.startswith("{")]
-    if any(codes) or len(lines) != 1:
-        sys.stdout.write(out0 or "")
-        raise SystemExit(f"bench.py --gpus {a.gpus}: rank exit codes {codes}, {len(lines)} JSON line(s) from rank 0")
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL, text=True))
+    deadline = time.monotonic() + a.launch_timeout
+    failed = None
+    while True:
+        codes = [p.poll() for p in procs]
+        if all(c is not None for c in codes):
+            break
+        bad = [i for i, c in enumerate(codes) if c not in (None, 0)]
+        if bad or time.monotonic() > deadline:
+            failed = (f"rank {bad[0]} exited with code {codes[bad[0]]}" if bad else f"no result within --launch-timeout {a.launch_timeout} s")
+            for p in procs:  # exactly the processes started above
+                if p.poll() is None:
+                    p.terminate()
+            for p in procs:
+                try:
+                    p.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+                    p.wait()
+            break
+        time.sleep(0.05)
+    codes = [p.returncode for p in procs]
+    out0.seek(0)
+    text = out0.read()
+    lines = [ln for ln in text.splitlines() if ln.startswith("{")]
+    if failed or any(codes) or len(lines) != 1:
+        sys.stdout.write(text)
+        raise SystemExit(f"bench.py --gpus {a.gpus}: {failed or 'failed'}; rank exit codes {codes}, {len(lines)} JSON line(s) from rank 0")
     print(lines[0], flush=True)
 
 
@@ -629,12 +811,18 @@ def main():
     if a.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         return launch_ranks(a)  # invoked directly: be the launcher (under torchrun the environment is there already)
     cx = Ctx(a)
+    if a.dry_orchestration and a.dry_fail_rank == cx.rank:
+        raise SystemExit(7)
     if cx.world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={cx.world}: start one rank per GPU (python bench.py --gpus N does "
                          f"that by itself when no launcher environment is present)")
     cpu = None
     if cx.rank == 0 and cx.world == 1 and not a.no_cpu_baseline and not a.dry_orchestration:
         cpu = cpu_baseline(a)  # before the GPU is initialised (spawns worker processes)
+    # in-run parity checker (rank 0): its CPU workers start before this process touches the GPU
+    cx.parity = ParityChecker(cx.rank == 0 and not a.no_parity and not a.dry_orchestration)
+    if cx.parity.pool is None:
+        cx.parity = None
     cx.init_gpu()
     if a.dry_orchestration:
         res = run_dry(cx)
@@ -646,7 +834,9 @@ def main():
         res = run_rank_sweep(cx)
     else:
         res = run_tsharded(cx)
+    seen = cx.ranks_seen()
     if cx.rank == 0:
+        parity = res.get("parity")
         out = {
             "metric": "NMF mu-iters/sec",
             "value": res["units"] / res["elapsed"],
@@ -663,9 +853,18 @@ def main():
             "config": res["config"],
             "roofline": res["roofline"],
             "cpu_baseline": cpu,
+            "parity": parity,
+            "ranks_seen": seen,
+            "process_group_backend": cx.backend,
         }
+        if "collective" in res:
+            out["collective"] = res["collective"]
         print(json.dumps(out), flush=True)
+    if cx.parity is not None:
+        cx.parity.close()
     cx.finish()
+    if cx.rank == 0 and res.get("parity") is not None and not res["parity"]["ok"]:
+        raise SystemExit("bench.py: the in-run parity check FAILED (see \"parity\" in the JSON line): the number above is not valid")
 
 
 if __name__ == "__main__":

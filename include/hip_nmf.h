@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define HIPNMF_VERSION 200 /* 0.2.0: round 3 grew hipnmf_envelope_params and added hipnmf_rank_sweep_stop_*; round 4 added hipnmf_sosfilt_params.mode */
+#define HIPNMF_VERSION 210 /* 0.2.1: round 5 added HIPNMF_W_ROW_MAJOR_PAD16 (the shard entry points no longer read plain W_ROW_MAJOR as padded); 0.2.0: round 3 grew hipnmf_envelope_params and added hipnmf_rank_sweep_stop_*, round 4 added hipnmf_sosfilt_params.mode */
 
 #define HIPNMF_OK 0
 #define HIPNMF_ERR_BAD_ARG (-1)
@@ -52,6 +52,8 @@ extern "C" {
 /* memory layout of one W matrix (ldw / batch stride are implied: contiguous) */
 #define HIPNMF_W_ROW_MAJOR 0       /* W[t*k + c]  (T x k, C order: what sklearn returns)               */
 #define HIPNMF_W_COMPONENT_MAJOR 1 /* W[c*T + t]  (k x T: the engine's native streaming layout)        */
+#define HIPNMF_W_ROW_MAJOR_PAD16 2 /* W[t*KP + c], KP = n_components rounded up to a multiple of 16, columns >= n_components zero:
+                                    * the general-shape kernels' layout; hipnmf_shard_* / hipnmf_fit_tsharded_* only (version 210) */
 
 /* objective (sklearn's beta_loss, _nmf.py:1397-1401) */
 #define HIPNMF_LOSS_FROBENIUS 0 /* 'frobenius' (beta = 2): the reference's default, every entry point          */
@@ -164,9 +166,10 @@ int hipnmf_fit_ragged_f64(hipnmf_handle* h, const hipnmf_problem* p, const int64
  * Up to 32 channels and 8 components the shard entry points require p->w_layout == HIPNMF_W_COMPONENT_MAJOR and channel-major X
  * with ldx % 4 == 0 (no per-call layout conversion on the per-iteration path).  Beyond (round 4: up to 512 x 64, Frobenius) they
  * run on the general-shape kernels and require p->x_layout == HIPNMF_X_ROW_MAJOR with 16-byte aligned rows (ldx * sizeof % 16
- * == 0) and p->w_layout == HIPNMF_W_ROW_MAJOR with W stored as [n_samples][KP], KP = n_components rounded up to 16, the padding
- * columns zero (they stay zero); sums keeps the [k*m + k*k] layout: W^T X (k x m) then W^T W (k x k).
- * Those layouts select the general-shape kernels for narrow shapes too.
+ * == 0; the padding columns n_features..ldx-1 of X MUST be zero: they are read) and p->w_layout == HIPNMF_W_ROW_MAJOR_PAD16: W stored
+ * as [n_samples][KP], KP = n_components rounded up to 16, the padding columns zero (they stay zero); sums keeps the
+ * [k*m + k*k] layout: W^T X (k x m) then W^T W (k x k).  HIPNMF_W_ROW_MAJOR_PAD16 selects the general-shape kernels for narrow
+ * shapes too; plain HIPNMF_W_ROW_MAJOR ([n_samples][n_components]) is HIPNMF_ERR_UNSUPPORTED on every shard entry point.
  * HIPNMF_LOSS_KL (round 4): always the general-shape kernels and their layouts, whatever the shape; sums = [W^T (X / WH) (k x m) |
  * colsum(W) in column 0 of the k x k block]; hipnmf_shard_residual returns the generalised Kullback-Leibler divergence per
  * column in sse_col (reconstruction_err_ = sqrt(2 * the sum over shards and columns)) -- call it with loss = FROBENIUS for the

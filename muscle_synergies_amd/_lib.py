@@ -30,6 +30,7 @@ X_ROW_MAJOR = 0
 X_CHANNEL_MAJOR = 1
 W_ROW_MAJOR = 0
 W_COMPONENT_MAJOR = 1
+W_ROW_MAJOR_PAD16 = 2  # [T][round_up(k, 16)], zero padding: general-shape shard entry points only
 
 #: every symbol ``include/hip_nmf.h`` declares (checked by tests/test_abi.py)
 EXPORTS = (

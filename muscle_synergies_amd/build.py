@@ -107,7 +107,9 @@ def lint_isa(srcs, objdir: str = OBJ, verbose: bool = False) -> None:
               f"{len(bad)} defective reload(s)", flush=True)
     if bad:
         raise RuntimeError("hipcc emitted the split-spill defect (a 64-bit value reloaded by halves from scratch and an AGPR, one half "
-                           "missing): refusing the library.\n" + "\n".join(f"{n}: {p}" for _, n, p in bad))
+                           "missing): refusing the library.  (The check is a pattern match on the assembly's spill comments; if it "
+                           "misfires on another hipcc, HIPNMF_SKIP_ISA_LINT=1 builds without it.)\n"
+                           + "\n".join(f"{n}: {p}" for _, n, p in bad))
 
 
 def build(force: bool = False, jobs: int | None = None, extra_flags=(), verbose: bool = False,
@@ -159,7 +161,10 @@ def build(force: bool = False, jobs: int | None = None, extra_flags=(), verbose:
         if verbose:
             print(f"[build] linked {lib}", flush=True)
     if not variant:
-        lint_isa(srcs, objdir, verbose)
+        # the lint reads the assembly of the translation units THIS call compiled (an up-to-date library was linted when it
+        # was built); HIPNMF_SKIP_ISA_LINT=1 is the escape hatch for a toolchain whose comment format the patterns misread
+        if todo and os.environ.get("HIPNMF_SKIP_ISA_LINT") != "1":
+            lint_isa(todo, objdir, verbose)
         _record(lib, srcs, todo, linked, verbose, record_profile)
     return lib
 

@@ -191,8 +191,10 @@ int validate(const hipnmf_problem* p, bool shard, bool ragged = false) {
                 p->n_features, HIPNMF_MAX_FEATURES, p->n_components, HIPNMF_MAX_COMPONENTS);
   if (p->x_layout != HIPNMF_X_ROW_MAJOR && p->x_layout != HIPNMF_X_CHANNEL_MAJOR)
     return fail(HIPNMF_ERR_BAD_ARG, "bad x_layout %d", p->x_layout);
-  if (p->w_layout != HIPNMF_W_ROW_MAJOR && p->w_layout != HIPNMF_W_COMPONENT_MAJOR)
+  if (p->w_layout != HIPNMF_W_ROW_MAJOR && p->w_layout != HIPNMF_W_COMPONENT_MAJOR && p->w_layout != HIPNMF_W_ROW_MAJOR_PAD16)
     return fail(HIPNMF_ERR_BAD_ARG, "bad w_layout %d", p->w_layout);
+  if (p->w_layout == HIPNMF_W_ROW_MAJOR_PAD16 && !shard)
+    return fail(HIPNMF_ERR_UNSUPPORTED, "w_layout = HIPNMF_W_ROW_MAJOR_PAD16 is a layout of the hipnmf_shard_* / hipnmf_fit_tsharded_* entry points only");
   if (p->loss != HIPNMF_LOSS_FROBENIUS && p->loss != HIPNMF_LOSS_KL)
     return fail(HIPNMF_ERR_BAD_ARG, "bad loss %d", p->loss);
   if (!ragged) {  // the ragged entry points take leading dimension and offsets per matrix from the descriptors
@@ -851,12 +853,14 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
 
 // ---- shard building blocks ------------------------------------------------------------------------
 // beyond the narrow lane mappings (32 channels / 8 components), for the Kullback-Leibler loss whatever the shape, and for any
-// caller that hands over the general-shape kernels' layouts (row-major X and W: e.g. the squared-error residual of a
-// Kullback-Leibler fit of a narrow recording), the building blocks run on the general-shape kernels (hipnmf_wide.hip)
+// caller that names the general-shape kernels' W layout (HIPNMF_W_ROW_MAJOR_PAD16: e.g. the squared-error residual of a
+// Kullback-Leibler fit of a narrow recording), the building blocks run on the general-shape kernels (hipnmf_wide.hip).
+// Plain HIPNMF_W_ROW_MAJOR ([T][k], what hipnmf_fit_batched_* means by it) never selects them: a [T][k] buffer read with a
+// stride of round_up(k, 16) would be an out-of-bounds access the library cannot detect (round-4 advisor finding).
 inline bool shard_is_wide(const hipnmf_problem* p) {
   return p && p->struct_size == (int32_t)sizeof(hipnmf_problem) &&
          (p->n_features > HIPNMF_NARROW_MAX_FEATURES || p->n_components > HIPNMF_NARROW_MAX_COMPONENTS || p->loss == HIPNMF_LOSS_KL ||
-          (p->x_layout == HIPNMF_X_ROW_MAJOR && p->w_layout == HIPNMF_W_ROW_MAJOR));
+          p->w_layout == HIPNMF_W_ROW_MAJOR_PAD16);
 }
 template <typename real>
 int shard_common(hipnmf_handle* h, const hipnmf_problem* p, const KernelSet<real>** ks_out, SolveArgs<real>* a,

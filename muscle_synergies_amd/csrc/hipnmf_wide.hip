@@ -17,7 +17,7 @@
 #include "hipnmf_internal.hpp"
 #include "nmf_wide4_inst.hpp"
 #include "nmf_wide_inst.hpp"
-#include "nmf_big.hpp"
+#include "nmf_big.hpp"  // (the one-pass kernel of nmf_big1.hpp is instantiated in inst_big1_f32.hip and reached through big1_kernel_f32)
 
 using namespace hipnmf;
 
@@ -83,6 +83,23 @@ const WideKernel<double>* pick<double>(int m, int k, int nw) {
   return wide_kernel_f64(m, k, nw);
 }
 }  // namespace
+
+// The one-pass update + record kernel of the general shapes (nmf_big1.hpp; round 5): fp32, Frobenius.  HIPNMF_BIG1=0 keeps the
+// two-pass pair big_pass_w_kernel + big_records_kernel (which remains the path of float64 and of the Kullback-Leibler loss).
+template <typename real>
+static const Big1Kernel<real>* pick_big1(hipnmf_handle*, int, int, bool) {
+  return nullptr;
+}
+template <>
+const Big1Kernel<float>* pick_big1<float>(hipnmf_handle* h, int KPb, int MPb, bool kl) {
+  static const bool on = [] {
+    const char* e = getenv("HIPNMF_BIG1");
+    return !(e && atoi(e) == 0);
+  }();
+  if (!on || kl) return nullptr;
+  const Big1Kernel<float>* b1 = big1_kernel_f32(KPb, MPb);
+  return (b1 && b1->smem <= (size_t)h->lds_per_block) ? b1 : nullptr;
+}
 
 // `p` has passed validate() of hipnmf_api.hip.  `ragged`: host copy of the caller's descriptors or nullptr.
 template <typename real>
@@ -468,6 +485,9 @@ int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
     ba.l1w = (real)p->l1_reg_W;
     ba.l2w = (real)p->l2_reg_W;
     ba.kl = kl ? 1 : 0;
+    ba.update_h = a.update_h;
+    const Big1Kernel<real>* b1 = pick_big1<real>(h, KPb, MPb, kl);
+    if (b1) snprintf(h->last_kernel, sizeof(h->last_kernel), "%s[sliced]", b1->name);
     // H in LDS: all of it when [KP][MP + 4] (+ H H^T, + the residual's column accumulators) fits 96 KiB, else blocks of channels
     const size_t fixed = sizeof(real) * ((size_t)KPb * (KPb + 4) + 12 * (size_t)MPb);
     const size_t cap = 96 * 1024;
@@ -509,7 +529,12 @@ int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
                              reinterpret_cast<const void*>(big_resid_kernel<real, KP>)})
         if (!arc) arc = hipnmf_allow_full_lds(h, fn);
     });
+    if (!arc && b1 && b1->smem > 48 * 1024) arc = hipnmf_allow_full_lds(h, reinterpret_cast<const void*>(b1->fn));
+    if (!arc && smem_h > 48 * 1024) arc = hipnmf_allow_full_lds(h, reinterpret_cast<const void*>(big_hupdate_kernel<real>));
     if (arc) return arc;
+    if (std::max(std::max(smem_w, smem_r), std::max(smem_rec, smem_h)) > (size_t)h->lds_per_block)
+      return fail(HIPNMF_ERR_UNSUPPORTED, "n_features=%d n_components=%d needs more LDS per workgroup than this device has (%d bytes)", m, k,
+                  h->lds_per_block);
     auto residual = [&](int it, auto&& emit) {
       with_kp([&](auto kp) { emit(big_resid_kernel<real, decltype(kp)::value>, gslice, dim3(256), smem_r, ba); });
       WideSliceArgs<real> f = sa;
@@ -519,11 +544,15 @@ int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
     auto enqueue = [&](int n, bool check, auto&& emit) {
       for (int i = 0; i < n; ++i) {
         emit(big_hht_kernel<real>, dim3(B, KPb), dim3(256), (size_t)0, ba);
-        with_kp([&](auto kp) {
-          constexpr int KP = decltype(kp)::value;
-          emit(big_pass_w_kernel<real, KP>, gslice, dim3(256), smem_w, ba);
-          if (a.update_h) emit(big_records_kernel<real, KP>, grec, dim3(256), smem_rec, ba);
-        });
+        if (b1) {  // one pass: the W update and the slice's record together
+          emit(b1->fn, gslice, dim3(512), b1->smem, ba);
+        } else {
+          with_kp([&](auto kp) {
+            constexpr int KP = decltype(kp)::value;
+            emit(big_pass_w_kernel<real, KP>, gslice, dim3(256), smem_w, ba);
+            if (a.update_h) emit(big_records_kernel<real, KP>, grec, dim3(256), smem_rec, ba);
+          });
+        }
         if (a.update_h) emit(big_hupdate_kernel<real>, ghup, dim3(256), smem_h, hb);
       }
       if (check) residual(1, emit);
@@ -602,11 +631,12 @@ int hipnmf_shard_wide(hipnmf_handle* h, const hipnmf_problem* p, int op, const r
   const long long T = p->n_samples;
   const int KPb = (int)round_up(k, 16), MPb = (int)round_up(m, 16);
   if (op != 1) {
-    if (p->x_layout != HIPNMF_X_ROW_MAJOR || p->w_layout != HIPNMF_W_ROW_MAJOR || (p->ldx % VEC) != 0 ||
+    if (p->x_layout != HIPNMF_X_ROW_MAJOR || p->w_layout != HIPNMF_W_ROW_MAJOR_PAD16 || (p->ldx % VEC) != 0 ||
         (reinterpret_cast<uintptr_t>(X) % 16) != 0 || ((p->x_batch_stride * (long long)sizeof(real)) % 16) != 0 ||
         (reinterpret_cast<uintptr_t>(W) % 16) != 0)
-      return fail(HIPNMF_ERR_UNSUPPORTED, "shard entry points beyond 32 channels / 8 components need row-major X with 16-byte aligned rows "
-                                          "(ldx %% %d == 0) and row-major W [n_samples][%d] (components padded to 16 with zeros)", VEC, KPb);
+      return fail(HIPNMF_ERR_UNSUPPORTED, "shard entry points beyond 32 channels / 8 components (and the Kullback-Leibler loss) need row-major X "
+                                          "with 16-byte aligned rows (ldx %% %d == 0) and w_layout = HIPNMF_W_ROW_MAJOR_PAD16: W [n_samples][%d], "
+                                          "components padded to 16 with zeros", VEC, KPb);
     if (T >= (1LL << 31)) return fail(HIPNMF_ERR_UNSUPPORTED, "n_samples must be < 2^31 per shard");
   }
   if (B > 65535) return fail(HIPNMF_ERR_UNSUPPORTED, "batch=%d: at most 65535 matrices", B);
@@ -653,6 +683,8 @@ int hipnmf_shard_wide(hipnmf_handle* h, const hipnmf_problem* p, int op, const r
   ba.l1w = (real)p->l1_reg_W;
   ba.l2w = (real)p->l2_reg_W;
   ba.kl = kl ? 1 : 0;
+  ba.update_h = p->update_h ? 1 : 0;
+  const Big1Kernel<real>* b1 = pick_big1<real>(h, KPb, MPb, kl);
   const size_t fixed = sizeof(real) * ((size_t)KPb * (KPb + 4) + 12 * (size_t)MPb);
   int cbh = MPb;
   while (cbh > 16 && fixed + sizeof(real) * (size_t)KPb * (cbh + 4) > 96 * 1024) cbh = (int)round_up(cbh / 2, 16);
@@ -675,15 +707,23 @@ int hipnmf_shard_wide(hipnmf_handle* h, const hipnmf_problem* p, int op, const r
   int arc = HIPNMF_OK;
   if (op == 0) {
     hipLaunchKernelGGL(big_hht_kernel<real>, dim3(B, KPb), dim3(256), 0, st, ba);
-    with_kp([&](auto kp) {
-      constexpr int KP = decltype(kp)::value;
-      if (!arc) arc = hipnmf_allow_full_lds(h, reinterpret_cast<const void*>(big_pass_w_kernel<real, KP>));
-      if (!arc) arc = hipnmf_allow_full_lds(h, reinterpret_cast<const void*>(big_records_kernel<real, KP>));
-      if (arc) return;
-      hipLaunchKernelGGL((big_pass_w_kernel<real, KP>), gslice, dim3(256), smem_w, st, ba);
-      if (p->update_h) hipLaunchKernelGGL((big_records_kernel<real, KP>), grec, dim3(256), smem_rec, st, ba);
-    });
-    if (arc) return arc;
+    if (b1) {
+      if (b1->smem > 48 * 1024) arc = hipnmf_allow_full_lds(h, reinterpret_cast<const void*>(b1->fn));
+      if (arc) return arc;
+      hipLaunchKernelGGL(b1->fn, gslice, dim3(512), b1->smem, st, ba);
+    } else {
+      if (std::max(smem_w, smem_rec) > (size_t)h->lds_per_block)
+        return fail(HIPNMF_ERR_UNSUPPORTED, "n_features=%d n_components=%d needs more LDS per workgroup than this device has", m, k);
+      with_kp([&](auto kp) {
+        constexpr int KP = decltype(kp)::value;
+        if (!arc) arc = hipnmf_allow_full_lds(h, reinterpret_cast<const void*>(big_pass_w_kernel<real, KP>));
+        if (!arc) arc = hipnmf_allow_full_lds(h, reinterpret_cast<const void*>(big_records_kernel<real, KP>));
+        if (arc) return;
+        hipLaunchKernelGGL((big_pass_w_kernel<real, KP>), gslice, dim3(256), smem_w, st, ba);
+        if (p->update_h) hipLaunchKernelGGL((big_records_kernel<real, KP>), grec, dim3(256), smem_rec, st, ba);
+      });
+      if (arc) return arc;
+    }
     if (p->update_h) hipLaunchKernelGGL(big_pack_sums_kernel<real>, dim3(B), dim3(256), 0, st, ba, sums);
   } else if (op == 1) {
     BigHArgs<real> hb;
@@ -700,10 +740,15 @@ int hipnmf_shard_wide(hipnmf_handle* h, const hipnmf_problem* p, int op, const r
     hb.l1h = (real)p->l1_reg_H;
     hb.l2h = (real)p->l2_reg_H;
     hb.kl = kl ? 1 : 0;
-    hipLaunchKernelGGL(big_hupdate_kernel<real>, dim3(B, (m + 63) / 64), dim3(256), sizeof(real) * ((size_t)k * k + 128 * (size_t)k), st, hb);
+    const size_t smem_h = sizeof(real) * ((size_t)k * k + 128 * (size_t)k);
+    if (smem_h > (size_t)h->lds_per_block)
+      return fail(HIPNMF_ERR_UNSUPPORTED, "n_components=%d needs more LDS per workgroup than this device has", k);
+    if (smem_h > 48 * 1024 && (arc = hipnmf_allow_full_lds(h, reinterpret_cast<const void*>(big_hupdate_kernel<real>)))) return arc;
+    hipLaunchKernelGGL(big_hupdate_kernel<real>, dim3(B, (m + 63) / 64), dim3(256), smem_h, st, hb);
   } else {
     with_kp([&](auto kp) {
       constexpr int KP = decltype(kp)::value;
+      if (!arc && smem_r > (size_t)h->lds_per_block) arc = fail(HIPNMF_ERR_UNSUPPORTED, "n_features=%d needs more LDS per workgroup than this device has", m);
       if (!arc) arc = hipnmf_allow_full_lds(h, reinterpret_cast<const void*>(big_resid_kernel<real, KP>));
       if (arc) return;
       hipLaunchKernelGGL((big_resid_kernel<real, KP>), gslice, dim3(256), smem_r, st, ba);

@@ -1,0 +1,25 @@
+// big1_pass_kernel<float, KP, NQ, RS> (nmf_big1.hpp): the one-pass update + record kernel of the general shapes, fp32.
+// KP = 16 / 32 / 48 / 64 padded components; NQ = 1 / 2 / 4: eight waves x 16 NQ channels cover 128 / 256 / 512 channels;
+// RS subtiles of 16 rows per round (the X block of a round sits in 4 NQ RS registers per lane).
+#include "nmf_big1.hpp"
+namespace hipnmf {
+namespace {
+template <int KP, int NQ, int RS>
+Big1Kernel<float> make_big1(const char* name) {
+  return Big1Kernel<float>{big1_pass_kernel<float, KP, NQ, RS>, Big1Cfg<float, KP, NQ, RS>::smem_bytes(), KP, NQ, RS, name};
+}
+}  // namespace
+const Big1Kernel<float>* big1_kernel_f32(int KP, int MP) {
+  static const Big1Kernel<float> t[4][3] = {
+      {make_big1<16, 1, 4>("big1_pass_kernel<float,16,1,4>"), make_big1<16, 2, 4>("big1_pass_kernel<float,16,2,4>"),
+       make_big1<16, 4, 4>("big1_pass_kernel<float,16,4,4>")},
+      {make_big1<32, 1, 4>("big1_pass_kernel<float,32,1,4>"), make_big1<32, 2, 4>("big1_pass_kernel<float,32,2,4>"),
+       make_big1<32, 4, 4>("big1_pass_kernel<float,32,4,4>")},
+      {make_big1<48, 1, 4>("big1_pass_kernel<float,48,1,4>"), make_big1<48, 2, 4>("big1_pass_kernel<float,48,2,4>"),
+       make_big1<48, 4, 2>("big1_pass_kernel<float,48,4,2>")},
+      {make_big1<64, 1, 4>("big1_pass_kernel<float,64,1,4>"), make_big1<64, 2, 2>("big1_pass_kernel<float,64,2,2>"),
+       make_big1<64, 4, 2>("big1_pass_kernel<float,64,4,2>")}};
+  if (KP < 16 || KP > 64 || KP % 16 || MP > 512) return nullptr;
+  return &t[KP / 16 - 1][MP <= 128 ? 0 : MP <= 256 ? 1 : 2];
+}
+}  // namespace hipnmf

@@ -47,7 +47,17 @@ struct BigArgs {
   int CBH;  // channels of H staged in LDS at a time (a multiple of 16; MP when all of H fits)
   real l1w, l2w;
   int kl;   // 1: Kullback-Leibler updates (_nmf.py:556-591, 642-684) -- see the KL notes in every kernel; column records are 3 MP then
+  int update_h;  // 0: H stays fixed (NMF.transform): the one-pass kernel (nmf_big1.hpp) skips the record
 };
+// the one-pass kernel of nmf_big1.hpp (instances: inst_big1_f32.hip): KP components padded, 8 waves x 16 NQ channels, RS subtiles per round
+template <typename real>
+struct Big1Kernel {
+  void (*fn)(BigArgs<real>);
+  size_t smem;
+  int KP, NQ, RS;
+  const char* name;
+};
+const Big1Kernel<float>* big1_kernel_f32(int KP, int MP);  // nullptr: no instance covers MP channels
 // values per slice of the column record: sse | xsq (| the Kullback-Leibler divergence per column)
 template <typename real>
 __device__ __forceinline__ int big_ncol(const BigArgs<real>& a) { return (a.kl ? 3 : 2) * a.MP; }

@@ -1,0 +1,324 @@
+// nmf_big1.hpp -- ONE pass over X per iteration for the general shapes (round 5): the row-local W update AND the slice's record
+// [W'^T X | W'^T W'] in a single kernel, replacing big_pass_w_kernel + big_records_kernel of nmf_big.hpp (which read X twice and
+// W three times per iteration: ~2.4x the algorithmic bytes, 0.29 of the fp32 matrix peak at 512 x 32 in round 4).
+//
+// Arithmetic replaced: sklearn/decomposition/_nmf.py (1.7.2) _multiplicative_update_w (:540-554, 615-631) and the two T-long
+// contractions of _multiplicative_update_h (:638-640); reached from src/muscle_synergies/analysis.py:862-863.
+//
+// Why the accumulators no longer fit one wave -- and what replaces "a wave owns rows".  W^T X is KP x MP values (32 x 512 = 256
+// registers per lane in one wave).  Here the EIGHT waves of a workgroup own CHANNEL blocks instead: wave w holds the CW = 16 NQ
+// channels [w CW, (w + 1) CW) of everything channel-indexed, for the whole slice, in registers:
+//     hreg   H[:, block w]           KP x CW      the A operand of the numerator          (KP CW / 64 registers)
+//     accA   (W'^T X)[:, block w]    KP x CW      its block of the slice's record         (KP CW / 64 registers)
+// and the rows of a slice go by in ROUNDS of 16 RS rows.  A round:
+//   a  every wave: partial numerator^T = H_w X_w^T (KP x rows) over ITS channels, X_w (rows x CW) in registers straight from
+//      HBM (16-byte loads; lane (row j, g) <-> channels 16 q + 4 g .. + 3); partial -> LDS (P[w], 16-byte pieces)
+//   -- barrier --
+//   c  the RS NKB (subtile, component block) UNITS of the round are dealt over the waves: sum of the eight partials (wave
+//      order), denominator^T = (H H^T) W^T on the pipe, W' = W num / den, 16-byte store to HBM and a row-major copy to LDS (Wst)
+//   -- barrier --
+//   e  every wave: accA += W'^T X_w.  The contraction now runs over rows: X_w goes through a private LDS stage once (written
+//      as loaded, read back with the channel on the low lane bits), W'^T is read transposed from Wst; the unit owners also
+//      accumulate their block row of W'^T W'.  The registers of a staged subtile are free: the NEXT round's loads of that
+//      subtile are issued right there (prefetch distance: half a round of matrix-pipe work).
+// X is read once, W read once and written once: the algorithmic 4 m + 8 k bytes per row.  Two workgroup barriers per round of
+// 64 rows (~17 000 matrix-pipe cycles at 512 x 32).  Every sum has a fixed order (channel blocks in wave order, rounds in
+// order, units in subtile order): bitwise reproducible.  Operand conventions: nmf_wide.hpp (WideMma).
+#pragma once
+#include "nmf_big.hpp"
+
+namespace hipnmf {
+
+template <typename real, int KP, int NQ, int RS>
+struct Big1Cfg {
+  static constexpr int NKB = KP / 16, CW = 16 * NQ, NW = 8, NU = RS * NKB, SLOTS = (NU + NW - 1) / NW;
+  static constexpr int SW = KP + 4, SX = CW + 4, ROWS = 16 * RS;
+  static constexpr int UNIT = 256;                                       // values of one unit's partial numerator (16 rows x 16 components)
+  static constexpr int PW0 = NU * UNIT > 2 * 16 * SX ? NU * UNIT : 2 * 16 * SX;  // per-wave region: the partials | two X stages
+  static constexpr int RED = NU * 16 * KP;                              // W'^T W' partial block rows at the end of the slice
+  static constexpr int PW = (NW * PW0 >= RED) ? PW0 : (RED + NW - 1) / NW;
+  static constexpr int MAXCH = NW * CW;                                  // channels one workgroup covers
+  __host__ __device__ static constexpr size_t smem_bytes() { return sizeof(real) * (size_t)(NW * PW + ROWS * SW); }
+  static_assert(KP % 16 == 0 && KP >= 16 && KP <= 64 && (NQ == 1 || NQ == 2 || NQ == 4) && RS % 2 == 0, "unsupported shape");
+};
+
+// grid (S, B), 512 threads; dynamic LDS Big1Cfg::smem_bytes().  a.HHt holds H H^T (big_hht_kernel), a.part receives the records.
+template <typename real, int KP, int NQ, int RS>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) big1_pass_kernel(BigArgs<real> a) {
+  using C = Big1Cfg<real, KP, NQ, RS>;
+  using M = WideMma<real>;
+  using acc = typename M::acc;
+  constexpr int NKB = C::NKB, CW = C::CW, NW = C::NW, NU = C::NU, SLOTS = C::SLOTS, SW = C::SW, SX = C::SX, ROWS = C::ROWS,
+                UNIT = C::UNIT, PW = C::PW;
+  extern __shared__ __attribute__((aligned(16))) unsigned char big_smem[];
+  const int b = blockIdx.y;
+  if (a.state && a.state[(long long)b * 8 + 3] != (real)0) return;
+  real* const P = reinterpret_cast<real*>(big_smem);  // [NW][PW]
+  real* const Wst = P + NW * PW;                      // [ROWS][SW]  the round's updated rows of W, row-major
+  const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ar = M::arow(j);
+  real* const Pw = P + wave * PW;
+  const real* __restrict__ Xb = a.X + (long long)b * a.x_bstride;
+  real* __restrict__ Wb = a.W + (long long)b * a.w_bstride;
+  const real* __restrict__ Hb = a.H + (long long)b * a.k * a.m;
+  int row_begin, row_end;
+  big_slice(a, row_begin, row_end);
+  const int ch_w0 = wave * CW;
+  const bool active = ch_w0 < a.MP;                   // this wave's channel block holds data
+  const int nwa = (a.MP + CW - 1) / CW;               // waves whose partials are summed
+  const bool upd = a.update_h != 0;
+  const unsigned ldx_b = (unsigned)(a.ldx * (long long)sizeof(real));
+  constexpr unsigned ldw_b = (unsigned)KP * (unsigned)sizeof(real);
+  constexpr int V = 16 / (int)sizeof(real);           // elements per 16-byte piece
+
+  // ---- operands that live in registers for the whole slice ---------------------------------------------------------
+  real hreg[NKB][NQ][4];  // numerator's A operand: lane (i, g), k-step (q, r) <-> H[16 kb + arow(i)][ch_w0 + 16 q + 4 g + r]
+#pragma unroll
+  for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int c = 16 * kb + ar, ch = ch_w0 + 16 * q + 4 * g + r;
+        hreg[kb][q][r] = (c < a.k && ch < a.m) ? Hb[(long long)c * a.m + ch] : (real)0;
+      }
+  // the units this wave owns in phase c: v = wave + NW slot <-> (subtile v / NKB, component block v % NKB)
+  int u_s[SLOTS], u_kb[SLOTS];
+  real hha[SLOTS][NKB][4];  // denominator's A operand: lane (i, g), k-step r of block kbi <-> HHt[16 kbo + arow(i)][16 kbi + 4 g + r]
+#pragma unroll
+  for (int sl = 0; sl < SLOTS; ++sl) {
+    const int v = wave + NW * sl;
+    u_s[sl] = v < NU ? v / NKB : -1;
+    u_kb[sl] = v < NU ? v % NKB : 0;
+#pragma unroll
+    for (int kbi = 0; kbi < NKB; ++kbi)
+      wide_lds_read<real, 4>(a.HHt + (long long)b * KP * KP + (16 * u_kb[sl] + ar) * KP + 16 * kbi + 4 * g, hha[sl][kbi]);
+  }
+  acc accA[NKB][NQ], accB[SLOTS][NKB];
+  const acc zero = {(real)0, (real)0, (real)0, (real)0};
+#pragma unroll
+  for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) accA[kb][q] = zero;
+#pragma unroll
+  for (int sl = 0; sl < SLOTS; ++sl)
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) accB[sl][kb] = zero;
+
+  // ---- addressing: descriptors start at a subtile's first row and end with the slice, so a lane is in range exactly when its
+  // row exists; pieces of a row beyond the data get the out-of-range sentinel once
+  unsigned xvoff[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int col = ch_w0 + 16 * q + 4 * g;
+    xvoff[q] = (active && col / V < a.xchunks) ? (unsigned)j * ldx_b + (unsigned)col * (unsigned)sizeof(real) : OOB;
+  }
+  const char* const xbase = reinterpret_cast<const char*>(Xb);
+  char* const wbase = reinterpret_cast<char*>(Wb);
+  auto x_rsrc = [&](int row0) __attribute__((always_inline)) {
+    const int rows = row0 < row_end ? row_end - row0 : 0;
+    return make_rsrc(xbase + (long long)(rows > 0 ? row0 : row_begin) * ldx_b, (unsigned)rows * ldx_b);
+  };
+  auto w_rsrc = [&](int row0) __attribute__((always_inline)) {
+    const int rows = row0 < row_end ? row_end - row0 : 0;
+    return make_rsrc(wbase + (long long)(rows > 0 ? row0 : row_begin) * ldw_b, (unsigned)rows * ldw_b);
+  };
+  real x[RS][NQ][4];  // the round's rows of this wave's channel block: lane (row j, g) <-> X[16 s + j][ch_w0 + 16 q + 4 g + r]
+  auto issue_x = [&](int s, int row0) __attribute__((always_inline)) {
+    const rsrc_t xr = x_rsrc(row0 + 16 * s);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      if constexpr (V == 4) {
+        buf_load<real, 4, (HIPNMF_WIDE_X_AUX)>(xr, xvoff[q], 0u, x[s][q]);
+      } else {  // fp64: two 16-byte pieces, the second one may lie beyond the data
+        real lo[2], hi[2];
+        const int col = ch_w0 + 16 * q + 4 * g;
+        buf_load<real, 2, (HIPNMF_WIDE_X_AUX)>(xr, xvoff[q], 0u, lo);
+        buf_load<real, 2, (HIPNMF_WIDE_X_AUX)>(xr, (xvoff[q] != OOB && (col + 2) / V < a.xchunks) ? xvoff[q] + 16u : OOB, 0u, hi);
+        x[s][q][0] = lo[0], x[s][q][1] = lo[1], x[s][q][2] = hi[0], x[s][q][3] = hi[1];
+      }
+    }
+  };
+
+  if (active) {
+#pragma unroll
+    for (int s = 0; s < RS; ++s) issue_x(s, row_begin);
+  }
+  for (int t0 = row_begin; t0 < row_end; t0 += ROWS) {
+    // the W fragments of this wave's units (B operand of the denominator: lane (row j, g) <-> components 16 kbi + 4 g .. + 3):
+    // requested now, needed after the first barrier
+    real wold[SLOTS][NKB][4];
+#pragma unroll
+    for (int sl = 0; sl < SLOTS; ++sl) {
+      const rsrc_t wr = w_rsrc(u_s[sl] >= 0 ? t0 + 16 * u_s[sl] : row_end);
+#pragma unroll
+      for (int kbi = 0; kbi < NKB; ++kbi) buf_load<real, 4>(wr, (unsigned)j * ldw_b + (unsigned)((16 * kbi + 4 * g) * (int)sizeof(real)), 0u, wold[sl][kbi]);
+    }
+    // ---- a: partial numerators of the round over this wave's channels, two subtiles (2 NKB chains) at a time ------------
+    if (active) {
+#pragma unroll
+      for (int s = 0; s < RS; s += 2) {
+        acc num[2][NKB];
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+          for (int kb = 0; kb < NKB; ++kb) num[e][kb] = zero;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+              for (int kb = 0; kb < NKB; ++kb) num[e][kb] = M::mma(hreg[kb][q][r], x[s + e][q][r], num[e][kb]);
+        // D: lane (row j, g), register r <-> component 16 kb + 4 g + r: one 16-byte piece per lane and unit
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+          for (int kb = 0; kb < NKB; ++kb) {
+            real v4[4] = {num[e][kb][0], num[e][kb][1], num[e][kb][2], num[e][kb][3]};
+            wide_lds_write<real, 4>(Pw + ((s + e) * NKB + kb) * UNIT + j * 16 + 4 * g, v4);
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __syncthreads();
+    // ---- c: this wave's units: sum of the partials, denominator, W' ---------------------------------------------------
+#pragma unroll
+    for (int sl = 0; sl < SLOTS; ++sl) {
+      if (u_s[sl] < 0) continue;
+      const int v = wave + NW * sl;
+      real nsum[4];
+      wide_lds_read<real, 4>(P + v * UNIT + j * 16 + 4 * g, nsum);
+      for (int w2 = 1; w2 < nwa; ++w2) {  // (channel blocks in wave order)
+        real t4[4];
+        wide_lds_read<real, 4>(P + w2 * PW + v * UNIT + j * 16 + 4 * g, t4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) nsum[r] += t4[r];
+      }
+      acc den = zero;
+#pragma unroll
+      for (int kbi = 0; kbi < NKB; ++kbi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) den = M::mma(hha[sl][kbi][r], wold[sl][kbi][r], den);
+      real wo[4], dd[4], qq[4], wn[4];
+#pragma unroll
+      for (int kbi = 0; kbi < NKB; ++kbi)
+        if (kbi == u_kb[sl]) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) wo[r] = wold[sl][kbi][r];
+        }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        real d = den[r];
+        if (a.l1w > (real)0) d = d + a.l1w;
+        if (a.l2w > (real)0) d = d + a.l2w * wo[r];
+        dd[r] = (d == (real)0) ? eps_val<real>() : d;
+      }
+      quotients<4>(nsum, dd, qq);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) wn[r] = wo[r] * qq[r];
+      const rsrc_t wr = w_rsrc(t0 + 16 * u_s[sl]);
+      wide_store4<real>(wr, (unsigned)j * ldw_b + (unsigned)((16 * u_kb[sl] + 4 * g) * (int)sizeof(real)), 0u, wn);
+      if (upd) wide_lds_write<real, 4>(Wst + (16 * u_s[sl] + j) * SW + 16 * u_kb[sl] + 4 * g, wn);
+    }
+    if (!upd) {  // nothing else needs X: the next round's rows may come
+      if (active && t0 + ROWS < row_end) {
+#pragma unroll
+        for (int s = 0; s < RS; ++s) issue_x(s, t0 + ROWS);
+      }
+      __syncthreads();  // (the partials are rewritten by the next round)
+      continue;
+    }
+    __syncthreads();
+    // ---- e: accA += W'^T X_w (contraction over the rows), W'^T W' by the unit owners ----------------------------------
+#pragma unroll
+    for (int s = 0; s < RS; ++s) {
+      real* const xst = Pw + (s & 1) * 16 * SX;  // this wave's stage (its partials are dead; nobody else touches the region now)
+      if (active) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) wide_lds_write<real, 4>(xst + j * SX + 16 * q + 4 * g, x[s][q]);
+      }
+      wide_wave_lds_fence();
+      if (active && t0 + ROWS < row_end) issue_x(s, t0 + ROWS);  // the registers are free: the next round's subtile s
+      // A: lane (c, g), k-step t <-> W'[row 4 g + t][16 kb + arow(c)];  B: lane (channel j, g) <-> X[row 4 g + t][16 q + j]
+      real wa[NKB][4], wb[NKB][4];
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          wa[kb][t] = Wst[(16 * s + 4 * g + t) * SW + 16 * kb + ar];
+          if constexpr (sizeof(real) == 8)
+            wb[kb][t] = Wst[(16 * s + 4 * g + t) * SW + 16 * kb + j];
+          else
+            wb[kb][t] = wa[kb][t];
+        }
+      if (active) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          real xb[4];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) xb[t] = xst[(4 * g + t) * SX + 16 * q + j];
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) accA[kb][q] = M::mma(wa[kb][t], xb[t], accA[kb][q]);
+        }
+      }
+#pragma unroll
+      for (int sl = 0; sl < SLOTS; ++sl)
+        if (u_s[sl] == s) {  // (wave-uniform)
+#pragma unroll
+          for (int kbo = 0; kbo < NKB; ++kbo)
+            if (kbo == u_kb[sl]) {
+#pragma unroll
+              for (int kbi = 0; kbi < NKB; ++kbi)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) accB[sl][kbi] = M::mma(wa[kbo][t], wb[kbi][t], accB[sl][kbi]);
+            }
+        }
+      wide_wave_lds_fence();
+      __builtin_amdgcn_sched_barrier(0);  // one subtile at a time: hoisting the next one's LDS reads up here costs spills
+    }
+  }
+  if (!upd) return;
+  // ---- the slice's record.  W'^T X: every wave owns its channel block outright.  D: lane (j, g), register r <->
+  // [component 16 kb + 4 g + r][channel ch_w0 + 16 q + j]
+  const int rec = KP * a.MP + KP * KP;
+  real* __restrict__ out = a.part + ((long long)b * a.S + blockIdx.x) * rec;
+  if (active) {
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const int ch = ch_w0 + 16 * q + j;
+        if (ch < a.MP) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) out[(16 * kb + 4 * g + r) * a.MP + ch] = accA[kb][q][r];
+        }
+      }
+  }
+  // W'^T W': block row kbo of unit v = (s, kbo) -> red[v][16][KP]; the units of one block row summed in subtile order
+  __syncthreads();  // (the stages inside P are dead)
+  real* const red = P;
+#pragma unroll
+  for (int sl = 0; sl < SLOTS; ++sl) {
+    if (u_s[sl] < 0) continue;
+    const int v = wave + NW * sl;
+#pragma unroll
+    for (int kbi = 0; kbi < NKB; ++kbi)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[(v * 16 + 4 * g + r) * KP + 16 * kbi + j] = accB[sl][kbi][r];
+  }
+  __syncthreads();
+  for (int idx = tid; idx < KP * KP; idx += 512) {
+    const int c = idx / KP, c2 = idx % KP, kbo = c / 16, i = c % 16;
+    real s = (real)0;
+#pragma unroll
+    for (int sb = 0; sb < RS; ++sb) s += red[((sb * NKB + kbo) * 16 + i) * KP + c2];
+    out[KP * a.MP + idx] = s;
+  }
+}
+
+}  // namespace hipnmf

@@ -118,7 +118,7 @@ class HipShardOps:
         self.handle.set_async(True)
         if self.wide:
             self.p = make_problem(self.B, self.T, self.m, self.k, x_layout=_lib.X_ROW_MAJOR, ldx=self.ldx,
-                                  x_batch_stride=self.T * self.ldx, w_layout=_lib.W_ROW_MAJOR, update_H=update_H,
+                                  x_batch_stride=self.T * self.ldx, w_layout=_lib.W_ROW_MAJOR_PAD16, update_H=update_H,
                                   max_iter=1, tol=0.0, l1_reg_W=l1_reg_W, l1_reg_H=l1_reg_H, l2_reg_W=l2_reg_W,
                                   l2_reg_H=l2_reg_H, loss=_lib.LOSS_KL if self.kl else _lib.LOSS_FROBENIUS)
         else:

@@ -82,7 +82,8 @@ def test_gpus_n_invoked_directly_starts_n_ranks_over_gloo():
     lines = _json_lines(out.stdout)
     assert len(lines) == 1
     r = lines[0]
-    assert r["n_gpus"] == 2 and r["config"]["ranks_seen"] == 2 and r["steps"] == 3 and r["warmup"] == 1
+    assert r["n_gpus"] == 2 and r["ranks_seen"] == 2 and r["steps"] == 3 and r["warmup"] == 1
+    assert r["process_group_backend"] == "gloo"
     assert r["ms_per_step"] >= 19.0          # rank 1 sleeps 20 ms per step, rank 0 10 ms: the slowest rank's time is reported
     assert r["data"].startswith("none") and r["cpu_baseline"] is None
 
@@ -110,9 +111,30 @@ def test_gpus_n_refuses_to_run_on_fewer_devices():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                          capture_output=True, text=True, env=env, timeout=300)
     assert out.returncode != 0 and not _json_lines(out.stdout)
-    assert "refusing" in (out.stderr + out.stdout)
+    assert "needs ROCm GPU index" in (out.stderr + out.stdout)  # said by the rank itself: the launcher parent loads no GPU library
     # a launcher environment that disagrees with --gpus is an error too
     env2 = dict(env, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-orchestration"],
                          capture_output=True, text=True, env=env2, timeout=300)
     assert out.returncode != 0 and "WORLD_SIZE=1" in (out.stderr + out.stdout)
+
+
+def test_launcher_ends_the_other_ranks_when_one_dies():
+    """A rank that dies before the rendezvous must not leave rank 0 waiting for the collective timeout (round-4 advisor
+    finding): the launcher polls every rank, ends the others and exits non-zero within seconds."""
+    import time
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    t0 = time.monotonic()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-orchestration", "--dry-fail-rank", "1"],
+                         capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode != 0 and not _json_lines(out.stdout)
+    assert "rank 1 exited with code 7" in (out.stderr + out.stdout)
+    assert time.monotonic() - t0 < 60
+
+
+def test_only_config5_uses_rccl():
+    """Configs 2-4 have no data-path collective: their barrier / max-over-ranks run over gloo (bench.py Ctx.init_gpu)."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert 'self.backend = "nccl" if (self.a.config == 5 and not self.dry) else "gloo"' in src
+    assert src.count('backend="nccl"') == 1

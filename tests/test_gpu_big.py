@@ -43,10 +43,11 @@ def test_big_shape_sweep_fp32(m, k, T):
     for layout in ("F", "C"):
         Xl = np.asfortranarray(X) if layout == "F" else np.ascontiguousarray(X)
         res = ms.fit_batched(Xl, W0, H0, max_iter=15, tol=0.0)
-        # 129..256 channels with at most 16 components keep the one-pass kernel (inst_wide_f32_xl.hip), the rest is nmf_big.hpp
+        # 129..256 channels with at most 16 components keep the one-wave one-pass kernel (inst_wide_f32_xl.hip), the rest is the
+        # workgroup-cooperative one-pass kernel of nmf_big1.hpp (round 5; the two-pass pair of nmf_big.hpp before)
         xl = 128 < m <= 256 and k <= 16
         assert _last_kernel().startswith("fit_wide_kernel<float,%d,16,4" % (160 if m <= 160 else 192 if m <= 192 else 256) if xl
-                                         else "big_pass_w_kernel<float"), _last_kernel()
+                                         else "big1_pass_kernel<float,%d,%d," % ((k + 15) // 16 * 16, 1 if m <= 128 else 2 if m <= 256 else 4)), _last_kernel()
         assert int(res.n_iter[0]) == 15
         assert _rel(X, res.W[0], res.H[0], ref) <= TOL, (layout, m, k, T)
         assert abs(float(res.reconstruction_err[0]) - float(ref["reconstruction_err"])) / np.linalg.norm(X) <= TOL
@@ -233,7 +234,7 @@ def test_ragged_batch_on_the_general_shape_kernels(dtype, m, k):
         X, W0, H0 = _case(T, m, k, dtype, seed=50 + s)
         Xs.append(X), Ws.append(W0), Hs.append(H0)
     res = ms.fit_ragged(Xs, Ws, Hs, max_iter=30, tol=0.0)
-    assert _last_kernel().startswith("big_pass_w_kernel"), _last_kernel()
+    assert _last_kernel().startswith("big1_pass_kernel<float" if dtype == np.float32 else "big_pass_w_kernel<double"), _last_kernel()
     tol = TOL if dtype == np.float32 else 1e-9
     for b, T in enumerate(Ts):
         ref = orc.nmf_mu_fit(Xs[b], Ws[b], Hs[b], max_iter=30, tol=0.0)
