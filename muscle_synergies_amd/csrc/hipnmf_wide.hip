@@ -101,6 +101,20 @@ const Big1Kernel<float>* pick_big1<float>(hipnmf_handle* h, int KPb, int MPb, bo
   return (b1 && b1->smem <= (size_t)h->lds_per_block) ? b1 : nullptr;
 }
 
+// Slices per matrix for the one-pass kernel: one workgroup fits a CU, so the launch runs in ceil(B S / CUs) waves of workgroups of
+// round_up(T / S, 64) rows each (+ ~96 rows' worth of prologue and record); the cheapest S, the smaller one on a tie.
+// 64 x (512 x 10 000), k = 32 on 256 CUs: S = 4 (one wave of 2 560-row slices) 30.4 ms per 50 iterations, S = 8 31.9, S = 2 51.9.
+static long long big1_slices(int num_cu, int B, long long T) {
+  const long long s_max = std::max<long long>(1, std::min<long long>((T + 63) / 64, (4LL * num_cu + B - 1) / B));
+  long long best = 1, best_cost = -1;
+  for (long long s = 1; s <= s_max; ++s) {
+    const long long rows = round_up((T + s - 1) / s, 64);
+    const long long cost = (((long long)B * s + num_cu - 1) / num_cu) * (rows + 96);
+    if (best_cost < 0 || cost < best_cost) best = s, best_cost = cost;
+  }
+  return best;
+}
+
 // `p` has passed validate() of hipnmf_api.hip.  `ragged`: host copy of the caller's descriptors or nullptr.
 template <typename real>
 int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, real* W, real* H, real* err_out,
@@ -213,6 +227,7 @@ int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
     }
   }
 
+  const int KPb0 = (int)round_up(k, 16), MPb0 = (int)round_up(m, 16);
   // ---- path: one workgroup per matrix, or row slices over the whole chip (few long matrices: the reference's own
   // single-DataFrame call)
   const WideKernel<real>* wk4 = big ? nullptr : pick<real>(m, k, 4);
@@ -222,6 +237,7 @@ int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
   if (big) {  // always row slices: enough of them to fill the chip, whole 64-row sweeps of a workgroup
     const long long want = std::max<long long>(1, (2LL * h->num_cu + B - 1) / B);
     long long s_try = std::min<long long>(want, (T + 63) / 64);
+    if (pick_big1<real>(h, KPb0, MPb0, kl)) s_try = big1_slices(h->num_cu, B, T);  // one 512-thread workgroup per CU
     if (h->max_slices > 0) s_try = std::min<long long>(s_try, h->max_slices);
     rps = round_up((T + s_try - 1) / s_try, 64);
     S = (int)((T + rps - 1) / rps);
@@ -292,6 +308,8 @@ int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
   const size_t o_col = sliced ? carve(sizeof(real) * (size_t)B * S * 3 * recMP) : 0;  // (3: sse | xsq | KL per column of the general-shape path)
   const size_t o_state = sliced ? carve(sizeof(real) * (size_t)B * 8) : 0;
   const size_t o_hht = big ? carve(sizeof(real) * (size_t)B * KPb * KPb) : 0;
+  const int n_hblk = (m + 63) / 64;
+  const size_t o_hhtp = big ? carve(sizeof(real) * (size_t)B * n_hblk * KPb * KPb) : 0;
   int rc = hipnmf_ensure_ws(h, std::max<size_t>(off, 256));
   if (rc) return rc;
   char* ws = static_cast<char*>(h->ws);
@@ -488,6 +506,8 @@ int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
     ba.update_h = a.update_h;
     const Big1Kernel<real>* b1 = pick_big1<real>(h, KPb, MPb, kl);
     if (b1) snprintf(h->last_kernel, sizeof(h->last_kernel), "%s[sliced]", b1->name);
+    ba.hht_part = reinterpret_cast<real*>(ws + o_hhtp);
+    ba.n_hblk = n_hblk;
     // H in LDS: all of it when [KP][MP + 4] (+ H H^T, + the residual's column accumulators) fits 96 KiB, else blocks of channels
     const size_t fixed = sizeof(real) * ((size_t)KPb * (KPb + 4) + 12 * (size_t)MPb);
     const size_t cap = 96 * 1024;
@@ -513,6 +533,8 @@ int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
     hb.l1h = (real)p->l1_reg_H;
     hb.l2h = (real)p->l2_reg_H;
     hb.kl = kl ? 1 : 0;
+    hb.hht_part = b1 ? reinterpret_cast<real*>(ws + o_hhtp) : nullptr;  // one-pass kernel: the H update leaves the next H H^T behind
+    hb.KP = KPb;
     const dim3 gslice(S, B), grec(S, B, (MPb + BIG_CB - 1) / BIG_CB + 1), ghup(B, (m + 63) / 64);
     auto with_kp = [&](auto&& f) {  // the padded component count is a compile-time parameter of three of the kernels
       switch (KPb) {
@@ -543,10 +565,10 @@ int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
     };
     auto enqueue = [&](int n, bool check, auto&& emit) {
       for (int i = 0; i < n; ++i) {
-        emit(big_hht_kernel<real>, dim3(B, KPb), dim3(256), (size_t)0, ba);
-        if (b1) {  // one pass: the W update and the slice's record together
+        if (b1) {  // one pass: the W update and the slice's record together (H H^T comes with the H update)
           emit(b1->fn, gslice, dim3(512), b1->smem, ba);
         } else {
+          emit(big_hht_kernel<real>, dim3(B, KPb), dim3(256), (size_t)0, ba);
           with_kp([&](auto kp) {
             constexpr int KP = decltype(kp)::value;
             emit(big_pass_w_kernel<real, KP>, gslice, dim3(256), smem_w, ba);
@@ -557,6 +579,7 @@ int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
       }
       if (check) residual(1, emit);
     };
+    if (b1) hipLaunchKernelGGL(big_hht_part_kernel<real>, ghup, dim3(256), sizeof(real) * 64 * (size_t)k, st, hb);  // H H^T of the initial H
     rc = drive(enqueue, residual);
     if (rc) return rc;
   } else {
@@ -644,6 +667,7 @@ int hipnmf_shard_wide(hipnmf_handle* h, const hipnmf_problem* p, int op, const r
   hipStream_t st = h->stream;
   const long long want = std::max<long long>(1, (2LL * h->num_cu + B - 1) / B);
   long long s_try = std::min<long long>(want, (T + 63) / 64);
+  if (pick_big1<real>(h, KPb, MPb, p->loss == HIPNMF_LOSS_KL)) s_try = big1_slices(h->num_cu, B, T);
   if (h->max_slices > 0) s_try = std::min<long long>(s_try, h->max_slices);
   const long long rps = round_up((T + s_try - 1) / s_try, 64);
   const int S = (int)((T + rps - 1) / rps);
@@ -658,6 +682,8 @@ int hipnmf_shard_wide(hipnmf_handle* h, const hipnmf_problem* p, int op, const r
   const bool kl = p->loss == HIPNMF_LOSS_KL;
   const size_t o_col = carve(sizeof(real) * (size_t)B * S * 3 * MPb);
   const size_t o_hht = carve(sizeof(real) * (size_t)B * KPb * KPb);
+  const int n_hblk = (m + 63) / 64;
+  const size_t o_hhtp = carve(sizeof(real) * (size_t)B * n_hblk * KPb * KPb);
   int rc = hipnmf_ensure_ws(h, off);
   if (rc) return rc;
   char* ws = static_cast<char*>(h->ws);
@@ -684,6 +710,8 @@ int hipnmf_shard_wide(hipnmf_handle* h, const hipnmf_problem* p, int op, const r
   ba.l2w = (real)p->l2_reg_W;
   ba.kl = kl ? 1 : 0;
   ba.update_h = p->update_h ? 1 : 0;
+  ba.hht_part = reinterpret_cast<real*>(ws + o_hhtp);
+  ba.n_hblk = n_hblk;
   const Big1Kernel<real>* b1 = pick_big1<real>(h, KPb, MPb, kl);
   const size_t fixed = sizeof(real) * ((size_t)KPb * (KPb + 4) + 12 * (size_t)MPb);
   int cbh = MPb;
@@ -706,12 +734,20 @@ int hipnmf_shard_wide(hipnmf_handle* h, const hipnmf_problem* p, int op, const r
   if (!async) HIP_TRY(hipEventRecord(h->ev0, st));
   int arc = HIPNMF_OK;
   if (op == 0) {
-    hipLaunchKernelGGL(big_hht_kernel<real>, dim3(B, KPb), dim3(256), 0, st, ba);
     if (b1) {
       if (b1->smem > 48 * 1024) arc = hipnmf_allow_full_lds(h, reinterpret_cast<const void*>(b1->fn));
       if (arc) return arc;
+      BigHArgs<real> hp;
+      std::memset(&hp, 0, sizeof(hp));
+      hp.H = H;
+      hp.m = m;
+      hp.k = k;
+      hp.KP = KPb;
+      hp.hht_part = reinterpret_cast<real*>(ws + o_hhtp);
+      hipLaunchKernelGGL(big_hht_part_kernel<real>, dim3(B, n_hblk), dim3(256), sizeof(real) * 64 * (size_t)k, st, hp);
       hipLaunchKernelGGL(b1->fn, gslice, dim3(512), b1->smem, st, ba);
     } else {
+      hipLaunchKernelGGL(big_hht_kernel<real>, dim3(B, KPb), dim3(256), 0, st, ba);
       if (std::max(smem_w, smem_rec) > (size_t)h->lds_per_block)
         return fail(HIPNMF_ERR_UNSUPPORTED, "n_features=%d n_components=%d needs more LDS per workgroup than this device has", m, k);
       with_kp([&](auto kp) {
@@ -740,6 +776,8 @@ int hipnmf_shard_wide(hipnmf_handle* h, const hipnmf_problem* p, int op, const r
     hb.l1h = (real)p->l1_reg_H;
     hb.l2h = (real)p->l2_reg_H;
     hb.kl = kl ? 1 : 0;
+    hb.hht_part = nullptr;
+    hb.KP = KPb;
     const size_t smem_h = sizeof(real) * ((size_t)k * k + 128 * (size_t)k);
     if (smem_h > (size_t)h->lds_per_block)
       return fail(HIPNMF_ERR_UNSUPPORTED, "n_components=%d needs more LDS per workgroup than this device has", k);

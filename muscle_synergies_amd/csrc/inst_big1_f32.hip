@@ -4,9 +4,9 @@
 #include "nmf_big1.hpp"
 namespace hipnmf {
 namespace {
-template <int KP, int NQ, int RS>
+template <int KP, int NQ, int RS, bool HL = false, int NST = 2>
 Big1Kernel<float> make_big1(const char* name) {
-  return Big1Kernel<float>{big1_pass_kernel<float, KP, NQ, RS>, Big1Cfg<float, KP, NQ, RS>::smem_bytes(), KP, NQ, RS, name};
+  return Big1Kernel<float>{big1_pass_kernel<float, KP, NQ, RS, HL, NST>, Big1Cfg<float, KP, NQ, RS, HL, NST>::smem_bytes(), KP, NQ, RS, name};
 }
 }  // namespace
 const Big1Kernel<float>* big1_kernel_f32(int KP, int MP) {
@@ -14,9 +14,9 @@ const Big1Kernel<float>* big1_kernel_f32(int KP, int MP) {
       {make_big1<16, 1, 4>("big1_pass_kernel<float,16,1,4>"), make_big1<16, 2, 4>("big1_pass_kernel<float,16,2,4>"),
        make_big1<16, 4, 4>("big1_pass_kernel<float,16,4,4>")},
       {make_big1<32, 1, 4>("big1_pass_kernel<float,32,1,4>"), make_big1<32, 2, 4>("big1_pass_kernel<float,32,2,4>"),
-       make_big1<32, 4, 4>("big1_pass_kernel<float,32,4,4>")},
+       make_big1<32, 4, 4, true>("big1_pass_kernel<float,32,4,4>")},
       {make_big1<48, 1, 4>("big1_pass_kernel<float,48,1,4>"), make_big1<48, 2, 4>("big1_pass_kernel<float,48,2,4>"),
-       make_big1<48, 4, 2>("big1_pass_kernel<float,48,4,2>")},
+       make_big1<48, 4, 2, true, 1>("big1_pass_kernel<float,48,4,2>")},
       {make_big1<64, 1, 4>("big1_pass_kernel<float,64,1,4>"), make_big1<64, 2, 2>("big1_pass_kernel<float,64,2,2>"),
        make_big1<64, 4, 2>("big1_pass_kernel<float,64,4,2>")}};
   if (KP < 16 || KP > 64 || KP % 16 || MP > 512) return nullptr;

@@ -48,6 +48,8 @@ struct BigArgs {
   real l1w, l2w;
   int kl;   // 1: Kullback-Leibler updates (_nmf.py:556-591, 642-684) -- see the KL notes in every kernel; column records are 3 MP then
   int update_h;  // 0: H stays fixed (NMF.transform): the one-pass kernel (nmf_big1.hpp) skips the record
+  const real* hht_part;  // one-pass kernel: H H^T as partial products per 64-channel block, [B][n_hblk][KP][KP] (big_hupdate_kernel /
+  int n_hblk;            // big_hht_part_kernel write them, the kernel adds them in block order): no H H^T launch per iteration
 };
 // the one-pass kernel of nmf_big1.hpp (instances: inst_big1_f32.hip): KP components padded, 8 waves x 16 NQ channels, RS subtiles per round
 template <typename real>
@@ -396,7 +398,40 @@ struct BigHArgs {
   int rec, ldA, offB, ldB;  // slice records of big_records_kernel: KP MP + KP KP, MP, KP MP, KP; packed sums: k m + k k, m, k m, k
   real l1h, l2h;
   int kl;  // 1: H <- H * (W^T Q) / colsum(W)  (_nmf.py:663-684; colsum in column 0 of the second block), H[H < eps64] = 0 (:866-868)
+  real* hht_part;  // or nullptr: [B][gridDim.y][KP][KP], this workgroup's 64 channels of the NEW H times themselves (zero padded)
+  int KP;
 };
+// partial H H^T of 64 channels held in LDS as sH [k][64] (columns >= ncol are ignored): out [KP][KP], zero beyond k
+template <typename real>
+__device__ __forceinline__ void big_hht_partial(const real* __restrict__ sHn, int k, int ncol, int KP, real* __restrict__ out) {
+  for (int idx = threadIdx.x; idx < KP * KP; idx += blockDim.x) {
+    const int c = idx / KP, c2 = idx % KP;
+    real s = (real)0;
+    if (c < k && c2 < k) {
+      // the lanes of a wave differ in c2: each starts c2 channels further on (rows are 64 values apart: without the skew all
+      // lanes would sit on one bank); a fixed order per entry all the same
+      int jj = c2 % ncol;
+      for (int n = 0; n < ncol; ++n) {
+        s = fma_(sHn[c * 64 + jj], sHn[c2 * 64 + jj], s);
+        jj = (jj + 1 == ncol) ? 0 : jj + 1;
+      }
+    }
+    out[idx] = s;
+  }
+}
+// the same partial products straight from H (before the first iteration; transform): grid (B, ceil(m / 64)), 256 threads,
+// dynamic LDS k * 64 values
+template <typename real>
+__global__ void __launch_bounds__(256) big_hht_part_kernel(BigHArgs<real> a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char big_smem[];
+  real* const sHn = reinterpret_cast<real*>(big_smem);
+  const int b = blockIdx.x, c0 = (int)blockIdx.y * 64, k = a.k;
+  const int ncol = (a.m - c0 < 64) ? a.m - c0 : 64;
+  const real* __restrict__ Hb = a.H + (long long)b * k * a.m;
+  for (int idx = threadIdx.x; idx < k * ncol; idx += 256) sHn[(idx / ncol) * 64 + idx % ncol] = Hb[(long long)(idx / ncol) * a.m + c0 + idx % ncol];
+  __syncthreads();
+  big_hht_partial<real>(sHn, k, ncol, a.KP, a.hht_part + ((long long)b * gridDim.y + blockIdx.y) * a.KP * a.KP);
+}
 template <typename real>
 __global__ void __launch_bounds__(256) big_hupdate_kernel(BigHArgs<real> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char big_smem[];
@@ -409,18 +444,22 @@ __global__ void __launch_bounds__(256) big_hupdate_kernel(BigHArgs<real> a) {
   const int rec = a.rec;
   const real* __restrict__ pb = a.part + (long long)b * a.S * rec;
   real* __restrict__ Hb = a.H + (long long)b * k * a.m;
-  for (int idx = tid; idx < k * k; idx += 256) {
-    const int off = a.offB + (idx / k) * a.ldB + idx % k;
+  // records summed in slice order; four loads in flight per value (the additions keep the order)
+  auto slice_sum = [&](int off) __attribute__((always_inline)) -> real {
     real s = (real)0;
-    for (int q = 0; q < a.S; ++q) s += pb[(long long)q * rec + off];
-    sB[idx] = s;
-  }
+    int q = 0;
+    for (; q + 4 <= a.S; q += 4) {
+      const real v0 = pb[(long long)q * rec + off], v1 = pb[(long long)(q + 1) * rec + off], v2 = pb[(long long)(q + 2) * rec + off],
+                 v3 = pb[(long long)(q + 3) * rec + off];
+      s = (((s + v0) + v1) + v2) + v3;
+    }
+    for (; q < a.S; ++q) s += pb[(long long)q * rec + off];
+    return s;
+  };
+  for (int idx = tid; idx < k * k; idx += 256) sB[idx] = slice_sum(a.offB + (idx / k) * a.ldB + idx % k);
   for (int idx = tid; idx < k * ncol; idx += 256) {
     const int c = idx / ncol, jj = idx % ncol;
-    const int off = c * a.ldA + c0 + jj;
-    real s = (real)0;
-    for (int q = 0; q < a.S; ++q) s += pb[(long long)q * rec + off];
-    sNum[c * 64 + jj] = s;
+    sNum[c * 64 + jj] = slice_sum(c * a.ldA + c0 + jj);
     sHo[c * 64 + jj] = Hb[(long long)c * a.m + c0 + jj];
   }
   __syncthreads();
@@ -441,6 +480,11 @@ __global__ void __launch_bounds__(256) big_hupdate_kernel(BigHArgs<real> a) {
     real hn = hold * (sNum[c * 64 + jj] / d);
     if (a.kl && hn < (real)2.220446049250313e-16) hn = (real)0;
     Hb[(long long)c * a.m + c0 + jj] = hn;
+    if (a.hht_part) sNum[c * 64 + jj] = hn;  // (each thread overwrites only the numerators it has consumed)
+  }
+  if (a.hht_part) {  // the next iteration's H H^T, this block's share (the one-pass kernel adds the blocks in order)
+    __syncthreads();
+    big_hht_partial<real>(sNum, k, ncol, a.KP, a.hht_part + ((long long)b * gridDim.y + blockIdx.y) * a.KP * a.KP);
   }
 }
 

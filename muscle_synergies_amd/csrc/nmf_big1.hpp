@@ -29,23 +29,29 @@
 
 namespace hipnmf {
 
-template <typename real, int KP, int NQ, int RS>
+// HL: the wave's block of H (the numerator's A operand) lives in LDS instead of registers -- the instances whose register
+// budget (256 at two waves per SIMD) it would break: <32, 4, 4> spilled 66 values, reloaded from scratch at the top of every
+// round BEHIND the X prefetch in the memory counter's order, i.e. every round waited for its youngest load.  NST: X stages per wave.
+template <typename real, int KP, int NQ, int RS, bool HL = false, int NST = 2>
 struct Big1Cfg {
   static constexpr int NKB = KP / 16, CW = 16 * NQ, NW = 8, NU = RS * NKB, SLOTS = (NU + NW - 1) / NW;
   static constexpr int SW = KP + 4, SX = CW + 4, ROWS = 16 * RS;
   static constexpr int UNIT = 256;                                       // values of one unit's partial numerator (16 rows x 16 components)
-  static constexpr int PW0 = NU * UNIT > 2 * 16 * SX ? NU * UNIT : 2 * 16 * SX;  // per-wave region: the partials | two X stages
+  static constexpr int PW0 = NU * UNIT > NST * 16 * SX ? NU * UNIT : NST * 16 * SX;  // per-wave region: the partials | the X stages
   static constexpr int RED = NU * 16 * KP;                              // W'^T W' partial block rows at the end of the slice
   static constexpr int PW = (NW * PW0 >= RED) ? PW0 : (RED + NW - 1) / NW;
   static constexpr int MAXCH = NW * CW;                                  // channels one workgroup covers
-  __host__ __device__ static constexpr size_t smem_bytes() { return sizeof(real) * (size_t)(NW * PW + ROWS * SW); }
+  static constexpr int HW = HL ? KP * SX : 0;                            // per-wave block of H: [KP][CW + 4]
+  __host__ __device__ static constexpr size_t smem_bytes() { return sizeof(real) * (size_t)(NW * PW + ROWS * SW + NW * HW); }
   static_assert(KP % 16 == 0 && KP >= 16 && KP <= 64 && (NQ == 1 || NQ == 2 || NQ == 4) && RS % 2 == 0, "unsupported shape");
+  static_assert(smem_bytes() <= 160 * 1024, "LDS");
 };
 
-// grid (S, B), 512 threads; dynamic LDS Big1Cfg::smem_bytes().  a.HHt holds H H^T (big_hht_kernel), a.part receives the records.
-template <typename real, int KP, int NQ, int RS>
+// grid (S, B), 512 threads; dynamic LDS Big1Cfg::smem_bytes().  a.hht_part holds H H^T as per-block partial products
+// (big_hht_part_kernel before the first iteration, big_hupdate_kernel afterwards), a.part receives the records.
+template <typename real, int KP, int NQ, int RS, bool HL = false, int NST = 2>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) big1_pass_kernel(BigArgs<real> a) {
-  using C = Big1Cfg<real, KP, NQ, RS>;
+  using C = Big1Cfg<real, KP, NQ, RS, HL, NST>;
   using M = WideMma<real>;
   using acc = typename M::acc;
   constexpr int NKB = C::NKB, CW = C::CW, NW = C::NW, NU = C::NU, SLOTS = C::SLOTS, SW = C::SW, SX = C::SX, ROWS = C::ROWS,
@@ -59,6 +65,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ar = M::arow(j);
   real* const Pw = P + wave * PW;
+  real* const sHw = Wst + ROWS * SW + wave * C::HW;  // HL: [KP][SX] this wave's block of H
   const real* __restrict__ Xb = a.X + (long long)b * a.x_bstride;
   real* __restrict__ Wb = a.W + (long long)b * a.w_bstride;
   const real* __restrict__ Hb = a.H + (long long)b * a.k * a.m;
@@ -73,16 +80,25 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
   constexpr int V = 16 / (int)sizeof(real);           // elements per 16-byte piece
 
   // ---- operands that live in registers for the whole slice ---------------------------------------------------------
-  real hreg[NKB][NQ][4];  // numerator's A operand: lane (i, g), k-step (q, r) <-> H[16 kb + arow(i)][ch_w0 + 16 q + 4 g + r]
+  // numerator's A operand: lane (i, g), k-step (q, r) <-> H[16 kb + arow(i)][ch_w0 + 16 q + 4 g + r]
+  real hreg[HL ? 1 : NKB][HL ? 1 : NQ][4];
+  if constexpr (HL) {  // private to the wave: written and read by the same wave, no barrier
+    for (int idx = lane; idx < KP * CW; idx += 64) {
+      const int c = idx / CW, ch = ch_w0 + idx % CW;
+      sHw[c * SX + idx % CW] = (c < a.k && ch < a.m) ? Hb[(long long)c * a.m + ch] : (real)0;
+    }
+    wide_wave_lds_fence();
+  } else {
 #pragma unroll
-  for (int kb = 0; kb < NKB; ++kb)
+    for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-    for (int q = 0; q < NQ; ++q)
+      for (int q = 0; q < NQ; ++q)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int c = 16 * kb + ar, ch = ch_w0 + 16 * q + 4 * g + r;
-        hreg[kb][q][r] = (c < a.k && ch < a.m) ? Hb[(long long)c * a.m + ch] : (real)0;
-      }
+        for (int r = 0; r < 4; ++r) {
+          const int c = 16 * kb + ar, ch = ch_w0 + 16 * q + 4 * g + r;
+          hreg[kb][q][r] = (c < a.k && ch < a.m) ? Hb[(long long)c * a.m + ch] : (real)0;
+        }
+  }
   // the units this wave owns in phase c: v = wave + NW slot <-> (subtile v / NKB, component block v % NKB)
   int u_s[SLOTS], u_kb[SLOTS];
   real hha[SLOTS][NKB][4];  // denominator's A operand: lane (i, g), k-step r of block kbi <-> HHt[16 kbo + arow(i)][16 kbi + 4 g + r]
@@ -92,8 +108,16 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     u_s[sl] = v < NU ? v / NKB : -1;
     u_kb[sl] = v < NU ? v % NKB : 0;
 #pragma unroll
-    for (int kbi = 0; kbi < NKB; ++kbi)
-      wide_lds_read<real, 4>(a.HHt + (long long)b * KP * KP + (16 * u_kb[sl] + ar) * KP + 16 * kbi + 4 * g, hha[sl][kbi]);
+    for (int kbi = 0; kbi < NKB; ++kbi) {  // H H^T = the 64-channel blocks' partial products added in block order
+      const real* __restrict__ hp = a.hht_part + (long long)b * a.n_hblk * KP * KP + (16 * u_kb[sl] + ar) * KP + 16 * kbi + 4 * g;
+      wide_lds_read<real, 4>(hp, hha[sl][kbi]);
+      for (int blk = 1; blk < a.n_hblk; ++blk) {
+        real t4[4];
+        wide_lds_read<real, 4>(hp + (long long)blk * KP * KP, t4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hha[sl][kbi][r] += t4[r];
+      }
+    }
   }
   acc accA[NKB][NQ], accB[SLOTS][NKB];
   const acc zero = {(real)0, (real)0, (real)0, (real)0};
@@ -165,20 +189,32 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
           for (int kb = 0; kb < NKB; ++kb) num[e][kb] = zero;
 #pragma unroll
-        for (int q = 0; q < NQ; ++q)
+        for (int q = 0; q < NQ; ++q) {
+          real ha[NKB][4];
+#pragma unroll
+          for (int kb = 0; kb < NKB; ++kb) {
+            if constexpr (HL) {
+              wide_lds_read<real, 4>(sHw + (16 * kb + ar) * SX + 16 * q + 4 * g, ha[kb]);
+            } else {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) ha[kb][r] = hreg[kb][q][r];
+            }
+          }
 #pragma unroll
           for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int e = 0; e < 2; ++e)
 #pragma unroll
-              for (int kb = 0; kb < NKB; ++kb) num[e][kb] = M::mma(hreg[kb][q][r], x[s + e][q][r], num[e][kb]);
-        // D: lane (row j, g), register r <-> component 16 kb + 4 g + r: one 16-byte piece per lane and unit
+              for (int kb = 0; kb < NKB; ++kb) num[e][kb] = M::mma(ha[kb][r], x[s + e][q][r], num[e][kb]);
+        }
+        // D: lane (row j, g), register r <-> component 16 kb + 4 g + r: one 16-byte piece per lane and unit, stored at 4 * lane
+        // (consecutive lanes on consecutive pieces: [row][component] order put eight lanes of a pass on two bank groups)
 #pragma unroll
         for (int e = 0; e < 2; ++e)
 #pragma unroll
           for (int kb = 0; kb < NKB; ++kb) {
             real v4[4] = {num[e][kb][0], num[e][kb][1], num[e][kb][2], num[e][kb][3]};
-            wide_lds_write<real, 4>(Pw + ((s + e) * NKB + kb) * UNIT + j * 16 + 4 * g, v4);
+            wide_lds_write<real, 4>(Pw + ((s + e) * NKB + kb) * UNIT + 4 * lane, v4);
           }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -190,10 +226,10 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
       if (u_s[sl] < 0) continue;
       const int v = wave + NW * sl;
       real nsum[4];
-      wide_lds_read<real, 4>(P + v * UNIT + j * 16 + 4 * g, nsum);
+      wide_lds_read<real, 4>(P + v * UNIT + 4 * lane, nsum);
       for (int w2 = 1; w2 < nwa; ++w2) {  // (channel blocks in wave order)
         real t4[4];
-        wide_lds_read<real, 4>(P + w2 * PW + v * UNIT + j * 16 + 4 * g, t4);
+        wide_lds_read<real, 4>(P + w2 * PW + v * UNIT + 4 * lane, t4);
 #pragma unroll
         for (int r = 0; r < 4; ++r) nsum[r] += t4[r];
       }
@@ -235,7 +271,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     // ---- e: accA += W'^T X_w (contraction over the rows), W'^T W' by the unit owners ----------------------------------
 #pragma unroll
     for (int s = 0; s < RS; ++s) {
-      real* const xst = Pw + (s & 1) * 16 * SX;  // this wave's stage (its partials are dead; nobody else touches the region now)
+      real* const xst = Pw + (s % NST) * 16 * SX;  // this wave's stage (its partials are dead; nobody else touches the region now)
       if (active) {
 #pragma unroll
         for (int q = 0; q < NQ; ++q) wide_lds_write<real, 4>(xst + j * SX + 16 * q + 4 * g, x[s][q]);

@@ -15,6 +15,7 @@ ap.add_argument("--k", type=int, default=5)
 ap.add_argument("--iters", type=int, default=100)
 ap.add_argument("--threads", type=int, nargs="*", default=[256, 512])
 ap.add_argument("--variant", type=int, default=0)
+ap.add_argument("--max-slices", type=int, nargs="*", default=[0])
 ap.add_argument("--reps", type=int, default=2)
 ap.add_argument("--loss", default="frobenius")
 ap.add_argument("--dtype", default="float32")
@@ -27,8 +28,8 @@ Xv = X.transpose(1, 2)  # [B, T, m] view of channel-major storage
 if a.rowmajor:
     Xv = Xv.contiguous()
 h = _lib.get_handle(0)
-for nt in a.threads:
-    h.set_tuning(nt, 0, a.variant)
+for nt, msl in [(t, s) for t in a.threads for s in a.max_slices]:
+    h.set_tuning(nt, msl, a.variant)
     for rep in range(a.reps):
         t0 = time.perf_counter()
         r = ms.fit_batched(Xv, W0, H0, max_iter=a.iters, tol=0.0, beta_loss=a.loss)
@@ -36,4 +37,4 @@ for nt in a.threads:
         dt = time.perf_counter() - t0
         its = a.batch * a.iters / (r.kernel_ms * 1e-3)
         gbs = its * X.element_size() * a.T * (a.m + 2 * a.k) / 1e9
-        print(f"threads={nt} rep={rep} wall={dt*1e3:.1f} ms kernel={r.kernel_ms:.1f} ms  {its/1e6:.3f} M matrix-it/s  {gbs:.0f} GB/s algorithmic  err0={float(r.reconstruction_err[0]):.4f}  {h.last_kernel()}", flush=True)
+        print(f"threads={nt} max_slices={msl} rep={rep} wall={dt*1e3:.1f} ms kernel={r.kernel_ms:.1f} ms  {its/1e6:.3f} M matrix-it/s  {gbs:.0f} GB/s algorithmic  err0={float(r.reconstruction_err[0]):.4f}  {h.last_kernel()}", flush=True)
