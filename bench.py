@@ -334,7 +334,7 @@ def _traffic(kernel, **key):
         with open(tpath) as f:
             entries = json.load(f)
         for e in entries if isinstance(entries, list) else [entries]:
-            if e.get("kernel") == kernel and all(e.get(k) == v for k, v in key.items()):
+            if e.get("kernel") == kernel and all(e.get(k) == v for k, v in key.items()):  # (the instance AND the workload)
                 _traffic.source = {"file": "profiles/traffic.json", "measured_round": e.get("measured_round"),
                                    "source_commit": e.get("source_commit"), "method": e.get("method")}
                 return e.get("l2_fabric_bytes_per_launch")

@@ -11,14 +11,14 @@ Big1Kernel<float> make_big1(const char* name) {
 }  // namespace
 const Big1Kernel<float>* big1_kernel_f32(int KP, int MP) {
   static const Big1Kernel<float> t[4][3] = {
-      {make_big1<16, 1, 4>("big1_pass_kernel<float,16,1,4>"), make_big1<16, 2, 4>("big1_pass_kernel<float,16,2,4>"),
-       make_big1<16, 4, 4>("big1_pass_kernel<float,16,4,4>")},
-      {make_big1<32, 1, 4>("big1_pass_kernel<float,32,1,4>"), make_big1<32, 2, 4>("big1_pass_kernel<float,32,2,4>"),
-       make_big1<32, 4, 4, true>("big1_pass_kernel<float,32,4,4>")},
-      {make_big1<48, 1, 4>("big1_pass_kernel<float,48,1,4>"), make_big1<48, 2, 4>("big1_pass_kernel<float,48,2,4>"),
-       make_big1<48, 4, 2, true, 1>("big1_pass_kernel<float,48,4,2>")},
-      {make_big1<64, 1, 4>("big1_pass_kernel<float,64,1,4>"), make_big1<64, 2, 2>("big1_pass_kernel<float,64,2,2>"),
-       make_big1<64, 4, 2>("big1_pass_kernel<float,64,4,2>")}};
+      {make_big1<16, 1, 4>("big1_pass_kernel<float,16,1,4,false,2>"), make_big1<16, 2, 4>("big1_pass_kernel<float,16,2,4,false,2>"),
+       make_big1<16, 4, 4>("big1_pass_kernel<float,16,4,4,false,2>")},
+      {make_big1<32, 1, 4>("big1_pass_kernel<float,32,1,4,false,2>"), make_big1<32, 2, 4>("big1_pass_kernel<float,32,2,4,false,2>"),
+       make_big1<32, 4, 4, true>("big1_pass_kernel<float,32,4,4,true,2>")},
+      {make_big1<48, 1, 4>("big1_pass_kernel<float,48,1,4,false,2>"), make_big1<48, 2, 4>("big1_pass_kernel<float,48,2,4,false,2>"),
+       make_big1<48, 4, 2, true, 1>("big1_pass_kernel<float,48,4,2,true,1>")},
+      {make_big1<64, 1, 4>("big1_pass_kernel<float,64,1,4,false,2>"), make_big1<64, 2, 2>("big1_pass_kernel<float,64,2,2,false,2>"),
+       make_big1<64, 4, 2>("big1_pass_kernel<float,64,4,2,false,2>")}};
   if (KP < 16 || KP > 64 || KP % 16 || MP > 512) return nullptr;
   return &t[KP / 16 - 1][MP <= 128 ? 0 : MP <= 256 ? 1 : 2];
 }

@@ -21,7 +21,7 @@ ap.add_argument("--m", type=int, default=16)
 ap.add_argument("--k", type=int, default=5)
 ap.add_argument("--x-layout", default="row")
 ap.add_argument("--commit", default=os.environ.get("HIPNMF_SOURCE_COMMIT", "unknown"), help="source commit the library was built from")
-ap.add_argument("--round", default=os.environ.get("HIPNMF_ROUND", "r03"))
+ap.add_argument("--round", default=os.environ.get("HIPNMF_ROUND", "r05"))
 a, _ = ap.parse_known_args()
 
 
@@ -29,7 +29,7 @@ def biggest(sub, counter):
     best = {}
     for f in glob.glob(os.path.join(a.dir, sub, "**", "*_counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            if r["Counter_Name"] == counter and r["Kernel_Name"].startswith("void hipnmf::fit_"):
+            if r["Counter_Name"] == counter and r["Kernel_Name"].startswith(("void hipnmf::fit_", "void hipnmf::big1_pass_")):
                 key = (r["Kernel_Name"], r.get("Dispatch_Id"))
                 best[key] = float(r["Counter_Value"])
     if not best:
@@ -42,12 +42,18 @@ def biggest(sub, counter):
 kname, fetch_kib, n1 = biggest("fetch", "FETCH_SIZE")
 _, write_kib, n2 = biggest("write", "WRITE_SIZE")
 short = kname.split("hipnmf::", 1)[1].split("(", 1)[0].replace(" ", "")
+per_fit = 1
+if short.startswith("big1_pass_kernel"):  # row-sliced path: one launch per ITERATION; the library names it so (hipnmf_last_kernel)
+    short += "[sliced]"
+    per_fit = a.iters  # bench.py's "launch" is the whole fit (HIP events around it): its iterations' launches added up
+    fetch_kib *= per_fit
+    write_kib *= per_fit
 entry = {
     "kernel": short, "batch": a.batch, "iters": a.iters, "T": a.T, "m": a.m, "k": a.k, "x_layout": a.x_layout,
     "fetch_size_kib_avg": fetch_kib, "write_size_kib_avg": write_kib, "launches_averaged": [n1, n2],
     "l2_fabric_bytes_per_launch": 2.0 * fetch_kib * 1024 + write_kib * 1024,
     "l2_fabric_bytes_per_unit": (2.0 * fetch_kib * 1024 + write_kib * 1024) / (a.batch * a.iters),
-    "measured_round": a.round, "source_commit": a.commit,
+    "kernel_launches_per_fit": per_fit, "measured_round": a.round, "source_commit": a.commit,
     "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE -- python3 bench.py --steps 1 --warmup 1 "
               "(tools/measure_traffic.sh); FETCH_SIZE x 2 (gfx950, 16 B/lane streams); includes Infinity-Cache hits",
 }
