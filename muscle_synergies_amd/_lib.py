@@ -250,6 +250,16 @@ def get_handle(device: int = 0) -> Handle:
         return h
 
 
+def release_thread_handles() -> None:
+    """Destroy the calling thread's cached handles (their streams and workspaces): worker threads call this when done."""
+    me = threading.get_ident()
+    with _handles_lock:
+        mine = [k for k in _handles if k[0] == me]
+        hs = [_handles.pop(k) for k in mine]
+    for h in hs:
+        h.close()
+
+
 def device_count() -> int:
     n = load().hipnmf_device_count()
     if n < 0:

@@ -194,8 +194,13 @@ def find_synergies(processed_emg_df: pandas.DataFrame, n_components: int, max_co
 def find_synergies_batched(processed_emg_dfs, n_components: int, max_components: Optional[int] = None, *,
                            max_iter: int = 100_000, tol: float = 1e-6, init=None, random_state=None,
                            alpha_W: float = 0.0, alpha_H="same", l1_ratio: float = 0.0, beta_loss="frobenius",
-                           device=None):
+                           device=None, devices=None, _batched_init: Optional[bool] = None):
     """``find_synergies(df, ..., solver='mu')`` for a list of trials in one GPU launch per rank.
+
+    ``devices=`` scatters the trials over several GPUs (BASELINE.json config #4; the loop this replaces is
+    ``analysis.py:907-912`` over the trials of ``project/segment.py:160-207``): contiguous runs of trials balanced by
+    their rows, one host thread and handle per device, no collective, the per-trial results in the order of the input --
+    trial by trial what the one-device call returns.
 
     ``processed_emg_dfs`` is a sequence of DataFrames with the same muscles (columns) and any numbers of rows
     (e.g. the gait cycles cut by ``project/segment.py``).  Returns one :class:`SynergyRunResult` per trial,
@@ -210,6 +215,19 @@ def find_synergies_batched(processed_emg_dfs, n_components: int, max_components:
     dfs = list(processed_emg_dfs)
     if not dfs:
         raise ValueError("empty EMG DataFrame")
+    if devices is not None:
+        from .multi_gpu import resolve_devices, scatter
+
+        for df in dfs:  # every trial is validated before any device starts (same errors as the one-device call)
+            _check_component_range(df, n_components, max_components)
+        same_len = len({len(df) for df in dfs}) == 1  # decides the init path: fixed for the whole call, not per slice
+        kw = dict(max_iter=max_iter, tol=tol, init=init, random_state=random_state, alpha_W=alpha_W, alpha_H=alpha_H,
+                  l1_ratio=l1_ratio, beta_loss=beta_loss)
+        parts = scatter(len(dfs), resolve_devices(devices),
+                        lambda lo, hi, d: find_synergies_batched(dfs[lo:hi], n_components, max_components, device=f"cuda:{d}",
+                                                                 _batched_init=same_len, **kw),
+                        weights=[len(df) for df in dfs])
+        return [r for _, _, _, part in parts for r in part]
     columns = dfs[0].columns
     for df in dfs:
         _check_component_range(df, n_components, max_components)
@@ -224,7 +242,7 @@ def find_synergies_batched(processed_emg_dfs, n_components: int, max_components:
         template = HipNMF(rank, init=init, tol=tol, max_iter=max_iter, random_state=random_state, alpha_W=alpha_W,
                           alpha_H=alpha_H, l1_ratio=l1_ratio, beta_loss=beta_loss, device=device)
         template._check_params()
-        equal_len = len({a.shape[0] for a in arrays}) == 1
+        equal_len = len({a.shape[0] for a in arrays}) == 1 if _batched_init is None else bool(_batched_init)
         if equal_len and init in (None, "nndsvd", "nndsvda") and rank <= min(arrays[0].shape):
             # one batched on-device NNDSVD (exact Gram-matrix SVD) instead of one randomized SVD per trial
             from .init import nndsvd_init_batched

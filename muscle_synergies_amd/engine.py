@@ -116,8 +116,10 @@ def make_problem(B, T, m, k, *, x_layout, ldx, x_batch_stride, w_layout=_lib.W_R
 def fit_batched(X, W0, H0, *, max_iter: int = 200, tol: float = 1e-4, check_every: int = 10,
                 update_H: bool = True, l1_reg_W: float = 0.0, l1_reg_H: float = 0.0, l2_reg_W: float = 0.0,
                 l2_reg_H: float = 0.0, beta_loss="frobenius", device=None, handle: Optional[_lib.Handle] = None,
-                return_numpy: Optional[bool] = None, overwrite_init: bool = False) -> BatchedResult:
-    """Factorise a batch of matrices on one GPU.
+                return_numpy: Optional[bool] = None, overwrite_init: bool = False, devices=None) -> BatchedResult:
+    """Factorise a batch of matrices on one GPU -- or, with ``devices=``, scattered by matrix over several
+    (:mod:`muscle_synergies_amd.multi_gpu`: contiguous slices, one host thread and handle per device, no collective;
+    results on the host in batch order: NumPy when NumPy went in, CPU tensors otherwise).
 
     Args:
         X: ``[B, T, m]`` (or ``[T, m]``) non-negative float32/float64, NumPy or torch, any dense layout
@@ -132,6 +134,10 @@ def fit_batched(X, W0, H0, *, max_iter: int = 200, tol: float = 1e-4, check_ever
         overwrite_init: let the solver update contiguous device tensors ``W0``/``H0`` in place (no copy).
     """
     torch = _torch()
+    if devices is not None:
+        kw = dict(max_iter=max_iter, tol=tol, check_every=check_every, update_H=update_H, l1_reg_W=l1_reg_W, l1_reg_H=l1_reg_H,
+                  l2_reg_W=l2_reg_W, l2_reg_H=l2_reg_H, beta_loss=beta_loss)
+        return _fit_batched_scattered(X, W0, H0, devices, return_numpy, kw)
     dev = resolve_device(device)
     was_numpy = not isinstance(X, torch.Tensor)
     if return_numpy is None:
@@ -185,45 +191,50 @@ def fit_batched(X, W0, H0, *, max_iter: int = 200, tol: float = 1e-4, check_ever
     return res
 
 
-def fit_batched_multi_gpu(X, W0, H0, *, devices=None, **kw) -> BatchedResult:
-    """Scatter a host-resident batch over the GPUs of this process (contiguous slices, one host thread and
-    one handle per device, no collectives: every factorisation is independent).  Inputs are NumPy arrays;
-    outputs are NumPy arrays in batch order.  The multi-process flavour (one rank per GPU under
-    ``torch.distributed.run``) lives in ``bench.py``."""
-    import threading
+def _gather_batched(parts, as_numpy: bool, ragged: bool = False) -> BatchedResult:
+    """``parts``: the per-device :class:`BatchedResult` objects in batch order -> one result on the host."""
+    from .multi_gpu import cat_host, to_host
+
+    def cat(name):
+        return cat_host([to_host(getattr(r, name), as_numpy) for r in parts])
+
+    if ragged:
+        W = [to_host(w, as_numpy) for r in parts for w in r.W]
+    else:
+        W = cat("W")
+    return BatchedResult(W, cat("H"), cat("n_iter"), cat("reconstruction_err"), cat("vaf"), cat("sse_col"), cat("xsq_col"),
+                         max(r.kernel_ms for r in parts))
+
+
+def _fit_batched_scattered(X, W0, H0, devices, return_numpy, kw) -> BatchedResult:
+    from .multi_gpu import resolve_devices, scatter
 
     torch = _torch()
-    n_dev = torch.cuda.device_count()
-    if n_dev < 1:
-        raise _lib.HipNmfError(_lib.HIPNMF_ERR_NO_DEVICE, "no ROCm GPU visible; no CPU fallback")
-    devices = list(range(n_dev)) if devices is None else list(devices)
-    X = np.asarray(X)
+    devs = resolve_devices(devices)
+    as_numpy = (not isinstance(X, torch.Tensor)) if return_numpy is None else bool(return_numpy)
+    if not isinstance(X, torch.Tensor):
+        X = np.asarray(X)
+    if X.ndim == 2:
+        X, W0, H0 = X[None], W0[None], H0[None]
+    if X.ndim != 3:
+        raise ValueError(f"X must be [B, T, m] or [T, m], got shape {tuple(X.shape)}")
     B = X.shape[0]
-    bounds = partition(B, len(devices))
-    results: list = [None] * len(devices)
-    errors: list = []
+    if B == 0:
+        raise ValueError("empty input")
+    if len(W0) != B or len(H0) != B:
+        raise ValueError("W0 and H0 must hold one starting point per matrix of X")
 
-    def work(i):
-        lo, hi = bounds[i]
-        if hi <= lo:
-            return
-        try:
-            results[i] = fit_batched(X[lo:hi], W0[lo:hi], H0[lo:hi], device=f"cuda:{devices[i]}",
-                                     return_numpy=True, **kw)
-        except Exception as e:  # noqa: BLE001
-            errors.append(e)
+    def work(lo, hi, d):
+        return fit_batched(X[lo:hi], W0[lo:hi], H0[lo:hi], device=f"cuda:{d}", return_numpy=False, **kw)
 
-    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(devices))]
-    for t in threads:
-        t.start()
-    for t in threads:
-        t.join()
-    if errors:
-        raise errors[0]
-    parts = [r for r in results if r is not None]
-    cat = lambda name: np.concatenate([getattr(r, name) for r in parts], axis=0)  # noqa: E731
-    return BatchedResult(cat("W"), cat("H"), cat("n_iter"), cat("reconstruction_err"), cat("vaf"),
-                         cat("sse_col"), cat("xsq_col"), max(r.kernel_ms for r in parts))
+    parts = [r for _, _, _, r in scatter(B, devs, work)]
+    return _gather_batched(parts, as_numpy)
+
+
+def fit_batched_multi_gpu(X, W0, H0, *, devices="all", **kw) -> BatchedResult:
+    """``fit_batched(..., devices=devices)`` (default: every visible GPU).  The multi-process flavour (one rank per GPU
+    under ``torch.distributed.run``) lives in ``bench.py``."""
+    return fit_batched(X, W0, H0, devices=devices, **kw)
 
 
 def partition(n_items: int, n_parts: int):
@@ -276,7 +287,7 @@ def random_init_device(X, k: int, *, seed: int = 0, first_matrix: int = 0, handl
 
 def rank_sweep_native(X, k_min: int, k_max: int, *, vaf_threshold: float = 0.90, max_iter: int = 500, tol: float = 1e-4,
                       seed: int = 0, first_matrix: int = 0, device=None, handle: Optional[_lib.Handle] = None,
-                      stop_at_threshold: bool = False) -> "RankSweepResult":
+                      stop_at_threshold: bool = False, devices=None) -> "RankSweepResult":
     """:func:`rank_sweep_batched` as ONE library call (``hipnmf_rank_sweep_*``: random starting points, fits, VAF
     table and threshold selection inside the library; usable from any host language).  Frobenius loss,
     ``init='random'`` from the library's generator; ``vaf[k]`` holds the all-muscles column only.
@@ -284,8 +295,16 @@ def rank_sweep_native(X, k_min: int, k_max: int, *, vaf_threshold: float = 0.90,
     ``stop_at_threshold=True`` (``hipnmf_rank_sweep_stop_*``): a trial whose VAF has reached ``vaf_threshold`` is not
     fitted at the higher ranks (BASELINE.json config #4's "stop"); the skipped (trial, rank) pairs report NaN VAF /
     residual, 0 iterations and zero components, ``selected`` is identical to the compute-all mode.  ``kernel_ms``
-    is not available from the native sweep (several launches); time the call."""
+    is not available from the native sweep (several launches); time the call.
+
+    ``devices=``: trials scattered over several GPUs, results on the host.  The library's generator is keyed by
+    ``(seed, first_matrix + b, element)``, so the scattered sweep returns exactly what the one-device call returns."""
     torch = _torch()
+    if devices is not None:
+        def one(Xs, lo, d):
+            return rank_sweep_native(Xs, k_min, k_max, vaf_threshold=vaf_threshold, max_iter=max_iter, tol=tol, seed=seed,
+                                     first_matrix=first_matrix + lo, device=f"cuda:{d}", stop_at_threshold=stop_at_threshold)
+        return _rank_sweep_scattered(X, devices, one)
     dev = resolve_device(device)
     Xt = _as_device_tensor(X, dev)
     if Xt.dim() == 2:
@@ -341,11 +360,20 @@ class RankSweepResult:
 
 def rank_sweep_batched(X, k_min: int, k_max: int, *, vaf_threshold: float = 0.90, max_iter: int = 500,
                        tol: float = 1e-4, seed: int = 0, device=None, keep_W: bool = False,
-                       init: str = "random", beta_loss="frobenius") -> RankSweepResult:
+                       init: str = "random", beta_loss="frobenius", devices=None) -> RankSweepResult:
     """``find_synergies(df, k_min, k_max)`` for a whole batch of trials: one batched fit per rank, VAF per
     trial and rank, and the smallest rank with VAF >= ``vaf_threshold``.  ``init='random'`` draws the starting
-    factors on the device; ``'nndsvda'`` / ``'nndsvd'`` (sklearn's default family) use the on-device NNDSVD."""
+    factors on the device; ``'nndsvda'`` / ``'nndsvd'`` (sklearn's default family) use the on-device NNDSVD.
+
+    ``devices=``: trials scattered over several GPUs, results on the host.  The slice that starts at trial ``lo`` draws its
+    random starting points with ``seed + lo`` (torch's generator is a stream, not a counter: the draws of a slice cannot
+    be those of the same trials inside a longer batch; same law) -- the NNDSVD inits do not depend on the split."""
     torch = _torch()
+    if devices is not None:
+        def one(Xs, lo, d):
+            return rank_sweep_batched(Xs, k_min, k_max, vaf_threshold=vaf_threshold, max_iter=max_iter, tol=tol, seed=seed + lo,
+                                      device=f"cuda:{d}", keep_W=keep_W, init=init, beta_loss=beta_loss)
+        return _rank_sweep_scattered(X, devices, one)
     dev = resolve_device(device)
     Xt = _as_device_tensor(X, dev)
     if Xt.dim() == 2:
@@ -379,12 +407,38 @@ def rank_sweep_batched(X, k_min: int, k_max: int, *, vaf_threshold: float = 0.90
     return res
 
 
+def _rank_sweep_scattered(X, devices, one) -> RankSweepResult:
+    """Trials of ``X [B, T, m]`` in contiguous slices over ``devices``; ``one(X_slice, lo, device_index)`` is the one-device
+    sweep of a slice.  Gathers on the host (CPU tensors) in trial order."""
+    from .multi_gpu import cat_host, resolve_devices, scatter, to_host
+
+    torch = _torch()
+    devs = resolve_devices(devices)
+    Xa = X if isinstance(X, torch.Tensor) else np.asarray(X)
+    if Xa.ndim == 2:
+        Xa = Xa[None]
+    parts = [r for _, _, _, r in scatter(Xa.shape[0], devs, lambda lo, hi, d: one(Xa[lo:hi], lo, d))]
+    ranks = parts[0].ranks
+
+    def cat(get):
+        return cat_host([to_host(get(r), False) for r in parts])
+
+    res = RankSweepResult(ranks, cat(lambda r: r.vaf_all), {k: cat(lambda r: r.vaf[k]) for k in ranks},
+                          {k: cat(lambda r: r.n_iter[k]) for k in ranks}, {k: cat(lambda r: r.reconstruction_err[k]) for k in ranks},
+                          {k: cat(lambda r: r.components[k]) for k in ranks}, cat(lambda r: r.selected),
+                          max(r.kernel_ms for r in parts))
+    if all(hasattr(r, "W") for r in parts):
+        res.W = {k: cat(lambda r: r.W[k]) for k in ranks}
+    return res
+
+
 # ------------------------------------------------------------------------------------------------
 # Ragged batches: trials of unequal length (gait cycles, segments of a recording)
 def fit_ragged(Xs, W0s, H0s, *, max_iter: int = 200, tol: float = 1e-4, check_every: int = 10,
                update_H: bool = True, l1_reg_W: float = 0.0, l1_reg_H: float = 0.0, l2_reg_W: float = 0.0,
-               l2_reg_H: float = 0.0, beta_loss="frobenius", device=None, handle: Optional[_lib.Handle] = None):
-    """Factorise ``B`` matrices with different numbers of rows in one launch.
+               l2_reg_H: float = 0.0, beta_loss="frobenius", device=None, handle: Optional[_lib.Handle] = None, devices=None):
+    """Factorise ``B`` matrices with different numbers of rows in one launch (``devices=``: one launch per GPU, the
+    matrices scattered in contiguous runs balanced by their rows; results on the host as CPU tensors).
 
     ``Xs[b]`` is ``(T_b, m)``, ``W0s[b]`` ``(T_b, k)``, ``H0s[b]`` ``(k, m)`` (NumPy or torch; one dtype, one
     ``m`` and one ``k`` for the whole batch).  The matrices are packed on the device in the engine-native
@@ -393,10 +447,19 @@ def fit_ragged(Xs, W0s, H0s, *, max_iter: int = 200, tol: float = 1e-4, check_ev
     a list of ``(T_b, k)`` tensors; the other fields are batched tensors as in :func:`fit_batched`.
     """
     torch = _torch()
-    dev = resolve_device(device)
     B = len(Xs)
     if B == 0 or len(W0s) != B or len(H0s) != B:
         raise ValueError("Xs, W0s and H0s must be non-empty lists of equal length")
+    if devices is not None:
+        from .multi_gpu import resolve_devices, scatter
+
+        kw = dict(max_iter=max_iter, tol=tol, check_every=check_every, update_H=update_H, l1_reg_W=l1_reg_W, l1_reg_H=l1_reg_H,
+                  l2_reg_W=l2_reg_W, l2_reg_H=l2_reg_H, beta_loss=beta_loss)
+        parts = scatter(B, resolve_devices(devices),
+                        lambda lo, hi, d: fit_ragged(Xs[lo:hi], W0s[lo:hi], H0s[lo:hi], device=f"cuda:{d}", **kw),
+                        weights=[int(x.shape[0]) for x in Xs])
+        return _gather_batched([r for _, _, _, r in parts], False, ragged=True)
+    dev = resolve_device(device)
     first = _as_device_tensor(Xs[0], dev)
     dtype = first.dtype if first.dtype in (torch.float32, torch.float64) else torch.float64
     m = first.shape[1]
@@ -459,15 +522,31 @@ class RestartResult:
 
 def fit_restarts(X, k: int, n_restarts: int = 8, *, seed: int = 0, max_iter: int = 200, tol: float = 1e-4,
                  check_every: int = 10, beta_loss="frobenius", l1_reg_W: float = 0.0, l1_reg_H: float = 0.0,
-                 l2_reg_W: float = 0.0, l2_reg_H: float = 0.0, device=None) -> RestartResult:
+                 l2_reg_W: float = 0.0, l2_reg_H: float = 0.0, device=None, devices=None) -> RestartResult:
     """``n_restarts`` random-init factorisations (sklearn's ``init='random'`` law, drawn on the device) of every
     matrix of ``X [B, T, m]`` in ONE launch, and the best of them per matrix by final residual.
 
     The ``B * R`` factorisations are independent units for the engine (one workgroup each); the restarts of a
     trial read the same copy of its X through the per-matrix descriptors of ``hipnmf_fit_ragged_*``, so X is
     neither duplicated in HBM nor re-uploaded.
+
+    ``devices=``: trials scattered over several GPUs (all restarts of a trial stay together), results on the host; the slice
+    that starts at trial ``lo`` draws with ``seed + lo``.
     """
     torch = _torch()
+    if devices is not None:
+        from .multi_gpu import cat_host, resolve_devices, scatter, to_host
+
+        Xa = X if isinstance(X, torch.Tensor) else np.asarray(X)
+        if Xa.ndim == 2:
+            Xa = Xa[None]
+        kw = dict(max_iter=max_iter, tol=tol, check_every=check_every, beta_loss=beta_loss, l1_reg_W=l1_reg_W, l1_reg_H=l1_reg_H,
+                  l2_reg_W=l2_reg_W, l2_reg_H=l2_reg_H)
+        parts = [r for _, _, _, r in scatter(Xa.shape[0], resolve_devices(devices),
+                                             lambda lo, hi, d: fit_restarts(Xa[lo:hi], k, n_restarts, seed=seed + lo, device=f"cuda:{d}", **kw))]
+        best = _gather_batched([r.best for r in parts], False)
+        return RestartResult(best, cat_host([to_host(r.restart_err, False) for r in parts]),
+                             cat_host([to_host(r.chosen, False) for r in parts]), max(r.kernel_ms for r in parts))
     dev = resolve_device(device)
     Xt = _as_device_tensor(X, dev)
     if Xt.dim() == 2:

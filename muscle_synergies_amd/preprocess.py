@@ -83,8 +83,9 @@ def window_in_samples(window_size: Union[int, float], sampling_frequency: Option
 
 def emg_envelope_batched(raw, window_size: Union[int, float] = 0, *, sampling_frequency: Optional[int] = None,
                          zero_center: bool = True, reduce_to: Optional[int] = None, normalize: bool = True,
-                         device=None, kind="linear"):
-    """``zero_center -> rms -> time_normalize -> normalize`` for a batch of recordings on one GPU.
+                         device=None, kind="linear", devices=None):
+    """``zero_center -> rms -> time_normalize -> normalize`` for a batch of recordings on one GPU (``devices=``: the
+    recordings scattered over several, the envelopes gathered on the host as a CPU tensor ``[B, T_out, m]``).
 
     Args:
         raw: ``[B, T, m]`` (or ``[T, m]``) float32/float64, NumPy or torch, any dense layout.
@@ -96,6 +97,10 @@ def emg_envelope_batched(raw, window_size: Union[int, float] = 0, *, sampling_fr
         ``fit_batched`` streams without any copy).
     """
     torch = _torch()
+    if devices is not None:
+        return _scatter_recordings(raw, devices, lambda part, d: emg_envelope_batched(
+            part, window_size, sampling_frequency=sampling_frequency, zero_center=zero_center, reduce_to=reduce_to,
+            normalize=normalize, device=f"cuda:{d}", kind=kind))
     dev = resolve_device(device)
     Xt = _as_device_tensor(raw, dev)
     if Xt.dim() == 2:
@@ -123,6 +128,21 @@ def emg_envelope_batched(raw, window_size: Union[int, float] = 0, *, sampling_fr
     torch.cuda.synchronize(dev)
     _lib.check(fn(h.ptr, ctypes.byref(p), ctypes.c_void_p(Xt.data_ptr()), ctypes.c_void_p(out.data_ptr())))
     return out.transpose(1, 2)
+
+
+def _scatter_recordings(raw, devices, one):
+    """Recordings ``[B, T, m]`` in contiguous slices over ``devices`` (no collective: every recording is independent);
+    ``one(slice, device_index)`` returns the slice's result on its device; gathered as one CPU tensor in batch order."""
+    from .multi_gpu import cat_host, resolve_devices, scatter, to_host
+
+    torch = _torch()
+    Xa = raw if isinstance(raw, torch.Tensor) else np.asarray(raw)
+    if Xa.ndim == 2:
+        Xa = Xa[None]
+    if Xa.ndim != 3 or Xa.shape[0] == 0:
+        raise ValueError(f"need [B, T, m] or [T, m] with B >= 1, got shape {tuple(Xa.shape)}")
+    parts = scatter(Xa.shape[0], resolve_devices(devices), lambda lo, hi, d: one(Xa[lo:hi], d))
+    return cat_host([to_host(r, False) for _, _, _, r in parts])
 
 
 def _frame_through_gpu(signal_df: pandas.DataFrame, **kw) -> np.ndarray:
@@ -208,7 +228,7 @@ SOSFILT_MODES = {"exact": 0, "scan": 1}  # HIPNMF_SOSFILT_EXACT / HIPNMF_SOSFILT
 
 
 def sosfilt_batched(x, sos, *, zero_lag: bool = True, zero_center: bool = False, rectify: bool = False,
-                    padlen: Optional[int] = None, device=None, mode: str = "exact"):
+                    padlen: Optional[int] = None, device=None, mode: str = "exact", devices=None):
     """``scipy.signal.sosfiltfilt(sos, x, axis=time)`` (``zero_lag``) or ``sosfilt`` for a batch of recordings.
 
     Args:
@@ -221,9 +241,12 @@ def sosfilt_batched(x, sos, *, zero_lag: bool = True, zero_center: bool = False,
             and runs about four times faster on a batch).
     Returns:
         tensor ``[B, T, m]`` on the device (transposed view of channel-major storage), dtype of ``x``; the
-        arithmetic is fp64 either way.
+        arithmetic is fp64 either way.  ``devices=``: recordings scattered over several GPUs, a CPU tensor comes back.
     """
     torch = _torch()
+    if devices is not None:
+        return _scatter_recordings(x, devices, lambda part, d: sosfilt_batched(
+            part, sos, zero_lag=zero_lag, zero_center=zero_center, rectify=rectify, padlen=padlen, device=f"cuda:{d}", mode=mode))
     dev = resolve_device(device)
     sos = np.ascontiguousarray(np.asarray(sos, dtype=np.float64))
     if sos.ndim != 2 or sos.shape[1] != 6:
@@ -306,11 +329,15 @@ def linear_envelope(signal_df: pandas.DataFrame, critical_freqs, sampling_freque
 
 def linear_envelope_batched(raw, critical_freqs, sampling_frequency, order: int = 4, *, filter_type: str = "butter",
                             zero_lag: bool = True, cheby_param: Optional[float] = None, zero_center: bool = True,
-                            reduce_to: Optional[int] = None, normalize: bool = True, device=None, mode: str = "scan"):
+                            reduce_to: Optional[int] = None, normalize: bool = True, device=None, mode: str = "scan", devices=None):
     """``linear_envelope -> time_normalize -> normalize`` for a batch of recordings ``[B, T, m]`` on one GPU
     (the filter-based alternative to :func:`emg_envelope_batched`).  Returns ``[B, T_out, m]`` on the device,
     channel-major underneath, ready for ``fit_batched``.  ``mode``: see :func:`sosfilt_batched`; the batched producer of X defaults
     to the time-parallel filter (the reference-facing single-frame functions keep scipy's bits)."""
+    if devices is not None:  # the whole chain per slice on its device, one gather at the end
+        return _scatter_recordings(raw, devices, lambda part, d: linear_envelope_batched(
+            part, critical_freqs, sampling_frequency, order, filter_type=filter_type, zero_lag=zero_lag, cheby_param=cheby_param,
+            zero_center=zero_center, reduce_to=reduce_to, normalize=normalize, device=f"cuda:{d}", mode=mode))
     sos = design_sos(filter_type, order, sampling_frequency, critical_freqs, "lowpass", cheby_param)
     env = sosfilt_batched(raw, sos, zero_lag=zero_lag, zero_center=zero_center, rectify=True, device=device, mode=mode)
     if reduce_to or normalize:

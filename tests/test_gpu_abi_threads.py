@@ -18,7 +18,12 @@ pytestmark = pytest.mark.gpu
 
 PATHS = ("fit_persistent_kernel<", "fit_rowlane_kernel<", "fit_small_kernel<", "fit_coop_kernel<", "slice_pass_kernel<",
          "fit_wide_kernel<", "fit_wide4_kernel<", "fit_wide4d_kernel<", "[sliced]", "[ragged]", "[kl]", "rank_sweep,",
-         "rank_sweep_stop", "random_init", "emg_envelope", "sosfilt,", "sosfilt_scan")
+         "rank_sweep_stop", "random_init", "emg_envelope", "sosfilt,", "sosfilt_scan",
+         # round 4 / 5 entry points: the general-shape kernels (one-pass fp32, two-pass fp64 / KL), the 256-channel one-wave
+         # instance, the shard building blocks (narrow and general-shape layouts, KL), the native sharded loop with a host-side
+         # collective callback, the NNDSVD building blocks
+         "big1_pass_kernel<", "big_pass_w_kernel<double", "big_pass_w_kernel<float", "fit_wide_kernel<float,256", "shard_narrow,",
+         "shard_wide,", "shard_wide_kl", "fit_tsharded,", "fit_tsharded_wide", "gram+nndsvd_stats+nndsvd_write")
 
 
 def _stress(*args, timeout=900):
@@ -41,7 +46,8 @@ def test_graph_replayed_and_cooperative_paths_in_lock_step():
     """The chip-filling paths -- both row-sliced families replayed as hipGraphs, the cooperative kernel -- with every thread in
     the same case at the same time (round 3's failure: 'operation failed due to a previous error during capture')."""
     _stress("--threads", "3", "--rounds", "4", "--same-order", "--only",
-            "wide_sliced,wide4_sliced,wide4d_sliced_stop,wide_sliced_auto,sliced_graph,sliced_graph_stop,coop,coop_f64")
+            "wide_sliced,wide4_sliced,wide4d_sliced_stop,wide_sliced_auto,sliced_graph,sliced_graph_stop,coop,coop_f64,big,big_stop,"
+            "big_f64,big_kl")
 
 
 def test_rank_range_on_long_and_wide_frames_runs_concurrently_with_torch_in_the_process():

@@ -255,6 +255,127 @@ def sosfilt_case(dtype, B, T, m, zero_lag, mode=0):
     return run
 
 
+def shard_case(dtype, T, m, k, *, wide=False, loss=0, iters=3):
+    """hipnmf_shard_pass / _hupdate / _residual (one rank: sums go straight back in), `iters` iterations.  Narrow layouts
+    (channel-major X, component-major W) or the general-shape ones (row-major X, W padded to 16 components: W_ROW_MAJOR_PAD16)."""
+    sfx = "f32" if dtype == np.float32 else "f64"
+
+    def run(h):
+        d = Dev()
+        try:
+            X, W0, H0 = fit_inputs(dtype, 1, T, m, k, wide)
+            if wide:
+                vec = 16 // np.dtype(dtype).itemsize
+                ldx, kp = (m + vec - 1) // vec * vec, (k + 15) // 16 * 16
+                Xc = np.zeros((1, T, ldx), dtype)
+                Xc[:, :, :m] = X
+                Wc = np.zeros((1, T, kp), dtype)
+                Wc[:, :, :k] = W0
+                p = problem(1, T, m, k, x_layout=L.X_ROW_MAJOR, ldx=ldx, xbs=T * ldx, w_layout=L.W_ROW_MAJOR_PAD16, max_iter=1, loss=loss)
+            else:
+                Xc, Wc = X, np.ascontiguousarray(W0.transpose(0, 2, 1))
+                p = problem(1, T, m, k, x_layout=L.X_CHANNEL_MAJOR, ldx=T, xbs=T * m, w_layout=L.W_COMPONENT_MAJOR, max_iter=1)
+            dX, dW, dH = d.put(Xc), d.put(Wc), d.put(H0)
+            dS = d.put(np.zeros((1, k * m + k * k), dtype))
+            dE, dQ = d.put(np.zeros((1, m), dtype)), d.put(np.zeros((1, m), dtype))
+            for _ in range(iters):
+                ok(getattr(lib, "hipnmf_shard_pass_" + sfx)(h, ctypes.byref(p), dX, dW, dH, dS), "shard_pass")
+                ok(getattr(lib, "hipnmf_shard_hupdate_" + sfx)(h, ctypes.byref(p), dH, dS), "shard_hupdate")
+            ok(getattr(lib, "hipnmf_shard_residual_" + sfx)(h, ctypes.byref(p), dX, dW, dH, dE, dQ), "shard_residual")
+            return ("shard_wide" if wide else "shard_narrow") + ("_kl" if loss else ""), [
+                d.get(dW, Wc.shape, dtype), d.get(dH, H0.shape, dtype), d.get(dS, (1, k * m + k * k), dtype), d.get(dE, (1, m), dtype),
+                d.get(dQ, (1, m), dtype)]
+        finally:
+            d.free()
+
+    return run
+
+
+def tsharded_case(dtype, T, m, k, *, wide=False, max_iter=25):
+    """hipnmf_fit_tsharded_* with a HOST-SIDE all-reduce callback (one rank: it synchronises the stream, reads the buffer back,
+    counts the call and leaves the sums as they are) -- the C frames call back into Python from several threads at once."""
+    sfx = "f32" if dtype == np.float32 else "f64"
+    hip.hipStreamSynchronize.argtypes = [vp]
+
+    def run(h):
+        d = Dev()
+        calls = []
+
+        def cb(buf, count, elem_size, stream, user):
+            if hip.hipStreamSynchronize(vp(stream)) != 0:
+                return 1
+            host = np.empty(count, dtype)
+            if hip.hipMemcpy(host.ctypes.data_as(vp), vp(buf), count * elem_size, 2) != 0:
+                return 1
+            calls.append((count, float(host.sum())))
+            return 0
+
+        fn_cb = L.ALLREDUCE_FN(cb)
+        try:
+            X, W0, H0 = fit_inputs(dtype, 1, T, m, k, wide)
+            if wide:
+                vec = 16 // np.dtype(dtype).itemsize
+                ldx, kp = (m + vec - 1) // vec * vec, (k + 15) // 16 * 16
+                Xc = np.zeros((1, T, ldx), dtype)
+                Xc[:, :, :m] = X
+                Wc = np.zeros((1, T, kp), dtype)
+                Wc[:, :, :k] = W0
+                p = problem(1, T, m, k, x_layout=L.X_ROW_MAJOR, ldx=ldx, xbs=T * ldx, w_layout=L.W_ROW_MAJOR_PAD16, max_iter=max_iter)
+            else:
+                Xc, Wc = X, np.ascontiguousarray(W0.transpose(0, 2, 1))
+                p = problem(1, T, m, k, x_layout=L.X_CHANNEL_MAJOR, ldx=T, xbs=T * m, w_layout=L.W_COMPONENT_MAJOR, max_iter=max_iter)
+            dX, dW, dH = d.put(Xc), d.put(Wc), d.put(H0)
+            dE, dN = d.put(np.zeros(1, dtype)), d.put(np.zeros(1, np.int32))
+            dS, dQ = d.put(np.zeros((1, m), dtype)), d.put(np.zeros((1, m), dtype))
+            fn = getattr(lib, "hipnmf_fit_tsharded_" + sfx)
+            fn.argtypes = [vp, vp, vp, vp, vp, L.ALLREDUCE_FN, vp, vp, vp, vp, vp]
+            fn.restype = ctypes.c_int
+            ok(fn(h, ctypes.addressof(p), dX, dW, dH, fn_cb, None, dE, dN, dS, dQ), "fit_tsharded")
+            if len(calls) != max_iter + 1 or calls[0][0] != k * m + k * k or calls[-1][0] != 2 * m:
+                raise Fail("fit_tsharded: %d all-reduce calls, sizes %s" % (len(calls), sorted({c for c, _ in calls})))
+            return "fit_tsharded_wide" if wide else "fit_tsharded", [
+                d.get(dW, Wc.shape, dtype), d.get(dH, H0.shape, dtype), d.get(dE, (1,), dtype), d.get(dS, (1, m), dtype),
+                np.array([s for _, s in calls])]
+        finally:
+            d.free()
+
+    return run
+
+
+def nndsvd_case(dtype, B, T, m, k):
+    """hipnmf_gram, then (host: eigenvectors of the Gram matrix) hipnmf_nndsvd_stats and hipnmf_nndsvd_write."""
+    sfx = "f32" if dtype == np.float32 else "f64"
+
+    def run(h):
+        d = Dev()
+        try:
+            X, _, _ = fit_inputs(dtype, B, T, m, k, True)
+            dX = d.put(X)
+            p = problem(B, T, m, k, x_layout=L.X_ROW_MAJOR, ldx=m, xbs=T * m)
+            dG, dC = d.put(np.zeros((B, m, m))), d.put(np.zeros((B, m)))
+            ok(getattr(lib, "hipnmf_gram_" + sfx)(h, ctypes.byref(p), dX, dG, dC), "gram")
+            G = d.get(dG, (B, m, m), np.float64)
+            V, inv_s = np.zeros((B, k, m)), np.zeros((B, k))
+            for b in range(B):
+                w, v = np.linalg.eigh(G[b])
+                V[b] = v[:, ::-1][:, :k].T
+                inv_s[b] = 1.0 / np.sqrt(np.maximum(w[::-1][:k], 1e-300))
+            dV, dI = d.put(V), d.put(inv_s)
+            dSt = d.put(np.zeros((B, k, 4)))
+            ok(getattr(lib, "hipnmf_nndsvd_stats_" + sfx)(h, ctypes.byref(p), dX, dV, dI, dSt), "nndsvd_stats")
+            st = d.get(dSt, (B, k, 4), np.float64)
+            coef = np.ones((B, k, 2))
+            coef[:, :, 0] = 0.5
+            dCo, dF = d.put(coef), d.put(np.full(B, 0.01))
+            dW = d.put(np.zeros((B, T, k), dtype))
+            ok(getattr(lib, "hipnmf_nndsvd_write_" + sfx)(h, ctypes.byref(p), dX, dV, dI, dCo, dF, 1e-6, dW), "nndsvd_write")
+            return "gram+nndsvd_stats+nndsvd_write", [G, d.get(dC, (B, m), np.float64), st, d.get(dW, (B, T, k), dtype)]
+        finally:
+            d.free()
+
+    return run
+
+
 f32, f64 = np.float32, np.float64
 CASES = {
     # narrow kernels (nmf_kernels.hpp, nmf_rowlane.hpp, nmf_small.hpp)
@@ -280,6 +401,24 @@ CASES = {
     "wide4_sliced": fit_case(f32, 1, 20000, 64, 8, variant=2, max_iter=140, expect="[sliced]"),
     "wide4d_sliced_stop": fit_case(f64, 1, 20000, 64, 5, variant=2, max_iter=200, tol=1e-5, expect="[sliced]"),
     "wide_sliced_auto": fit_case(f64, 1, 20000, 64, 4, max_iter=140, expect="[sliced]"),
+    # general shapes (nmf_big1.hpp one-pass kernel: a kernel-node graph of two launches per iteration, per-handle workspace;
+    # nmf_big.hpp for float64 and the Kullback-Leibler loss) and the one-wave 256-channel instance
+    "big": fit_case(f32, 2, 3000, 300, 20, max_iter=140, expect="big1_pass_kernel<float,32,4"),
+    "big_stop": fit_case(f32, 3, 1500, 144, 48, max_iter=200, tol=1e-4, expect="big1_pass_kernel<float,48,2"),
+    "big_f64": fit_case(f64, 2, 1200, 130, 33, max_iter=140, expect="big_pass_w_kernel<double"),
+    "big_kl": fit_case(f32, 2, 1500, 300, 20, loss=1, expect="big_pass_w_kernel<float"),
+    "big_ragged": ragged_case(f32, [500, 900, 700], 300, 20),
+    "wide_xl": fit_case(f32, 3, 2000, 256, 16, expect="fit_wide_kernel<float,256"),
+    # time-shard building blocks and the native sharded loop with a host-side collective callback
+    "shard_narrow": shard_case(f32, 40000, 16, 5),
+    "shard_narrow_f64": shard_case(f64, 20000, 8, 3),
+    "shard_wide": shard_case(f32, 6000, 200, 20, wide=True),
+    "shard_wide_kl": shard_case(f64, 3000, 64, 8, wide=True, loss=1),
+    "fit_tsharded": tsharded_case(f32, 40000, 16, 5),
+    "fit_tsharded_wide": tsharded_case(f32, 5000, 64, 12, wide=True),
+    # on-device NNDSVD building blocks
+    "nndsvd": nndsvd_case(f32, 4, 3000, 24, 5),
+    "nndsvd_f64_wide": nndsvd_case(f64, 2, 1500, 100, 8),
     # the other entry points
     "ragged": ragged_case(f32, [900, 1400, 700, 1100], 12, 4),
     "ragged_wide": ragged_case(f32, [500, 900, 700], 48, 6),
