@@ -557,8 +557,12 @@ int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
     if (std::max(std::max(smem_w, smem_r), std::max(smem_rec, smem_h)) > (size_t)h->lds_per_block)
       return fail(HIPNMF_ERR_UNSUPPORTED, "n_features=%d n_components=%d needs more LDS per workgroup than this device has (%d bytes)", m, k,
                   h->lds_per_block);
+    const Big1Kernel<real>* b1r = pick_big1<real>(h, KPb, MPb, false);  // its residual kernel serves both losses
     auto residual = [&](int it, auto&& emit) {
-      with_kp([&](auto kp) { emit(big_resid_kernel<real, decltype(kp)::value>, gslice, dim3(256), smem_r, ba); });
+      if (b1r)
+        emit(b1r->resid, gslice, dim3(512), (size_t)0, ba);
+      else
+        with_kp([&](auto kp) { emit(big_resid_kernel<real, decltype(kp)::value>, gslice, dim3(256), smem_r, ba); });
       WideSliceArgs<real> f = sa;
       f.it = it;
       emit(big_resid_finalize_kernel<real>, dim3(B), dim3(1024), sizeof(real) * 3 * (size_t)MPb, f);
@@ -783,6 +787,9 @@ int hipnmf_shard_wide(hipnmf_handle* h, const hipnmf_problem* p, int op, const r
       return fail(HIPNMF_ERR_UNSUPPORTED, "n_components=%d needs more LDS per workgroup than this device has", k);
     if (smem_h > 48 * 1024 && (arc = hipnmf_allow_full_lds(h, reinterpret_cast<const void*>(big_hupdate_kernel<real>)))) return arc;
     hipLaunchKernelGGL(big_hupdate_kernel<real>, dim3(B, (m + 63) / 64), dim3(256), smem_h, st, hb);
+  } else if (const Big1Kernel<real>* b1r = pick_big1<real>(h, KPb, MPb, false)) {
+    hipLaunchKernelGGL(b1r->resid, gslice, dim3(512), 0, st, ba);
+    hipLaunchKernelGGL(big_colsum_kernel<real>, dim3(B), dim3(256), 0, st, ba, sse_col, xsq_col);
   } else {
     with_kp([&](auto kp) {
       constexpr int KP = decltype(kp)::value;

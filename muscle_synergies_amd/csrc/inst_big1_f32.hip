@@ -6,7 +6,8 @@ namespace hipnmf {
 namespace {
 template <int KP, int NQ, int RS, bool HL = false, int NST = 2>
 Big1Kernel<float> make_big1(const char* name) {
-  return Big1Kernel<float>{big1_pass_kernel<float, KP, NQ, RS, HL, NST>, Big1Cfg<float, KP, NQ, RS, HL, NST>::smem_bytes(), KP, NQ, RS, name};
+  return Big1Kernel<float>{big1_pass_kernel<float, KP, NQ, RS, HL, NST>, Big1Cfg<float, KP, NQ, RS, HL, NST>::smem_bytes(), KP, NQ, RS, name,
+                           big1_resid_kernel<float, KP, NQ>};
 }
 }  // namespace
 const Big1Kernel<float>* big1_kernel_f32(int KP, int MP) {

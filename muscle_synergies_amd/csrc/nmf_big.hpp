@@ -58,6 +58,7 @@ struct Big1Kernel {
   size_t smem;
   int KP, NQ, RS;
   const char* name;
+  void (*resid)(BigArgs<real>);  // big1_resid_kernel<real, KP, NQ>: the residual on the same decomposition (512 threads, no LDS)
 };
 const Big1Kernel<float>* big1_kernel_f32(int KP, int MP);  // nullptr: no instance covers MP channels
 // values per slice of the column record: sse | xsq (| the Kullback-Leibler divergence per column)

@@ -17,7 +17,7 @@ template <int MP, int KQ, int NW, int NSET>
 const char* wide4_kernel_name() {
   static char buf[96];
   static const bool once = [] {
-    snprintf(buf, sizeof(buf), "fit_wide4_kernel<%d,%d,%d,%d>", MP, KQ, NW, NSET);
+    snprintf(buf, sizeof(buf), "fit_wide4_kernel<%d,%d,%d,%d,0>", MP, KQ, NW, NSET);  // (as rocprofv3 prints it: LOSS = 0)
     return true;
   }();
   (void)once;

@@ -558,6 +558,14 @@ sosfilt_chunk_kernel(SosArgs a, const double* __restrict__ tab, int ns, int regi
   const double* __restrict__ Mp = tab + SCAN_G_CAP;
   const unsigned voff = (unsigned)t * (unsigned)sizeof(real);
 
+#ifdef HIPNMF_SOS_TIMING  // development build (tools/sos_phase_timing.py): shader-clock stamps at the phase boundaries, written
+  long long stamp[9];     // over the head of the output
+  int n_stamp = 0;
+#define SOS_STAMP() stamp[n_stamp++] = (long long)__builtin_readcyclecounter()
+#else
+#define SOS_STAMP() ((void)0)
+#endif
+  SOS_STAMP();  // 0: start
   double c[NSP][5];
   scan_coeffs<NSP>(a, ns, c);
   // this thread's entries of the G table: requested now, written to the overlay once the series buffer is dead
@@ -579,6 +587,10 @@ sosfilt_chunk_kernel(SosArgs a, const double* __restrict__ tab, int ns, int regi
       buf_load<real, 1>(xrs, voff, (unsigned)(k * NT) * (unsigned)sizeof(real), r1);
       raw[k] = r1[0];
     }
+#ifdef HIPNMF_SOS_TIMING
+    __builtin_amdgcn_s_waitcnt(0);
+#endif
+    SOS_STAMP();  // 1: the samples have arrived
     real mean = (real)0;
     if (a.zero_center) {  // fp64 sum in a fixed order (zeros past the end of the series)
       double sum = 0.0;
@@ -615,6 +627,7 @@ sosfilt_chunk_kernel(SosArgs a, const double* __restrict__ tab, int ns, int regi
   }
   const double x0 = (double)xs[0];
   __syncthreads();  // the series buffer is dead from here: the overlay takes it
+  SOS_STAMP();  // 2: mean, staging through LDS, odd extension, chunk in registers
 #pragma unroll
   for (int u = 0; u < GN; ++u) {
     const int i = t + u * NT;
@@ -640,7 +653,9 @@ sosfilt_chunk_kernel(SosArgs a, const double* __restrict__ tab, int ns, int regi
       E[2 * s + 1] = z[s][1];
     }
   }
+  SOS_STAMP();  // 3: forward zero-state response
   scan_states<NST, NT>(E, s_init, false, Mp, xch, s_start);  // (its first barrier also publishes Gl)
+  SOS_STAMP();  // 4: forward scan
 #pragma unroll
   for (int n = 0; n < C; ++n) {
     double acc = v[n];
@@ -649,6 +664,7 @@ sosfilt_chunk_kernel(SosArgs a, const double* __restrict__ tab, int ns, int regi
     v[n] = acc;
   }
 
+  SOS_STAMP();  // 5: forward correction
   if (a.zero_lag) {
     // ---- backward over the forward output: start state zi * y[L-1]; the tail of the last chunk holds that constant ---------
     const int tL = (L - 1) / C, nL = (L - 1) - tL * C;  // (wave-uniform)
@@ -690,6 +706,7 @@ sosfilt_chunk_kernel(SosArgs a, const double* __restrict__ tab, int ns, int regi
     }
   }
 
+  SOS_STAMP();  // 6: backward pass (zero-state response, scan, correction)
   // ---- registers -> LDS (natural order) -> HBM, the T samples of the recording -----------------------------------------------
   __syncthreads();  // the overlay is dead
   {
@@ -699,6 +716,7 @@ sosfilt_chunk_kernel(SosArgs a, const double* __restrict__ tab, int ns, int regi
     for (int n = 0; n < C; ++n) mine[n < nval ? n : L - C * t] = (real)v[n];  // (behind the series: the dump slot)
   }
   __syncthreads();
+  SOS_STAMP();  // 7: output staged in LDS
   constexpr int CB = 8;
   const int kmax = (T + NT - 1) / NT;
   for (int k0 = 0; k0 < kmax; k0 += CB) {
@@ -709,6 +727,16 @@ sosfilt_chunk_kernel(SosArgs a, const double* __restrict__ tab, int ns, int regi
 #pragma unroll
     for (int u = 0; u < CB; ++u) buf_store<real>(yrs, voff, (unsigned)((k0 + u) * NT) * (unsigned)sizeof(real), y[u]);
   }
+#ifdef HIPNMF_SOS_TIMING
+  __builtin_amdgcn_s_waitcnt(0);
+  SOS_STAMP();  // 8: stores acknowledged
+  __syncthreads();
+  if (t == 0) {
+    for (int i = 0; i < 8; ++i) yr[i] = (real)(stamp[i + 1] - stamp[i]);
+    yr[8] = (real)(stamp[0] & 0xffffff);  // (low bits of the start time: order of the workgroups)
+  }
+#endif
+#undef SOS_STAMP
 }
 
 // =================================================================================================================================

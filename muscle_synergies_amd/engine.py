@@ -116,7 +116,8 @@ def make_problem(B, T, m, k, *, x_layout, ldx, x_batch_stride, w_layout=_lib.W_R
 def fit_batched(X, W0, H0, *, max_iter: int = 200, tol: float = 1e-4, check_every: int = 10,
                 update_H: bool = True, l1_reg_W: float = 0.0, l1_reg_H: float = 0.0, l2_reg_W: float = 0.0,
                 l2_reg_H: float = 0.0, beta_loss="frobenius", device=None, handle: Optional[_lib.Handle] = None,
-                return_numpy: Optional[bool] = None, overwrite_init: bool = False, devices=None) -> BatchedResult:
+                return_numpy: Optional[bool] = None, overwrite_init: bool = False, devices=None,
+                host_chunk: Optional[int] = None) -> BatchedResult:
     """Factorise a batch of matrices on one GPU -- or, with ``devices=``, scattered by matrix over several
     (:mod:`muscle_synergies_amd.multi_gpu`: contiguous slices, one host thread and handle per device, no collective;
     results on the host in batch order: NumPy when NumPy went in, CPU tensors otherwise).
@@ -132,6 +133,9 @@ def fit_batched(X, W0, H0, *, max_iter: int = 200, tol: float = 1e-4, check_ever
         beta_loss: ``'frobenius'`` (the reference's default) or ``'kullback-leibler'``
            (``reconstruction_err`` is then ``sqrt(2 KL(X || WH))``; ``vaf`` stays the squared-error VAF).
         overwrite_init: let the solver update contiguous device tensors ``W0``/``H0`` in place (no copy).
+        host_chunk: host-resident (NumPy) batches are fitted in chunks of this many matrices with the transfers of the
+            neighbouring chunks overlapped (:func:`_fit_batched_pipelined`); ``None`` = automatic (batches of more than
+            :data:`PIPELINE_MIN_BYTES`), ``0`` = one upload, one fit, one download.
     """
     torch = _torch()
     if devices is not None:
@@ -142,6 +146,12 @@ def fit_batched(X, W0, H0, *, max_iter: int = 200, tol: float = 1e-4, check_ever
     was_numpy = not isinstance(X, torch.Tensor)
     if return_numpy is None:
         return_numpy = was_numpy
+    if was_numpy and return_numpy and host_chunk != 0 and isinstance(W0, np.ndarray) and isinstance(H0, np.ndarray) and np.ndim(X) == 3:
+        chunk = _pipeline_chunk(np.asarray(X), host_chunk)
+        if chunk:
+            kw = dict(max_iter=max_iter, tol=tol, check_every=check_every, update_H=update_H, l1_reg_W=l1_reg_W, l1_reg_H=l1_reg_H,
+                      l2_reg_W=l2_reg_W, l2_reg_H=l2_reg_H, beta_loss=beta_loss)
+            return _fit_batched_pipelined(np.asarray(X), W0, H0, dev, chunk, kw, handle)
     Xt = _as_device_tensor(X, dev)
     if Xt.dim() == 2:
         Xt = Xt.unsqueeze(0)
@@ -191,6 +201,86 @@ def fit_batched(X, W0, H0, *, max_iter: int = 200, tol: float = 1e-4, check_ever
     return res
 
 
+# ------------------------------------------------------------------------------------------------
+# Host-resident batches.  The reference's input lives in host memory (a DataFrame: analysis.py:739-746); uploading a whole
+# batch before the first kernel and downloading W after the last one adds the transfer time to the fit (4096 x (16 x 10 000)
+# fp32: 2.6 GB up, 0.8 GB down against ~0.2 s of compute).  Chunks of the batch go through a three-stage pipeline instead:
+# worker threads upload chunk i + 1 (and i + 2) and download chunk i - 1 on their own streams while the calling thread fits
+# chunk i -- the library call blocks its host thread and releases the GIL, the copies block theirs.  The per-matrix results do
+# not depend on the chunking (one workgroup per matrix; tests/test_gpu_pipeline.py compares bitwise).
+PIPELINE_MIN_BYTES = 256 << 20   # X smaller than this: one upload, one fit
+PIPELINE_CHUNK_BYTES = 192 << 20  # automatic chunk: about this much of X, a multiple of 256 matrices (whole rounds of workgroups)
+
+
+def _pipeline_chunk(X, host_chunk) -> int:
+    """Matrices per chunk, or 0 for no pipeline."""
+    B = X.shape[0]
+    if host_chunk is not None:
+        c = int(host_chunk)
+        return c if 0 < c < B else 0
+    if X.nbytes < PIPELINE_MIN_BYTES or X.dtype not in (np.float32, np.float64):
+        return 0
+    per = max(1, X.nbytes // B)
+    c = max(1, PIPELINE_CHUNK_BYTES // per)
+    if c >= 256:
+        c = c // 256 * 256
+    return c if c < B else 0
+
+
+def _fit_batched_pipelined(X, W0, H0, dev, chunk: int, kw, handle=None) -> BatchedResult:
+    from concurrent.futures import ThreadPoolExecutor
+
+    torch = _torch()
+    W0, H0 = np.asarray(W0), np.asarray(H0)
+    B, T, m = X.shape
+    if X.dtype not in (np.float32, np.float64):
+        raise TypeError(f"X must be float32 or float64, got {X.dtype}")
+    if W0.ndim != 3 or H0.ndim != 3 or W0.shape[:2] != (B, T) or H0.shape[0] != B or H0.shape[2] != m or W0.shape[2] != H0.shape[1]:
+        raise ValueError(f"W0 must be [{B}, {T}, k] and H0 [{B}, k, {m}]; got {W0.shape} and {H0.shape}")
+    k = H0.shape[1]
+    dt = X.dtype
+    W0, H0 = W0.astype(dt, copy=False), H0.astype(dt, copy=False)
+    bounds = [(lo, min(lo + chunk, B)) for lo in range(0, B, chunk)]
+    out = BatchedResult(np.empty((B, T, k), dt), np.empty((B, k, m), dt), np.empty((B,), np.int32), np.empty((B,), dt),
+                        np.empty((B, 1 + m), dt), np.empty((B, m), dt), np.empty((B, m), dt), 0.0)
+    h = handle if handle is not None else _lib.get_handle(dev.index)
+
+    def upload(i):
+        lo, hi = bounds[i]
+        torch.cuda.set_device(dev)
+        st = torch.cuda.Stream(dev)
+        with torch.cuda.stream(st):
+            parts = tuple(_as_device_tensor(a[lo:hi], dev) for a in (X, W0, H0))
+        st.synchronize()
+        return parts
+
+    def download(i, r):
+        lo, hi = bounds[i]
+        torch.cuda.set_device(dev)
+        st = torch.cuda.Stream(dev)
+        with torch.cuda.stream(st):
+            for name in ("W", "H", "n_iter", "reconstruction_err", "vaf", "sse_col", "xsq_col"):
+                torch.from_numpy(getattr(out, name)[lo:hi]).copy_(getattr(r, name))  # straight into the result array
+        st.synchronize()
+
+    ms_total = 0.0
+    with ThreadPoolExecutor(max_workers=3, thread_name_prefix="hipnmf-xfer") as pool:
+        ups = {i: pool.submit(upload, i) for i in range(min(2, len(bounds)))}
+        downs = []
+        for i in range(len(bounds)):
+            Xd, Wd, Hd = ups.pop(i).result()
+            if i + 2 < len(bounds):
+                ups[i + 2] = pool.submit(upload, i + 2)
+            r = fit_batched(Xd, Wd, Hd, device=dev, handle=h, return_numpy=False, overwrite_init=True, **kw)
+            ms_total += r.kernel_ms
+            downs.append(pool.submit(download, i, r))
+            del Xd, Wd, Hd, r
+        for f in downs:
+            f.result()
+    out.kernel_ms = ms_total
+    return out
+
+
 def _gather_batched(parts, as_numpy: bool, ragged: bool = False) -> BatchedResult:
     """``parts``: the per-device :class:`BatchedResult` objects in batch order -> one result on the host."""
     from .multi_gpu import cat_host, to_host
@@ -224,8 +314,10 @@ def _fit_batched_scattered(X, W0, H0, devices, return_numpy, kw) -> BatchedResul
     if len(W0) != B or len(H0) != B:
         raise ValueError("W0 and H0 must hold one starting point per matrix of X")
 
+    host_in = isinstance(X, np.ndarray)  # host-resident slices go through the chunked transfer pipeline of their device
+
     def work(lo, hi, d):
-        return fit_batched(X[lo:hi], W0[lo:hi], H0[lo:hi], device=f"cuda:{d}", return_numpy=False, **kw)
+        return fit_batched(X[lo:hi], W0[lo:hi], H0[lo:hi], device=f"cuda:{d}", return_numpy=host_in, **kw)
 
     parts = [r for _, _, _, r in scatter(B, devs, work)]
     return _gather_batched(parts, as_numpy)

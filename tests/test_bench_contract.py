@@ -55,7 +55,7 @@ def test_committed_traffic_measurements_name_their_kernel_and_source():
     for e in entries:
         for key in ("kernel", "batch", "iters", "T", "m", "k", "x_layout", "l2_fabric_bytes_per_launch", "source_commit", "method"):
             assert key in e, key
-        assert e["kernel"].startswith(("fit_persistent_kernel<", "fit_rowlane_kernel<", "fit_wide_kernel<", "fit_wide4_kernel<"))
+        assert e["kernel"].startswith(("fit_persistent_kernel<", "fit_rowlane_kernel<", "fit_wide_kernel<", "fit_wide4_kernel<", "big1_pass_kernel<"))
     assert bench._traffic("no-such-kernel", batch=1) is None
 
 
