@@ -12,6 +12,7 @@ C ABI of ``libhip_nmf.so``.  No computation of the solver happens in torch or Nu
 from __future__ import annotations
 
 import ctypes
+import threading
 from dataclasses import dataclass
 from typing import Optional
 
@@ -117,7 +118,7 @@ def fit_batched(X, W0, H0, *, max_iter: int = 200, tol: float = 1e-4, check_ever
                 update_H: bool = True, l1_reg_W: float = 0.0, l1_reg_H: float = 0.0, l2_reg_W: float = 0.0,
                 l2_reg_H: float = 0.0, beta_loss="frobenius", device=None, handle: Optional[_lib.Handle] = None,
                 return_numpy: Optional[bool] = None, overwrite_init: bool = False, devices=None,
-                host_chunk: Optional[int] = None) -> BatchedResult:
+                host_chunk: Optional[int] = None, _inputs_ready: bool = False) -> BatchedResult:
     """Factorise a batch of matrices on one GPU -- or, with ``devices=``, scattered by matrix over several
     (:mod:`muscle_synergies_amd.multi_gpu`: contiguous slices, one host thread and handle per device, no collective;
     results on the host in batch order: NumPy when NumPy went in, CPU tensors otherwise).
@@ -191,7 +192,8 @@ def fit_batched(X, W0, H0, *, max_iter: int = 200, tol: float = 1e-4, check_ever
     h = handle if handle is not None else _lib.get_handle(dev.index)
     lib = _lib.load()
     fn = lib.hipnmf_fit_batched_f32 if Xt.dtype == torch.float32 else lib.hipnmf_fit_batched_f64
-    torch.cuda.synchronize(dev)  # inputs were produced on torch's stream; the handle has its own
+    if not _inputs_ready:  # inputs were produced on torch's stream; the handle has its own.  (The transfer pipeline hands over
+        torch.cuda.synchronize(dev)  # tensors whose copies have completed: a device-wide wait here would serialise its stages.)
     _lib.check(fn(h.ptr, ctypes.byref(p), Xt.data_ptr(), Wt.data_ptr(), Ht.data_ptr(), err.data_ptr(),
                   n_iter.data_ptr(), sse.data_ptr(), xsq.data_ptr()))
     vaf = torch.cat([(1 - sse.sum(dim=1) / xsq.sum(dim=1)).unsqueeze(1), 1 - sse / xsq], dim=1)
@@ -208,6 +210,7 @@ def fit_batched(X, W0, H0, *, max_iter: int = 200, tol: float = 1e-4, check_ever
 # worker threads upload chunk i + 1 (and i + 2) and download chunk i - 1 on their own streams while the calling thread fits
 # chunk i -- the library call blocks its host thread and releases the GIL, the copies block theirs.  The per-matrix results do
 # not depend on the chunking (one workgroup per matrix; tests/test_gpu_pipeline.py compares bitwise).
+_pipeline_trace = None  # development aid (tools/probes/host_pipeline_trace.py): a list to receive (stage, chunk, t_start, t_end)
 PIPELINE_MIN_BYTES = 256 << 20   # X smaller than this: one upload, one fit
 PIPELINE_CHUNK_BYTES = 192 << 20  # automatic chunk: about this much of X, a multiple of 256 matrices (whole rounds of workgroups)
 
@@ -229,8 +232,10 @@ def _pipeline_chunk(X, host_chunk) -> int:
 
 def _fit_batched_pipelined(X, W0, H0, dev, chunk: int, kw, handle=None) -> BatchedResult:
     from concurrent.futures import ThreadPoolExecutor
+    import time as _time
 
     torch = _torch()
+    t_enter = _time.perf_counter()
     W0, H0 = np.asarray(W0), np.asarray(H0)
     B, T, m = X.shape
     if X.dtype not in (np.float32, np.float64):
@@ -239,44 +244,119 @@ def _fit_batched_pipelined(X, W0, H0, dev, chunk: int, kw, handle=None) -> Batch
         raise ValueError(f"W0 must be [{B}, {T}, k] and H0 [{B}, k, {m}]; got {W0.shape} and {H0.shape}")
     k = H0.shape[1]
     dt = X.dtype
+    tdt = torch.float32 if dt == np.float32 else torch.float64
     W0, H0 = W0.astype(dt, copy=False), H0.astype(dt, copy=False)
     bounds = [(lo, min(lo + chunk, B)) for lo in range(0, B, chunk)]
-    out = BatchedResult(np.empty((B, T, k), dt), np.empty((B, k, m), dt), np.empty((B,), np.int32), np.empty((B,), dt),
-                        np.empty((B, 1 + m), dt), np.empty((B, m), dt), np.empty((B, m), dt), 0.0)
+    w_raw = np.empty(B * T * k * dt.itemsize + 4096, np.uint8)  # W page-aligned: its chunks can be pinned one by one
+    w_off = (-w_raw.ctypes.data) % 4096
+    out = BatchedResult(w_raw[w_off: w_off + B * T * k * dt.itemsize].view(dt).reshape(B, T, k), np.empty((B, k, m), dt),
+                        np.empty((B,), np.int32), np.empty((B,), dt), np.empty((B, 1 + m), dt), np.empty((B, m), dt),
+                        np.empty((B, m), dt), 0.0)
     h = handle if handle is not None else _lib.get_handle(dev.index)
 
-    def upload(i):
-        lo, hi = bounds[i]
-        torch.cuda.set_device(dev)
-        st = torch.cuda.Stream(dev)
-        with torch.cuda.stream(st):
-            parts = tuple(_as_device_tensor(a[lo:hi], dev) for a in (X, W0, H0))
-        st.synchronize()
-        return parts
+    def traced(stage):
+        def deco(fn):
+            def run(i, *a):
+                t0 = _time.perf_counter()
+                try:
+                    return fn(i, *a)
+                finally:
+                    if _pipeline_trace is not None:
+                        _pipeline_trace.append((stage, i, t0, _time.perf_counter()))
+            return run
+        return deco
 
-    def download(i, r):
+    # Device side: three slots of chunk buffers allocated once (the transfer threads copy on their own streams, and torch's
+    # caching allocator keeps a pool per stream: tensors allocated inside the upload threads meant a hipMalloc per chunk --
+    # uploads of 7 ms instead of 4, and 20 - 35 ms for the first ones).  X keeps the strides of the caller's array (row- or
+    # channel-major per matrix), W and H are updated in place and downloaded from the slot.
+    NSLOT = min(3, len(bounds))
+    es = X.itemsize
+    channel_major = X.strides == (T * m * es, es, T * es)  # every matrix stored m x T (a DataFrame's F order), seen as T x m
+    slots = []
+    for _ in range(NSLOT):
+        xs = torch.empty((chunk, m, T), dtype=tdt, device=dev).transpose(1, 2) if channel_major else torch.empty((chunk, T, m), dtype=tdt, device=dev)
+        slots.append((xs, torch.empty((chunk, T, k), dtype=tdt, device=dev), torch.empty((chunk, k, m), dtype=tdt, device=dev)))
+    # (no device-wide synchronisation anywhere in this function: with the 32 pooled side streams of a previous call around,
+    #  hipDeviceSynchronize alone took 27 - 39 ms; every hand-over below is an event or a stream synchronisation)
+    if _pipeline_trace is not None:
+        _pipeline_trace.append(("alloc", 0, t_enter, _time.perf_counter()))
+
+    @traced("upload")
+    def upload(i, after):
+        if after is not None:
+            after.result()  # the slot's previous chunk has left it
+        lo, hi = bounds[i]
+        n = hi - lo
+        torch.cuda.set_device(dev)
+        xs, ws, hs = slots[i % NSLOT]
+        st = torch.cuda.Stream(dev)
+        with torch.cuda.stream(st):
+            xs[:n].copy_(torch.from_numpy(X[lo:hi]))
+            ws[:n].copy_(torch.from_numpy(W0[lo:hi]))
+            hs[:n].copy_(torch.from_numpy(H0[lo:hi]))
+        st.synchronize()
+        return xs[:n], ws[:n], hs[:n]
+
+    # Results.  W (T x k per matrix: 0.8 GB at the headline batch) goes home chunk by chunk, each chunk's destination pinned in
+    # place just before its copy (hipHostRegister, ~2 ms per 51 MB; the result array is page-aligned and the chunks are whole
+    # pages) so that the copy is an asynchronous copy-engine transfer.  A copy straight into pageable, never-touched memory runs
+    # at the page-fault rate and, as a shader copy, waits for the fit kernel that holds every CU (measured 3.5 - 7 GB/s: the
+    # downloads fell 60 ms behind the fits).  Also measured and not kept: pinning the whole array in one call (34 - 42 ms; it
+    # stalls the uploads, which pin their own pages at the same time: one 24 ms hole in the fits), pinned staging slots + a host
+    # copy (erratic: stalls of 40 - 90 ms), two fitting lanes (two kernels in flight push the matrices being streamed out of the
+    # Infinity Cache: 0.82 vs 0.86 of the device-resident rate).  The small outputs stay on the device until the last fit has
+    # ended: one copy each.
+    rt = torch.cuda.cudart()
+    SMALL = ("H", "n_iter", "reconstruction_err", "vaf", "sse_col", "xsq_col")
+    small_parts = [None] * len(bounds)
+    page_ok = out.W.ctypes.data % 4096 == 0 and (chunk * T * k * out.W.itemsize) % 4096 == 0
+
+    @traced("download")
+    def download(i, Wd, ready):
         lo, hi = bounds[i]
         torch.cuda.set_device(dev)
         st = torch.cuda.Stream(dev)
-        with torch.cuda.stream(st):
-            for name in ("W", "H", "n_iter", "reconstruction_err", "vaf", "sse_col", "xsq_col"):
-                torch.from_numpy(getattr(out, name)[lo:hi]).copy_(getattr(r, name))  # straight into the result array
-        st.synchronize()
+        st.wait_event(ready)
+        dst = out.W[lo:hi]
+        pinned = False
+        if page_ok:
+            try:
+                pinned = int(rt.cudaHostRegister(dst.ctypes.data, dst.nbytes, 0)) == 0
+            except Exception:  # noqa: BLE001 -- the pageable copy below works, only slower
+                pinned = False
+        try:
+            with torch.cuda.stream(st):
+                torch.from_numpy(dst).copy_(Wd, non_blocking=pinned)
+            st.synchronize()
+        finally:
+            if pinned:
+                rt.cudaHostUnregister(dst.ctypes.data)
 
     ms_total = 0.0
-    with ThreadPoolExecutor(max_workers=3, thread_name_prefix="hipnmf-xfer") as pool:
-        ups = {i: pool.submit(upload, i) for i in range(min(2, len(bounds)))}
-        downs = []
+    with ThreadPoolExecutor(max_workers=4, thread_name_prefix="hipnmf-xfer") as pool:
+        downs = {}
+        ups = {0: pool.submit(upload, 0, None)}
+        if len(bounds) > 1:  # one after the other: side by side the first two share the link and chunk 0 arrives twice as late
+            ups[1] = pool.submit(upload, 1, ups[0])
         for i in range(len(bounds)):
             Xd, Wd, Hd = ups.pop(i).result()
-            if i + 2 < len(bounds):
-                ups[i + 2] = pool.submit(upload, i + 2)
-            r = fit_batched(Xd, Wd, Hd, device=dev, handle=h, return_numpy=False, overwrite_init=True, **kw)
+            if i + 2 < len(bounds):  # (its slot was chunk i - 1's: free once that chunk's W is home)
+                ups[i + 2] = pool.submit(upload, i + 2, downs.get(i + 2 - NSLOT))
+            r = fit_batched(Xd, Wd, Hd, device=dev, handle=h, return_numpy=False, overwrite_init=True, _inputs_ready=True, **kw)
             ms_total += r.kernel_ms
-            downs.append(pool.submit(download, i, r))
+            ready = torch.cuda.Event()
+            ready.record()
+            small_parts[i] = {name: getattr(r, name).clone() if name == "H" else getattr(r, name) for name in SMALL}
+            downs[i] = pool.submit(download, i, r.W, ready)
             del Xd, Wd, Hd, r
-        for f in downs:
+        for f in downs.values():
             f.result()
+    t_sm = _time.perf_counter()
+    for name in SMALL:  # the device is idle now: one copy per small output
+        getattr(out, name)[...] = torch.cat([p[name] for p in small_parts]).cpu().numpy()
+    if _pipeline_trace is not None:
+        _pipeline_trace.append(("small", 0, t_sm, _time.perf_counter()))
     out.kernel_ms = ms_total
     return out
 
