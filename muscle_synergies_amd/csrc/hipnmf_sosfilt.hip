@@ -43,16 +43,7 @@ void steady_state_zi(const double* sos, int ns, double (*zi)[2]) {
   }
 }
 
-template <typename real, int NS>
-hipError_t launch_ns(const SosArgs& a, const double* stat, hipStream_t st) {
-  constexpr int S = SOS_SERIES;
-  // at most four of these one-wave workgroups per CU (160 KiB of LDS / 40 KiB)
-  constexpr size_t smem = sos_smem_bytes<S>() > 40960 ? sos_smem_bytes<S>() : 40960;
-  hipLaunchKernelGGL((sosfilt_kernel<real, NS, S>), dim3((a.N + S - 1) / S), dim3(64), smem, st, a, stat);
-  return hipSuccess;
-}
-
-// round 2 kernel: LPS lanes per series (sections rounded up to a power of two), a second wave moves the data
+// the sequential (bit-exact) kernel: LPS lanes per series (sections rounded up to a power of two), a second wave moves the data
 template <typename real, int LPS>
 hipError_t launch_v2(hipnmf_handle* h, const SosArgs& a, const double* stat, int ns, hipStream_t st) {
   constexpr int S = sos2_series<LPS>();
@@ -60,17 +51,6 @@ hipError_t launch_v2(hipnmf_handle* h, const SosArgs& a, const double* stat, int
   const void* kern = reinterpret_cast<const void*>(&sosfilt2_kernel<real, LPS>);
   if (smem > 48 * 1024 && hipnmf_allow_full_lds(h, kern)) return hipErrorInvalidValue;
   hipLaunchKernelGGL((sosfilt2_kernel<real, LPS>), dim3((a.N + S - 1) / S), dim3(128), smem, st, a, stat, ns);
-  return hipSuccess;
-}
-
-// round 3 kernel (zero-lag only): section states checkpointed per tile, forward output recomputed in the backward pass
-template <typename real, int LPS>
-hipError_t launch_v3(hipnmf_handle* h, const SosArgs& a, const double* stat, int ns, hipStream_t st) {
-  constexpr int S = sos2_series<LPS>();
-  constexpr size_t smem = sos3_smem_bytes<LPS>();
-  const void* kern = reinterpret_cast<const void*>(&sosfilt3_kernel<real, LPS>);
-  if (smem > 48 * 1024 && hipnmf_allow_full_lds(h, kern)) return hipErrorInvalidValue;
-  hipLaunchKernelGGL((sosfilt3_kernel<real, LPS>), dim3((a.N + S - 1) / S), dim3(192), smem, st, a, stat, ns);
   return hipSuccess;
 }
 
@@ -227,19 +207,12 @@ int sosfilt_impl(hipnmf_handle* h, const hipnmf_sosfilt_params* p, const double*
   const size_t o_x = inplace ? 0 : carve(sizeof(real) * (size_t)N * T);
   // forward output of the zero-lag filter: SOS_SERIES rows per wave, so the last wave needs no row guards
   // forward output of the zero-lag filter: whole 64-sample tiles, 64 rows per workgroup-group (both kernels fit)
-  // HIPNMF_SOS_V3=1: sosfilt3_kernel (section states checkpointed, forward output recomputed in the backward pass: half the
-  // traffic).  Not the default: measured 2.40 vs 2.08 ms at 1024 x 16 x 20 000 fp32 order 4 -- the filter is bound by the
-  // dependent fp64 chain of the recursion (25 ns per step, two passes of 41 200 steps), not by the bytes it moves, and a
-  // second recursion wave per workgroup slows the first.
-  static const bool sos_v3 = [] {
-    const char* e = getenv("HIPNMF_SOS_V3");
-    return e && atoi(e) != 0;
-  }();
-  const bool use_v3 = zero_lag && sos_v3;
-  // v2: forward output over the extended signal (whole 64-sample tiles, 64 rows per workgroup group);
-  // v3: section states per workgroup and tile only: [workgroups <= N / 8 + 1][tiles + 1][64 lanes][2]
+  // (sosfilt3_kernel -- section states checkpointed per tile, forward output recomputed in the backward pass: half the traffic --
+  //  was measured slower, 2.40 vs 2.08 ms at 1024 x 16 x 20 000 fp32 order 4, because the filter is bound by the dependent fp64
+  //  chain of the recursion, not by bytes; it and the round-1 sosfilt_kernel were removed in round 5: HISTORY.md)
+  // workspace of the zero-lag sequential kernel: the forward output over the extended signal (whole 64-sample tiles, 64 rows per
+  // workgroup group)
   const size_t ws_v2 = sizeof(double) * (size_t)round_up(N, 64) * (size_t)round_up(L, 64);
-  const size_t ws_v3 = sizeof(double) * (size_t)(N / 8 + 1) * (size_t)(round_up(L, 64) / 64 + 1) * 128;
   // time-parallel mode: the whole extended series in the registers of one workgroup (256 chunks of at most SCAN_CMAX samples, whole
   // groups of four), all staging traffic in 16-byte vectors: series and outputs 16-byte aligned, n_samples a multiple of the vector
   constexpr int VS = 16 / (int)sizeof(real);
@@ -318,7 +291,7 @@ int sosfilt_impl(hipnmf_handle* h, const hipnmf_sosfilt_params* p, const double*
   const size_t o_fwd = (use_block_scan && zero_lag) ? carve(sizeof(real) * (size_t)N * (size_t)L) : 0;
   const size_t o_bend = use_block_scan ? carve(sizeof(double) * (size_t)N * (size_t)blk_nb * 2 * nsp_c) : 0;
   const size_t o_bstart = use_block_scan ? carve(sizeof(double) * (size_t)N * (size_t)blk_nb * 2 * nsp_c) : 0;
-  const size_t o_ws = (zero_lag && !scan_fits && !use_chunk_scan && !use_block_scan) ? carve(use_v3 ? ws_v3 : ws_v2) : 0;
+  const size_t o_ws = (zero_lag && !scan_fits && !use_chunk_scan && !use_block_scan) ? carve(ws_v2) : 0;
   const size_t o_stat = carve(sizeof(double) * (size_t)N * 3);
   // time-parallel mode: the whole extended series in the registers of one workgroup (256 chunks of at most SCAN_CMAX samples);
   // longer series take the sequential kernel
@@ -428,23 +401,9 @@ int sosfilt_impl(hipnmf_handle* h, const hipnmf_sosfilt_params* p, const double*
     }
     return HIPNMF_OK;
   }
-  snprintf(h->last_kernel, sizeof(h->last_kernel), "sosfilt (sequential)");
+  snprintf(h->last_kernel, sizeof(h->last_kernel), "sosfilt2_kernel<%s>", sizeof(real) == 4 ? "float" : "double");
   hipLaunchKernelGGL(sos_stats_kernel<real>, dim3((unsigned)N), dim3(256), 0, st, a, stat);
-  static const bool sos_v1 = [] {
-    const char* e = getenv("HIPNMF_SOS_V1");
-    return e && atoi(e) != 0;
-  }();
-  if (use_v3 && !sos_v1) {
-    const int ns = p->n_sections;
-    if (ns == 1)
-      HIP_TRY((launch_v3<real, 1>(h, a, stat, ns, st)));
-    else if (ns == 2)
-      HIP_TRY((launch_v3<real, 2>(h, a, stat, ns, st)));
-    else if (ns <= 4)
-      HIP_TRY((launch_v3<real, 4>(h, a, stat, ns, st)));
-    else
-      HIP_TRY((launch_v3<real, 8>(h, a, stat, ns, st)));
-  } else if (!sos_v1) {
+  {
     const int ns = p->n_sections;
     if (ns == 1)
       HIP_TRY((launch_v2<real, 1>(h, a, stat, ns, st)));
@@ -454,16 +413,6 @@ int sosfilt_impl(hipnmf_handle* h, const hipnmf_sosfilt_params* p, const double*
       HIP_TRY((launch_v2<real, 4>(h, a, stat, ns, st)));
     else
       HIP_TRY((launch_v2<real, 8>(h, a, stat, ns, st)));
-  } else
-  switch (p->n_sections) {
-    case 1: HIP_TRY((launch_ns<real, 1>(a, stat, st))); break;
-    case 2: HIP_TRY((launch_ns<real, 2>(a, stat, st))); break;
-    case 3: HIP_TRY((launch_ns<real, 3>(a, stat, st))); break;
-    case 4: HIP_TRY((launch_ns<real, 4>(a, stat, st))); break;
-    case 5: HIP_TRY((launch_ns<real, 5>(a, stat, st))); break;
-    case 6: HIP_TRY((launch_ns<real, 6>(a, stat, st))); break;
-    case 7: HIP_TRY((launch_ns<real, 7>(a, stat, st))); break;
-    default: HIP_TRY((launch_ns<real, 8>(a, stat, st))); break;
   }
   HIP_TRY(hipGetLastError());
   if (!async) {

@@ -132,215 +132,6 @@ __global__ void __launch_bounds__(256) sos_stats_kernel(SosArgs a, double* __res
   }
 }
 
-// filter `nval` consecutive samples of this lane's series in place in LDS, eight at a time; the next eight
-// are read before the current eight are filtered (LDS latency hidden behind the dependent recursion);
-// DIR = +1 forward in time, -1 backward
-template <int NS, int DIR>
-__device__ __forceinline__ double sos_run_tile(double* __restrict__ row, int nval, double (&z)[NS][2],
-                                               const double (&c)[NS][5], double ylast) {
-  if (nval == SOS_TT) {
-    double cur[8], nxt[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) cur[e] = row[DIR > 0 ? e : SOS_TT - 1 - e];
-#pragma unroll
-    for (int q = 0; q < SOS_TT; q += 8) {
-      if (q + 8 < SOS_TT) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) nxt[e] = row[DIR > 0 ? q + 8 + e : SOS_TT - 1 - q - 8 - e];
-      }
-#pragma unroll
-      for (int e = 0; e < 8; ++e) cur[e] = sos_step<NS>(cur[e], z, c);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) row[DIR > 0 ? q + e : SOS_TT - 1 - q - e] = cur[e];
-      ylast = cur[7];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) cur[e] = nxt[e];
-    }
-  } else {
-    for (int n = 0; n < nval; ++n) {
-      const int idx = DIR > 0 ? n : nval - 1 - n;
-      ylast = sos_step<NS>(row[idx], z, c);
-      row[idx] = ylast;
-    }
-  }
-  return ylast;
-}
-
-constexpr int SOS_SERIES = 32;  // series per wave (S)
-template <int S>
-constexpr size_t sos_smem_bytes() {
-  return sizeof(double) * 2 * S * SOS_LD;
-}
-
-// Per tile k (both passes): wait for the rows of tile k -> LDS buffer k%2; issue the row stores of tile k-1
-// (other buffer) and then the row loads of tile k+1; run the recursion on tile k.  Every global access thus
-// has a whole tile's recursion to complete before the wave waits on it, and the wait (vmcnt(0)) never covers
-// an operation that was issued just before it.
-template <typename real, int NS, int S>
-__global__ void __launch_bounds__(64) sosfilt_kernel(SosArgs a, const double* __restrict__ stat_g) {
-  constexpr int TILE = S * SOS_LD;  // doubles per LDS tile
-  extern __shared__ __attribute__((aligned(16))) double sos_smem[];
-  double* tile = sos_smem;  // [2][TILE]
-  const int lane = threadIdx.x;
-  const int s0 = blockIdx.x * S;
-  const int T = a.T, edge = a.edge, L = T + 2 * edge, N = a.N;
-  const int nrows = (N - s0 < S) ? N - s0 : S;  // series handled by this wave
-  const real* __restrict__ xbase = static_cast<const real*>(a.x);
-  // series s0 + r starts at xbase + off_r; the offsets advance by ld inside a recording and jump at its end
-  const long long off0 = (long long)(s0 / a.m) * a.bstride + (long long)(s0 % a.m) * a.ld;
-  const int ch0 = s0 % a.m;
-  const long long jump = a.bstride - (long long)a.m * a.ld;
-  // lane r < S keeps the statistics of series s0 + r: mean, first and last pre-processed sample
-  const int sl = lane < nrows ? lane : nrows - 1;
-  const real mean_l = (real)stat_g[3LL * (s0 + sl) + 0];
-  const real first_l = (real)stat_g[3LL * (s0 + sl) + 1];
-  const real last_l = (real)stat_g[3LL * (s0 + sl) + 2];
-  const bool active = lane < S;  // lanes that own a series in the recursion
-
-  double c[NS][5];
-#pragma unroll
-  for (int s = 0; s < NS; ++s) {
-    c[s][0] = a.sos[s][0];
-    c[s][1] = a.sos[s][1];
-    c[s][2] = a.sos[s][2];
-    c[s][3] = a.sos[s][4];
-    c[s][4] = a.sos[s][5];
-  }
-  const int ntiles = (L + SOS_TT - 1) / SOS_TT;
-  double* __restrict__ myrow = tile + (active ? lane : 0) * SOS_LD;
-
-  // ---- forward pass over the (odd-)extended signal ------------------------------------------------------------
-  real pf[S];
-  auto issue_fwd = [&](int k) {  // rows of tile k -> registers (raw samples; reflection applied on the index)
-    const int i = k * SOS_TT + lane;
-    int j = i - edge;
-    if (j < 0) j = -j;
-    if (j >= T) j = 2 * (T - 1) - j;
-    j = j < 0 ? 0 : j;  // lanes past the end of the extended signal: any valid address, value unused
-    // branch-free on purpose: a load inside a conditional makes hipcc wait for it at the join, which would
-    // serialise the row loads; rows past the last series re-read the last valid row instead
-    long long off = off0;
-    int ch = ch0;
-#pragma unroll
-    for (int r = 0; r < S; ++r) {
-      pf[r] = xbase[off + j];
-      const bool more = r + 1 < nrows;
-      long long step = a.ld;
-      if (ch + 1 == a.m) step += jump;
-      ch = more ? (ch + 1 == a.m ? 0 : ch + 1) : ch;
-      off += more ? step : 0;
-    }
-  };
-  auto commit_fwd = [&](int k, double* __restrict__ buf) {  // registers -> LDS: centre, rectify, odd extension
-    const int i = k * SOS_TT + lane;
-    const int j = i - edge;
-    const bool left = j < 0, ext = left || j >= T;
-    if (k * SOS_TT >= edge && k * SOS_TT + SOS_TT <= edge + T) {  // interior tile (wave-uniform): no extension
-#pragma unroll
-      for (int r = 0; r < S; ++r)
-        buf[r * SOS_LD + lane] = (double)sos_pre<real>(pf[r], lane_bcast(mean_l, r), a.rectify);
-    } else {
-#pragma unroll
-      for (int r = 0; r < S; ++r) {
-        const real v = sos_pre<real>(pf[r], lane_bcast(mean_l, r), a.rectify);
-        const real e0 = lane_bcast(first_l, r), e1 = lane_bcast(last_l, r);
-        const real end = left ? e0 : e1;
-        const real refl = (real)2 * end - v;  // odd extension about the end sample
-        buf[r * SOS_LD + lane] = (double)(ext ? refl : v);
-      }
-    }
-  };
-  auto store_y = [&](const double* __restrict__ buf, int j) {  // LDS rows -> y[series][j] where j is in range
-    if (j < 0 || j >= T) return;
-    real* __restrict__ yp = static_cast<real*>(a.y) + (long long)s0 * T + j;
-    if (nrows == S) {
-      double v[S];
-#pragma unroll
-      for (int r = 0; r < S; ++r) v[r] = buf[r * SOS_LD + lane];
-#pragma unroll
-      for (int r = 0; r < S; ++r) yp[(long long)r * T] = (real)v[r];
-    } else {
-      for (int r = 0; r < nrows; ++r) yp[(long long)r * T] = (real)buf[r * SOS_LD + lane];
-    }
-  };
-  auto store_fwd = [&](int k, const double* __restrict__ buf) {  // filtered tile k of the forward pass
-    const int i = k * SOS_TT + lane;
-    if (a.zero_lag) {
-      if (i < L) {  // ws has room for S rows per wave: no row guard
-        double* __restrict__ wp = a.ws + (long long)s0 * L + i;
-        double v[S];
-#pragma unroll
-        for (int r = 0; r < S; ++r) v[r] = buf[r * SOS_LD + lane];
-#pragma unroll
-        for (int r = 0; r < S; ++r) wp[(long long)r * L] = v[r];
-      }
-    } else {
-      store_y(buf, i);
-    }
-  };
-
-  double z[NS][2];
-  double ylast = 0.0;
-  issue_fwd(0);
-  for (int k = 0; k < ntiles; ++k) {
-    double* buf = tile + (k & 1) * TILE;
-    __syncthreads();
-    commit_fwd(k, buf);
-    __syncthreads();
-    if (k > 0) store_fwd(k - 1, tile + ((k - 1) & 1) * TILE);
-    if (k + 1 < ntiles) issue_fwd(k + 1);
-    const int t0 = k * SOS_TT;
-    const int nval = (L - t0 < SOS_TT) ? L - t0 : SOS_TT;
-    if (active) {
-      double* __restrict__ row = myrow + (k & 1) * TILE;
-      if (k == 0) {  // initial state: zi * ext[0] (sosfiltfilt) or zeros (sosfilt)
-        const double x0 = row[0];
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-          z[s][0] = a.zero_lag ? a.zi[s][0] * x0 : 0.0;
-          z[s][1] = a.zero_lag ? a.zi[s][1] * x0 : 0.0;
-        }
-      }
-      ylast = sos_run_tile<NS, +1>(row, nval, z, c, ylast);
-    }
-  }
-  __syncthreads();
-  store_fwd(ntiles - 1, tile + ((ntiles - 1) & 1) * TILE);
-  if (!a.zero_lag) return;
-
-  // ---- backward pass: the forward output reversed, initial state zi * y[L-1]; keep the central T samples ------
-  __threadfence();  // this wave's own stores to ws are re-read below
-#pragma unroll
-  for (int s = 0; s < NS; ++s) {
-    z[s][0] = a.zi[s][0] * ylast;
-    z[s][1] = a.zi[s][1] * ylast;
-  }
-  double pb[S];
-  auto issue_bwd = [&](int k) {
-    int i = k * SOS_TT + lane;
-    i = i < L ? i : L - 1;  // branch-free (see issue_fwd); ws holds S rows for every wave
-    const double* __restrict__ wp = a.ws + (long long)s0 * L + i;
-#pragma unroll
-    for (int r = 0; r < S; ++r) pb[r] = wp[(long long)r * L];
-  };
-  issue_bwd(ntiles - 1);
-  for (int k = ntiles - 1; k >= 0; --k) {
-    double* buf = tile + (k & 1) * TILE;
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < S; ++r) buf[r * SOS_LD + lane] = pb[r];
-    __syncthreads();
-    if (k + 1 < ntiles) store_y(tile + ((k + 1) & 1) * TILE, (k + 1) * SOS_TT + lane - edge);
-    if (k > 0) issue_bwd(k - 1);
-    const int t0 = k * SOS_TT;
-    const int nval = (L - t0 < SOS_TT) ? L - t0 : SOS_TT;
-    if (active) sos_run_tile<NS, -1>(myrow + (k & 1) * TILE, nval, z, c, 0.0);
-  }
-  __syncthreads();
-  store_y(tile, lane - edge);
-}
-
-
 // =================================================================================================
 // Round 2: sosfilt2_kernel -- the same filter, restructured around what bounds it.
 //
@@ -676,281 +467,6 @@ __global__ void __launch_bounds__(128) sosfilt2_kernel(SosArgs a, const double* 
         if (k - 3 >= 0) issue_bwd(k - 3, P);
       };
       if ((ntiles - k) & 1)
-        mover(P1{});
-      else
-        mover(P0{});
-    }
-    __syncthreads();
-  }
-}
-
-// =================================================================================================
-// Round 3: sosfilt3_kernel -- the zero-lag filter without the fp64 workspace round trip.
-//
-// sosfilt2_kernel writes the forward output of the extended signal (8 bytes per sample) to a workspace and reads it back
-// for the backward pass: 5.3 of the 7.9 GB a 1024 x 16 x 20 000 fp32 call moves.  Here the forward pass keeps only the
-// section states at the tile boundaries (16 bytes per lane and 64-sample tile: 0.5 byte per sample and series at order 4)
-// and the backward pass RECOMPUTES each tile's forward output from the raw samples and the checkpoint, on a third wave,
-// one tile ahead of the backward recursion:
-//   phase 1  wave 1 moves raw tiles into LDS (as before), wave 0 runs the forward recursion and stores its state after
-//            every tile; nothing else is written.
-//   phase 2  for tile k = last .. 0 in one workgroup step: wave 1 commits raw tile k - 2 and stores the finished tile
-//            k + 1, wave 2 recomputes the forward output of tile k - 1 in place (state from the checkpoint), wave 0 runs
-//            the backward recursion over tile k in DESCENDING sample order in place.  Four LDS tiles, one barrier per step.
-// The recomputation executes the very instructions of phase 1 on the very same inputs and state, so the forward
-// output -- and with it the result -- is bit-identical to scipy's, like sosfilt2_kernel's.  Traffic per sample: the raw
-// samples twice + the output + 0.5 byte of checkpoints (13 bytes for fp32 instead of 24), plus the mean pass.
-template <int LPS, int DIR, bool WRITE>
-__device__ __forceinline__ void sos3_run_tile(double* row, int sec, int nval, SosLane& f) {
-  double xn = 0.0;
-  auto input = [&](double lds_val) -> double {
-    if constexpr (LPS == 1) return lds_val;
-    const unsigned long long v = __builtin_bit_cast(unsigned long long, xn);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)v, 0x111, 0xf, 0xf, true);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(v >> 32), 0x111, 0xf, 0xf, true);
-    const double sh = __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
-    return sec == 0 ? lds_val : sh;
-  };
-  // recursion step n handles sample n of the tile in recursion order, which sits at position n (ascending pass) or
-  // nval - 1 - n (descending pass); rd[DIR * n] is that position, wrp[DIR * n] the sample this lane's section filters then
-  // The stores of consecutive steps hit the SAME position from different lanes (section s overwrites what section s - 1
-  // stored one step earlier), so their program order is the data flow: nothing else keeps the compiler from pairing two steps
-  // into one ds_write2_b64 -- whose address order, not step order, then decides which section's value stays (in the
-  // descending pass the pair came out reversed: every other sample kept the first section's output).  A compiler barrier
-  // after every store pins the order (the pointer keeps its LDS address space).
-  auto put = [](double* p, double v) __attribute__((always_inline)) {
-    *p = v;
-    asm volatile("" ::: "memory");
-  };
-  double* rd = DIR > 0 ? row : row + (nval - 1);
-  double* wrp = rd - DIR * sec;
-  auto masked_step = [&](int n) {
-    const int j = n - sec;
-    const int jr = n < nval ? n : nval - 1;
-    const double xin = input(rd[DIR * jr]);
-    if (j >= 0 && j < nval) {
-      xn = f.step(xin);
-      if constexpr (WRITE) put(wrp + DIR * n, xn);
-    }
-  };
-  if (nval == SOS_TT) {
-    int n = 0;
-    for (; n < LPS - 1; ++n) masked_step(n);
-    double cur[8], nxt[8];
-    constexpr int n_main_end = LPS - 1 + ((SOS_TT - (LPS - 1)) / 8) * 8;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) cur[e] = rd[DIR * (n + e)];
-    for (; n < n_main_end; n += 8) {
-      if (n + 8 < n_main_end) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) nxt[e] = rd[DIR * (n + 8 + e)];
-      }
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        xn = f.step(input(cur[e]));
-        if constexpr (WRITE) put(wrp + DIR * (n + e), xn);
-      }
-#pragma unroll
-      for (int e = 0; e < 8; ++e) cur[e] = nxt[e];
-    }
-    for (; n < SOS_TT + LPS - 1; ++n) masked_step(n);
-  } else {
-    for (int n = 0; n < nval + LPS - 1; ++n) masked_step(n);
-  }
-}
-
-template <int LPS>
-constexpr size_t sos3_smem_bytes() {
-  return sizeof(double) * (4 * sos2_series<LPS>() * SOS_LD + 8);  // four tiles
-}
-
-// a.ws: checkpoints, [workgroup][tile 0 .. ntiles][64 lanes][2] doubles
-template <typename real, int LPS>
-__global__ void __launch_bounds__(192) sosfilt3_kernel(SosArgs a, const double* __restrict__ stat_g, int ns) {
-  constexpr int S = sos2_series<LPS>();
-  constexpr int TILE = S * SOS_LD;
-  extern __shared__ __attribute__((aligned(16))) double sos_smem[];
-  double* tile = sos_smem;  // [4][TILE]
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int s0 = blockIdx.x * S;
-  const int T = a.T, edge = a.edge, L = T + 2 * edge, N = a.N, a_m = a.m, a_rectify = a.rectify;
-  const long long a_ld = a.ld;
-  real* const a_y = static_cast<real*>(a.y);
-  const int nrows = (N - s0 < S) ? N - s0 : S;
-  const int ntiles = (L + SOS_TT - 1) / SOS_TT;
-  auto nval_of = [&](int k) __attribute__((always_inline)) { return (L - k * SOS_TT < SOS_TT) ? L - k * SOS_TT : SOS_TT; };
-
-  // ---- wave 1: data mover state (as in sosfilt2_kernel) ----------------------------------------------------------
-  const real* __restrict__ xbase = static_cast<const real*>(a.x);
-  const long long off0 = (long long)(s0 / a.m) * a.bstride + (long long)(s0 % a.m) * a.ld;
-  const int ch0 = s0 % a.m;
-  const long long jump = a.bstride - (long long)a.m * a.ld;
-  const int sl = lane < nrows ? lane : nrows - 1;
-  const real mean_l = (real)stat_g[3LL * (s0 + sl) + 0];
-  const real first_l = (real)stat_g[3LL * (s0 + sl) + 1];
-  const real last_l = (real)stat_g[3LL * (s0 + sl) + 2];
-  real pf[2][S];
-  auto issue_raw = [&](int k, auto P) __attribute__((always_inline)) {  // raw rows of tile k -> registers (reflection applied on the index)
-    constexpr int p = decltype(P)::value;
-    const int i = k * SOS_TT + lane;
-    int j = i - edge;
-    if (j < 0) j = -j;
-    if (j >= T) j = 2 * (T - 1) - j;
-    j = j < 0 ? 0 : j;
-    long long off = off0;
-    int ch = ch0;
-#pragma unroll
-    for (int r = 0; r < S; ++r) {  // branch-free: rows past the last series re-read the last valid row
-      pf[p][r] = xbase[off + j];
-      const bool more = r + 1 < nrows;
-      long long step = a_ld;
-      if (ch + 1 == a_m) step += jump;
-      ch = more ? (ch + 1 == a_m ? 0 : ch + 1) : ch;
-      off += more ? step : 0;
-    }
-  };
-  auto commit_raw = [&](int k, double* __restrict__ buf, auto P) __attribute__((always_inline)) {  // registers -> LDS: centre, rectify, odd extension
-    constexpr int p = decltype(P)::value;
-    const int i = k * SOS_TT + lane;
-    const int j = i - edge;
-    const bool left = j < 0, ext = left || j >= T;
-    if (k * SOS_TT >= edge && k * SOS_TT + SOS_TT <= edge + T) {
-#pragma unroll
-      for (int r = 0; r < S; ++r)
-        buf[r * SOS_LD + lane] = (double)sos_pre<real>(pf[p][r], lane_bcast(mean_l, r), a_rectify);
-    } else {
-#pragma unroll
-      for (int r = 0; r < S; ++r) {
-        const real v = sos_pre<real>(pf[p][r], lane_bcast(mean_l, r), a_rectify);
-        const real e0 = lane_bcast(first_l, r), e1 = lane_bcast(last_l, r);
-        const real end = left ? e0 : e1;
-        const real refl = (real)2 * end - v;
-        buf[r * SOS_LD + lane] = (double)(ext ? refl : v);
-      }
-    }
-  };
-  auto store_y = [&](const double* __restrict__ buf, int k) __attribute__((always_inline)) {
-    const int j = k * SOS_TT + lane - edge;
-    if (j < 0 || j >= T) return;
-    real* __restrict__ yp = a_y + (long long)s0 * T + j;
-    if (nrows == S) {
-      double v[S];
-#pragma unroll
-      for (int r = 0; r < S; ++r) v[r] = buf[r * SOS_LD + lane];
-#pragma unroll
-      for (int r = 0; r < S; ++r) yp[(long long)r * T] = (real)v[r];
-    } else {
-      for (int r = 0; r < nrows; ++r) yp[(long long)r * T] = (real)buf[r * SOS_LD + lane];
-    }
-  };
-  using P0 = std::integral_constant<int, 0>;
-  using P1 = std::integral_constant<int, 1>;
-
-  // ---- recursion state (waves 0 and 2) -------------------------------------------------------------------------------
-  const int ser = (lane / LPS) < S ? lane / LPS : S - 1, sec = lane % LPS;
-  SosLane f;
-  double zi0 = 0.0, zi1 = 0.0;
-  f.c0 = 1.0;
-  f.c1 = f.c2 = f.c3 = f.c4 = 0.0;  // identity section for sec >= ns
-#pragma unroll
-  for (int q = 0; q < SOS_MAX_SECTIONS; ++q) {
-    if (q < LPS && sec == q && q < ns) {
-      f.c0 = a.sos[q][0];
-      f.c1 = a.sos[q][1];
-      f.c2 = a.sos[q][2];
-      f.c3 = a.sos[q][4];
-      f.c4 = a.sos[q][5];
-      zi0 = a.zi[q][0];
-      zi1 = a.zi[q][1];
-    }
-  }
-  f.z0 = f.z1 = 0.0;
-  // checkpoints of this workgroup: state at the START of tile t at ck[(t * 64 + lane) * 2 .. + 2)
-  double* __restrict__ ck = a.ws + (long long)blockIdx.x * (ntiles + 1) * 128;
-
-  // ---- phase 1: forward recursion, checkpoints only --------------------------------------------------------------------
-  // tile t lives in register set t & 1 and LDS tile t % 4
-  if (wave == 1) {
-    issue_raw(0, P0{});
-    if (ntiles > 1) issue_raw(1, P1{});
-    commit_raw(0, tile, P0{});
-    if (ntiles > 2) issue_raw(2, P0{});
-  }
-  __syncthreads();
-  for (int k = 0; k < ntiles; ++k) {
-    if (wave == 0) {
-      double* row = tile + (k % 4) * TILE + ser * SOS_LD;
-      if (k == 0) {  // initial state: zi * ext[0] (sosfiltfilt); surplus sections: zi = 0
-        const double x0 = row[0];
-        f.z0 = zi0 * x0;
-        f.z1 = zi1 * x0;
-      }
-      ck[((long long)k * 64 + lane) * 2 + 0] = f.z0;
-      ck[((long long)k * 64 + lane) * 2 + 1] = f.z1;
-      sos3_run_tile<LPS, 1, false>(row, sec, nval_of(k), f);
-    } else if (wave == 1) {
-      auto mover = [&](auto P) __attribute__((always_inline)) {  // P = (k + 1) & 1: the set holding tile k + 1, refilled with tile k + 3
-        if (k + 1 < ntiles) commit_raw(k + 1, tile + ((k + 1) % 4) * TILE, P);
-        if (k + 3 < ntiles) issue_raw(k + 3, P);
-      };
-      if ((k + 1) & 1)
-        mover(P1{});
-      else
-        mover(P0{});
-    }
-    __syncthreads();
-  }
-
-  // ---- phase 2: backward recursion over recomputed forward tiles ---------------------------------------------------------
-  // mover register sets: tile t lives in set (ntiles - 1 - t) & 1
-  __threadfence();  // wave 2 reads the checkpoints wave 0 stored
-  double ck_z0 = 0.0, ck_z1 = 0.0;
-  if (wave == 2) {
-    ck_z0 = ck[((long long)(ntiles - 1) * 64 + lane) * 2 + 0];
-    ck_z1 = ck[((long long)(ntiles - 1) * 64 + lane) * 2 + 1];
-  }
-  if (wave == 1) {
-    issue_raw(ntiles - 1, P0{});
-    if (ntiles > 1) issue_raw(ntiles - 2, P1{});
-    commit_raw(ntiles - 1, tile + ((ntiles - 1) % 4) * TILE, P0{});
-    if (ntiles > 2) issue_raw(ntiles - 3, P0{});
-  }
-  __syncthreads();
-  // step k: wave 0 filters tile k backwards, wave 2 recomputes the forward output of tile k - 1, wave 1 commits raw tile
-  // k - 2 (requested two steps earlier), requests tile k - 4 and stores the finished tile k + 1
-  for (int k = ntiles; k >= -1; --k) {
-    if (wave == 0) {
-      if (k >= 0 && k < ntiles) {
-        double* row = tile + (k % 4) * TILE + ser * SOS_LD;
-        const int nv = nval_of(k);
-        if (k == ntiles - 1) {
-          const double yl = row[nv - 1];  // y_fwd[L - 1]
-          f.z0 = zi0 * yl;
-          f.z1 = zi1 * yl;
-        }
-        sos3_run_tile<LPS, -1, true>(row, sec, nv, f);
-      }
-    } else if (wave == 2) {
-      const int t = k - 1;
-      if (t >= 0 && t < ntiles) {
-        double* row = tile + (t % 4) * TILE + ser * SOS_LD;
-        SosLane g = f;  // coefficients; the state comes from the checkpoint, requested one step ahead of its use
-        g.z0 = ck_z0;
-        g.z1 = ck_z1;
-        if (t > 0) {  // (a global-memory round trip per tile on this wave's critical path cost 0.4 ms per call)
-          ck_z0 = ck[((long long)(t - 1) * 64 + lane) * 2 + 0];
-          ck_z1 = ck[((long long)(t - 1) * 64 + lane) * 2 + 1];
-        }
-        sos3_run_tile<LPS, 1, true>(row, sec, nval_of(t), g);
-      }
-    } else {
-      auto mover = [&](auto P) __attribute__((always_inline)) {  // P = (ntiles - 1 - (k - 2)) & 1: the set holding tile k - 2, refilled with tile k - 4
-        if (k - 2 >= 0 && k - 2 < ntiles - 1) commit_raw(k - 2, tile + ((k - 2) % 4) * TILE, P);
-        if (k + 1 < ntiles) store_y(tile + ((k + 1) % 4) * TILE, k + 1);
-        if (k - 4 >= 0) issue_raw(k - 4, P);
-      };
-      if ((ntiles - 1 - (k - 2)) & 1)
         mover(P1{});
       else
         mover(P0{});

@@ -138,16 +138,6 @@ def test_traffic_measurements_still_name_the_kernel_the_library_launches():
         assert _lib.get_handle(0).last_kernel() == e["kernel"], (e["kernel"], _lib.get_handle(0).last_kernel())
 
 
-def test_checkpointed_filter_kernel_is_bit_exact_too():
-    """sosfilt3_kernel (HIPNMF_SOS_V3=1: section states checkpointed per tile, forward output recomputed in the backward
-    pass -- half the traffic of the default kernel, not faster: the filter is bound by its dependent fp64 chain): the
-    randomised scipy cross-check, bit-identical in fp64."""
-    env = dict(os.environ, HIPNMF_SOS_V3="1")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz_sosfilt_gpu.py"), "--cases", "150", "--seed", "21"],
-                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
-    assert r.returncode == 0 and "0 problems" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
-
-
 @pytest.mark.parametrize("k", [1, 2, 3, 4, 5, 6, 7, 8])
 def test_kullback_leibler_on_the_matrix_pipe(k):
     """fit_rowlane_kernel's Kullback-Leibler flavour (both W H reconstructions and Q H^T on v_mfma_f32_4x4x1; the library's
