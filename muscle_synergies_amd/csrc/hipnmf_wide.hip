@@ -84,8 +84,9 @@ const WideKernel<double>* pick<double>(int m, int k, int nw) {
 }
 }  // namespace
 
-// The one-pass update + record kernel of the general shapes (nmf_big1.hpp; round 5): fp32, Frobenius.  HIPNMF_BIG1=0 keeps the
-// two-pass pair big_pass_w_kernel + big_records_kernel (which remains the path of float64 and of the Kullback-Leibler loss).
+// The one-pass update + record kernel of the general shapes (nmf_big1.hpp; round 5): fp32, both losses.  HIPNMF_BIG1=0 keeps the
+// two-pass pair big_pass_w_kernel + big_records_kernel (which remains the path of float64, and of Kullback-Leibler fits with 48 /
+// 64 padded components on more than 256 channels, whose two operand layouts of H do not fit LDS beside the exchange areas).
 template <typename real>
 static const Big1Kernel<real>* pick_big1(hipnmf_handle*, int, int, bool) {
   return nullptr;
@@ -96,9 +97,11 @@ const Big1Kernel<float>* pick_big1<float>(hipnmf_handle* h, int KPb, int MPb, bo
     const char* e = getenv("HIPNMF_BIG1");
     return !(e && atoi(e) == 0);
   }();
-  if (!on || kl) return nullptr;
+  if (!on) return nullptr;
   const Big1Kernel<float>* b1 = big1_kernel_f32(KPb, MPb);
-  return (b1 && b1->smem <= (size_t)h->lds_per_block) ? b1 : nullptr;
+  if (!b1) return nullptr;
+  if (kl) return (b1->fn_kl && b1->smem_kl <= (size_t)h->lds_per_block) ? b1 : nullptr;  // (48 / 64 components on > 256 channels: two-pass)
+  return b1->smem <= (size_t)h->lds_per_block ? b1 : nullptr;
 }
 
 // Slices per matrix for the one-pass kernel: one workgroup fits a CU, so the launch runs in ceil(B S / CUs) waves of workgroups of
@@ -505,7 +508,9 @@ int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
     ba.kl = kl ? 1 : 0;
     ba.update_h = a.update_h;
     const Big1Kernel<real>* b1 = pick_big1<real>(h, KPb, MPb, kl);
-    if (b1) snprintf(h->last_kernel, sizeof(h->last_kernel), "%s[sliced]", b1->name);
+    const auto b1fn = b1 ? (kl ? b1->fn_kl : b1->fn) : nullptr;
+    const size_t b1smem = b1 ? (kl ? b1->smem_kl : b1->smem) : 0;
+    if (b1) snprintf(h->last_kernel, sizeof(h->last_kernel), "%s[sliced]", kl ? b1->name_kl : b1->name);
     ba.hht_part = reinterpret_cast<real*>(ws + o_hhtp);
     ba.n_hblk = n_hblk;
     // H in LDS: all of it when [KP][MP + 4] (+ H H^T, + the residual's column accumulators) fits 96 KiB, else blocks of channels
@@ -551,7 +556,7 @@ int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
                              reinterpret_cast<const void*>(big_resid_kernel<real, KP>)})
         if (!arc) arc = hipnmf_allow_full_lds(h, fn);
     });
-    if (!arc && b1 && b1->smem > 48 * 1024) arc = hipnmf_allow_full_lds(h, reinterpret_cast<const void*>(b1->fn));
+    if (!arc && b1 && b1smem > 48 * 1024) arc = hipnmf_allow_full_lds(h, reinterpret_cast<const void*>(b1fn));
     if (!arc && smem_h > 48 * 1024) arc = hipnmf_allow_full_lds(h, reinterpret_cast<const void*>(big_hupdate_kernel<real>));
     if (arc) return arc;
     if (std::max(std::max(smem_w, smem_r), std::max(smem_rec, smem_h)) > (size_t)h->lds_per_block)
@@ -570,7 +575,7 @@ int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
     auto enqueue = [&](int n, bool check, auto&& emit) {
       for (int i = 0; i < n; ++i) {
         if (b1) {  // one pass: the W update and the slice's record together (H H^T comes with the H update)
-          emit(b1->fn, gslice, dim3(512), b1->smem, ba);
+          emit(b1fn, gslice, dim3(512), b1smem, ba);
         } else {
           emit(big_hht_kernel<real>, dim3(B, KPb), dim3(256), (size_t)0, ba);
           with_kp([&](auto kp) {
@@ -739,7 +744,9 @@ int hipnmf_shard_wide(hipnmf_handle* h, const hipnmf_problem* p, int op, const r
   int arc = HIPNMF_OK;
   if (op == 0) {
     if (b1) {
-      if (b1->smem > 48 * 1024) arc = hipnmf_allow_full_lds(h, reinterpret_cast<const void*>(b1->fn));
+      const auto b1fn = kl ? b1->fn_kl : b1->fn;
+      const size_t b1smem = kl ? b1->smem_kl : b1->smem;
+      if (b1smem > 48 * 1024) arc = hipnmf_allow_full_lds(h, reinterpret_cast<const void*>(b1fn));
       if (arc) return arc;
       BigHArgs<real> hp;
       std::memset(&hp, 0, sizeof(hp));
@@ -748,8 +755,9 @@ int hipnmf_shard_wide(hipnmf_handle* h, const hipnmf_problem* p, int op, const r
       hp.k = k;
       hp.KP = KPb;
       hp.hht_part = reinterpret_cast<real*>(ws + o_hhtp);
+      hp.kl = kl ? 1 : 0;
       hipLaunchKernelGGL(big_hht_part_kernel<real>, dim3(B, n_hblk), dim3(256), sizeof(real) * 64 * (size_t)k, st, hp);
-      hipLaunchKernelGGL(b1->fn, gslice, dim3(512), b1->smem, st, ba);
+      hipLaunchKernelGGL(b1fn, gslice, dim3(512), b1smem, st, ba);
     } else {
       hipLaunchKernelGGL(big_hht_kernel<real>, dim3(B, KPb), dim3(256), 0, st, ba);
       if (std::max(smem_w, smem_rec) > (size_t)h->lds_per_block)

@@ -59,6 +59,9 @@ struct Big1Kernel {
   int KP, NQ, RS;
   const char* name;
   void (*resid)(BigArgs<real>);  // big1_resid_kernel<real, KP, NQ>: the residual on the same decomposition (512 threads, no LDS)
+  void (*fn_kl)(BigArgs<real>);  // the Kullback-Leibler flavour (LOSS = 1) or nullptr; its LDS and name:
+  size_t smem_kl;
+  const char* name_kl;
 };
 const Big1Kernel<float>* big1_kernel_f32(int KP, int MP);  // nullptr: no instance covers MP channels
 // values per slice of the column record: sse | xsq (| the Kullback-Leibler divergence per column)
@@ -404,11 +407,14 @@ struct BigHArgs {
 };
 // partial H H^T of 64 channels held in LDS as sH [k][64] (columns >= ncol are ignored): out [KP][KP], zero beyond k
 template <typename real>
-__device__ __forceinline__ void big_hht_partial(const real* __restrict__ sHn, int k, int ncol, int KP, real* __restrict__ out) {
+__device__ __forceinline__ void big_hht_partial(const real* __restrict__ sHn, int k, int ncol, int KP, real* __restrict__ out, int kl) {
   for (int idx = threadIdx.x; idx < KP * KP; idx += blockDim.x) {
     const int c = idx / KP, c2 = idx % KP;
     real s = (real)0;
-    if (c < k && c2 < k) {
+    if (kl) {  // Kullback-Leibler: column 0 holds the block's share of rowsum(H) (_nmf.py:577-581), the rest stays 0
+      if (c < k && c2 == 0)
+        for (int jj = 0; jj < ncol; ++jj) s += sHn[c * 64 + jj];
+    } else if (c < k && c2 < k) {
       // the lanes of a wave differ in c2: each starts c2 channels further on (rows are 64 values apart: without the skew all
       // lanes would sit on one bank); a fixed order per entry all the same
       int jj = c2 % ncol;
@@ -431,7 +437,7 @@ __global__ void __launch_bounds__(256) big_hht_part_kernel(BigHArgs<real> a) {
   const real* __restrict__ Hb = a.H + (long long)b * k * a.m;
   for (int idx = threadIdx.x; idx < k * ncol; idx += 256) sHn[(idx / ncol) * 64 + idx % ncol] = Hb[(long long)(idx / ncol) * a.m + c0 + idx % ncol];
   __syncthreads();
-  big_hht_partial<real>(sHn, k, ncol, a.KP, a.hht_part + ((long long)b * gridDim.y + blockIdx.y) * a.KP * a.KP);
+  big_hht_partial<real>(sHn, k, ncol, a.KP, a.hht_part + ((long long)b * gridDim.y + blockIdx.y) * a.KP * a.KP, a.kl);
 }
 template <typename real>
 __global__ void __launch_bounds__(256) big_hupdate_kernel(BigHArgs<real> a) {
@@ -485,7 +491,7 @@ __global__ void __launch_bounds__(256) big_hupdate_kernel(BigHArgs<real> a) {
   }
   if (a.hht_part) {  // the next iteration's H H^T, this block's share (the one-pass kernel adds the blocks in order)
     __syncthreads();
-    big_hht_partial<real>(sNum, k, ncol, a.KP, a.hht_part + ((long long)b * gridDim.y + blockIdx.y) * a.KP * a.KP);
+    big_hht_partial<real>(sNum, k, ncol, a.KP, a.hht_part + ((long long)b * gridDim.y + blockIdx.y) * a.KP * a.KP, a.kl);
   }
 }
 

@@ -32,7 +32,13 @@ namespace hipnmf {
 // HL: the wave's block of H (the numerator's A operand) lives in LDS instead of registers -- the instances whose register
 // budget (256 at two waves per SIMD) it would break: <32, 4, 4> spilled 66 values, reloaded from scratch at the top of every
 // round BEHIND the X prefetch in the memory counter's order, i.e. every round waited for its youngest load.  NST: X stages per wave.
-template <typename real, int KP, int NQ, int RS, bool HL = false, int NST = 2>
+// LOSS = 1: the Kullback-Leibler updates (_nmf.py:556-591, 642-684) on the same decomposition.  Per round: (a) every wave
+// reconstructs (W H) for ITS channels and the round's rows on the pipe (A = its block of H^T, B = the old rows of W, which the
+// unit owners put in LDS one round ahead), Q = X / max(W H, eps), partial numerator^T = H_w Q_w^T; (c) the owners divide by
+// rowsum(H) (column 0 of the per-block partial products the H update leaves), store W'; (e) every wave reconstructs (W' H) for
+// its channels, Q' = X / max(W' H, eps) goes through the transposition stage instead of X, accA += W'^T Q'; the owners add up
+// colsum(W') (column 0 of the record's second block).  Both operand layouts of H come from the wave's LDS block (HL implied).
+template <typename real, int KP, int NQ, int RS, bool HL = false, int NST = 2, int LOSS = 0>
 struct Big1Cfg {
   static constexpr int NKB = KP / 16, CW = 16 * NQ, NW = 8, NU = RS * NKB, SLOTS = (NU + NW - 1) / NW;
   static constexpr int SW = KP + 4, SX = CW + 4, ROWS = 16 * RS;
@@ -41,17 +47,20 @@ struct Big1Cfg {
   static constexpr int RED = NU * 16 * KP;                              // W'^T W' partial block rows at the end of the slice
   static constexpr int PW = (NW * PW0 >= RED) ? PW0 : (RED + NW - 1) / NW;
   static constexpr int MAXCH = NW * CW;                                  // channels one workgroup covers
-  static constexpr int HW = HL ? KP * SX : 0;                            // per-wave block of H: [KP][CW + 4]
-  __host__ __device__ static constexpr size_t smem_bytes() { return sizeof(real) * (size_t)(NW * PW + ROWS * SW + NW * HW); }
+  static constexpr bool HLL = HL || LOSS == 1;
+  static constexpr int HW = HLL ? KP * SX : 0;                           // per-wave block of H: [KP][CW + 4]
+  static constexpr int WOLD = LOSS == 1 ? ROWS * SW : 0;                 // KL: the round's OLD rows of W, row-major
+  __host__ __device__ static constexpr size_t smem_bytes() { return sizeof(real) * (size_t)(NW * PW + ROWS * SW + WOLD + NW * HW); }
   static_assert(KP % 16 == 0 && KP >= 16 && KP <= 64 && (NQ == 1 || NQ == 2 || NQ == 4) && RS % 2 == 0, "unsupported shape");
   static_assert(smem_bytes() <= 160 * 1024, "LDS");
 };
 
 // grid (S, B), 512 threads; dynamic LDS Big1Cfg::smem_bytes().  a.hht_part holds H H^T as per-block partial products
 // (big_hht_part_kernel before the first iteration, big_hupdate_kernel afterwards), a.part receives the records.
-template <typename real, int KP, int NQ, int RS, bool HL = false, int NST = 2>
+template <typename real, int KP, int NQ, int RS, bool HL = false, int NST = 2, int LOSS = 0>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) big1_pass_kernel(BigArgs<real> a) {
-  using C = Big1Cfg<real, KP, NQ, RS, HL, NST>;
+  using C = Big1Cfg<real, KP, NQ, RS, HL, NST, LOSS>;
+  constexpr bool HLL = C::HLL;
   using M = WideMma<real>;
   using acc = typename M::acc;
   constexpr int NKB = C::NKB, CW = C::CW, NW = C::NW, NU = C::NU, SLOTS = C::SLOTS, SW = C::SW, SX = C::SX, ROWS = C::ROWS,
@@ -65,7 +74,8 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ar = M::arow(j);
   real* const Pw = P + wave * PW;
-  real* const sHw = Wst + ROWS * SW + wave * C::HW;  // HL: [KP][SX] this wave's block of H
+  real* const WoldSt = Wst + ROWS * SW;               // KL: [ROWS][SW] the round's old rows of W
+  real* const sHw = WoldSt + C::WOLD + wave * C::HW;  // HLL: [KP][SX] this wave's block of H
   const real* __restrict__ Xb = a.X + (long long)b * a.x_bstride;
   real* __restrict__ Wb = a.W + (long long)b * a.w_bstride;
   const real* __restrict__ Hb = a.H + (long long)b * a.k * a.m;
@@ -81,8 +91,8 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 
   // ---- operands that live in registers for the whole slice ---------------------------------------------------------
   // numerator's A operand: lane (i, g), k-step (q, r) <-> H[16 kb + arow(i)][ch_w0 + 16 q + 4 g + r]
-  real hreg[HL ? 1 : NKB][HL ? 1 : NQ][4];
-  if constexpr (HL) {  // private to the wave: written and read by the same wave, no barrier
+  real hreg[HLL ? 1 : NKB][HLL ? 1 : NQ][4];
+  if constexpr (HLL) {  // private to the wave: written and read by the same wave, no barrier
     for (int idx = lane; idx < KP * CW; idx += 64) {
       const int c = idx / CW, ch = ch_w0 + idx % CW;
       sHw[c * SX + idx % CW] = (c < a.k && ch < a.m) ? Hb[(long long)c * a.m + ch] : (real)0;
@@ -107,6 +117,15 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     const int v = wave + NW * sl;
     u_s[sl] = v < NU ? v / NKB : -1;
     u_kb[sl] = v < NU ? v % NKB : 0;
+    if constexpr (LOSS == 1) {  // rowsum(H) of the unit's components 16 kbo + 4 g + r: column 0 of the partial products, block order
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const real* __restrict__ hp = a.hht_part + (long long)b * a.n_hblk * KP * KP + (16 * u_kb[sl] + 4 * g + r) * KP;
+        real sH = hp[0];
+        for (int blk = 1; blk < a.n_hblk; ++blk) sH += hp[(long long)blk * KP * KP];
+        hha[sl][0][r] = sH;
+      }
+    } else
 #pragma unroll
     for (int kbi = 0; kbi < NKB; ++kbi) {  // H H^T = the 64-channel blocks' partial products added in block order
       const real* __restrict__ hp = a.hht_part + (long long)b * a.n_hblk * KP * KP + (16 * u_kb[sl] + ar) * KP + 16 * kbi + 4 * g;
@@ -120,6 +139,11 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     }
   }
   acc accA[NKB][NQ], accB[SLOTS][NKB];
+  real wsum[SLOTS][4];  // KL: this lane's share of colsum(W') (its row, the unit's components)
+#pragma unroll
+  for (int sl = 0; sl < SLOTS; ++sl)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) wsum[sl][r] = (real)0;
   const acc zero = {(real)0, (real)0, (real)0, (real)0};
 #pragma unroll
   for (int kb = 0; kb < NKB; ++kb)
@@ -169,15 +193,41 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
     for (int s = 0; s < RS; ++s) issue_x(s, row_begin);
   }
+  // (W H) block for the lane's row and the channel block q: A = H^T block (lane (channel i, g), k-step (kb, t) <->
+  // H[16 kb + 4 g + t][ch_w0 + 16 q + arow(i)]), B = a row-major W fragment; D: lane (row j, g), register r <-> channel 16 q + 4 g + r
+  auto wh_block = [&](const real (&w)[NKB][4], int q) __attribute__((always_inline)) -> acc {
+    acc rec = zero;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) rec = M::mma(sHw[(16 * kb + 4 * g + t) * SX + 16 * q + ar], w[kb][t], rec);
+    return rec;
+  };
+  real wold1[SLOTS][4];  // KL: the unit's own block of the old rows (the denominator needs no other)
+  if constexpr (LOSS == 1) {
+#pragma unroll
+    for (int sl = 0; sl < SLOTS; ++sl) {
+      const rsrc_t wr = w_rsrc(u_s[sl] >= 0 ? row_begin + 16 * u_s[sl] : row_end);
+      buf_load<real, 4>(wr, (unsigned)j * ldw_b + (unsigned)((16 * u_kb[sl] + 4 * g) * (int)sizeof(real)), 0u, wold1[sl]);
+      if (u_s[sl] >= 0) wide_lds_write<real, 4>(WoldSt + (16 * u_s[sl] + j) * SW + 16 * u_kb[sl] + 4 * g, wold1[sl]);
+    }
+    __syncthreads();
+  }
   for (int t0 = row_begin; t0 < row_end; t0 += ROWS) {
     // the W fragments of this wave's units (B operand of the denominator: lane (row j, g) <-> components 16 kbi + 4 g .. + 3):
     // requested now, needed after the first barrier
-    real wold[SLOTS][NKB][4];
+    real wold[LOSS == 1 ? 1 : SLOTS][LOSS == 1 ? 1 : NKB][4];
+    real wnext[SLOTS][4];  // KL: the unit's block of the NEXT round's old rows (into LDS in phase c)
 #pragma unroll
     for (int sl = 0; sl < SLOTS; ++sl) {
-      const rsrc_t wr = w_rsrc(u_s[sl] >= 0 ? t0 + 16 * u_s[sl] : row_end);
+      if constexpr (LOSS == 1) {
+        const rsrc_t wr = w_rsrc(u_s[sl] >= 0 ? t0 + ROWS + 16 * u_s[sl] : row_end);
+        buf_load<real, 4>(wr, (unsigned)j * ldw_b + (unsigned)((16 * u_kb[sl] + 4 * g) * (int)sizeof(real)), 0u, wnext[sl]);
+      } else {
+        const rsrc_t wr = w_rsrc(u_s[sl] >= 0 ? t0 + 16 * u_s[sl] : row_end);
 #pragma unroll
-      for (int kbi = 0; kbi < NKB; ++kbi) buf_load<real, 4>(wr, (unsigned)j * ldw_b + (unsigned)((16 * kbi + 4 * g) * (int)sizeof(real)), 0u, wold[sl][kbi]);
+        for (int kbi = 0; kbi < NKB; ++kbi) buf_load<real, 4>(wr, (unsigned)j * ldw_b + (unsigned)((16 * kbi + 4 * g) * (int)sizeof(real)), 0u, wold[sl][kbi]);
+      }
     }
     // ---- a: partial numerators of the round over this wave's channels, two subtiles (2 NKB chains) at a time ------------
     if (active) {
@@ -188,12 +238,31 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         for (int e = 0; e < 2; ++e)
 #pragma unroll
           for (int kb = 0; kb < NKB; ++kb) num[e][kb] = zero;
+        real wB[LOSS == 1 ? 2 : 1][LOSS == 1 ? NKB : 1][4];  // KL: the old rows of the two subtiles, row-major fragments
+        if constexpr (LOSS == 1) {
+#pragma unroll
+          for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) wide_lds_read<real, 4>(WoldSt + (16 * (s + e) + j) * SW + 16 * kb + 4 * g, wB[e][kb]);
+        }
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
+          real xq[2][4];  // the B operand of the numerator: X, or Q = X / max(W H, eps) (_nmf.py:574-577)
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            if constexpr (LOSS == 1) {
+              const acc rec = wh_block(wB[e], q);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) xq[e][r] = big_quot(x[s + e][q][r], kl_floor(rec[r]));
+            } else {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) xq[e][r] = x[s + e][q][r];
+            }
+          }
           real ha[NKB][4];
 #pragma unroll
           for (int kb = 0; kb < NKB; ++kb) {
-            if constexpr (HL) {
+            if constexpr (HLL) {
               wide_lds_read<real, 4>(sHw + (16 * kb + ar) * SX + 16 * q + 4 * g, ha[kb]);
             } else {
 #pragma unroll
@@ -205,7 +274,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
             for (int e = 0; e < 2; ++e)
 #pragma unroll
-              for (int kb = 0; kb < NKB; ++kb) num[e][kb] = M::mma(ha[kb][r], x[s + e][q][r], num[e][kb]);
+              for (int kb = 0; kb < NKB; ++kb) num[e][kb] = M::mma(ha[kb][r], xq[e][r], num[e][kb]);
         }
         // D: lane (row j, g), register r <-> component 16 kb + 4 g + r: one 16-byte piece per lane and unit, stored at 4 * lane
         // (consecutive lanes on consecutive pieces: [row][component] order put eight lanes of a pass on two bank groups)
@@ -234,17 +303,25 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         for (int r = 0; r < 4; ++r) nsum[r] += t4[r];
       }
       acc den = zero;
-#pragma unroll
-      for (int kbi = 0; kbi < NKB; ++kbi)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) den = M::mma(hha[sl][kbi][r], wold[sl][kbi][r], den);
       real wo[4], dd[4], qq[4], wn[4];
+      if constexpr (LOSS == 1) {  // W *= ((X / WH) H^T) / rowsum(H)   (_nmf.py:577-581)
 #pragma unroll
-      for (int kbi = 0; kbi < NKB; ++kbi)
-        if (kbi == u_kb[sl]) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) wo[r] = wold[sl][kbi][r];
+        for (int r = 0; r < 4; ++r) {
+          den[r] = hha[sl][0][r];
+          wo[r] = wold1[sl][r];
         }
+      } else {
+#pragma unroll
+        for (int kbi = 0; kbi < NKB; ++kbi)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) den = M::mma(hha[sl][kbi][r], wold[sl][kbi][r], den);
+#pragma unroll
+        for (int kbi = 0; kbi < NKB; ++kbi)
+          if (kbi == u_kb[sl]) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) wo[r] = wold[sl][kbi][r];
+          }
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         real d = den[r];
@@ -257,7 +334,15 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
       for (int r = 0; r < 4; ++r) wn[r] = wo[r] * qq[r];
       const rsrc_t wr = w_rsrc(t0 + 16 * u_s[sl]);
       wide_store4<real>(wr, (unsigned)j * ldw_b + (unsigned)((16 * u_kb[sl] + 4 * g) * (int)sizeof(real)), 0u, wn);
-      if (upd) wide_lds_write<real, 4>(Wst + (16 * u_s[sl] + j) * SW + 16 * u_kb[sl] + 4 * g, wn);
+      if (upd || LOSS == 1) wide_lds_write<real, 4>(Wst + (16 * u_s[sl] + j) * SW + 16 * u_kb[sl] + 4 * g, wn);
+      if constexpr (LOSS == 1) {  // the next round's old rows (this round's were read before the barrier), colsum(W')
+        wide_lds_write<real, 4>(WoldSt + (16 * u_s[sl] + j) * SW + 16 * u_kb[sl] + 4 * g, wnext[sl]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          wsum[sl][r] += wn[r];
+          wold1[sl][r] = wnext[sl][r];
+        }
+      }
     }
     if (!upd) {  // nothing else needs X: the next round's rows may come
       if (active && t0 + ROWS < row_end) {
@@ -273,8 +358,22 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     for (int s = 0; s < RS; ++s) {
       real* const xst = Pw + (s % NST) * 16 * SX;  // this wave's stage (its partials are dead; nobody else touches the region now)
       if (active) {
+        if constexpr (LOSS == 1) {  // Q' = X / max(W' H, eps) with the updated rows (_nmf.py:660-663) takes X's place in the stage
+          real wnB[NKB][4];
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) wide_lds_write<real, 4>(xst + j * SX + 16 * q + 4 * g, x[s][q]);
+          for (int kb = 0; kb < NKB; ++kb) wide_lds_read<real, 4>(Wst + (16 * s + j) * SW + 16 * kb + 4 * g, wnB[kb]);
+#pragma unroll
+          for (int q = 0; q < NQ; ++q) {
+            const acc rec = wh_block(wnB, q);
+            real qv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) qv[r] = big_quot(x[s][q][r], kl_floor(rec[r]));
+            wide_lds_write<real, 4>(xst + j * SX + 16 * q + 4 * g, qv);
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < NQ; ++q) wide_lds_write<real, 4>(xst + j * SX + 16 * q + 4 * g, x[s][q]);
+        }
       }
       wide_wave_lds_fence();
       if (active && t0 + ROWS < row_end) issue_x(s, t0 + ROWS);  // the registers are free: the next round's subtile s
@@ -302,6 +401,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
             for (int kb = 0; kb < NKB; ++kb) accA[kb][q] = M::mma(wa[kb][t], xb[t], accA[kb][q]);
         }
       }
+      if constexpr (LOSS == 0)
 #pragma unroll
       for (int sl = 0; sl < SLOTS; ++sl)
         if (u_s[sl] == s) {  // (wave-uniform)
@@ -338,6 +438,22 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
   // W'^T W': block row kbo of unit v = (s, kbo) -> red[v][16][KP]; the units of one block row summed in subtile order
   __syncthreads();  // (the stages inside P are dead)
   real* const red = P;
+  if constexpr (LOSS == 1) {  // colsum(W') in column 0 of the block (the 16 row lanes j of one g: a fixed butterfly), zeros elsewhere
+    for (int idx = tid; idx < NU * 16 * KP; idx += 512) red[idx] = (real)0;
+    __syncthreads();
+#pragma unroll
+    for (int sl = 0; sl < SLOTS; ++sl) {
+      if (u_s[sl] < 0) continue;
+      const int v = wave + NW * sl;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        real sw = wsum[sl][r];
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) sw += __shfl_xor(sw, off, 64);
+        if (j == 0) red[(v * 16 + 4 * g + r) * KP] = sw;
+      }
+    }
+  } else {
 #pragma unroll
   for (int sl = 0; sl < SLOTS; ++sl) {
     if (u_s[sl] < 0) continue;
@@ -346,6 +462,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     for (int kbi = 0; kbi < NKB; ++kbi)
 #pragma unroll
       for (int r = 0; r < 4; ++r) red[(v * 16 + 4 * g + r) * KP + 16 * kbi + j] = accB[sl][kbi][r];
+  }
   }
   __syncthreads();
   for (int idx = tid; idx < KP * KP; idx += 512) {

@@ -47,7 +47,7 @@ def test_graph_replayed_and_cooperative_paths_in_lock_step():
     the same case at the same time (round 3's failure: 'operation failed due to a previous error during capture')."""
     _stress("--threads", "3", "--rounds", "4", "--same-order", "--only",
             "wide_sliced,wide4_sliced,wide4d_sliced_stop,wide_sliced_auto,sliced_graph,sliced_graph_stop,coop,coop_f64,big,big_stop,"
-            "big_f64,big_kl")
+            "big_f64,big_kl,big_kl_two_pass")
 
 
 def test_rank_range_on_long_and_wide_frames_runs_concurrently_with_torch_in_the_process():
