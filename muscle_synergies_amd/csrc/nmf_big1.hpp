@@ -288,8 +288,23 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    // denominator^T = (H H^T) W^T of this wave's units: needs only the old rows, so it runs BEFORE the barrier (the pipe
+    // is idle there while the waves arrive; after it the owners' chain is partials -> quotient -> stores only)
+    acc denu[SLOTS];
+    if constexpr (LOSS == 0) {
+#pragma unroll
+      for (int sl = 0; sl < SLOTS; ++sl) {
+        denu[sl] = zero;
+        if (u_s[sl] >= 0) {
+#pragma unroll
+          for (int kbi = 0; kbi < NKB; ++kbi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) denu[sl] = M::mma(hha[sl][kbi][r], wold[sl][kbi][r], denu[sl]);
+        }
+      }
+    }
     __syncthreads();
-    // ---- c: this wave's units: sum of the partials, denominator, W' ---------------------------------------------------
+    // ---- c: this wave's units: sum of the partials, W' ----------------------------------------------------------------
 #pragma unroll
     for (int sl = 0; sl < SLOTS; ++sl) {
       if (u_s[sl] < 0) continue;
@@ -311,10 +326,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
           wo[r] = wold1[sl][r];
         }
       } else {
-#pragma unroll
-        for (int kbi = 0; kbi < NKB; ++kbi)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) den = M::mma(hha[sl][kbi][r], wold[sl][kbi][r], den);
+        den = denu[sl];
 #pragma unroll
         for (int kbi = 0; kbi < NKB; ++kbi)
           if (kbi == u_kb[sl]) {
