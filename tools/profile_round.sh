@@ -1,6 +1,6 @@
 #!/bin/bash
-# rocprofv3 kernel statistics of the round's benchmarks (run on the GPU box: gpurun -- 'bash tools/profile_round.sh r04')
-tag=${1:-r04}
+# rocprofv3 kernel statistics of the round's benchmarks (run on the GPU box: gpurun -- 'bash tools/profile_round.sh r05')
+tag=${1:-r05}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_$tag
@@ -42,4 +42,9 @@ bash $R/tools/profile_envelope.sh $tag > $O/profile_envelope.log 2>&1
 cd /tmp
 run kl_narrow $R/tools/quick_bench.py --batch 2048 --iters 200 --threads 512 --loss kullback-leibler --rowmajor --reps 3
 run kl_wide4_64x8 $R/tools/quick_bench.py --batch 2048 --T 1000 --m 64 --k 8 --iters 200 --loss kullback-leibler --reps 3
+run kl_big_m512_k32 $R/tools/quick_bench.py --batch 64 --m 512 --k 32 --iters 50 --threads 0 --reps 3 --rowmajor --loss kullback-leibler
+run big_stop_rule_m512_k32 $R/tools/quick_bench.py --batch 64 --m 512 --k 32 --iters 50 --threads 0 --reps 3 --rowmajor --tol 1e-9
+for n in kl_narrow kl_wide4_64x8 kl_big_m512_k32 big_stop_rule_m512_k32; do grep -h "rep=" $O/$n.log > $O/${tag}_$n.log; done
+# the threading clause of the ABI over every entry point, 2 / 3 / 8 host threads (plain ctypes, no torch)
+for nt in 2 3 8; do python3 $R/tools/abi_threads_stress.py --threads $nt --rounds 2 2>&1 | tail -1; done > $O/${tag}_abi_threads_stress.log
 ls $O/*.csv $O/*.json $O/*.txt $O/*_filter_bench.log

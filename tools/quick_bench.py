@@ -18,6 +18,7 @@ ap.add_argument("--variant", type=int, default=0)
 ap.add_argument("--max-slices", type=int, nargs="*", default=[0])
 ap.add_argument("--reps", type=int, default=2)
 ap.add_argument("--loss", default="frobenius")
+ap.add_argument("--tol", type=float, default=0.0, help="> 0: the stop rule is live (a residual pass every 10 iterations)")
 ap.add_argument("--dtype", default="float32")
 ap.add_argument("--rowmajor", action="store_true", help="X as [B, T, m] C-contiguous (row-major) instead of channel-major")
 a = ap.parse_args()
@@ -32,7 +33,7 @@ for nt, msl in [(t, s) for t in a.threads for s in a.max_slices]:
     h.set_tuning(nt, msl, a.variant)
     for rep in range(a.reps):
         t0 = time.perf_counter()
-        r = ms.fit_batched(Xv, W0, H0, max_iter=a.iters, tol=0.0, beta_loss=a.loss)
+        r = ms.fit_batched(Xv, W0, H0, max_iter=a.iters, tol=a.tol, beta_loss=a.loss)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         its = a.batch * a.iters / (r.kernel_ms * 1e-3)
