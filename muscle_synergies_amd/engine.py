@@ -212,6 +212,7 @@ def fit_batched(X, W0, H0, *, max_iter: int = 200, tol: float = 1e-4, check_ever
 # not depend on the chunking (one workgroup per matrix; tests/test_gpu_pipeline.py compares bitwise).
 _pipeline_trace = None  # development aid (tools/probes/host_pipeline_trace.py): a list to receive (stage, chunk, t_start, t_end)
 PIPELINE_MIN_BYTES = 256 << 20   # X smaller than this: one upload, one fit
+PIPELINE_MAX_CHUNK_BYTES = 1 << 30  # ... but never more than this per chunk
 PIPELINE_CHUNK_BYTES = 192 << 20  # automatic chunk: about this much of X, a multiple of 256 matrices (whole rounds of workgroups)
 
 
@@ -224,9 +225,11 @@ def _pipeline_chunk(X, host_chunk) -> int:
     if X.nbytes < PIPELINE_MIN_BYTES or X.dtype not in (np.float32, np.float64):
         return 0
     per = max(1, X.nbytes // B)
-    c = max(1, PIPELINE_CHUNK_BYTES // per)
-    if c >= 256:
-        c = c // 256 * 256
+    # whole rounds of workgroups: at least 256 matrices per chunk (fewer leave CUs idle in the one-workgroup-per-matrix kernels,
+    # and every chunk of the row-sliced general shapes would pay its own graph build); matrices too big for that: one call
+    c = max(256, PIPELINE_CHUNK_BYTES // per // 256 * 256)
+    if c * per > PIPELINE_MAX_CHUNK_BYTES:
+        return 0
     return c if c < B else 0
 
 
