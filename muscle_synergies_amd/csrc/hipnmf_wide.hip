@@ -84,23 +84,33 @@ const WideKernel<double>* pick<double>(int m, int k, int nw) {
 }
 }  // namespace
 
-// The one-pass update + record kernel of the general shapes (nmf_big1.hpp; round 5): fp32, both losses.  HIPNMF_BIG1=0 keeps the
-// two-pass pair big_pass_w_kernel + big_records_kernel (which remains the path of float64, and of Kullback-Leibler fits with 48 /
-// 64 padded components on more than 256 channels, whose two operand layouts of H do not fit LDS beside the exchange areas).
-template <typename real>
-static const Big1Kernel<real>* pick_big1(hipnmf_handle*, int, int, bool) {
-  return nullptr;
-}
-template <>
-const Big1Kernel<float>* pick_big1<float>(hipnmf_handle* h, int KPb, int MPb, bool kl) {
+// The one-pass update + record kernel of the general shapes (nmf_big1.hpp; round 5), both losses: fp32 everywhere, float64 up to
+// 256 channels x 32 components.  HIPNMF_BIG1=0 keeps the two-pass pair big_pass_w_kernel + big_records_kernel, which remains the
+// path of the instances that do not fit LDS: float64 beyond that, Kullback-Leibler fp32 with 48 / 64 padded components on more
+// than 256 channels and float64 with 32 on more than 128.
+static bool big1_enabled() {
   static const bool on = [] {
     const char* e = getenv("HIPNMF_BIG1");
     return !(e && atoi(e) == 0);
   }();
-  if (!on) return nullptr;
-  const Big1Kernel<float>* b1 = big1_kernel_f32(KPb, MPb);
+  return on;
+}
+template <typename real>
+static const Big1Kernel<real>* big1_table(int KPb, int MPb);
+template <>
+const Big1Kernel<float>* big1_table<float>(int KPb, int MPb) {
+  return big1_kernel_f32(KPb, MPb);
+}
+template <>
+const Big1Kernel<double>* big1_table<double>(int KPb, int MPb) {
+  return big1_kernel_f64(KPb, MPb);
+}
+template <typename real>
+static const Big1Kernel<real>* pick_big1(hipnmf_handle* h, int KPb, int MPb, bool kl) {
+  if (!big1_enabled()) return nullptr;
+  const Big1Kernel<real>* b1 = big1_table<real>(KPb, MPb);
   if (!b1) return nullptr;
-  if (kl) return (b1->fn_kl && b1->smem_kl <= (size_t)h->lds_per_block) ? b1 : nullptr;  // (48 / 64 components on > 256 channels: two-pass)
+  if (kl) return (b1->fn_kl && b1->smem_kl <= (size_t)h->lds_per_block) ? b1 : nullptr;  // (instances whose two layouts of H do not fit: two-pass)
   return b1->smem <= (size_t)h->lds_per_block ? b1 : nullptr;
 }
 

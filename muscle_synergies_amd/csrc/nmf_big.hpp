@@ -63,7 +63,8 @@ struct Big1Kernel {
   size_t smem_kl;
   const char* name_kl;
 };
-const Big1Kernel<float>* big1_kernel_f32(int KP, int MP);  // nullptr: no instance covers MP channels
+const Big1Kernel<float>* big1_kernel_f32(int KP, int MP);    // nullptr: no instance covers MP channels
+const Big1Kernel<double>* big1_kernel_f64(int KP, int MP);  // (inst_big1_f64.hip: 16 / 32 padded components, up to 256 channels)
 // values per slice of the column record: sse | xsq (| the Kullback-Leibler divergence per column)
 template <typename real>
 __device__ __forceinline__ int big_ncol(const BigArgs<real>& a) { return (a.kl ? 3 : 2) * a.MP; }

@@ -69,7 +69,9 @@ def test_big_shape_sweep_fp64(m, k, T):
     for layout in ("F", "C"):
         Xl = np.asfortranarray(X) if layout == "F" else np.ascontiguousarray(X)
         res = ms.fit_batched(Xl, W0, H0, max_iter=40, tol=0.0)
-        assert _last_kernel().startswith("big_pass_w_kernel<double"), _last_kernel()
+        # float64: the one-pass kernel up to 256 channels x 32 components (round 5), the two-pass pair beyond
+        one_pass = m <= 256 and k <= 32
+        assert _last_kernel().startswith("big1_pass_kernel<double" if one_pass else "big_pass_w_kernel<double"), _last_kernel()
         np.testing.assert_allclose(res.W[0], ref["W"], rtol=1e-9, atol=1e-13)
         np.testing.assert_allclose(res.H[0], ref["H"], rtol=1e-9, atol=1e-13)
         np.testing.assert_allclose(res.reconstruction_err[0], ref["reconstruction_err"], rtol=1e-9)
@@ -234,7 +236,7 @@ def test_ragged_batch_on_the_general_shape_kernels(dtype, m, k):
         X, W0, H0 = _case(T, m, k, dtype, seed=50 + s)
         Xs.append(X), Ws.append(W0), Hs.append(H0)
     res = ms.fit_ragged(Xs, Ws, Hs, max_iter=30, tol=0.0)
-    assert _last_kernel().startswith("big1_pass_kernel<float" if dtype == np.float32 else "big_pass_w_kernel<double"), _last_kernel()
+    assert _last_kernel().startswith("big1_pass_kernel<float" if dtype == np.float32 else "big1_pass_kernel<double"), _last_kernel()
     tol = TOL if dtype == np.float32 else 1e-9
     for b, T in enumerate(Ts):
         ref = orc.nmf_mu_fit(Xs[b], Ws[b], Hs[b], max_iter=30, tol=0.0)
@@ -257,7 +259,7 @@ def test_ragged_batch_on_the_general_shape_kernels(dtype, m, k):
             except ImportError:
                 pass
             got = ms.find_synergies_batched(dfs, 3, 4, max_iter=60, tol=0.0, random_state=0)
-        assert _last_kernel().startswith("big_pass_w_kernel"), _last_kernel()
+        assert _last_kernel().startswith("big1_pass_kernel<double"), _last_kernel()
         for g in got:
             assert g.vaf_values.shape[0] == 2 and np.isfinite(g.vaf_values.to_numpy()).all()
 
@@ -281,8 +283,9 @@ def test_kullback_leibler_on_the_general_shape_kernels(dtype, m, k, T):
         res = ms.fit_batched(Xl, W0, H0, max_iter=20, tol=0.0, beta_loss="kullback-leibler")
         # fp32: the one-pass kernel's Kullback-Leibler flavour (round 5) wherever both operand layouts of H fit LDS; float64 and
         # 48 / 64 padded components on more than 256 channels: the two-pass pair
-        one_pass = dtype == np.float32 and not ((k + 15) // 16 * 16 >= 48 and m > 256)
-        assert _last_kernel().startswith("big1_pass_kernel<float" if one_pass else "big_pass_w_kernel"), _last_kernel()
+        kp = (k + 15) // 16 * 16
+        one_pass = (not (kp >= 48 and m > 256)) if dtype == np.float32 else (kp <= 32 and m <= 256 and not (kp == 32 and m > 128))
+        assert _last_kernel().startswith("big1_pass_kernel<" if one_pass else "big_pass_w_kernel"), _last_kernel()
         assert (",1>[sliced]" in _last_kernel()) == one_pass, _last_kernel()
         assert _rel(X, res.W[0], res.H[0], {"W": Wr, "H": Hr}) <= tol, layout
         err = orc.kl_divergence(X, Wr, Hr, square_root=True)

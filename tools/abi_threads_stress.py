@@ -406,6 +406,7 @@ CASES = {
     "big": fit_case(f32, 2, 3000, 300, 20, max_iter=140, expect="big1_pass_kernel<float,32,4"),
     "big_stop": fit_case(f32, 3, 1500, 144, 48, max_iter=200, tol=1e-4, expect="big1_pass_kernel<float,48,2"),
     "big_f64": fit_case(f64, 2, 1200, 130, 33, max_iter=140, expect="big_pass_w_kernel<double"),
+    "big1_f64": fit_case(f64, 2, 1200, 200, 20, max_iter=140, expect="big1_pass_kernel<double,32,2,2"),
     "big_kl": fit_case(f32, 2, 1500, 300, 20, loss=1, expect="big1_pass_kernel<float,32,4,4,true,2,1>"),
     "big_kl_two_pass": fit_case(f32, 2, 1200, 300, 40, loss=1, expect="big_pass_w_kernel<float"),
     "big_ragged": ragged_case(f32, [500, 900, 700], 300, 20),

@@ -32,12 +32,12 @@ HELPERS = {
     "colsum_kernel": "shard residual: column sums over the slices",
     "wide_hupdate_kernel": "[sliced] wide path: H update from the slice records",
     "wide_resid_finalize_kernel": "[sliced] wide path: error, stop rule, outputs",
-    "big_hht_kernel": "general shapes, two-pass pair (float64 / Kullback-Leibler): H H^T per iteration",
+    "big_hht_kernel": "general shapes, two-pass pair (the instances the one-pass kernel does not cover): H H^T per iteration",
     "big_records_kernel": "general shapes, two-pass pair: the slice records (second pass over X)",
-    "big_resid_kernel": "general shapes, float64: residual of a slice",
+    "big_resid_kernel": "general shapes beyond the one-pass instances: residual of a slice",
     "big_hupdate_kernel": "general shapes: H update (+ the next H H^T as per-block partial products on the one-pass path)",
     "big_hht_part_kernel": "general shapes, one-pass path: H H^T partial products before the first iteration",
-    "big1_resid_kernel": "general shapes, fp32: residual of a slice on the one-pass decomposition",
+    "big1_resid_kernel": "general shapes: residual of a slice on the one-pass decomposition",
     "big_resid_finalize_kernel": "general shapes: error, stop rule, outputs",
     "big_pack_sums_kernel": "shard pass on general shapes: records packed for the all-reduce",
     "big_colsum_kernel": "shard residual on general shapes: column sums over the slices",

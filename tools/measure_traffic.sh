@@ -7,6 +7,6 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 out=$R/gpurun_out/traffic
 rm -rf $out && mkdir -p $out
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline "$@" > $out/fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/write -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline "$@" > $out/write.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-host-resident --no-parity "$@" > $out/fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/write -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-host-resident --no-parity "$@" > $out/write.log 2>&1
 python3 $R/tools/traffic_from_pmc.py $out "$@"
