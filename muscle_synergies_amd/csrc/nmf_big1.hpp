@@ -213,6 +213,17 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     }
     __syncthreads();
   }
+#ifdef HIPNMF_BIG1_TIMING  // development build: shader-clock time per phase of this wave, printed by workgroup (0, 0)
+  long long tphase[5] = {0, 0, 0, 0, 0}, tlast = (long long)__builtin_readcyclecounter();
+#define BIG1_LAP(i)                                                  \
+  {                                                                  \
+    const long long now_ = (long long)__builtin_readcyclecounter();  \
+    tphase[i] += now_ - tlast;                                       \
+    tlast = now_;                                                    \
+  }
+#else
+#define BIG1_LAP(i)
+#endif
   for (int t0 = row_begin; t0 < row_end; t0 += ROWS) {
     // the W fragments of this wave's units (B operand of the denominator: lane (row j, g) <-> components 16 kbi + 4 g .. + 3):
     // requested now, needed after the first barrier
@@ -303,17 +314,27 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         }
       }
     }
+    BIG1_LAP(0)  // a: partial numerators (+ denominator)
     __syncthreads();
+    BIG1_LAP(1)  // wait at the first barrier
     // ---- c: this wave's units: sum of the partials, W' ----------------------------------------------------------------
+    // The LDS addresses of this phase are recomputed every round from an opaque copy of the lane id.  Hoisted out of the loop
+    // they were the four values hipcc spilled at the 256-register cap, and a scratch reload HERE is expensive far beyond its
+    // own latency: its destination register is reused by the first MFMA of phase e, so the compiler waits for vmcnt(0) there --
+    // with the next round's X prefetch already in flight, i.e. for HBM latency, every round (measured: phase e 10.6 k cycles on
+    // the older wave of a SIMD and 15 - 16 k on the younger one, against 5.1 k of matrix-pipe work each).
+    int lane_r = lane;
+    asm volatile("" : "+v"(lane_r));
+    const int j_r = lane_r & 15, g_r = lane_r >> 4;
 #pragma unroll
     for (int sl = 0; sl < SLOTS; ++sl) {
       if (u_s[sl] < 0) continue;
       const int v = wave + NW * sl;
       real nsum[4];
-      wide_lds_read<real, 4>(P + v * UNIT + 4 * lane, nsum);
+      wide_lds_read<real, 4>(P + v * UNIT + 4 * lane_r, nsum);
       for (int w2 = 1; w2 < nwa; ++w2) {  // (channel blocks in wave order)
         real t4[4];
-        wide_lds_read<real, 4>(P + w2 * PW + v * UNIT + 4 * lane, t4);
+        wide_lds_read<real, 4>(P + w2 * PW + v * UNIT + 4 * lane_r, t4);
 #pragma unroll
         for (int r = 0; r < 4; ++r) nsum[r] += t4[r];
       }
@@ -346,9 +367,9 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
       for (int r = 0; r < 4; ++r) wn[r] = wo[r] * qq[r];
       const rsrc_t wr = w_rsrc(t0 + 16 * u_s[sl]);
       wide_store4<real>(wr, (unsigned)j * ldw_b + (unsigned)((16 * u_kb[sl] + 4 * g) * (int)sizeof(real)), 0u, wn);
-      if (upd || LOSS == 1) wide_lds_write<real, 4>(Wst + (16 * u_s[sl] + j) * SW + 16 * u_kb[sl] + 4 * g, wn);
+      if (upd || LOSS == 1) wide_lds_write<real, 4>(Wst + (16 * u_s[sl] + j_r) * SW + 16 * u_kb[sl] + 4 * g_r, wn);
       if constexpr (LOSS == 1) {  // the next round's old rows (this round's were read before the barrier), colsum(W')
-        wide_lds_write<real, 4>(WoldSt + (16 * u_s[sl] + j) * SW + 16 * u_kb[sl] + 4 * g, wnext[sl]);
+        wide_lds_write<real, 4>(WoldSt + (16 * u_s[sl] + j_r) * SW + 16 * u_kb[sl] + 4 * g_r, wnext[sl]);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           wsum[sl][r] += wn[r];
@@ -364,7 +385,9 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
       __syncthreads();  // (the partials are rewritten by the next round)
       continue;
     }
+    BIG1_LAP(2)  // c: the owners' chain
     __syncthreads();
+    BIG1_LAP(3)  // wait at the second barrier
     // ---- e: accA += W'^T X_w (contraction over the rows), W'^T W' by the unit owners ----------------------------------
 #pragma unroll
     for (int s = 0; s < RS; ++s) {
@@ -429,7 +452,16 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
       wide_wave_lds_fence();
       __builtin_amdgcn_sched_barrier(0);  // one subtile at a time: hoisting the next one's LDS reads up here costs spills
     }
+    BIG1_LAP(4)  // e: transposition + W'^T X (+ W'^T W')
   }
+#ifdef HIPNMF_BIG1_TIMING
+  if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0)
+    printf("big1 wave %d rounds %d: a %lld  wait1 %lld  c %lld  wait2 %lld  e %lld  (cycles per round)\n", wave, (row_end - row_begin + ROWS - 1) / ROWS,
+           tphase[0] / ((row_end - row_begin + ROWS - 1) / ROWS), tphase[1] / ((row_end - row_begin + ROWS - 1) / ROWS),
+           tphase[2] / ((row_end - row_begin + ROWS - 1) / ROWS), tphase[3] / ((row_end - row_begin + ROWS - 1) / ROWS),
+           tphase[4] / ((row_end - row_begin + ROWS - 1) / ROWS));
+#endif
+#undef BIG1_LAP
   if (!upd) return;
   // ---- the slice's record.  W'^T X: every wave owns its channel block outright.  D: lane (j, g), register r <->
   // [component 16 kb + 4 g + r][channel ch_w0 + 16 q + j]

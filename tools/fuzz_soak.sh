@@ -1,6 +1,6 @@
 #!/bin/bash
-# the four randomised cross-checks against the oracle at soak sizes (gpurun -- 'bash tools/fuzz_soak.sh r04')
-tag=${1:-r04}
+# the four randomised cross-checks against the oracle at soak sizes (gpurun -- 'bash tools/fuzz_soak.sh r05')
+tag=${1:-r05}
 R=${GRAFT_REPO_ROOT:-.}
 O=$R/gpurun_out/fuzz_$tag
 mkdir -p $O
