@@ -194,9 +194,18 @@ def _record(lib: str, srcs, todo, linked: bool, verbose: bool, record_profile: b
     paths = [os.path.join(LIBDIR, "build_info.json")]
     if record_profile and os.path.isdir(os.path.join(os.path.dirname(PKG), "profiles")):
         paths.append(os.path.join(os.path.dirname(PKG), "profiles", "build_info.json"))
+    lib_record = os.path.join(LIBDIR, "build_info.json")
     for path in paths:
         try:
             old = json.load(open(path)) if os.path.exists(path) else {}
+            if "profiles" in path and not todo and not linked and os.path.exists(lib_record):
+                # --record-profile on an up-to-date library: the tracked record takes the record of the build that PRODUCED this
+                # library (kept beside it), not "reused"
+                made = json.load(open(lib_record))
+                if made.get("sha256") == sha:
+                    with open(path, "w") as f:
+                        json.dump({k: v for k, v in made.items() if k not in ("last_checked_utc", "last_check")}, f, indent=1)
+                    continue
             if not todo and not linked and old.get("sha256") == sha:
                 if "profiles" in path:
                     continue  # the tracked record keeps the build that produced this library; reuse is logged beside the .so

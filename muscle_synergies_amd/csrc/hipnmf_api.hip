@@ -165,15 +165,21 @@ CoopBudget g_coop_budget;
 struct CoopReservation {
   int device = 0, need = 0, capacity = 0;
   bool held = false;
-  void take(int dev, int n, int cap) {
+  hipStream_t stream = nullptr;  // the stream the cooperative grid is launched on
+  void take(int dev, int n, int cap, hipStream_t st) {
     g_coop_budget.acquire(dev, n, cap);
-    device = dev, need = n, capacity = cap, held = true;
+    device = dev, need = n, capacity = cap, held = true, stream = st;
   }
   void drop() {
     if (held) g_coop_budget.release(device, need, capacity);
     held = false;
   }
-  ~CoopReservation() { drop(); }
+  // An early error return between the launch and the call's own synchronisation must not hand the CUs to the next cooperative
+  // launch while this grid may still be running (round-4 advisor finding): drain the stream first, best effort.
+  ~CoopReservation() {
+    if (held && stream) (void)hipStreamSynchronize(stream);
+    drop();
+  }
 };
 
 int validate(const hipnmf_problem* p, bool shard, bool ragged = false) {
@@ -669,7 +675,7 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
     // records travel as {value bits, generation} granules: those of a previous fit must not look fresh
     HIP_TRY(hipMemsetAsync(c.part, 0, 2 * sizeof(real) * (size_t)B * 2 * coop_S * ks->NACC, st));
     void* args[] = {&c};
-    coop_cus.take(h->device, (c.coop_xcd ? 8 * coop_S : coop_S) * B, h->num_cu);
+    coop_cus.take(h->device, (c.coop_xcd ? 8 * coop_S : coop_S) * B, h->num_cu, st);
     const hipError_t e = hipLaunchCooperativeKernel(kern, dim3(c.coop_xcd ? 8 * coop_S : coop_S, B), dim3(coop_threads), args,
                                                     (unsigned)coop_smem, st);
     coop_xcd_used = c.coop_xcd != 0;

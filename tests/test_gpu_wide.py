@@ -231,12 +231,12 @@ def test_wide_17_to_32_components(dtype, m, k, T):
     if dtype == np.float64 and m > 64:
         ref = orc.nmf_mu_fit(X, W0, H0, max_iter=25, tol=0.0)
         res = ms.fit_batched(X, W0, H0, max_iter=25, tol=0.0)
-        assert _last_kernel().startswith("big_pass_w_kernel<double,32>"), _last_kernel()
+        assert _last_kernel().startswith("big1_pass_kernel<double,32,1,2"), _last_kernel()  # (round 5: the one-pass kernel in float64)
         assert _rel(X, res.W[0], res.H[0], ref) <= 1e-9
         # (round 4, later: the Kullback-Leibler loss runs there too)
         Wk, Hk, _ = orc.fit_multiplicative_update_kl(X, W0.copy(), H0.copy(), 5, 0.0)
         rk = ms.fit_batched(X, W0, H0, max_iter=5, tol=0.0, beta_loss="kullback-leibler")
-        assert _last_kernel().startswith("big_pass_w_kernel<double,32>"), _last_kernel()
+        assert _last_kernel().startswith("big1_pass_kernel<double,32,1,2,true,2,1>"), _last_kernel()
         assert _rel(X, rk.W[0], rk.H[0], {"W": Wk, "H": Hk}) <= 1e-9
         return
     ref = orc.nmf_mu_fit(X, W0, H0, max_iter=25, tol=0.0)

@@ -10,7 +10,7 @@ from muscle_synergies_amd.engine import make_problem
 from muscle_synergies_amd.preprocess import EnvelopeParams, SosfiltParams
 
 lib = _lib.load()
-assert lib.hipnmf_version() == 200
+assert lib.hipnmf_version() == 210
 h = ctypes.c_void_p()
 rc = lib.hipnmf_create(0, ctypes.byref(h))
 have_gpu = rc == 0
