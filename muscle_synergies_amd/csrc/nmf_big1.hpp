@@ -389,10 +389,19 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     __syncthreads();
     BIG1_LAP(3)  // wait at the second barrier
     // ---- e: accA += W'^T X_w (contraction over the rows), W'^T W' by the unit owners ----------------------------------
+    // Frobenius with two stages: subtile s + 1 is written into the other stage BEFORE the products of subtile s (its registers hold
+    // the data already), so its write -> read round trip runs under those MFMAs instead of in front of its own
+    constexpr bool AHEAD = LOSS == 0 && NST == 2;
+    if constexpr (AHEAD) {
+      if (active) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) wide_lds_write<real, 4>(Pw + j * SX + 16 * q + 4 * g, x[0][q]);
+      }
+    }
 #pragma unroll
     for (int s = 0; s < RS; ++s) {
       real* const xst = Pw + (s % NST) * 16 * SX;  // this wave's stage (its partials are dead; nobody else touches the region now)
-      if (active) {
+      if (active && !AHEAD) {
         if constexpr (LOSS == 1) {  // Q' = X / max(W' H, eps) with the updated rows (_nmf.py:660-663) takes X's place in the stage
           real wnB[NKB][4];
 #pragma unroll
@@ -411,6 +420,13 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         }
       }
       wide_wave_lds_fence();
+      if constexpr (AHEAD) {
+        if (active && s + 1 < RS) {
+          real* const nst = Pw + ((s + 1) % NST) * 16 * SX;  // (last read by subtile s - 1: in order behind those reads)
+#pragma unroll
+          for (int q = 0; q < NQ; ++q) wide_lds_write<real, 4>(nst + j * SX + 16 * q + 4 * g, x[s + 1][q]);
+        }
+      }
       if (active && t0 + ROWS < row_end) issue_x(s, t0 + ROWS);  // the registers are free: the next round's subtile s
       // A: lane (c, g), k-step t <-> W'[row 4 g + t][16 kb + arow(c)];  B: lane (channel j, g) <-> X[row 4 g + t][16 q + j]
       real wa[NKB][4], wb[NKB][4];
