@@ -25,6 +25,7 @@
 // 64 rows (~17 000 matrix-pipe cycles at 512 x 32).  Every sum has a fixed order (channel blocks in wave order, rounds in
 // order, units in subtile order): bitwise reproducible.  Operand conventions: nmf_wide.hpp (WideMma).
 #pragma once
+#include <type_traits>
 #include "nmf_big.hpp"
 
 namespace hipnmf {
@@ -224,252 +225,271 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 #else
 #define BIG1_LAP(i)
 #endif
-  for (int t0 = row_begin; t0 < row_end; t0 += ROWS) {
-    // the W fragments of this wave's units (B operand of the denominator: lane (row j, g) <-> components 16 kbi + 4 g .. + 3):
-    // requested now, needed after the first barrier
-    real wold[LOSS == 1 ? 1 : SLOTS][LOSS == 1 ? 1 : NKB][4];
-    real wnext[SLOTS][4];  // KL: the unit's block of the NEXT round's old rows (into LDS in phase c)
+  // The round loop exists twice -- for waves whose channel block holds data and for those beyond the matrix (they only take part in
+  // phase c and the barriers) -- so that no wave-uniform branch on `active` sits INSIDE it: such branches made the compiler keep two
+  // register copies of the accumulators around every subtile (16 v_mov_b64 each way) and a second set of X registers.  Rows past
+  // the slice need no branch either: their descriptors are empty, the prefetch moves nothing.
+  auto rounds = [&](auto act_) __attribute__((always_inline)) {
+    constexpr bool ACT = decltype(act_)::value;
+    for (int t0 = row_begin; t0 < row_end; t0 += ROWS) {
+      // the W fragments of this wave's units (B operand of the denominator: lane (row j, g) <-> components 16 kbi + 4 g .. + 3):
+      // requested now, needed after the first barrier
+      real wold[LOSS == 1 ? 1 : SLOTS][LOSS == 1 ? 1 : NKB][4];
+      real wnext[SLOTS][4];  // KL: the unit's block of the NEXT round's old rows (into LDS in phase c)
 #pragma unroll
-    for (int sl = 0; sl < SLOTS; ++sl) {
-      if constexpr (LOSS == 1) {
-        const rsrc_t wr = w_rsrc(u_s[sl] >= 0 ? t0 + ROWS + 16 * u_s[sl] : row_end);
-        buf_load<real, 4>(wr, (unsigned)j * ldw_b + (unsigned)((16 * u_kb[sl] + 4 * g) * (int)sizeof(real)), 0u, wnext[sl]);
-      } else {
-        const rsrc_t wr = w_rsrc(u_s[sl] >= 0 ? t0 + 16 * u_s[sl] : row_end);
-#pragma unroll
-        for (int kbi = 0; kbi < NKB; ++kbi) buf_load<real, 4>(wr, (unsigned)j * ldw_b + (unsigned)((16 * kbi + 4 * g) * (int)sizeof(real)), 0u, wold[sl][kbi]);
-      }
-    }
-    // ---- a: partial numerators of the round over this wave's channels, two subtiles (2 NKB chains) at a time ------------
-    if (active) {
-#pragma unroll
-      for (int s = 0; s < RS; s += 2) {
-        acc num[2][NKB];
-#pragma unroll
-        for (int e = 0; e < 2; ++e)
-#pragma unroll
-          for (int kb = 0; kb < NKB; ++kb) num[e][kb] = zero;
-        real wB[LOSS == 1 ? 2 : 1][LOSS == 1 ? NKB : 1][4];  // KL: the old rows of the two subtiles, row-major fragments
+      for (int sl = 0; sl < SLOTS; ++sl) {
         if constexpr (LOSS == 1) {
+          const rsrc_t wr = w_rsrc(u_s[sl] >= 0 ? t0 + ROWS + 16 * u_s[sl] : row_end);
+          buf_load<real, 4>(wr, (unsigned)j * ldw_b + (unsigned)((16 * u_kb[sl] + 4 * g) * (int)sizeof(real)), 0u, wnext[sl]);
+        } else {
+          const rsrc_t wr = w_rsrc(u_s[sl] >= 0 ? t0 + 16 * u_s[sl] : row_end);
+#pragma unroll
+          for (int kbi = 0; kbi < NKB; ++kbi) buf_load<real, 4>(wr, (unsigned)j * ldw_b + (unsigned)((16 * kbi + 4 * g) * (int)sizeof(real)), 0u, wold[sl][kbi]);
+        }
+      }
+      // ---- a: partial numerators of the round over this wave's channels, two subtiles (2 NKB chains) at a time ------------
+      if constexpr (ACT) {
+#pragma unroll
+        for (int s = 0; s < RS; s += 2) {
+          acc num[2][NKB];
 #pragma unroll
           for (int e = 0; e < 2; ++e)
 #pragma unroll
-            for (int kb = 0; kb < NKB; ++kb) wide_lds_read<real, 4>(WoldSt + (16 * (s + e) + j) * SW + 16 * kb + 4 * g, wB[e][kb]);
-        }
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-          real xq[2][4];  // the B operand of the numerator: X, or Q = X / max(W H, eps) (_nmf.py:574-577)
-#pragma unroll
-          for (int e = 0; e < 2; ++e) {
-            if constexpr (LOSS == 1) {
-              const acc rec = wh_block(wB[e], q);
-#pragma unroll
-              for (int r = 0; r < 4; ++r) xq[e][r] = big_quot(x[s + e][q][r], kl_floor(rec[r]));
-            } else {
-#pragma unroll
-              for (int r = 0; r < 4; ++r) xq[e][r] = x[s + e][q][r];
-            }
-          }
-          real ha[NKB][4];
-#pragma unroll
-          for (int kb = 0; kb < NKB; ++kb) {
-            if constexpr (HLL) {
-              wide_lds_read<real, 4>(sHw + (16 * kb + ar) * SX + 16 * q + 4 * g, ha[kb]);
-            } else {
-#pragma unroll
-              for (int r = 0; r < 4; ++r) ha[kb][r] = hreg[kb][q][r];
-            }
-          }
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
+            for (int kb = 0; kb < NKB; ++kb) num[e][kb] = zero;
+          real wB[LOSS == 1 ? 2 : 1][LOSS == 1 ? NKB : 1][4];  // KL: the old rows of the two subtiles, row-major fragments
+          if constexpr (LOSS == 1) {
 #pragma unroll
             for (int e = 0; e < 2; ++e)
 #pragma unroll
-              for (int kb = 0; kb < NKB; ++kb) num[e][kb] = M::mma(ha[kb][r], xq[e][r], num[e][kb]);
-        }
-        // D: lane (row j, g), register r <-> component 16 kb + 4 g + r: one 16-byte piece per lane and unit, stored at 4 * lane
-        // (consecutive lanes on consecutive pieces: [row][component] order put eight lanes of a pass on two bank groups)
-#pragma unroll
-        for (int e = 0; e < 2; ++e)
-#pragma unroll
-          for (int kb = 0; kb < NKB; ++kb) {
-            real v4[4] = {num[e][kb][0], num[e][kb][1], num[e][kb][2], num[e][kb][3]};
-            wide_lds_write<real, 4>(Pw + ((s + e) * NKB + kb) * UNIT + 4 * lane, v4);
+              for (int kb = 0; kb < NKB; ++kb) wide_lds_read<real, 4>(WoldSt + (16 * (s + e) + j) * SW + 16 * kb + 4 * g, wB[e][kb]);
           }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    // denominator^T = (H H^T) W^T of this wave's units: needs only the old rows, so it runs BEFORE the barrier (the pipe
-    // is idle there while the waves arrive; after it the owners' chain is partials -> quotient -> stores only)
-    acc denu[SLOTS];
-    if constexpr (LOSS == 0) {
 #pragma unroll
-      for (int sl = 0; sl < SLOTS; ++sl) {
-        denu[sl] = zero;
-        if (u_s[sl] >= 0) {
+          for (int q = 0; q < NQ; ++q) {
+            real xq[2][4];  // the B operand of the numerator: X, or Q = X / max(W H, eps) (_nmf.py:574-577)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+              if constexpr (LOSS == 1) {
+                const acc rec = wh_block(wB[e], q);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xq[e][r] = big_quot(x[s + e][q][r], kl_floor(rec[r]));
+              } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xq[e][r] = x[s + e][q][r];
+              }
+            }
+            real ha[NKB][4];
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) {
+              if constexpr (HLL) {
+                wide_lds_read<real, 4>(sHw + (16 * kb + ar) * SX + 16 * q + 4 * g, ha[kb]);
+              } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ha[kb][r] = hreg[kb][q][r];
+              }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+              for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int kb = 0; kb < NKB; ++kb) num[e][kb] = M::mma(ha[kb][r], xq[e][r], num[e][kb]);
+          }
+          // D: lane (row j, g), register r <-> component 16 kb + 4 g + r: one 16-byte piece per lane and unit, stored at 4 * lane
+          // (consecutive lanes on consecutive pieces: [row][component] order put eight lanes of a pass on two bank groups)
+#pragma unroll
+          for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) {
+              real v4[4] = {num[e][kb][0], num[e][kb][1], num[e][kb][2], num[e][kb][3]};
+              wide_lds_write<real, 4>(Pw + ((s + e) * NKB + kb) * UNIT + 4 * lane, v4);
+            }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      // denominator^T = (H H^T) W^T of this wave's units: needs only the old rows, so it runs BEFORE the barrier (the pipe
+      // is idle there while the waves arrive; after it the owners' chain is partials -> quotient -> stores only)
+      acc denu[SLOTS];
+      if constexpr (LOSS == 0) {
+#pragma unroll
+        for (int sl = 0; sl < SLOTS; ++sl) {
+          // NOT under `if (u_s[sl] >= 0)`: a slot without a unit loaded zeros through an empty descriptor, and a load that is
+          // consumed on one path only stays "pending" on the other in the compiler's wait-count model -- every later write to its
+          // registers then waited for vmcnt(0), i.e. for the X prefetch issued just before: one HBM latency per SUBTILE of phase e
+          // (profiles/r05_big1_phase_timing.txt: 10.3 k cycles for 5.1 k of MFMAs)
+          denu[sl] = zero;
 #pragma unroll
           for (int kbi = 0; kbi < NKB; ++kbi)
 #pragma unroll
             for (int r = 0; r < 4; ++r) denu[sl] = M::mma(hha[sl][kbi][r], wold[sl][kbi][r], denu[sl]);
         }
       }
-    }
-    BIG1_LAP(0)  // a: partial numerators (+ denominator)
-    __syncthreads();
-    BIG1_LAP(1)  // wait at the first barrier
-    // ---- c: this wave's units: sum of the partials, W' ----------------------------------------------------------------
-    // The LDS addresses of this phase are recomputed every round from an opaque copy of the lane id.  Hoisted out of the loop
-    // they were the four values hipcc spilled at the 256-register cap, and a scratch reload HERE is expensive far beyond its
-    // own latency: its destination register is reused by the first MFMA of phase e, so the compiler waits for vmcnt(0) there --
-    // with the next round's X prefetch already in flight, i.e. for HBM latency, every round (measured: phase e 10.6 k cycles on
-    // the older wave of a SIMD and 15 - 16 k on the younger one, against 5.1 k of matrix-pipe work each).
-    int lane_r = lane;
-    asm volatile("" : "+v"(lane_r));
-    const int j_r = lane_r & 15, g_r = lane_r >> 4;
+      BIG1_LAP(0)  // a: partial numerators (+ denominator)
+      __syncthreads();
+      BIG1_LAP(1)  // wait at the first barrier
+      // ---- c: this wave's units: sum of the partials, W' ----------------------------------------------------------------
+      // The LDS addresses of this phase are recomputed every round from an opaque copy of the lane id.  Hoisted out of the loop
+      // they were the four values hipcc spilled at the 256-register cap, and a scratch reload HERE is expensive far beyond its
+      // own latency: its destination register is reused by the first MFMA of phase e, so the compiler waits for vmcnt(0) there --
+      // with the next round's X prefetch already in flight, i.e. for HBM latency, every round (measured: phase e 10.6 k cycles on
+      // the older wave of a SIMD and 15 - 16 k on the younger one, against 5.1 k of matrix-pipe work each).
+      int lane_r = lane;
+      asm volatile("" : "+v"(lane_r));
+      const int j_r = lane_r & 15, g_r = lane_r >> 4;
 #pragma unroll
-    for (int sl = 0; sl < SLOTS; ++sl) {
-      if (u_s[sl] < 0) continue;
-      const int v = wave + NW * sl;
-      real nsum[4];
-      wide_lds_read<real, 4>(P + v * UNIT + 4 * lane_r, nsum);
-      for (int w2 = 1; w2 < nwa; ++w2) {  // (channel blocks in wave order)
-        real t4[4];
-        wide_lds_read<real, 4>(P + w2 * PW + v * UNIT + 4 * lane_r, t4);
+      for (int sl = 0; sl < SLOTS; ++sl) {
+        if (u_s[sl] < 0) {
+          if constexpr (LOSS == 1) {  // (the slot's loads must not stay pending on this path: see the denominator above)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) nsum[r] += t4[r];
-      }
-      acc den = zero;
-      real wo[4], dd[4], qq[4], wn[4];
-      if constexpr (LOSS == 1) {  // W *= ((X / WH) H^T) / rowsum(H)   (_nmf.py:577-581)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          den[r] = hha[sl][0][r];
-          wo[r] = wold1[sl][r];
-        }
-      } else {
-        den = denu[sl];
-#pragma unroll
-        for (int kbi = 0; kbi < NKB; ++kbi)
-          if (kbi == u_kb[sl]) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) wo[r] = wold[sl][kbi][r];
+            for (int r = 0; r < 4; ++r) asm volatile("" ::"v"(wnext[sl][r]));
           }
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        real d = den[r];
-        if (a.l1w > (real)0) d = d + a.l1w;
-        if (a.l2w > (real)0) d = d + a.l2w * wo[r];
-        dd[r] = (d == (real)0) ? eps_val<real>() : d;
-      }
-      quotients<4>(nsum, dd, qq);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) wn[r] = wo[r] * qq[r];
-      const rsrc_t wr = w_rsrc(t0 + 16 * u_s[sl]);
-      wide_store4<real>(wr, (unsigned)j * ldw_b + (unsigned)((16 * u_kb[sl] + 4 * g) * (int)sizeof(real)), 0u, wn);
-      if (upd || LOSS == 1) wide_lds_write<real, 4>(Wst + (16 * u_s[sl] + j_r) * SW + 16 * u_kb[sl] + 4 * g_r, wn);
-      if constexpr (LOSS == 1) {  // the next round's old rows (this round's were read before the barrier), colsum(W')
-        wide_lds_write<real, 4>(WoldSt + (16 * u_s[sl] + j_r) * SW + 16 * u_kb[sl] + 4 * g_r, wnext[sl]);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          wsum[sl][r] += wn[r];
-          wold1[sl][r] = wnext[sl][r];
+          continue;
         }
-      }
-    }
-    if (!upd) {  // nothing else needs X: the next round's rows may come
-      if (active && t0 + ROWS < row_end) {
+        const int v = wave + NW * sl;
+        real nsum[4];
+        wide_lds_read<real, 4>(P + v * UNIT + 4 * lane_r, nsum);
+        for (int w2 = 1; w2 < nwa; ++w2) {  // (channel blocks in wave order)
+          real t4[4];
+          wide_lds_read<real, 4>(P + w2 * PW + v * UNIT + 4 * lane_r, t4);
 #pragma unroll
-        for (int s = 0; s < RS; ++s) issue_x(s, t0 + ROWS);
-      }
-      __syncthreads();  // (the partials are rewritten by the next round)
-      continue;
-    }
-    BIG1_LAP(2)  // c: the owners' chain
-    __syncthreads();
-    BIG1_LAP(3)  // wait at the second barrier
-    // ---- e: accA += W'^T X_w (contraction over the rows), W'^T W' by the unit owners ----------------------------------
-    // Frobenius with two stages: subtile s + 1 is written into the other stage BEFORE the products of subtile s (its registers hold
-    // the data already), so its write -> read round trip runs under those MFMAs instead of in front of its own
-    constexpr bool AHEAD = LOSS == 0 && NST == 2;
-    if constexpr (AHEAD) {
-      if (active) {
+          for (int r = 0; r < 4; ++r) nsum[r] += t4[r];
+        }
+        acc den = zero;
+        real wo[4], dd[4], qq[4], wn[4];
+        if constexpr (LOSS == 1) {  // W *= ((X / WH) H^T) / rowsum(H)   (_nmf.py:577-581)
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) wide_lds_write<real, 4>(Pw + j * SX + 16 * q + 4 * g, x[0][q]);
-      }
-    }
-#pragma unroll
-    for (int s = 0; s < RS; ++s) {
-      real* const xst = Pw + (s % NST) * 16 * SX;  // this wave's stage (its partials are dead; nobody else touches the region now)
-      if (active && !AHEAD) {
-        if constexpr (LOSS == 1) {  // Q' = X / max(W' H, eps) with the updated rows (_nmf.py:660-663) takes X's place in the stage
-          real wnB[NKB][4];
-#pragma unroll
-          for (int kb = 0; kb < NKB; ++kb) wide_lds_read<real, 4>(Wst + (16 * s + j) * SW + 16 * kb + 4 * g, wnB[kb]);
-#pragma unroll
-          for (int q = 0; q < NQ; ++q) {
-            const acc rec = wh_block(wnB, q);
-            real qv[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) qv[r] = big_quot(x[s][q][r], kl_floor(rec[r]));
-            wide_lds_write<real, 4>(xst + j * SX + 16 * q + 4 * g, qv);
+          for (int r = 0; r < 4; ++r) {
+            den[r] = hha[sl][0][r];
+            wo[r] = wold1[sl][r];
           }
         } else {
+          den = denu[sl];
 #pragma unroll
-          for (int q = 0; q < NQ; ++q) wide_lds_write<real, 4>(xst + j * SX + 16 * q + 4 * g, x[s][q]);
-        }
-      }
-      wide_wave_lds_fence();
-      if constexpr (AHEAD) {
-        if (active && s + 1 < RS) {
-          real* const nst = Pw + ((s + 1) % NST) * 16 * SX;  // (last read by subtile s - 1: in order behind those reads)
+          for (int kbi = 0; kbi < NKB; ++kbi)
+            if (kbi == u_kb[sl]) {
 #pragma unroll
-          for (int q = 0; q < NQ; ++q) wide_lds_write<real, 4>(nst + j * SX + 16 * q + 4 * g, x[s + 1][q]);
-        }
-      }
-      if (active && t0 + ROWS < row_end) issue_x(s, t0 + ROWS);  // the registers are free: the next round's subtile s
-      // A: lane (c, g), k-step t <-> W'[row 4 g + t][16 kb + arow(c)];  B: lane (channel j, g) <-> X[row 4 g + t][16 q + j]
-      real wa[NKB][4], wb[NKB][4];
-#pragma unroll
-      for (int kb = 0; kb < NKB; ++kb)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          wa[kb][t] = Wst[(16 * s + 4 * g + t) * SW + 16 * kb + ar];
-          if constexpr (sizeof(real) == 8)
-            wb[kb][t] = Wst[(16 * s + 4 * g + t) * SW + 16 * kb + j];
-          else
-            wb[kb][t] = wa[kb][t];
-        }
-      if (active) {
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-          real xb[4];
-#pragma unroll
-          for (int t = 0; t < 4; ++t) xb[t] = xst[(4 * g + t) * SX + 16 * q + j];
-#pragma unroll
-          for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int kb = 0; kb < NKB; ++kb) accA[kb][q] = M::mma(wa[kb][t], xb[t], accA[kb][q]);
-        }
-      }
-      if constexpr (LOSS == 0)
-#pragma unroll
-      for (int sl = 0; sl < SLOTS; ++sl)
-        if (u_s[sl] == s) {  // (wave-uniform)
-#pragma unroll
-          for (int kbo = 0; kbo < NKB; ++kbo)
-            if (kbo == u_kb[sl]) {
-#pragma unroll
-              for (int kbi = 0; kbi < NKB; ++kbi)
-#pragma unroll
-                for (int t = 0; t < 4; ++t) accB[sl][kbi] = M::mma(wa[kbo][t], wb[kbi][t], accB[sl][kbi]);
+              for (int r = 0; r < 4; ++r) wo[r] = wold[sl][kbi][r];
             }
         }
-      wide_wave_lds_fence();
-      __builtin_amdgcn_sched_barrier(0);  // one subtile at a time: hoisting the next one's LDS reads up here costs spills
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          real d = den[r];
+          if (a.l1w > (real)0) d = d + a.l1w;
+          if (a.l2w > (real)0) d = d + a.l2w * wo[r];
+          dd[r] = (d == (real)0) ? eps_val<real>() : d;
+        }
+        quotients<4>(nsum, dd, qq);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) wn[r] = wo[r] * qq[r];
+        const rsrc_t wr = w_rsrc(t0 + 16 * u_s[sl]);
+        wide_store4<real>(wr, (unsigned)j * ldw_b + (unsigned)((16 * u_kb[sl] + 4 * g) * (int)sizeof(real)), 0u, wn);
+        if (upd || LOSS == 1) wide_lds_write<real, 4>(Wst + (16 * u_s[sl] + j_r) * SW + 16 * u_kb[sl] + 4 * g_r, wn);
+        if constexpr (LOSS == 1) {  // the next round's old rows (this round's were read before the barrier), colsum(W')
+          wide_lds_write<real, 4>(WoldSt + (16 * u_s[sl] + j_r) * SW + 16 * u_kb[sl] + 4 * g_r, wnext[sl]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            wsum[sl][r] += wn[r];
+            wold1[sl][r] = wnext[sl][r];
+          }
+        }
+      }
+      if (!upd) {  // nothing else needs X: the next round's rows may come
+        if constexpr (ACT) {
+#pragma unroll
+          for (int s = 0; s < RS; ++s) issue_x(s, t0 + ROWS);
+        }
+        __syncthreads();  // (the partials are rewritten by the next round)
+        continue;
+      }
+      BIG1_LAP(2)  // c: the owners' chain
+      __syncthreads();
+      BIG1_LAP(3)  // wait at the second barrier
+      // ---- e: accA += W'^T X_w (contraction over the rows), W'^T W' by the unit owners ----------------------------------
+      // Frobenius with two stages: subtile s + 1 is written into the other stage BEFORE the products of subtile s (its registers hold
+      // the data already), so its write -> read round trip runs under those MFMAs instead of in front of its own
+      constexpr bool AHEAD = LOSS == 0 && NST == 2;
+      if constexpr (AHEAD) {
+        if constexpr (ACT) {
+#pragma unroll
+          for (int q = 0; q < NQ; ++q) wide_lds_write<real, 4>(Pw + j * SX + 16 * q + 4 * g, x[0][q]);
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < RS; ++s) {
+        real* const xst = Pw + (s % NST) * 16 * SX;  // this wave's stage (its partials are dead; nobody else touches the region now)
+        if constexpr (ACT && !AHEAD) {
+          if constexpr (LOSS == 1) {  // Q' = X / max(W' H, eps) with the updated rows (_nmf.py:660-663) takes X's place in the stage
+            real wnB[NKB][4];
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) wide_lds_read<real, 4>(Wst + (16 * s + j) * SW + 16 * kb + 4 * g, wnB[kb]);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+              const acc rec = wh_block(wnB, q);
+              real qv[4];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) qv[r] = big_quot(x[s][q][r], kl_floor(rec[r]));
+              wide_lds_write<real, 4>(xst + j * SX + 16 * q + 4 * g, qv);
+            }
+          } else {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) wide_lds_write<real, 4>(xst + j * SX + 16 * q + 4 * g, x[s][q]);
+          }
+        }
+        wide_wave_lds_fence();
+        if constexpr (AHEAD) {
+          if constexpr (ACT) if (s + 1 < RS) {
+            real* const nst = Pw + ((s + 1) % NST) * 16 * SX;  // (last read by subtile s - 1: in order behind those reads)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) wide_lds_write<real, 4>(nst + j * SX + 16 * q + 4 * g, x[s + 1][q]);
+          }
+        }
+        if constexpr (ACT) issue_x(s, t0 + ROWS);  // the registers are free: the next round's subtile s
+        // A: lane (c, g), k-step t <-> W'[row 4 g + t][16 kb + arow(c)];  B: lane (channel j, g) <-> X[row 4 g + t][16 q + j]
+        real wa[NKB][4], wb[NKB][4];
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            wa[kb][t] = Wst[(16 * s + 4 * g + t) * SW + 16 * kb + ar];
+            if constexpr (sizeof(real) == 8)
+              wb[kb][t] = Wst[(16 * s + 4 * g + t) * SW + 16 * kb + j];
+            else
+              wb[kb][t] = wa[kb][t];
+          }
+        if constexpr (ACT) {
+#pragma unroll
+          for (int q = 0; q < NQ; ++q) {
+            real xb[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) xb[t] = xst[(4 * g + t) * SX + 16 * q + j];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+              for (int kb = 0; kb < NKB; ++kb) accA[kb][q] = M::mma(wa[kb][t], xb[t], accA[kb][q]);
+          }
+        }
+        if constexpr (LOSS == 0)
+#pragma unroll
+        for (int sl = 0; sl < SLOTS; ++sl)
+          if (u_s[sl] == s) {  // (wave-uniform)
+#pragma unroll
+            for (int kbo = 0; kbo < NKB; ++kbo)
+              if (kbo == u_kb[sl]) {
+#pragma unroll
+                for (int kbi = 0; kbi < NKB; ++kbi)
+#pragma unroll
+                  for (int t = 0; t < 4; ++t) accB[sl][kbi] = M::mma(wa[kbo][t], wb[kbi][t], accB[sl][kbi]);
+              }
+          }
+        wide_wave_lds_fence();
+        __builtin_amdgcn_sched_barrier(0);  // one subtile at a time: hoisting the next one's LDS reads up here costs spills
+      }
+      BIG1_LAP(4)  // e: transposition + W'^T X (+ W'^T W')
     }
-    BIG1_LAP(4)  // e: transposition + W'^T X (+ W'^T W')
-  }
+  };
+  if (active)
+    rounds(std::true_type{});
+  else
+    rounds(std::false_type{});
 #ifdef HIPNMF_BIG1_TIMING
   if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0)
     printf("big1 wave %d rounds %d: a %lld  wait1 %lld  c %lld  wait2 %lld  e %lld  (cycles per round)\n", wave, (row_end - row_begin + ROWS - 1) / ROWS,
