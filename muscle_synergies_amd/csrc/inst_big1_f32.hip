@@ -23,7 +23,7 @@ const Big1Kernel<float>* big1_kernel_f32(int KP, int MP) {
       {make_big1<16, 1, 4>("big1_pass_kernel<float,16,1,4,false,2,0>"), make_big1<16, 2, 4>("big1_pass_kernel<float,16,2,4,false,2,0>"),
        make_big1<16, 4, 4>("big1_pass_kernel<float,16,4,4,false,2,0>")},
       {make_big1<32, 1, 4>("big1_pass_kernel<float,32,1,4,false,2,0>"), make_big1<32, 2, 4>("big1_pass_kernel<float,32,2,4,false,2,0>"),
-       make_big1<32, 4, 4, true>("big1_pass_kernel<float,32,4,4,true,2,0>")},
+       make_big1<32, 4, 4, true>("big1_pass_kernel<float,32,4,4,true,2,0>")},  // (H in registers fits since the loop carries no branch: 250 VGPRs, same rate)
       {make_big1<48, 1, 4>("big1_pass_kernel<float,48,1,4,false,2,0>"), make_big1<48, 2, 4>("big1_pass_kernel<float,48,2,4,false,2,0>"),
        make_big1<48, 4, 2, true, 1>("big1_pass_kernel<float,48,4,2,true,1,0>")},
       {make_big1<64, 1, 4>("big1_pass_kernel<float,64,1,4,false,2,0>"), make_big1<64, 2, 2>("big1_pass_kernel<float,64,2,2,false,2,0>"),
