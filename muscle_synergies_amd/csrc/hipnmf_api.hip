@@ -292,9 +292,16 @@ int small_long_min_batch(const hipnmf_handle* h) {
 
 template <typename real>
 bool wide_preferred(int m, int k, const hipnmf_problem* p, const hipnmf_handle* h, bool ragged) {
-  if (m > HIPNMF_NARROW_MAX_FEATURES || p->loss != HIPNMF_LOSS_FROBENIUS || h->variant != 0) return false;
+  if (m > HIPNMF_NARROW_MAX_FEATURES || h->variant != 0) return false;
   if (!(ragged || p->batch >= h->num_cu / 2 || h->path_batch_hint >= h->num_cu / 2)) return false;
   const long long T = p->n_samples;
+  if (p->loss != HIPNMF_LOSS_FROBENIUS) {
+    // Kullback-Leibler (round 5): fit_wide4_kernel<32, 2, 4, 1, 1> keeps both reconstructions on the matrix pipe, the lane mappings
+    // keep them on the VALU.  tools/quick_bench.py --loss kullback-leibler, 4096 x (m x 2 500), M matrix-it/s lane mapping -> 4x4x1:
+    // 32 ch k = 8: 6.64 -> 9.15; 24 ch k = 6: 8.58 -> 9.59; 32 ch k = 5: 9.55 -> 9.34; 20 ch k = 4 (T = 5 000): 6.68 -> 6.38;
+    // up to 16 channels: 16 ch k = 8: 14.3 -> 14.2, k = 5 (T = 10 000): 6.3 -> 3.5
+    return sizeof(real) == 4 && m > 16 && k >= 6;
+  }
   if (m <= 16) {  // beyond the reach of fit_small_kernel (one wave per matrix: n_samples <= 256, and up to 1 024 for some shapes
                   // when the batch gives every SIMD a wave -- then that kernel is the fastest of the three: inst_small_long.hpp)
     if (T <= 256) {

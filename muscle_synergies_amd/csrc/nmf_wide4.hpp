@@ -110,11 +110,10 @@ struct Wide4Tile {
 // lane (row r, part p) gathers its row's other component quads from the three lanes "below" (DPP row rotations) and multiplies
 // by H^T read from a transposed copy in LDS (sA, idle during a pass), D: lane (r, p), register e <-> W H [r][16 cb + 4 p + e] --
 // exactly where the lane's X values sit, so Q = X / max(W H, eps) IS the numerator's B operand; Q' goes over X in the stage and
-// W'^T Q' is the Frobenius W^T X.  (Instances with 64 lanes per row only: 33..128 channels.)
+// W'^T Q' is the Frobenius W^T X (every lanes-are-channels layout: 16 / 32 / 64 lanes per row; round 5: 17..32 channels too).
 template <int MP, int KQ, int NW, int NSET, int LOSS = 0>
 __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 8))) fit_wide4_kernel(WideArgs<float> a) {
   using C = Wide4Cfg<MP, KQ>;
-  static_assert(LOSS == 0 || C::LP == 64, "the Kullback-Leibler flavour exists for the 64-lanes-per-row instances");
   using Tile = Wide4Tile<MP, KQ>;
   constexpr int KP = C::KP, NH = C::NH, NCB = C::NCB, SX = C::SX, SW = C::SW, SH = C::SH, NLD = C::NLD, RPL = C::RPL,
                 CPR = C::CPR, NT = NW * 64, LP = C::LP, NG = C::NG, CB = C::CB;
@@ -280,6 +279,44 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
   w4f4 accA[NH][KQ], accB[KQ][KQ];
   const w4f4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
 
+  // W'^T X (KL: W'^T Q') of the subtile in the stage, with the new rows of W in `wst`; leaves the A operand in `wa`
+  float wa[KQ];  // lane 4 blk + i <-> W'[row of blk][4 cg + i]
+  auto accumulate_wtx = [&]() __attribute__((always_inline)) {
+    // block blk stands for row blk (64 channel lanes: one row per instruction, broadcast from block s) or, with LP < 64 lanes
+    // per row, for row NG (blk mod LP / 4) + blk / (LP / 4): NG rows per instruction, lanes [G LP, G LP + LP) row NG s + G,
+    // CBSZ broadcasts block s of each group to the group's LP / 4 blocks
+    const int wrow = NG * (blk % (LP / 4)) + blk / (LP / 4);
+#pragma unroll
+    for (int cg = 0; cg < KQ; ++cg) wa[cg] = wst[wrow * SW + 4 * cg + ii];
+    // W^T X: lanes are channels, the row's W broadcast from block s
+    // (all sixteen rows are requested before the first product: left to itself the compiler reads two, waits, multiplies, reads
+    //  the next two ... and every wait exposes a full LDS round trip)
+    const float* xcol = xs + lane;
+    if constexpr (LP < 64) {
+      float xc[16 / NG];
+#pragma unroll
+      for (int s = 0; s < 16 / NG; ++s) xc[s] = xs[(NG * s + lane / LP) * SX + lane % LP];
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<16 / NG>([&](auto S_) {
+        constexpr int s = decltype(S_)::value;
+#pragma unroll
+        for (int cg = 0; cg < KQ; ++cg) accA[0][cg] = w4_mfma<CB, s>(wa[cg], xc[s], accA[0][cg]);
+      });
+    } else
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      float xc[16];
+#pragma unroll
+      for (int s = 0; s < 16; ++s) xc[s] = xcol[s * SX + 64 * h];
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<16>([&](auto S_) {
+        constexpr int s = decltype(S_)::value;
+#pragma unroll
+        for (int cg = 0; cg < KQ; ++cg) accA[h][cg] = w4_mfma<4, s>(wa[cg], xc[s], accA[h][cg]);
+      });
+    }
+  };
+
   // ---- one subtile: W update (_nmf.py:540-554, 615-631) and the sums of W^T X / W^T W (:638-640) ------------------
   auto update_subtile = [&](Tile& t, int i, int inext, bool upd) __attribute__((always_inline)) {
     stage_x(t);
@@ -347,22 +384,7 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
           wide_lds_write<float, 4>(xs + r * SX + 4 * p + 16 * cb, qv);
         }
         wide_wave_lds_fence();
-        float wa[KQ];  // lane 4 blk + i <-> W'[row blk][4 cg + i]  (64 lanes per row: block blk stands for row blk)
-#pragma unroll
-        for (int cg = 0; cg < KQ; ++cg) wa[cg] = wst[blk * SW + 4 * cg + ii];
-        const float* xcol = xs + lane;
-#pragma unroll
-        for (int h = 0; h < NH; ++h) {
-          float xc[16];
-#pragma unroll
-          for (int s = 0; s < 16; ++s) xc[s] = xcol[s * SX + 64 * h];
-          __builtin_amdgcn_sched_barrier(0);
-          static_for<16>([&](auto S_) {
-            constexpr int s = decltype(S_)::value;
-#pragma unroll
-            for (int cg = 0; cg < KQ; ++cg) accA[h][cg] = w4_mfma<4, s>(wa[cg], xc[s], accA[h][cg]);
-          });
-        }
+        accumulate_wtx();  // W'^T Q'
       }
       wide_wave_lds_fence();
       return;
@@ -422,40 +444,7 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
     if (upd) {
       wide_lds_write<float, KQ>(wst + r * SW + KQ * p, wn);
       wide_wave_lds_fence();
-      // block blk stands for row blk (64 channel lanes: one row per instruction, broadcast from block s) or, with LP < 64 lanes
-      // per row, for row NG (blk mod LP / 4) + blk / (LP / 4): NG rows per instruction, lanes [G LP, G LP + LP) row NG s + G,
-      // CBSZ broadcasts block s of each group to the group's LP / 4 blocks
-      const int wrow = NG * (blk % (LP / 4)) + blk / (LP / 4);
-      float wa[KQ];  // lane 4 blk + i <-> W'[row of blk][4 cg + i]
-#pragma unroll
-      for (int cg = 0; cg < KQ; ++cg) wa[cg] = wst[wrow * SW + 4 * cg + ii];
-      // W^T X: lanes are channels, the row's W broadcast from block s
-      // (all sixteen rows are requested before the first product: left to itself the compiler reads two, waits, multiplies, reads
-      //  the next two ... and every wait exposes a full LDS round trip)
-      const float* xcol = xs + lane;
-      if constexpr (LP < 64) {
-        float xc[16 / NG];
-#pragma unroll
-        for (int s = 0; s < 16 / NG; ++s) xc[s] = xs[(NG * s + lane / LP) * SX + lane % LP];
-        __builtin_amdgcn_sched_barrier(0);
-        static_for<16 / NG>([&](auto S_) {
-          constexpr int s = decltype(S_)::value;
-#pragma unroll
-          for (int cg = 0; cg < KQ; ++cg) accA[0][cg] = w4_mfma<CB, s>(wa[cg], xc[s], accA[0][cg]);
-        });
-      } else
-#pragma unroll
-      for (int h = 0; h < NH; ++h) {
-        float xc[16];
-#pragma unroll
-        for (int s = 0; s < 16; ++s) xc[s] = xcol[s * SX + 64 * h];
-        __builtin_amdgcn_sched_barrier(0);
-        static_for<16>([&](auto S_) {
-          constexpr int s = decltype(S_)::value;
-#pragma unroll
-          for (int cg = 0; cg < KQ; ++cg) accA[h][cg] = w4_mfma<4, s>(wa[cg], xc[s], accA[h][cg]);
-        });
-      }
+      accumulate_wtx();
 #pragma unroll
       for (int cg = 0; cg < KQ; ++cg)
 #pragma unroll
@@ -530,7 +519,7 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
               const float lg = fma_(xv, log_(xs_ / whc), whv - xv);
               const float term = (xv > eps_val<float>()) ? lg : whv;
               // MP = 48 / 96: the lanes past the padded width hold no channel (their sse / xsq are dropped below)
-              kl += (MP % 64 == 0 || 64 * h + lane < MP) ? term : 0.0f;
+              kl += (MP % LP == 0 || 64 * h + lane < MP) ? term : 0.0f;
             }
           }
         });

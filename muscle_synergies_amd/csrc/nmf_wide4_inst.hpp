@@ -30,7 +30,7 @@ WideKernel<float> make_wide4_kernel() {
   w.fn = fit_wide4_kernel<MP, KQ, NW, NSET>;
   w.fn_kl = nullptr;
   w.name_kl = "";
-  if constexpr (NW == 4 && Wide4Cfg<MP, KQ>::LP == 64) {  // the Kullback-Leibler flavour: 256-thread instances of 33..128 channels
+  if constexpr (NW == 4) {  // the Kullback-Leibler flavour: the 256-thread instances
     w.fn_kl = fit_wide4_kernel<MP, KQ, NW, 1, 1>;
     static char kl_name[96];
     snprintf(kl_name, sizeof(kl_name), "fit_wide4_kernel<%d,%d,%d,1,1>", MP, KQ, NW);
