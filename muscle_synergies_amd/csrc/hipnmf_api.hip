@@ -300,7 +300,12 @@ bool wide_preferred(int m, int k, const hipnmf_problem* p, const hipnmf_handle* 
     // keep them on the VALU.  tools/quick_bench.py --loss kullback-leibler, 4096 x (m x 2 500), M matrix-it/s lane mapping -> 4x4x1:
     // 32 ch k = 8: 6.64 -> 9.15; 24 ch k = 6: 8.58 -> 9.59; 32 ch k = 5: 9.55 -> 9.34; 20 ch k = 4 (T = 5 000): 6.68 -> 6.38;
     // up to 16 channels: 16 ch k = 8: 14.3 -> 14.2, k = 5 (T = 10 000): 6.3 -> 3.5
-    return sizeof(real) == 4 && m > 16 && k >= 6;
+    // float64 (fit_wide4d_kernel<.., LOSS = 1>, v_mfma_f64_4x4x4): 2048 x (m x 2 500): 32 ch k = 8: 0.71 -> 4.15; 24 ch k = 6: 1.11 -> 4.50;
+    // 16 ch k = 5: 4.84 -> 7.35; 4096 x (32 x 1 000), k = 4: 5.6 -> 13.6
+    // 16 ch k = 5: 4.84 -> 7.35; 4096 x (32 x 1 000), k = 4: 5.6 -> 13.6; 8192 x (32 x 128), k = 8: 4.3 -> 62.5; 4096 x (12 x 1 000), k = 3: 13.5 -> 24.9;
+    // up to 8 channels (one row per lane): 8 ch k = 4: 17.6 -> 10.7; 4 ch k = 2: 57 -> 27
+    if (sizeof(real) == 8) return m > 8;
+    return m > 16 && k >= 6;
   }
   if (m <= 16) {  // beyond the reach of fit_small_kernel (one wave per matrix: n_samples <= 256, and up to 1 024 for some shapes
                   // when the batch gives every SIMD a wave -- then that kernel is the fastest of the three: inst_small_long.hpp)

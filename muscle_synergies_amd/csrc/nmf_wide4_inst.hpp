@@ -75,7 +75,7 @@ template <int MP, int KQ, int NW, int NSET, int WPE>
 const char* wide4d_kernel_name() {
   static char buf[96];
   static const bool once = [] {
-    snprintf(buf, sizeof(buf), "fit_wide4d_kernel<%d,%d,%d,%d,%d>", MP, KQ, NW, NSET, WPE);
+    snprintf(buf, sizeof(buf), "fit_wide4d_kernel<%d,%d,%d,%d,%d,0>", MP, KQ, NW, NSET, WPE);  // (as rocprofv3 prints it: LOSS = 0)
     return true;
   }();
   (void)once;
@@ -89,6 +89,12 @@ WideKernel<double> make_wide4d_kernel() {
   w.fn = fit_wide4d_kernel<MP, KQ, NW, NSET, WPE>;
   w.fn_kl = nullptr;
   w.name_kl = "";
+  if constexpr (NW == 4) {  // the Kullback-Leibler flavour (round 5): the 256-thread instances
+    w.fn_kl = fit_wide4d_kernel<MP, KQ, NW, 1, WPE, 1>;
+    static char kl_name[96];
+    snprintf(kl_name, sizeof(kl_name), "fit_wide4d_kernel<%d,%d,%d,1,%d,1>", MP, KQ, NW, WPE);
+    w.name_kl = kl_name;
+  }
   w.smem = Wide4dCfg<MP, KQ>::smem_bytes(NW);
   w.MP = MP;
   w.KP = 4 * KQ;

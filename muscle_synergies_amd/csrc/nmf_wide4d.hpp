@@ -62,7 +62,12 @@ struct Wide4dTile {
 };
 
 // WPE: waves per SIMD the instance is compiled for (2 = at most 256 registers: up to 64 channels; 1 beyond)
-template <int MP, int KQ, int NW, int NSET, int WPE = 2>
+// LOSS: 0 = Frobenius, 1 = Kullback-Leibler (beta_loss = 1; _nmf.py:556-591, 642-684; round 5), as in fit_wide4_kernel: both
+// reconstructions on the pipe in the numerator's own layout.  D lane (j, b, i) = (W H)[row 4 b + j][8 u + 2 i + e] needs
+// A lane (i, b, k) = H[4 cg + k][8 u + 2 i + e] (a 16-byte read of H per quad and piece) and B lane (j, b, k) = W[row 4 b + j][4 cg + k]
+// -- the lane's own W value of the quad; the lane's X values sit exactly there, so Q = X / max(W H, eps) is the numerator's B
+// operand, Q' (with the updated rows) goes over X in the stage and W'^T Q' is the Frobenius W^T X.
+template <int MP, int KQ, int NW, int NSET, int WPE = 2, int LOSS = 0>
 __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WPE > 1 ? 8 : 1))) fit_wide4d_kernel(WideArgs<double> a) {
   using C = Wide4dCfg<MP, KQ>;
   using Tile = Wide4dTile<MP, KQ>;
@@ -161,6 +166,14 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WP
   }
   __syncthreads();
   auto compute_hht_lds = [&]() __attribute__((always_inline)) {  // call between barriers
+    if constexpr (LOSS == 1) {  // rowsum(H), the W update's denominator (_nmf.py:577-581), in sHHt[0 .. KP)
+      for (int c = tid; c < KP; c += NT) {
+        double s = 0.0;
+        for (int jj = 0; jj < MP; ++jj) s += sH[c * SH + jj];
+        sHHt[c] = s;
+      }
+      return;
+    }
     for (int idx = tid; idx < KP * KP; idx += NT) {
       const int c = idx / KP, c2 = idx % KP;
       double s = 0.0;
@@ -174,18 +187,67 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WP
   // A operands that change once per iteration: lane (i = q0, b, k = q2)
   double hA[KQ][NU][2];  // H[4 cg + q0][8 u + 2 q2 + e]
   double hhA[KQ][KQ];    // HHt[4 cg + q0][4 cg' + q2]
+  double hsum[KQ];       // KL: rowsum(H) of the lane's components 4 cg + q2
   auto load_operands = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int cg = 0; cg < KQ; ++cg) {
 #pragma unroll
       for (int u = 0; u < NU; ++u) wide_lds_read<double, 2>(sH + (4 * cg + q0) * SH + 8 * u + 2 * q2, hA[cg][u]);
+      if constexpr (LOSS == 1) {
+        hsum[cg] = sHHt[4 * cg + q2];
+      } else {
 #pragma unroll
-      for (int cg2 = 0; cg2 < KQ; ++cg2) hhA[cg][cg2] = sHHt[(4 * cg + q0) * KP + 4 * cg2 + q2];
+        for (int cg2 = 0; cg2 < KQ; ++cg2) hhA[cg][cg2] = sHHt[(4 * cg + q0) * KP + 4 * cg2 + q2];
+      }
     }
   };
   load_operands();
 
   double accA[NQ][KQ], accB[KQ][KQ];
+  double csum[KQ];  // KL: this lane's share of colsum(W') (its row, its components)
+  // KL: (W H)[row r][8 u + 2 q2 + e], e = 0, 1, from the lane's W values of the row (old or new)
+  const double* const ht_lane = sH + q2 * SH + 2 * q0;  // H[4 cg + q2][8 u + 2 q0 + e] at + 4 cg SH + 8 u
+  auto wh_piece = [&](const double (&w)[KQ], int u, double (&wh)[2]) __attribute__((always_inline)) {
+    wh[0] = wh[1] = 0.0;
+#pragma unroll
+    for (int cg = 0; cg < KQ; ++cg) {
+      double ht[2];
+      wide_lds_read<double, 2>(ht_lane + 4 * cg * SH + 8 * u, ht);
+#pragma unroll
+      for (int e = 0; e < 2; ++e) wh[e] = w4d_mfma(ht[e], w[cg], wh[e]);
+    }
+  };
+  // W'^T X (KL: W'^T Q') of the subtile in the stage with the new rows in `wst`: every LDS operand of the phase is requested
+  // before its first product (see nmf_wide.hpp, HOIST)
+  auto accumulate_wtx = [&]() __attribute__((always_inline)) {
+    double wa[4][KQ];  // lane (i, b, k): W'[row 4 t + k][4 cg + i]
+    double wb[KQ];     // lane (i, b, k): W'[row 4 b + k][4 cg + i]
+    double xc[4][NQ];  // lane (j, b, k): X[row 4 t + k][16 q + 4 b + j]
+#pragma unroll
+    for (int t4 = 0; t4 < 4; ++t4) {
+#pragma unroll
+      for (int cg = 0; cg < KQ; ++cg) wa[t4][cg] = wst[(4 * t4 + q2) * SW + 4 * cg + q0];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) xc[t4][q] = xs[(4 * t4 + q2) * SX + 16 * q + 4 * q1 + q0];
+    }
+    if constexpr (LOSS == 0) {
+#pragma unroll
+      for (int cg = 0; cg < KQ; ++cg) wb[cg] = wst[(4 * q1 + q2) * SW + 4 * cg + q0];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t4 = 0; t4 < 4; ++t4)
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int cg = 0; cg < KQ; ++cg) accA[q][cg] = w4d_mfma(wa[t4][cg], xc[t4][q], accA[q][cg]);
+    if constexpr (LOSS == 0) {
+#pragma unroll
+      for (int cg = 0; cg < KQ; ++cg)
+#pragma unroll
+        for (int cg2 = 0; cg2 < KQ; ++cg2) accB[cg][cg2] = w4d_mfma(wb[cg], wb[cg2], accB[cg][cg2]);
+    }
+  };
 
   auto update_subtile = [&](Tile& t, int i, int inext, bool upd) __attribute__((always_inline)) {
     stage_x(t);
@@ -198,6 +260,62 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WP
       for (int cg = 0; cg < KQ; ++cg) wold[cg] = t.w[cg];
     }
     if (inext >= 0) issue(t, inext);
+    if constexpr (LOSS == 1) {
+      const double* xrow = xs + r * SX + 2 * q2;
+      double num[KQ];
+#pragma unroll
+      for (int cg = 0; cg < KQ; ++cg) num[cg] = 0.0;
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        double xb[2], wh[2];
+        wide_lds_read<double, 2>(xrow + 8 * u, xb);
+        wh_piece(wold, u, wh);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const double qv = xb[e] / kl_floor(wh[e]);  // X / max(WH, EPSILON) (_nmf.py:574-575)
+#pragma unroll
+          for (int cg = 0; cg < KQ; ++cg) num[cg] = w4d_mfma(hA[cg][u][e], qv, num[cg]);
+        }
+      }
+      double wn[KQ];
+#pragma unroll
+      for (int cg = 0; cg < KQ; ++cg) {
+        double d = hsum[cg];
+        if (a.l1w > 0.0) d = d + a.l1w;
+        if (a.l2w > 0.0) d = d + a.l2w * wold[cg];
+        d = (d == 0.0) ? eps_val<double>() : d;
+        wn[cg] = wold[cg] * (num[cg] / d);
+      }
+      if (i < ncached) {
+#pragma unroll
+        for (int cg = 0; cg < KQ; ++cg) wc_lane[i * 16 * KP + 4 * cg] = wn[cg];
+      } else {
+        const rsrc_t wr = w_rsrc(i);
+#pragma unroll
+        for (int cg = 0; cg < KQ; ++cg) buf_store<double>(wr, wvoff[cg], 0u, wn[cg]);
+      }
+      if (upd) {
+#pragma unroll
+        for (int cg = 0; cg < KQ; ++cg) {
+          wst[r * SW + 4 * cg + q2] = wn[cg];
+          csum[cg] += wn[cg];
+        }
+        // Q' = X / max(W' H, eps) with the updated rows, written over X in the stage (each lane replaces exactly what it read)
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+          double xb[2], wh[2], qv[2];
+          wide_lds_read<double, 2>(xrow + 8 * u, xb);
+          wh_piece(wn, u, wh);
+#pragma unroll
+          for (int e = 0; e < 2; ++e) qv[e] = xb[e] / kl_floor(wh[e]);
+          wide_lds_write<double, 2>(xs + r * SX + 2 * q2 + 8 * u, qv);
+        }
+        wide_wave_lds_fence();
+        accumulate_wtx();  // W'^T Q'
+      }
+      wide_wave_lds_fence();
+      return;
+    }
     // numerator (two chains per quad) and denominator
     double num[KQ], num2[KQ], den[KQ];
 #pragma unroll
@@ -242,30 +360,7 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WP
 #pragma unroll
       for (int cg = 0; cg < KQ; ++cg) wst[r * SW + 4 * cg + q2] = wn[cg];
       wide_wave_lds_fence();
-      // every LDS operand of the phase is requested before its first product (see nmf_wide.hpp, HOIST)
-      double wa[4][KQ];  // lane (i, b, k): W'[row 4 t + k][4 cg + i]
-      double wb[KQ];     // lane (i, b, k): W'[row 4 b + k][4 cg + i]
-      double xc[4][NQ];  // lane (j, b, k): X[row 4 t + k][16 q + 4 b + j]
-#pragma unroll
-      for (int t4 = 0; t4 < 4; ++t4) {
-#pragma unroll
-        for (int cg = 0; cg < KQ; ++cg) wa[t4][cg] = wst[(4 * t4 + q2) * SW + 4 * cg + q0];
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) xc[t4][q] = xs[(4 * t4 + q2) * SX + 16 * q + 4 * q1 + q0];
-      }
-#pragma unroll
-      for (int cg = 0; cg < KQ; ++cg) wb[cg] = wst[(4 * q1 + q2) * SW + 4 * cg + q0];
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int t4 = 0; t4 < 4; ++t4)
-#pragma unroll
-        for (int q = 0; q < NQ; ++q)
-#pragma unroll
-          for (int cg = 0; cg < KQ; ++cg) accA[q][cg] = w4d_mfma(wa[t4][cg], xc[t4][q], accA[q][cg]);
-#pragma unroll
-      for (int cg = 0; cg < KQ; ++cg)
-#pragma unroll
-        for (int cg2 = 0; cg2 < KQ; ++cg2) accB[cg][cg2] = w4d_mfma(wb[cg], wb[cg2], accB[cg][cg2]);
+      accumulate_wtx();
     }
     wide_wave_lds_fence();  // the next subtile's stage writes stay behind this one's reads
   };
@@ -273,6 +368,7 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WP
   // ---- ||X - W H||_F^2 per column and sum X^2 per column of the whole matrix -> sPart[0 .. 2 MP); barriers inside ----
   auto block_resid = [&]() __attribute__((always_inline)) {
     double sse[NQ], xsq[NQ];
+    double kl = 0.0;    // LOSS == 1: generalised KL divergence, element by element as x log(x / wh) - x + wh (_nmf.py:138-161)
     double hB[KQ][NQ];  // lane (j, b, k): H[4 cg + k][16 q + 4 b + j]
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
@@ -302,6 +398,12 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WP
           const double d = xv - rec;
           sse[q] = fma_(d, d, sse[q]);
           xsq[q] = fma_(xv, xv, xsq[q]);
+          if constexpr (LOSS == 1) {  // branch-free, as in nmf_wide.hpp (padded rows / channels: x = wh = 0 -> 0)
+            const double whc = rec < eps_val<double>() ? eps_val<double>() : rec;
+            const double xs_ = xv > eps_val<double>() ? xv : eps_val<double>();
+            const double lg = fma_(xv, log_(xs_ / whc), rec - xv);
+            kl += (xv > eps_val<double>()) ? lg : rec;
+          }
         }
       }
       wide_wave_lds_fence();
@@ -313,6 +415,11 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WP
       rec[q2 * 2 * MP + 16 * q + 4 * q1 + q0] = sse[q];
       rec[q2 * 2 * MP + MP + 16 * q + 4 * q1 + q0] = xsq[q];
     }
+    if constexpr (LOSS == 1) {
+#pragma unroll
+      for (int off = 1; off < WAVE; off <<= 1) kl += __shfl_xor(kl, off, WAVE);
+      if (lane == 0) rec[8 * MP] = kl;  // (behind the four row slots; PERWAVE >= 16 SX > 8 MP)
+    }
     __syncthreads();
     for (int idx = tid; idx < 2 * MP; idx += NT) {
       double s = 0.0;
@@ -320,9 +427,20 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WP
         for (int qq = 0; qq < 4; ++qq) s += wv0[w2 * C::PERWAVE + qq * 2 * MP + idx];
       sPart[idx] = s;
     }
+    if constexpr (LOSS == 1) {
+      if (tid == 0) {
+        double s = 0.0;
+        for (int w2 = 0; w2 < NW; ++w2) s += wv0[w2 * C::PERWAVE + 8 * MP];
+        sPart[2 * MP] = s;
+      }
+    }
     __syncthreads();
   };
   auto error_from_part = [&]() __attribute__((always_inline)) -> double {
+    if constexpr (LOSS == 1) {  // sqrt(2 KL(X || WH)) (_nmf.py:185-189)
+      const double d = sPart[2 * MP];
+      return sqrt_(2.0 * (d > 0.0 ? d : 0.0));
+    }
     double tot = 0.0;
     for (int jj = 0; jj < m; ++jj) tot += sPart[jj];
     return sqrt_(tot);
@@ -335,6 +453,15 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WP
     for (int cg = 0; cg < KQ; ++cg) {
 #pragma unroll
       for (int q = 0; q < NQ; ++q) rec[(4 * cg + q2) * MP + 16 * q + 4 * q1 + q0] = accA[q][cg];
+      if constexpr (LOSS == 1) {  // colsum(W') instead of W^T W: the lanes of one q2 hold the 16 rows of component 4 cg + q2
+        double v = csum[cg];
+        v += __shfl_xor(v, 1, WAVE);
+        v += __shfl_xor(v, 2, WAVE);
+        v += __shfl_xor(v, 4, WAVE);
+        v += __shfl_xor(v, 8, WAVE);
+        if (q0 == 0 && q1 == 0) rec[KP * MP + 4 * cg + q2] = v;
+        continue;
+      }
 #pragma unroll
       for (int cg2 = 0; cg2 < KQ; ++cg2) {
         // accB lane (j, b, i): partial over the rows of quad b of W^T W[4 cg + i][4 cg2 + j]: sum over b (lane bits 2, 3)
@@ -401,6 +528,7 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WP
       for (int q = 0; q < NQ; ++q) accA[q][cg] = 0.0;
 #pragma unroll
       for (int cg2 = 0; cg2 < KQ; ++cg2) accB[cg][cg2] = 0.0;
+      csum[cg] = 0.0;
     }
     if constexpr (NSET > 1) {
       int i = wave;  // (pairs without inner exits, a tail that requests nothing: see fit_wide_kernel)
@@ -428,7 +556,7 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WP
     if (upd) {
       write_record();
       __syncthreads();
-      for (int idx = tid; idx < C::REC; idx += NT) {
+      for (int idx = tid; idx < (LOSS == 1 ? KP * MP + KP : C::REC); idx += NT) {
         double s = wv0[idx];
         for (int w2 = 1; w2 < NW; ++w2) s += wv0[w2 * C::PERWAVE + idx];
         sA[idx] = s;  // sB follows sA
@@ -443,13 +571,22 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WP
         const int c = idx / MP, jj = idx % MP;
         nh[q] = 0.0;
         if (idx < KP * MP && c < k && jj < m) {
-          double d = sB[c * KP] * sH[jj];
-          for (int c2 = 1; c2 < k; ++c2) d = fma_(sB[c * KP + c2], sH[c2 * SH + jj], d);
+          double d;
+          if constexpr (LOSS == 1) {  // H *= (W'^T Q') / colsum(W')   (_nmf.py:663-684; colsum 0 -> 1)
+            d = sB[c];
+            if (d == 0.0) d = 1.0;
+          } else {
+            d = sB[c * KP] * sH[jj];
+            for (int c2 = 1; c2 < k; ++c2) d = fma_(sB[c * KP + c2], sH[c2 * SH + jj], d);
+          }
           const double hold = sH[c * SH + jj];
           if (a.l1h > 0.0) d = d + a.l1h;
           if (a.l2h > 0.0) d = d + a.l2h * hold;
           d = (d == 0.0) ? eps_val<double>() : d;
           nh[q] = hold * (sA[idx] / d);
+          if constexpr (LOSS == 1) {
+            if (nh[q] < 2.220446049250313e-16) nh[q] = 0.0;  // H[H < float64 eps] = 0 (_nmf.py:866-868)
+          }
         }
       }
       __syncthreads();

@@ -187,7 +187,8 @@ def test_wide_kullback_leibler(dtype, m, k, T):
         Xl = np.asfortranarray(X) if layout == "F" else np.ascontiguousarray(X)
         res = ms.fit_batched(Xl, W0, H0, max_iter=25, tol=0.0, beta_loss="kullback-leibler")
         # (round 4: fp32 with at most 8 components on 33..128 channels takes the 4x4x1 kernel's KL flavour)
-        want = "fit_wide4_kernel" if dtype == np.float32 and k <= 8 and m > 32 else "fit_wide_kernel"
+        # (round 5: float64 with at most 8 components takes the 4x4x4 kernel's)
+        want = ("fit_wide4_kernel" if dtype == np.float32 else "fit_wide4d_kernel") if k <= 8 and m > 32 else "fit_wide_kernel"
         assert _last_kernel().endswith(",1>") and _last_kernel().startswith(want + "<"), _last_kernel()
         assert _rel(X, res.W[0], res.H[0], {"W": Wr, "H": Hr}) <= tol, layout
         err = orc.kl_divergence(X, Wr, Hr, square_root=True)

@@ -364,6 +364,72 @@ print('problems', bad)
     assert r.returncode == 0 and "problems 0" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_wide4d_kullback_leibler():
+    """Round 5: fit_wide4d_kernel<MP, KQ, 4, 1, WPE, LOSS = 1> -- float64 Kullback-Leibler on v_mfma_f64_4x4x4, 1..128 channels with
+    at most 8 components (HIPNMF_FORCE_WIDE=1: the shapes of the lane mappings too): fixed iteration count in both layouts, stop
+    rule per matrix, regularisation, transform and trials of unequal length against the oracle (_nmf.py:556-591, 642-684)."""
+    code = f"""
+import sys, numpy as np
+sys.path.insert(0, {ROOT!r})
+sys.path.insert(0, {os.path.join(ROOT, "tests")!r})
+import muscle_synergies_amd as ms
+from muscle_synergies_amd import _lib
+from muscle_synergies_amd.synth import emg_matrix, random_init
+from oracle import nmf_mu_oracle as orc
+bad = 0
+KL = dict(beta_loss='kullback-leibler')
+def relwh(X, W, H, Wr, Hr):
+    return np.linalg.norm(W @ H - Wr @ Hr) / np.linalg.norm(X)
+for m in (3, 16, 17, 32, 33, 48, 64, 65, 96, 100, 128):
+    for k in (1, 4, 5, 8):
+        if k > m: continue
+        for T in (1, 16, 33, 700, 1603):
+            X = emg_matrix(m * 10 + k, T=T, m=m, k_true=min(5, m), dtype=np.float64); W0, H0 = random_init(X, k, m + k)
+            for layout in ('F', 'C'):
+                Xl = np.asfortranarray(X) if layout == 'F' else np.ascontiguousarray(X)
+                r = ms.fit_batched(np.stack([Xl, Xl]), np.stack([W0, W0]), np.stack([H0, H0]), max_iter=25, tol=0.0, **KL)
+                name = _lib.get_handle(0).last_kernel()
+                MP = 16 if m <= 16 else 32 if m <= 32 else 48 if m <= 48 else 64 if m <= 64 else 96 if m <= 96 else 128
+                assert name.startswith('fit_wide4d_kernel<%d,' % MP) and name.endswith(',1>'), name
+                Wr, Hr, _ = orc.fit_multiplicative_update_kl(X, W0.copy(), H0.copy(), 25, 0.0)
+                d = relwh(X, r.W[1], r.H[1], Wr, Hr)
+                ref_err = np.sqrt(2 * max(orc.kl_divergence(X, Wr, Hr), 0.0))
+                e = abs(float(r.reconstruction_err[1]) ** 2 - ref_err ** 2) / 2 / float(X.sum())
+                if not (d <= 1e-11 and e <= 1e-12 and int(r.n_iter[0]) == 25 and np.array_equal(r.W[0], r.W[1]) and (r.W[0] >= 0).all() and (r.H[0] >= 0).all()):
+                    print('MISMATCH', m, k, T, layout, d, e); bad += 1
+for m, k in ((64, 8), (100, 5), (32, 8), (12, 6)):
+    Xu = [emg_matrix(90 + s + m, T=600, m=m, k_true=min(6, m), dtype=np.float64) for s in range(4)]
+    iu = [random_init(x, k, s) for s, x in enumerate(Xu)]
+    res = ms.fit_batched(np.stack(Xu), np.stack([w for w, _ in iu]), np.stack([h for _, h in iu]), max_iter=200, tol=2e-3, **KL)
+    assert _lib.get_handle(0).last_kernel().startswith('fit_wide4d_kernel<')
+    for b in range(4):
+        Wr, Hr, n_it = orc.fit_multiplicative_update_kl(Xu[b], iu[b][0].copy(), iu[b][1].copy(), 200, 2e-3)
+        if int(res.n_iter[b]) != n_it or relwh(Xu[b], res.W[b], res.H[b], Wr, Hr) > 1e-10:
+            print('STOP RULE', m, k, b, int(res.n_iter[b]), n_it); bad += 1
+    regs = dict(l1_reg_W=0.02, l1_reg_H=0.03, l2_reg_W=0.05, l2_reg_H=0.01)
+    Wr, Hr, _ = orc.fit_multiplicative_update_kl(Xu[0], iu[0][0].copy(), iu[0][1].copy(), 30, 0.0, *regs.values())
+    r = ms.fit_batched(Xu[0], iu[0][0], iu[0][1], max_iter=30, tol=0.0, **KL, **regs)
+    if relwh(Xu[0], r.W[0], r.H[0], Wr, Hr) > 1e-11:
+        print('REG', m, k); bad += 1
+    Wt = np.full_like(iu[0][0], np.sqrt(Xu[0].mean() / k))
+    Wt_ref, _, _ = orc.fit_multiplicative_update_kl(Xu[0], Wt.copy(), Hr.copy(), 20, 0.0, update_H=False)
+    rt = ms.fit_batched(Xu[0], Wt, Hr, max_iter=20, tol=0.0, update_H=False, **KL)
+    if not (np.array_equal(rt.H[0], Hr) and np.allclose(rt.W[0], Wt_ref, rtol=1e-9, atol=1e-13)):
+        print('TRANSFORM', m, k); bad += 1
+    Xs = [emg_matrix(80 + s, T=500 + 37 * s, m=m, k_true=min(6, m), dtype=np.float64) for s in range(5)]
+    ir = [random_init(x, k, s) for s, x in enumerate(Xs)]
+    rr = ms.fit_ragged(Xs, [w for w, _ in ir], [h for _, h in ir], max_iter=25, tol=0.0, **KL)
+    assert _lib.get_handle(0).last_kernel().startswith('fit_wide4d_kernel<'), _lib.get_handle(0).last_kernel()
+    for b in range(5):
+        Wr, Hr, _ = orc.fit_multiplicative_update_kl(Xs[b], ir[b][0].copy(), ir[b][1].copy(), 25, 0.0)
+        if relwh(Xs[b], rr.W[b].cpu().numpy(), rr.H[b].cpu().numpy(), Wr, Hr) > 1e-11:
+            print('RAGGED', m, k, b); bad += 1
+print('problems', bad)
+"""
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, HIPNMF_FORCE_WIDE="1"), capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0 and "problems 0" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 @pytest.mark.parametrize("dtype,m,k,T,B,kernel", [
     (np.float64, 16, 5, 600, 640, "fit_wide4d_kernel<16,2"),    # short float64 matrices, up to 16 channels
     (np.float64, 8, 4, 900, 640, "fit_wide4d_kernel<16,1"),
