@@ -293,6 +293,10 @@ int small_long_min_batch(const hipnmf_handle* h) {
 template <typename real>
 bool wide_preferred(int m, int k, const hipnmf_problem* p, const hipnmf_handle* h, bool ragged) {
   if (m > HIPNMF_NARROW_MAX_FEATURES || h->variant != 0) return false;
+  // float64 Kullback-Leibler beyond 8 channels: whatever the batch (the lane mappings have no multi-workgroup form for this loss,
+  // and one workgroup of the 4x4x4 kernel beats one of theirs: 1 x (32 x 2 500), k = 8: 49 -> 15 ms per 200 iterations; 16 x (24 x 1 000),
+  // k = 6: 0.20 -> 0.50 M matrix-it/s; 1 x (16 x 10 000), k = 5: 32.2 -> 29.6 ms; float32: 16 x (24 x 2 500), k = 6: 0.55 -> 0.41, so not there)
+  if (p->loss != HIPNMF_LOSS_FROBENIUS && sizeof(real) == 8 && m > 8) return true;
   if (!(ragged || p->batch >= h->num_cu / 2 || h->path_batch_hint >= h->num_cu / 2)) return false;
   const long long T = p->n_samples;
   if (p->loss != HIPNMF_LOSS_FROBENIUS) {

@@ -34,6 +34,8 @@ for case in range(a.cases):
     if wide and m > 128 and T > 2049:
         T = 2049
     B = int(rng.choice([1, 1, 2, 3, 7]))
+    if T <= 200 and rng.random() < 0.2:
+        B = 130  # half the CUs or more: the routes chosen for batches (wide_preferred: 4x4 kernels for shapes of the lane mappings)
     variant = int(rng.choice([0, 0, 1, 2, 3, 4, 5, 5, 6]))  # 4 / 5: the VALU / matrix-pipe instance of path 1, 6: one wave per matrix
     order = rng.choice(["C", "F"])
     loss = "kullback-leibler" if rng.random() < 0.2 else "frobenius"
