@@ -483,6 +483,15 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
   if (h->variant == 3 && coop_S == 0)
     return fail(HIPNMF_ERR_UNSUPPORTED, "cooperative path not applicable (batch=%d, n_samples=%lld)", B, T);
   const bool coop = coop_S > 0;
+  // float64 beyond 8 channels and the choice above is one workgroup per matrix (a batch below half the CUs that neither the
+  // cooperative nor the one-wave form serves): a workgroup of the 4x4x4 kernel beats one of the (G = 4) lane mappings.
+  // tools/quick_bench.py --dtype float64, ms per 200 iterations (tools/probes/f64_small_batch_ab.sh): 100 x (32 x 600), k = 8: 9.4 -> 1.8;
+  // 32 x (32 x 3 000), k = 8: 27.8 -> 3.3 ([sliced]); 100 x (32 x 10 000), k = 8: 119.5 -> 17.3; 100 x (24 x 3 000), k = 6: 10.0 -> 6.6;
+  // 32 x (32 x 3 000), k = 3: 5.7 -> 3.1, 100 of them: 5.9 -> 6.4; 60 x (12 x 300), k = 4: 1.0 -> 0.4; 100 x (16 x 600), k = 5: 1.6 -> 1.4.
+  // Up to 16 channels only short matrices: 100 x (16 x 3 000), k = 5: 3.7 -> 4.8; 100 x (12 x 10 000), k = 4: 7.8 -> 12.6
+  if (sizeof(real) == 8 && m > 8 && (m > 16 || T <= 1000) && persistent && !coop && !use_small && !kl && !ragged && h->variant == 0 &&
+      force_wide != -1)
+    return hipnmf_fit_wide<real>(h, p, X, W, H, err_out, n_iter_out, sse_col_out, xsq_col_out, ragged);
 
   // fp32, 9..16 channels, any k <= 8, Frobenius, one workgroup per matrix: fit_rowlane_kernel (nmf_rowlane.hpp).
   // It streams the same row-major X as the (G=1, CH=16) instance, whose KernelSet supplies the layout handling

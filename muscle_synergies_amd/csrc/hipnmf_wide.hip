@@ -285,7 +285,8 @@ int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
     if (w4s && w4s->NW == 4 && w4s->smem <= (size_t)h->lds_per_block) wk = w4s;
   }
   // one workgroup per matrix, at most 8 components: the 4x4x1 / 4x4x4 formulation (HIPNMF_WIDE4=0: the 16x16x4 one); the
-  // Kullback-Leibler loss on its 256-thread fp32 instances of 33..128 channels (round 4), Frobenius on all of them
+  // Kullback-Leibler loss on its 256-thread instances (fp32 33..128 channels: round 4; fp32 up to 32 channels and float64: round 5),
+  // Frobenius on all of them
   if (!sliced) {
     static const bool use4 = [] {
       const char* e = getenv("HIPNMF_WIDE4");
