@@ -489,8 +489,13 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
   // 32 x (32 x 3 000), k = 8: 27.8 -> 3.3 ([sliced]); 100 x (32 x 10 000), k = 8: 119.5 -> 17.3; 100 x (24 x 3 000), k = 6: 10.0 -> 6.6;
   // 32 x (32 x 3 000), k = 3: 5.7 -> 3.1, 100 of them: 5.9 -> 6.4; 60 x (12 x 300), k = 4: 1.0 -> 0.4; 100 x (16 x 600), k = 5: 1.6 -> 1.4.
   // Up to 16 channels only short matrices: 100 x (16 x 3 000), k = 5: 3.7 -> 4.8; 100 x (12 x 10 000), k = 4: 7.8 -> 12.6
-  if (sizeof(real) == 8 && m > 8 && (m > 16 || T <= 1000) && persistent && !coop && !use_small && !kl && !ragged && h->variant == 0 &&
-      force_wide != -1)
+  // ... and with 7 or 8 components on 17..32 channels the cooperative form of those mappings loses to the row-sliced 16x16x4 kernel too
+  // (1 x (32 x 2 500), k = 8: 5.1 -> 2.4 ms per 200 iterations; 16 of them: 7.0 -> 2.8; k <= 6: 24 x 6, 1 x 10 000 rows: 4.1 -> 3.9; 32 x 4: 3.2 -> 4.1)
+  // whatever form was chosen, up to 50 000 rows (ms per 100 iterations: 1 x (32 x 10 000), k = 8: 3.4 -> 1.9; 2 x (24 x 30 000), k = 7: 4.3 -> 2.6;
+  // 40 x (32 x 5 000), k = 8: 5.4 -> 2.6; 1 x (24 x 100 000), k = 7: 3.1 -> 3.5; 10^6 rows: 14.8 -> 17.1)
+  const bool f64_heavy = sizeof(real) == 8 && m > 16 && k >= 7 && T <= 50000 && h->variant == 0 && !kl && !ragged && !use_small;
+  if (sizeof(real) == 8 && m > 8 && (f64_heavy || ((m > 16 || T <= 1000) && persistent && !coop)) && !use_small && !kl && !ragged &&
+      h->variant == 0 && force_wide != -1)
     return hipnmf_fit_wide<real>(h, p, X, W, H, err_out, n_iter_out, sse_col_out, xsq_col_out, ragged);
 
   // fp32, 9..16 channels, any k <= 8, Frobenius, one workgroup per matrix: fit_rowlane_kernel (nmf_rowlane.hpp).
