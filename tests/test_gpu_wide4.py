@@ -578,3 +578,40 @@ def test_wide4_kullback_leibler_batch_stop_rule_regularisation_transform_ragged(
         xn = np.linalg.norm(Xs[b].astype(np.float64))
         W, H = rr.W[b].cpu().numpy(), rr.H[b].cpu().numpy()
         assert np.linalg.norm(W.astype(np.float64) @ H - Wr.astype(np.float64) @ Hr) / xn <= 3e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,k,T,B,loss,kernel", [
+    (24, 6, 700, 5, "frobenius", "fit_wide4d_kernel<32,2"),        # one workgroup per matrix either way: the 4x4x4 kernel's (round 5)
+    (12, 4, 600, 3, "frobenius", "fit_wide4d_kernel<16,1"),
+    (32, 8, 3000, 2, "frobenius", "fit_wide_kernel<double,32,16"),  # 7 / 8 components on 17..32 channels: never the lane mappings up to 50 000 rows
+    (20, 7, 9000, 1, "frobenius", "fit_wide_kernel<double,32,16"),
+    (16, 5, 3000, 3, "frobenius", "fit_coop_kernel<double"),        # up to 16 channels the cooperative form stays
+    (8, 4, 900, 3, "frobenius", "fit_"),                             # up to 8 channels: the lane mappings (whichever form)
+    (24, 6, 700, 5, "kullback-leibler", "fit_wide4d_kernel<32,2"),  # Kullback-Leibler beyond 8 channels: at every batch size
+    (12, 3, 2500, 1, "kullback-leibler", "fit_wide4d_kernel<16,1"),
+    (8, 4, 900, 3, "kullback-leibler", "fit_persistent_kernel<double"),
+])
+def test_float64_small_batches_routing_and_parity(m, k, T, B, loss, kernel):
+    """Round 5: float64 calls of the reference's own size (a handful of matrices) leave the (G = 4) lane mappings where the
+    4x4x4 / 16x16x4 kernels measured faster (hipnmf_api.hip, fit_batched_impl; tools/probes/f64_small_batch_ab.sh): the route taken
+    and parity with the oracle through it."""
+    import muscle_synergies_amd as ms
+    from muscle_synergies_amd import _lib
+
+    Xs = [emg_matrix(31 * m + b, T=T, m=m, k_true=min(5, m), dtype=np.float64) for b in range(B)]
+    inits = [random_init(x, k, b) for b, x in enumerate(Xs)]
+    res = ms.fit_batched(np.stack(Xs), np.stack([w for w, _ in inits]), np.stack([h for _, h in inits]), max_iter=40, tol=0.0, beta_loss=loss)
+    name = _lib.get_handle(0).last_kernel()
+    assert name.startswith(kernel), name
+    if m <= 8 and loss == "frobenius":
+        assert not name.startswith("fit_wide"), name
+    for b in range(B):
+        if loss == "frobenius":
+            ref = orc.nmf_mu_fit(Xs[b], inits[b][0], inits[b][1], max_iter=40, tol=0.0)
+            Wr, Hr = ref["W"], ref["H"]
+        else:
+            Wr, Hr, _ = orc.fit_multiplicative_update_kl(Xs[b], inits[b][0].copy(), inits[b][1].copy(), 40, 0.0)
+        d = np.linalg.norm(res.W[b] @ res.H[b] - Wr @ Hr) / np.linalg.norm(Xs[b])
+        assert d <= 1e-10, (b, d)
+        np.testing.assert_allclose(res.H[b], Hr, rtol=1e-7, atol=1e-12)
