@@ -309,7 +309,9 @@ bool wide_preferred(int m, int k, const hipnmf_problem* p, const hipnmf_handle* 
     // 16 ch k = 5: 4.84 -> 7.35; 4096 x (32 x 1 000), k = 4: 5.6 -> 13.6; 8192 x (32 x 128), k = 8: 4.3 -> 62.5; 4096 x (12 x 1 000), k = 3: 13.5 -> 24.9;
     // up to 8 channels (one row per lane): 8 ch k = 4: 17.6 -> 10.7; 4 ch k = 2: 57 -> 27
     if (sizeof(real) == 8) return m > 8;
-    return m > 16 && k >= 6;
+    // short matrices, any k (tools/probes/kl32_short_ab.sh): 8192 x (32 x 300), k = 5: 32.2 -> 68.6; k = 4: 40.9 -> 94.6; 8192 x (20 x 300), k = 3: 48.4 -> 104.7;
+    // 4096 x (32 x 1 000), k = 5: 18.2 -> 21.1; 20 ch k = 3: 26.9 -> 33.7; 2 500 rows, k = 5: 9.4 -> 8.6
+    return m > 16 && (k >= 6 || T <= 1500);
   }
   if (m <= 16) {  // beyond the reach of fit_small_kernel (one wave per matrix: n_samples <= 256, and up to 1 024 for some shapes
                   // when the batch gives every SIMD a wave -- then that kernel is the fastest of the three: inst_small_long.hpp)
