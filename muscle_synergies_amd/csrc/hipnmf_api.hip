@@ -496,8 +496,14 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
   // whatever form was chosen, up to 50 000 rows (ms per 100 iterations: 1 x (32 x 10 000), k = 8: 3.4 -> 1.9; 2 x (24 x 30 000), k = 7: 4.3 -> 2.6;
   // 40 x (32 x 5 000), k = 8: 5.4 -> 2.6; 1 x (24 x 100 000), k = 7: 3.1 -> 3.5; 10^6 rows: 14.8 -> 17.1)
   const bool f64_heavy = sizeof(real) == 8 && m > 16 && k >= 7 && T <= 50000 && h->variant == 0 && !kl && !ragged && !use_small;
-  if (sizeof(real) == 8 && m > 8 && (f64_heavy || ((m > 16 || T <= 1000) && persistent && !coop)) && !use_small && !kl && !ragged &&
-      h->variant == 0 && force_wide != -1)
+  bool to_wide = sizeof(real) == 8 && m > 8 && (f64_heavy || ((m > 16 || T <= 1000) && persistent && !coop));
+  // float32, 17..32 channels (the (G = 4, CH = 8) mappings), same finding at a smaller scale (tools/probes/f32_small_batch_ab.sh, ms per 200
+  // iterations, lane mappings -> matrix pipe): 100 x (32 x 600), k = 8: 2.5 -> 1.2, k = 4: 1.2 -> 0.8; 60 x (20 x 300), k = 3: 1.0 -> 0.5;
+  // 32 x (32 x 3 000), k = 8: 6.2 -> 2.3, k = 6 (24 ch): 4.3 -> 2.2; 100 x (32 x 10 000), k = 8: 18.5 -> 10.2; cooperative form, k = 8:
+  // 1 x 3 000 rows 2.7 -> 2.1, 8 x 10 000 rows 3.6 -> 2.6.  Not: k <= 5 beyond 1 000 rows (100 x (32 x 3 000), k = 4: 3.0 -> 4.1) and the
+  // cooperative form up to 6 components (1 x (24 x 10 000), k = 6: 2.4 -> 3.1)
+  if (sizeof(real) == 4 && m > 16) to_wide = (k >= 8 && T <= 20000) || (persistent && !coop && (k >= 6 || T <= 1000));  // (k = 7, cooperative: 2.0 -> 2.1, 2.7 -> 2.7)
+  if (to_wide && !use_small && !kl && !ragged && h->variant == 0 && force_wide != -1)
     return hipnmf_fit_wide<real>(h, p, X, W, H, err_out, n_iter_out, sse_col_out, xsq_col_out, ragged);
 
   // fp32, 9..16 channels, any k <= 8, Frobenius, one workgroup per matrix: fit_rowlane_kernel (nmf_rowlane.hpp).

@@ -615,3 +615,26 @@ def test_float64_small_batches_routing_and_parity(m, k, T, B, loss, kernel):
         d = np.linalg.norm(res.W[b] @ res.H[b] - Wr @ Hr) / np.linalg.norm(Xs[b])
         assert d <= 1e-10, (b, d)
         np.testing.assert_allclose(res.H[b], Hr, rtol=1e-7, atol=1e-12)
+
+
+@pytest.mark.parametrize("m,k,T,B,kernel", [
+    (32, 8, 600, 5, "fit_wide4_kernel<32,2"),         # one workgroup per matrix either way: the 4x4x1 kernel's
+    (20, 3, 300, 7, "fit_wide4_kernel<32,1"),
+    (24, 6, 3000, 20, "fit_wide_kernel<float,32,16"),  # k >= 6 on long matrices: the row-sliced 16x16x4 kernel
+    (32, 8, 9000, 1, "fit_wide_kernel<float,32,16"),   # k = 8: the cooperative lane-mapping form too
+    (32, 4, 3000, 20, "fit_persistent_kernel<float,4,8,4"),  # k <= 5 beyond 1 000 rows stays
+    (24, 6, 9000, 1, "fit_coop_kernel<float,4,8,6"),
+])
+def test_float32_17_to_32_channels_small_batches_routing_and_parity(m, k, T, B, kernel):
+    """Round 5: the same finding for float32 on 17..32 channels (tools/probes/f32_small_batch_ab.sh): route and parity."""
+    import muscle_synergies_amd as ms
+    from muscle_synergies_amd import _lib
+
+    Xs = [emg_matrix(17 * m + b, T=T, m=m, k_true=min(5, m), dtype=np.float32) for b in range(B)]
+    inits = [random_init(x, k, b) for b, x in enumerate(Xs)]
+    res = ms.fit_batched(np.stack(Xs), np.stack([w for w, _ in inits]), np.stack([h for _, h in inits]), max_iter=40, tol=0.0)
+    name = _lib.get_handle(0).last_kernel()
+    assert name.startswith(kernel), name
+    for b in range(min(B, 4)):
+        ref = orc.nmf_mu_fit(Xs[b], inits[b][0], inits[b][1], max_iter=40, tol=0.0)
+        assert _rel(Xs[b], res.W[b], res.H[b], ref) <= TOL, b
