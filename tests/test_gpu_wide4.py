@@ -620,9 +620,9 @@ def test_float64_small_batches_routing_and_parity(m, k, T, B, loss, kernel):
 @pytest.mark.parametrize("m,k,T,B,kernel", [
     (32, 8, 600, 5, "fit_wide4_kernel<32,2"),         # one workgroup per matrix either way: the 4x4x1 kernel's
     (20, 3, 300, 7, "fit_wide4_kernel<32,1"),
-    (24, 6, 3000, 20, "fit_wide_kernel<float,32,16"),  # k >= 6 on long matrices: the row-sliced 16x16x4 kernel
+    (24, 6, 3000, 40, "fit_wide_kernel<float,32,16"),  # k >= 6 on long matrices: the row-sliced 16x16x4 kernel
     (32, 8, 9000, 1, "fit_wide_kernel<float,32,16"),   # k = 8: the cooperative lane-mapping form too
-    (32, 4, 3000, 20, "fit_persistent_kernel<float,4,8,4"),  # k <= 5 beyond 1 000 rows stays
+    (32, 4, 3000, 40, "fit_persistent_kernel<float,4,8,4"),  # k <= 5 beyond 1 000 rows stays
     (24, 6, 9000, 1, "fit_coop_kernel<float,4,8,6"),
 ])
 def test_float32_17_to_32_channels_small_batches_routing_and_parity(m, k, T, B, kernel):
