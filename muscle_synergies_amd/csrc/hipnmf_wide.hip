@@ -298,9 +298,19 @@ int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
     // k <= 4 (one component quad, at the X stream's rate with 8 waves already: 11.4 M at 64 x 2 500): 8
     const WideKernel<real>* w4 = nullptr;
     if (use4) {
-      const int want = kl ? 4 : h->threads == 256 ? 4 : h->threads == 512 ? 8 : (h->threads == 768 || k > 4) ? 12 : 8;
+      // Kullback-Leibler: 4 waves, two workgroups per CU, for chip-filling batches; 8 waves where a CU gets one matrix at most.
+      // tools/probes/kl_waves_ab.sh, ms per 100 iterations, 4 -> 8 waves: 1 x (32 x 2 500), k = 8, float64: 7.5 -> 5.7; 16 x (24 x 1 000), k = 6:
+      // 3.2 -> 2.5; 4096 x (64 x 2 500), k = 8, fp32: 83.4 -> 81.9; 8192 x (32 x 300): 12.3 -> 15.7; float64 8192 x (32 x 128): 13.1 -> 15.5
+      // (HIPNMF_KL_WAVES=4 / 8 pins it)
+      static const int kl_waves_env = [] {
+        const char* e = getenv("HIPNMF_KL_WAVES");
+        return e ? atoi(e) : 0;
+      }();
+      const int kl_waves = kl_waves_env ? kl_waves_env : (B <= h->num_cu ? 8 : 4);
+      const int want = kl ? (h->threads == 256 ? 4 : kl_waves) : h->threads == 256 ? 4 : h->threads == 512 ? 8 : (h->threads == 768 || k > 4) ? 12 : 8;
       w4 = pick4<real>(m, k, want);
       if (!w4 && want == 12) w4 = pick4<real>(m, k, 8);
+      if (kl && !(w4 && w4->fn_kl && w4->smem <= (size_t)h->lds_per_block)) w4 = pick4<real>(m, k, 4);
       if (kl && !(w4 && w4->fn_kl)) w4 = nullptr;
     }
     if (w4 && w4->smem <= (size_t)h->lds_per_block) wk = w4;

@@ -30,7 +30,7 @@ WideKernel<float> make_wide4_kernel() {
   w.fn = fit_wide4_kernel<MP, KQ, NW, NSET>;
   w.fn_kl = nullptr;
   w.name_kl = "";
-  if constexpr (NW == 4) {  // the Kullback-Leibler flavour: the 256-thread instances
+  if constexpr (NW == 4 || NW == 8) {  // the Kullback-Leibler flavour: the 256- and 512-thread instances
     w.fn_kl = fit_wide4_kernel<MP, KQ, NW, 1, 1>;
     static char kl_name[96];
     snprintf(kl_name, sizeof(kl_name), "fit_wide4_kernel<%d,%d,%d,1,1>", MP, KQ, NW);
@@ -89,7 +89,7 @@ WideKernel<double> make_wide4d_kernel() {
   w.fn = fit_wide4d_kernel<MP, KQ, NW, NSET, WPE>;
   w.fn_kl = nullptr;
   w.name_kl = "";
-  if constexpr (NW == 4) {  // the Kullback-Leibler flavour (round 5): the 256-thread instances
+  if constexpr (NW == 4 || NW == 8) {  // the Kullback-Leibler flavour (round 5)
     w.fn_kl = fit_wide4d_kernel<MP, KQ, NW, 1, WPE, 1>;
     static char kl_name[96];
     snprintf(kl_name, sizeof(kl_name), "fit_wide4d_kernel<%d,%d,%d,1,%d,1>", MP, KQ, NW, WPE);

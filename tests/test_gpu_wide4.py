@@ -308,6 +308,8 @@ import muscle_synergies_amd as ms
 from muscle_synergies_amd import _lib
 from muscle_synergies_amd.synth import emg_matrix, random_init
 from oracle import nmf_mu_oracle as orc
+import os
+WAVES = os.environ['HIPNMF_KL_WAVES']
 bad = 0
 KL = dict(beta_loss='kullback-leibler')
 def relwh(X, W, H, Wr, Hr):
@@ -321,7 +323,7 @@ for m in (3, 8, 9, 16, 17, 20, 24, 32):
                 Xl = np.asfortranarray(X) if layout == 'F' else np.ascontiguousarray(X)
                 r = ms.fit_batched(np.stack([Xl, Xl]), np.stack([W0, W0]), np.stack([H0, H0]), max_iter=25, tol=0.0, **KL)
                 name = _lib.get_handle(0).last_kernel()
-                assert name.startswith('fit_wide4_kernel<16,' if m <= 16 else 'fit_wide4_kernel<32,') and name.endswith(',4,1,1>'), name
+                assert name.startswith('fit_wide4_kernel<16,' if m <= 16 else 'fit_wide4_kernel<32,') and name.endswith(',%s,1,1>' % WAVES), name
                 Wr, Hr, _ = orc.fit_multiplicative_update_kl(X, W0.copy(), H0.copy(), 25, 0.0)
                 d = relwh(X, r.W[1], r.H[1], Wr, Hr)
                 ref_err = np.sqrt(2 * max(orc.kl_divergence(X.astype(np.float64), Wr.astype(np.float64), Hr.astype(np.float64)), 0.0))
@@ -335,7 +337,7 @@ for m, k in ((32, 8), (20, 5), (12, 6)):
     Xu = [emg_matrix(90 + s + m, T=600, m=m, k_true=min(6, m), dtype=np.float32) for s in range(4)]
     iu = [random_init(x, k, s) for s, x in enumerate(Xu)]
     res = ms.fit_batched(np.stack(Xu), np.stack([w for w, _ in iu]), np.stack([h for _, h in iu]), max_iter=200, tol=2e-3, **KL)
-    assert _lib.get_handle(0).last_kernel().endswith(',4,1,1>')
+    assert _lib.get_handle(0).last_kernel().endswith(',%s,1,1>' % WAVES)
     for b in range(4):
         Wr, Hr, n_it = orc.fit_multiplicative_update_kl(Xu[b], iu[b][0].copy(), iu[b][1].copy(), 200, 2e-3)
         if int(res.n_iter[b]) != n_it or relwh(Xu[b], res.W[b], res.H[b], Wr, Hr) > 5e-5:
@@ -353,15 +355,17 @@ for m, k in ((32, 8), (20, 5), (12, 6)):
     Xs = [emg_matrix(80 + s, T=500 + 37 * s, m=m, k_true=min(6, m), dtype=np.float32) for s in range(5)]
     ir = [random_init(x, k, s) for s, x in enumerate(Xs)]
     rr = ms.fit_ragged(Xs, [w for w, _ in ir], [h for _, h in ir], max_iter=25, tol=0.0, **KL)
-    assert _lib.get_handle(0).last_kernel().endswith(',4,1,1>'), _lib.get_handle(0).last_kernel()
+    assert _lib.get_handle(0).last_kernel().endswith(',%s,1,1>' % WAVES), _lib.get_handle(0).last_kernel()
     for b in range(5):
         Wr, Hr, _ = orc.fit_multiplicative_update_kl(Xs[b], ir[b][0].copy(), ir[b][1].copy(), 25, 0.0)
         if relwh(Xs[b], rr.W[b].cpu().numpy(), rr.H[b].cpu().numpy(), Wr, Hr) > 3e-5:
             print('RAGGED', m, k, b); bad += 1
 print('problems', bad)
 """
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, HIPNMF_FORCE_WIDE="1"), capture_output=True, text=True, timeout=1500)
-    assert r.returncode == 0 and "problems 0" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    for waves in ("4", "8"):  # the 256- and the 512-thread instances (the library picks by batch size: hipnmf_wide.hip)
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, HIPNMF_FORCE_WIDE="1", HIPNMF_KL_WAVES=waves), capture_output=True,
+                           text=True, timeout=1500)
+        assert r.returncode == 0 and "problems 0" in r.stdout, waves + r.stdout[-2000:] + r.stderr[-2000:]
 
 
 def test_wide4d_kullback_leibler():
@@ -369,7 +373,7 @@ def test_wide4d_kullback_leibler():
     at most 8 components (HIPNMF_FORCE_WIDE=1: the shapes of the lane mappings too): fixed iteration count in both layouts, stop
     rule per matrix, regularisation, transform and trials of unequal length against the oracle (_nmf.py:556-591, 642-684)."""
     code = f"""
-import sys, numpy as np
+import os, sys, numpy as np
 sys.path.insert(0, {ROOT!r})
 sys.path.insert(0, {os.path.join(ROOT, "tests")!r})
 import muscle_synergies_amd as ms
@@ -390,7 +394,7 @@ for m in (3, 16, 17, 32, 33, 48, 64, 65, 96, 100, 128):
                 r = ms.fit_batched(np.stack([Xl, Xl]), np.stack([W0, W0]), np.stack([H0, H0]), max_iter=25, tol=0.0, **KL)
                 name = _lib.get_handle(0).last_kernel()
                 MP = 16 if m <= 16 else 32 if m <= 32 else 48 if m <= 48 else 64 if m <= 64 else 96 if m <= 96 else 128
-                assert name.startswith('fit_wide4d_kernel<%d,' % MP) and name.endswith(',1>'), name
+                assert name.startswith('fit_wide4d_kernel<%d,' % MP) and name.endswith(',1>') and name.split(',')[2] == (os.environ['HIPNMF_KL_WAVES'] if MP <= 64 else '4'), name
                 Wr, Hr, _ = orc.fit_multiplicative_update_kl(X, W0.copy(), H0.copy(), 25, 0.0)
                 d = relwh(X, r.W[1], r.H[1], Wr, Hr)
                 ref_err = np.sqrt(2 * max(orc.kl_divergence(X, Wr, Hr), 0.0))
@@ -426,8 +430,10 @@ for m, k in ((64, 8), (100, 5), (32, 8), (12, 6)):
             print('RAGGED', m, k, b); bad += 1
 print('problems', bad)
 """
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, HIPNMF_FORCE_WIDE="1"), capture_output=True, text=True, timeout=1500)
-    assert r.returncode == 0 and "problems 0" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    for waves in ("4", "8"):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, HIPNMF_FORCE_WIDE="1", HIPNMF_KL_WAVES=waves), capture_output=True,
+                           text=True, timeout=1500)
+        assert r.returncode == 0 and "problems 0" in r.stdout, waves + r.stdout[-2000:] + r.stderr[-2000:]
 
 
 @pytest.mark.parametrize("dtype,m,k,T,B,kernel", [
@@ -529,7 +535,7 @@ def test_wide4_kullback_leibler_shape_sweep(m, k, T):
         Xl = np.asfortranarray(X) if layout == "F" else np.ascontiguousarray(X)
         res = ms.fit_batched(Xl, W0, H0, max_iter=25, tol=0.0, beta_loss="kullback-leibler")
         name = _lib.get_handle(0).last_kernel()
-        assert name.startswith("fit_wide4_kernel<") and name.endswith(",4,1,1>"), name
+        assert name.startswith("fit_wide4_kernel<") and name.endswith(",8,1,1>"), name  # (a batch of at most one matrix per CU: 8 waves)
         xn = np.linalg.norm(X.astype(np.float64))
         d = np.linalg.norm(res.W[0].astype(np.float64) @ res.H[0] - Wr.astype(np.float64) @ Hr) / xn
         assert d <= 3e-5, (layout, d)
@@ -553,7 +559,7 @@ def test_wide4_kullback_leibler_batch_stop_rule_regularisation_transform_ragged(
     iu = [random_init(x, k, s) for s, x in enumerate(Xu)]
     res = ms.fit_batched(np.stack(Xu), np.stack([w for w, _ in iu]), np.stack([h for _, h in iu]), max_iter=200, tol=2e-3,
                          beta_loss="kullback-leibler")
-    assert _lib.get_handle(0).last_kernel().endswith(",4,1,1>")
+    assert _lib.get_handle(0).last_kernel().endswith(",8,1,1>")
     for b in range(4):
         Wr, Hr, n_it = orc.fit_multiplicative_update_kl(Xu[b], iu[b][0].copy(), iu[b][1].copy(), 200, 2e-3)
         assert int(res.n_iter[b]) == n_it
@@ -572,7 +578,7 @@ def test_wide4_kullback_leibler_batch_stop_rule_regularisation_transform_ragged(
     np.testing.assert_allclose(rt.W[0], Wt_ref, rtol=2e-3, atol=1e-6)
     # trials of unequal length
     rr = ms.fit_ragged(Xs, Ws, Hs, max_iter=25, tol=0.0, beta_loss="kullback-leibler")
-    assert _lib.get_handle(0).last_kernel().endswith(",4,1,1>")
+    assert _lib.get_handle(0).last_kernel().endswith(",8,1,1>")
     for b in range(5):
         Wr, Hr, _ = orc.fit_multiplicative_update_kl(Xs[b], Ws[b].copy(), Hs[b].copy(), 25, 0.0)
         xn = np.linalg.norm(Xs[b].astype(np.float64))

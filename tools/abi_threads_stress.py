@@ -394,9 +394,9 @@ CASES = {
     "wide_f64": fit_case(f64, 3, 900, 40, 10, variant=1, expect="fit_wide_kernel"),
     "wide_kl": fit_case(f32, 3, 900, 64, 12, loss=1, expect="fit_wide_kernel"),
     "wide4_kl": fit_case(f32, 3, 900, 64, 6, loss=1, expect="fit_wide4_kernel"),
-    "wide4_kl_32": fit_case(f32, 130, 400, 24, 7, loss=1, row_major=True, expect="fit_wide4_kernel<32,2,4,1,1>"),
-    "wide4d_kl": fit_case(f64, 3, 700, 64, 6, loss=1, expect="fit_wide4d_kernel<64,2,4,1,2,1>"),
-    "wide4d_kl_16": fit_case(f64, 130, 300, 12, 4, loss=1, row_major=True, expect="fit_wide4d_kernel<16,1,4,1,2,1>"),
+    "wide4_kl_32": fit_case(f32, 130, 400, 24, 7, loss=1, row_major=True, expect="fit_wide4_kernel<32,2,8,1,1>"),
+    "wide4d_kl": fit_case(f64, 3, 700, 64, 6, loss=1, expect="fit_wide4d_kernel<64,2,8,1,2,1>"),
+    "wide4d_kl_16": fit_case(f64, 130, 300, 12, 4, loss=1, row_major=True, expect="fit_wide4d_kernel<16,1,8,1,2,1>"),
     "wide4_a": fit_case(f32, 6, 600, 64, 8, variant=1, expect="fit_wide4_kernel"),
     "wide4_b": fit_case(f32, 3, 4000, 64, 8, variant=1, expect="fit_wide4_kernel"),
     "wide4d": fit_case(f64, 4, 1200, 64, 6, variant=1, expect="fit_wide4d_kernel"),
