@@ -281,7 +281,16 @@ int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
       const char* e4 = getenv("HIPNMF_WIDE4");
       return !(e && e[0] == '0') && !(e4 && e4[0] == '0');
     }();
-    const WideKernel<real>* w4s = (sliced4 && !kl && m > HIPNMF_NARROW_MAX_FEATURES) ? pick4<real>(m, k, 4) : nullptr;
+    // up to 32 channels (reached from fit_batched_impl's routing of small batches since round 5): float64 yes, fp32 no difference
+    // (tools/probes/sliced4_narrow_ab.sh, ms per 200 iterations, 16x16x4 -> 4x4: float64 32 x (32 x 3 000), k = 8: 3.3 -> 2.7; 1 x 10 000 rows: 4.0 -> 3.0;
+    //  2 x (24 x 30 000), k = 7: 5.3 -> 3.7; k = 3: 3.1 -> 2.0; fp32 32 x (32 x 3 000), k = 8: 2.2 -> 2.3; 100 x 10 000 rows: 10.2 -> 9.4).
+    // HIPNMF_WIDE4_SLICED_NARROW=0 / 1: never / for fp32 too
+    static const int sliced4_narrow_env = [] {
+      const char* e = getenv("HIPNMF_WIDE4_SLICED_NARROW");
+      return e ? atoi(e) : -1;
+    }();
+    const bool sliced4_narrow = sliced4_narrow_env < 0 ? sizeof(real) == 8 : sliced4_narrow_env != 0;
+    const WideKernel<real>* w4s = (sliced4 && !kl && (m > HIPNMF_NARROW_MAX_FEATURES || sliced4_narrow)) ? pick4<real>(m, k, 4) : nullptr;
     if (w4s && w4s->NW == 4 && w4s->smem <= (size_t)h->lds_per_block) wk = w4s;
   }
   // one workgroup per matrix, at most 8 components: the 4x4x1 / 4x4x4 formulation (HIPNMF_WIDE4=0: the 16x16x4 one); the
