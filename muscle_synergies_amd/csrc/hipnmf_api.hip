@@ -491,12 +491,13 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
   // 32 x (32 x 3 000), k = 8: 27.8 -> 3.3 ([sliced]); 100 x (32 x 10 000), k = 8: 119.5 -> 17.3; 100 x (24 x 3 000), k = 6: 10.0 -> 6.6;
   // 32 x (32 x 3 000), k = 3: 5.7 -> 3.1, 100 of them: 5.9 -> 6.4; 60 x (12 x 300), k = 4: 1.0 -> 0.4; 100 x (16 x 600), k = 5: 1.6 -> 1.4.
   // Up to 16 channels only short matrices: 100 x (16 x 3 000), k = 5: 3.7 -> 4.8; 100 x (12 x 10 000), k = 4: 7.8 -> 12.6
-  // ... and with 7 or 8 components on 17..32 channels the cooperative form of those mappings loses to the row-sliced 16x16x4 kernel too
-  // (1 x (32 x 2 500), k = 8: 5.1 -> 2.4 ms per 200 iterations; 16 of them: 7.0 -> 2.8; k <= 6: 24 x 6, 1 x 10 000 rows: 4.1 -> 3.9; 32 x 4: 3.2 -> 4.1)
-  // whatever form was chosen, up to 50 000 rows (ms per 100 iterations: 1 x (32 x 10 000), k = 8: 3.4 -> 1.9; 2 x (24 x 30 000), k = 7: 4.3 -> 2.6;
-  // 40 x (32 x 5 000), k = 8: 5.4 -> 2.6; 1 x (24 x 100 000), k = 7: 3.1 -> 3.5; 10^6 rows: 14.8 -> 17.1)
-  const bool f64_heavy = sizeof(real) == 8 && m > 16 && k >= 7 && T <= 50000 && h->variant == 0 && !kl && !ragged && !use_small;
-  bool to_wide = sizeof(real) == 8 && m > 8 && (f64_heavy || ((m > 16 || T <= 1000) && persistent && !coop));
+  // ... and since the row-sliced path runs on the 4x4x4 kernel for these widths too (hipnmf_wide.hip), the cooperative and row-sliced forms
+  // of the lane mappings lose as well: 17..32 channels at every k, up to 16 channels with 7 / 8 components, up to 200 000 rows
+  // (tools/probes/f64_coop_ab.sh, ms per 100 iterations, lane mappings -> matrix pipe: 1 x (32 x 10 000), k = 8: 3.4 -> 1.5; 2 x (24 x 30 000), k = 6:
+  // 3.5 -> 1.8; 40 x (32 x 5 000), k = 4: 3.2 -> 1.7; 1 x (32 x 100 000), k = 4: 2.2 -> 1.9; 2 x (16 x 30 000), k = 8: 3.1 -> 1.6; but 10^6 rows: 20 x 5
+  // 10.6 -> 13.4; up to 16 channels with k <= 6: 1 x (16 x 3 000), k = 5: 0.9 -> 1.0, 10^6 rows: 5.4 -> 12.1, 1 x (12 x 3 000), k = 4: 0.7 -> 0.9)
+  const bool f64_pipe = sizeof(real) == 8 && (m > 16 || k >= 7) && T <= 200000;
+  bool to_wide = sizeof(real) == 8 && m > 8 && (f64_pipe || (T <= 1000 && persistent && !coop));
   // float32, 17..32 channels (the (G = 4, CH = 8) mappings), same finding at a smaller scale (tools/probes/f32_small_batch_ab.sh, ms per 200
   // iterations, lane mappings -> matrix pipe): 100 x (32 x 600), k = 8: 2.5 -> 1.2, k = 4: 1.2 -> 0.8; 60 x (20 x 300), k = 3: 1.0 -> 0.5;
   // 32 x (32 x 3 000), k = 8: 6.2 -> 2.3, k = 6 (24 ch): 4.3 -> 2.2; 100 x (32 x 10 000), k = 8: 18.5 -> 10.2; cooperative form, k = 8:

@@ -592,7 +592,9 @@ def test_wide4_kullback_leibler_batch_stop_rule_regularisation_transform_ragged(
     (12, 4, 600, 3, "frobenius", "fit_wide4d_kernel<16,1"),
     (32, 8, 3000, 2, "frobenius", "fit_wide4d_kernel<32,2,4"),  # 7 / 8 components on 17..32 channels: never the lane mappings up to 50 000 rows ([sliced])
     (20, 7, 9000, 1, "frobenius", "fit_wide4d_kernel<32,2,4"),
-    (16, 5, 3000, 3, "frobenius", "fit_coop_kernel<double"),        # up to 16 channels the cooperative form stays
+    (24, 6, 9000, 1, "frobenius", "fit_wide4d_kernel<32,2,4"),     # 17..32 channels: every k, cooperative form of the lane mappings included
+    (16, 8, 9000, 2, "frobenius", "fit_wide4d_kernel<16,2,4"),     # up to 16 channels: with 7 / 8 components
+    (16, 5, 3000, 3, "frobenius", "fit_coop_kernel<double"),        # up to 16 channels and 6 components the cooperative form stays
     (8, 4, 900, 3, "frobenius", "fit_"),                             # up to 8 channels: the lane mappings (whichever form)
     (24, 6, 700, 5, "kullback-leibler", "fit_wide4d_kernel<32,2"),  # Kullback-Leibler beyond 8 channels: at every batch size
     (12, 3, 2500, 1, "kullback-leibler", "fit_wide4d_kernel<16,1"),
