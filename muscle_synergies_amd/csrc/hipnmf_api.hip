@@ -297,6 +297,15 @@ bool wide_preferred(int m, int k, const hipnmf_problem* p, const hipnmf_handle* 
   // and one workgroup of the 4x4x4 kernel beats one of theirs: 1 x (32 x 2 500), k = 8: 49 -> 15 ms per 200 iterations; 16 x (24 x 1 000),
   // k = 6: 0.20 -> 0.50 M matrix-it/s; 1 x (16 x 10 000), k = 5: 32.2 -> 29.6 ms; float32: 16 x (24 x 2 500), k = 6: 0.55 -> 0.41, so not there)
   if (p->loss != HIPNMF_LOSS_FROBENIUS && sizeof(real) == 8 && m > 8) return true;
+  // Kullback-Leibler, few long matrices: the row-sliced one-pass kernel behind hipnmf_fit_wide (kl_row_sliced_wins) -- the lane mappings'
+  // one workgroup per matrix runs at the 4x4 kernels' rate (1 x (32 x 2 500), k = 8, fp32: 7.6 vs 7.7 ms per 200 iterations)
+  if (p->loss != HIPNMF_LOSS_FROBENIUS && !ragged && kl_row_sliced_wins(sizeof(real) == 8, m, p->n_samples, p->batch, h->num_cu)) {
+    static const bool kl_sliced_env = [] {
+      const char* e = getenv("HIPNMF_KL_SLICED");
+      return !(e && e[0] == '0');
+    }();
+    if (kl_sliced_env) return true;
+  }
   if (!(ragged || p->batch >= h->num_cu / 2 || h->path_batch_hint >= h->num_cu / 2)) return false;
   const long long T = p->n_samples;
   if (p->loss != HIPNMF_LOSS_FROBENIUS) {

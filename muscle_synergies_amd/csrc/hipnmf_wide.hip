@@ -151,7 +151,22 @@ int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
     const char* e = getenv("HIPNMF_FORCE_BIG");
     return e && atoi(e) != 0;
   }();
-  const bool big = !wk || wk->smem > (size_t)h->lds_per_block || (force_big && !kl);
+  // Kullback-Leibler has no row-sliced form on the kernels of nmf_wide.hpp / nmf_wide4.hpp: a few long matrices would each sit on ONE
+  // workgroup.  The one-pass general-shape kernel is row-sliced by construction (components padded to 16, channels to 64) and fills
+  // the chip with them: chosen where its cost model wins (round 5; tools/probes/kl_long_ab.sh, ms per 100 iterations, one workgroup per
+  // matrix -> row slices: fp32 1 x (64 x 100 000), k = 8: 183.5 -> 8.0; 32 x (64 x 5 000): 9.5 -> 3.8; 64 x (32 x 2 500): 2.8 -> 3.3;
+  // float64 1 x (128 x 5 000), k = 6: 53.8 -> 4.0; 128 x (128 x 10 000): 108.5 -> 60.7; 128 x (64 x 2 500), k = 8: 10.9 -> 11.5).
+  // (cost model: kl_row_sliced_wins, hipnmf_internal.hpp; HIPNMF_KL_SLICED=0: never)
+  bool kl_sliced = false;
+  if (kl && !ragged && wk && h->variant == 0 && !force_big) {
+    static const bool kl_sliced_env = [] {
+      const char* e = getenv("HIPNMF_KL_SLICED");
+      return !(e && e[0] == '0');
+    }();
+    kl_sliced = kl_sliced_env && kl_row_sliced_wins(sizeof(real) == 8, m, T, B, h->num_cu) &&
+                pick_big1<real>(h, (int)round_up(k, 16), (int)round_up(m, 16), true) != nullptr;
+  }
+  const bool big = !wk || wk->smem > (size_t)h->lds_per_block || force_big || kl_sliced;
   if (big) {
     if (m > HIPNMF_MAX_FEATURES || k > HIPNMF_MAX_COMPONENTS)
       return fail(HIPNMF_ERR_UNSUPPORTED, "no kernel for n_features=%d (max %d) n_components=%d (max %d)", m, HIPNMF_MAX_FEATURES, k,

@@ -385,3 +385,45 @@ def test_time_sharded_kullback_leibler_fit(dtype, m, k):
         np.testing.assert_allclose(float(rn.reconstruction_err[0]), float(ref_s["reconstruction_err"]), rtol=1e-9)
         va_s, vc_s = orc.vaf(X, ref_s["W"], ref_s["H"])
         np.testing.assert_allclose(rn.vaf[0].cpu().numpy(), np.r_[va_s, vc_s], atol=1e-9)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("m,k,T,B", [(2, 1, 30000, 1), (5, 3, 20001, 2), (16, 5, 40000, 1), (24, 8, 20000, 3), (33, 8, 9000, 2), (64, 8, 12000, 1),
+                                     (100, 12, 6000, 2), (128, 6, 5000, 4)])
+def test_kullback_leibler_few_long_matrices_take_the_row_sliced_kernel(dtype, m, k, T, B):
+    """Round 5: the Kullback-Leibler loss has one workgroup per matrix on every other family; a few long matrices go to the one-pass
+    general-shape kernel, which is row-sliced by construction (kl_row_sliced_wins, hipnmf_internal.hpp) -- whatever their width.
+    Route, parity with the oracle (fixed iteration count, then the stop rule with regularisation), transform."""
+    import muscle_synergies_amd as ms
+    from muscle_synergies_amd import _lib
+
+    f32 = dtype == np.float32
+    tol = 3e-5 if f32 else 1e-10
+    Xs = [emg_matrix(13 * m + b, T=T, m=m, k_true=min(5, m), dtype=dtype) for b in range(B)]
+    inits = [random_init(x, k, b) for b, x in enumerate(Xs)]
+    W0, H0 = np.stack([w for w, _ in inits]), np.stack([h for _, h in inits])
+    res = ms.fit_batched(np.stack(Xs), W0, H0, max_iter=20, tol=0.0, beta_loss="kullback-leibler")
+    name = _lib.get_handle(0).last_kernel()
+    assert name.startswith("big1_pass_kernel<%s,16," % ("float" if f32 else "double")) and name.endswith(",1>[sliced]"), name
+    for b in range(B):
+        Wr, Hr, _ = orc.fit_multiplicative_update_kl(Xs[b], W0[b].copy(), H0[b].copy(), 20, 0.0)
+        xn = np.linalg.norm(Xs[b].astype(np.float64))
+        d = np.linalg.norm(res.W[b].astype(np.float64) @ res.H[b].astype(np.float64) - Wr.astype(np.float64) @ Hr.astype(np.float64)) / xn
+        assert d <= tol, (b, d)
+        ref_err = np.sqrt(2 * max(orc.kl_divergence(Xs[b].astype(np.float64), Wr.astype(np.float64), Hr.astype(np.float64)), 0.0))
+        assert abs(float(res.reconstruction_err[b]) - ref_err) <= (2e-3 if f32 else 1e-9) * max(ref_err, 1.0)
+    regs = dict(l1_reg_W=0.01, l1_reg_H=0.02, l2_reg_W=0.03, l2_reg_H=0.01)
+    Wr, Hr, n_it = orc.fit_multiplicative_update_kl(Xs[0], W0[0].copy(), H0[0].copy(), 100, 1e-3, *regs.values())
+    r = ms.fit_batched(Xs[0], W0[0], H0[0], max_iter=100, tol=1e-3, beta_loss="kullback-leibler", **regs)
+    assert _lib.get_handle(0).last_kernel().startswith("big1_pass_kernel<"), _lib.get_handle(0).last_kernel()
+    if not f32:
+        assert int(r.n_iter[0]) == n_it
+        assert np.linalg.norm(r.W[0] @ r.H[0] - Wr @ Hr) / np.linalg.norm(Xs[0]) <= 1e-9
+    else:
+        assert abs(int(r.n_iter[0]) - n_it) <= 10
+    Wt = np.full_like(W0[0], np.sqrt(Xs[0].mean() / k))
+    Wt_ref, _, _ = orc.fit_multiplicative_update_kl(Xs[0], Wt.copy(), Hr.copy(), 15, 0.0, update_H=False)
+    rt = ms.fit_batched(Xs[0], Wt, Hr, max_iter=15, tol=0.0, beta_loss="kullback-leibler", update_H=False)
+    np.testing.assert_array_equal(rt.H[0], Hr)
+    np.testing.assert_allclose(rt.W[0], Wt_ref, rtol=2e-3 if f32 else 1e-9, atol=1e-6 if f32 else 1e-13)

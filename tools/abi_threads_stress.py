@@ -395,6 +395,8 @@ CASES = {
     "wide_kl": fit_case(f32, 3, 900, 64, 12, loss=1, expect="fit_wide_kernel"),
     "wide4_kl": fit_case(f32, 3, 900, 64, 6, loss=1, expect="fit_wide4_kernel"),
     "wide4_kl_32": fit_case(f32, 130, 400, 24, 7, loss=1, row_major=True, expect="fit_wide4_kernel<32,2,8,1,1>"),
+    "kl_long_sliced": fit_case(f32, 2, 12000, 24, 6, loss=1, row_major=True, max_iter=20, expect="big1_pass_kernel<float,16"),
+    "kl_long_sliced_f64": fit_case(f64, 1, 9000, 12, 4, loss=1, max_iter=20, expect="big1_pass_kernel<double,16"),
     "wide4d_kl": fit_case(f64, 3, 700, 64, 6, loss=1, expect="fit_wide4d_kernel<64,2,8,1,2,1>"),
     "wide4d_kl_16": fit_case(f64, 130, 300, 12, 4, loss=1, row_major=True, expect="fit_wide4d_kernel<16,1,8,1,2,1>"),
     "wide4_a": fit_case(f32, 6, 600, 64, 8, variant=1, expect="fit_wide4_kernel"),
