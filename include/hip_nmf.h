@@ -116,7 +116,8 @@ int hipnmf_set_async(hipnmf_handle* h, int enable);
  * library also routes float64 17..32 channels with k >= 6 there): variants 0, 1 (= 4) and 2 exist -- 2 = rows sliced over
  * the chip, Frobenius loss and uniform batches only --, threads = 256 / 512 / 768 pins the instance (two workgroups per
  * CU / one with the larger W cache / three waves per SIMD, fit_wide4_kernel up to 64 channels only); 3, 5, 6 answer
- * HIPNMF_ERR_UNSUPPORTED. */
+ * HIPNMF_ERR_UNSUPPORTED.  Kullback-Leibler loss: a few long matrices (at most one per CU, where the library's cost model says so)
+ * run row-sliced on the one-pass general-shape kernel whatever their width; variant 1 or max_slices = 1 keeps one workgroup per matrix. */
 int hipnmf_set_tuning(hipnmf_handle* h, int threads, int max_slices, int variant);
 
 /* ---- batched fit: replaces NMF(solver='mu').fit_transform / .transform for B matrices ------------- */

@@ -299,7 +299,7 @@ bool wide_preferred(int m, int k, const hipnmf_problem* p, const hipnmf_handle* 
   if (p->loss != HIPNMF_LOSS_FROBENIUS && sizeof(real) == 8 && m > 8) return true;
   // Kullback-Leibler, few long matrices: the row-sliced one-pass kernel behind hipnmf_fit_wide (kl_row_sliced_wins) -- the lane mappings'
   // one workgroup per matrix runs at the 4x4 kernels' rate (1 x (32 x 2 500), k = 8, fp32: 7.6 vs 7.7 ms per 200 iterations)
-  if (p->loss != HIPNMF_LOSS_FROBENIUS && !ragged && kl_row_sliced_wins(sizeof(real) == 8, m, p->n_samples, p->batch, h->num_cu)) {
+  if (p->loss != HIPNMF_LOSS_FROBENIUS && !ragged && h->max_slices != 1 && kl_row_sliced_wins(sizeof(real) == 8, m, p->n_samples, p->batch, h->num_cu)) {
     static const bool kl_sliced_env = [] {
       const char* e = getenv("HIPNMF_KL_SLICED");
       return !(e && e[0] == '0');

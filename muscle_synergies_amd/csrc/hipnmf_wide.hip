@@ -158,7 +158,7 @@ int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
   // float64 1 x (128 x 5 000), k = 6: 53.8 -> 4.0; 128 x (128 x 10 000): 108.5 -> 60.7; 128 x (64 x 2 500), k = 8: 10.9 -> 11.5).
   // (cost model: kl_row_sliced_wins, hipnmf_internal.hpp; HIPNMF_KL_SLICED=0: never)
   bool kl_sliced = false;
-  if (kl && !ragged && wk && h->variant == 0 && !force_big) {
+  if (kl && !ragged && wk && h->variant == 0 && h->max_slices != 1 && !force_big) {  // (hipnmf_set_tuning(max_slices = 1): one workgroup per matrix)
     static const bool kl_sliced_env = [] {
       const char* e = getenv("HIPNMF_KL_SLICED");
       return !(e && e[0] == '0');

@@ -179,23 +179,26 @@ def test_wide_kullback_leibler(dtype, m, k, T):
     """beta_loss='kullback-leibler' on the wide shapes (both W H reconstructions and both products on the matrix pipe)
     against the oracle's restatement of _nmf.py:556-591, 642-684: fixed iteration count, stop rule, regularisation."""
     import muscle_synergies_amd as ms
+    from muscle_synergies_amd import _lib
 
+    h1 = _lib.Handle(0)
+    h1.set_tuning(0, 1, 0)  # one workgroup per matrix (a lone matrix of 1 000 rows would take the row-sliced one-pass kernel: test_gpu_big.py)
     X, W0, H0 = _case(T, m, k, dtype, seed=m + k)
     tol = 3e-5 if dtype == np.float32 else 1e-9
     Wr, Hr, _ = orc.fit_multiplicative_update_kl(X, W0.copy(), H0.copy(), 25, 0.0)
     for layout in ("F", "C"):
         Xl = np.asfortranarray(X) if layout == "F" else np.ascontiguousarray(X)
-        res = ms.fit_batched(Xl, W0, H0, max_iter=25, tol=0.0, beta_loss="kullback-leibler")
+        res = ms.fit_batched(Xl, W0, H0, max_iter=25, tol=0.0, beta_loss="kullback-leibler", handle=h1)
         # (round 4: fp32 with at most 8 components on 33..128 channels takes the 4x4x1 kernel's KL flavour)
         # (round 5: float64 with at most 8 components takes the 4x4x4 kernel's)
         want = ("fit_wide4_kernel" if dtype == np.float32 else "fit_wide4d_kernel") if k <= 8 and m > 32 else "fit_wide_kernel"
-        assert _last_kernel().endswith(",1>") and _last_kernel().startswith(want + "<"), _last_kernel()
+        assert h1.last_kernel().endswith(",1>") and h1.last_kernel().startswith(want + "<"), h1.last_kernel()
         assert _rel(X, res.W[0], res.H[0], {"W": Wr, "H": Hr}) <= tol, layout
         err = orc.kl_divergence(X, Wr, Hr, square_root=True)
         assert abs(float(res.reconstruction_err[0]) - err) <= (5e-3 if dtype == np.float32 else 1e-9) * max(err, 1e-30)
     Ws, Hs, n_it = orc.fit_multiplicative_update_kl(X, W0.copy(), H0.copy(), 150, 1e-3, 0.01, 0.02, 0.03, 0.01)
     res = ms.fit_batched(X, W0, H0, max_iter=150, tol=1e-3, beta_loss="kullback-leibler", l1_reg_W=0.01, l1_reg_H=0.02,
-                         l2_reg_W=0.03, l2_reg_H=0.01)
+                         l2_reg_W=0.03, l2_reg_H=0.01, handle=h1)
     if dtype == np.float64:
         assert int(res.n_iter[0]) == n_it
         assert _rel(X, res.W[0], res.H[0], {"W": Ws, "H": Hs}) <= 1e-9

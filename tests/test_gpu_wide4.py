@@ -363,7 +363,7 @@ for m, k in ((32, 8), (20, 5), (12, 6)):
 print('problems', bad)
 """
     for waves in ("4", "8"):  # the 256- and the 512-thread instances (the library picks by batch size: hipnmf_wide.hip)
-        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, HIPNMF_FORCE_WIDE="1", HIPNMF_KL_WAVES=waves), capture_output=True,
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, HIPNMF_FORCE_WIDE="1", HIPNMF_KL_WAVES=waves, HIPNMF_KL_SLICED="0"), capture_output=True,
                            text=True, timeout=1500)
         assert r.returncode == 0 and "problems 0" in r.stdout, waves + r.stdout[-2000:] + r.stderr[-2000:]
 
@@ -431,7 +431,7 @@ for m, k in ((64, 8), (100, 5), (32, 8), (12, 6)):
 print('problems', bad)
 """
     for waves in ("4", "8"):
-        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, HIPNMF_FORCE_WIDE="1", HIPNMF_KL_WAVES=waves), capture_output=True,
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, HIPNMF_FORCE_WIDE="1", HIPNMF_KL_WAVES=waves, HIPNMF_KL_SLICED="0"), capture_output=True,
                            text=True, timeout=1500)
         assert r.returncode == 0 and "problems 0" in r.stdout, waves + r.stdout[-2000:] + r.stderr[-2000:]
 
@@ -528,13 +528,15 @@ def test_wide4_kullback_leibler_shape_sweep(m, k, T):
     import muscle_synergies_amd as ms
     from muscle_synergies_amd import _lib
 
+    h1 = _lib.Handle(0)
+    h1.set_tuning(0, 1, 0)  # one workgroup per matrix (a lone 1 000-row matrix would take the row-sliced one-pass kernel: test_gpu_big.py)
     X = emg_matrix(m * 7 + k, T=T, m=m, k_true=min(6, m), dtype=np.float32)
     W0, H0 = random_init(X, k, 3)
     Wr, Hr, _ = orc.fit_multiplicative_update_kl(X, W0.copy(), H0.copy(), 25, 0.0)
     for layout in ("F", "C"):
         Xl = np.asfortranarray(X) if layout == "F" else np.ascontiguousarray(X)
-        res = ms.fit_batched(Xl, W0, H0, max_iter=25, tol=0.0, beta_loss="kullback-leibler")
-        name = _lib.get_handle(0).last_kernel()
+        res = ms.fit_batched(Xl, W0, H0, max_iter=25, tol=0.0, beta_loss="kullback-leibler", handle=h1)
+        name = h1.last_kernel()
         assert name.startswith("fit_wide4_kernel<") and name.endswith(",8,1,1>"), name  # (a batch of at most one matrix per CU: 8 waves)
         xn = np.linalg.norm(X.astype(np.float64))
         d = np.linalg.norm(res.W[0].astype(np.float64) @ res.H[0] - Wr.astype(np.float64) @ Hr) / xn
@@ -597,7 +599,8 @@ def test_wide4_kullback_leibler_batch_stop_rule_regularisation_transform_ragged(
     (16, 5, 3000, 3, "frobenius", "fit_coop_kernel<double"),        # up to 16 channels and 6 components the cooperative form stays
     (8, 4, 900, 3, "frobenius", "fit_"),                             # up to 8 channels: the lane mappings (whichever form)
     (24, 6, 700, 5, "kullback-leibler", "fit_wide4d_kernel<32,2"),  # Kullback-Leibler beyond 8 channels: at every batch size
-    (12, 3, 2500, 1, "kullback-leibler", "fit_wide4d_kernel<16,1"),
+    (12, 3, 600, 1, "kullback-leibler", "fit_wide4d_kernel<16,1"),
+    (12, 3, 2500, 1, "kullback-leibler", "big1_pass_kernel<double,16"),  # ... and row-sliced on the one-pass kernel once long enough
     (8, 4, 900, 3, "kullback-leibler", "fit_persistent_kernel<double"),
 ])
 def test_float64_small_batches_routing_and_parity(m, k, T, B, loss, kernel):

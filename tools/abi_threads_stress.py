@@ -108,7 +108,7 @@ def fit_inputs(dtype, B, T, m, k, row_major):
         return _inputs[key]
 
 
-def fit_case(dtype, B, T, m, k, *, variant=0, threads=0, row_major=False, max_iter=60, tol=0.0, loss=0, expect=None):
+def fit_case(dtype, B, T, m, k, *, variant=0, threads=0, row_major=False, max_iter=60, tol=0.0, loss=0, expect=None, max_slices=0):
     """hipnmf_fit_batched_*: returns (kernel name, [W, H, err, n_iter, sse, xsq])."""
     sfx = "f32" if dtype == np.float32 else "f64"
 
@@ -121,7 +121,7 @@ def fit_case(dtype, B, T, m, k, *, variant=0, threads=0, row_major=False, max_it
             dS, dQ = d.put(np.zeros((B, m), dtype)), d.put(np.zeros((B, m), dtype))
             p = problem(B, T, m, k, x_layout=L.X_ROW_MAJOR if row_major else L.X_CHANNEL_MAJOR, ldx=m if row_major else T,
                         xbs=T * m, max_iter=max_iter, tol=tol, loss=loss)
-            ok(lib.hipnmf_set_tuning(h, threads, 0, variant), "set_tuning")
+            ok(lib.hipnmf_set_tuning(h, threads, max_slices, variant), "set_tuning")
             ok(getattr(lib, "hipnmf_fit_batched_" + sfx)(h, ctypes.byref(p), dX, dW, dH, dE, dN, dS, dQ), "fit_batched")
             name = lib.hipnmf_last_kernel(h).decode()
             ok(lib.hipnmf_set_tuning(h, 0, 0, 0), "set_tuning")
@@ -392,12 +392,12 @@ CASES = {
     "wide_a": fit_case(f32, 6, 700, 64, 12, variant=1, expect="fit_wide_kernel"),
     "wide_b": fit_case(f32, 3, 5000, 64, 12, variant=1, expect="fit_wide_kernel"),
     "wide_f64": fit_case(f64, 3, 900, 40, 10, variant=1, expect="fit_wide_kernel"),
-    "wide_kl": fit_case(f32, 3, 900, 64, 12, loss=1, expect="fit_wide_kernel"),
-    "wide4_kl": fit_case(f32, 3, 900, 64, 6, loss=1, expect="fit_wide4_kernel"),
+    "wide_kl": fit_case(f32, 3, 900, 64, 12, loss=1, expect="fit_wide_kernel", max_slices=1),  # (max_slices = 1: one workgroup per matrix)
+    "wide4_kl": fit_case(f32, 3, 900, 64, 6, loss=1, expect="fit_wide4_kernel", max_slices=1),
     "wide4_kl_32": fit_case(f32, 130, 400, 24, 7, loss=1, row_major=True, expect="fit_wide4_kernel<32,2,8,1,1>"),
     "kl_long_sliced": fit_case(f32, 2, 12000, 24, 6, loss=1, row_major=True, max_iter=20, expect="big1_pass_kernel<float,16"),
     "kl_long_sliced_f64": fit_case(f64, 1, 9000, 12, 4, loss=1, max_iter=20, expect="big1_pass_kernel<double,16"),
-    "wide4d_kl": fit_case(f64, 3, 700, 64, 6, loss=1, expect="fit_wide4d_kernel<64,2,8,1,2,1>"),
+    "wide4d_kl": fit_case(f64, 3, 700, 64, 6, loss=1, expect="fit_wide4d_kernel<64,2,8,1,2,1>", max_slices=1),
     "wide4d_kl_16": fit_case(f64, 130, 300, 12, 4, loss=1, row_major=True, expect="fit_wide4d_kernel<16,1,8,1,2,1>"),
     "wide4_a": fit_case(f32, 6, 600, 64, 8, variant=1, expect="fit_wide4_kernel"),
     "wide4_b": fit_case(f32, 3, 4000, 64, 8, variant=1, expect="fit_wide4_kernel"),
