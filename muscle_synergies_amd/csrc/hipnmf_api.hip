@@ -297,9 +297,13 @@ bool wide_preferred(int m, int k, const hipnmf_problem* p, const hipnmf_handle* 
   // and one workgroup of the 4x4x4 kernel beats one of theirs: 1 x (32 x 2 500), k = 8: 49 -> 15 ms per 200 iterations; 16 x (24 x 1 000),
   // k = 6: 0.20 -> 0.50 M matrix-it/s; 1 x (16 x 10 000), k = 5: 32.2 -> 29.6 ms; float32: 16 x (24 x 2 500), k = 6: 0.55 -> 0.41, so not there)
   if (p->loss != HIPNMF_LOSS_FROBENIUS && sizeof(real) == 8 && m > 8) return true;
-  // Kullback-Leibler, few long matrices: the row-sliced one-pass kernel behind hipnmf_fit_wide (kl_row_sliced_wins) -- the lane mappings'
-  // one workgroup per matrix runs at the 4x4 kernels' rate (1 x (32 x 2 500), k = 8, fp32: 7.6 vs 7.7 ms per 200 iterations)
-  if (p->loss != HIPNMF_LOSS_FROBENIUS && !ragged && h->max_slices != 1 && kl_row_sliced_wins(sizeof(real) == 8, m, p->n_samples, p->batch, h->num_cu)) {
+  // Kullback-Leibler, few long matrices: the row-sliced one-pass kernel behind hipnmf_fit_wide (hipnmf_kl_row_sliced_wins).  The lane
+  // mappings' one workgroup per matrix runs at the 4x4 kernels' rate on 17..32 channels (1 x (32 x 2 500), k = 8, fp32: 7.6 vs 7.7 ms per 200
+  // iterations) and faster below (tools/probes/kl_long_narrow_ab.sh, ms per 1 000 rows and 100 iterations: fp32 up to 16 channels 0.0225 m with
+  // k <= 5, 0.035 m on fit_rowlane_kernel; float64 up to 8 channels 0.05 m)
+  const double kl_one = sizeof(real) == 4 ? (m <= 16 ? (k <= 5 ? 0.0225 : 0.035) * m : -1.0) : (m <= 8 ? 0.05 * m : -1.0);
+  if (p->loss != HIPNMF_LOSS_FROBENIUS && !ragged && h->max_slices != 1 &&
+      hipnmf_kl_row_sliced_wins(sizeof(real) == 8, m, p->n_samples, p->batch, h->num_cu, kl_one)) {
     static const bool kl_sliced_env = [] {
       const char* e = getenv("HIPNMF_KL_SLICED");
       return !(e && e[0] == '0');

@@ -146,17 +146,8 @@ constexpr int HIPNMF_NARROW_MAX_FEATURES = 32, HIPNMF_NARROW_MAX_COMPONENTS = 8;
 constexpr int HIPNMF_MAX_FEATURES = 512, HIPNMF_MAX_COMPONENTS = 64;              // nmf_big.hpp (nmf_wide.hpp: 128 / 32)
 
 // Kullback-Leibler, few long matrices: does the row-sliced one-pass general-shape kernel (nmf_big1.hpp; components padded to 16, channels
-// to 64) beat one workgroup per matrix (the only form the other families have for this loss)?  Fitted on MI355X (tools/probes/kl_long_ab.sh,
-// ms per 100 iterations): one workgroup per matrix costs (0.35 + 0.0265 m) [float64: 0.3 + 0.06 m] per 1 000 rows whatever the batch up to one
-// matrix per CU; the sliced path 1.2 (12 us per iteration) + 15 ns [29 ns] per row of the whole batch, x 1.6 at 128 channels.
-// Checked against: fp32 1 x (64 x 100 000), k = 8: 183.5 -> 8.0; 32 x (64 x 5 000): 9.5 -> 3.8; 64 x (32 x 2 500): 2.8 -> 3.3 (not taken);
-// float64 1 x (128 x 5 000), k = 6: 53.8 -> 4.0; 128 x (128 x 10 000): 108.5 -> 60.7; 128 x (64 x 2 500), k = 8: 10.9 -> 11.5 (not taken).
-inline bool kl_row_sliced_wins(bool f64, int m, long long T, int B, int num_cu) {
-  if (B > num_cu) return false;
-  const double t_one = (double)T * 1e-3 * (f64 ? 0.3 + 0.06 * m : 0.35 + 0.0265 * m);
-  const double mp64 = (double)round_up(m, 64) / 64.0;
-  const double t_rows = 1.2 + (double)B * (double)T * (f64 ? 2.9e-5 : 1.5e-5) * (1.0 + 0.6 * (mp64 - 1.0));
-  return t_rows < 0.9 * t_one;
-}
+// to 64) beat one workgroup per matrix (the only form the other families have for this loss)?  hipnmf_wide.hip; `t_one_per_krow`: ms per
+// 1 000 rows and 100 iterations of the one-workgroup kernel the call would otherwise run (< 0: the 4x4 kernels' fitted rate).
+bool hipnmf_kl_row_sliced_wins(bool f64, int m, long long T, int B, int num_cu, double t_one_per_krow);
 
 // X layout canonicalisation kernel (nmf_kernels.hpp) reused by the envelope entry point

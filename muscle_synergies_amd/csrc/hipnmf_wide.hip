@@ -128,6 +128,26 @@ static long long big1_slices(int num_cu, int B, long long T) {
   return best;
 }
 
+// Fitted on MI355X, ms per 100 iterations (tools/probes/kl_long_ab.sh, kl_long_narrow_ab.sh; profiles/r05_kl_long_matrices_ab.log):
+//  * one workgroup per matrix, whatever the batch up to one matrix per CU: (0.35 + 0.0265 m) [float64: 0.3 + 0.06 m] per 1 000 rows on the
+//    4x4 kernels; the lane mappings' own kernels are faster on few channels (fit_batched_impl passes their rate);
+//  * row slices: 1.0 (10 us per iteration of launches) + 0.015 per slice of a matrix (the H update sums the slices' records) +
+//    0.005 [x 1.9] per row of a slice and wave of workgroups, x 1.6 at 128 channels.
+// Checked against: fp32 1 x (64 x 100 000), k = 8: 183.5 -> 8.0; 32 x (64 x 5 000): 9.5 -> 3.8; 64 x (32 x 2 500): 2.8 -> 3.3 (not taken);
+// 1 x (16 x 10 000), k = 5 on the lane mappings: 3.6 -> 3.3 (not taken), k = 8: 5.6 -> 3.3; 1 x (4 x 5 000), k = 2: 0.5 -> 2.1 (not taken);
+// float64 1 x (128 x 5 000), k = 6: 53.8 -> 4.0; 128 x (128 x 10 000): 108.5 -> 60.7; 128 x (64 x 2 500), k = 8: 10.9 -> 11.5 (not taken).
+bool hipnmf_kl_row_sliced_wins(bool f64, int m, long long T, int B, int num_cu, double t_one_per_krow) {
+  if (B > num_cu) return false;
+  if (t_one_per_krow < 0) t_one_per_krow = f64 ? 0.3 + 0.06 * m : 0.35 + 0.0265 * m;
+  const double t_one = (double)T * 1e-3 * t_one_per_krow;
+  const long long S = big1_slices(num_cu, B, T);
+  const long long rows = round_up((T + S - 1) / S, 64);
+  const double waves = (double)(((long long)B * S + num_cu - 1) / num_cu);
+  const double mp64 = (double)round_up(m, 64) / 64.0;
+  const double t_rows = 1.0 + 0.015 * (double)S + 0.005 * (f64 ? 1.9 : 1.0) * (1.0 + 0.6 * (mp64 - 1.0)) * (double)rows * waves;
+  return t_rows < 0.9 * t_one;
+}
+
 // `p` has passed validate() of hipnmf_api.hip.  `ragged`: host copy of the caller's descriptors or nullptr.
 template <typename real>
 int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, real* W, real* H, real* err_out,
@@ -156,14 +176,14 @@ int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
   // the chip with them: chosen where its cost model wins (round 5; tools/probes/kl_long_ab.sh, ms per 100 iterations, one workgroup per
   // matrix -> row slices: fp32 1 x (64 x 100 000), k = 8: 183.5 -> 8.0; 32 x (64 x 5 000): 9.5 -> 3.8; 64 x (32 x 2 500): 2.8 -> 3.3;
   // float64 1 x (128 x 5 000), k = 6: 53.8 -> 4.0; 128 x (128 x 10 000): 108.5 -> 60.7; 128 x (64 x 2 500), k = 8: 10.9 -> 11.5).
-  // (cost model: kl_row_sliced_wins, hipnmf_internal.hpp; HIPNMF_KL_SLICED=0: never)
+  // (cost model: hipnmf_kl_row_sliced_wins above; HIPNMF_KL_SLICED=0: never)
   bool kl_sliced = false;
   if (kl && !ragged && wk && h->variant == 0 && h->max_slices != 1 && !force_big) {  // (hipnmf_set_tuning(max_slices = 1): one workgroup per matrix)
     static const bool kl_sliced_env = [] {
       const char* e = getenv("HIPNMF_KL_SLICED");
       return !(e && e[0] == '0');
     }();
-    kl_sliced = kl_sliced_env && kl_row_sliced_wins(sizeof(real) == 8, m, T, B, h->num_cu) &&
+    kl_sliced = kl_sliced_env && hipnmf_kl_row_sliced_wins(sizeof(real) == 8, m, T, B, h->num_cu, -1.0) &&
                 pick_big1<real>(h, (int)round_up(k, 16), (int)round_up(m, 16), true) != nullptr;
   }
   const bool big = !wk || wk->smem > (size_t)h->lds_per_block || force_big || kl_sliced;

@@ -389,11 +389,11 @@ def test_time_sharded_kullback_leibler_fit(dtype, m, k):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
-@pytest.mark.parametrize("m,k,T,B", [(2, 1, 30000, 1), (5, 3, 20001, 2), (16, 5, 40000, 1), (24, 8, 20000, 3), (33, 8, 9000, 2), (64, 8, 12000, 1),
+@pytest.mark.parametrize("m,k,T,B", [(9, 3, 60001, 1), (12, 6, 30000, 1), (16, 5, 40000, 1), (24, 8, 20000, 3), (33, 8, 9000, 2), (64, 8, 12000, 1),
                                      (100, 12, 6000, 2), (128, 6, 5000, 4)])
 def test_kullback_leibler_few_long_matrices_take_the_row_sliced_kernel(dtype, m, k, T, B):
     """Round 5: the Kullback-Leibler loss has one workgroup per matrix on every other family; a few long matrices go to the one-pass
-    general-shape kernel, which is row-sliced by construction (kl_row_sliced_wins, hipnmf_internal.hpp) -- whatever their width.
+    general-shape kernel, which is row-sliced by construction (hipnmf_kl_row_sliced_wins, hipnmf_wide.hip) -- whatever their width.
     Route, parity with the oracle (fixed iteration count, then the stop rule with regularisation), transform."""
     import muscle_synergies_amd as ms
     from muscle_synergies_amd import _lib
@@ -427,3 +427,25 @@ def test_kullback_leibler_few_long_matrices_take_the_row_sliced_kernel(dtype, m,
     rt = ms.fit_batched(Xs[0], Wt, Hr, max_iter=15, tol=0.0, beta_loss="kullback-leibler", update_H=False)
     np.testing.assert_array_equal(rt.H[0], Hr)
     np.testing.assert_allclose(rt.W[0], Wt_ref, rtol=2e-3 if f32 else 1e-9, atol=1e-6 if f32 else 1e-13)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,m,k,T,B,kernel", [
+    (np.float32, 2, 1, 30000, 1, "fit_persistent_kernel<float"),    # few channels: the lane mappings' one workgroup is faster than 256 CUs of padding
+    (np.float32, 16, 5, 4000, 1, "fit_persistent_kernel<float"),
+    (np.float64, 4, 2, 10000, 1, "fit_persistent_kernel<double"),
+    (np.float32, 64, 8, 2500, 200, "fit_wide4_kernel<64,2"),         # a batch near one matrix per CU
+    (np.float64, 64, 8, 200, 2, "fit_wide4d_kernel<64,2"),           # short matrices
+])
+def test_kullback_leibler_cost_model_leaves_these_on_one_workgroup_per_matrix(dtype, m, k, T, B, kernel):
+    import muscle_synergies_amd as ms
+    from muscle_synergies_amd import _lib
+    from muscle_synergies_amd.synth import emg_batch
+
+    X = np.ascontiguousarray(emg_batch(range(7, 7 + B), T=T, m=m, k_true=min(4, m)).astype(dtype).transpose(0, 2, 1))  # [B, T, m]
+    inits = [random_init(X[b], k, b) for b in range(B)]
+    res = ms.fit_batched(X, np.stack([w for w, _ in inits]), np.stack([h for _, h in inits]), max_iter=10, tol=0.0, beta_loss="kullback-leibler")
+    assert _lib.get_handle(0).last_kernel().startswith(kernel), _lib.get_handle(0).last_kernel()
+    Wr, Hr, _ = orc.fit_multiplicative_update_kl(X[0], inits[0][0].copy(), inits[0][1].copy(), 10, 0.0)
+    d = np.linalg.norm(res.W[0].astype(np.float64) @ res.H[0].astype(np.float64) - Wr.astype(np.float64) @ Hr.astype(np.float64)) / np.linalg.norm(X[0].astype(np.float64))
+    assert d <= (3e-5 if dtype == np.float32 else 1e-10), d
