@@ -113,7 +113,7 @@ int hipnmf_set_async(hipnmf_handle* h, int enable);
  * in registers, which batches of at least two (float64: three) matrices per CU take by themselves --; HIPNMF_ERR_UNSUPPORTED otherwise).
  * Wide shapes (n_features > 32 or n_components > 8: fit_wide_kernel, every contraction on v_mfma_*_16x16x4; at most 8
  * components with the Frobenius loss: fit_wide4_kernel / fit_wide4d_kernel on v_mfma_f32_4x4x1 / v_mfma_f64_4x4x4; the
- * library also routes float64 17..32 channels with k >= 6 there): variants 0, 1 (= 4) and 2 exist -- 2 = rows sliced over
+ * library also routes narrower shapes there where it measured faster -- DISPATCH.md): variants 0, 1 (= 4) and 2 exist -- 2 = rows sliced over
  * the chip, Frobenius loss and uniform batches only --, threads = 256 / 512 / 768 pins the instance (two workgroups per
  * CU / one with the larger W cache / three waves per SIMD, fit_wide4_kernel up to 64 channels only); 3, 5, 6 answer
  * HIPNMF_ERR_UNSUPPORTED.  Kullback-Leibler loss: a few long matrices (at most one per CU, where the library's cost model says so)
