@@ -48,6 +48,7 @@ run kl_wide4_32x8 $R/tools/quick_bench.py --batch 4096 --T 2500 --m 32 --k 8 --i
 run kl_wide4d_64x8_f64 $R/tools/quick_bench.py --batch 2048 --T 2500 --m 64 --k 8 --iters 100 --threads 0 --loss kullback-leibler --rowmajor --reps 3 --dtype float64
 for n in kl_narrow kl_wide4_64x8 kl_big_m512_k32 big_stop_rule_m512_k32 kl_wide4_32x8 kl_wide4d_64x8_f64; do grep -h "rep=" $O/$n.log > $O/${tag}_$n.log; done
 bash $R/tools/kl_routing_ab.sh > $O/${tag}_kl_routing_ab.log 2>&1
+bash $R/tools/routing_before_after.sh > $O/${tag}_routing_before_after.log 2>&1
 # the threading clause of the ABI over every entry point, 2 / 3 / 8 host threads (plain ctypes, no torch)
 for nt in 2 3 8; do python3 $R/tools/abi_threads_stress.py --threads $nt --rounds 2 2>&1 | tail -1; done > $O/${tag}_abi_threads_stress.log
 ls $O/*.csv $O/*.json $O/*.txt $O/*_filter_bench.log $O/*_ab.log
