@@ -7,9 +7,12 @@
 
 --config 3 (default, BASELINE.json configs[2], the configuration the metric is quoted on): one *step* = one batched
     fit (``hipnmf_fit_batched_f32`` through the Python host) of 4096 synthetic EMG matrices 16 ch x 10 000 samples
-    per GPU, k = 5, fp32, ``--iters`` (500) Lee-Seung iterations (tol = 0, so exactly that many, as sklearn does)
-    from a fixed ``init='custom'`` W0/H0, inputs resident in HBM.  The factorisations are independent: ranks share
-    nothing, no data-path collective, weak scaling (4096 matrices per GPU).
+    IN TOTAL, scattered over the GPUs in contiguous runs (BASELINE.json: "batch 4096 ... scattered across 1 -> 8 MI355X":
+    strong scaling; at N = 1 all 4096 on the one GPU), k = 5, fp32, ``--iters`` (500) Lee-Seung iterations (tol = 0, so
+    exactly that many, as sklearn does) from a fixed ``init='custom'`` W0/H0, inputs resident in HBM.  The factorisations
+    are independent: ranks share nothing, no data-path collective.  ``--batch-per-gpu N``: the weak-scaling form.
+    ``--dtype f64`` (configs 2/3/4): the same workload in float64, the dtype the reference itself hands to scikit-learn;
+    priced against the 8 TB/s HBM line (256 resident matrices do not fit the Infinity Cache), parity gated at 1e-9.
 --config 4 (configs[3]): per-trial rank sweep k = 2..8 (500 iterations each, random init drawn on the device, VAF >=
     0.90 selection) over 1024 trials IN TOTAL, scattered by trial over the ranks (strong scaling, no collective).
 --config 5 (configs[4]): ONE matrix 16 x 2e8 (``--T5``), rows sharded over the ranks (strong scaling), generated shard
@@ -57,6 +60,15 @@ def parse_args():
     ap.add_argument("--T", type=int, default=10_000)
     ap.add_argument("--m", type=int, default=16)
     ap.add_argument("--k", type=int, default=5)
+    ap.add_argument("--dtype", choices=["f32", "f64"], default="f32",
+                    help="arithmetic type of configs 2/3/4: f32 = BASELINE.json's metric; f64 = what the reference itself hands to "
+                         "scikit-learn (the Vicon loader builds float64 frames: vicon_data/user_data.py:391-396, analysis.py:862-863)")
+    ap.add_argument("--batch-per-gpu", type=int, default=None,
+                    help="config 3: the weak-scaling form (this many matrices on EVERY GPU); default: --batch (4096) matrices "
+                         "IN TOTAL scattered over the GPUs, BASELINE.json's wording (strong scaling)")
+    ap.add_argument("--force-nccl", action="store_true",
+                    help="config 5: open the RCCL ('nccl') process group even with one rank, so the per-iteration all-reduce "
+                         "really executes on the GPU (world size 1)")
     ap.add_argument("--T5", type=int, default=200_000_000, help="config 5: rows of the single long matrix")
     ap.add_argument("--iters5", type=int, default=20, help="config 5: iterations per step")
     ap.add_argument("--subshard", type=int, default=25_000_000, help="config 5: rows per sub-shard (< 2 GiB of X each)")
@@ -79,7 +91,7 @@ def parse_args():
 # CPU baseline: sklearn (the dependency that holds the reference's NMF arithmetic).  Runs before anything touches
 # the GPU.  (i) one matrix, 1 BLAS thread and all cores, best of 3; (ii) one worker process per core x 1 BLAS thread.
 def _cpu_worker(job):
-    seeds, T, m, k, iters = job
+    seeds, T, m, k, iters, dt_name = job
     import warnings
 
     import numpy as np
@@ -92,7 +104,7 @@ def _cpu_worker(job):
 
     data = []
     for s in seeds:
-        X = emg_matrix(s, T=T, m=m, dtype=np.float32)
+        X = emg_matrix(s, T=T, m=m, dtype=np.dtype(dt_name))
         W0, H0 = random_init(X, k, s)
         data.append((X, W0, H0))
     with threadpool_limits(limits=1):
@@ -104,7 +116,7 @@ def _cpu_worker(job):
 
 
 def _cpu_single(job):
-    T, m, k, iters, nthreads = job
+    T, m, k, iters, nthreads, dt_name = job
     import warnings
 
     import numpy as np
@@ -115,7 +127,7 @@ def _cpu_single(job):
     warnings.simplefilter("ignore")
     from sklearn.decomposition import NMF
 
-    X = emg_matrix(0, T=T, m=m, dtype=np.float32)
+    X = emg_matrix(0, T=T, m=m, dtype=np.dtype(dt_name))
     W0, H0 = random_init(X, k, 0)
     best = float("inf")
     with threadpool_limits(limits=nthreads):
@@ -142,11 +154,12 @@ def cpu_baseline(a):
     n = a.cpu_sample or max(64, cores)
     n = (n + cores - 1) // cores * cores
     per = n // cores
-    jobs = [(list(range(1000 + w * per, 1000 + (w + 1) * per)), a.T, a.m, a.k, a.iters) for w in range(cores)]
+    dt_name = "float64" if a.dtype == "f64" else "float32"
+    jobs = [(list(range(1000 + w * per, 1000 + (w + 1) * per)), a.T, a.m, a.k, a.iters, dt_name) for w in range(cores)]
     ctx = mp.get_context("spawn")
     with ctx.Pool(1) as pool:  # single-matrix numbers in a fresh process each
-        one = pool.apply(_cpu_single, ((a.T, a.m, a.k, a.iters, 1),))
-        allc = pool.apply(_cpu_single, ((a.T, a.m, a.k, a.iters, cores),))
+        one = pool.apply(_cpu_single, ((a.T, a.m, a.k, a.iters, 1, dt_name),))
+        allc = pool.apply(_cpu_single, ((a.T, a.m, a.k, a.iters, cores, dt_name),))
     t0 = time.perf_counter()
     with ctx.Pool(cores) as pool:
         out = pool.map(_cpu_worker, jobs)
@@ -161,7 +174,7 @@ def cpu_baseline(a):
         "single_matrix_1_thread": one,
         "single_matrix_all_cores": allc,
         "sample": (f"scikit-learn {sklearn.__version__} NMF(solver='mu', init='custom', tol=0, max_iter={a.iters}) "
-                   f"on {total} of the synthetic {a.m}x{a.T} k={a.k} fp32 matrices, {cores} worker processes x 1 BLAS "
+                   f"on {total} of the synthetic {a.m}x{a.T} k={a.k} {dt_name} matrices, {cores} worker processes x 1 BLAS "
                    f"thread; fit time of the slowest worker {slowest:.2f} s (pool wall {wall:.1f} s incl. data "
                    f"generation).  One matrix alone, best of 3: {one:.0f} it/s with 1 BLAS thread, {allc:.0f} it/s "
                    f"with {cores} BLAS threads"),
@@ -172,6 +185,7 @@ def cpu_baseline(a):
 # In-run parity: a few matrices of the LAST timed step's output against scikit-learn (the dependency that holds the
 # reference's arithmetic, sklearn/decomposition/_nmf.py:731-893) from the same W0/H0, in CPU worker processes that
 # were started before this process touched the GPU.  Checker leg only: nothing here is timed or shipped.
+PARITY_TOL_F64 = 1e-9  # float64 calls (the reference's own dtype): DESIGN.md section 6
 PARITY_TOL = 1e-5  # BASELINE.json north_star: 1e-5 relative Frobenius error; SURVEY.md 8c: |d(WH)|_F / |X|_F and |d err| / |X|_F
 
 
@@ -195,6 +209,8 @@ def _parity_worker(job):
 
         mdl = NMF(H0.shape[0], solver="mu", init="custom", tol=0, max_iter=iters, beta_loss=loss)
         W = mdl.fit_transform(X, W=W0.copy(), H=H0.copy())
+        if X.dtype == np.float64:
+            return "scikit-learn", W, mdl.components_, float(mdl.reconstruction_err_), None
         # the same fit in float64: how far scikit-learn's own float32 run is from it (the rounding noise of this case)
         m64 = NMF(H0.shape[0], solver="mu", init="custom", tol=0, max_iter=iters, beta_loss=loss)
         W64 = m64.fit_transform(X.astype(np.float64), W=W0.astype(np.float64), H=H0.astype(np.float64))
@@ -215,51 +231,72 @@ class ParityChecker:
             self.pool = mp.get_context("spawn").Pool(4)
             self._warm = self.pool.map_async(_parity_noop, range(4))
 
-    def check(self, jobs, ours):
-        """jobs: [(X [T, m], W0, H0, iters, loss)] NumPy; ours: [(W or None, H, err)].  Returns the ``parity`` object."""
+    def check(self, jobs, ours, names=None):
+        """jobs: [(X [T, m], W0, H0, iters, loss)] NumPy; ours: [(W or None, H, err)].  Returns the ``parity`` object.
+
+        The gate (BASELINE.json north_star: "within 1e-5 relative Frobenius error" of sklearn at the same iteration count) is the
+        distance to scikit-learn's fit IN THE DTYPE OF THE CALL: float32 inputs against its float32 fit at 1e-5, float64 inputs
+        against its float64 fit at 1e-9.  For float32 the distance to scikit-learn's float64 fit of the same case is reported
+        beside it.  A float32 case beyond 1e-5 of the float32 fit is an EXCEPTION, listed by name with all three distances, and
+        only tolerated when scikit-learn's own float32 fit is demonstrably not a 1e-5 yardstick for it (its float32 and float64
+        fits of that case differ by more than the tolerance) while this engine is within the tolerance of the float64 fit."""
         import numpy as np
 
         if self.pool is None:
             return None
         ref = self.pool.map(_parity_worker, jobs)
+        f64 = all(j[0].dtype == np.float64 for j in jobs)
+        tol = PARITY_TOL_F64 if f64 else PARITY_TOL
         d_wh, d_err, d_h, checker = 0.0, 0.0, 0.0, None
-        per_case, noise, ours64, d_eff = [], 0.0, 0.0, 0.0
-        for (X, _w0, _h0, _it, _loss), (W, H, err), (who, Wr, Hr, err_r, WH64) in zip(jobs, ours, ref):
+        per_case, noise, ours64, exceptions = [], 0.0, 0.0, []
+        for n, ((X, _w0, _h0, _it, _loss), (W, H, err), (who, Wr, Hr, err_r, WH64)) in enumerate(zip(jobs, ours, ref)):
             checker = who
             xn = float(np.linalg.norm(X.astype(np.float64)))
             Hd = H.astype(np.float64)
             WHr = Wr.astype(np.float64) @ Hr.astype(np.float64)
-            case = {}
+            case = {"name": names[n] if names else f"case {n}"}
+            gate_ok = True
             if W is not None:
                 WHo = W.astype(np.float64) @ Hd
                 case["rel_dWH"] = float(np.linalg.norm(WHo - WHr)) / xn
                 d_wh = max(d_wh, case["rel_dWH"])
-                if WH64 is not None:
+                gate_ok = case["rel_dWH"] <= tol
+                if WH64 is not None and not f64:
                     case["rel_dWH_vs_float64_fit"] = float(np.linalg.norm(WHo - WH64)) / xn
                     case["checker_float32_vs_its_float64_fit"] = float(np.linalg.norm(WHr - WH64)) / xn
                     ours64, noise = max(ours64, case["rel_dWH_vs_float64_fit"]), max(noise, case["checker_float32_vs_its_float64_fit"])
             d_h = max(d_h, float(np.linalg.norm(Hd - Hr) / max(np.linalg.norm(Hr), 1e-300)))
             case["rel_derr"] = abs(float(err) - err_r) / xn
             d_err = max(d_err, case["rel_derr"])
-            # a case passes when it is within the tolerance of scikit-learn's float32 run OR of its float64 run: where the
-            # checker's own float32 rounding exceeds the tolerance (over-parameterised trials at 500 iterations: its two runs
-            # differ by up to 6e-5) the float32 run is not a 1e-5 yardstick, the float64 one is
-            eff = min(case.get("rel_dWH", 0.0), case.get("rel_dWH_vs_float64_fit", float("inf"))) if W is not None else 0.0
-            case["ok"] = bool(eff <= PARITY_TOL and case["rel_derr"] <= PARITY_TOL)
-            d_eff = max(d_eff, eff)
+            case["within_tol_of_checker_fit_in_call_dtype"] = bool(gate_ok)
+            ok = gate_ok
+            if not gate_ok and "rel_dWH_vs_float64_fit" in case:
+                tolerated = (case["checker_float32_vs_its_float64_fit"] > tol and case["rel_dWH_vs_float64_fit"] <= tol)
+                exceptions.append({"name": case["name"], "rel_dWH_vs_float32_fit": case["rel_dWH"],
+                                   "rel_dWH_vs_float64_fit": case["rel_dWH_vs_float64_fit"],
+                                   "checker_float32_vs_its_float64_fit": case["checker_float32_vs_its_float64_fit"],
+                                   "tolerated": bool(tolerated),
+                                   "why": "scikit-learn's float32 fit of this case is itself further than the tolerance from its float64 "
+                                          "fit, and this engine is within the tolerance of the float64 fit" if tolerated else
+                                          "beyond the tolerance of the float32 fit with no such excuse"})
+                ok = tolerated
+            case["ok"] = bool(ok and case["rel_derr"] <= tol)
             per_case.append(case)
         ok = bool(all(c["ok"] for c in per_case) and np.isfinite(d_wh) and np.isfinite(d_err))
-        return {"n_checked": len(jobs), "max_rel_dWH": d_wh, "max_rel_dWH_to_nearer_of_float32_float64_fit": d_eff, "max_rel_derr": d_err,
-                "max_rel_dH": d_h, "tol": PARITY_TOL,
-                "ok": ok, "checker": checker, "per_case": per_case,
-                "float32_rounding_noise": {"checker_float32_vs_its_own_float64_fit_max_rel_dWH": noise, "ours_vs_the_float64_fit_max_rel_dWH": ours64,
-                                           "note": "how far scikit-learn's float32 run is from scikit-learn's float64 run of the same case, and how far "
-                                                   "this engine is from that float64 run: the scale of float32 rounding at this iteration count"},
-                "what": "matrices of the last timed step's output vs the checker's fit from the same W0/H0 at the same iteration "
-                        "count: |W H - W_ref H_ref|_F / |X|_F and |err - err_ref| / |X|_F per case; a case is ok within tol of the "
-                        "checker's float32 fit or of its float64 fit of the same case (per_case has both distances; max_rel_dH is "
-                        "informational: the factors themselves drift ~1e-3 at 500 fp32 iterations under ANY change of summation "
-                        "order, SURVEY.md 8c)"}
+        out = {"n_checked": len(jobs), "dtype": "float64" if f64 else "float32", "max_rel_dWH": d_wh, "max_rel_derr": d_err,
+               "max_rel_dH": d_h, "tol": tol, "ok": ok,
+               "all_within_tol_of_checker_fit_in_call_dtype": bool(all(c["within_tol_of_checker_fit_in_call_dtype"] for c in per_case)),
+               "exceptions": exceptions, "checker": checker, "per_case": per_case,
+               "what": "matrices of the last timed step's output vs the checker's fit from the same W0/H0 at the same iteration "
+                       "count and IN THE SAME DTYPE: |W H - W_ref H_ref|_F / |X|_F and |err - err_ref| / |X|_F per case, gated at tol; "
+                       "`exceptions` names every case that is not within tol of that fit (max_rel_dH is informational: the "
+                       "factors themselves drift ~1e-3 at 500 fp32 iterations under ANY change of summation order, SURVEY.md 8c)"}
+        if not f64:
+            out["float32_rounding_noise"] = {
+                "checker_float32_vs_its_own_float64_fit_max_rel_dWH": noise, "ours_vs_the_float64_fit_max_rel_dWH": ours64,
+                "note": "how far scikit-learn's float32 run is from scikit-learn's float64 run of the same case, and how far "
+                        "this engine is from that float64 run: the scale of float32 rounding at this iteration count"}
+        return out
 
     def close(self):
         if self.pool is not None:
@@ -277,7 +314,8 @@ class Ctx:
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
-        self.distributed = self.world > 1 or "TORCHELASTIC_RUN_ID" in os.environ  # under torchrun: always a group
+        self.force_nccl = bool(a.force_nccl and a.config == 5 and not a.dry_orchestration)
+        self.distributed = self.world > 1 or "TORCHELASTIC_RUN_ID" in os.environ or self.force_nccl  # under torchrun: always a group
         self.dry = bool(a.dry_orchestration)
 
     def init_gpu(self):
@@ -303,7 +341,10 @@ class Ctx:
             # nothing between ranks: their timing barrier and the max over ranks of one float64 go over gloo on the CPU,
             # so the scaling record of the embarrassingly parallel configurations does not depend on RCCL coming up.
             self.backend = "nccl" if (self.a.config == 5 and not self.dry) else "gloo"
-            if self.backend == "nccl":
+            if self.backend == "nccl" and "RANK" not in os.environ:  # --force-nccl without a launcher: a world of one
+                dist.init_process_group(backend="nccl", device_id=self.dev, rank=0, world_size=1,
+                                        init_method=f"tcp://127.0.0.1:{_free_port()}")
+            elif self.backend == "nccl":
                 dist.init_process_group(backend="nccl", device_id=self.dev)
             else:
                 dist.init_process_group(backend="gloo")
@@ -405,11 +446,42 @@ def _bound_detail(kernel):
     return "fp32 issue (f32 MFMA = f32 VALU = 157.3 TFLOP/s on gfx950)"
 
 
-def compute_roofline(kernel, kernel_ms, units_per_launch, T, m, k, traffic=None, moved_bytes_per_unit=None, stream_gbs=None):
+FP64_PEAK_TFLOPS = 78.6    # fp64 vector = fp64 matrix rate of gfx950 (half the packed-fp32 rate; AMD's MI355X data sheet)
+
+
+def roofline_f64_narrow(kernel, kernel_ms, units_per_launch, T, m, k, traffic, stream_gbs):
+    """float64 on the narrow (<= 32 channel) shapes: HBM-bound.  256 resident matrices x 8 T m bytes (328 MB at 16 x 10 000) do
+    not fit the 256 MiB Infinity Cache, so -- unlike the fp32 headline -- X comes from HBM every iteration and the 8 TB/s
+    line is the roof.  `achieved` = ALGORITHMIC bytes (X once, W read + written: 8 T (m + 2k) per unit) / kernel time."""
+    fl = flops_per_unit(T, m, k)
+    by = 8 * T * (m + 2 * k)
+    sec = kernel_ms * 1e-3
+    gbs = by * units_per_launch / sec / 1e9
+    tf = fl * units_per_launch / sec / 1e12
+    mem = {"algorithmic_bytes_per_unit": by, "hbm_peak_gbs": HBM_PEAK_GBS, "l2_fabric_bytes_per_launch": traffic,
+           "note": ("rows of W that fit the workgroup's LDS (40 bytes per row at k = 5) never leave it, so the bytes really "
+                    "moved are below the algorithmic count: l2_fabric_bytes_per_launch (PMC) when a measurement is committed")}
+    if traffic:
+        mem["l2_fabric_source"] = _traffic.source
+        mem["l2_fabric_gbs"] = traffic / sec / 1e9
+        mem["l2_fabric_over_algorithmic"] = traffic / (by * units_per_launch)
+    if stream_gbs:
+        mem["stream_peak_gbs_measured_in_this_run"] = stream_gbs
+    return {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": traffic,
+            "kernel": kernel, "kernel_ms_avg": kernel_ms, "algorithmic_bytes_per_unit": by, "flops_per_unit": fl,
+            "units_per_launch": units_per_launch,
+            "fp64_issue": {"achieved_tflops": tf, "peak_tflops": FP64_PEAK_TFLOPS, "frac": tf / FP64_PEAK_TFLOPS,
+                           "note": "v_fma_f64 on the VALU (lane mapping G = 4, CH = 4: DPP reduce-scatter inside quads)"},
+            "memory": mem}
+
+
+def compute_roofline(kernel, kernel_ms, units_per_launch, T, m, k, traffic=None, moved_bytes_per_unit=None, stream_gbs=None, esize=4):
     """``stream_gbs``: the memory system's rate for the solver's access pattern measured in this run (None: the committed constant)."""
+    if esize == 8 and not (m > 32 or k > 8):
+        return roofline_f64_narrow(kernel, kernel_ms, units_per_launch, T, m, k, traffic, stream_gbs)
     fl = flops_per_unit(T, m, k)
     peak_stream = stream_gbs if stream_gbs else STREAM_PEAK_GBS
-    by = 4 * T * (m + 2 * k)  # read X once, read + write W once (SURVEY 8d)
+    by = esize * T * (m + 2 * k)  # read X once, read + write W once (SURVEY 8d)
     sec = kernel_ms * 1e-3
     tf = fl * units_per_launch / sec / 1e12
     mem = {
@@ -490,12 +562,27 @@ def run_batch(cx, single):
     from muscle_synergies_amd import _lib
     from muscle_synergies_amd.synth import emg_batch_torch
 
+    from muscle_synergies_amd.engine import partition
+
     wide = a.m > 32 or a.k > 8
-    B = 1 if single else (a.batch or (4096 if not wide else max(256, 4096 * 16 // max(a.m, 16))))
+    f64 = a.dtype == "f64"
+    # config 3: BASELINE.json's wording is "batch 4096 ... scattered across 1 -> 8 MI355X": --batch matrices IN TOTAL, contiguous
+    # runs of them per rank (strong scaling); --batch-per-gpu N keeps N matrices on every GPU instead (weak scaling)
+    weak = bool(a.batch_per_gpu) and not single
+    total = a.batch or (4096 if not wide else max(256, 4096 * 16 // max(a.m, 16)))
+    if single:
+        B = 1
+    elif weak:
+        B = a.batch_per_gpu
+    else:
+        lo_b, hi_b = partition(total, cx.world)[cx.rank]
+        B = hi_b - lo_b
     # synthetic workload, generated on the device (seeded per rank).  X is handed over as [B, T, m] in C order
     # (row-major, what sklearn itself takes): the layout the fp32 16-channel kernels stream in place.  The
     # [B, m, T] storage (a DataFrame's F order) is timed too: the engine then converts it once per fit.
     X, W0, H0 = emg_batch_torch(B, T=a.T, m=a.m, k=a.k, device=cx.dev, seed=cx.rank)
+    if f64:  # the same values as float64: what DataFrame.to_numpy() hands to the estimator in the reference
+        X, W0, H0 = X.double(), W0.double(), H0.double()
     Xc = X.transpose(1, 2)  # logical [B, T, m] view of channel-major storage
     Xr = Xc.contiguous()
     handle = _lib.get_handle(cx.local_rank)
@@ -551,18 +638,26 @@ def run_batch(cx, single):
     avg_ms = sum(kernel_ms) / len(kernel_ms)
     layout = "row-major [B][T][m] (C order)" if a.x_layout == "row" else "channel-major [B][m][T] (F order)"
     traffic = _traffic(kernel, batch=B, iters=a.iters, T=a.T, m=a.m, k=a.k, x_layout=a.x_layout)
-    moved = 4 * (a.T * 16 + 2 * a.k * max(0, a.T - lds_rows_of_w(a.k))) if (a.m > 8 and not single and not wide) else None
+    if f64:
+        cfg_dtype_note = ("float64 is the reference's own dtype (vicon_data/user_data.py:391-396 builds dtype=float frames, "
+                          "analysis.py:862-863 hands them to scikit-learn unchanged); BASELINE.json's metric is quoted on fp32")
+    moved = 4 * (a.T * 16 + 2 * a.k * max(0, a.T - lds_rows_of_w(a.k))) if (a.m > 8 and not single and not wide and not f64) else None
+    dt_words = "float64" if f64 else "fp32"
+    global_batch = 1 * cx.world if single else (B * cx.world if weak else total)
     cfg = {
-        "workload": (f"one synthetic EMG matrix {a.m} ch x {a.T} samples per GPU, k={a.k}, fp32, {a.iters} mu iterations "
+        "workload": (f"one synthetic EMG matrix {a.m} ch x {a.T} samples per GPU, k={a.k}, {dt_words}, {a.iters} mu iterations "
                      f"per fit (BASELINE.json configs[1]; N > 1 = independent replicas)") if single else
-                    (f"batch of {B} synthetic EMG matrices {a.m} ch x {a.T} samples per GPU, k={a.k}, fp32, "
-                     f"{a.iters} mu iterations per fit, tol=0, init='custom' (BASELINE.json configs[2])"),
-        "batch_per_gpu": B, "global_batch": B * cx.world, "n_samples": a.T, "n_features": a.m, "n_components": a.k,
+                    (f"batch of {global_batch} synthetic EMG matrices {a.m} ch x {a.T} samples"
+                     + (f" ({B} on every GPU: weak-scaling form)" if weak else f" scattered over {cx.world} GPU(s) ({B} on rank 0)")
+                     + f", k={a.k}, {dt_words}, {a.iters} mu iterations per fit, tol=0, init='custom' (BASELINE.json configs[2])"),
+        "batch_rank0": B, "global_batch": global_batch, "n_samples": a.T, "n_features": a.m, "n_components": a.k,
         "iters_per_step": a.iters, "x_layout": layout,
         "parallelism": f"independent factorisations scattered over {cx.world} GPU(s), no collective",
         "all_fits_ran_full_iters": bool((r.n_iter == a.iters).all().item()),
         "all_residuals_finite": bool(torch.isfinite(r.reconstruction_err).all().item()),
     }
+    if f64:
+        cfg["dtype_note"] = cfg_dtype_note
     if other is not None:
         cfg["value_other_x_layout"] = {"x_layout": "channel-major [B][m][T] (F order, DataFrame.to_numpy())"
                                        if a.x_layout == "row" else "row-major [B][T][m]",
@@ -570,7 +665,7 @@ def run_batch(cx, single):
                                        "note": "one conversion kernel per fit inside the timed call"}
     stream = None
     if not single and not wide:  # the ceiling the headline kernel is priced against, measured now (after the timed region)
-        region = (4 * a.T * a.m + 1023) // 1024 * 1024
+        region = ((8 if f64 else 4) * a.T * a.m + 1023) // 1024 * 1024
         try:
             stream = handle.stream_gbs(region, B, 20)
         except Exception as e:  # noqa: BLE001 -- a diagnostic must not cost the benchmark line
@@ -583,11 +678,11 @@ def run_batch(cx, single):
         host = lambda t: t.detach().cpu().numpy()  # noqa: E731
         jobs = [(host(Xr[i]), host(W0[i]), host(H0[i]), a.iters, "frobenius") for i in idx]
         ours = [(host(r.W[i]), host(r.H[i]), float(r.reconstruction_err[i])) for i in idx]
-        parity = cx.parity.check(jobs, ours)
+        parity = cx.parity.check(jobs, ours, names=[f"matrix {i} of rank 0's batch" for i in idx])
         parity["matrices"] = idx
-    return {"units": cx.world * B * a.iters * a.steps, "elapsed": elapsed, "scaling": "weak", "config": cfg, "parity": parity,
-            "host_resident": host_res,
-            "roofline": compute_roofline(kernel, avg_ms, units_per_launch, a.T, a.m, a.k, traffic, moved, stream)}
+    return {"units": global_batch * a.iters * a.steps, "elapsed": elapsed, "scaling": "weak" if (weak or single) else "strong",
+            "config": cfg, "parity": parity, "host_resident": host_res,
+            "roofline": compute_roofline(kernel, avg_ms, units_per_launch, a.T, a.m, a.k, traffic, moved, stream, esize=8 if f64 else 4)}
 
 
 # ------------------------------------------------------------------------------------------------ config 4
@@ -604,6 +699,9 @@ def run_rank_sweep(cx):
     # trials whose smallest sufficient rank differs (bursting synergies, k_true = 2..6: synth.emg_rank_trials_torch); round
     # 2's smoothed-noise batch selected k = 2 for every trial and could not tell a real stop from a post-hoc one
     X, k_true = emg_rank_trials_torch(B, T=a.T, m=a.m, device=cx.dev, seed=1000 + cx.rank)
+    f64 = a.dtype == "f64"
+    if f64:
+        X = X.double()
     Xv = X.transpose(1, 2).contiguous()
     kmin, kmax = 2, 8
     kms = []
@@ -646,7 +744,7 @@ def run_rank_sweep(cx):
             del W0k, H0k
         same = all(bool(torch.equal(rw.reconstruction_err[k], r.reconstruction_err[k])) for k in r.ranks)
         del rw
-        parity = cx.parity.check(jobs, ours)
+        parity = cx.parity.check(jobs, ours, names=[f"trial {i}, k={k}" for i, k in what])
         parity["trial_rank_pairs"] = what
         parity["untimed_rerun_bitwise_equal_to_last_timed_step"] = same
         parity["ok"] = bool(parity["ok"] and same)
@@ -662,7 +760,7 @@ def run_rank_sweep(cx):
     return {"units": total * nk * a.iters * a.steps, "elapsed": elapsed, "scaling": "strong", "parity": parity,
             "config": {"workload": (f"rank sweep k={kmin}..{kmax} ({a.iters} mu iterations each, random init drawn on the "
                                     f"device, smallest k with VAF >= 0.90 selected) over {total} synthetic EMG trials "
-                                    f"{a.m} ch x {a.T} samples in total, fp32 (BASELINE.json configs[3])"),
+                                    f"{a.m} ch x {a.T} samples in total, {'float64' if f64 else 'fp32'} (BASELINE.json configs[3])"),
                        "trials_total": total, "trials_rank0": B, "n_samples": a.T, "n_features": a.m,
                        "ranks": [kmin, kmax], "iters_per_fit": a.iters,
                        "parallelism": f"trials scattered over {cx.world} GPU(s), no collective",
@@ -675,10 +773,21 @@ def run_rank_sweep(cx):
                            "matrix_iterations_per_s_compute_all": B * nk * a.iters / t_all,
                            "note": "hipnmf_rank_sweep_* vs hipnmf_rank_sweep_stop_* (one library call each, random init "
                                    "drawn inside); `value` above is the compute-all sweep through the Python host"}},
-            "roofline": {"bound": "fp32_issue", "bound_detail": "fp32 issue (f32 MFMA = f32 VALU = 157.3 TFLOP/s); seven kernels, one per rank",
-                         "achieved": tf, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_PEAK_TFLOPS,
-                         "traffic": None, "kernel": "fit_persistent_kernel<float,1,16,k,0> (k <= 5), fit_rowlane_kernel<k,...> (k >= 6)",
-                         "kernel_ms_avg": avg_ms, "units_per_launch": B * nk * a.iters}}
+            "roofline": _sweep_roofline(a, f64, tf, fl, avg_ms, B, nk, kmin, kmax)}
+
+
+def _sweep_roofline(a, f64, tf, fl, avg_ms, B, nk, kmin, kmax):
+    if f64:  # seven kernels, one per rank; HBM-bound like the float64 batch (roofline_f64_narrow)
+        by = sum(8 * a.T * (a.m + 2 * k) for k in range(kmin, kmax + 1)) * B * a.iters
+        gbs = by / (avg_ms * 1e-3) / 1e9
+        return {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+                "kernel": "fit_persistent_kernel<double,4,4,k,0> (k <= 6), fit_wide4d_kernel<16,2,8,..> (k >= 7): DISPATCH.md",
+                "kernel_ms_avg": avg_ms, "units_per_launch": B * nk * a.iters,
+                "fp64_issue": {"achieved_tflops": tf, "peak_tflops": FP64_PEAK_TFLOPS, "frac": tf / FP64_PEAK_TFLOPS}}
+    return {"bound": "fp32_issue", "bound_detail": "fp32 issue (f32 MFMA = f32 VALU = 157.3 TFLOP/s); seven kernels, one per rank",
+            "achieved": tf, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_PEAK_TFLOPS,
+            "traffic": None, "kernel": "fit_persistent_kernel<float,1,16,k,0> (k <= 5), fit_rowlane_kernel<k,...> (k >= 6)",
+            "kernel_ms_avg": avg_ms, "units_per_launch": B * nk * a.iters}
 
 
 # ------------------------------------------------------------------------------------------------ config 5
@@ -901,7 +1010,7 @@ def main():
             "higher_is_better": True,
             "scaling": res["scaling"],
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": a.dtype if a.config in (2, 3, 4) else "f32",
             "data": "none (dry orchestration)" if a.dry_orchestration else "synthetic",
             "config": res["config"],
             "roofline": res["roofline"],

@@ -11,6 +11,7 @@ already mapped, so torch's device pointers and streams and our kernels live in o
 
 from __future__ import annotations
 
+import atexit
 import ctypes
 import os
 import threading
@@ -170,6 +171,9 @@ def load():
         lib = ctypes.CDLL(path)
         _declare(lib)
         _lib = lib
+        # registered AFTER torch's import, so (atexit is last-in-first-out) it runs BEFORE any exit handler of torch: every
+        # handle this process still caches is destroyed while the HIP runtime torch shares with us is fully alive
+        atexit.register(shutdown)
     return _lib
 
 
@@ -185,8 +189,12 @@ class Handle:
     def __init__(self, device: int = 0):
         lib = load()
         self._h = ctypes.c_void_p()
+        if _closed:
+            raise HipNmfError(HIPNMF_ERR_HIP, "the interpreter is shutting down: libhip_nmf's handles are closed")
         check(lib.hipnmf_create(int(device), ctypes.byref(self._h)))
         self.device = int(device)
+        self._owner = threading.get_ident()  # the thread that created (and, for cached handles, alone drives) this handle
+        _live.add(self)
 
     @property
     def ptr(self):
@@ -224,9 +232,13 @@ class Handle:
         return name.decode() if name else ""
 
     def close(self):
-        if getattr(self, "_h", None) is not None and self._h:
-            load().hipnmf_destroy(self._h)
+        """Destroy the native handle (stream, events, workspaces).  After :func:`shutdown` (interpreter exit) this is a no-op:
+        a handle that is only collected during module teardown must not call into a HIP runtime that may be unloading."""
+        h = getattr(self, "_h", None)
+        if h is not None and h and not _closed:
             self._h = ctypes.c_void_p()
+            _live.discard(self)
+            load().hipnmf_destroy(h)
 
     def __del__(self):
         try:
@@ -237,6 +249,41 @@ class Handle:
 
 _handles: dict = {}
 _handles_lock = threading.Lock()
+_closed = False  # set by shutdown(): no native call is made after it
+import weakref  # noqa: E402
+
+_live: "weakref.WeakSet" = weakref.WeakSet()  # every open Handle of the process (cached or not)
+_shutdown_hooks: list = []  # callables run first by shutdown() (analysis.py: its rank-range worker pool)
+
+
+def shutdown() -> None:
+    """Orderly teardown, run by ``atexit`` (and callable by a host that unloads the engine earlier): stop the package's worker
+    threads, then destroy EVERY open handle of the process -- the per-thread cache, including those of threads that are
+    gone, and handles user code still holds -- while the HIP runtime is still loaded.  Afterwards ``Handle.close`` /
+    ``__del__`` do nothing.  (handles used to be destroyed from ``__del__`` during module teardown, in no
+    defined order relative to torch's own exit handlers and to worker threads that were still alive.)"""
+    global _closed
+    for hook in list(_shutdown_hooks):
+        try:
+            hook()
+        except Exception:  # noqa: BLE001
+            pass
+    with _handles_lock:
+        cached = list(_handles.values())
+        _handles.clear()
+        others = [h for h in list(_live) if h not in cached]
+    # a handle whose owner thread is still running (a daemon thread inside a call: the interpreter does not join those) may be
+    # in use this very moment: it is left alone -- its device memory goes with the process -- and never touched again
+    me = threading.get_ident()
+    running = {t.ident for t in threading.enumerate() if t.is_alive()} - {me}
+    for h in cached + others:
+        if getattr(h, "_owner", me) in running:
+            continue
+        try:
+            h.close()
+        except Exception:  # noqa: BLE001
+            pass
+    _closed = True
 
 
 def get_handle(device: int = 0) -> Handle:

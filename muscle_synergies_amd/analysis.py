@@ -21,6 +21,7 @@ from typing import Any, Mapping, Optional, Union
 import numpy as np
 import pandas
 
+from . import _lib
 from .hip_nmf import HipNMF
 
 
@@ -106,7 +107,18 @@ def _rank_pool():
 
         _RANK_POOL = ThreadPoolExecutor(max_workers=8, thread_name_prefix="hipnmf-rank")
         _RANK_POOL_PID = os.getpid()
+        if _shutdown_rank_pool not in _lib._shutdown_hooks:
+            _lib._shutdown_hooks.append(_shutdown_rank_pool)  # joined before the handles its workers cached are destroyed
     return _RANK_POOL
+
+
+def _shutdown_rank_pool() -> None:
+    global _RANK_POOL
+    import os
+
+    pool, _RANK_POOL = _RANK_POOL, None
+    if pool is not None and _RANK_POOL_PID == os.getpid():
+        pool.shutdown(wait=True, cancel_futures=True)
 
 
 def _ranks_concurrently(n_ranks: int, nmf_kwargs, shape=None) -> bool:

@@ -13,6 +13,7 @@ import os
 import shutil
 import subprocess
 import sys
+import time
 from concurrent.futures import ThreadPoolExecutor
 
 PKG = os.path.dirname(os.path.abspath(__file__))
@@ -109,7 +110,7 @@ def lint_isa(srcs, objdir: str = OBJ, verbose: bool = False) -> None:
         raise RuntimeError("hipcc emitted the split-spill defect (a 64-bit value reloaded by halves from scratch and an AGPR, one half "
                            "missing): refusing the library.  (The check is a pattern match on the assembly's spill comments; if it "
                            "misfires on another hipcc, HIPNMF_SKIP_ISA_LINT=1 builds without it.)\n"
-                           + "\n".join(f"{n}: {p}" for _, n, p in bad))
+                           + "\n".join(f"{a_}: {n}: {p}" for a_, n, p in bad))
 
 
 def build(force: bool = False, jobs: int | None = None, extra_flags=(), verbose: bool = False,
@@ -144,12 +145,40 @@ def build(force: bool = False, jobs: int | None = None, extra_flags=(), verbose:
         return lib
     todo = [s for s in srcs
             if force or _obj_stale(os.path.join(objdir, os.path.basename(s)[:-4] + ".o"), s, hdrs)]
+    skip_lint = bool(variant) or os.environ.get("HIPNMF_SKIP_ISA_LINT") == "1"
+    if not skip_lint:
+        # an object whose assembly is gone cannot be linted: it is compiled again rather than trusted
+        todo += [s for s in srcs if s not in todo and not _lint_ok(s, objdir) and not os.path.exists(_device_asm(s, objdir))]
     jobs = jobs or min(8, os.cpu_count() or 1)
+    t_compile = time.monotonic()
     if todo:
         if verbose:
             print(f"[build] compiling {len(todo)} translation unit(s) for {ARCH} with {jobs} job(s)", flush=True)
+        for s_ in todo:  # a recompiled unit loses its stamp first: if this call dies half-way the next one lints it again
+            _drop(_lint_stamp(s_, objdir))
         with ThreadPoolExecutor(max_workers=jobs) as ex:
             list(ex.map(lambda s: _compile(s, list(extra_flags), objdir), todo))
+    t_compile = time.monotonic() - t_compile
+    if not skip_lint:
+        # BEFORE linking, and over every unit that has no 'lint passed' stamp newer than its object -- not only over the units
+        # this call compiled (round-5 advisor finding: a refused library used to be accepted by the next call, which found nothing
+        # to compile and skipped the lint).  A refused unit loses its object, assembly and stamp, and the library is removed:
+        # re-running the build can only reproduce the refusal or succeed on different code.
+        pending = [s_ for s_ in srcs if not _lint_ok(s_, objdir)]
+        try:
+            lint_isa(pending, objdir, verbose)
+        except RuntimeError as e:
+            bad_asm = {line.split(":", 1)[0] for line in str(e).splitlines() if ARCH + ".s" in line}
+            for s_ in pending:
+                if _device_asm(s_, objdir) in bad_asm or not bad_asm:
+                    base = os.path.join(objdir, os.path.basename(s_)[:-4])
+                    for f in (base + ".o", base + ".d", _device_asm(s_, objdir), _lint_stamp(s_, objdir)):
+                        _drop(f)
+            _drop(lib)
+            raise
+        for s_ in pending:
+            with open(_lint_stamp(s_, objdir), "w") as f:
+                f.write("isa_split_spill_lint passed\n")
     objs = [os.path.join(objdir, os.path.basename(s)[:-4] + ".o") for s in srcs]
     linked = False
     if todo or _stale(lib, objs):
@@ -161,15 +190,29 @@ def build(force: bool = False, jobs: int | None = None, extra_flags=(), verbose:
         if verbose:
             print(f"[build] linked {lib}", flush=True)
     if not variant:
-        # the lint reads the assembly of the translation units THIS call compiled (an up-to-date library was linted when it
-        # was built); HIPNMF_SKIP_ISA_LINT=1 is the escape hatch for a toolchain whose comment format the patterns misread
-        if todo and os.environ.get("HIPNMF_SKIP_ISA_LINT") != "1":
-            lint_isa(todo, objdir, verbose)
-        _record(lib, srcs, todo, linked, verbose, record_profile)
+        _record(lib, srcs, todo, linked, verbose, record_profile, compile_seconds=t_compile, jobs=jobs)
     return lib
 
 
-def _record(lib: str, srcs, todo, linked: bool, verbose: bool, record_profile: bool = False) -> None:
+def _drop(path: str) -> None:
+    try:
+        os.remove(path)
+    except OSError:
+        pass
+
+
+def _lint_stamp(src: str, objdir: str) -> str:
+    return os.path.join(objdir, os.path.basename(src)[:-4] + ".lint_ok")
+
+
+def _lint_ok(src: str, objdir: str) -> bool:
+    """The unit's object passed the ISA lint: a stamp written after the lint, not older than the object."""
+    stamp, obj = _lint_stamp(src, objdir), os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
+    return os.path.exists(stamp) and os.path.exists(obj) and os.path.getmtime(stamp) >= os.path.getmtime(obj)
+
+
+def _record(lib: str, srcs, todo, linked: bool, verbose: bool, record_profile: bool = False, compile_seconds: float = 0.0,
+            jobs: int = 0) -> None:
     """What this call did -- compiled from source or found up to date -- next to the library (lib/build_info.json, untracked).
     Only ``record_profile`` (``--record-profile``, used by tools/profile_round.sh) also updates the tracked
     profiles/build_info.json: an ordinary rebuild must not dirty the work tree."""
@@ -189,6 +232,7 @@ def _record(lib: str, srcs, todo, linked: bool, verbose: bool, record_profile: b
         "build_mode": ("compiled all from source" if len(todo) == len(srcs) else
                        "compiled %d of %d translation units" % (len(todo), len(srcs)) if todo else "up to date: reused"),
         "flags": CXXFLAGS,
+        "compile_seconds": round(compile_seconds, 1), "jobs": jobs,
         "time_utc": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime()),
     }
     paths = [os.path.join(LIBDIR, "build_info.json")]

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <condition_variable>
 #include <cstdarg>
@@ -1404,6 +1405,13 @@ int hipnmf_device_count(void) {
   return n;
 }
 
+// Set by an exit handler registered at the first hipnmf_create -- i.e. AFTER the HIP runtime registered its own, so (exit handlers
+// run last-in-first-out) it fires BEFORE the runtime starts to unload.  A handle destroyed after that point (a host that frees
+// its objects from static destructors or from a garbage collector running at interpreter teardown) is released on the host side only:
+// calling hipStreamSynchronize / hipFree into a runtime that is being torn down is how a process aborts at exit.
+static std::atomic<bool> g_process_exiting{false};
+static void hipnmf_mark_exiting() { g_process_exiting.store(true, std::memory_order_release); }
+
 int hipnmf_create(int device, hipnmf_handle** out) {
   if (!out) return fail(HIPNMF_ERR_BAD_ARG, "out is NULL");
   *out = nullptr;
@@ -1414,6 +1422,8 @@ int hipnmf_create(int device, hipnmf_handle** out) {
                 e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
   if (device < 0 || device >= n) return fail(HIPNMF_ERR_BAD_ARG, "device %d out of range [0, %d)", device, n);
   HIP_TRY(hipSetDevice(device));
+  static std::once_flag exit_hook_once;
+  std::call_once(exit_hook_once, [] { std::atexit(hipnmf_mark_exiting); });
   hipnmf_handle* h = new hipnmf_handle();
   h->device = device;
   hipDeviceProp_t prop;
@@ -1439,13 +1449,24 @@ int hipnmf_create(int device, hipnmf_handle** out) {
 
 int hipnmf_destroy(hipnmf_handle* h) {
   if (!h) return HIPNMF_OK;
-  (void)hipSetDevice(h->device);
+  if (g_process_exiting.load(std::memory_order_acquire)) {  // the device memory goes with the process
+    delete h;
+    return HIPNMF_OK;
+  }
+  const hipError_t se = hipSetDevice(h->device);
+  if (se == hipErrorDeinitialized || se == hipErrorContextIsDestroyed || se == hipErrorNotInitialized || se == hipErrorNoDevice ||
+      se == hipErrorInvalidContext) {
+    (void)hipGetLastError();
+    delete h;  // the runtime is gone (or was never up in this process, e.g. after a fork): nothing of ours is left on the device
+    return HIPNMF_OK;
+  }
   if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
   if (h->ws) (void)hipFree(h->ws);
   if (h->aux) (void)hipFree(h->aux);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+  (void)hipGetLastError();
   delete h;
   return HIPNMF_OK;
 }

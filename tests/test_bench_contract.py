@@ -137,4 +137,78 @@ def test_only_config5_uses_rccl():
     """Configs 2-4 have no data-path collective: their barrier / max-over-ranks run over gloo (bench.py Ctx.init_gpu)."""
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert 'self.backend = "nccl" if (self.a.config == 5 and not self.dry) else "gloo"' in src
-    assert src.count('backend="nccl"') == 1
+    assert src.count('backend="nccl"') == 2  # under a launcher, and --force-nccl's world of one (config 5 only: Ctx.force_nccl)
+    assert 'self.force_nccl = bool(a.force_nccl and a.config == 5' in src
+
+
+def test_float64_batches_report_against_the_hbm_line():
+    """--dtype f64 (the reference's own dtype): 256 resident matrices of 16 x 10 000 doubles exceed the Infinity Cache, so the
+    roofline object is priced against the 8 TB/s HBM line with 8-byte elements."""
+    import bench
+
+    r = bench.compute_roofline("fit_persistent_kernel<double,4,4,5,0>", 600.0, 4096 * 500, 10_000, 16, 5, esize=8)
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert r["algorithmic_bytes_per_unit"] == 8 * 10_000 * 26
+    assert abs(r["achieved"] - 8 * 10_000 * 26 * 4096 * 500 / 0.6 / 1e9) < 1e-6 * r["achieved"]
+    assert abs(r["frac"] - r["achieved"] / 8000.0) < 1e-12
+
+
+def test_parity_gate_is_the_call_dtype_fit_and_names_exceptions():
+    """the gate is the distance to scikit-learn's fit in the dtype of the call; a float32 case beyond it is
+    listed by name and tolerated only when sklearn's own float32 fit is further than the tolerance from its float64 fit."""
+    import numpy as np
+
+    import bench
+
+    class FakePool:
+        def __init__(self, refs):
+            self.refs = refs
+
+        def map(self, _f, _jobs):
+            return self.refs
+
+    rng = np.random.default_rng(0)
+    X = np.abs(rng.standard_normal((50, 4))).astype(np.float32)
+    W = np.abs(rng.standard_normal((50, 2))).astype(np.float32)
+    H = np.abs(rng.standard_normal((2, 4))).astype(np.float32)
+    xn = float(np.linalg.norm(X))
+    WH = W.astype(np.float64) @ H.astype(np.float64)
+
+    def shifted(rel):  # a reconstruction at relative distance `rel` from ours
+        D = rng.standard_normal(WH.shape)
+        return WH + D * (rel * xn / np.linalg.norm(D))
+
+    pc = bench.ParityChecker(False)
+    job = (X, W, H, 5, "frobenius")
+    # (a) within 1e-5 of the float32 fit: plain pass, no exception
+    pc.pool = FakePool([("scikit-learn", W, H, 1.0, shifted(3e-6))])
+    out = pc.check([job], [(W, H, 1.0)], names=["a"])
+    assert out["ok"] and out["exceptions"] == [] and out["all_within_tol_of_checker_fit_in_call_dtype"]
+    # (b) 3e-5 from the float32 fit, 0 from the float64 fit, sklearn's two fits 3e-5 apart: a NAMED, tolerated exception
+    W32 = W.copy()
+    W32[0, 0] += np.float32(3e-5 * xn / np.linalg.norm(H[0]))
+    pc.pool = FakePool([("scikit-learn", W32, H, 1.0, WH)])
+    out = pc.check([job], [(W, H, 1.0)], names=["b"])
+    assert out["ok"] and not out["all_within_tol_of_checker_fit_in_call_dtype"]
+    assert [e["name"] for e in out["exceptions"]] == ["b"] and out["exceptions"][0]["tolerated"]
+    # (c) the same distance from the float32 fit while sklearn's own fits agree: fails
+    pc.pool = FakePool([("scikit-learn", W32, H, 1.0, W32.astype(np.float64) @ H.astype(np.float64))])
+    out = pc.check([job], [(W, H, 1.0)], names=["c"])
+    assert not out["ok"] and not out["exceptions"][0]["tolerated"]
+    # (d) float64 calls are gated at 1e-9 against the float64 fit, no second clause
+    X64, W64, H64 = X.astype(np.float64), W.astype(np.float64), H.astype(np.float64)
+    pc.pool = FakePool([("scikit-learn", W64 * (1 + 1e-7), H64, 1.0, None)])
+    out = pc.check([(X64, W64, H64, 5, "frobenius")], [(W64, H64, 1.0)])
+    assert out["tol"] == 1e-9 and not out["ok"]
+    pc.pool = None
+
+
+def test_config3_is_strong_scaling_by_default():
+    """BASELINE.json: 'batch 4096 ... scattered across 1 -> 8 MI355X'.  --batch is the total; --batch-per-gpu the weak form."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert 'lo_b, hi_b = partition(total, cx.world)[cx.rank]' in src and '"--batch-per-gpu"' in src
+    from muscle_synergies_amd.engine import partition
+
+    for n in (1, 2, 4, 8):
+        parts = partition(4096, n)
+        assert sum(hi - lo for lo, hi in parts) == 4096 and len(parts) == n

@@ -60,3 +60,87 @@ def test_lint_fires_on_the_known_defective_build(tmp_path):
     if not bad:
         pytest.skip("this hipcc no longer emits the split-spill defect for the TG = 4 build")
     assert all("fit_small_kernel<double, 16, 5" in name for _, name, _ in bad), bad
+
+
+def _fake_build_tree(tmp_path, monkeypatch, state):
+    """muscle_synergies_amd.build pointed at a scratch tree with two translation units; compile, lint and link are stand-ins
+    (the real ones are exercised above and by __graft_entry__.build()): this tests the ORDER and BOOKKEEPING of build()."""
+    from muscle_synergies_amd import build as b
+
+    csrc, libdir = tmp_path / "csrc", tmp_path / "lib"
+    csrc.mkdir(), libdir.mkdir()
+    (csrc / "a.hip").write_text("// a\n"), (csrc / "b.hip").write_text("// b\n")
+    monkeypatch.setattr(b, "CSRC", str(csrc))
+    monkeypatch.setattr(b, "OBJ", str(csrc / "_build"))
+    monkeypatch.setattr(b, "LIBDIR", str(libdir))
+    monkeypatch.setattr(b, "LIB", str(libdir / "libhip_nmf.so"))
+    monkeypatch.setattr(b, "INCLUDE", str(tmp_path))
+    (tmp_path / "hip_nmf.h").write_text("\n")
+    monkeypatch.delenv("HIPNMF_SKIP_ISA_LINT", raising=False)
+
+    def fake_compile(src, extra, objdir=None):
+        base = os.path.basename(src)[:-4]
+        if base in state["compile_error"]:
+            raise RuntimeError(f"hipcc failed for {src}")
+        state["compiled"].append(base)
+        open(os.path.join(objdir, base + ".o"), "w").write("obj")
+        open(b._device_asm(src, objdir), "w").write("DEFECT\n" if base in state["defective"] else "clean\n")
+        return os.path.join(objdir, base + ".o")
+
+    def fake_lint(srcs, objdir=None, verbose=False):
+        state["linted"].append(sorted(os.path.basename(s)[:-4] for s in srcs))
+        bad = [b._device_asm(s, objdir) for s in srcs if open(b._device_asm(s, objdir)).read().startswith("DEFECT")]
+        if bad:
+            raise RuntimeError("hipcc emitted the split-spill defect: refusing the library.\n" + "\n".join(f"{a}: kern: reload" for a in bad))
+
+    class R:
+        returncode, stdout, stderr = 0, "", ""
+
+    def fake_run(cmd, **kw):
+        assert "-shared" in cmd
+        state["links"] += 1
+        open(cmd[cmd.index("-o") + 1], "w").write("lib of " + " ".join(sorted(os.path.basename(c) for c in cmd if c.endswith(".o"))))
+        return R()
+
+    monkeypatch.setattr(b, "_compile", fake_compile)
+    monkeypatch.setattr(b, "lint_isa", fake_lint)
+    monkeypatch.setattr(b, "_hipcc", lambda: "hipcc")
+    monkeypatch.setattr(b.subprocess, "run", fake_run)
+    return b
+
+
+def test_a_refused_library_is_never_accepted_by_a_later_build_call(tmp_path, monkeypatch):
+    """Round-5 advisor finding (medium): the lint ran after linking and only over the units a call compiled, so a second
+    build() found nothing to compile, skipped the lint and returned the refused library.  Now: lint BEFORE link, over every
+    unit without a 'lint passed' stamp; a refusal deletes the unit's object and the library."""
+    state = {"compile_error": set(), "defective": {"b"}, "compiled": [], "linted": [], "links": 0}
+    b = _fake_build_tree(tmp_path, monkeypatch, state)
+    for _ in range(2):  # the second call must reproduce the refusal, not return a library
+        with pytest.raises(RuntimeError, match="split-spill"):
+            b.build()
+        assert not os.path.exists(b.LIB) and state["links"] == 0
+        assert not os.path.exists(os.path.join(b.OBJ, "b.o"))  # the refused object is gone: it will be compiled again
+    assert state["compiled"].count("b") == 2
+    state["defective"] = set()  # the source was fixed
+    lib = b.build()
+    assert os.path.exists(lib) and state["links"] == 1
+    n_lint = len(state["linted"])
+    b.build()  # up to date: nothing compiled, nothing left to lint, no link
+    assert state["links"] == 1 and state["linted"][n_lint:] == [[]]
+
+
+def test_a_unit_compiled_before_a_failed_call_is_still_linted_by_the_retry(tmp_path, monkeypatch):
+    """The other half of the finding: unit b (defective) compiles, unit a fails to compile, the call dies before any lint; the
+    retry only has a to compile -- and must still lint b."""
+    state = {"compile_error": {"a"}, "defective": {"b"}, "compiled": [], "linted": [], "links": 0}
+    b = _fake_build_tree(tmp_path, monkeypatch, state)
+    monkeypatch.setattr(b, "ThreadPoolExecutor", lambda max_workers=None: __import__("contextlib").nullcontext(
+        type("Seq", (), {"map": staticmethod(lambda f, it: [f(x) for x in sorted(it, reverse=True)])})()))  # b first, then a fails
+    with pytest.raises(RuntimeError, match="hipcc failed"):
+        b.build()
+    assert state["compiled"] == ["b"] and state["linted"] == []
+    state["compile_error"] = set()
+    with pytest.raises(RuntimeError, match="split-spill"):
+        b.build()
+    assert state["compiled"] == ["b", "a"] and state["linted"][-1] == ["a", "b"]
+    assert not os.path.exists(b.LIB) and state["links"] == 0

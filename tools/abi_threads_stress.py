@@ -455,6 +455,8 @@ def main():
     ap.add_argument("--rounds", type=int, default=2)
     ap.add_argument("--only", default="", help="comma separated case names (default: all)")
     ap.add_argument("--same-order", action="store_true", help="every thread runs the cases in the same order (same case at the same time)")
+    ap.add_argument("--churn", type=int, default=0, help="every thread destroys its handle and creates a new one after this many cases (0: one handle per thread)")
+    ap.add_argument("--seconds", type=float, default=0.0, help="keep starting rounds until this much time has passed (overrides --rounds as the upper bound)")
     ap.add_argument("--list", action="store_true")
     ap.add_argument("--device", type=int, default=0)
     args = ap.parse_args()
@@ -482,6 +484,7 @@ def main():
     ok(lib.hipnmf_destroy(h0), "hipnmf_destroy")
 
     errors = []
+    rounds_done = [0] * args.threads
     start = threading.Barrier(args.threads)
 
     def worker(tid):
@@ -490,10 +493,19 @@ def main():
             h = new_handle()
             order = list(names)
             start.wait()
-            for r in range(args.rounds):
+            n_cases = 0
+            t_end = time.monotonic() + args.seconds if args.seconds > 0 else None
+            for r in range(args.rounds if t_end is None else 10**9):
+                if t_end is not None and time.monotonic() > t_end:
+                    break
+                rounds_done[tid] = r + 1
                 if not args.same_order:
                     random.Random(1000 * tid + r).shuffle(order)
                 for n in order:
+                    n_cases += 1
+                    if args.churn and n_cases % args.churn == 0:
+                        ok(lib.hipnmf_destroy(h), "hipnmf_destroy")
+                        h = new_handle()
                     try:
                         _, out = CASES[n](h)
                     except Fail as e:
@@ -518,7 +530,7 @@ def main():
     if errors:
         print("ABI-THREADS-FAILED %d errors, threads=%d rounds=%d (%.1f s)" % (len(errors), args.threads, args.rounds, dt))
         return 1
-    print("ABI-THREADS-OK threads=%d rounds=%d cases=%d (%.1f s) paths=%s" % (args.threads, args.rounds, len(names), dt,
+    print("ABI-THREADS-OK threads=%d rounds=%s churn=%d cases=%d (%.1f s) paths=%s" % (args.threads, "/".join(map(str, rounds_done)), args.churn, len(names), dt,
                                                                               ",".join(sorted(set(kernels.values())))))
     return 0
 
