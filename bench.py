@@ -618,21 +618,41 @@ def run_batch(cx, single):
         import numpy as np
 
         Xh, Wh, Hh = Xr.cpu().numpy(), W0.cpu().numpy(), H0.cpu().numpy()
+        # (a) the reusable form: the caller's arrays page-locked once (ms.HostBatch), first call untimed, SECOND call timed --
+        # what a rank range / restarts / any repeated fit of the same host batch gets on every call after the first
+        t0 = time.perf_counter()
+        hb = ms.HostBatch(Xh, Wh, Hh, device=cx.dev, reuse_outputs=True)
+        t_reg = time.perf_counter() - t0
+        hb.fit(max_iter=a.iters, tol=0.0, handle=handle)
+        torch.cuda.synchronize(cx.dev)
+        t0 = time.perf_counter()
+        rh = hb.fit(max_iter=a.iters, tol=0.0, handle=handle)
+        dt_h = time.perf_counter() - t0
+        Wb, Hb = rh.W.copy(), rh.H.copy()
+        reg_s = hb.register_seconds
+        hb.close()
+        # (b) one-shot calls on the same arrays (nothing kept between calls): pipelined, and one upload / fit / download
         ms.fit_batched(Xh, Wh, Hh, max_iter=a.iters, tol=0.0, device=cx.dev, handle=handle)
         torch.cuda.synchronize(cx.dev)
         t0 = time.perf_counter()
-        rh = ms.fit_batched(Xh, Wh, Hh, max_iter=a.iters, tol=0.0, device=cx.dev, handle=handle)
-        dt_h = time.perf_counter() - t0
+        r1 = ms.fit_batched(Xh, Wh, Hh, max_iter=a.iters, tol=0.0, device=cx.dev, handle=handle)
+        dt_1 = time.perf_counter() - t0
         t0 = time.perf_counter()
         ru = ms.fit_batched(Xh, Wh, Hh, max_iter=a.iters, tol=0.0, device=cx.dev, handle=handle, host_chunk=0)
         dt_u = time.perf_counter() - t0
         host_res = {"matrix_iterations_per_s": B * a.iters / dt_h, "seconds": dt_h,
+                    "how": "ms.HostBatch(X, W0, H0, reuse_outputs=True): arrays page-locked once (hipHostRegister in place), the SECOND "
+                           "fit of the same host batch timed, NumPy in, NumPy out",
+                    "register_seconds_once": reg_s, "constructor_seconds_once": t_reg,
+                    "one_shot_matrix_iterations_per_s": B * a.iters / dt_1,
                     "unpipelined_matrix_iterations_per_s": B * a.iters / dt_u,
                     "bytes_up": int(Xh.nbytes + Wh.nbytes + Hh.nbytes), "bytes_down": int(rh.W.nbytes + rh.H.nbytes),
-                    "bitwise_equal_to_device_resident_fit": bool(np.array_equal(rh.W, r.W.cpu().numpy()) and np.array_equal(rh.H, r.H.cpu().numpy())),
-                    "bitwise_equal_to_unpipelined": bool(np.array_equal(rh.W, ru.W) and np.array_equal(rh.H, ru.H)),
+                    "bitwise_equal_to_device_resident_fit": bool(np.array_equal(Wb, r.W.cpu().numpy()) and np.array_equal(Hb, r.H.cpu().numpy())),
+                    "bitwise_equal_to_unpipelined": bool(np.array_equal(Wb, ru.W) and np.array_equal(Hb, ru.H)),
+                    "one_shot_bitwise_equal_to_unpipelined": bool(np.array_equal(r1.W, ru.W) and np.array_equal(r1.H, ru.H)),
                     "note": "NumPy in, NumPy out on one GPU: chunks of the batch uploaded / fitted / downloaded concurrently "
                             "(engine._fit_batched_pipelined); `value` keeps the inputs resident in HBM as the contract says"}
+        del r1, Wb, Hb
         del Xh, Wh, Hh, rh, ru
     units_per_launch = B * a.iters
     avg_ms = sum(kernel_ms) / len(kernel_ms)
@@ -850,6 +870,18 @@ def run_tsharded(cx):
     torch.cuda.synchronize(cx.dev)
     it_ms = ev[0].elapsed_time(ev[1]) / 10
     step_it_ms = (sum(pass_ms) / len(pass_ms)) / a.iters5  # includes 1 / iters5 of the final residual pass
+    # the exchange step on its own: 200 packed all-reduces of k*m + k*k values back to back on the solver's stream
+    ar_us = None
+    if cx.distributed:
+        buf = torch.zeros(k * m + k * k, dtype=torch.float32, device=cx.dev)
+        for _ in range(20):
+            cx.dist.all_reduce(buf, op=cx.dist.ReduceOp.SUM)
+        ev[0].record()
+        for _ in range(200):
+            cx.dist.all_reduce(buf, op=cx.dist.ReduceOp.SUM)
+        ev[1].record()
+        torch.cuda.synchronize(cx.dev)
+        ar_us = ev[0].elapsed_time(ev[1]) / 200 * 1e3
     achieved = by_rank / (it_ms * 1e-3) / 1e9
     parity = None
     if cx.parity is not None:
@@ -867,6 +899,9 @@ def run_tsharded(cx):
     n_fit = a.steps + a.warmup
     return {"units": a.iters5 * a.steps, "elapsed": elapsed, "scaling": "strong", "parity": parity,
             "collective": {"backend": (cx.backend + (" (RCCL over xGMI)" if cx.backend == "nccl" else "")) if cx.distributed else "none (single rank)",
+                           "world_size": cx.world,
+                           "all_reduce_us_each_back_to_back": ar_us,
+                           "all_reduce_share_of_iteration": (ar_us * 1e-3 / step_it_ms) if ar_us else None,
                            "all_reduce_calls_per_fit": coll["calls"] // n_fit,
                            "all_reduce_elements_per_iteration": k * m + k * k,
                            "all_reduce_elements_issued_per_fit": coll["elements"] // n_fit,

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define HIPNMF_VERSION 210 /* 0.2.1: round 5 added HIPNMF_W_ROW_MAJOR_PAD16 (the shard entry points no longer read plain W_ROW_MAJOR as padded); 0.2.0: round 3 grew hipnmf_envelope_params and added hipnmf_rank_sweep_stop_*, round 4 added hipnmf_sosfilt_params.mode */
+#define HIPNMF_VERSION 211 /* 0.2.2: round 6 added hipnmf_set_batch_hint; 0.2.1: round 5 added HIPNMF_W_ROW_MAJOR_PAD16 (the shard entry points no longer read plain W_ROW_MAJOR as padded); 0.2.0: round 3 grew hipnmf_envelope_params and added hipnmf_rank_sweep_stop_*, round 4 added hipnmf_sosfilt_params.mode */
 
 #define HIPNMF_OK 0
 #define HIPNMF_ERR_BAD_ARG (-1)
@@ -119,6 +119,14 @@ int hipnmf_set_async(hipnmf_handle* h, int enable);
  * HIPNMF_ERR_UNSUPPORTED.  Kullback-Leibler loss: a few long matrices (at most one per CU, where the library's cost model says so)
  * run row-sliced on the one-pass general-shape kernel whatever their width; variant 1 or max_slices = 1 keeps one workgroup per matrix. */
 int hipnmf_set_tuning(hipnmf_handle* h, int threads, int max_slices, int variant);
+/* A host that hands ONE batch to the library in several calls (chunks of a transfer pipeline, a compacted sub-batch) names the
+ * size of the whole batch here: until reset with 0, every batched fit on this handle chooses its kernel family, workgroup
+ * geometry and row-slice count as for a batch of max(p->batch, batch) matrices, so that a tail chunk of 52 matrices is fitted
+ * by the same kernel -- bit for bit the same per-matrix arithmetic -- as the 256-matrix chunks before it (the choice between
+ * the lane mappings and the matrix-pipe kernels, and between one workgroup per matrix and row slices, depends on the batch).
+ * The native rank sweep uses the same mechanism internally.  No reference counterpart: sklearn's fit is one matrix per call
+ * (src/muscle_synergies/analysis.py:862-863). */
+int hipnmf_set_batch_hint(hipnmf_handle* h, int batch);
 
 /* ---- batched fit: replaces NMF(solver='mu').fit_transform / .transform for B matrices ------------- */
 /*

@@ -12,12 +12,13 @@ Importing this package never loads the HIP library; the first compute call does,
 """
 
 from .analysis import SynergyRunResult, find_synergies, find_synergies_batched, vaf
-from .engine import (BatchedResult, RankSweepResult, RestartResult, fit_batched, fit_batched_multi_gpu, fit_ragged,
+from .engine import (BatchedResult, HostBatch, RankSweepResult, RestartResult, fit_batched, fit_batched_multi_gpu, fit_ragged,
                      fit_restarts, random_init_batched, random_init_device, rank_sweep_batched, rank_sweep_native)
 from .hip_nmf import HipNMF
 from .preprocess import (digital_filter, emg_envelope_batched, linear_envelope, linear_envelope_batched, normalize, set_filter_mode,
                          rms, sosfilt_batched, time_normalize, zero_center)
 from .segments import find_synergies_segments, segment_frames
+from .tsharded import fit_tsharded_devices
 from ._lib import HipNmfError
 
 __version__ = "0.1.0"
@@ -32,10 +33,12 @@ __all__ = [
     "HipNMF",
     "fit_batched",
     "fit_batched_multi_gpu",
+    "fit_tsharded_devices",
     "fit_ragged",
     "fit_restarts",
     "RestartResult",
     "BatchedResult",
+    "HostBatch",
     "rank_sweep_batched",
     "rank_sweep_native",
     "random_init_device",

@@ -37,7 +37,7 @@ W_ROW_MAJOR_PAD16 = 2  # [T][round_up(k, 16)], zero padding: general-shape shard
 EXPORTS = (
     "hipnmf_version", "hipnmf_last_error", "hipnmf_device_count", "hipnmf_create", "hipnmf_destroy",
     "hipnmf_set_stream", "hipnmf_workspace_bytes", "hipnmf_last_kernel_ms", "hipnmf_last_kernel", "hipnmf_set_async",
-    "hipnmf_set_tuning",
+    "hipnmf_set_tuning", "hipnmf_set_batch_hint",
     "hipnmf_fit_batched_f32", "hipnmf_fit_batched_f64", "hipnmf_fit_ragged_f32", "hipnmf_fit_ragged_f64",
     "hipnmf_shard_pass_f32", "hipnmf_shard_hupdate_f32", "hipnmf_shard_residual_f32",
     "hipnmf_shard_pass_f64", "hipnmf_shard_hupdate_f64", "hipnmf_shard_residual_f64",
@@ -116,6 +116,8 @@ def _declare(lib):
     lib.hipnmf_set_async.argtypes = [vp, ip]
     lib.hipnmf_set_tuning.restype = ip
     lib.hipnmf_set_tuning.argtypes = [vp, ip, ip, ip]
+    lib.hipnmf_set_batch_hint.restype = ip
+    lib.hipnmf_set_batch_hint.argtypes = [vp, ip]
     lib.hipnmf_diag_stream_gbs.restype = ip
     lib.hipnmf_diag_stream_gbs.argtypes = [vp, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_double)]
     for sfx in ("f32", "f64"):
@@ -202,6 +204,10 @@ class Handle:
 
     def set_tuning(self, threads: int = 0, max_slices: int = 0, variant: int = 0):
         check(load().hipnmf_set_tuning(self._h, int(threads), int(max_slices), int(variant)))
+
+    def set_batch_hint(self, batch: int = 0):
+        """``hipnmf_set_batch_hint``: route the following fits as for a batch of this many matrices (0 = off)."""
+        check(load().hipnmf_set_batch_hint(self._h, int(batch)))
 
     def set_stream(self, stream_ptr):
         """``stream_ptr``: a ``hipStream_t`` as int; 0 = the device's default (null) stream; None = the

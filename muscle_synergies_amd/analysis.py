@@ -211,8 +211,10 @@ def find_synergies_batched(processed_emg_dfs, n_components: int, max_components:
 
     ``devices=`` scatters the trials over several GPUs (BASELINE.json config #4; the loop this replaces is
     ``analysis.py:907-912`` over the trials of ``project/segment.py:160-207``): contiguous runs of trials balanced by
-    their rows, one host thread and handle per device, no collective, the per-trial results in the order of the input --
-    trial by trial what the one-device call returns.
+    their rows, one host thread and handle per device, no collective, the per-trial results in the order of the input.
+    Every trial's fit is the same arithmetic as in the one-device call; it is the same BITS whenever the device's share of
+    the batch takes the same kernel family as the whole batch would (the choice depends on the batch size: DISPATCH.md) --
+    a share is routed on its own size on purpose, a GPU that receives two long trials must slice them over all its CUs.
 
     ``processed_emg_dfs`` is a sequence of DataFrames with the same muscles (columns) and any numbers of rows
     (e.g. the gait cycles cut by ``project/segment.py``).  Returns one :class:`SynergyRunResult` per trial,

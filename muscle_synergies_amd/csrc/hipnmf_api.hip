@@ -304,7 +304,7 @@ bool wide_preferred(int m, int k, const hipnmf_problem* p, const hipnmf_handle* 
   // k <= 5, 0.035 m on fit_rowlane_kernel; float64 up to 8 channels 0.05 m)
   const double kl_one = sizeof(real) == 4 ? (m <= 16 ? (k <= 5 ? 0.0225 : 0.035) * m : -1.0) : (m <= 8 ? 0.05 * m : -1.0);
   if (p->loss != HIPNMF_LOSS_FROBENIUS && !ragged && h->max_slices != 1 &&
-      hipnmf_kl_row_sliced_wins(sizeof(real) == 8, m, p->n_samples, p->batch, h->num_cu, kl_one)) {
+      hipnmf_kl_row_sliced_wins(sizeof(real) == 8, m, p->n_samples, std::max(p->batch, h->path_batch_hint), h->num_cu, kl_one, h->max_slices)) {
     static const bool kl_sliced_env = [] {
       const char* e = getenv("HIPNMF_KL_SLICED");
       return !(e && e[0] == '0');
@@ -1270,7 +1270,7 @@ int rank_sweep_impl(hipnmf_handle* h, const hipnmf_problem* p, int k_min, int k_
   int rc = HIPNMF_OK;
   size_t h_off = 0;
   const int saved_hint = h->path_batch_hint;
-  h->path_batch_hint = B;
+  h->path_batch_hint = std::max(B, saved_hint);
   for (int k = k_min; k <= k_max && !rc; ++k) {
     real* Hk = H_out + h_off;
     h_off += (size_t)B * k * m;
@@ -1468,6 +1468,13 @@ int hipnmf_destroy(hipnmf_handle* h) {
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   (void)hipGetLastError();
   delete h;
+  return HIPNMF_OK;
+}
+
+int hipnmf_set_batch_hint(hipnmf_handle* h, int batch) {
+  if (!h) return fail(HIPNMF_ERR_BAD_ARG, "handle is NULL");
+  if (batch < 0) return fail(HIPNMF_ERR_BAD_ARG, "batch hint must be >= 0 (got %d)", batch);
+  h->path_batch_hint = batch;
   return HIPNMF_OK;
 }
 

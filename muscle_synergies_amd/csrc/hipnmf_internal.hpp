@@ -148,6 +148,6 @@ constexpr int HIPNMF_MAX_FEATURES = 512, HIPNMF_MAX_COMPONENTS = 64;            
 // Kullback-Leibler, few long matrices: does the row-sliced one-pass general-shape kernel (nmf_big1.hpp; components padded to 16, channels
 // to 64) beat one workgroup per matrix (the only form the other families have for this loss)?  hipnmf_wide.hip; `t_one_per_krow`: ms per
 // 1 000 rows and 100 iterations of the one-workgroup kernel the call would otherwise run (< 0: the 4x4 kernels' fitted rate).
-bool hipnmf_kl_row_sliced_wins(bool f64, int m, long long T, int B, int num_cu, double t_one_per_krow);
+bool hipnmf_kl_row_sliced_wins(bool f64, int m, long long T, int B, int num_cu, double t_one_per_krow, int max_slices = 0);
 
 // X layout canonicalisation kernel (nmf_kernels.hpp) reused by the envelope entry point

@@ -136,11 +136,14 @@ static long long big1_slices(int num_cu, int B, long long T) {
 // Checked against: fp32 1 x (64 x 100 000), k = 8: 183.5 -> 8.0; 32 x (64 x 5 000): 9.5 -> 3.8; 64 x (32 x 2 500): 2.8 -> 3.3 (not taken);
 // 1 x (16 x 10 000), k = 5 on the lane mappings: 3.6 -> 3.3 (not taken), k = 8: 5.6 -> 3.3; 1 x (4 x 5 000), k = 2: 0.5 -> 2.1 (not taken);
 // float64 1 x (128 x 5 000), k = 6: 53.8 -> 4.0; 128 x (128 x 10 000): 108.5 -> 60.7; 128 x (64 x 2 500), k = 8: 10.9 -> 11.5 (not taken).
-bool hipnmf_kl_row_sliced_wins(bool f64, int m, long long T, int B, int num_cu, double t_one_per_krow) {
+// `max_slices` > 0: the caller's cap on slices per matrix (hipnmf_set_tuning) -- the launch applies it, so the estimate must too (round-5
+// advisor finding: max_slices = 2..N used to be priced as if the uncapped slice count ran).
+bool hipnmf_kl_row_sliced_wins(bool f64, int m, long long T, int B, int num_cu, double t_one_per_krow, int max_slices) {
   if (B > num_cu) return false;
   if (t_one_per_krow < 0) t_one_per_krow = f64 ? 0.3 + 0.06 * m : 0.35 + 0.0265 * m;
   const double t_one = (double)T * 1e-3 * t_one_per_krow;
-  const long long S = big1_slices(num_cu, B, T);
+  long long S = big1_slices(num_cu, B, T);
+  if (max_slices > 0) S = std::min<long long>(S, max_slices);
   const long long rows = round_up((T + S - 1) / S, 64);
   const double waves = (double)(((long long)B * S + num_cu - 1) / num_cu);
   const double mp64 = (double)round_up(m, 64) / 64.0;
@@ -153,6 +156,7 @@ template <typename real>
 int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, real* W, real* H, real* err_out,
                     int32_t* n_iter_out, real* sse_col_out, real* xsq_col_out, const int64_t* ragged) {
   const int B = p->batch, m = p->n_features, k = p->n_components;
+  const int Br = std::max(B, h->path_batch_hint);  // the batch the ROUTE is chosen for (hipnmf_set_batch_hint: chunks of one batch)
   const long long T = p->n_samples;
   // Instance: 512 threads (one workgroup per CU, two waves per SIMD) with every byte of LDS the stages leave as W cache,
   // wherever that instance exists; 256 threads (two workgroups per CU, small cache) otherwise, or on request
@@ -183,7 +187,7 @@ int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
       const char* e = getenv("HIPNMF_KL_SLICED");
       return !(e && e[0] == '0');
     }();
-    kl_sliced = kl_sliced_env && hipnmf_kl_row_sliced_wins(sizeof(real) == 8, m, T, B, h->num_cu, -1.0) &&
+    kl_sliced = kl_sliced_env && hipnmf_kl_row_sliced_wins(sizeof(real) == 8, m, T, Br, h->num_cu, -1.0, h->max_slices) &&
                 pick_big1<real>(h, (int)round_up(k, 16), (int)round_up(m, 16), true) != nullptr;
   }
   const bool big = !wk || wk->smem > (size_t)h->lds_per_block || force_big || kl_sliced;
@@ -283,16 +287,16 @@ int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
   long long rps = 0;
   bool sliced = false;
   if (big) {  // always row slices: enough of them to fill the chip, whole 64-row sweeps of a workgroup
-    const long long want = std::max<long long>(1, (2LL * h->num_cu + B - 1) / B);
+    const long long want = std::max<long long>(1, (2LL * h->num_cu + Br - 1) / Br);
     long long s_try = std::min<long long>(want, (T + 63) / 64);
-    if (pick_big1<real>(h, KPb0, MPb0, kl)) s_try = big1_slices(h->num_cu, B, T);  // one 512-thread workgroup per CU
+    if (pick_big1<real>(h, KPb0, MPb0, kl)) s_try = big1_slices(h->num_cu, Br, T);  // one 512-thread workgroup per CU
     if (h->max_slices > 0) s_try = std::min<long long>(s_try, h->max_slices);
     rps = round_up((T + s_try - 1) / s_try, 64);
     S = (int)((T + rps - 1) / rps);
     sliced = true;
     if (B > 65535) return fail(HIPNMF_ERR_UNSUPPORTED, "batch=%d: the general-shape path takes at most 65535 matrices", B);
   } else if (!ragged && !kl && wk4 && wk4->smem <= (size_t)h->lds_per_block && h->variant != 1 && h->variant != 4 && B <= 65535) {
-    const long long target = std::min<long long>(128, std::max<long long>(1, 2LL * h->num_cu / B));  // (the H update sums S records per launch)
+    const long long target = std::min<long long>(128, std::max<long long>(1, 2LL * h->num_cu / Br));  // (the H update sums S records per launch)
     long long s_try = std::min<long long>(target, (T + 127) / 128);  // at least two subtiles per wave and slice
     if (h->max_slices > 0) s_try = std::min<long long>(s_try, h->max_slices);
     s_try = std::max<long long>(s_try, 1);
@@ -301,7 +305,7 @@ int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
     // fitted to tools/quick_bench.py --batch 1 --m 64 --k 8 (us per iteration, one workgroup / sliced): T = 1 000 20 / 12.7,
     // 4 000 71 / 11, 10 000 171 / 20.6, 100 000 1 692 / 28.7; 8 x (128 x 20 000), k = 16: 480 / 39
     const double unit = 1.1e-6 * (double)wk4->MP / 64.0;  // one round of four 16-row subtiles on a workgroup that has its CU to itself
-    const double t_pers = 3e-6 + (double)((B + 2 * h->num_cu - 1) / (2 * h->num_cu)) * (double)((T + 63) / 64) * unit * 4.0 / (double)wk->NW;
+    const double t_pers = 3e-6 + (double)((Br + 2 * h->num_cu - 1) / (2 * h->num_cu)) * (double)((T + 63) / 64) * unit * 4.0 / (double)wk->NW;
     const double t_sliced = 11e-6 + (double)((rps + 63) / 64) * unit;  // two graph-replayed launches: the pass, the record sums + H update
     sliced = h->variant == 2 ? S >= 1 : (S >= 2 && t_sliced < 0.85 * t_pers);
   } else if (h->variant == 2) {
@@ -350,7 +354,7 @@ int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
         const char* e = getenv("HIPNMF_KL_WAVES");
         return e ? atoi(e) : 0;
       }();
-      const int kl_waves = kl_waves_env ? kl_waves_env : (B <= h->num_cu ? 8 : 4);
+      const int kl_waves = kl_waves_env ? kl_waves_env : (Br <= h->num_cu ? 8 : 4);
       const int want = kl ? (h->threads == 256 ? 4 : kl_waves) : h->threads == 256 ? 4 : h->threads == 512 ? 8 : (h->threads == 768 || k > 4) ? 12 : 8;
       w4 = pick4<real>(m, k, want);
       if (!w4 && want == 12) w4 = pick4<real>(m, k, 8);
@@ -624,10 +628,17 @@ int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
     if (!arc && b1 && b1smem > 48 * 1024) arc = hipnmf_allow_full_lds(h, reinterpret_cast<const void*>(b1fn));
     if (!arc && smem_h > 48 * 1024) arc = hipnmf_allow_full_lds(h, reinterpret_cast<const void*>(big_hupdate_kernel<real>));
     if (arc) return arc;
-    if (std::max(std::max(smem_w, smem_r), std::max(smem_rec, smem_h)) > (size_t)h->lds_per_block)
-      return fail(HIPNMF_ERR_UNSUPPORTED, "n_features=%d n_components=%d needs more LDS per workgroup than this device has (%d bytes)", m, k,
-                  h->lds_per_block);
     const Big1Kernel<real>* b1r = pick_big1<real>(h, KPb, MPb, false);  // its residual kernel serves both losses
+    {  // only the kernels this call will launch count (round-5 advisor finding: the two-pass pair's footprint used to refuse calls
+       // that the one-pass kernel -- smaller LDS, a residual kernel with none -- serves entirely)
+      size_t need = smem_h;
+      if (b1) need = std::max(need, b1smem);
+      else need = std::max(need, std::max(smem_w, smem_rec));
+      if (!b1r) need = std::max(need, smem_r);
+      if (need > (size_t)h->lds_per_block)
+        return fail(HIPNMF_ERR_UNSUPPORTED, "n_features=%d n_components=%d needs more LDS per workgroup than this device has (%d bytes)", m, k,
+                    h->lds_per_block);
+    }
     auto residual = [&](int it, auto&& emit) {
       if (b1r)
         emit(b1r->resid, gslice, dim3(512), (size_t)0, ba);

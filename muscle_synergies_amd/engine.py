@@ -140,8 +140,11 @@ def fit_batched(X, W0, H0, *, max_iter: int = 200, tol: float = 1e-4, check_ever
     """
     torch = _torch()
     if devices is not None:
+        if handle is not None or overwrite_init or device is not None:
+            raise ValueError("devices= scatters the batch over one thread, handle and private copy per device: it cannot be "
+                             "combined with handle=, overwrite_init=True or device=")
         kw = dict(max_iter=max_iter, tol=tol, check_every=check_every, update_H=update_H, l1_reg_W=l1_reg_W, l1_reg_H=l1_reg_H,
-                  l2_reg_W=l2_reg_W, l2_reg_H=l2_reg_H, beta_loss=beta_loss)
+                  l2_reg_W=l2_reg_W, l2_reg_H=l2_reg_H, beta_loss=beta_loss, host_chunk=host_chunk)
         return _fit_batched_scattered(X, W0, H0, devices, return_numpy, kw)
     dev = resolve_device(device)
     was_numpy = not isinstance(X, torch.Tensor)
@@ -209,7 +212,9 @@ def fit_batched(X, W0, H0, *, max_iter: int = 200, tol: float = 1e-4, check_ever
 # fp32: 2.6 GB up, 0.8 GB down against ~0.2 s of compute).  Chunks of the batch go through a three-stage pipeline instead:
 # worker threads upload chunk i + 1 (and i + 2) and download chunk i - 1 on their own streams while the calling thread fits
 # chunk i -- the library call blocks its host thread and releases the GIL, the copies block theirs.  The per-matrix results do
-# not depend on the chunking (one workgroup per matrix; tests/test_gpu_pipeline.py compares bitwise).
+# not depend on the chunking: every chunk is routed as the whole batch would be (hipnmf_set_batch_hint -- a tail chunk below half the
+# CUs would otherwise take another kernel family) and a matrix's arithmetic does not depend on its neighbours
+# (tests/test_gpu_pipeline.py compares bitwise, tail chunk included).
 _pipeline_trace = None  # development aid (tools/probes/host_pipeline_trace.py): a list to receive (stage, chunk, t_start, t_end)
 PIPELINE_MIN_BYTES = 256 << 20   # X smaller than this: one upload, one fit
 PIPELINE_MAX_CHUNK_BYTES = 1 << 30  # ... but never more than this per chunk
@@ -219,10 +224,12 @@ PIPELINE_CHUNK_BYTES = 192 << 20  # automatic chunk: about this much of X, a mul
 def _pipeline_chunk(X, host_chunk) -> int:
     """Matrices per chunk, or 0 for no pipeline."""
     B = X.shape[0]
+    if X.dtype not in (np.float32, np.float64) or any(st < 0 for st in X.strides):
+        return 0  # the ordinary path reports unsupported dtypes; torch.from_numpy cannot view negative strides
     if host_chunk is not None:
         c = int(host_chunk)
         return c if 0 < c < B else 0
-    if X.nbytes < PIPELINE_MIN_BYTES or X.dtype not in (np.float32, np.float64):
+    if X.nbytes < PIPELINE_MIN_BYTES:
         return 0
     per = max(1, X.nbytes // B)
     # whole rounds of workgroups: at least 256 matrices per chunk (fewer leave CUs idle in the one-workgroup-per-matrix kernels,
@@ -233,7 +240,7 @@ def _pipeline_chunk(X, host_chunk) -> int:
     return c if c < B else 0
 
 
-def _fit_batched_pipelined(X, W0, H0, dev, chunk: int, kw, handle=None) -> BatchedResult:
+def _fit_batched_pipelined(X, W0, H0, dev, chunk: int, kw, handle=None, ctx=None) -> BatchedResult:
     from concurrent.futures import ThreadPoolExecutor
     import time as _time
 
@@ -250,11 +257,15 @@ def _fit_batched_pipelined(X, W0, H0, dev, chunk: int, kw, handle=None) -> Batch
     tdt = torch.float32 if dt == np.float32 else torch.float64
     W0, H0 = W0.astype(dt, copy=False), H0.astype(dt, copy=False)
     bounds = [(lo, min(lo + chunk, B)) for lo in range(0, B, chunk)]
-    w_raw = np.empty(B * T * k * dt.itemsize + 4096, np.uint8)  # W page-aligned: its chunks can be pinned one by one
-    w_off = (-w_raw.ctypes.data) % 4096
-    out = BatchedResult(w_raw[w_off: w_off + B * T * k * dt.itemsize].view(dt).reshape(B, T, k), np.empty((B, k, m), dt),
-                        np.empty((B,), np.int32), np.empty((B,), dt), np.empty((B, 1 + m), dt), np.empty((B, m), dt),
-                        np.empty((B, m), dt), 0.0)
+    out_pinned = False
+    if ctx is not None and ctx.reuse_outputs:
+        out, out_pinned = ctx._outputs(B, T, k, m, dt)  # the batch's own result arrays, registered once, reused from call to call
+    else:
+        w_raw = np.empty(B * T * k * dt.itemsize + 4096, np.uint8)  # W page-aligned: its chunks can be pinned one by one
+        w_off = (-w_raw.ctypes.data) % 4096
+        out = BatchedResult(w_raw[w_off: w_off + B * T * k * dt.itemsize].view(dt).reshape(B, T, k), np.empty((B, k, m), dt),
+                            np.empty((B,), np.int32), np.empty((B,), dt), np.empty((B, 1 + m), dt), np.empty((B, m), dt),
+                            np.empty((B, m), dt), 0.0)
     h = handle if handle is not None else _lib.get_handle(dev.index)
 
     def traced(stage):
@@ -276,10 +287,18 @@ def _fit_batched_pipelined(X, W0, H0, dev, chunk: int, kw, handle=None) -> Batch
     NSLOT = min(3, len(bounds))
     es = X.itemsize
     channel_major = X.strides == (T * m * es, es, T * es)  # every matrix stored m x T (a DataFrame's F order), seen as T x m
-    slots = []
-    for _ in range(NSLOT):
-        xs = torch.empty((chunk, m, T), dtype=tdt, device=dev).transpose(1, 2) if channel_major else torch.empty((chunk, T, m), dtype=tdt, device=dev)
-        slots.append((xs, torch.empty((chunk, T, k), dtype=tdt, device=dev), torch.empty((chunk, k, m), dtype=tdt, device=dev)))
+    def make_slots():
+        made = []
+        for _ in range(NSLOT):
+            xs = torch.empty((chunk, m, T), dtype=tdt, device=dev).transpose(1, 2) if channel_major else torch.empty((chunk, T, m), dtype=tdt, device=dev)
+            made.append((xs, torch.empty((chunk, T, k), dtype=tdt, device=dev), torch.empty((chunk, k, m), dtype=tdt, device=dev)))
+        return made
+
+    slots = ctx._slots((NSLOT, chunk, T, m, k, tdt, channel_major), make_slots) if ctx is not None else make_slots()
+    # inputs registered by a HostBatch are page-locked already: asynchronous copy-engine transfers, no on-the-fly pinning by the driver
+    x_pin = ctx is not None and ctx.is_registered(X)
+    w_pin = ctx is not None and ctx.is_registered(W0)
+    h_pin = ctx is not None and ctx.is_registered(H0)
     # (no device-wide synchronisation anywhere in this function: with the 32 pooled side streams of a previous call around,
     #  hipDeviceSynchronize alone took 27 - 39 ms; every hand-over below is an event or a stream synchronisation)
     if _pipeline_trace is not None:
@@ -295,9 +314,9 @@ def _fit_batched_pipelined(X, W0, H0, dev, chunk: int, kw, handle=None) -> Batch
         xs, ws, hs = slots[i % NSLOT]
         st = torch.cuda.Stream(dev)
         with torch.cuda.stream(st):
-            xs[:n].copy_(torch.from_numpy(X[lo:hi]))
-            ws[:n].copy_(torch.from_numpy(W0[lo:hi]))
-            hs[:n].copy_(torch.from_numpy(H0[lo:hi]))
+            xs[:n].copy_(torch.from_numpy(X[lo:hi]), non_blocking=x_pin)
+            ws[:n].copy_(torch.from_numpy(W0[lo:hi]), non_blocking=w_pin)
+            hs[:n].copy_(torch.from_numpy(H0[lo:hi]), non_blocking=h_pin)
         st.synchronize()
         return xs[:n], ws[:n], hs[:n]
 
@@ -323,6 +342,11 @@ def _fit_batched_pipelined(X, W0, H0, dev, chunk: int, kw, handle=None) -> Batch
         st.wait_event(ready)
         dst = out.W[lo:hi]
         pinned = False
+        if out_pinned:  # (HostBatch(reuse_outputs=True): the whole result array is registered for the batch's lifetime)
+            with torch.cuda.stream(st):
+                torch.from_numpy(dst).copy_(Wd, non_blocking=True)
+            st.synchronize()
+            return
         if page_ok:
             try:
                 pinned = int(rt.cudaHostRegister(dst.ctypes.data, dst.nbytes, 0)) == 0
@@ -337,31 +361,217 @@ def _fit_batched_pipelined(X, W0, H0, dev, chunk: int, kw, handle=None) -> Batch
                 rt.cudaHostUnregister(dst.ctypes.data)
 
     ms_total = 0.0
-    with ThreadPoolExecutor(max_workers=4, thread_name_prefix="hipnmf-xfer") as pool:
-        downs = {}
-        ups = {0: pool.submit(upload, 0, None)}
-        if len(bounds) > 1:  # one after the other: side by side the first two share the link and chunk 0 arrives twice as late
-            ups[1] = pool.submit(upload, 1, ups[0])
-        for i in range(len(bounds)):
-            Xd, Wd, Hd = ups.pop(i).result()
-            if i + 2 < len(bounds):  # (its slot was chunk i - 1's: free once that chunk's W is home)
-                ups[i + 2] = pool.submit(upload, i + 2, downs.get(i + 2 - NSLOT))
-            r = fit_batched(Xd, Wd, Hd, device=dev, handle=h, return_numpy=False, overwrite_init=True, _inputs_ready=True, **kw)
-            ms_total += r.kernel_ms
-            ready = torch.cuda.Event()
-            ready.record()
-            small_parts[i] = {name: getattr(r, name).clone() if name == "H" else getattr(r, name) for name in SMALL}
-            downs[i] = pool.submit(download, i, r.W, ready)
-            del Xd, Wd, Hd, r
-        for f in downs.values():
-            f.result()
-    t_sm = _time.perf_counter()
-    for name in SMALL:  # the device is idle now: one copy per small output
-        getattr(out, name)[...] = torch.cat([p[name] for p in small_parts]).cpu().numpy()
-    if _pipeline_trace is not None:
-        _pipeline_trace.append(("small", 0, t_sm, _time.perf_counter()))
-    out.kernel_ms = ms_total
-    return out
+    # every chunk is fitted by the kernel the WHOLE batch would get (hipnmf_set_batch_hint): a tail chunk below half the CUs
+    # would otherwise be routed like a small batch -- a valid fit, but not the bits of the one-call fit
+    h.set_batch_hint(B)
+    try:
+        ms_total = 0.0
+        with ThreadPoolExecutor(max_workers=4, thread_name_prefix="hipnmf-xfer") as pool:
+            downs = {}
+            ups = {0: pool.submit(upload, 0, None)}
+            if len(bounds) > 1:  # one after the other: side by side the first two share the link and chunk 0 arrives twice as late
+                ups[1] = pool.submit(upload, 1, ups[0])
+            for i in range(len(bounds)):
+                Xd, Wd, Hd = ups.pop(i).result()
+                if i + 2 < len(bounds):  # (its slot was chunk i - 1's: free once that chunk's W is home)
+                    ups[i + 2] = pool.submit(upload, i + 2, downs.get(i + 2 - NSLOT))
+                r = fit_batched(Xd, Wd, Hd, device=dev, handle=h, return_numpy=False, overwrite_init=True, _inputs_ready=True, **kw)
+                ms_total += r.kernel_ms
+                # H leaves the slot first (a copy on torch's stream), THEN the event: the upload that reuses this slot is gated on the
+                # download, the download on this event -- so it also orders the clone before the slot is overwritten (round-5 advisor
+                # finding: the event used to be recorded before the clone was enqueued, and on the calling thread's current device)
+                small_parts[i] = {name: getattr(r, name).clone() if name == "H" else getattr(r, name) for name in SMALL}
+                ready = torch.cuda.Event()
+                ready.record(torch.cuda.current_stream(dev))
+                downs[i] = pool.submit(download, i, r.W, ready)
+                del Xd, Wd, Hd, r
+            for f in downs.values():
+                f.result()
+        t_sm = _time.perf_counter()
+        for name in SMALL:  # the device is idle now: one copy per small output
+            getattr(out, name)[...] = torch.cat([p[name] for p in small_parts]).cpu().numpy()
+        if _pipeline_trace is not None:
+            _pipeline_trace.append(("small", 0, t_sm, _time.perf_counter()))
+        out.kernel_ms = ms_total
+        return out
+    finally:
+        h.set_batch_hint(0)
+
+
+class HostBatch:
+    """A host-resident batch that is fitted MORE THAN ONCE -- a rank range (``analysis.py:907-912`` fits the same frame for every
+    rank), restarts, a parameter study: the caller's arrays are page-locked ONCE (``hipHostRegister`` in place, no copy) and the
+    registration, the device slots of the transfer pipeline and (``reuse_outputs=True``) the page-locked result arrays are kept
+    from call to call.  What a one-shot ``fit_batched(X_numpy, ...)`` pays on every call -- the driver pinning the caller's pages
+    on the fly for the first chunk's upload (10 - 30 ms of an otherwise idle GPU), device allocations, per-chunk pinning of
+    the result -- is paid once here.
+
+        hb = HostBatch(X, W0, H0)                 # X [B, T, m] float32 / float64, dense
+        r5 = hb.fit(max_iter=500, tol=0)          # NumPy in, NumPy out, chunks uploaded / fitted / downloaded concurrently
+        r6 = hb.fit(W0_k6, H0_k6, max_iter=500)   # other starting points (registered on first sight, remembered by identity)
+        hb.close()                                # or ``with HostBatch(...) as hb:``
+
+    ``reuse_outputs=True``: ``fit`` returns views of result arrays owned by this object, one set per ``n_components``; a later
+    ``fit`` with the same ``n_components`` overwrites them (copy what must survive).  ``keep_on_device=True`` additionally keeps
+    X in HBM after the first call (288 GB hold any batch the reference's users have): later calls upload only W0 / H0.
+    Results are bitwise those of ``fit_batched`` on the same arrays (tests/test_gpu_pipeline.py)."""
+
+    def __init__(self, X, W0=None, H0=None, *, device=None, host_chunk: Optional[int] = None, reuse_outputs: bool = False,
+                 keep_on_device: bool = False):
+        torch = _torch()
+        X = np.asarray(X)
+        if X.ndim != 3 or X.dtype not in (np.float32, np.float64):
+            raise ValueError("HostBatch takes X [B, T, m] float32 / float64 in host memory")
+        self.dev = resolve_device(device)
+        self.X = X
+        self.reuse_outputs = bool(reuse_outputs)
+        self.keep_on_device = bool(keep_on_device)
+        self.host_chunk = host_chunk
+        self._rt = torch.cuda.cudart()
+        self._reg: dict = {}      # id(base buffer) -> (array kept alive, address, bytes)
+        self._slot_cache: dict = {}
+        self._out_cache: dict = {}
+        self._Xd = None
+        self._lock = threading.Lock()
+        self.register_seconds = 0.0
+        self._closed = False
+        self._register(X)
+        self.W0, self.H0 = (None if W0 is None else np.asarray(W0)), (None if H0 is None else np.asarray(H0))
+        for a in (self.W0, self.H0):
+            if a is not None:
+                self._register(a)
+
+    # -- registration -----------------------------------------------------------------------------------------------
+    @staticmethod
+    def _span(a):
+        """(address, bytes) of the memory a dense array occupies (any axis order, positive strides)."""
+        if a.size == 0 or any(st < 0 for st in a.strides):
+            return None
+        lo = a.ctypes.data
+        hi = lo + sum((n - 1) * st for n, st in zip(a.shape, a.strides)) + a.itemsize
+        return lo, hi - lo
+
+    def _register(self, a) -> bool:
+        import time as _time
+
+        span = self._span(a)
+        if span is None or span[0] in self._reg:
+            return span is not None and span[0] in self._reg
+        t0 = _time.perf_counter()
+        try:
+            ok = int(self._rt.cudaHostRegister(span[0], span[1], 0)) == 0
+        except Exception:  # noqa: BLE001 -- an unregistered array still works (pageable copies), only slower
+            ok = False
+        self.register_seconds += _time.perf_counter() - t0
+        if ok:
+            self._reg[span[0]] = (a, span[1])
+        return ok
+
+    def is_registered(self, a) -> bool:
+        span = self._span(np.asarray(a))
+        if span is None:
+            return False
+        for addr, (_, nbytes) in self._reg.items():
+            if addr <= span[0] and span[0] + span[1] <= addr + nbytes:
+                return True
+        return False
+
+    # -- caches used by _fit_batched_pipelined ------------------------------------------------------------------------
+    def _slots(self, key, make):
+        with self._lock:
+            if key not in self._slot_cache:
+                self._slot_cache.clear()  # one geometry at a time: a rank range changes k, the old slots are released
+                self._slot_cache[key] = make()
+            return self._slot_cache[key]
+
+    def _outputs(self, B, T, k, m, dt):
+        key = (B, T, k, m, np.dtype(dt).str)
+        with self._lock:
+            hit = self._out_cache.get(key)
+            if hit is None:
+                raw = np.empty(B * T * k * dt.itemsize + 4096, np.uint8)
+                off = (-raw.ctypes.data) % 4096
+                W = raw[off: off + B * T * k * dt.itemsize].view(dt).reshape(B, T, k)
+                out = BatchedResult(W, np.empty((B, k, m), dt), np.empty((B,), np.int32), np.empty((B,), dt), np.empty((B, 1 + m), dt),
+                                    np.empty((B, m), dt), np.empty((B, m), dt), 0.0)
+                hit = (out, self._register(W), raw)
+                self._out_cache[key] = hit
+            return hit[0], hit[1]
+
+    # -- the call -----------------------------------------------------------------------------------------------------
+    def fit(self, W0=None, H0=None, *, handle: Optional[_lib.Handle] = None, **kw) -> BatchedResult:
+        """``fit_batched(self.X, W0, H0, **kw)`` through the kept registration; ``W0`` / ``H0`` default to the constructor's."""
+        if self._closed:
+            raise ValueError("HostBatch is closed")
+        W0 = self.W0 if W0 is None else np.asarray(W0)
+        H0 = self.H0 if H0 is None else np.asarray(H0)
+        if W0 is None or H0 is None:
+            raise ValueError("no starting point: pass W0 and H0 here or to the constructor")
+        self._register(W0), self._register(H0)
+        B = self.X.shape[0]
+        for name in ("devices", "device", "return_numpy", "overwrite_init", "host_chunk"):
+            if name in kw:
+                raise ValueError(f"HostBatch.fit does not take {name}=")
+        solver_kw = dict(max_iter=kw.pop("max_iter", 200), tol=kw.pop("tol", 1e-4), check_every=kw.pop("check_every", 10),
+                         update_H=kw.pop("update_H", True), l1_reg_W=kw.pop("l1_reg_W", 0.0), l1_reg_H=kw.pop("l1_reg_H", 0.0),
+                         l2_reg_W=kw.pop("l2_reg_W", 0.0), l2_reg_H=kw.pop("l2_reg_H", 0.0), beta_loss=kw.pop("beta_loss", "frobenius"))
+        if kw:
+            raise TypeError(f"unexpected arguments {sorted(kw)}")
+        if self.keep_on_device:
+            return self._fit_resident(W0, H0, solver_kw, handle)
+        chunk = _pipeline_chunk(self.X, self.host_chunk)
+        if not chunk:  # small batches: one upload (from page-locked memory), one fit, one download
+            chunk = B
+        return _fit_batched_pipelined(self.X, W0, H0, self.dev, chunk, solver_kw, handle, ctx=self)
+
+    def _fit_resident(self, W0, H0, solver_kw, handle):
+        torch = _torch()
+        if self._Xd is None:
+            self._Xd = _as_device_tensor(self.X, self.dev)
+        Wd = torch.from_numpy(np.ascontiguousarray(W0)).to(self.dev, self._Xd.dtype, non_blocking=self.is_registered(W0))
+        Hd = torch.from_numpy(np.ascontiguousarray(H0)).to(self.dev, self._Xd.dtype, non_blocking=self.is_registered(H0))
+        r = fit_batched(self._Xd, Wd, Hd, device=self.dev, handle=handle, return_numpy=False, overwrite_init=True, **solver_kw)
+        if self.reuse_outputs:
+            B, T, m = self.X.shape
+            out, pinned = self._outputs(B, T, Hd.shape[1], m, self.X.dtype)
+            torch.from_numpy(out.W).copy_(r.W, non_blocking=pinned)
+            for name in ("H", "n_iter", "reconstruction_err", "vaf", "sse_col", "xsq_col"):
+                getattr(out, name)[...] = getattr(r, name).cpu().numpy()
+            torch.cuda.current_stream(self.dev).synchronize()
+            out.kernel_ms = r.kernel_ms
+            return out
+        return BatchedResult(*(t.cpu().numpy() for t in (r.W, r.H, r.n_iter, r.reconstruction_err, r.vaf, r.sse_col, r.xsq_col)), r.kernel_ms)
+
+    def close(self):
+        """Give the page locks and the device memory back (idempotent).  The arrays themselves are the caller's, untouched."""
+        if self._closed:
+            return
+        self._closed = True
+        try:
+            _torch().cuda.synchronize(self.dev)
+        except Exception:  # noqa: BLE001
+            pass
+        for addr in list(self._reg):
+            try:
+                self._rt.cudaHostUnregister(addr)
+            except Exception:  # noqa: BLE001
+                pass
+        self._reg.clear()
+        self._slot_cache.clear()
+        self._out_cache.clear()
+        self._Xd = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
 
 
 def _gather_batched(parts, as_numpy: bool, ragged: bool = False) -> BatchedResult:

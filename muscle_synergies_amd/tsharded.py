@@ -175,14 +175,16 @@ class HipShardOps:
         return self
 
     def fit_native(self, *, max_iter: int = 200, tol: float = 1e-4, check_every: int = 10, group=None,
-                   all_reduce: Optional[Callable] = None) -> "ShardedResult":
+                   all_reduce: Optional[Callable] = None, collective_fn=None) -> "ShardedResult":
         """The whole sharded fit inside the library (``hipnmf_fit_tsharded_*``): same loop, same kernels and the same
         collective as :func:`fit_tsharded`, but driven from C++ -- the per-iteration Python overhead (three ctypes
         calls, a tensor clone) is gone and the entry point is usable from any host language.  ``all_reduce(tensor)``
         must sum ``tensor`` in place over all ranks; the default is ``torch.distributed.all_reduce`` over ``group``
-        when a process group is initialised, nothing otherwise.  Collective: every rank calls it."""
+        when a process group is initialised, nothing otherwise.  Collective: every rank calls it.
+        ``collective_fn``: a ready-made C callback (``_lib.ALLREDUCE_FN``, e.g. ``rccl.RcclComm.callback()``: ``ncclAllReduce``
+        on the stream the library hands over) used instead of ``all_reduce`` -- no Python tensor, no torch.distributed."""
         torch = self.torch
-        if all_reduce is None:
+        if all_reduce is None and collective_fn is None:
             import torch.distributed as dist
 
             if dist.is_available() and dist.is_initialized():
@@ -204,7 +206,10 @@ class HipShardOps:
                 failure.append(e)
                 return 1
 
-        cb = _lib.ALLREDUCE_FN(_cb) if all_reduce is not None else _lib.ALLREDUCE_FN()  # NULL: single rank
+        if collective_fn is not None:
+            cb = collective_fn
+        else:
+            cb = _lib.ALLREDUCE_FN(_cb) if all_reduce is not None else _lib.ALLREDUCE_FN()  # NULL: single rank
         p = _lib.Problem.from_buffer_copy(self.p)
         p.max_iter, p.tol, p.check_every = int(max_iter), float(tol), int(check_every)
         err = torch.empty((self.B,), dtype=dtype, device=dev)
@@ -377,3 +382,184 @@ def fit_tsharded_hip(X_local, W_local, H, *, max_iter=200, tol=1e-4, check_every
     (``beta_loss='kullback-leibler'`` among the keyword arguments selects that loss)."""
     ops = HipShardOps(X_local, W_local, H, update_H=update_H, device=device, **reg)
     return fit_tsharded(ops, max_iter=max_iter, tol=tol, check_every=check_every, update_H=update_H, group=group)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# Config #5 in ONE process: one host thread + handle per device, the per-iteration sums added through host memory.
+class HostStagedAllReduce:
+    """SUM all-reduce between the shard threads of one process (``fit_tsharded_devices``): every participant copies its
+    ``k*m + k*k`` (or ``2m``) values into its slot of one pinned host buffer, a barrier, every participant adds ALL slots in slot
+    order -- so each gets bitwise the same sum, whatever the arrival order -- and takes the result back to its device; a second
+    barrier frees the slots.  Two tiny copies and two thread barriers per iteration (tens of microseconds) against
+    milliseconds of shard pass: the same exchange step RCCL performs between processes (``fit_tsharded``), for the caller
+    who has one process -- a notebook -- and several GPUs.  Works with the same device named twice."""
+
+    def __init__(self, n: int, pinned: bool = True):
+        import threading
+
+        self.n = int(n)
+        self.pinned = pinned
+        self.barrier = threading.Barrier(self.n)
+        self.slots = None
+        self.calls = 0
+        self.elements = 0
+        self._lock = threading.Lock()
+
+    def _ensure(self, t):
+        import torch
+
+        numel = t.numel()
+        with self._lock:
+            if self.slots is None or self.slots.shape[1] < numel or self.slots.dtype != t.dtype:
+                buf = torch.empty((self.n, max(numel, 256)), dtype=t.dtype)
+                if self.pinned and t.is_cuda:
+                    buf = buf.pin_memory()
+                self.slots = buf
+        return self.slots
+
+    def reducer(self, index: int):
+        """The ``all_reduce(tensor) -> tensor`` callable of participant ``index`` (in place on ``tensor``)."""
+        import torch
+
+        def all_reduce(t):
+            numel = t.numel()
+            if index == 0:
+                self._ensure(t)
+                self.calls += 1
+                self.elements += numel
+            self.barrier.wait()  # slots allocated; the previous round's readers are done
+            slot = self.slots[index, :numel]
+            slot.copy_(t.reshape(-1), non_blocking=False)  # device -> pinned host, waited for (orders behind the shard pass)
+            self.barrier.wait()  # all slots written
+            total = self.slots[0, :numel].clone()
+            for j in range(1, self.n):  # fixed order: every participant computes the very same bits
+                total += self.slots[j, :numel]
+            t.copy_(total.reshape(t.shape).to(t.device, non_blocking=False) if t.is_cuda else total.reshape(t.shape))
+            return t
+
+        return all_reduce
+
+    def abort(self):
+        self.barrier.abort()
+
+
+def fit_tsharded_devices(X, W0, H0, *, devices, max_iter: int = 200, tol: float = 1e-4, check_every: int = 10,
+                         update_H: bool = True, native: bool = False, subshard: int = 25_000_000, beta_loss="frobenius",
+                         l1_reg_W: float = 0.0, l1_reg_H: float = 0.0, l2_reg_W: float = 0.0, l2_reg_H: float = 0.0,
+                         _ops_factory=None) -> ShardedResult:
+    """BASELINE.json config #5 from ONE process: factorise one long recording ``X [T, m]`` (host memory: NumPy or a CPU
+    tensor -- what the reference holds, ``analysis.py:862-863``) with its rows sharded over ``devices`` -- device indices,
+    ``"cuda:i"`` strings or ``"all"``; the same device may be named twice, which is how the exchange is exercised per slice
+    on a one-GPU box.  One host thread, one engine handle and one copy of ``H`` per entry; per iteration each thread runs its
+    shard pass and the ``k*m + k*k`` sums are added through pinned host memory (:class:`HostStagedAllReduce`), then every
+    replica of ``H`` takes the same update.  ``native=True`` drives each shard's loop inside the library
+    (``hipnmf_fit_tsharded_*`` with the host-staged sum as its collective callback).  A device's rows beyond ``subshard``
+    (< 2 GiB of X per shard) are kept as sub-shards sharing one ``H`` (:class:`MultiShardOps`; narrow shapes).
+
+    Returns a :class:`ShardedResult` whose ``W_local`` is the WHOLE ``W [1, T, k]`` gathered on the host in row order
+    (NumPy when NumPy went in), ``H [1, k, m]``, ``reconstruction_err [1]``, ``vaf [1, 1 + m]`` on the host."""
+    import threading
+
+    import numpy as np
+    import torch
+
+    from .multi_gpu import resolve_devices
+
+    as_numpy = isinstance(X, np.ndarray)
+    Xt, Wt, Ht = torch.as_tensor(X), torch.as_tensor(W0), torch.as_tensor(H0)
+    if Xt.dim() != 2 or Wt.dim() != 2 or Ht.dim() != 2:
+        raise ValueError("fit_tsharded_devices takes ONE recording: X [T, m], W0 [T, k], H0 [k, m]")
+    T, m = Xt.shape
+    k = Ht.shape[0]
+    if Wt.shape != (T, k) or Ht.shape != (k, m):
+        raise ValueError(f"shapes do not agree: X {tuple(Xt.shape)}, W0 {tuple(Wt.shape)}, H0 {tuple(Ht.shape)}")
+    devs = resolve_devices(devices) if _ops_factory is None else list(devices)
+    if not devs:
+        raise ValueError("devices must name at least one GPU")
+    bounds = [b for b in shard_bounds(T, len(devs)) if b[1] > b[0]]
+    devs = devs[: len(bounds)]
+    n = len(bounds)
+    red = HostStagedAllReduce(n, pinned=_ops_factory is None)
+    reg = dict(l1_reg_W=l1_reg_W, l1_reg_H=l1_reg_H, l2_reg_W=l2_reg_W, l2_reg_H=l2_reg_H)
+    results: list = [None] * n
+    errors: list = [None] * n
+
+    def make_ops(i, lo, hi, dev):
+        if _ops_factory is not None:
+            return _ops_factory(Xt[lo:hi], Wt[lo:hi], Ht, i)
+        rows = hi - lo
+        wide = _is_wide(m, k, beta_loss != "frobenius")
+        if rows <= subshard or wide:
+            return HipShardOps(Xt[lo:hi], Wt[lo:hi], Ht, update_H=update_H, device=torch.device("cuda", dev), beta_loss=beta_loss, **reg)
+        d = torch.device("cuda", dev)
+        Hd = Ht.to(d).unsqueeze(0).contiguous().clone()
+        shards, t = [], lo
+        while t < hi:
+            nr = min(subshard, hi - t)
+            ld = (nr + 3) // 4 * 4
+            Xc = torch.zeros((1, m, ld), dtype=Xt.dtype, device=d)
+            Xc[0, :, :nr] = Xt[t:t + nr].to(d).t()
+            Wc = torch.zeros((1, k, ld), dtype=Xt.dtype, device=d)
+            Wc[0, :, :nr] = Wt[t:t + nr].to(d, Xt.dtype).t()
+            sh = HipShardOps.from_native(Xc, Wc, Hd, T=nr, update_H=update_H, **reg)
+            sh._rows = nr
+            shards.append(sh)
+            t += nr
+        return MultiShardOps(shards)
+
+    def gather_w(ops, r):
+        if isinstance(ops, MultiShardOps):  # native sub-shards: [1, k, ld] component-major each
+            return torch.cat([sh.Wc[0, :, : sh._rows].t().cpu() for sh in ops.shards], dim=0).unsqueeze(0)
+        w = r.W_local
+        return w.detach().cpu() if hasattr(w, "detach") else torch.as_tensor(w)
+
+    def run(i):
+        lo, hi = bounds[i]
+        ops = None
+        try:
+            import contextlib
+
+            side = contextlib.nullcontext()
+            if _ops_factory is None:
+                torch.cuda.set_device(devs[i])
+                # a stream of this thread's own: torch ops and the library's kernels (HipShardOps binds its handle to the
+                # thread's current stream) are ordered on it, and two shards that share a device do not serialise on its default stream
+                side = torch.cuda.stream(torch.cuda.Stream(torch.device("cuda", devs[i])))
+            with side:
+                ops = make_ops(i, lo, hi, devs[i])
+                ar = red.reducer(i)
+                if native and hasattr(ops, "fit_native"):
+                    r = ops.fit_native(max_iter=max_iter, tol=tol, check_every=check_every, all_reduce=ar)
+                else:
+                    r = fit_tsharded(ops, max_iter=max_iter, tol=tol, check_every=check_every, update_H=update_H, all_reduce=ar)
+                host = lambda t: t.detach().cpu() if hasattr(t, "detach") else torch.as_tensor(t)  # noqa: E731
+                results[i] = (gather_w(ops, r), host(r.H), int(r.n_iter), host(r.reconstruction_err), host(r.vaf))
+        except BaseException as e:  # noqa: BLE001 -- re-raised by the caller's thread
+            errors[i] = e
+            red.abort()  # the other participants leave their barrier with BrokenBarrierError instead of waiting for ever
+        finally:
+            for sh in (getattr(ops, "shards", None) or ([ops] if ops is not None else [])):
+                h = getattr(sh, "handle", None)
+                if h is not None:
+                    h.close()
+
+    threads = [threading.Thread(target=run, args=(i,), name=f"hipnmf-tshard-{i}") for i in range(n)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    first = [e for e in errors if e is not None and not isinstance(e, threading.BrokenBarrierError)] or [e for e in errors if e is not None]
+    if first:
+        raise first[0]
+    W = torch.cat([r[0].reshape(1, -1, k) for r in results], dim=1)
+    H, n_iter, err, vaf = results[0][1], results[0][2], results[0][3], results[0][4]
+    for r in results[1:]:  # the replicas took the same sums in the same order: they must agree to the bit
+        if not torch.equal(r[1], H) or r[2] != n_iter:
+            raise RuntimeError("fit_tsharded_devices: the replicas of H diverged between shard threads")
+    out = ShardedResult(W, H.reshape(1, k, m), n_iter, err.reshape(-1), vaf.reshape(1, -1))
+    out.collective = {"backend": "host-staged sum between shard threads of one process", "participants": n,
+                      "all_reduce_calls": red.calls, "elements": red.elements}
+    if as_numpy:
+        out.W_local, out.H, out.reconstruction_err, out.vaf = (out.W_local.numpy(), out.H.numpy(), out.reconstruction_err.numpy(),
+                                                               out.vaf.numpy())
+    return out

@@ -10,7 +10,7 @@ from muscle_synergies_amd.engine import make_problem
 from muscle_synergies_amd.preprocess import EnvelopeParams, SosfiltParams
 
 lib = _lib.load()
-assert lib.hipnmf_version() == 210
+assert lib.hipnmf_version() == 211
 h = ctypes.c_void_p()
 rc = lib.hipnmf_create(0, ctypes.byref(h))
 have_gpu = rc == 0
@@ -61,9 +61,11 @@ assert lib.hipnmf_last_kernel(None) == b""
 ms = ctypes.c_float()
 assert lib.hipnmf_last_kernel_ms(None, ctypes.byref(ms)) < 0
 assert lib.hipnmf_set_stream(None, None) < 0 and lib.hipnmf_set_async(None, 1) < 0
+assert lib.hipnmf_set_batch_hint(None, 4) < 0
 if have_gpu:
     assert lib.hipnmf_set_tuning(h, 300, 0, 0) < 0 and lib.hipnmf_set_tuning(h, 512, 0, 9) < 0
     assert lib.hipnmf_set_tuning(h, 512, 0, 5) == 0
+    assert lib.hipnmf_set_batch_hint(h, -1) < 0 and lib.hipnmf_set_batch_hint(h, 4096) == 0 and lib.hipnmf_set_batch_hint(h, 0) == 0
     assert lib.hipnmf_destroy(h) == 0
 assert lib.hipnmf_destroy(None) <= 0
 print("abi-host-drive: ok", "(gpu present)" if have_gpu else "(no gpu)")
