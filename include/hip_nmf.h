@@ -87,6 +87,11 @@ int hipnmf_version(void);
 const char* hipnmf_last_error(void);
 int hipnmf_device_count(void);                            /* <0 on error (no ROCm device / driver)     */
 int hipnmf_create(int device, hipnmf_handle** out);       /* own stream + workspace on `device`        */
+/* Waits for the handle's own stream, frees its workspaces, events and stream.  Must not race with a call that uses `h`.
+ * Process exit: the first hipnmf_create registers an exit handler (it runs BEFORE the HIP runtime's own, registered earlier);
+ * a hipnmf_destroy that arrives after it -- a host freeing objects from static destructors or a garbage collector at interpreter
+ * teardown -- releases the host side only and returns 0 without calling into the runtime; so does one that finds the runtime
+ * deinitialised.  (The Python host closes every handle it still caches from an `atexit` hook: muscle_synergies_amd/_lib.py.) */
 int hipnmf_destroy(hipnmf_handle* h);
 #define HIPNMF_STREAM_NULL ((void*)1)                    /* the device's default (null) HIP stream    */
 int hipnmf_set_stream(hipnmf_handle* h, void* hip_stream);/* NULL restores the handle's own stream     */

@@ -91,6 +91,88 @@ _lock = threading.Lock()
 _lib = None
 
 
+class _Gate:
+    """Counts the native calls in flight and, once :func:`shutdown` has begun, parks every OTHER thread that tries to start one.
+
+    Why: a thread that is inside a HIP call while the main thread runs the process's exit handlers takes the process down
+    (``terminate called without an active exception`` -> SIGABRT, 1 run in 8 with a daemon thread fitting in a loop:
+    profiles/r06_abort_hunt.md) -- the HIP runtime tears itself down under it.  The interpreter joins its non-daemon threads before
+    ``atexit`` runs but knows nothing about daemon threads; with the gate the exit hook lets the call that is in flight return
+    (milliseconds), keeps the thread from starting another one, and only then destroys the handles."""
+
+    def __init__(self):
+        self.cond = threading.Condition(threading.Lock())
+        self.inflight = 0
+        self.closing = False
+        self.closer = None
+
+    def enter(self):
+        with self.cond:
+            if self.closing and threading.get_ident() != self.closer:
+                park = True
+            else:
+                park = False
+                self.inflight += 1
+        if park:  # the process is exiting: this (daemon) thread must not touch the runtime again
+            import time
+
+            while True:
+                time.sleep(3600)
+
+    def leave(self):
+        with self.cond:
+            self.inflight -= 1
+            if self.inflight == 0:
+                self.cond.notify_all()
+
+    def close(self, timeout: float) -> bool:
+        """Begin the shutdown; True when no native call of another thread is left in flight after at most ``timeout`` s."""
+        with self.cond:
+            self.closing = True
+            self.closer = threading.get_ident()
+            return self.cond.wait_for(lambda: self.inflight == 0, timeout)
+
+
+_gate = _Gate()
+
+
+class _Fn:
+    """A ctypes function behind the gate; ``argtypes`` / ``restype`` read and written through."""
+
+    __slots__ = ("_f",)
+
+    def __init__(self, f):
+        object.__setattr__(self, "_f", f)
+
+    def __call__(self, *args):
+        _gate.enter()
+        try:
+            return self._f(*args)
+        finally:
+            _gate.leave()
+
+    def __getattr__(self, name):
+        return getattr(self._f, name)
+
+    def __setattr__(self, name, value):
+        setattr(self._f, name, value)
+
+
+class _GatedLib:
+    """``ctypes.CDLL`` whose functions are :class:`_Fn` objects (what :func:`load` returns)."""
+
+    def __init__(self, cdll):
+        self._cdll = cdll
+        self._fns: dict = {}
+
+    def __getattr__(self, name):
+        fns = self.__dict__["_fns"]
+        f = fns.get(name)
+        if f is None:
+            f = fns[name] = _Fn(getattr(self.__dict__["_cdll"], name))
+        return f
+
+
 def _declare(lib):
     vp, ip = ctypes.c_void_p, ctypes.c_int
     pp = ctypes.POINTER(Problem)
@@ -172,7 +254,7 @@ def load():
 
         lib = ctypes.CDLL(path)
         _declare(lib)
-        _lib = lib
+        _lib = _GatedLib(lib)
         # registered AFTER torch's import, so (atexit is last-in-first-out) it runs BEFORE any exit handler of torch: every
         # handle this process still caches is destroyed while the HIP runtime torch shares with us is fully alive
         atexit.register(shutdown)
@@ -241,6 +323,8 @@ class Handle:
         """Destroy the native handle (stream, events, workspaces).  After :func:`shutdown` (interpreter exit) this is a no-op:
         a handle that is only collected during module teardown must not call into a HIP runtime that may be unloading."""
         h = getattr(self, "_h", None)
+        if _gate.closing and threading.get_ident() != _gate.closer:
+            return  # the exit hook owns the teardown now (a destructor must never park its thread at the gate)
         if h is not None and h and not _closed:
             self._h = ctypes.c_void_p()
             _live.discard(self)
@@ -274,14 +358,16 @@ def shutdown() -> None:
             hook()
         except Exception:  # noqa: BLE001
             pass
+    # no other thread starts a native call from here on; the ones in flight (a daemon thread inside a fit) get 10 s to return
+    drained = _gate.close(10.0)
     with _handles_lock:
         cached = list(_handles.values())
         _handles.clear()
         others = [h for h in list(_live) if h not in cached]
-    # a handle whose owner thread is still running (a daemon thread inside a call: the interpreter does not join those) may be
-    # in use this very moment: it is left alone -- its device memory goes with the process -- and never touched again
+    # not drained (a call that does not come back): a handle whose owner thread is still running may be in use this very moment --
+    # it is left alone, its device memory goes with the process, and it is never touched again
     me = threading.get_ident()
-    running = {t.ident for t in threading.enumerate() if t.is_alive()} - {me}
+    running = set() if drained else {t.ident for t in threading.enumerate() if t.is_alive()} - {me}
     for h in cached + others:
         if getattr(h, "_owner", me) in running:
             continue

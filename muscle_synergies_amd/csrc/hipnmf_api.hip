@@ -729,8 +729,21 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
     HIP_TRY(hipMemsetAsync(c.part, 0, 2 * sizeof(real) * (size_t)B * 2 * coop_S * ks->NACC, st));
     void* args[] = {&c};
     coop_cus.take(h->device, (c.coop_xcd ? 8 * coop_S : coop_S) * B, h->num_cu, st);
-    const hipError_t e = hipLaunchCooperativeKernel(kern, dim3(c.coop_xcd ? 8 * coop_S : coop_S, B), dim3(coop_threads), args,
-                                                    (unsigned)coop_smem, st);
+    // An ORDINARY launch since round 6.  hipLaunchCooperativeKernel bought nothing the kernel uses -- no grid-wide sync object (the
+    // exchange is the kernel's own tagged-granule protocol with a time-out and an abort flag), and co-residency is arranged here:
+    // at most one workgroup per CU (S B <= CUs, each takes most of a CU's LDS) out of a budget shared by the process's handles
+    // (CoopBudget) -- and it cost a process: on this runtime (ROCm 7.x CLR / ROCr) cooperative launches issued from two host
+    // threads (two streams) make the HSA runtime's shutdown, run from libamdhip64's exit handler, dereference freed memory:
+    // SIGSEGV at exit() after every call had returned correct results (profiles/r06_abort_hunt.md: 2 threads 3 / 3, native
+    // backtrace inside libhsa-runtime64.so <- libamdhip64.so <- __run_exit_handlers; one thread, or HIPNMF_COOP=0: never).
+    // HIPNMF_COOP_LAUNCH=1 restores the cooperative launch API (A/B and the regression probe tools/probes/exit_bt.sh).
+    static const bool coop_api = [] {
+      const char* e = getenv("HIPNMF_COOP_LAUNCH");
+      return e && atoi(e) != 0;
+    }();
+    const dim3 cgrid(c.coop_xcd ? 8 * coop_S : coop_S, B);
+    const hipError_t e = coop_api ? hipLaunchCooperativeKernel(kern, cgrid, dim3(coop_threads), args, (unsigned)coop_smem, st)
+                                  : hipLaunchKernel(kern, cgrid, dim3(coop_threads), args, coop_smem, st);
     coop_xcd_used = c.coop_xcd != 0;
     if (e == hipSuccess) {
       coop_done = true;
@@ -741,7 +754,7 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
       coop_cus.drop();
       (void)hipGetLastError();  // not launchable as a cooperative grid on this device: use the regular paths
       if (h->variant == 3)
-        return fail(HIPNMF_ERR_HIP, "hipLaunchCooperativeKernel failed: %s", hipGetErrorString(e));
+        return fail(HIPNMF_ERR_HIP, "launch of the cooperative multi-workgroup kernel failed: %s", hipGetErrorString(e));
     }
   }
   if (coop_done) {

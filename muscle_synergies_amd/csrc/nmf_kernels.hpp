@@ -579,6 +579,70 @@ __device__ __forceinline__ void update_tile_kl(RowTile<real, G, CH, K>& t, const
                                                real (&accA)[K][CH], real (&accB)[Cfg<real, G, CH, K>::NB],
                                                real l1w, real l2w, bool update_h) {
   const int g = ma.g;
+#ifndef HIPNMF_KL_NO_PK
+  if constexpr (G == 1 && sizeof(real) == 4 && (CH % 2) == 0) {
+    // Row-per-lane fp32 (round 6): the four K x CH products of the iteration -- W H, Q H^T, W' H, W'^T Q' -- as v_pk_fma_f32 over
+    // channel PAIRS (the scalar factor of a pair is an op_sel splat, no extra move): 160 + 5 packed instead of 320 scalar
+    // FMAs per row, and one packed multiply per pair of quotients.  Explicit two-element vectors: -fno-slp-vectorize stays on
+    // (left to itself the vectoriser packs the Frobenius tile with ~40 registers of shuffles, profiles/README.md round 1).
+    // The sums over a row's channels now add the even and the odd channels' partial sums at the end: another fixed order.
+    using f2 = float __attribute__((ext_vector_type(2)));
+    constexpr int P = CH / 2;
+    auto hv = [&](int c, int j) __attribute__((always_inline)) -> f2 { return f2{h[c][2 * j], h[c][2 * j + 1]}; };
+    auto quot = [&](const f2 (&rec)[P], f2 (&qo)[P]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int j = 0; j < P; ++j) {
+        const f2 r = f2{__builtin_amdgcn_rcpf(kl_floor(rec[j].x)), __builtin_amdgcn_rcpf(kl_floor(rec[j].y))};
+        qo[j] = f2{t.x[2 * j][0], t.x[2 * j + 1][0]} * r;
+      }
+    };
+    f2 rec[P], q2[P];
+#pragma unroll
+    for (int j = 0; j < P; ++j) rec[j] = f2{t.w[0], t.w[0]} * hv(0, j);
+#pragma unroll
+    for (int c = 1; c < K; ++c)
+#pragma unroll
+      for (int j = 0; j < P; ++j) rec[j] = __builtin_elementwise_fma(f2{t.w[c], t.w[c]}, hv(c, j), rec[j]);
+    quot(rec, q2);
+    real wn[K], den[K], num[K], quo[K];
+#pragma unroll
+    for (int c = 0; c < K; ++c) {
+      f2 s2 = q2[0] * hv(c, 0);
+#pragma unroll
+      for (int j = 1; j < P; ++j) s2 = __builtin_elementwise_fma(q2[j], hv(c, j), s2);
+      num[c] = s2.x + s2.y;
+      real d = hht[0][c];
+      d = d + l1w;
+      d = d + l2w * t.w[c];
+      den[c] = (d == (real)0) ? eps_val<real>() : d;
+    }
+    quotients<K>(num, den, quo);
+#pragma unroll
+    for (int c = 0; c < K; ++c) wn[c] = t.w[c] * quo[c];
+#pragma unroll
+    for (int c = 0; c < K; ++c) t.w[c] = wn[c];
+    if (update_h) {
+#pragma unroll
+      for (int j = 0; j < P; ++j) rec[j] = f2{wn[0], wn[0]} * hv(0, j);
+#pragma unroll
+      for (int c = 1; c < K; ++c)
+#pragma unroll
+        for (int j = 0; j < P; ++j) rec[j] = __builtin_elementwise_fma(f2{wn[c], wn[c]}, hv(c, j), rec[j]);
+      quot(rec, q2);
+#pragma unroll
+      for (int c = 0; c < K; ++c)
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+          const f2 a2 = __builtin_elementwise_fma(f2{wn[c], wn[c]}, q2[j], f2{accA[c][2 * j], accA[c][2 * j + 1]});
+          accA[c][2 * j] = a2.x;
+          accA[c][2 * j + 1] = a2.y;
+        }
+#pragma unroll
+      for (int c = 0; c < K; ++c) accB[c] += wn[c];
+    }
+    return;
+  }
+#endif
   // q = X / max(WH, EPSILON) for the group's G rows restricted to this lane's channels
   real q[CH][G];
   static_for<G>([&](auto R) {

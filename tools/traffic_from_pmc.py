@@ -21,7 +21,7 @@ ap.add_argument("--m", type=int, default=16)
 ap.add_argument("--k", type=int, default=5)
 ap.add_argument("--x-layout", default="row")
 ap.add_argument("--commit", default=os.environ.get("HIPNMF_SOURCE_COMMIT", "unknown"), help="source commit the library was built from")
-ap.add_argument("--round", default=os.environ.get("HIPNMF_ROUND", "r05"))
+ap.add_argument("--round", default=os.environ.get("HIPNMF_ROUND", "r06"))
 a, _ = ap.parse_known_args()
 
 
@@ -43,11 +43,21 @@ kname, fetch_kib, n1 = biggest("fetch", "FETCH_SIZE")
 _, write_kib, n2 = biggest("write", "WRITE_SIZE")
 short = kname.split("hipnmf::", 1)[1].split("(", 1)[0].replace(" ", "")
 per_fit = 1
-if short.startswith("big1_pass_kernel"):  # row-sliced path: one launch per ITERATION; the library names it so (hipnmf_last_kernel)
+# the name bench.py itself reported for this run (hipnmf_last_kernel): "[sliced]" = one launch of the pass kernel per ITERATION
+reported = None
+try:
+    for line in open(os.path.join(a.dir, "fetch.log")):
+        if line.startswith("{"):
+            reported = json.loads(line)["roofline"]["kernel"]
+except Exception:  # noqa: BLE001
+    pass
+if short.startswith("big1_pass_kernel") or (reported and reported.endswith("[sliced]") and reported.startswith(short)):
     short += "[sliced]"
     per_fit = a.iters  # bench.py's "launch" is the whole fit (HIP events around it): its iterations' launches added up
     fetch_kib *= per_fit
     write_kib *= per_fit
+if reported and reported != short:
+    print(f"note: bench.py reported {reported!r}, the PMC rows belong to {short!r}", file=sys.stderr)
 entry = {
     "kernel": short, "batch": a.batch, "iters": a.iters, "T": a.T, "m": a.m, "k": a.k, "x_layout": a.x_layout,
     "fetch_size_kib_avg": fetch_kib, "write_size_kib_avg": write_kib, "launches_averaged": [n1, n2],
