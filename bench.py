@@ -1007,6 +1007,12 @@ def main():
         raise SystemExit("--gpus must be >= 1")
     if a.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         return launch_ranks(a)  # invoked directly: be the launcher (under torchrun the environment is there already)
+    # ONE JSON line on stdout, whatever the libraries under us print: file descriptor 1 is pointed at stderr for the life of the
+    # process (RCCL writes a version banner to it when the first communicator comes up; C stdio flushes it at exit, after the
+    # line) and the line itself goes to a saved copy of the real stdout
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     cx = Ctx(a)
     if a.dry_orchestration and a.dry_fail_rank == cx.rank:
         raise SystemExit(7)
@@ -1059,7 +1065,8 @@ def main():
         if res.get("host_resident"):
             out["value_host_resident"] = res["host_resident"]["matrix_iterations_per_s"]
             out["host_resident"] = res["host_resident"]
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if cx.parity is not None:
         cx.parity.close()
     cx.finish()

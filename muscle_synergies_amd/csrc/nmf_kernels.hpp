@@ -580,12 +580,15 @@ __device__ __forceinline__ void update_tile_kl(RowTile<real, G, CH, K>& t, const
                                                real l1w, real l2w, bool update_h) {
   const int g = ma.g;
 #ifndef HIPNMF_KL_NO_PK
-  if constexpr (G == 1 && sizeof(real) == 4 && (CH % 2) == 0) {
-    // Row-per-lane fp32 (round 6): the four K x CH products of the iteration -- W H, Q H^T, W' H, W'^T Q' -- as v_pk_fma_f32 over
-    // channel PAIRS (the scalar factor of a pair is an op_sel splat, no extra move): 160 + 5 packed instead of 320 scalar
-    // FMAs per row, and one packed multiply per pair of quotients.  Explicit two-element vectors: -fno-slp-vectorize stays on
-    // (left to itself the vectoriser packs the Frobenius tile with ~40 registers of shuffles, profiles/README.md round 1).
-    // The sums over a row's channels now add the even and the odd channels' partial sums at the end: another fixed order.
+  if constexpr (G == 1 && sizeof(real) == 4 && CH == 8) {
+    // Row-per-lane fp32, 7..8 channels (round 6): the four K x CH products of the iteration -- W H, Q H^T, W' H, W'^T Q' -- as
+    // v_pk_fma_f32 over channel PAIRS (the scalar factor of a pair is an op_sel splat, no extra move): half the FMA instructions per
+    // row and one packed multiply per pair of quotients.  Explicit two-element vectors: -fno-slp-vectorize stays on (left to itself
+    // the vectoriser packs the Frobenius tile with ~40 registers of shuffles, profiles/README.md round 1).  Measured on one box
+    // (profiles/r06_kl_narrow_pk_ab.log, 2048+ matrices): 8 x 4 at 2 500 rows 41.3 -> 44.6 M matrix-it/s; 16 x 5 at 10 000 rows
+    // 6.49 -> 5.21 (the pairs cost 27 more spilled registers at the 256-register cap and a packed FMA has no rate advantage once
+    // two waves share the SIMD): so CH == 8 only.
+    // The sums over a row's channels add the even and the odd channels' partial sums at the end: another fixed order.
     using f2 = float __attribute__((ext_vector_type(2)));
     constexpr int P = CH / 2;
     auto hv = [&](int c, int j) __attribute__((always_inline)) -> f2 { return f2{h[c][2 * j], h[c][2 * j + 1]}; };

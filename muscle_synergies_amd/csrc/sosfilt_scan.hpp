@@ -560,10 +560,13 @@ sosfilt_chunk_kernel(SosArgs a, const double* __restrict__ tab, int ns, int regi
 
 #ifdef HIPNMF_SOS_TIMING  // development build (tools/sos_phase_timing.py): shader-clock stamps at the phase boundaries, written
   long long stamp[9];     // over the head of the output
+  long long sub[4] = {0, 0, 0, 0};  // finer stamps inside phase 2 (written behind the nine phase durations)
+#define SOS_SUB(i) sub[i] = (long long)__builtin_readcyclecounter()
   int n_stamp = 0;
 #define SOS_STAMP() stamp[n_stamp++] = (long long)__builtin_readcyclecounter()
 #else
 #define SOS_STAMP() ((void)0)
+#define SOS_SUB(i) ((void)0)
 #endif
   SOS_STAMP();  // 0: start
   double c[NSP][5];
@@ -597,6 +600,7 @@ sosfilt_chunk_kernel(SosArgs a, const double* __restrict__ tab, int ns, int regi
       if constexpr (NT == 512) tot += (misc[4] + misc[5]) + (misc[6] + misc[7]);
       mean = (real)(tot / (double)T);
     }
+    SOS_SUB(0);  // mean known
 #pragma unroll
     for (int k = 0; k < C; ++k) {
       const int j = t + k * NT;
@@ -604,11 +608,13 @@ sosfilt_chunk_kernel(SosArgs a, const double* __restrict__ tab, int ns, int regi
       xs[j < T ? edge + j : L] = pv;  // (slot L: a dump slot behind the series -- a branch per store would serialise them)
     }
     __syncthreads();
+    SOS_SUB(1);  // samples staged in LDS
     for (int e = t; e < edge; e += NT) {  // scipy's odd extension about the end samples, in the samples' precision
       xs[e] = (real)2 * xs[edge] - xs[2 * edge - e];
       xs[edge + T + e] = (real)2 * xs[edge + T - 1] - xs[edge + T - 2 - e];
     }
     __syncthreads();
+    SOS_SUB(2);  // odd extension built
     const real* __restrict__ mine = xs + C * t;
     const int nval = L - C * t;  // positions of this chunk inside the extended series (zeros behind it)
 #pragma unroll
@@ -723,9 +729,14 @@ sosfilt_chunk_kernel(SosArgs a, const double* __restrict__ tab, int ns, int regi
   if (t == 0) {
     for (int i = 0; i < 8; ++i) yr[i] = (real)(stamp[i + 1] - stamp[i]);
     yr[8] = (real)(stamp[0] & 0xffffff);  // (low bits of the start time: order of the workgroups)
+    yr[9] = (real)(sub[0] - stamp[1]);    // phase 2 in four parts: mean | staging stores + barrier | extension + barrier | chunk reads
+    yr[10] = (real)(sub[1] - sub[0]);     // (the stamps are not scheduling barriers: the compiler moves the forward zero-state
+    yr[11] = (real)(sub[2] - sub[1]);     //  recurrence up into the fourth part, next to the LDS reads it consumes)
+    yr[12] = (real)(stamp[2] - sub[2]);
   }
 #endif
 #undef SOS_STAMP
+#undef SOS_SUB
 }
 
 // =================================================================================================================================

@@ -28,7 +28,7 @@ PMC_KERNEL=fit_persistent bash tools/pmc_passes.sh r06_headline_f64 --dtype floa
 # the compute ceiling with X served from L2 (all restarts of a trial share X)
 python3 tools/shared_x_probe.py > $O/r06_shared_x_probe.log 2>&1
 # KL narrow: packed FMAs (default build) vs scalar (-DHIPNMF_KL_NO_PK variant), same box
-for lib in "" "$R/muscle_synergies_amd/lib/libhip_nmf_klnopk.so"; do
+for lib in "$R/muscle_synergies_amd/lib/libhip_nmf.so" "$R/muscle_synergies_amd/lib/libhip_nmf_klnopk.so"; do
   for rep in 1 2; do HIPNMF_LIBRARY=$lib python3 tools/quick_bench.py --batch 2048 --iters 200 --threads 512 --loss kullback-leibler --rowmajor --reps 2 2>&1 | tail -1 | sed "s|^|KL narrow lib=${lib:-default(pk)} |"; done
 done > $O/r06_kl_narrow_pk_ab.log 2>&1
 cat $O/r06_kl_narrow_pk_ab.log

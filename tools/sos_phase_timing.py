@@ -24,7 +24,7 @@ for B in (a.B, max(1, 256 // a.m)):  # the batch, then one workgroup per CU (eac
     for rep in range(2):
         y = sosfilt_batched(xb, sos, zero_lag=not a.causal, zero_center=True, rectify=True, mode="scan")
     torch.cuda.synchronize()
-    st = y.transpose(1, 2).reshape(B * a.m, a.T)[:, :9].double().cpu().numpy()
+    st = y.transpose(1, 2).reshape(B * a.m, a.T)[:, :13].double().cpu().numpy()
     names = ["load (HBM -> regs)", "mean + LDS staging + extension + chunk", "forward zero-state", "forward scan", "forward correction",
              "backward (all three)", "output -> LDS", "LDS -> HBM stores"]
     tot = st[:, :8].sum(axis=1)
@@ -32,3 +32,6 @@ for B in (a.B, max(1, 256 // a.m)):  # the batch, then one workgroup per CU (eac
     for i, n in enumerate(names):
         print(f"  {n:42s} {st[:, i].mean():9.0f}  ({st[:, i].min():7.0f} .. {st[:, i].max():7.0f})   {100 * st[:, i].mean() / tot.mean():5.1f} %")
     print(f"  {'workgroup lifetime':42s} {tot.mean():9.0f}  ({tot.min():7.0f} .. {tot.max():7.0f})")
+    for i, n in enumerate(["  phase 2a: mean (cvt, sum, shuffles, barrier)", "  phase 2b: pre-process + 79 LDS stores + barrier", "  phase 2c: odd extension + barrier",
+                           "  phase 2d: chunk reads + cvt (+ the zero-state recurrence the compiler moves up)"]):
+        print(f"  {n:50s} {st[:, 9 + i].mean():9.0f}  ({st[:, 9 + i].min():7.0f} .. {st[:, 9 + i].max():7.0f})")
