@@ -132,6 +132,11 @@ int hipnmf_set_tuning(hipnmf_handle* h, int threads, int max_slices, int variant
  * The native rank sweep uses the same mechanism internally.  No reference counterpart: sklearn's fit is one matrix per call
  * (src/muscle_synergies/analysis.py:862-863). */
 int hipnmf_set_batch_hint(hipnmf_handle* h, int batch);
+/* The fitted routing constants in force, as "name=value,name=value" (static string): the defaults of struct hipnmf_route_table
+ * (csrc/hipnmf_internal.hpp: every measured threshold of the dispatchers in one table) with the environment variable
+ * HIPNMF_ROUTES -- same syntax, read once per process -- applied.  tools/calibrate_routes.py re-derives the crossovers on the box
+ * at hand and prints such a string.  Diagnostics only; no reference counterpart. */
+const char* hipnmf_routes_describe(void);
 
 /* ---- batched fit: replaces NMF(solver='mu').fit_transform / .transform for B matrices ------------- */
 /*

@@ -37,7 +37,7 @@ W_ROW_MAJOR_PAD16 = 2  # [T][round_up(k, 16)], zero padding: general-shape shard
 EXPORTS = (
     "hipnmf_version", "hipnmf_last_error", "hipnmf_device_count", "hipnmf_create", "hipnmf_destroy",
     "hipnmf_set_stream", "hipnmf_workspace_bytes", "hipnmf_last_kernel_ms", "hipnmf_last_kernel", "hipnmf_set_async",
-    "hipnmf_set_tuning", "hipnmf_set_batch_hint",
+    "hipnmf_set_tuning", "hipnmf_set_batch_hint", "hipnmf_routes_describe",
     "hipnmf_fit_batched_f32", "hipnmf_fit_batched_f64", "hipnmf_fit_ragged_f32", "hipnmf_fit_ragged_f64",
     "hipnmf_shard_pass_f32", "hipnmf_shard_hupdate_f32", "hipnmf_shard_residual_f32",
     "hipnmf_shard_pass_f64", "hipnmf_shard_hupdate_f64", "hipnmf_shard_residual_f64",
@@ -200,6 +200,8 @@ def _declare(lib):
     lib.hipnmf_set_tuning.argtypes = [vp, ip, ip, ip]
     lib.hipnmf_set_batch_hint.restype = ip
     lib.hipnmf_set_batch_hint.argtypes = [vp, ip]
+    lib.hipnmf_routes_describe.restype = ctypes.c_char_p
+    lib.hipnmf_routes_describe.argtypes = []
     lib.hipnmf_diag_stream_gbs.restype = ip
     lib.hipnmf_diag_stream_gbs.argtypes = [vp, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_double)]
     for sfx in ("f32", "f64"):
@@ -397,6 +399,12 @@ def release_thread_handles() -> None:
         hs = [_handles.pop(k) for k in mine]
     for h in hs:
         h.close()
+
+
+def routes() -> dict:
+    """The routing constants in force (``hipnmf_routes_describe``): defaults of ``hipnmf_route_table`` + ``HIPNMF_ROUTES``."""
+    text = load().hipnmf_routes_describe().decode()
+    return {k: float(v) for k, v in (item.split("=") for item in text.split(","))}
 
 
 def device_count() -> int:

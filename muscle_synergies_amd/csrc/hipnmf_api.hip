@@ -31,6 +31,68 @@ using namespace hipnmf;
 
 thread_local std::string g_last_error;
 
+// ---- hipnmf_route_table: defaults + HIPNMF_ROUTES ------------------------------------------------------------------------------
+namespace {
+struct RouteField {
+  const char* name;
+  double hipnmf_route_table::*field;
+};
+#define RF(n) {#n, &hipnmf_route_table::n}
+const RouteField kRouteFields[] = {
+    RF(f32_16ch_wide_max_rows), RF(f32_16ch_k7_wide_max_rows), RF(f64_16ch_wide_max_rows), RF(f32_32ch_wide_max_rows),
+    RF(f32_32ch_k5_wide_max_rows), RF(kl_f32_32ch_short_max_rows), RF(wide_min_batch_cus), RF(small_long_min_batch_cus_f32),
+    RF(small_long_min_batch_cus_f64), RF(pers_s_per_row_rowmajor), RF(pers_s_per_row), RF(pers_s_fixed), RF(sliced_s_launches),
+    RF(sliced_s_per_row), RF(kl_one_f32_a), RF(kl_one_f32_b), RF(kl_one_f64_a), RF(kl_one_f64_b), RF(kl_lane_f32_k5_per_ch),
+    RF(kl_lane_f32_per_ch), RF(kl_lane_f64_per_ch), RF(kl_sliced_launches), RF(kl_sliced_per_slice), RF(kl_sliced_per_row),
+    RF(kl_sliced_f64_factor), RF(kl_sliced_wide_factor), RF(kl_sliced_margin)};
+#undef RF
+hipnmf_route_table make_routes() {
+  hipnmf_route_table t;
+  const char* e = getenv("HIPNMF_ROUTES");
+  if (!e) return t;
+  std::string spec(e);
+  size_t pos = 0;
+  while (pos < spec.size()) {
+    size_t end = spec.find(',', pos);
+    if (end == std::string::npos) end = spec.size();
+    const std::string item = spec.substr(pos, end - pos);
+    pos = end + 1;
+    const size_t eq = item.find('=');
+    if (eq == std::string::npos) continue;
+    const std::string name = item.substr(0, eq);
+    char* tail = nullptr;
+    const double v = strtod(item.c_str() + eq + 1, &tail);
+    bool known = false;
+    for (const RouteField& f : kRouteFields)
+      if (name == f.name && tail != item.c_str() + eq + 1 && std::isfinite(v)) {
+        t.*(f.field) = v;
+        known = true;
+      }
+    if (!known) fprintf(stderr, "libhip_nmf: HIPNMF_ROUTES: ignoring '%s'\n", item.c_str());
+  }
+  return t;
+}
+}  // namespace
+
+const hipnmf_route_table& hipnmf_routes() {
+  static const hipnmf_route_table t = make_routes();
+  return t;
+}
+
+extern "C" const char* hipnmf_routes_describe(void) {
+  static const std::string text = [] {
+    std::string s;
+    const hipnmf_route_table& t = hipnmf_routes();
+    char buf[96];
+    for (const RouteField& f : kRouteFields) {
+      snprintf(buf, sizeof(buf), "%s%s=%.9g", s.empty() ? "" : ",", f.name, t.*(f.field));
+      s += buf;
+    }
+    return s;
+  }();
+  return text.c_str();
+}
+
 int hipnmf_fail(int code, const char* fmt, ...) {
   char buf[512];
   va_list ap;
@@ -288,7 +350,8 @@ SliceGeom slice_geometry(const hipnmf_handle* h, long long T, int B) {
 // B = 256 55 / 41, 512 55 / 79, 768 57 / 117, 1 024 - / 152; 8 x 700, k = 4: 256 89 / 57, 512 91 / 106; fp64 8 x 400, k = 4: 512 129 / 100, 768 120 / 147
 template <typename real>
 int small_long_min_batch(const hipnmf_handle* h) {
-  return (sizeof(real) == 8 ? 3 : 2) * h->num_cu;
+  const hipnmf_route_table& rt = hipnmf_routes();
+  return (int)((sizeof(real) == 8 ? rt.small_long_min_batch_cus_f64 : rt.small_long_min_batch_cus_f32) * h->num_cu);
 }
 
 template <typename real>
@@ -302,7 +365,9 @@ bool wide_preferred(int m, int k, const hipnmf_problem* p, const hipnmf_handle* 
   // mappings' one workgroup per matrix runs at the 4x4 kernels' rate on 17..32 channels (1 x (32 x 2 500), k = 8, fp32: 7.6 vs 7.7 ms per 200
   // iterations) and faster below (tools/probes/kl_long_narrow_ab.sh, ms per 1 000 rows and 100 iterations: fp32 up to 16 channels 0.0225 m with
   // k <= 5, 0.035 m on fit_rowlane_kernel; float64 up to 8 channels 0.05 m)
-  const double kl_one = sizeof(real) == 4 ? (m <= 16 ? (k <= 5 ? 0.0225 : 0.035) * m : -1.0) : (m <= 8 ? 0.05 * m : -1.0);
+  const hipnmf_route_table& rt = hipnmf_routes();
+  const double kl_one = sizeof(real) == 4 ? (m <= 16 ? (k <= 5 ? rt.kl_lane_f32_k5_per_ch : rt.kl_lane_f32_per_ch) * m : -1.0)
+                                          : (m <= 8 ? rt.kl_lane_f64_per_ch * m : -1.0);
   if (p->loss != HIPNMF_LOSS_FROBENIUS && !ragged && h->max_slices != 1 &&
       hipnmf_kl_row_sliced_wins(sizeof(real) == 8, m, p->n_samples, std::max(p->batch, h->path_batch_hint), h->num_cu, kl_one, h->max_slices)) {
     static const bool kl_sliced_env = [] {
@@ -311,7 +376,8 @@ bool wide_preferred(int m, int k, const hipnmf_problem* p, const hipnmf_handle* 
     }();
     if (kl_sliced_env) return true;
   }
-  if (!(ragged || p->batch >= h->num_cu / 2 || h->path_batch_hint >= h->num_cu / 2)) return false;
+  const int fill = (int)(rt.wide_min_batch_cus * h->num_cu);
+  if (!(ragged || p->batch >= fill || h->path_batch_hint >= fill)) return false;
   const long long T = p->n_samples;
   if (p->loss != HIPNMF_LOSS_FROBENIUS) {
     // Kullback-Leibler (round 5): fit_wide4_kernel<32, 2, 4, 1, 1> keeps both reconstructions on the matrix pipe, the lane mappings
@@ -325,7 +391,7 @@ bool wide_preferred(int m, int k, const hipnmf_problem* p, const hipnmf_handle* 
     if (sizeof(real) == 8) return m > 8;
     // short matrices, any k (tools/probes/kl32_short_ab.sh): 8192 x (32 x 300), k = 5: 32.2 -> 68.6; k = 4: 40.9 -> 94.6; 8192 x (20 x 300), k = 3: 48.4 -> 104.7;
     // 4096 x (32 x 1 000), k = 5: 18.2 -> 21.1; 20 ch k = 3: 26.9 -> 33.7; 2 500 rows, k = 5: 9.4 -> 8.6
-    return m > 16 && (k >= 6 || T <= 1500);
+    return m > 16 && (k >= 6 || T <= rt.kl_f32_32ch_short_max_rows);
   }
   if (m <= 16) {  // beyond the reach of fit_small_kernel (one wave per matrix: n_samples <= 256, and up to 1 024 for some shapes
                   // when the batch gives every SIMD a wave -- then that kernel is the fastest of the three: inst_small_long.hpp)
@@ -342,10 +408,10 @@ bool wide_preferred(int m, int k, const hipnmf_problem* p, const hipnmf_handle* 
     if (!ragged && small_kernel_long<real>(m, k, T, &nt) && (p->batch >= small_min || h->path_batch_hint >= small_min)) return false;
     // float32 (four rows per W^T X instruction): 16 ch k = 5: T = 300 55.8 -> 62.8, 600 49.4 -> 50.7, 1 200 42 -> 35; k = 8: 46 -> 61, 41 -> 49, 33.7 -> 34.1;
     // 8 ch k = 4: 101 -> 177, 94 -> 124, 79 -> 75; 12 ch k = 3: 94 -> 179, 84 -> 118, 72 -> 71
-    return sizeof(real) == 8 ? (k >= 7 || T <= 1200) : T <= (k >= 7 ? 1200 : 600);
+    return sizeof(real) == 8 ? (k >= 7 || T <= rt.f64_16ch_wide_max_rows) : T <= (k >= 7 ? rt.f32_16ch_k7_wide_max_rows : rt.f32_16ch_wide_max_rows);
   }
   if (sizeof(real) == 8) return true;
-  return k >= 7 || T <= (k >= 5 ? 5000 : 2400);
+  return k >= 7 || T <= (k >= 5 ? rt.f32_32ch_k5_wide_max_rows : rt.f32_32ch_wide_max_rows);
 }
 
 template <typename real>
@@ -381,8 +447,9 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
   // persistent 2.7 ns per row of one matrix, num_cu matrices at a time; sliced 9.5 us of launches +
   // 0.021 ns per row of the whole batch; cooperative (further down) 3.7-5.5 us + 2.4 us per workgroup-step of rows
   const double waves = (double)((Bsel + h->num_cu - 1) / h->num_cu);
-  const double t_pers = waves * ((double)T * (ks->row_major ? 2.0e-9 : 2.7e-9) + 1e-6);  // row-per-lane: 20.8 us / 10 000 rows
-  const double t_sliced = 9.5e-6 + (double)Bsel * (double)T * 0.021e-9;
+  const hipnmf_route_table& rt = hipnmf_routes();
+  const double t_pers = waves * ((double)T * (ks->row_major ? rt.pers_s_per_row_rowmajor : rt.pers_s_per_row) + rt.pers_s_fixed);  // row-per-lane: 20.8 us / 10 000 rows
+  const double t_sliced = rt.sliced_s_launches + (double)Bsel * (double)T * rt.sliced_s_per_row;
   bool persistent;
   if (h->variant == 1 || h->variant == 4 || h->variant == 5 || h->variant == 6)
     persistent = true;

@@ -142,6 +142,38 @@ class hipnmf_kernel_chain {
   std::vector<std::unique_ptr<Slot>> slots_;
 };
 
+
+// ---- the fitted routing constants, in ONE table ---------------------------------------------------------------------------------
+// Which kernel family serves a call is decided by rules whose thresholds were MEASURED on one box type (MI355X, 256 CUs; the A/B
+// behind each rule is cited where the rule is applied: hipnmf_api.hip wide_preferred / fit_batched_impl, hipnmf_wide.hip).  They
+// are data, not code: every one lives here with its default, and HIPNMF_ROUTES="name=value,name=value" (read once per process)
+// overrides any of them -- the string tools/calibrate_routes.py prints after re-deriving the crossovers on the box at hand.
+struct hipnmf_route_table {
+  // -- narrow shapes (<= 32 channels, <= 8 components), chip-filling or ragged batches: lane mappings (fit_persistent_kernel,
+  //    fit_rowlane_kernel) vs the 4x4 matrix-pipe kernels (fit_wide4_kernel / fit_wide4d_kernel); "wide up to this many rows"
+  double f32_16ch_wide_max_rows = 600;        // fp32, <= 16 channels, k <= 6
+  double f32_16ch_k7_wide_max_rows = 1200;    // fp32, <= 16 channels, k = 7, 8
+  double f64_16ch_wide_max_rows = 1200;       // float64, <= 16 channels, k <= 6 (k = 7, 8: always the matrix pipe)
+  double f32_32ch_wide_max_rows = 2400;       // fp32, 17..32 channels, k <= 4
+  double f32_32ch_k5_wide_max_rows = 5000;    // fp32, 17..32 channels, k = 5, 6 (k = 7, 8: always)
+  double kl_f32_32ch_short_max_rows = 1500;   // Kullback-Leibler fp32, 17..32 channels, k <= 5: matrix pipe up to this many rows
+  double wide_min_batch_cus = 0.5;            // "chip-filling": at least this many matrices per CU
+  double small_long_min_batch_cus_f32 = 2;    // one wave per matrix beyond 256 rows: matrices per CU from which it wins
+  double small_long_min_batch_cus_f64 = 3;
+  // -- one workgroup per matrix vs row slices vs the cooperative kernel, lane mappings (seconds; tools/config2_bench.py)
+  double pers_s_per_row_rowmajor = 2.0e-9, pers_s_per_row = 2.7e-9, pers_s_fixed = 1e-6;
+  double sliced_s_launches = 9.5e-6, sliced_s_per_row = 0.021e-9;
+  // -- Kullback-Leibler on few long matrices: one workgroup per matrix vs the row-sliced one-pass kernel (ms per 100 iterations;
+  //    tools/probes/kl_long_ab.sh): one = (a + b m) per 1 000 rows; sliced = launches + per_slice S + per_row rows waves
+  double kl_one_f32_a = 0.35, kl_one_f32_b = 0.0265, kl_one_f64_a = 0.3, kl_one_f64_b = 0.06;
+  double kl_lane_f32_k5_per_ch = 0.0225, kl_lane_f32_per_ch = 0.035, kl_lane_f64_per_ch = 0.05;  // the lane mappings' own rates
+  double kl_sliced_launches = 1.0, kl_sliced_per_slice = 0.015, kl_sliced_per_row = 0.005, kl_sliced_f64_factor = 1.9,
+         kl_sliced_wide_factor = 0.6, kl_sliced_margin = 0.9;
+};
+// the process's table: the defaults above with HIPNMF_ROUTES applied (unknown names are reported once on stderr and ignored)
+const hipnmf_route_table& hipnmf_routes();
+// ("name=value" pairs of the table in force: hipnmf_routes_describe, include/hip_nmf.h)
+
 constexpr int HIPNMF_NARROW_MAX_FEATURES = 32, HIPNMF_NARROW_MAX_COMPONENTS = 8;  // nmf_kernels.hpp lane mappings
 constexpr int HIPNMF_MAX_FEATURES = 512, HIPNMF_MAX_COMPONENTS = 64;              // nmf_big.hpp (nmf_wide.hpp: 128 / 32)
 

@@ -140,15 +140,17 @@ static long long big1_slices(int num_cu, int B, long long T) {
 // advisor finding: max_slices = 2..N used to be priced as if the uncapped slice count ran).
 bool hipnmf_kl_row_sliced_wins(bool f64, int m, long long T, int B, int num_cu, double t_one_per_krow, int max_slices) {
   if (B > num_cu) return false;
-  if (t_one_per_krow < 0) t_one_per_krow = f64 ? 0.3 + 0.06 * m : 0.35 + 0.0265 * m;
+  const hipnmf_route_table& rt = hipnmf_routes();
+  if (t_one_per_krow < 0) t_one_per_krow = f64 ? rt.kl_one_f64_a + rt.kl_one_f64_b * m : rt.kl_one_f32_a + rt.kl_one_f32_b * m;
   const double t_one = (double)T * 1e-3 * t_one_per_krow;
   long long S = big1_slices(num_cu, B, T);
   if (max_slices > 0) S = std::min<long long>(S, max_slices);
   const long long rows = round_up((T + S - 1) / S, 64);
   const double waves = (double)(((long long)B * S + num_cu - 1) / num_cu);
   const double mp64 = (double)round_up(m, 64) / 64.0;
-  const double t_rows = 1.0 + 0.015 * (double)S + 0.005 * (f64 ? 1.9 : 1.0) * (1.0 + 0.6 * (mp64 - 1.0)) * (double)rows * waves;
-  return t_rows < 0.9 * t_one;
+  const double t_rows = rt.kl_sliced_launches + rt.kl_sliced_per_slice * (double)S +
+                        rt.kl_sliced_per_row * (f64 ? rt.kl_sliced_f64_factor : 1.0) * (1.0 + rt.kl_sliced_wide_factor * (mp64 - 1.0)) * (double)rows * waves;
+  return t_rows < rt.kl_sliced_margin * t_one;
 }
 
 // `p` has passed validate() of hipnmf_api.hip.  `ragged`: host copy of the caller's descriptors or nullptr.

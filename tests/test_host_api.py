@@ -228,3 +228,32 @@ def test_filter_mode_switch_of_the_single_frame_functions():
         params = inspect.signature(fn).parameters
         assert list(params)[: len(ref_names)] == ref_names  # the reference's positional order (analysis.py:252-432)
         assert params["mode"].kind is inspect.Parameter.KEYWORD_ONLY and params["mode"].default is None
+
+
+def test_route_table_is_one_table_with_an_environment_override():
+    """every fitted routing threshold of the dispatchers lives in struct hipnmf_route_table
+    (csrc/hipnmf_internal.hpp); hipnmf_routes_describe() reports the values in force, HIPNMF_ROUTES overrides them by name."""
+    import os
+    import re
+    import subprocess
+    import sys
+
+    from muscle_synergies_amd import _lib
+
+    r = _lib.routes()  # no GPU needed: the table is host data
+    assert r["f32_16ch_wide_max_rows"] == 600 and r["f64_16ch_wide_max_rows"] == 1200 and r["kl_sliced_margin"] == 0.9
+    hdr = open(os.path.join(os.path.dirname(_lib.PKG), "muscle_synergies_amd", "csrc", "hipnmf_internal.hpp")).read()
+    body = hdr[hdr.index("struct hipnmf_route_table {"):hdr.index("const hipnmf_route_table& hipnmf_routes();")]
+    fields = re.findall(r"\b([a-z][a-z0-9_]+)\s*=\s*[-0-9.e]+", body)
+    assert sorted(fields) == sorted(r), (sorted(set(fields) ^ set(r)))  # every field of the struct is reported (and overridable)
+    # the dispatchers hold no fitted row-count literal of their own any more
+    api = open(os.path.join(os.path.dirname(_lib.PKG), "muscle_synergies_amd", "csrc", "hipnmf_api.hip")).read()
+    wp = api[api.index("bool wide_preferred("):api.index("int fit_batched_impl(")]
+    # (T <= 256 / 128 stay: the reach of the one-wave kernel's four tiles, a property of that kernel and not a fitted crossover)
+    assert not re.search(r"T <= \(?(?!256\b|128\b)\d{3,}", wp), "a fitted threshold is back in wide_preferred as a literal"
+    code = ("import sys; sys.path.insert(0, %r); from muscle_synergies_amd import _lib; r = _lib.routes(); "
+            "print(r['f32_16ch_wide_max_rows'], r['pers_s_per_row'])" % os.path.dirname(_lib.PKG))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True,
+                         env=dict(os.environ, HIPNMF_ROUTES="f32_16ch_wide_max_rows=900,pers_s_per_row=3e-9,not_a_route=1"))
+    assert out.returncode == 0 and out.stdout.split() == ["900.0", "3e-09"], out.stdout + out.stderr
+    assert "ignoring 'not_a_route=1'" in out.stderr
