@@ -1846,10 +1846,17 @@ __global__ void __launch_bounds__((max_threads<real, G, CH, K>())) HIPNMF_OCC fi
     __syncthreads();
   }
   int n_iter = 0;
+#ifdef HIPNMF_TIMING  // development build (tools/coop_phase_timing.py): shader-clock cycles per phase of an iteration, summed
+  unsigned long long cacc[6] = {0, 0, 0, 0, 0, 0};
+#define COOP_STAMP(v) const unsigned long long v = __builtin_readcyclecounter()
+#else
+#define COOP_STAMP(v) ((void)0)
+#endif
   RowTile<real, G, CH, K> tiles_lds[PipeDepth<true, G, CH>::value];
   prefetch_head<real, G, CH, K, true>(tiles_lds, ma, 0, lds_rows);
   for (int it = 1; it <= a.max_iter && alive; ++it) {
     n_iter = it;
+    COOP_STAMP(c0);
     real accA[K][CH], accB[C::NB];
 #pragma unroll
     for (int c = 0; c < K; ++c)
@@ -1866,8 +1873,10 @@ __global__ void __launch_bounds__((max_threads<real, G, CH, K>())) HIPNMF_OCC fi
     }
     if (it < a.max_iter) prefetch_head<real, G, CH, K, true>(tiles_lds, ma, 0, lds_rows);
     if (a.update_h) {
+      COOP_STAMP(c1);  // row pass done (this wave)
       wave_reduce_acc<real, G, CH, K>(s.part + wave * C::NACC, accA, accB);
       __syncthreads();
+      COOP_STAMP(c2);  // wave records in LDS, workgroup barrier passed
       {
         // tagged granules {32 value bits, generation}: ONE 8-byte store each (plain into the shared L2, or written through
         // to the coherence point in the device-scope flavour), no barrier, no flag
@@ -1899,11 +1908,22 @@ __global__ void __launch_bounds__((max_threads<real, G, CH, K>())) HIPNMF_OCC fi
           }
         }
         __syncthreads();  // s.part is about to be overwritten by the sums
+        COOP_STAMP(c3);  // this workgroup's record published (tagged granules)
         alive = coop_sum_records_tagged<real>(g64, S, C::NACC, gen, scratch, s.part, abort_flag) && alive;
+        COOP_STAMP(c4);  // every slice's record polled and summed
+#ifdef HIPNMF_TIMING
+        cacc[0] += c1 - c0; cacc[1] += c2 - c1; cacc[2] += c3 - c2; cacc[3] += c4 - c3;
+#endif
       }
+      COOP_STAMP(c5);
       if (wave == 0) wave0_combine_and_update_h(s, 1, m, a.l1h, a.l2h);
       __syncthreads();
+      COOP_STAMP(c6);  // H updated, workgroup barrier passed
       load_h_regs(s, g, h, hht);
+      COOP_STAMP(c7);
+#ifdef HIPNMF_TIMING
+      cacc[4] += c6 - c5; cacc[5] += c7 - c6;
+#endif
     }
     if (a.tol > (real)0 && (it % a.check_every) == 0) {
       residual_all();
@@ -1923,6 +1943,14 @@ __global__ void __launch_bounds__((max_threads<real, G, CH, K>())) HIPNMF_OCC fi
       if (a.sse_col_out) a.sse_col_out[(long long)b * m + threadIdx.x] = s.part[threadIdx.x];
       if (a.xsq_col_out) a.xsq_col_out[(long long)b * m + threadIdx.x] = s.part[MP + threadIdx.x];
     }
+#ifdef HIPNMF_TIMING
+    // (overwrites the outputs) average cycles per iteration of the six phases as seen by wave 0 of slice 0, then by its last wave
+    __syncthreads();
+    if (lane == 0 && m >= 12 && (wave == 0 || wave == nw - 1) && a.sse_col_out && a.xsq_col_out) {
+      real* dst = wave == 0 ? a.sse_col_out : a.xsq_col_out;
+      for (int q = 0; q < 6; ++q) dst[(long long)b * m + q] = (real)((double)cacc[q] / (double)n_iter);
+    }
+#endif
     if (a.update_h) {
       for (int i = threadIdx.x; i < K * MP; i += blockDim.x) {
         const int c = i / MP, j = i % MP;
@@ -1937,6 +1965,7 @@ __global__ void __launch_bounds__((max_threads<real, G, CH, K>())) HIPNMF_OCC fi
       for (int c = 0; c < K; ++c) Wb[(long long)c * a.ldw + t] = lds_w[c * lds_stride + t];
     }
   }
+#undef COOP_STAMP
 }
 
 // =================================================================================================
