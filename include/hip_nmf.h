@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define HIPNMF_VERSION 211 /* 0.2.2: round 6 added hipnmf_set_batch_hint; 0.2.1: round 5 added HIPNMF_W_ROW_MAJOR_PAD16 (the shard entry points no longer read plain W_ROW_MAJOR as padded); 0.2.0: round 3 grew hipnmf_envelope_params and added hipnmf_rank_sweep_stop_*, round 4 added hipnmf_sosfilt_params.mode */
+#define HIPNMF_VERSION 212 /* 0.2.3: round 6 added hipnmf_set_batch_hint, hipnmf_routes_describe, hipnmf_resample_weights_*; 0.2.1: round 5 added HIPNMF_W_ROW_MAJOR_PAD16 (the shard entry points no longer read plain W_ROW_MAJOR as padded); 0.2.0: round 3 grew hipnmf_envelope_params and added hipnmf_rank_sweep_stop_*, round 4 added hipnmf_sosfilt_params.mode */
 
 #define HIPNMF_OK 0
 #define HIPNMF_ERR_BAD_ARG (-1)
@@ -300,8 +300,20 @@ typedef struct hipnmf_envelope_params {
 #define HIPNMF_RESAMPLE_NEAREST_UP 2 /* 'nearest-up': a tie goes up                                           */
 #define HIPNMF_RESAMPLE_PREVIOUS 3   /* 'previous' and 'zero' (order-0 spline): last knot <= the abscissa     */
 #define HIPNMF_RESAMPLE_NEXT 4       /* 'next': first knot >= the abscissa                                    */
-/* ('quadratic' / 'cubic' splines couple all samples of a channel through a banded solve: the Python host hands those
- * to scipy itself.) */
+/* 'quadratic' / 'cubic' (interp1d -> make_interp_spline: a banded collocation solve over all samples of a channel, then an
+ * evaluation) are linear in the samples and depend on (n_samples, n_out, kind) only; the solve's influence decays geometrically, so
+ * every output row is a short window of weights over the input.  The host builds that operator once per shape (the Python host:
+ * from scipy's own B-spline design matrices, preprocess._spline_operator) and hipnmf_resample_weights_* applies it on the device:
+ *   out[b][j][r] = sum_{i < taps} weights[r * taps + i] * x[b][first[r] + i][j]        (fp64 accumulation, two fixed chains)
+ * x as in hipnmf_envelope_params (batch, n_samples, n_channels, x_layout, ldx, x_batch_stride; n_out = rows of the operator; the
+ * other fields are ignored); first [n_out] int32 and weights [n_out][taps] doubles in DEVICE memory, first[r] + taps <= n_samples;
+ * out [B][n_channels][n_out], channel-major.  Errors: HIPNMF_ERR_BAD_ARG for NULL pointers, taps outside [1, n_samples] or a bad
+ * layout (the windows themselves are not range-checked: the host built them).  Replaces scipy.interpolate.interp1d(kind='quadratic' | 'cubic') inside
+ * time_normalize (src/muscle_synergies/analysis.py:551-594). */
+int hipnmf_resample_weights_f32(hipnmf_handle* h, const hipnmf_envelope_params* p, const float* x, const int32_t* first,
+                                const double* weights, int32_t taps, float* out);
+int hipnmf_resample_weights_f64(hipnmf_handle* h, const hipnmf_envelope_params* p, const double* x, const int32_t* first,
+                                const double* weights, int32_t taps, double* out);
 
 int hipnmf_emg_envelope_f32(hipnmf_handle* h, const hipnmf_envelope_params* p, const float* raw, float* out);
 int hipnmf_emg_envelope_f64(hipnmf_handle* h, const hipnmf_envelope_params* p, const double* raw, double* out);

@@ -44,7 +44,7 @@ EXPORTS = (
     "hipnmf_fit_tsharded_f32", "hipnmf_fit_tsharded_f64",
     "hipnmf_random_init_f32", "hipnmf_random_init_f64", "hipnmf_rank_sweep_f32", "hipnmf_rank_sweep_f64",
     "hipnmf_rank_sweep_stop_f32", "hipnmf_rank_sweep_stop_f64",
-    "hipnmf_emg_envelope_f32", "hipnmf_emg_envelope_f64", "hipnmf_sosfilt_f32", "hipnmf_sosfilt_f64",
+    "hipnmf_emg_envelope_f32", "hipnmf_emg_envelope_f64", "hipnmf_resample_weights_f32", "hipnmf_resample_weights_f64", "hipnmf_sosfilt_f32", "hipnmf_sosfilt_f64",
     "hipnmf_gram_f32", "hipnmf_gram_f64", "hipnmf_nndsvd_stats_f32", "hipnmf_nndsvd_stats_f64",
     "hipnmf_nndsvd_write_f32", "hipnmf_nndsvd_write_f64", "hipnmf_diag_stream_gbs",
 )
@@ -223,6 +223,9 @@ def _declare(lib):
         f = getattr(lib, f"hipnmf_emg_envelope_{sfx}")
         f.restype = ip
         f.argtypes = [vp, vp, vp, vp]
+        f = getattr(lib, f"hipnmf_resample_weights_{sfx}")
+        f.restype = ip
+        f.argtypes = [vp, vp, vp, vp, vp, ctypes.c_int32, vp]
         f = getattr(lib, f"hipnmf_sosfilt_{sfx}")
         f.restype = ip
         f.argtypes = [vp, vp, vp, vp, vp, vp]

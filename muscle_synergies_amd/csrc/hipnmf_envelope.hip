@@ -287,9 +287,78 @@ int envelope_impl(hipnmf_handle* h, const hipnmf_envelope_params* p, const real*
   return HIPNMF_OK;
 }
 
+// ---- banded resampling operator (round 6: the spline kinds of time_normalize) -----------------------------------------------------
+// interp1d(kind='quadratic' / 'cubic') is make_interp_spline (scipy/interpolate/_interpolate.py:397, _bsplines.py:1363-1580): a banded
+// collocation solve over ALL samples of a channel, then an evaluation.  Both are linear in the samples and depend on (T, n_out, kind)
+// only, and the solve's influence decays geometrically (cubic: 0.268 per sample, quadratic: 0.172): every output row is a short
+// window of weights over the input.  The host builds that operator once per shape from scipy's own design matrices; this kernel
+// applies it to every channel of every recording: out[b][j][r] = sum_i weights[r][i] * x[b][first[r] + i][j], fp64 accumulation.
+template <typename real>
+__global__ void __launch_bounds__(256) resample_weights_kernel(const real* __restrict__ x, long long bstride, long long ldx, int x_layout,
+                                                                const int* __restrict__ first, const double* __restrict__ weights, int taps,
+                                                                int n_out, int m, long long total, real* __restrict__ out) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // ((b * m) + j) * n_out + r: r fastest (coalesced stores)
+  if (e >= total) return;
+  const int r = (int)(e % n_out);
+  const long long bj = e / n_out;
+  const int j = (int)(bj % m);
+  const long long b = bj / m;
+  const real* __restrict__ xb = x + b * bstride;
+  const long long step = x_layout == HIPNMF_X_ROW_MAJOR ? ldx : 1;
+  const real* __restrict__ src = xb + (x_layout == HIPNMF_X_ROW_MAJOR ? (long long)j : (long long)j * ldx) + (long long)first[r] * step;
+  const double* __restrict__ w = weights + (long long)r * taps;
+  double acc0 = 0.0, acc1 = 0.0;  // two chains; a fixed order
+  int i = 0;
+  for (; i + 1 < taps; i += 2) {
+    acc0 = __builtin_fma(w[i], (double)src[(long long)i * step], acc0);
+    acc1 = __builtin_fma(w[i + 1], (double)src[(long long)(i + 1) * step], acc1);
+  }
+  if (i < taps) acc0 = __builtin_fma(w[i], (double)src[(long long)i * step], acc0);
+  out[e] = (real)(acc0 + acc1);
+}
+
+template <typename real>
+int resample_weights_impl(hipnmf_handle* h, const hipnmf_envelope_params* p, const real* x, const int32_t* first, const double* weights,
+                          int32_t taps, real* out) {
+  if (!h) return fail(HIPNMF_ERR_BAD_ARG, "handle is NULL");
+  if (!p || p->struct_size != (int32_t)sizeof(hipnmf_envelope_params))
+    return fail(HIPNMF_ERR_BAD_ARG, "hipnmf_envelope_params.struct_size mismatch");
+  if (!x || !first || !weights || !out) return fail(HIPNMF_ERR_BAD_ARG, "x, first, weights and out must be non-NULL device pointers");
+  if (p->batch < 1 || p->n_samples < 1 || p->n_channels < 1 || p->n_out < 1 || taps < 1 || taps > p->n_samples)
+    return fail(HIPNMF_ERR_BAD_ARG, "bad resampling problem (batch=%d, n_samples=%lld, n_channels=%d, n_out=%d, taps=%d)", p->batch,
+                (long long)p->n_samples, p->n_channels, p->n_out, taps);
+  if (p->x_layout != HIPNMF_X_ROW_MAJOR && p->x_layout != HIPNMF_X_CHANNEL_MAJOR) return fail(HIPNMF_ERR_BAD_ARG, "bad x_layout %d", p->x_layout);
+  if (p->ldx < (p->x_layout == HIPNMF_X_ROW_MAJOR ? p->n_channels : p->n_samples)) return fail(HIPNMF_ERR_BAD_ARG, "ldx too small");
+  HIP_TRY(hipSetDevice(h->device));
+  hipStream_t st = h->stream;
+  const long long total = (long long)p->batch * p->n_channels * p->n_out;
+  const long long blocks = (total + 255) / 256;
+  if (blocks > 0x7fffffffLL) return fail(HIPNMF_ERR_UNSUPPORTED, "too many output samples for one launch");
+  const bool async = h->async_mode != 0;
+  if (!async) HIP_TRY(hipEventRecord(h->ev0, st));
+  hipLaunchKernelGGL(resample_weights_kernel<real>, dim3((unsigned)blocks), dim3(256), 0, st, x, (long long)p->x_batch_stride, (long long)p->ldx,
+                     (int)p->x_layout, first, weights, (int)taps, (int)p->n_out, (int)p->n_channels, total, out);
+  snprintf(h->last_kernel, sizeof(h->last_kernel), "resample_weights_kernel<%s>", sizeof(real) == 4 ? "float" : "double");
+  HIP_TRY(hipGetLastError());
+  if (!async) {
+    HIP_TRY(hipEventRecord(h->ev1, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
+  }
+  return HIPNMF_OK;
+}
+
 }  // namespace
 
 extern "C" {
+int hipnmf_resample_weights_f32(hipnmf_handle* h, const hipnmf_envelope_params* p, const float* x, const int32_t* first, const double* weights,
+                                int32_t taps, float* out) {
+  return resample_weights_impl<float>(h, p, x, first, weights, taps, out);
+}
+int hipnmf_resample_weights_f64(hipnmf_handle* h, const hipnmf_envelope_params* p, const double* x, const int32_t* first, const double* weights,
+                                int32_t taps, double* out) {
+  return resample_weights_impl<double>(h, p, x, first, weights, taps, out);
+}
 int hipnmf_emg_envelope_f32(hipnmf_handle* h, const hipnmf_envelope_params* p, const float* raw, float* out) {
   return envelope_impl<float>(h, p, raw, out);
 }

@@ -145,6 +145,95 @@ def _scatter_recordings(raw, devices, one):
     return cat_host([to_host(r, False) for _, _, _, r in parts])
 
 
+# ------------------------------------------------------------------------------------------------
+# Spline kinds of time_normalize ('quadratic' / 'cubic' = interp1d -> make_interp_spline): a banded operator built once per
+# (T, n_out, degree) on the host from scipy's own design matrices, applied to every channel of every recording by
+# hipnmf_resample_weights_* (include/hip_nmf.h says why that is the same arithmetic up to rounding).
+_SPLINE_TOL = 1e-18  # weights below this fraction of a row's largest are dropped (cubic: the influence decays 0.268 per sample)
+_spline_cache: dict = {}
+_spline_dev_cache: dict = {}
+
+
+def _spline_operator(T: int, n_out: int, k: int):
+    """``(first [n_out] int32, weights [n_out, taps] float64)`` with ``interp1d(linspace(0, 1, T), y, kind=k)(linspace(0, 1, n_out))
+    == sum_i weights[r, i] * y[first[r] + i]``: the rows of ``E A^-1`` (A: collocation matrix of the degree-k B-splines on scipy's
+    not-a-knot knots at the samples, ``scipy/interpolate/_bsplines.py:1008-1027, 1363-1580``; E: the same splines at the new axis),
+    each cut to the window that holds everything above ``_SPLINE_TOL`` of its largest weight."""
+    key = (int(T), int(n_out), int(k))
+    hit = _spline_cache.get(key)
+    if hit is not None:
+        return hit
+    from scipy.interpolate import BSpline
+    from scipy.sparse.linalg import splu
+
+    if T <= k:
+        raise ValueError(f"a spline of degree {k} needs more than {k} samples (got {T})")  # scipy: "Got n knots, need at least ..."
+    xs, xn = np.linspace(0, 1, T), np.linspace(0, 1, n_out)
+    if k % 2 == 1:
+        k2, t = (k + 1) // 2, xs.copy()
+    else:
+        k2, t = k // 2, (xs[1:] + xs[:-1]) / 2
+    t = np.r_[(xs[0],) * (k + 1), t[k2:-k2], (xs[-1],) * (k + 1)]
+    A = BSpline.design_matrix(xs, t, k).tocsc()
+    lu = splu(A.T.tocsc())  # R = E A^-1  <=>  A^T R^T = E^T
+    first = np.empty(n_out, np.int32)
+    rows = []
+    for lo in range(0, n_out, 256):  # blocks of output rows: the dense right-hand side stays small whatever n_out is
+        E = BSpline.design_matrix(xn[lo:lo + 256], t, k)
+        R = lu.solve(np.ascontiguousarray(E.T.toarray())).T  # [block, T]
+        for r in range(R.shape[0]):
+            sig = np.flatnonzero(np.abs(R[r]) > _SPLINE_TOL * np.abs(R[r]).max())
+            first[lo + r] = sig[0]
+            rows.append(R[r, sig[0]: sig[-1] + 1])
+    taps = min(T, max(len(w) for w in rows))
+    weights = np.zeros((n_out, taps))
+    for r, w in enumerate(rows):
+        f = min(int(first[r]), T - taps)  # the window slides left at the end of the series so that it stays inside
+        weights[r, int(first[r]) - f: int(first[r]) - f + len(w)] = w
+        first[r] = f
+    if len(_spline_cache) > 16:
+        _spline_cache.clear()
+    _spline_cache[key] = (first, weights)
+    return first, weights
+
+
+def time_normalize_batched(X, reduce_to: int, kind="linear", *, device=None):
+    """``time_normalize`` for a batch ``[B, T, m]`` (or ``[T, m]``), any ``interp1d`` kind of the reference on the device: the index
+    kinds and ``linear`` through the envelope entry point, ``'quadratic'`` / ``'cubic'`` (2, 3) through the banded spline operator.
+    Returns ``[B, reduce_to, m]`` on the device (a transposed view of channel-major storage)."""
+    if kind in SPLINE_KINDS and not isinstance(kind, bool):
+        return _spline_resample(X, int(reduce_to), 2 if kind in ("quadratic", 2) else 3, device)
+    return emg_envelope_batched(X, 0, reduce_to=reduce_to, normalize=False, zero_center=False, kind=kind, device=device)
+
+
+def _spline_resample(X, n_out: int, k: int, device=None):
+    import torch
+
+    dev = resolve_device(device)
+    Xt = _as_device_tensor(X, dev)
+    if Xt.dim() == 2:
+        Xt = Xt.unsqueeze(0)
+    if Xt.dim() != 3 or Xt.dtype not in (torch.float32, torch.float64):
+        raise ValueError("time_normalize_batched takes [B, T, m] (or [T, m]) float32 / float64")
+    B, T, m = Xt.shape
+    layout, ldx, xbs, Xt = _x_layout(Xt)
+    dkey = (dev.index, T, n_out, k)
+    ops = _spline_dev_cache.get(dkey)
+    if ops is None:
+        first, weights = _spline_operator(T, n_out, k)
+        ops = (torch.from_numpy(first).to(dev), torch.from_numpy(weights).to(dev), weights.shape[1])
+        if len(_spline_dev_cache) > 16:
+            _spline_dev_cache.clear()
+        _spline_dev_cache[dkey] = ops
+    p = EnvelopeParams(ctypes.sizeof(EnvelopeParams), B, T, m, layout, ldx, xbs, 0, 0, n_out, 0, 0, 0)
+    out = torch.empty((B, m, n_out), dtype=Xt.dtype, device=dev)
+    lib = _lib.load()
+    fn = lib.hipnmf_resample_weights_f32 if Xt.dtype == torch.float32 else lib.hipnmf_resample_weights_f64
+    torch.cuda.synchronize(dev)
+    _lib.check(fn(_lib.get_handle(dev.index).ptr, ctypes.byref(p), Xt.data_ptr(), ops[0].data_ptr(), ops[1].data_ptr(), ops[2], out.data_ptr()))
+    return out.transpose(1, 2)
+
+
 def _frame_through_gpu(signal_df: pandas.DataFrame, **kw) -> np.ndarray:
     arr = signal_df.to_numpy()
     if arr.dtype != np.float32:
@@ -186,21 +275,17 @@ def time_normalize(signal_df: pandas.DataFrame, reduce_to: int, kind="linear",
 
     ``kind`` is forwarded like the reference does: ``'linear'`` (default), ``'slinear'``, ``'nearest'``,
     ``'nearest-up'``, ``'previous'``, ``'next'`` and ``'zero'`` run on the GPU (:data:`RESAMPLE_KINDS`);
-    ``'quadratic'`` / ``'cubic'`` (or the spline orders 2, 3) are evaluated by scipy on the host, with a warning --
-    they solve a banded system over all samples of a channel, which is not a streaming operation.  ``fill_value``
+    ``'quadratic'`` / ``'cubic'`` (or the spline orders 2, 3) too since round 6: the banded collocation solve behind them is
+    linear in the samples and depends on the shape only, so it is built once per ``(T, reduce_to, kind)`` on the host from
+    scipy's own design matrices (:func:`_spline_operator`) and applied on the device (``hipnmf_resample_weights_*``).  ``fill_value``
     is accepted for signature compatibility: both axes span exactly [0, 1], so nothing is ever extrapolated.
     """
     if kind in SPLINE_KINDS and not isinstance(kind, bool):
-        import warnings
-
-        from scipy import interpolate
-
-        warnings.warn(f"time_normalize(kind={kind!r}): spline kinds are evaluated by scipy on the CPU", RuntimeWarning,
-                      stacklevel=2)
-        T = signal_df.shape[0]
-        f = interpolate.interp1d(np.linspace(0, 1, T), signal_df, axis=0, copy=False, kind=kind, fill_value=fill_value)
-        domain = np.linspace(0, 1, reduce_to)
-        return pandas.DataFrame(f(domain), index=domain, columns=signal_df.columns)
+        arr = signal_df.to_numpy()
+        if arr.dtype != np.float32:
+            arr = arr.astype(np.float64, copy=False)
+        vals = _spline_resample(arr, int(reduce_to), 2 if kind in ("quadratic", 2) else 3)[0].cpu().numpy()
+        return pandas.DataFrame(vals, index=np.linspace(0, 1, reduce_to), columns=signal_df.columns)
     if kind not in RESAMPLE_KINDS or isinstance(kind, bool):
         raise NotImplementedError(f"interp1d kind {kind!r} is not understood")
     if signal_df.shape[0] < 2:

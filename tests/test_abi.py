@@ -40,7 +40,7 @@ def test_every_declared_symbol_is_exported(lib):
 def test_version_and_struct_layout(lib):
     from muscle_synergies_amd import _lib
 
-    assert lib.hipnmf_version() == 211
+    assert lib.hipnmf_version() == 212
     # struct hipnmf_problem: 4+4+8+4*6+8+8+4+4+8*5 bytes with natural alignment
     assert ctypes.sizeof(_lib.Problem) == 104
     text = open(HEADER).read()

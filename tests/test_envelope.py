@@ -283,6 +283,26 @@ def g10():
     return load_npz("g10_time_normalize_kinds.npz")
 
 
+def test_oracle_and_host_operator_of_the_spline_kinds_match_the_reference(g10):
+    """G10's 'quadratic' / 'cubic' outputs of the reference's time_normalize: (a) the oracle's own restatement of
+    make_interp_spline (Cox - de Boor basis on scipy's not-a-knot knots + a dense collocation solve); (b) the banded operator the
+    product builds on the host (preprocess._spline_operator) applied with NumPy -- what hipnmf_resample_weights_* computes."""
+    from muscle_synergies_amd.preprocess import _spline_operator
+
+    raw = g10["raw"]
+    T = raw.shape[0]
+    for reduce_to in (40, 97, 230, 2, 193):
+        for kind, k in (("quadratic", 2), ("cubic", 3)):
+            ref = g10[f"{kind}_{reduce_to}"]
+            np.testing.assert_allclose(eo.time_normalize(raw, reduce_to, kind), ref, rtol=1e-12, atol=1e-14 * np.abs(raw).max())
+            first, w = _spline_operator(T, reduce_to, k)
+            assert first.dtype == np.int32 and w.shape[0] == reduce_to and (first >= 0).all() and (first + w.shape[1] <= T).all()
+            got = np.stack([(w[r][:, None] * raw[first[r]: first[r] + w.shape[1]]).sum(axis=0) for r in range(reduce_to)])
+            np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-14 * np.abs(raw).max())
+    with pytest.raises(ValueError):
+        _spline_operator(3, 10, 3)  # scipy needs more than k samples too
+
+
 def test_oracle_time_normalize_kinds_match_the_reference(g10):
     """G10: outputs of the reference's time_normalize (scipy interp1d) for every kind it forwards."""
     raw = g10["raw"]
@@ -297,8 +317,9 @@ def test_oracle_time_normalize_kinds_match_the_reference(g10):
 
 @pytest.mark.gpu
 def test_gpu_time_normalize_kinds(g10):
-    """Every interp1d kind the reference forwards: index kinds and (s)linear on the device, spline kinds through scipy
-    with a warning; the frames carry the reference's index / columns."""
+    """Every interp1d kind the reference forwards, all on the device: index kinds and (s)linear in the envelope kernels, the
+    spline kinds through the banded operator; the frames carry the reference's index / columns."""
+    from muscle_synergies_amd import _lib
     from muscle_synergies_amd import preprocess as pp
 
     raw = g10["raw"]
@@ -312,10 +333,12 @@ def test_gpu_time_normalize_kinds(g10):
                 np.testing.assert_allclose(out.to_numpy(), g10[f"{kind}_{reduce_to}"], rtol=1e-12, atol=1e-15)
             else:
                 np.testing.assert_array_equal(out.to_numpy(), g10[f"{kind}_{reduce_to}"], err_msg=f"{kind} {reduce_to}")
-        for kind in ("quadratic", "cubic"):
-            with pytest.warns(RuntimeWarning, match="evaluated by scipy"):
-                out = pp.time_normalize(df, reduce_to, kind=kind) if reduce_to > 3 else pp.time_normalize(df, 40, kind=kind)
-            np.testing.assert_allclose(out.to_numpy(), g10[f"{kind}_{reduce_to if reduce_to > 3 else 40}"], rtol=1e-12)
+        for kind in ("quadratic", "cubic"):  # round 6: on the device too (banded spline operator, hipnmf_resample_weights_*)
+            out = pp.time_normalize(df, reduce_to, kind=kind)
+            assert _lib.get_handle(0).last_kernel() == "resample_weights_kernel<double>"
+            assert list(out.columns) == list("abc")
+            np.testing.assert_allclose(out.index.to_numpy(), np.linspace(0, 1, reduce_to))
+            np.testing.assert_allclose(out.to_numpy(), g10[f"{kind}_{reduce_to}"], rtol=1e-12, atol=1e-14 * np.abs(raw).max())
     with pytest.raises(NotImplementedError):
         pp.time_normalize(df, 10, kind="lagrange")
     assert pp.time_normalize(df, 10, kind=0).equals(pp.time_normalize(df, 10, kind="zero"))
@@ -337,3 +360,29 @@ def test_gpu_index_kinds_fused_with_rms_over_many_lengths(dtype):
             ref = eo.envelope(raw.astype(np.float64), win, n_out, kind=kind)
             tol = dict(rtol=1e-9, atol=1e-12) if dtype == np.float64 else dict(rtol=3e-5, atol=1e-6)
             np.testing.assert_allclose(got, ref, err_msg=f"T={T} n_out={n_out} win={win} {kind}", **tol)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,layout", [(np.float64, "row"), (np.float32, "row"), (np.float64, "channel")])
+def test_gpu_spline_time_normalize_batched_vs_scipy(dtype, layout):
+    """A batch at the reference's real size (rows of a recording -> 200 points of a gait cycle) against scipy's interp1d, both
+    spline kinds, both memory orders of the input."""
+    from scipy.interpolate import interp1d
+
+    from muscle_synergies_amd import _lib
+    from muscle_synergies_amd.preprocess import time_normalize_batched
+
+    rng = np.random.default_rng(4)
+    B, T, m, n_out = 5, 6001, 7, 200
+    X = np.abs(rng.standard_normal((B, T, m))).cumsum(axis=1).astype(dtype)
+    Xin = X if layout == "row" else np.ascontiguousarray(X.transpose(0, 2, 1)).transpose(0, 2, 1)
+    for kind in ("cubic", "quadratic", 3, 2):
+        out = time_normalize_batched(Xin, n_out, kind=kind).cpu().numpy()
+        assert out.shape == (B, n_out, m) and out.dtype == dtype
+        assert _lib.get_handle(0).last_kernel().startswith("resample_weights_kernel<")
+        ref = interp1d(np.linspace(0, 1, T), X.astype(np.float64), axis=1, kind=kind)(np.linspace(0, 1, n_out))
+        tol = 1e-12 if dtype == np.float64 else 3e-7
+        assert np.abs(out - ref).max() <= tol * np.abs(ref).max()
+    lin = time_normalize_batched(Xin, n_out, kind="linear").cpu().numpy()  # the other kinds through the same entry point
+    ref = interp1d(np.linspace(0, 1, T), X.astype(np.float64), axis=1)(np.linspace(0, 1, n_out))
+    assert np.abs(lin - ref).max() <= (1e-12 if dtype == np.float64 else 3e-7) * np.abs(ref).max()

@@ -10,7 +10,7 @@ from muscle_synergies_amd.engine import make_problem
 from muscle_synergies_amd.preprocess import EnvelopeParams, SosfiltParams
 
 lib = _lib.load()
-assert lib.hipnmf_version() == 211
+assert lib.hipnmf_version() == 212
 h = ctypes.c_void_p()
 rc = lib.hipnmf_create(0, ctypes.byref(h))
 have_gpu = rc == 0
@@ -51,6 +51,9 @@ for sfx in ("f32", "f64"):
     f = getattr(lib, f"hipnmf_emg_envelope_{sfx}")
     f.restype = ctypes.c_int
     assert f(None, ctypes.byref(e), None, None) < 0
+    f = getattr(lib, f"hipnmf_resample_weights_{sfx}")
+    f.restype = ctypes.c_int
+    assert f(None, ctypes.byref(e), None, None, None, 4, None) < 0
     s = SosfiltParams(ctypes.sizeof(SosfiltParams), 1, 100, 4, 0, 4, 400, 2, 1, -1, 0, 0, 0)
     f = getattr(lib, f"hipnmf_sosfilt_{sfx}")
     f.restype = ctypes.c_int

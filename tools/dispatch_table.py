@@ -166,6 +166,14 @@ def generate():
                     raw = torch.randn((4, T, 8), device="cuda", dtype=dtype)
                     emg_envelope_batched(raw, window, reduce_to=n_out or None)
                     out.append(f"| {str(dtype).split('.')[1]} | {T} | {window} | {n_out or 'T'} | `{h.last_kernel()}` |")
+    out += ["", "## Spline kinds of `time_normalize`: `hipnmf_resample_weights_*` (`time_normalize(kind='quadratic' | 'cubic')`, `time_normalize_batched`)", "",
+            "| dtype | samples | n_out | kind | kernel |", "|---|---|---|---|---|"]
+    from muscle_synergies_amd.preprocess import time_normalize_batched
+    for dtype in (torch.float32, torch.float64):
+        for T, n_out, kind in ((1000, 200, "cubic"), (9000, 200, "quadratic"), (20000, 200, "cubic")):
+            raw = torch.rand((4, T, 8), device="cuda", dtype=dtype)
+            time_normalize_batched(raw, n_out, kind=kind)
+            out.append(f"| {str(dtype).split('.')[1]} | {T} | {n_out} | {kind} | `{h.last_kernel()}` |")
     out += ["", "## IIR filter: `hipnmf_sosfilt_*` (`sosfilt_batched`, `digital_filter`, `linear_envelope`)", "",
             "| dtype | samples | sections | zero_lag | mode | kernel |", "|---|---|---|---|---|---|"]
     for dtype in (torch.float32, torch.float64):
