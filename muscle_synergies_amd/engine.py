@@ -416,6 +416,8 @@ class HostBatch:
     X in HBM after the first call (288 GB hold any batch the reference's users have): later calls upload only W0 / H0.
     Results are bitwise those of ``fit_batched`` on the same arrays (tests/test_gpu_pipeline.py)."""
 
+    MIN_REGISTER_BYTES = 1 << 20  # arrays below this are never page-locked (see _register)
+
     def __init__(self, X, W0=None, H0=None, *, device=None, host_chunk: Optional[int] = None, reuse_outputs: bool = False,
                  keep_on_device: bool = False):
         torch = _torch()
@@ -457,6 +459,13 @@ class HostBatch:
         span = self._span(a)
         if span is None or span[0] in self._reg:
             return span is not None and span[0] in self._reg
+        if span[1] < self.MIN_REGISTER_BYTES:
+            # A small array lives on pages of the allocator's heap that it shares with other objects (and with other small arrays
+            # this batch might register): page-locking such pages twice and unlocking them once, or leaving a range of the heap
+            # known to the runtime as pinned, is how a LATER pageable copy of an unrelated array aborted inside the HIP runtime
+            # (3 of 8 full-suite runs, round 6: profiles/r06_abort_hunt.md).  Only arrays that own their pages -- mmap'ed
+            # allocations, far beyond the allocator's threshold -- are registered; the small ones cost microseconds to copy anyway.
+            return False
         t0 = _time.perf_counter()
         try:
             ok = int(self._rt.cudaHostRegister(span[0], span[1], 0)) == 0

@@ -142,9 +142,11 @@ def test_traffic_measurements_still_name_the_kernel_the_library_launches():
 
     for e in json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))):
         B = min(int(e["batch"]), 320)  # the instance depends on the shape and on "more matrices than CUs", not on B itself
-        X = torch.rand((B, e["T"], e["m"]), device="cuda") if e["x_layout"] == "row" else torch.rand((B, e["m"], e["T"]), device="cuda").transpose(1, 2)
-        W0 = torch.rand((B, e["T"], e["k"]), device="cuda")
-        H0 = torch.rand((B, e["k"], e["m"]), device="cuda")
+        dt = torch.float64 if "<double" in e["kernel"] else torch.float32  # (round 6: the float64 headline has an entry too)
+        X = (torch.rand((B, e["T"], e["m"]), device="cuda", dtype=dt) if e["x_layout"] == "row"
+             else torch.rand((B, e["m"], e["T"]), device="cuda", dtype=dt).transpose(1, 2))
+        W0 = torch.rand((B, e["T"], e["k"]), device="cuda", dtype=dt)
+        H0 = torch.rand((B, e["k"], e["m"]), device="cuda", dtype=dt)
         ms.fit_batched(X, W0, H0, max_iter=2, tol=0.0)
         assert _lib.get_handle(0).last_kernel() == e["kernel"], (e["kernel"], _lib.get_handle(0).last_kernel())
 

@@ -161,6 +161,9 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--log", default="")
     ap.add_argument("--timeout", type=float, default=300.0)
+    ap.add_argument("--native-bt", action="store_true",
+                    help="preload tools/probes/segv_bt.c (compiled here with gcc): a native backtrace on SIGSEGV / SIGABRT, also when the "
+                         "process dies inside C exit handlers where faulthandler is gone")
     a = ap.parse_args()
     names = [n for n in (a.only.split(",") if a.only else CASES) if n]
     log = open(a.log, "w") if a.log else None
@@ -173,19 +176,29 @@ def main():
             log.flush()
 
     env = dict(os.environ, PYTHONFAULTHANDLER="1", PYTHONUNBUFFERED="1")
+    fh = ["-X", "faulthandler"]
+    if a.native_bt:
+        import tempfile
+
+        so = os.path.join(tempfile.mkdtemp(), "segv_bt.so")
+        subprocess.run(["gcc", "-shared", "-fPIC", "-O1", "-o", so, os.path.join(ROOT, "tools", "probes", "segv_bt.c")], check=True)
+        env["LD_PRELOAD"] = so
+        env.pop("PYTHONFAULTHANDLER")
+        fh = []  # (faulthandler would take the signal first)
     bad = 0
     for n in names:
         t0 = time.monotonic()
         fails = []
         for rep in range(a.reps):
             try:
-                r = subprocess.run([sys.executable, "-X", "faulthandler", "-c", CASES[n]], capture_output=True, text=True,
+                r = subprocess.run([sys.executable, *fh, "-c", CASES[n]], capture_output=True, text=True,
                                    env=env, timeout=a.timeout)
                 rc, out, err = r.returncode, r.stdout, r.stderr
             except subprocess.TimeoutExpired as e:
                 rc, out, err = -999, (e.stdout or b"").decode(errors="replace") if isinstance(e.stdout, bytes) else (e.stdout or ""), "TIMEOUT"
             if rc != 0 or "MARK" not in out:
-                fails.append((rep, rc, out[-400:], err[-3000:]))
+                keep = [ln for ln in err.splitlines() if not ln.startswith("Extension modules:")]
+                fails.append((rep, rc, out[-400:], "\n".join(keep)[-9000:]))
         say("%-28s reps=%d failures=%d (%.1f s)" % (n, a.reps, len(fails), time.monotonic() - t0))
         for rep, rc, out, err in fails[:3]:
             say("  rep %d rc=%d\n  stdout: %s\n  stderr: %s" % (rep, rc, out.strip(), err.strip()))

@@ -1,4 +1,4 @@
-/* LD_PRELOAD helper: on SIGSEGV / SIGABRT print a native backtrace (glibc backtrace_symbols_fd) and the mapped libraries' load
+/* LD_PRELOAD helper: on SIGSEGV / SIGBUS / SIGABRT print a native backtrace (glibc backtrace_symbols_fd) and the mapped libraries' load
  * addresses to stderr, then _exit(139).  Python's faulthandler is already gone when a process dies inside C exit handlers.
  *   gcc -shared -fPIC -O1 -o segv_bt.so segv_bt.c && LD_PRELOAD=./segv_bt.so python3 ... */
 #define _GNU_SOURCE
@@ -27,4 +27,5 @@ __attribute__((constructor)) static void install(void) {
   sa.sa_flags = SA_SIGINFO | SA_RESETHAND;
   sigaction(SIGSEGV, &sa, 0);
   sigaction(SIGBUS, &sa, 0);
+  sigaction(SIGABRT, &sa, 0);
 }
