@@ -105,11 +105,14 @@ class _Gate:
         self.inflight = 0
         self.closing = False
         self.closer = None
+        self.parked: set = set()
 
     def enter(self):
         with self.cond:
             if self.closing and threading.get_ident() != self.closer:
                 park = True
+                self.parked.add(threading.get_ident())
+                self.cond.notify_all()
             else:
                 park = False
                 self.inflight += 1
@@ -131,6 +134,15 @@ class _Gate:
             self.closing = True
             self.closer = threading.get_ident()
             return self.cond.wait_for(lambda: self.inflight == 0, timeout)
+
+    def wait_parked(self, idents, timeout: float) -> bool:
+        """Wait until every thread of ``idents`` (threads that own a handle and are still running: daemon threads) has arrived
+        at the gate.  Between two native calls such a thread runs Python / torch code; CPython 3.10 ends a daemon thread that
+        wants the GIL during finalisation with pthread_exit, and unwinding through torch's C++ frames is ``terminate called
+        without an active exception`` (native backtrace: profiles/r06_abort_hunt.md).  A thread that fits in a loop reaches
+        the gate within one call; one that never calls again costs the exit this timeout."""
+        with self.cond:
+            return self.cond.wait_for(lambda: set(idents) <= self.parked, timeout)
 
 
 _gate = _Gate()
@@ -365,6 +377,11 @@ def shutdown() -> None:
             pass
     # no other thread starts a native call from here on; the ones in flight (a daemon thread inside a fit) get 10 s to return
     drained = _gate.close(10.0)
+    me0 = threading.get_ident()
+    owners = {getattr(h, "_owner", me0) for h in list(_live)}
+    still = {t.ident for t in threading.enumerate() if t.is_alive() and t.ident != me0 and t.ident in owners}
+    if still:
+        _gate.wait_parked(still, 2.0)
     with _handles_lock:
         cached = list(_handles.values())
         _handles.clear()

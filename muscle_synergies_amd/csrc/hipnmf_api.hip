@@ -93,6 +93,52 @@ extern "C" const char* hipnmf_routes_describe(void) {
   return text.c_str();
 }
 
+// ---- hipnmf_first_use (hipnmf_internal.hpp) --------------------------------------------------------------------------------------
+namespace {
+constexpr size_t kSeenSlots = 1 << 14;  // ~1 500 kernel instances x devices; open addressing, never deleted from
+std::atomic<uintptr_t> g_seen[kSeenSlots];
+std::mutex g_first_use_mu;
+inline size_t seen_slot(uintptr_t key) { return (size_t)((key * 0x9E3779B97F4A7C15ull) >> 50) & (kSeenSlots - 1); }
+bool seen_lookup(uintptr_t key) {
+  size_t i = seen_slot(key);
+  for (size_t probe = 0; probe < kSeenSlots; ++probe, i = (i + 1) & (kSeenSlots - 1)) {
+    const uintptr_t v = g_seen[i].load(std::memory_order_acquire);
+    if (v == key) return true;
+    if (v == 0) return false;
+  }
+  return false;
+}
+void seen_insert(uintptr_t key) {
+  size_t i = seen_slot(key);
+  for (size_t probe = 0; probe < kSeenSlots; ++probe, i = (i + 1) & (kSeenSlots - 1)) {
+    uintptr_t v = g_seen[i].load(std::memory_order_acquire);
+    if (v == key) return;
+    if (v == 0 && g_seen[i].compare_exchange_strong(v, key, std::memory_order_acq_rel)) return;
+    if (v == key) return;
+  }  // (a full table only means every later launch of that function takes the lock)
+}
+const bool g_first_use_lock = [] {  // HIPNMF_FIRST_LAUNCH_LOCK=0: no lock (the A/B of tools/probes/cold_start_threads.py)
+  const char* e = getenv("HIPNMF_FIRST_LAUNCH_LOCK");
+  return !(e && e[0] == '0');
+}();
+}  // namespace
+
+hipnmf_first_use::hipnmf_first_use(const void* fn) : key_(nullptr), locked_(false) {
+  if (!g_first_use_lock) return;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const uintptr_t key = reinterpret_cast<uintptr_t>(fn) ^ ((uintptr_t)(dev + 1) << 56);
+  if (seen_lookup(key)) return;
+  g_first_use_mu.lock();
+  locked_ = true;
+  key_ = reinterpret_cast<const void*>(key);
+}
+hipnmf_first_use::~hipnmf_first_use() {
+  if (!locked_) return;
+  seen_insert(reinterpret_cast<uintptr_t>(key_));
+  g_first_use_mu.unlock();
+}
+
 int hipnmf_fail(int code, const char* fmt, ...) {
   char buf[512];
   va_list ap;
@@ -187,6 +233,7 @@ int hipnmf_allow_full_lds(hipnmf_handle* h, const void* fn) {
   std::lock_guard<std::mutex> lock(mu);
   if (done.count({fn, h->device})) return HIPNMF_OK;
   hipFuncAttributes fa;
+  hipnmf_first_use first_use_guard_(fn);  // (looking the function up loads its code object, like a first launch: same lock)
   HIP_TRY(hipFuncGetAttributes(&fa, fn));  // static + dynamic LDS must fit the CU: the runtime rejects more (invalid argument)
   HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_per_block - (int)fa.sharedSizeBytes));
   done.insert({fn, h->device});
@@ -299,7 +346,7 @@ int check_matrix_bytes(const hipnmf_problem* p) {
 template <typename real>
 void launch(typename KernelSet<real>::Fn fn, dim3 grid, dim3 block, size_t smem, hipStream_t st,
             const SolveArgs<real>& a) {
-  hipLaunchKernelGGL(fn, grid, block, smem, st, a);
+  HIPNMF_LAUNCH(fn, grid, block, smem, st, a);
 }
 
 // geometry of the row-sliced path
@@ -703,7 +750,7 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
     if (ks->row_major && ragged) {
       for (const RaggedSrc& r : rsrc) {
         dim3 grd((unsigned)((r.T + 31) / 32), (unsigned)((ldx_c + 31) / 32), 1u);
-        hipLaunchKernelGGL(x_to_row_major_kernel<real>, grd, blk, 0, st, X + r.xoff, 0LL, r.ld, (int)HIPNMF_X_CHANNEL_MAJOR,
+        HIPNMF_LAUNCH(x_to_row_major_kernel<real>, grd, blk, 0, st, X + r.xoff, 0LL, r.ld, (int)HIPNMF_X_CHANNEL_MAJOR,
                            xc + r.roff, 0LL, (int)ldx_c, (int)r.T, m);
       }
     } else {
@@ -713,11 +760,11 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
         real* xout = xc + (size_t)b0 * x_elems;
         if (ks->row_major) {
           dim3 grd((unsigned)((T + 31) / 32), (unsigned)((ldx_c + 31) / 32), nb);
-          hipLaunchKernelGGL(x_to_row_major_kernel<real>, grd, blk, 0, st, xin, (long long)p->x_batch_stride,
+          HIPNMF_LAUNCH(x_to_row_major_kernel<real>, grd, blk, 0, st, xin, (long long)p->x_batch_stride,
                              (long long)p->ldx, (int)p->x_layout, xout, (long long)x_elems, (int)ldx_c, (int)T, m);
         } else {
           dim3 grd((unsigned)((ldx_c + 31) / 32), (unsigned)((m + 31) / 32), nb);
-          hipLaunchKernelGGL(x_to_channel_major_kernel<real>, grd, blk, 0, st, xin, (long long)p->x_batch_stride,
+          HIPNMF_LAUNCH(x_to_channel_major_kernel<real>, grd, blk, 0, st, xin, (long long)p->x_batch_stride,
                              (long long)p->ldx, (int)p->x_layout, xout, (long long)x_elems, ldx_c, (int)T, m);
         }
       }
@@ -735,7 +782,7 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
     const long long n = (long long)k * ldw_c;
     for (int b0 = 0; b0 < B; b0 += 65535) {  // the batch rides on grid.y
       dim3 grd((unsigned)std::min<long long>((n + 255) / 256, 1024), (unsigned)std::min(65535, B - b0));
-      hipLaunchKernelGGL(w_convert_kernel<real>, grd, dim3(256), 0, st, W + (long long)b0 * T * k,
+      HIPNMF_LAUNCH(w_convert_kernel<real>, grd, dim3(256), 0, st, W + (long long)b0 * T * k,
                          wc + (long long)b0 * k * ldw_c, ldw_c, (int)T, k, 0);
     }
     a.W = wc;
@@ -809,8 +856,12 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
       return e && atoi(e) != 0;
     }();
     const dim3 cgrid(c.coop_xcd ? 8 * coop_S : coop_S, B);
-    const hipError_t e = coop_api ? hipLaunchCooperativeKernel(kern, cgrid, dim3(coop_threads), args, (unsigned)coop_smem, st)
-                                  : hipLaunchKernel(kern, cgrid, dim3(coop_threads), args, coop_smem, st);
+    hipError_t e;
+    {
+      hipnmf_first_use first_use_guard_(kern);
+      e = coop_api ? hipLaunchCooperativeKernel(kern, cgrid, dim3(coop_threads), args, (unsigned)coop_smem, st)
+                   : hipLaunchKernel(kern, cgrid, dim3(coop_threads), args, coop_smem, st);
+    }
     coop_xcd_used = c.coop_xcd != 0;
     if (e == hipSuccess) {
       coop_done = true;
@@ -834,7 +885,7 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
     else
       snprintf(h->last_kernel, sizeof(h->last_kernel), "fit_small_kernel<%s,%d,%d,%d>", sizeof(real) == 4 ? "float" : "double",
                m <= 8 ? 8 : 16, k, small_nt);
-    hipLaunchKernelGGL(small_fn, dim3(B), dim3(64), small_smem_bytes<real>(m, k), st, a);
+    HIPNMF_LAUNCH(small_fn, dim3(B), dim3(64), small_smem_bytes<real>(m, k), st, a);
   } else if (persistent) {
     h->last_path = 1;
     int threads = h->threads > 0 ? h->threads : 512;
@@ -966,7 +1017,7 @@ int fit_batched_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, r
     const long long n = (long long)k * ldw_c;
     for (int b0 = 0; b0 < B; b0 += 65535) {
       dim3 grd((unsigned)std::min<long long>((n + 255) / 256, 1024), (unsigned)std::min(65535, B - b0));
-      hipLaunchKernelGGL(w_convert_kernel<real>, grd, dim3(256), 0, st, W + (long long)b0 * T * k,
+      HIPNMF_LAUNCH(w_convert_kernel<real>, grd, dim3(256), 0, st, W + (long long)b0 * T * k,
                          wc + (long long)b0 * k * ldw_c, ldw_c, (int)T, k, 1);
     }
   }
@@ -1090,7 +1141,7 @@ int shard_pass_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
               (reinterpret_cast<uintptr_t>(W) % 16) == 0;
     if (rl_pass) {
       const KernelSet<float>* k16 = kernels_f32_g1c16(p->n_components);
-      hipLaunchKernelGGL(slice_pass_rowlane(p->n_components), dim3(sg.S, p->batch), dim3(256), k16->smem_bytes(4), st, a);
+      HIPNMF_LAUNCH(slice_pass_rowlane(p->n_components), dim3(sg.S, p->batch), dim3(256), k16->smem_bytes(4), st, a);
     }
   }
   if (!rl_pass)
@@ -1378,7 +1429,7 @@ int rank_sweep_impl(hipnmf_handle* h, const hipnmf_problem* p, int k_min, int k_
       }
       for (int b0 = 0; b0 < nA; b0 += 65535) {
         dim3 grd((unsigned)std::min<long long>((span + 255) / 256, 256), (unsigned)std::min(65535, nA - b0));
-        hipLaunchKernelGGL(gather_matrices_kernel<real>, grd, dim3(256), 0, h->stream, X, (long long)p->x_batch_stride, d_index + b0,
+        HIPNMF_LAUNCH(gather_matrices_kernel<real>, grd, dim3(256), 0, h->stream, X, (long long)p->x_batch_stride, d_index + b0,
                            xc + (size_t)b0 * cstride, cstride, span);
       }
       q.x_batch_stride = cstride;

@@ -53,9 +53,9 @@ extern "C" int hipnmf_diag_stream_gbs(hipnmf_handle* h, int64_t region_bytes, in
   const void* kern = reinterpret_cast<const void*>(diag_stream_kernel<2>);
   if ((rc = hipnmf_allow_full_lds(h, kern))) return rc;
   const size_t lds = 150 * 1024 <= (size_t)h->lds_per_block ? 150 * 1024 : (size_t)h->lds_per_block;
-  hipLaunchKernelGGL(diag_stream_kernel<2>, dim3(regions), dim3(512), lds, st, (const char*)d, (size_t)region_bytes, 2, out);  // warm-up
+  HIPNMF_LAUNCH(diag_stream_kernel<2>, dim3(regions), dim3(512), lds, st, (const char*)d, (size_t)region_bytes, 2, out);  // warm-up
   HIP_TRY(hipEventRecord(h->ev0, st));
-  hipLaunchKernelGGL(diag_stream_kernel<2>, dim3(regions), dim3(512), lds, st, (const char*)d, (size_t)region_bytes, (int)passes, out);
+  HIPNMF_LAUNCH(diag_stream_kernel<2>, dim3(regions), dim3(512), lds, st, (const char*)d, (size_t)region_bytes, (int)passes, out);
   HIP_TRY(hipEventRecord(h->ev1, st));
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(st));

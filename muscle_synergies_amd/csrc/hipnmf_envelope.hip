@@ -191,7 +191,7 @@ int envelope_impl(hipnmf_handle* h, const hipnmf_envelope_params* p, const real*
     real* xc = reinterpret_cast<real*>(ws + o_x);
     dim3 blk(32, 8);
     dim3 grd((unsigned)((T + 31) / 32), (unsigned)((m + 31) / 32), (unsigned)B);
-    hipLaunchKernelGGL(x_to_channel_major_kernel<real>, grd, blk, 0, st, raw, (long long)p->x_batch_stride,
+    HIPNMF_LAUNCH(x_to_channel_major_kernel<real>, grd, blk, 0, st, raw, (long long)p->x_batch_stride,
                        (long long)p->ldx, (int)p->x_layout, xc, (long long)m * T, T, (int)T, m);
     a.raw = xc;
     a.bstride = (long long)m * T;
@@ -212,13 +212,13 @@ int envelope_impl(hipnmf_handle* h, const hipnmf_envelope_params* p, const real*
   const bool async = h->async_mode != 0;
   if (!async) HIP_TRY(hipEventRecord(h->ev0, st));
   if (resample_tab)
-    hipLaunchKernelGGL(env_resample_table_kernel, dim3((unsigned)((p->n_out + 255) / 256)), dim3(256), 0, st, (int)T, (int)p->n_out, (int)p->resample_kind,
+    HIPNMF_LAUNCH(env_resample_table_kernel, dim3((unsigned)((p->n_out + 255) / 256)), dim3(256), 0, st, (int)T, (int)p->n_out, (int)p->resample_kind,
                        reinterpret_cast<int*>(ws + o_ti), reinterpret_cast<double*>(ws + o_tw));
   if (chunk) {
     auto launch_chunk = [&](auto kern, const char* name) -> int {
       if (chunk_lds > 48 * 1024)
         if (int arc = hipnmf_allow_full_lds(h, reinterpret_cast<const void*>(kern))) return arc;
-      hipLaunchKernelGGL(kern, dim3(m, B), dim3(chunk_nt), chunk_lds, st, a, chunk_nact);
+      HIPNMF_LAUNCH(kern, dim3(m, B), dim3(chunk_nt), chunk_lds, st, a, chunk_nact);
       snprintf(h->last_kernel, sizeof(h->last_kernel), "%s", name);
       return HIPNMF_OK;
     };
@@ -252,7 +252,7 @@ int envelope_impl(hipnmf_handle* h, const hipnmf_envelope_params* p, const real*
     auto launch_wg = [&](auto kern) -> int {
       if (wg_lds > 48 * 1024)
         if (int arc = hipnmf_allow_full_lds(h, reinterpret_cast<const void*>(kern))) return arc;
-      hipLaunchKernelGGL(kern, dim3(m, B), dim3(64 * wg_nw), wg_lds, st, a, ring4);
+      HIPNMF_LAUNCH(kern, dim3(m, B), dim3(64 * wg_nw), wg_lds, st, a, ring4);
       return HIPNMF_OK;
     };
     int rcw;
@@ -265,18 +265,18 @@ int envelope_impl(hipnmf_handle* h, const hipnmf_envelope_params* p, const real*
     snprintf(h->last_kernel, sizeof(h->last_kernel), "emg_wave_kernel");
     const size_t lds = sizeof(double) * (size_t)(ring + ring / 8);
     if (wave_spl == 4)
-      hipLaunchKernelGGL((emg_wave_kernel<real, 4>), dim3(m, B), dim3(64), lds, st, a, ring);
+      HIPNMF_LAUNCH((emg_wave_kernel<real, 4>), dim3(m, B), dim3(64), lds, st, a, ring);
     else
-      hipLaunchKernelGGL((emg_wave_kernel<real, 8>), dim3(m, B), dim3(64), lds, st, a, ring);
+      HIPNMF_LAUNCH((emg_wave_kernel<real, 8>), dim3(m, B), dim3(64), lds, st, a, ring);
   } else if (fused) {
     snprintf(h->last_kernel, sizeof(h->last_kernel), "emg_fused_kernel");
     if (fused_lds > 48 * 1024)
       if (int arc = hipnmf_allow_full_lds(h, reinterpret_cast<const void*>(emg_fused_kernel<real>))) return arc;
-    hipLaunchKernelGGL(emg_fused_kernel<real>, dim3(m, B), dim3(256), fused_lds, st, a);
+    HIPNMF_LAUNCH(emg_fused_kernel<real>, dim3(m, B), dim3(256), fused_lds, st, a);
   } else {
     snprintf(h->last_kernel, sizeof(h->last_kernel), "emg_prefix_kernel+emg_output_kernel");
-    hipLaunchKernelGGL(emg_prefix_kernel<real>, dim3(m, B), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(emg_output_kernel<real>, dim3(m, B), dim3(256), 0, st, a);
+    HIPNMF_LAUNCH(emg_prefix_kernel<real>, dim3(m, B), dim3(256), 0, st, a);
+    HIPNMF_LAUNCH(emg_output_kernel<real>, dim3(m, B), dim3(256), 0, st, a);
   }
   HIP_TRY(hipGetLastError());
   if (!async) {
@@ -336,7 +336,7 @@ int resample_weights_impl(hipnmf_handle* h, const hipnmf_envelope_params* p, con
   if (blocks > 0x7fffffffLL) return fail(HIPNMF_ERR_UNSUPPORTED, "too many output samples for one launch");
   const bool async = h->async_mode != 0;
   if (!async) HIP_TRY(hipEventRecord(h->ev0, st));
-  hipLaunchKernelGGL(resample_weights_kernel<real>, dim3((unsigned)blocks), dim3(256), 0, st, x, (long long)p->x_batch_stride, (long long)p->ldx,
+  HIPNMF_LAUNCH(resample_weights_kernel<real>, dim3((unsigned)blocks), dim3(256), 0, st, x, (long long)p->x_batch_stride, (long long)p->ldx,
                      (int)p->x_layout, first, weights, (int)taps, (int)p->n_out, (int)p->n_channels, total, out);
   snprintf(h->last_kernel, sizeof(h->last_kernel), "resample_weights_kernel<%s>", sizeof(real) == 4 ? "float" : "double");
   HIP_TRY(hipGetLastError());

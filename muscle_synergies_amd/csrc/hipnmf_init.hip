@@ -43,7 +43,7 @@ int canonical_x(hipnmf_handle* h, const hipnmf_problem* p, const real* X, InitAr
   dim3 blk(32, 8);
   for (int b0 = 0; b0 < B; b0 += 65535) {  // the batch rides on grid.z (HIP limit 65535)
     dim3 grd((unsigned)((T + 31) / 32), (unsigned)((m + 31) / 32), (unsigned)std::min(65535, B - b0));
-    hipLaunchKernelGGL(x_to_channel_major_kernel<real>, grd, blk, 0, h->stream, X + (long long)b0 * p->x_batch_stride,
+    HIPNMF_LAUNCH(x_to_channel_major_kernel<real>, grd, blk, 0, h->stream, X + (long long)b0 * p->x_batch_stride,
                        (long long)p->x_batch_stride, (long long)p->ldx, (int)p->x_layout, xc + (size_t)b0 * m * T, (long long)m * T, T,
                        (int)T, m);
   }
@@ -62,7 +62,7 @@ void launch_gram(hipnmf_handle* h, int B, const InitArgs& a) {
     ab.X = static_cast<const real*>(a.X) + (long long)b0 * a.bstride;
     ab.gram = a.gram + (size_t)b0 * a.m * a.m;
     ab.colsum = a.colsum + (size_t)b0 * a.m;
-    hipLaunchKernelGGL(gram_kernel<real>, dim3(nblk * nblk, std::min(65535, B - b0)), dim3(256), 0, h->stream, ab);
+    HIPNMF_LAUNCH(gram_kernel<real>, dim3(nblk * nblk, std::min(65535, B - b0)), dim3(256), 0, h->stream, ab);
   }
 }
 
@@ -94,7 +94,7 @@ int stats_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, const d
   a.V = V;
   a.inv_s = inv_s;
   a.stats = stats;
-  hipLaunchKernelGGL(nndsvd_stats_kernel<real>, dim3(p->batch, (a.k + NNDSVD_KB - 1) / NNDSVD_KB), dim3(256),
+  HIPNMF_LAUNCH(nndsvd_stats_kernel<real>, dim3(p->batch, (a.k + NNDSVD_KB - 1) / NNDSVD_KB), dim3(256),
                      sizeof(double) * NNDSVD_KB * (size_t)a.m, h->stream, a);
   return finish(h);
 }
@@ -112,7 +112,7 @@ int write_impl(hipnmf_handle* h, const hipnmf_problem* p, const real* X, const d
   a.fill = fill;
   a.eps = eps;
   a.W0 = W0;
-  hipLaunchKernelGGL(nndsvd_write_kernel<real>, dim3(p->batch, (a.k + NNDSVD_KB - 1) / NNDSVD_KB), dim3(256),
+  HIPNMF_LAUNCH(nndsvd_write_kernel<real>, dim3(p->batch, (a.k + NNDSVD_KB - 1) / NNDSVD_KB), dim3(256),
                      sizeof(double) * NNDSVD_KB * (size_t)a.m, h->stream, a);
   return finish(h);
 }
@@ -147,7 +147,7 @@ int random_init_impl(hipnmf_handle* h, const hipnmf_problem* p, uint64_t seed, i
   if (m <= GRAM_BLK)
     launch_gram<real>(h, B, a);  // (one block: the column sums of round 2's kernel, bit for bit)
   else  // only the column sums are needed here
-    hipLaunchKernelGGL(colsum_kernel<real>, dim3(B), dim3(256), 0, h->stream, a);
+    HIPNMF_LAUNCH(colsum_kernel<real>, dim3(B), dim3(256), 0, h->stream, a);
   RandomInitArgs r{};
   r.colsum = a.colsum;
   r.W = W;
@@ -168,7 +168,7 @@ int random_init_impl(hipnmf_handle* h, const hipnmf_problem* p, uint64_t seed, i
     rb.H = static_cast<real*>(H) + (size_t)b0 * r.k * m;
     rb.first_matrix = first_matrix + (index ? 0 : b0);
     rb.index = index ? index + b0 : nullptr;
-    hipLaunchKernelGGL(random_init_kernel<real>, dim3(gx, nb), dim3(256), 0, h->stream, rb);
+    HIPNMF_LAUNCH(random_init_kernel<real>, dim3(gx, nb), dim3(256), 0, h->stream, rb);
   }
   return finish(h);
 }

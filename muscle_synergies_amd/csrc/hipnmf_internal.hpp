@@ -80,6 +80,30 @@ int hipnmf_copy(hipnmf_handle* h, void* dst, const void* src, size_t bytes, hipM
 // the whole LDS of the CU instead of per call with the call's own size (round 3 did that from concurrent threads)
 int hipnmf_allow_full_lds(hipnmf_handle* h, const void* fn);
 
+// ---- first use of a kernel function: under a process-wide lock -----------------------------------------------------------------
+// The HIP runtime loads a code object lazily, at the first launch of one of its functions on a device.  On this runtime (ROCm 7.x
+// CLR) two host threads that make such FIRST launches at the same time can crash inside hipLaunchKernel (SIGSEGV at address 0,
+// 3 of 30 fresh processes whose worker threads start fitting at once -- the rank range of find_synergies; never once every kernel
+// had been launched before, which is why the thread stress with its sequential reference pass never saw it:
+// profiles/r06_abort_hunt.md).  Every launch of the library goes through HIPNMF_LAUNCH: a lock-free look-up of (function, device)
+// in a table of functions already launched, and only on a miss the process-wide mutex around the launch.
+class hipnmf_first_use {
+ public:
+  explicit hipnmf_first_use(const void* fn);
+  ~hipnmf_first_use();
+  hipnmf_first_use(const hipnmf_first_use&) = delete;
+  hipnmf_first_use& operator=(const hipnmf_first_use&) = delete;
+
+ private:
+  const void* key_;
+  bool locked_;
+};
+#define HIPNMF_LAUNCH(kern, grid, block, smem, stream, ...)                  \
+  do {                                                                        \
+    hipnmf_first_use first_use_guard_(reinterpret_cast<const void*>(kern));  \
+    hipLaunchKernelGGL(kern, grid, block, smem, stream, __VA_ARGS__);        \
+  } while (0)
+
 // Replayed launch sequences (the row-sliced paths: two small kernels per iteration, launch-bound) are hipGraphs built EXPLICITLY
 // -- hipGraphCreate + hipGraphAddKernelNode, a linear chain -- and never by stream capture.  Root cause of round 3's "operation
 // failed due to a previous error during capture" (profiles/r04_threads_root_cause.md): on this runtime (ROCm 7.x CLR) ANY
@@ -117,6 +141,7 @@ class hipnmf_kernel_chain {
     np.kernelParams = s.params;
     np.extra = nullptr;
     hipGraphNode_t node = nullptr;
+    hipnmf_first_use first_use_guard_(fn);  // (resolving the function for the node loads its code object like a launch does)
     e = hipGraphAddKernelNode(&node, graph_, n_nodes_ ? &last_ : nullptr, n_nodes_ ? 1 : 0, &np);
     if (e != hipSuccess) return e;
     last_ = node;

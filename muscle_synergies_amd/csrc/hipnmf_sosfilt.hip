@@ -50,7 +50,7 @@ hipError_t launch_v2(hipnmf_handle* h, const SosArgs& a, const double* stat, int
   constexpr size_t smem = sos2_smem_bytes<LPS>();
   const void* kern = reinterpret_cast<const void*>(&sosfilt2_kernel<real, LPS>);
   if (smem > 48 * 1024 && hipnmf_allow_full_lds(h, kern)) return hipErrorInvalidValue;
-  hipLaunchKernelGGL((sosfilt2_kernel<real, LPS>), dim3((a.N + S - 1) / S), dim3(128), smem, st, a, stat, ns);
+  HIPNMF_LAUNCH((sosfilt2_kernel<real, LPS>), dim3((a.N + S - 1) / S), dim3(128), smem, st, a, stat, ns);
   return hipSuccess;
 }
 
@@ -58,12 +58,12 @@ hipError_t launch_v2(hipnmf_handle* h, const SosArgs& a, const double* stat, int
 template <typename real, int NSP>
 int launch_scan(hipnmf_handle* h, const SosArgs& a, int ns, int C_run, double* tab, hipStream_t st) {
   constexpr int NST = 2 * NSP;
-  hipLaunchKernelGGL((sos_scan_tables_kernel<NSP>), dim3(1), dim3(256), 0, st, a, ns, C_run, tab);
+  HIPNMF_LAUNCH((sos_scan_tables_kernel<NSP>), dim3(1), dim3(256), 0, st, a, ns, C_run, tab);
   const size_t smem = (size_t)SCAN_STAGE_BYTES + sizeof(double) * (SCAN_THREADS * NST + 8 + (size_t)C_run * NST);
   auto go = [&](auto kern) -> int {
     if (smem > 48 * 1024)
       if (int rc = hipnmf_allow_full_lds(h, reinterpret_cast<const void*>(kern))) return rc;
-    hipLaunchKernelGGL(kern, dim3((unsigned)a.N), dim3(SCAN_THREADS), smem, st, a, (const double*)tab, ns);
+    HIPNMF_LAUNCH(kern, dim3((unsigned)a.N), dim3(SCAN_THREADS), smem, st, a, (const double*)tab, ns);
     return HIPNMF_OK;
   };
   return C_run == 16 ? go(sosfilt_scan_kernel<real, NSP, 16>) : C_run == 40 ? go(sosfilt_scan_kernel<real, NSP, 40>)
@@ -74,12 +74,12 @@ int launch_scan(hipnmf_handle* h, const SosArgs& a, int ns, int C_run, double* t
 // one wave per series (short series)
 template <typename real, int NSP>
 int launch_chunk_scan(hipnmf_handle* h, const SosArgs& a, int ns, int C, int NT, size_t region, double* tab, hipStream_t st) {
-  hipLaunchKernelGGL((sos_scan_tables_kernel<NSP>), dim3(1), dim3(256), 0, st, a, ns, C, tab);
+  HIPNMF_LAUNCH((sos_scan_tables_kernel<NSP>), dim3(1), dim3(256), 0, st, a, ns, C, tab);
   const size_t smem = region + 8 * sizeof(double);
   auto go = [&](auto kern) -> int {
     if (smem > 48 * 1024)
       if (int rc = hipnmf_allow_full_lds(h, reinterpret_cast<const void*>(kern))) return rc;
-    hipLaunchKernelGGL(kern, dim3((unsigned)a.N), dim3(NT), smem, st, a, (const double*)tab, ns, (int)region);
+    HIPNMF_LAUNCH(kern, dim3((unsigned)a.N), dim3(NT), smem, st, a, (const double*)tab, ns, (int)region);
     return HIPNMF_OK;
   };
   if (NT == 512) {
@@ -126,7 +126,7 @@ template <typename real, int NSP>
 int launch_block_scan(hipnmf_handle* h, const SosArgs& a, int ns, long long L, int NB, size_t region, double* tab, const double* stat,
                       real* fwd, double* bend, double* bstart, real* y, hipStream_t st) {
   constexpr int C = sizeof(real) == 4 ? 79 : 41;
-  hipLaunchKernelGGL((sos_scan_tables_kernel<NSP>), dim3(1), dim3(256), 0, st, a, ns, C, tab);
+  HIPNMF_LAUNCH((sos_scan_tables_kernel<NSP>), dim3(1), dim3(256), 0, st, a, ns, C, tab);
   const size_t smem = region + 8 * sizeof(double);
   auto kern = sosfilt_block_kernel<real, NSP, C>;
   if (smem > 48 * 1024)
@@ -144,14 +144,14 @@ int launch_block_scan(hipnmf_handle* h, const SosArgs& a, int ns, long long L, i
     k.full = 0;
     k.dst = nullptr;
     k.dst_is_y = 0;
-    hipLaunchKernelGGL(kern, grid, dim3(SCAN_THREADS), smem, st, a, k, (const double*)tab, ns, (int)region);
-    hipLaunchKernelGGL((sos_block_scan_kernel<real, NSP>), gscan, dim3(64), 0, st, a, k, (const double*)tab, ns, bstart);
+    HIPNMF_LAUNCH(kern, grid, dim3(SCAN_THREADS), smem, st, a, k, (const double*)tab, ns, (int)region);
+    HIPNMF_LAUNCH((sos_block_scan_kernel<real, NSP>), gscan, dim3(64), 0, st, a, k, (const double*)tab, ns, bstart);
     k.block_start = bstart;
     k.full = 1;
     const bool last = dir == (a.zero_lag ? 1 : 0);
     k.dst = last ? y : fwd;
     k.dst_is_y = last ? 1 : 0;
-    hipLaunchKernelGGL(kern, grid, dim3(SCAN_THREADS), smem, st, a, k, (const double*)tab, ns, (int)region);
+    HIPNMF_LAUNCH(kern, grid, dim3(SCAN_THREADS), smem, st, a, k, (const double*)tab, ns, (int)region);
   }
   return HIPNMF_OK;
 }
@@ -311,7 +311,7 @@ int sosfilt_impl(hipnmf_handle* h, const hipnmf_sosfilt_params* p, const double*
     real* xc = reinterpret_cast<real*>(ws + o_x);
     dim3 blk(32, 8);
     dim3 grd((unsigned)((T + 31) / 32), (unsigned)((m + 31) / 32), (unsigned)B);
-    hipLaunchKernelGGL(x_to_channel_major_kernel<real>, grd, blk, 0, st, x, (long long)p->x_batch_stride,
+    HIPNMF_LAUNCH(x_to_channel_major_kernel<real>, grd, blk, 0, st, x, (long long)p->x_batch_stride,
                        (long long)p->ldx, (int)p->x_layout, xc, (long long)m * T, T, (int)T, m);
     a.x = xc;
     a.bstride = (long long)m * T;
@@ -366,7 +366,7 @@ int sosfilt_impl(hipnmf_handle* h, const hipnmf_sosfilt_params* p, const double*
   if (use_block_scan) {
     const int ns = p->n_sections;
     double* tab = reinterpret_cast<double*>(ws + o_tab);
-    hipLaunchKernelGGL(sos_stats_kernel<real>, dim3((unsigned)N), dim3(256), 0, st, a, stat);
+    HIPNMF_LAUNCH(sos_stats_kernel<real>, dim3((unsigned)N), dim3(256), 0, st, a, stat);
     real* fwd = reinterpret_cast<real*>(ws + o_fwd);
     double* bend = reinterpret_cast<double*>(ws + o_bend);
     double* bstart = reinterpret_cast<double*>(ws + o_bstart);
@@ -402,7 +402,7 @@ int sosfilt_impl(hipnmf_handle* h, const hipnmf_sosfilt_params* p, const double*
     return HIPNMF_OK;
   }
   snprintf(h->last_kernel, sizeof(h->last_kernel), "sosfilt2_kernel<%s>", sizeof(real) == 4 ? "float" : "double");
-  hipLaunchKernelGGL(sos_stats_kernel<real>, dim3((unsigned)N), dim3(256), 0, st, a, stat);
+  HIPNMF_LAUNCH(sos_stats_kernel<real>, dim3((unsigned)N), dim3(256), 0, st, a, stat);
   {
     const int ns = p->n_sections;
     if (ns == 1)

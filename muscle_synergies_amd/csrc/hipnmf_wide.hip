@@ -400,14 +400,14 @@ int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
     if (ragged) {
       for (const Src& r : srcs) {
         dim3 grd((unsigned)((r.T + 31) / 32), (unsigned)((ldx_c + 31) / 32), 1u);
-        hipLaunchKernelGGL(x_to_row_major_kernel<real>, grd, blk, 0, st, X + r.xoff, 0LL, r.ld, (int)HIPNMF_X_CHANNEL_MAJOR,
+        HIPNMF_LAUNCH(x_to_row_major_kernel<real>, grd, blk, 0, st, X + r.xoff, 0LL, r.ld, (int)HIPNMF_X_CHANNEL_MAJOR,
                            xc + r.roff, 0LL, (int)ldx_c, (int)r.T, m);
       }
     } else {
       for (int b0 = 0; b0 < B; b0 += 65535) {  // the batch rides on grid.z (HIP limit 65535)
         const unsigned nb = (unsigned)std::min(65535, B - b0);
         dim3 grd((unsigned)((T + 31) / 32), (unsigned)((ldx_c + 31) / 32), nb);
-        hipLaunchKernelGGL(x_to_row_major_kernel<real>, grd, blk, 0, st, X + (long long)b0 * p->x_batch_stride,
+        HIPNMF_LAUNCH(x_to_row_major_kernel<real>, grd, blk, 0, st, X + (long long)b0 * p->x_batch_stride,
                            (long long)p->x_batch_stride, (long long)p->ldx, (int)p->x_layout, xc + (size_t)b0 * x_elems,
                            (long long)x_elems, (int)ldx_c, (int)T, m);
       }
@@ -432,14 +432,14 @@ int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
       const int nb = std::min(65535, B - b0);
       dim3 grd((unsigned)std::min<long long>((n + 255) / 256, 1024), (unsigned)nb);
       if (ragged)
-        hipLaunchKernelGGL(wide_w_convert_kernel<real>, grd, dim3(256), 0, st, W, 1, 0LL, 0LL, wc, 0LL, ks, (int)T, k, dir,
+        HIPNMF_LAUNCH(wide_w_convert_kernel<real>, grd, dim3(256), 0, st, W, 1, 0LL, 0LL, wc, 0LL, ks, (int)T, k, dir,
                            d_cdesc + 4LL * b0, d_kdesc + 4LL * b0);
       else if (p->w_layout == HIPNMF_W_ROW_MAJOR)
-        hipLaunchKernelGGL(wide_w_convert_kernel<real>, grd, dim3(256), 0, st, W + (long long)b0 * T * k, 0, (long long)T * k, 0LL,
+        HIPNMF_LAUNCH(wide_w_convert_kernel<real>, grd, dim3(256), 0, st, W + (long long)b0 * T * k, 0, (long long)T * k, 0LL,
                            wc + (size_t)b0 * w_elems, (long long)w_elems, ks, (int)T, k, dir, (const long long*)nullptr,
                            (const long long*)nullptr);
       else
-        hipLaunchKernelGGL(wide_w_convert_kernel<real>, grd, dim3(256), 0, st, W + (long long)b0 * T * k, 1, (long long)T * k,
+        HIPNMF_LAUNCH(wide_w_convert_kernel<real>, grd, dim3(256), 0, st, W + (long long)b0 * T * k, 1, (long long)T * k,
                            (long long)T, wc + (size_t)b0 * w_elems, (long long)w_elems, ks, (int)T, k, dir,
                            (const long long*)nullptr, (const long long*)nullptr);
     }
@@ -472,7 +472,7 @@ int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
   // not a stream capture).  The done flags live on the device (state[b][3]).
   const bool stop_rule = p->tol > 0;
   real* d_state = sliced ? reinterpret_cast<real*>(ws + o_state) : nullptr;
-  auto direct = [&](auto fn, dim3 g, dim3 blk, size_t sm, const auto& args) { hipLaunchKernelGGL(fn, g, blk, sm, st, args); };
+  auto direct = [&](auto fn, dim3 g, dim3 blk, size_t sm, const auto& args) { HIPNMF_LAUNCH(fn, g, blk, sm, st, args); };
   auto drive = [&](auto&& enqueue, auto&& residual) -> int {
     std::vector<real> host_state((size_t)B * 8);
     auto all_converged = [&](bool* done) -> int {
@@ -666,7 +666,7 @@ int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
       }
       if (check) residual(1, emit);
     };
-    if (b1) hipLaunchKernelGGL(big_hht_part_kernel<real>, ghup, dim3(256), sizeof(real) * 64 * (size_t)k, st, hb);  // H H^T of the initial H
+    if (b1) HIPNMF_LAUNCH(big_hht_part_kernel<real>, ghup, dim3(256), sizeof(real) * 64 * (size_t)k, st, hb);  // H H^T of the initial H
     rc = drive(enqueue, residual);
     if (rc) return rc;
   } else {
@@ -688,7 +688,7 @@ int hipnmf_fit_wide(hipnmf_handle* h, const hipnmf_problem* p, const real* X, re
   if (!sliced) {
     h->last_path = 1;
     snprintf(h->last_kernel, sizeof(h->last_kernel), "%s", kl ? wk->name_kl : wk->name);
-    hipLaunchKernelGGL(kern, dim3(B), dim3(wk->NW * 64), smem, st, a);
+    HIPNMF_LAUNCH(kern, dim3(B), dim3(wk->NW * 64), smem, st, a);
   } else {
     // ---- row-sliced: per iteration one pass over all slices (mode 1) and the H update; the stop rule's residual (mode 2 +
     // finalize) every check_every iterations with the done flags on the device; chunks of iterations replayed as a hipGraph
@@ -834,10 +834,10 @@ int hipnmf_shard_wide(hipnmf_handle* h, const hipnmf_problem* p, int op, const r
       hp.KP = KPb;
       hp.hht_part = reinterpret_cast<real*>(ws + o_hhtp);
       hp.kl = kl ? 1 : 0;
-      hipLaunchKernelGGL(big_hht_part_kernel<real>, dim3(B, n_hblk), dim3(256), sizeof(real) * 64 * (size_t)k, st, hp);
-      hipLaunchKernelGGL(b1fn, gslice, dim3(512), b1smem, st, ba);
+      HIPNMF_LAUNCH(big_hht_part_kernel<real>, dim3(B, n_hblk), dim3(256), sizeof(real) * 64 * (size_t)k, st, hp);
+      HIPNMF_LAUNCH(b1fn, gslice, dim3(512), b1smem, st, ba);
     } else {
-      hipLaunchKernelGGL(big_hht_kernel<real>, dim3(B, KPb), dim3(256), 0, st, ba);
+      HIPNMF_LAUNCH(big_hht_kernel<real>, dim3(B, KPb), dim3(256), 0, st, ba);
       if (std::max(smem_w, smem_rec) > (size_t)h->lds_per_block)
         return fail(HIPNMF_ERR_UNSUPPORTED, "n_features=%d n_components=%d needs more LDS per workgroup than this device has", m, k);
       with_kp([&](auto kp) {
@@ -845,12 +845,12 @@ int hipnmf_shard_wide(hipnmf_handle* h, const hipnmf_problem* p, int op, const r
         if (!arc) arc = hipnmf_allow_full_lds(h, reinterpret_cast<const void*>(big_pass_w_kernel<real, KP>));
         if (!arc) arc = hipnmf_allow_full_lds(h, reinterpret_cast<const void*>(big_records_kernel<real, KP>));
         if (arc) return;
-        hipLaunchKernelGGL((big_pass_w_kernel<real, KP>), gslice, dim3(256), smem_w, st, ba);
-        if (p->update_h) hipLaunchKernelGGL((big_records_kernel<real, KP>), grec, dim3(256), smem_rec, st, ba);
+        HIPNMF_LAUNCH((big_pass_w_kernel<real, KP>), gslice, dim3(256), smem_w, st, ba);
+        if (p->update_h) HIPNMF_LAUNCH((big_records_kernel<real, KP>), grec, dim3(256), smem_rec, st, ba);
       });
       if (arc) return arc;
     }
-    if (p->update_h) hipLaunchKernelGGL(big_pack_sums_kernel<real>, dim3(B), dim3(256), 0, st, ba, sums);
+    if (p->update_h) HIPNMF_LAUNCH(big_pack_sums_kernel<real>, dim3(B), dim3(256), 0, st, ba, sums);
   } else if (op == 1) {
     BigHArgs<real> hb;
     hb.H = H;
@@ -872,20 +872,20 @@ int hipnmf_shard_wide(hipnmf_handle* h, const hipnmf_problem* p, int op, const r
     if (smem_h > (size_t)h->lds_per_block)
       return fail(HIPNMF_ERR_UNSUPPORTED, "n_components=%d needs more LDS per workgroup than this device has", k);
     if (smem_h > 48 * 1024 && (arc = hipnmf_allow_full_lds(h, reinterpret_cast<const void*>(big_hupdate_kernel<real>)))) return arc;
-    hipLaunchKernelGGL(big_hupdate_kernel<real>, dim3(B, (m + 63) / 64), dim3(256), smem_h, st, hb);
+    HIPNMF_LAUNCH(big_hupdate_kernel<real>, dim3(B, (m + 63) / 64), dim3(256), smem_h, st, hb);
   } else if (const Big1Kernel<real>* b1r = pick_big1<real>(h, KPb, MPb, false)) {
-    hipLaunchKernelGGL(b1r->resid, gslice, dim3(512), 0, st, ba);
-    hipLaunchKernelGGL(big_colsum_kernel<real>, dim3(B), dim3(256), 0, st, ba, sse_col, xsq_col);
+    HIPNMF_LAUNCH(b1r->resid, gslice, dim3(512), 0, st, ba);
+    HIPNMF_LAUNCH(big_colsum_kernel<real>, dim3(B), dim3(256), 0, st, ba, sse_col, xsq_col);
   } else {
     with_kp([&](auto kp) {
       constexpr int KP = decltype(kp)::value;
       if (!arc && smem_r > (size_t)h->lds_per_block) arc = fail(HIPNMF_ERR_UNSUPPORTED, "n_features=%d needs more LDS per workgroup than this device has", m);
       if (!arc) arc = hipnmf_allow_full_lds(h, reinterpret_cast<const void*>(big_resid_kernel<real, KP>));
       if (arc) return;
-      hipLaunchKernelGGL((big_resid_kernel<real, KP>), gslice, dim3(256), smem_r, st, ba);
+      HIPNMF_LAUNCH((big_resid_kernel<real, KP>), gslice, dim3(256), smem_r, st, ba);
     });
     if (arc) return arc;
-    hipLaunchKernelGGL(big_colsum_kernel<real>, dim3(B), dim3(256), 0, st, ba, sse_col, xsq_col);
+    HIPNMF_LAUNCH(big_colsum_kernel<real>, dim3(B), dim3(256), 0, st, ba, sse_col, xsq_col);
   }
   HIP_TRY(hipGetLastError());
   if (!async) {
