@@ -6,6 +6,9 @@ Round 6 found two ways a process that had computed everything correctly still di
     its cooperative kernel with an ordinary launch;
   * SIGABRT ("terminate called without an active exception") when a daemon thread was inside a fit while the main thread ran the
     exit handlers (1 / 8 runs) -- the exit hook of muscle_synergies_amd._lib now drains and gates native calls first.
+  * (found by the full-suite runs that followed) SIGSEGV inside hipLaunchKernel when several threads make their first launches at
+    once -- HIPNMF_LAUNCH takes a process-wide lock around the first launch of every (function, device); the pool_idle case is the
+    reproducer (HIPNMF_FIRST_LAUNCH_LOCK=0: 4 of 40 fresh processes).
 Every case runs in a fresh child process (tools/exit_cases.py) and must exit with code 0 after printing its marker."""
 import os
 import subprocess
