@@ -257,3 +257,54 @@ def test_route_table_is_one_table_with_an_environment_override():
                          env=dict(os.environ, HIPNMF_ROUTES="f32_16ch_wide_max_rows=900,pers_s_per_row=3e-9,not_a_route=1"))
     assert out.returncode == 0 and out.stdout.split() == ["900.0", "3e-09"], out.stdout + out.stderr
     assert "ignoring 'not_a_route=1'" in out.stderr
+
+
+def test_exit_gate_counts_calls_parks_late_comers_and_waits_for_daemons():
+    """_lib._Gate (round 6): native calls in flight are counted; once the exit hook has closed the gate a thread that tries to START
+    a call is parked (never returns into the runtime), the hook's own calls still pass, close() waits for the calls in flight and
+    wait_parked() for the daemon threads between two calls."""
+    import threading
+    import time
+
+    from muscle_synergies_amd._lib import _Fn, _Gate
+    from muscle_synergies_amd import _lib
+
+    gate = _Gate()
+    saved, _lib._gate = _lib._gate, gate
+    try:
+        release = threading.Event()
+        entered = threading.Event()
+        calls = []
+
+        def slow(x):  # stands for a ctypes function that is in flight when the exit begins
+            entered.set()
+            release.wait(5)
+            calls.append(x)
+            return x + 1
+
+        f = _Fn(slow)
+        out = []
+        t1 = threading.Thread(target=lambda: out.append(f(1)), daemon=True)
+        t1.start()
+        assert entered.wait(5) and gate.inflight == 1
+        # the exit hook: close() must wait for the call in flight ...
+        closer = []
+        tc = threading.Thread(target=lambda: closer.append(gate.close(5.0)))
+        tc.start()
+        time.sleep(0.1)
+        assert gate.closing and tc.is_alive()
+        # ... and a thread that wants to START a call now is parked, not let through
+        t2 = threading.Thread(target=lambda: out.append(f(10)), daemon=True)
+        t2.start()
+        assert gate.wait_parked({t2.ident}, 5.0)
+        release.set()
+        tc.join(5)
+        assert closer == [True] and out == [2] and calls == [1] and gate.inflight == 0
+        time.sleep(0.1)
+        assert t2.is_alive() and 10 not in calls  # still parked; its call never ran
+        # the closing thread itself may still call (it destroys the handles)
+        gate.closer = threading.get_ident()
+        assert _Fn(lambda: 7)() == 7
+        assert not gate.wait_parked({12345}, 0.05)  # a thread that never shows up only costs the timeout
+    finally:
+        _lib._gate = saved
