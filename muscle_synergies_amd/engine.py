@@ -414,7 +414,8 @@ class HostBatch:
     ``reuse_outputs=True``: ``fit`` returns views of result arrays owned by this object, one set per ``n_components``; a later
     ``fit`` with the same ``n_components`` overwrites them (copy what must survive).  ``keep_on_device=True`` additionally keeps
     X in HBM after the first call (288 GB hold any batch the reference's users have): later calls upload only W0 / H0.
-    Results are bitwise those of ``fit_batched`` on the same arrays (tests/test_gpu_pipeline.py)."""
+    Results are bitwise those of ``fit_batched`` on the same arrays (tests/test_gpu_pipeline.py).  One ``fit`` at a time per object (the
+    device slots and result arrays are the object's); several objects may be used from several threads."""
 
     MIN_REGISTER_BYTES = 1 << 20  # arrays below this are never page-locked (see _register)
 
@@ -556,6 +557,12 @@ class HostBatch:
         if self._closed:
             return
         self._closed = True
+        if _lib._closed:  # the interpreter is past the engine's exit hook: the page locks go with the process, no runtime call any more
+            self._reg.clear()
+            self._slot_cache.clear()
+            self._out_cache.clear()
+            self._Xd = None
+            return
         try:
             _torch().cuda.synchronize(self.dev)
         except Exception:  # noqa: BLE001
