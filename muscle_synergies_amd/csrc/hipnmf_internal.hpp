@@ -180,7 +180,8 @@ struct hipnmf_route_table {
   double f32_16ch_k7_wide_max_rows = 1200;    // fp32, <= 16 channels, k = 7, 8
   double f64_16ch_wide_max_rows = 1200;       // float64, <= 16 channels, k <= 6 (k = 7, 8: always the matrix pipe)
   double f32_32ch_wide_max_rows = 2400;       // fp32, 17..32 channels, k <= 4
-  double f32_32ch_k5_wide_max_rows = 5000;    // fp32, 17..32 channels, k = 5, 6 (k = 7, 8: always)
+  double f32_32ch_k5_wide_max_rows = 3000;    // fp32, 17..32 channels, k = 5, 6 (k = 7, 8: always); 5000 until round 6: tools/calibrate_routes.py
+                                              // measured the crossover at 2 900 rows (5 000 rows: 14.2 ms lanes, 16.3 ms matrix pipe; profiles/r06_calibrate_routes.log)
   double kl_f32_32ch_short_max_rows = 1500;   // Kullback-Leibler fp32, 17..32 channels, k <= 5: matrix pipe up to this many rows
   double wide_min_batch_cus = 0.5;            // "chip-filling": at least this many matrices per CU
   double small_long_min_batch_cus_f32 = 2;    // one wave per matrix beyond 256 rows: matrices per CU from which it wins

@@ -41,3 +41,27 @@ def test_traffic_entries_are_not_older_than_their_kernels():
         ok = _git("merge-base", "--is-ancestor", last, src).returncode == 0
         assert ok, (f"{e['kernel']}: measured at {src} ({e.get('measured_round')}), but {paths} changed afterwards in {last[:7]}: "
                     f"re-run tools/measure_traffic.sh (HIPNMF_SOURCE_COMMIT=$(git rev-parse --short HEAD)) for this workload")
+
+
+def test_sq_counter_files_are_not_older_than_their_kernels():
+    """profiles/pmc_index.json names the SQ-counter summaries DESIGN.md quotes for the headline kernels together with the commit
+    they were taken on (the round-2 file was still the evidence in round 5): same rule as the
+    traffic entries -- the kernel's header must not have changed after the measured commit."""
+    if _git("rev-parse", "--git-dir").returncode != 0:
+        pytest.skip("no git history here")
+    path = os.path.join(ROOT, "profiles", "pmc_index.json")
+    entries = json.load(open(path))
+    assert entries
+    for e in entries:
+        f = os.path.join(ROOT, "profiles", e["file"])
+        assert os.path.exists(f), e["file"]
+        text = open(f).read()
+        assert "SQ_WAVE_CYCLES" in text and "SQ_ACTIVE_INST_VALU" in text and "SQ_WAIT_ANY" in text, e["file"]
+        assert e["kernel_trace_name"] in text, (e["file"], e["kernel_trace_name"])  # the summary really is of that instance
+        fam = next((k for k in HEADERS if e["kernel"].startswith(k)), None)
+        assert fam, e["kernel"]
+        last = _git("log", "-1", "--format=%H", "--", *[CSRC + h for h in HEADERS[fam]]).stdout.strip()
+        src = e["source_commit"]
+        assert _git("cat-file", "-e", src + "^{commit}").returncode == 0, f"{e['file']}: {src!r} is not a commit of this repository"
+        assert _git("merge-base", "--is-ancestor", last, src).returncode == 0, (
+            f"{e['file']}: taken at {src}, but {HEADERS[fam]} changed afterwards in {last[:7]}: re-run tools/pmc_passes.sh")

@@ -4,7 +4,7 @@
 The dispatchers send chip-filling batches of narrow shapes (<= 32 channels, <= 8 components) to the 4x4 matrix-pipe kernels up to a
 number of rows per matrix and to the lane mappings beyond it; the thresholds were fitted on one box type and live in ONE table
 (``csrc/hipnmf_internal.hpp``, ``struct hipnmf_route_table``; in force: ``hipnmf_routes_describe()`` / ``_lib.routes()``).
-This tool measures both kernel families over a grid of row counts -- one child process per pinned route (the pins are read once
+This tool measures both kernel families over a grid of row counts -- one child process per routing -- the library's own choice and the two families pinned -- (the pins are read once
 per process: HIPNMF_FORCE_WIDE = -1 lanes / 1 matrix pipe), every grid point in it -- and prints, per rule, the measured crossover
 next to the value in force, and a ``HIPNMF_ROUTES=...`` string that applies the measured values without a rebuild.
 
@@ -92,7 +92,7 @@ def main():
     if a.child:
         return child(grid, a.iters)
     data = {}
-    for tag, pin in (("lanes", "-1"), ("matrix", "1")):
+    for tag, pin in (("default", "0"), ("lanes", "-1"), ("matrix", "1")):  # the library's own choice, and the two families pinned
         env = dict(os.environ, HIPNMF_FORCE_WIDE=pin)
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", "--iters", str(a.iters)] + (["--quick"] if a.quick else []),
                            capture_output=True, text=True, env=env)
@@ -106,17 +106,22 @@ def main():
     for rule, (dt, m, k, loss) in RULES.items():
         lanes = {d["T"]: d["ms"] for d in data["lanes"] if d["rule"] == rule}
         matrix = {d["T"]: d["ms"] for d in data["matrix"] if d["rule"] == rule}
+        dflt = {d["T"]: d["ms"] for d in data["default"] if d["rule"] == rule}
         kl = {d["T"]: d["kernel"] for d in data["lanes"] if d["rule"] == rule}
         km = {d["T"]: d["kernel"] for d in data["matrix"] if d["rule"] == rule}
+        kd = {d["T"]: d["kernel"] for d in data["default"] if d["rule"] == rule}
         lines.append("%s  (%s, %d channels, k = %d, %s)  in force: %g rows" % (rule, dt, m, k, loss, in_force[rule]))
-        lines.append("    rows      " + " ".join("%8d" % T for T in grid))
-        lines.append("    lanes  ms " + " ".join("%8.3f" % lanes[T] for T in grid) + "   " + kl[grid[-1]])
-        lines.append("    matrix ms " + " ".join("%8.3f" % matrix[T] for T in grid) + "   " + km[grid[-1]])
+        lines.append("    rows       " + " ".join("%8d" % T for T in grid))
+        lines.append("    default ms " + " ".join("%8.3f" % dflt[T] for T in grid) + "   " + " | ".join(sorted({v.split("<")[0] for v in kd.values()})))
+        lines.append("    lanes   ms " + " ".join("%8.3f" % lanes[T] for T in grid) + "   " + " | ".join(sorted({v.split("<")[0] for v in kl.values()})))
+        lines.append("    matrix  ms " + " ".join("%8.3f" % matrix[T] for T in grid) + "   " + " | ".join(sorted({v.split("<")[0] for v in km.values()})))
         t, why = crossover(grid, lanes, matrix)
-        # what the value in force costs: the slower / faster ratio at every grid point under the rule as it stands
-        worst = max((matrix[T] / lanes[T]) if T <= in_force[rule] else (lanes[T] / matrix[T]) for T in grid)
-        lines.append("    measured: %s%s; the value in force is at most %.0f %% behind the better family on this grid" %
-                     (why, "" if t is None else " -> %.0f rows" % t, max(0.0, worst - 1.0) * 100))
+        # what the library's own choice costs: its time over the better pinned family, at every grid point (other rules -- the
+        # one-wave kernel for short matrices in big batches -- act before this threshold does: hence the default's own run)
+        worst_T = max(grid, key=lambda T: dflt[T] / min(lanes[T], matrix[T]))
+        worst = dflt[worst_T] / min(lanes[worst_T], matrix[worst_T])
+        lines.append("    measured: %s%s; the library's own choice is at most %.0f %% behind the better pinned family (at %d rows)" %
+                     (why, "" if t is None else " -> %.0f rows" % t, max(0.0, worst - 1.0) * 100, worst_T))
         if t is not None:
             suggest.append("%s=%.0f" % (rule, t))
     lines.append("")
