@@ -538,8 +538,10 @@ class HostBatch:
         torch = _torch()
         if self._Xd is None:
             self._Xd = _as_device_tensor(self.X, self.dev)
-        Wd = torch.from_numpy(np.ascontiguousarray(W0)).to(self.dev, self._Xd.dtype, non_blocking=self.is_registered(W0))
-        Hd = torch.from_numpy(np.ascontiguousarray(H0)).to(self.dev, self._Xd.dtype, non_blocking=self.is_registered(H0))
+        def up(a):  # asynchronous only straight out of the registered array itself (a contiguous copy is an unregistered temporary)
+            return torch.from_numpy(np.ascontiguousarray(a)).to(self.dev, self._Xd.dtype, non_blocking=a.flags.c_contiguous and self.is_registered(a))
+
+        Wd, Hd = up(W0), up(H0)
         r = fit_batched(self._Xd, Wd, Hd, device=self.dev, handle=handle, return_numpy=False, overwrite_init=True, **solver_kw)
         if self.reuse_outputs:
             B, T, m = self.X.shape
