@@ -382,10 +382,15 @@ def shutdown() -> None:
     still = {t.ident for t in threading.enumerate() if t.is_alive() and t.ident != me0 and t.ident in owners}
     if still:
         _gate.wait_parked(still, 2.0)
-    with _handles_lock:
+    # (a thread that slipped past the check in get_handle and parked inside hipnmf_create holds this lock for ever: do not wait for it)
+    locked = _handles_lock.acquire(timeout=2.0)
+    try:
         cached = list(_handles.values())
         _handles.clear()
         others = [h for h in list(_live) if h not in cached]
+    finally:
+        if locked:
+            _handles_lock.release()
     # not drained (a call that does not come back): a handle whose owner thread is still running may be in use this very moment --
     # it is left alone, its device memory goes with the process, and it is never touched again
     me = threading.get_ident()
@@ -403,6 +408,8 @@ def shutdown() -> None:
 def get_handle(device: int = 0) -> Handle:
     """Per-(thread, device) cached handle."""
     key = (threading.get_ident(), int(device))
+    if _gate.closing and threading.get_ident() != _gate.closer:
+        _gate.enter()  # parks this thread for good -- BEFORE it takes the lock the exit hook needs (never while holding it)
     with _handles_lock:
         h = _handles.get(key)
         if h is None:
