@@ -215,6 +215,26 @@ def fit_batched(X, W0, H0, *, max_iter: int = 200, tol: float = 1e-4, check_ever
 # not depend on the chunking: every chunk is routed as the whole batch would be (hipnmf_set_batch_hint -- a tail chunk below half the
 # CUs would otherwise take another kernel family) and a matrix's arithmetic does not depend on its neighbours
 # (tests/test_gpu_pipeline.py compares bitwise, tail chunk included).
+_never_free: list = []  # arrays whose page lock could not be released: kept alive for the life of the process (see _unregister)
+
+
+def _unregister(rt, arr, addr: int) -> bool:
+    """hipHostUnregister with its status CHECKED.  A page lock that cannot be released (the call fails) while the array goes back to
+    the allocator leaves the runtime with a pinned range whose pages are gone; the next array that lands on those addresses is
+    then copied through stale bookkeeping (the abort of profiles/r06_abort_hunt.md, defect 4).  If the release fails the array is
+    parked in ``_never_free`` instead: its addresses are never handed out again."""
+    try:
+        ok = int(rt.cudaHostUnregister(addr)) == 0
+    except Exception:  # noqa: BLE001
+        ok = False
+    if not ok:
+        _never_free.append(arr)
+        import warnings
+
+        warnings.warn("hipHostUnregister failed: the array stays allocated (and page-locked) for the life of the process", RuntimeWarning)
+    return ok
+
+
 _pipeline_trace = None  # development aid (tools/probes/host_pipeline_trace.py): a list to receive (stage, chunk, t_start, t_end)
 PIPELINE_MIN_BYTES = 256 << 20   # X smaller than this: one upload, one fit
 PIPELINE_MAX_CHUNK_BYTES = 1 << 30  # ... but never more than this per chunk
@@ -332,7 +352,12 @@ def _fit_batched_pipelined(X, W0, H0, dev, chunk: int, kw, handle=None, ctx=None
     rt = torch.cuda.cudart()
     SMALL = ("H", "n_iter", "reconstruction_err", "vaf", "sse_col", "xsq_col")
     small_parts = [None] * len(bounds)
-    page_ok = out.W.ctypes.data % 4096 == 0 and (chunk * T * k * out.W.itemsize) % 4096 == 0
+    import os as _os
+
+    # HIPNMF_PIPELINE_PIN=0: never page-lock the result array chunk by chunk (pageable downloads: slower, and no register /
+    # unregister traffic at all -- the switch for a long-lived host that prefers that; profiles/r06_abort_hunt.md, defect 4)
+    page_ok = (out.W.ctypes.data % 4096 == 0 and (chunk * T * k * out.W.itemsize) % 4096 == 0
+               and _os.environ.get("HIPNMF_PIPELINE_PIN", "1") != "0")
 
     @traced("download")
     def download(i, Wd, ready):
@@ -358,7 +383,7 @@ def _fit_batched_pipelined(X, W0, H0, dev, chunk: int, kw, handle=None, ctx=None
             st.synchronize()
         finally:
             if pinned:
-                rt.cudaHostUnregister(dst.ctypes.data)
+                _unregister(rt, out.W, dst.ctypes.data)
 
     ms_total = 0.0
     # every chunk is fitted by the kernel the WHOLE batch would get (hipnmf_set_batch_hint): a tail chunk below half the CUs
@@ -569,11 +594,8 @@ class HostBatch:
             _torch().cuda.synchronize(self.dev)
         except Exception:  # noqa: BLE001
             pass
-        for addr in list(self._reg):
-            try:
-                self._rt.cudaHostUnregister(addr)
-            except Exception:  # noqa: BLE001
-                pass
+        for addr, (arr, _n) in list(self._reg.items()):
+            _unregister(self._rt, arr, addr)
         self._reg.clear()
         self._slot_cache.clear()
         self._out_cache.clear()
