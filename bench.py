@@ -941,9 +941,11 @@ def run_dry(cx):
     elapsed, _ = cx.timed(step)
     if cx.rank != 0:
         return None
-    return {"units": cx.world * B * a.iters * a.steps, "elapsed": elapsed, "scaling": "weak",
+    weak = bool(a.batch_per_gpu)
+    total = a.batch_per_gpu * cx.world if weak else B  # the units of config 3: --batch in total, or --batch-per-gpu on every rank
+    return {"units": total * a.iters * a.steps, "elapsed": elapsed, "scaling": "weak" if weak else "strong",
             "config": {"workload": "DRY ORCHESTRATION: no GPU work, a sleep per step (rank plumbing check only)",
-                       "global_batch": B * cx.world}, "roofline": None}
+                       "global_batch": total}, "roofline": None}
 
 
 def _free_port():
